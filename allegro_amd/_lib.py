@@ -1,0 +1,145 @@
+"""ctypes binding of the C ABI in include/allegro_amd.h.
+
+`load()` returns the gfx950 library (building it in-tree with hipcc when the sources are newer) and
+raises if it cannot -- there is NO CPU fallback in the product path.  `AllegroLib` is parameterised
+by the CDLL handle only so that tests can bind the same wrapper to their emulation build.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+AA_MAX_LAYERS = 4
+AA_MAX_MLP_LAYERS = 4
+AA_F32, AA_F64 = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class TpDesc(C.Structure):
+    _fields_ = [("mul", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("dout", C.c_int32),
+                ("num_paths", C.c_int32), ("coupling", C.c_int32), ("nnz", C.c_int32),
+                ("nz_i", _ip), ("nz_j", _ip), ("nz_k", _ip), ("nz_path", _ip), ("nz_val", _dp)]
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("num_types", C.c_int32), ("num_bessels", C.c_int32), ("poly_p", C.c_double),
+                ("l_max", C.c_int32), ("num_layers", C.c_int32), ("num_scalar", C.c_int32), ("num_tensor", C.c_int32),
+                ("embed_dim", C.c_int32), ("embed_mlp_depth", C.c_int32), ("embed_mlp_width", C.c_int32),
+                ("latent_mlp_depth", C.c_int32), ("latent_mlp_width", C.c_int32),
+                ("readout_mlp_depth", C.c_int32), ("readout_mlp_width", C.c_int32),
+                ("forward_weight_init", C.c_int32), ("avg_num_neighbors", C.c_double), ("act_const", C.c_double),
+                ("has_scales", C.c_int32), ("has_shifts", C.c_int32), ("tps", TpDesc * AA_MAX_LAYERS)]
+
+
+class RawWeights(C.Structure):
+    _fields_ = [("rmax_recip", _dp), ("bessel_weights", _dp), ("center_embed", _dp), ("neighbor_embed", _dp),
+                ("basis_linear", _dp), ("embed_mlp", _dp * AA_MAX_MLP_LAYERS), ("env_embed_linear", _dp),
+                ("first_proj", _dp), ("latent", (_dp * AA_MAX_MLP_LAYERS) * AA_MAX_LAYERS),
+                ("tp_weights", _dp * AA_MAX_LAYERS), ("readout", _dp * AA_MAX_MLP_LAYERS), ("scales", _dp),
+                ("shifts", _dp)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("num_atoms", C.c_int64), ("num_edges", C.c_int64), ("center", C.c_void_p), ("nbr", C.c_void_p),
+                ("rowptr", C.c_void_p), ("types", C.c_void_p), ("shift_vec", C.c_void_p)]
+
+
+class AllegroError(RuntimeError):
+    pass
+
+
+def make_tp_desc(mul, d1, d2, dout, num_paths, coupling, nz_i, nz_j, nz_k, nz_path, nz_val):
+    """Returns (TpDesc, keepalive list of numpy arrays)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) for a in (nz_i, nz_j, nz_k, nz_path)]
+    val = np.ascontiguousarray(nz_val, dtype=np.float64)
+    d = TpDesc(int(mul), int(d1), int(d2), int(dout), int(num_paths), int(bool(coupling)), int(len(val)),
+               arrs[0].ctypes.data_as(_ip), arrs[1].ctypes.data_as(_ip), arrs[2].ctypes.data_as(_ip),
+               arrs[3].ctypes.data_as(_ip), val.ctypes.data_as(_dp))
+    return d, arrs + [val]
+
+
+class AllegroLib:
+    def __init__(self, cdll: C.CDLL, is_emulation: bool = False):
+        self.lib = cdll
+        self.is_emulation = is_emulation
+        L = cdll
+        L.aa_last_error.restype = C.c_char_p
+        L.aa_version.restype = C.c_int
+        L.aa_tp_plan_create.argtypes = [C.POINTER(TpDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.aa_tp_plan_destroy.argtypes = [C.c_void_p]
+        L.aa_tp_plan_destroy.restype = None
+        L.aa_tp_forward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_tp_backward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_model_plan_create.argtypes = [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]
+        L.aa_model_plan_destroy.argtypes = [C.c_void_p]
+        L.aa_model_plan_destroy.restype = None
+        L.aa_model_weights_bytes.argtypes = [C.c_void_p]
+        L.aa_model_weights_bytes.restype = C.c_size_t
+        L.aa_model_pack_weights.argtypes = [C.c_void_p, C.POINTER(RawWeights), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.aa_model_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+        L.aa_model_workspace_bytes.restype = C.c_size_t
+        L.aa_model_energy_forces.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_model_debug_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise AllegroError(f"{what} failed ({rc}): {self.lib.aa_last_error().decode()}")
+
+    # -- tensor-product operator
+    def tp_plan_create(self, desc: TpDesc, dtype: int) -> int:
+        h = C.c_void_p()
+        self.check(self.lib.aa_tp_plan_create(C.byref(desc), dtype, C.byref(h)), "aa_tp_plan_create")
+        return h.value
+
+    def tp_plan_destroy(self, h):
+        if h:
+            self.lib.aa_tp_plan_destroy(h)
+
+    def tp_forward(self, h, E, N, x1, x2, w, rowptr, eids, sf, x2s, out, stream):
+        self.check(self.lib.aa_tp_forward(h, E, N, x1, x2, w, rowptr, eids, sf, x2s, out, stream), "aa_tp_forward")
+
+    def tp_backward(self, h, E, N, x1, x2s, w, rowptr, eids, sf, gout, gx1, gx2, stream):
+        self.check(self.lib.aa_tp_backward(h, E, N, x1, x2s, w, rowptr, eids, sf, gout, gx1, gx2, stream),
+                   "aa_tp_backward")
+
+    # -- model
+    def model_plan_create(self, cfg: ModelConfig) -> int:
+        h = C.c_void_p()
+        self.check(self.lib.aa_model_plan_create(C.byref(cfg), C.byref(h)), "aa_model_plan_create")
+        return h.value
+
+    def model_plan_destroy(self, h):
+        if h:
+            self.lib.aa_model_plan_destroy(h)
+
+
+_LIB: Optional[AllegroLib] = None
+LIB_NAME = "liballegro_amd.so"
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+def load(build_if_stale: bool = True) -> AllegroLib:
+    """Load the gfx950 library; build it in-tree when stale and hipcc exists.  Raises if unavailable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if build_if_stale and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        from .build import build_library
+
+        build_library(verbose=False)
+    path = lib_path()
+    if not os.path.exists(path):
+        raise AllegroError(f"{path} is missing: build it with `python -m allegro_amd.build` (needs hipcc); "
+                           "there is no CPU fallback")
+    _LIB = AllegroLib(C.CDLL(path))
+    return _LIB

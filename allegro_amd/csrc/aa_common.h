@@ -1,0 +1,215 @@
+// Shared declarations of the gfx950 Allegro hot-path library (internal; the public C ABI is
+// include/allegro_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "allegro_amd.h"
+
+// Every kernel carves its scratch from this single dynamic-LDS symbol (keeping ONE __shared__
+// object also avoids the ROCm 7.2 "second __shared__ object" vmcnt(0) trap, HIP guide §5 item 4a).
+extern __shared__ unsigned char aa_smem[];
+
+namespace aa {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define AA_CHECK_HIP(expr)                                                                      \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return aa::fail(AA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+  } while (0)
+
+#define AA_REQUIRE(cond, msg)                                       \
+  do {                                                              \
+    if (!(cond)) return aa::fail(AA_ERR_INVALID, std::string(msg)); \
+  } while (0)
+
+constexpr int kThreads = 256;
+
+// ----------------------------------------------------------------------------------------------
+// small device helpers
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T silu(T x) {
+  return x / (T(1) + exp(-x));
+}
+template <typename T>
+__device__ __forceinline__ T dsilu(T x) {
+  T s = T(1) / (T(1) + exp(-x));
+  return s * (T(1) + x * (T(1) - s));
+}
+__device__ __forceinline__ float aa_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double aa_sin(double x) { return sin(x); }
+__device__ __forceinline__ float aa_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double aa_cos(double x) { return cos(x); }
+__device__ __forceinline__ float aa_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double aa_pow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float aa_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double aa_sqrt(double x) { return sqrt(x); }
+
+// irrep index r of SH component i (m ordered -l..l per l): l = floor(sqrt(i))
+__device__ __forceinline__ int sh_l_of(int i) { return i < 1 ? 0 : (i < 4 ? 1 : (i < 9 ? 2 : 3)); }
+
+// Column-segmented row-major matrix view: logical [M, sum n] split over up to 3 buffers
+// (this is how torch.cat / torch.narrow of the reference never materialise here,
+//  _allegro.py:253-258,278,284-294,300).
+struct Seg {
+  void* p;
+  int ld;
+  int n;
+};
+struct SegList {
+  int count;
+  Seg s[3];
+};
+
+// ----------------------------------------------------------------------------------------------
+// GEMM  C_segs (=|+=) (act(A_segs)[M,K] @ B[K,N]) (* dsilu(Z_segs))
+// ----------------------------------------------------------------------------------------------
+struct GemmArgs {
+  int64_t M;
+  int K, N;
+  SegList a;       // K split
+  const void* B;   // [K,N] row-major
+  SegList c;       // N split
+  int c_accum[3];  // per C segment: 1 -> +=
+  int has_z;       // multiply result by dsilu(z) (z split like c)
+  SegList z;
+  int act_a;       // apply silu to A on load
+};
+template <typename T>
+int launch_gemm(const GemmArgs& g, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------
+// Sparse trilinear (Clebsch-Gordan) tables on device
+// ----------------------------------------------------------------------------------------------
+// One table computes  o[c] = sum_groups(c,p) W[.,p] * sum_{nz in group} val * A[a] * B[b]
+struct TpGroup {
+  int32_t out_idx;  // c
+  int32_t path;     // p
+  int32_t begin, end;
+};
+struct TpEntry {
+  int32_t a, b;
+  float val_f;
+  double val_d;
+};
+struct TpTable {
+  int32_t num_groups;
+  const TpGroup* groups;   // device
+  const TpEntry* entries;  // device
+};
+struct TpLayerDev {
+  int32_t mul, d1, d2, dout, num_paths, coupling;
+  TpTable fwd;   // out k ; A = x1[i],  B = x2[j]
+  TpTable bx1;   // out i ; A = gout[k], B = x2[j]
+  TpTable bx2;   // out j ; A = gout[k], B = x1[i]
+};
+
+// x1 / x2 operand sources of a TP layer
+struct TpOperand {
+  const void* dense;   // explicit [E,u,d] (or nullptr)
+  const void* sh;      // implicit: sh[E,D] ...
+  const void* w;       // ... times w[E, ldw] viewed as [u,R]  (MakeWeightedChannels, _channels.py:44-57)
+  int ldw;
+  int ld_sh;
+};
+struct TpOperandGrad {
+  void* dense;     // explicit grad [E,u,d] (written) or nullptr
+  void* gw;        // implicit: grad of w [E, ldgw] (written)
+  int ldgw;
+  void* gsh;       // grad of sh [E, ld_gsh] (accumulated, +=)
+  int ld_gsh;
+};
+
+struct TpLayerFwdArgs {
+  int64_t E, N;
+  const int32_t* rowptr;
+  const int32_t* eids;  // nullable
+  TpOperand x1, x2;
+  const void* weights;  // [u,p] or [p]
+  double scatter_factor;
+  void* x2s;            // [N,u,d2]
+  void* out;            // [E,u,dout] or nullptr
+  void* scal;           // [E, ld_scal] scalars (k=0) or nullptr
+  int ld_scal;
+};
+struct TpLayerBwdArgs {
+  int64_t E, N;
+  const int32_t* rowptr;
+  const int32_t* eids;
+  TpOperand x1, x2;     // x2 only needed when implicit (for gsh)
+  const void* weights;
+  double scatter_factor;
+  const void* x2s;      // saved [N,u,d2]
+  const void* gout;     // [E,u,dout] or nullptr
+  const void* gscal;    // [E, ld_gscal] added at k=0, or nullptr
+  int ld_gscal;
+  TpOperandGrad g1, g2;
+};
+template <typename T>
+int launch_tp_layer_fwd(const TpLayerDev& L, const TpLayerFwdArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_layer_bwd(const TpLayerDev& L, const TpLayerBwdArgs& a, hipStream_t stream);
+
+int build_tp_layer(const aa_tp_desc& d, TpLayerDev* out, std::vector<void*>* owned);
+
+// ----------------------------------------------------------------------------------------------
+// edge prologue / epilogue / readout reduce
+// ----------------------------------------------------------------------------------------------
+struct EdgeGeomArgs {
+  int64_t E, N;
+  const int32_t *center, *nbr, *types;
+  const void* pos;        // [N,3]
+  const void* shift_vec;  // [E,3] or nullptr
+  int num_types, num_bessels, l_max, S0;
+  double poly_p;
+  const void* rmax_recip;      // [T,T]
+  const void* bessel_w;        // [B]
+  const void* center_embed;    // [T,S0/2]
+  const void* neighbor_embed;  // [T,S0/2]
+  const void* basis_w;         // [B,S0] (alpha folded)
+  void* vec;                   // [E,4]  (unit vector xyz, r)
+  void* sh;                    // [E,D]
+  void* emb0;                  // [E,S0]
+};
+template <typename T>
+int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream);
+
+struct EdgeBwdArgs {
+  EdgeGeomArgs g;
+  const void* g_emb0;  // [E,S0]
+  const void* g_sh;    // [E,D]
+  void* forces;        // [N,3] (pre-zeroed; accumulated with atomics)
+};
+template <typename T>
+int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t stream);
+
+struct ReadoutArgs {
+  int64_t E, N;
+  const int32_t *rowptr, *center, *types;
+  const void* h;   // [E,H] (pre-activation if act) , ld
+  int ld, H, act;
+  const void* w;   // [H] final linear (alpha folded)
+  double factor;   // 1/sqrt(2 avg_nn)   (allegro_models.py:245)
+  const void* scales;  // [T] or nullptr
+  const void* shifts;  // [T] or nullptr
+  void* atom_energy;   // [N]
+  void* g_h;           // bwd: [E,H] written
+};
+template <typename T>
+int launch_readout_reduce(const ReadoutArgs& a, hipStream_t stream);
+template <typename T>
+int launch_readout_backward(const ReadoutArgs& a, hipStream_t stream);
+
+}  // namespace aa

@@ -1,0 +1,310 @@
+// Edge prologue / epilogue of the Allegro hot path (gfx950):
+//   prologue : with_edge_vectors_ (called at allegro/nn/tensorembed.py:86), EdgeLengthNormalizer +
+//              Bessel x polynomial cutoff + ProductTypeEmbedding (allegro/nn/scalarembed.py:60-81,
+//              allegro/nn/_edgeembed.py:68-84), SphericalHarmonics (tensorembed.py:92)
+//   readout  : last linear of edge_readout + EdgewiseReduce + PerTypeScaleShift
+//              (allegro_models.py:231-260, allegro/nn/edgewise.py:40-60)
+//   backward : hand-written reverse of the prologue -> dE/dr_ij -> forces on center and neighbor
+//              (what ForceStressOutput's autograd does in the reference, allegro_models.py:101-103)
+#include "aa_common.h"
+
+namespace aa {
+
+// --------------------------------------------------------------------------------------------
+// real spherical harmonics, component normalised, y polar, m = -l..l (same polynomials as
+// oracle/restatement.py; l <= 3)
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void sh_eval(int l_max, T x, T y, T z, T* Y) {
+  Y[0] = T(1);
+  if (l_max >= 1) {
+    const T s3 = T(1.7320508075688772);
+    Y[1] = s3 * x;
+    Y[2] = s3 * y;
+    Y[3] = s3 * z;
+  }
+  if (l_max >= 2) {
+    const T s15 = T(3.872983346207417), s5 = T(2.23606797749979);
+    Y[4] = s15 * x * z;
+    Y[5] = s15 * x * y;
+    Y[6] = s5 * (y * y - T(0.5) * (x * x + z * z));
+    Y[7] = s15 * y * z;
+    Y[8] = T(0.5) * s15 * (z * z - x * x);
+  }
+  if (l_max >= 3) {
+    const T c70 = T(2.091650066335189), c105 = T(10.246950765959598), c42 = T(1.620185174601965),
+            c7 = T(1.3228756555322954);
+    Y[9] = c70 * x * (T(3) * z * z - x * x);
+    Y[10] = c105 * x * y * z;
+    Y[11] = c42 * x * (T(5) * y * y - T(1));
+    Y[12] = c7 * y * (T(5) * y * y - T(3));
+    Y[13] = c42 * z * (T(5) * y * y - T(1));
+    Y[14] = T(0.5) * c105 * y * (z * z - x * x);
+    Y[15] = c70 * z * (z * z - T(3) * x * x);
+  }
+}
+
+// g = sum_i gY[i] * dY_i/d(x,y,z)  (polynomials as written; the caller projects onto the tangent plane)
+template <typename T>
+__device__ __forceinline__ void sh_grad(int l_max, T x, T y, T z, const T* gY, T& gx, T& gy, T& gz) {
+  gx = gy = gz = T(0);
+  if (l_max >= 1) {
+    const T s3 = T(1.7320508075688772);
+    gx += s3 * gY[1];
+    gy += s3 * gY[2];
+    gz += s3 * gY[3];
+  }
+  if (l_max >= 2) {
+    const T s15 = T(3.872983346207417), s5 = T(2.23606797749979);
+    gx += s15 * z * gY[4] + s15 * y * gY[5] - s5 * x * gY[6] - s15 * x * gY[8];
+    gy += s15 * x * gY[5] + T(2) * s5 * y * gY[6] + s15 * z * gY[7];
+    gz += s15 * x * gY[4] - s5 * z * gY[6] + s15 * y * gY[7] + s15 * z * gY[8];
+  }
+  if (l_max >= 3) {
+    const T c70 = T(2.091650066335189), c105 = T(10.246950765959598), c42 = T(1.620185174601965),
+            c7 = T(1.3228756555322954);
+    T a = T(5) * y * y - T(1);
+    gx += c70 * T(3) * (z * z - x * x) * gY[9] + c105 * y * z * gY[10] + c42 * a * gY[11] - c105 * x * y * gY[14] -
+          c70 * T(6) * x * z * gY[15];
+    gy += c105 * x * z * gY[10] + c42 * T(10) * x * y * gY[11] + c7 * (T(15) * y * y - T(3)) * gY[12] +
+          c42 * T(10) * y * z * gY[13] + T(0.5) * c105 * (z * z - x * x) * gY[14];
+    gz += c70 * T(6) * x * z * gY[9] + c105 * x * y * gY[10] + c42 * a * gY[13] + c105 * y * z * gY[14] +
+          c70 * T(3) * (z * z - x * x) * gY[15];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void cutoff_and_grad(T x, T p, T& f, T& df) {
+  if (x < T(1)) {
+    T a = (p + T(1)) * (p + T(2)) * T(0.5), b = p * (p + T(2)), c = p * (p + T(1)) * T(0.5);
+    T xp1 = aa_pow(x, p - T(1));  // x^(p-1)
+    T xp = xp1 * x, xq = xp * x, xr = xq * x;
+    f = T(1) - a * xp + b * xq - c * xr;
+    df = -a * p * xp1 + b * (p + T(1)) * xp - c * (p + T(2)) * xq;
+  } else {
+    f = T(0);
+    df = T(0);
+  }
+}
+
+constexpr int kMaxBessel = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
+  const int B = a.num_bessels, S0 = a.S0, D = (a.l_max + 1) * (a.l_max + 1), Tn = a.num_types;
+  T* sB = reinterpret_cast<T*>(aa_smem);           // [256][B+1]
+  T* sWb = sB + 256 * (B + 1);                     // [B][S0]
+  int* sTy = reinterpret_cast<int*>(sWb + B * S0);  // [256][2]
+  const int tid = threadIdx.x;
+  const int64_t e0 = int64_t(blockIdx.x) * 256;
+  const T* pos = static_cast<const T*>(a.pos);
+  for (int idx = tid; idx < B * S0; idx += 256) sWb[idx] = static_cast<const T*>(a.basis_w)[idx];
+  {
+    int64_t e = e0 + tid;
+    if (e < a.E) {
+      int i = a.center[e], j = a.nbr[e];
+      T vx = pos[3 * int64_t(j)] - pos[3 * int64_t(i)];
+      T vy = pos[3 * int64_t(j) + 1] - pos[3 * int64_t(i) + 1];
+      T vz = pos[3 * int64_t(j) + 2] - pos[3 * int64_t(i) + 2];
+      if (a.shift_vec) {
+        const T* sv = static_cast<const T*>(a.shift_vec) + 3 * e;
+        vx += sv[0];
+        vy += sv[1];
+        vz += sv[2];
+      }
+      T r = aa_sqrt(vx * vx + vy * vy + vz * vz);
+      T inv = T(1) / r;
+      T nx = vx * inv, ny = vy * inv, nz = vz * inv;
+      T* vec = static_cast<T*>(a.vec) + 4 * e;
+      vec[0] = nx;
+      vec[1] = ny;
+      vec[2] = nz;
+      vec[3] = r;
+      T Y[16];
+      sh_eval<T>(a.l_max, nx, ny, nz, Y);
+      T* sh = static_cast<T*>(a.sh) + e * D;
+      for (int m = 0; m < D; ++m) sh[m] = Y[m];
+      int ti = a.types[i], tj = a.types[j];
+      sTy[2 * tid] = ti;
+      sTy[2 * tid + 1] = tj;
+      T x = r * static_cast<const T*>(a.rmax_recip)[ti * Tn + tj];
+      T f, df;
+      cutoff_and_grad<T>(x, T(a.poly_p), f, df);
+      for (int nb = 0; nb < B; ++nb) {
+        T w = static_cast<const T*>(a.bessel_w)[nb];
+        sB[tid * (B + 1) + nb] = aa_sin(w * x) / x * f;
+      }
+    }
+  }
+  __syncthreads();
+  const int half = S0 / 2;
+  const T* cemb = static_cast<const T*>(a.center_embed);
+  const T* nemb = static_cast<const T*>(a.neighbor_embed);
+  for (int idx = tid; idx < 256 * S0; idx += 256) {
+    int le = idx / S0, c = idx % S0;
+    int64_t e = e0 + le;
+    if (e >= a.E) break;
+    T basis = T(0);
+    for (int nb = 0; nb < B; ++nb) basis += sB[le * (B + 1) + nb] * sWb[nb * S0 + c];
+    T te = c < half ? cemb[sTy[2 * le] * half + c] : nemb[sTy[2 * le + 1] * half + (c - half)];
+    static_cast<T*>(a.emb0)[e * S0 + c] = te * basis;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
+  const EdgeGeomArgs& a = b.g;
+  const int B = a.num_bessels, S0 = a.S0, D = (a.l_max + 1) * (a.l_max + 1), Tn = a.num_types;
+  T* sT = reinterpret_cast<T*>(aa_smem);  // [256][B+1]  dE/d(bessel_n * cutoff)
+  T* sWb = sT + 256 * (B + 1);            // [B][S0]
+  const int tid = threadIdx.x;
+  const int64_t e0 = int64_t(blockIdx.x) * 256;
+  const int half = S0 / 2;
+  const T* cemb = static_cast<const T*>(a.center_embed);
+  const T* nemb = static_cast<const T*>(a.neighbor_embed);
+  for (int idx = tid; idx < B * S0; idx += 256) sWb[idx] = static_cast<const T*>(a.basis_w)[idx];
+  __syncthreads();
+  // phase 1: t[le][n] = sum_c g_emb0[e][c] * type_embed[c] * Wb[n][c]
+  for (int idx = tid; idx < 256 * B; idx += 256) {
+    int le = idx / B, nb = idx % B;
+    int64_t e = e0 + le;
+    T acc = T(0);
+    if (e < a.E) {
+      int ti = a.types[a.center[e]], tj = a.types[a.nbr[e]];
+      const T* g = static_cast<const T*>(b.g_emb0) + e * S0;
+      for (int c = 0; c < S0; ++c) {
+        T te = c < half ? cemb[ti * half + c] : nemb[tj * half + (c - half)];
+        acc += g[c] * te * sWb[nb * S0 + c];
+      }
+    }
+    sT[le * (B + 1) + nb] = acc;
+  }
+  __syncthreads();
+  // phase 2: per edge chain rule to the edge vector, then scatter to both atoms
+  int64_t e = e0 + tid;
+  if (e < a.E) {
+    int i = a.center[e], j = a.nbr[e];
+    const T* vec = static_cast<const T*>(a.vec) + 4 * e;
+    T nx = vec[0], ny = vec[1], nz = vec[2], r = vec[3];
+    int ti = a.types[i], tj = a.types[j];
+    T recip = static_cast<const T*>(a.rmax_recip)[ti * Tn + tj];
+    T x = r * recip;
+    T f, df;
+    cutoff_and_grad<T>(x, T(a.poly_p), f, df);
+    T dEdx = T(0);
+    for (int nb = 0; nb < B; ++nb) {
+      T w = static_cast<const T*>(a.bessel_w)[nb];
+      T s = aa_sin(w * x), c = aa_cos(w * x);
+      T bv = s / x;
+      T dbv = (w * c * x - s) / (x * x);
+      dEdx += sT[tid * (B + 1) + nb] * (dbv * f + bv * df);
+    }
+    T dEdr = dEdx * recip;
+    T gY[16];
+    const T* gsh = static_cast<const T*>(b.g_sh) + e * D;
+    for (int m = 0; m < D; ++m) gY[m] = gsh[m];
+    T gx, gy, gz;
+    sh_grad<T>(a.l_max, nx, ny, nz, gY, gx, gy, gz);
+    T dot = gx * nx + gy * ny + gz * nz;
+    T inv = T(1) / r;
+    T dx = dEdr * nx + (gx - dot * nx) * inv;
+    T dy = dEdr * ny + (gy - dot * ny) * inv;
+    T dz = dEdr * nz + (gz - dot * nz) * inv;
+    // r_ij = pos_j - pos_i : dE/dpos_j = +d, dE/dpos_i = -d ; F = -dE/dpos
+    T* F = static_cast<T*>(b.forces);
+    atomicAdd(&F[3 * int64_t(i)], dx);
+    atomicAdd(&F[3 * int64_t(i) + 1], dy);
+    atomicAdd(&F[3 * int64_t(i) + 2], dz);
+    atomicAdd(&F[3 * int64_t(j)], -dx);
+    atomicAdd(&F[3 * int64_t(j) + 1], -dy);
+    atomicAdd(&F[3 * int64_t(j) + 2], -dz);
+  }
+}
+
+// one wave per atom: E_i = scale_t * factor * sum_{e in seg(i)} sum_c act(h[e,c]) w[c] + shift_t
+template <typename T>
+__global__ __launch_bounds__(256) void readout_reduce_kernel(ReadoutArgs a) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t n = int64_t(blockIdx.x) * 4 + wv;
+  T acc = T(0);
+  if (n < a.N) {
+    int beg = a.rowptr[n], end = a.rowptr[n + 1];
+    const T* w = static_cast<const T*>(a.w);
+    for (int c = lane; c < a.H; c += 64) {
+      T wc = w[c];
+      for (int s = beg; s < end; ++s) {
+        T h = static_cast<const T*>(a.h)[int64_t(s) * a.ld + c];
+        acc += (a.act ? silu(h) : h) * wc;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+  if (n < a.N && lane == 0) {
+    T en = acc * T(a.factor);
+    int t = a.types[n];
+    if (a.scales) en *= static_cast<const T*>(a.scales)[t];
+    if (a.shifts) en += static_cast<const T*>(a.shifts)[t];
+    static_cast<T*>(a.atom_energy)[n] = en;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void readout_backward_kernel(ReadoutArgs a) {
+  const int64_t total = a.E * a.H;
+  for (int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * 256) {
+    int64_t e = idx / a.H;
+    int c = int(idx % a.H);
+    T g = T(a.factor) * static_cast<const T*>(a.w)[c];
+    if (a.scales) g *= static_cast<const T*>(a.scales)[a.types[a.center[e]]];
+    if (a.act) g *= dsilu(static_cast<const T*>(a.h)[e * a.ld + c]);
+    static_cast<T*>(a.g_h)[e * a.H + c] = g;
+  }
+}
+
+template <typename T>
+int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream) {
+  if (a.E == 0) return AA_OK;
+  AA_REQUIRE(a.num_bessels <= kMaxBessel && a.l_max >= 1 && a.l_max <= 3 && a.S0 % 2 == 0, "prologue: unsupported sizes");
+  size_t smem = sizeof(T) * (256 * size_t(a.num_bessels + 1) + size_t(a.num_bessels) * a.S0) + sizeof(int) * 512;
+  hipLaunchKernelGGL(edge_prologue_kernel<T>, dim3((unsigned)((a.E + 255) / 256)), dim3(256), smem, stream, a);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template <typename T>
+int launch_edge_backward(const EdgeBwdArgs& b, hipStream_t stream) {
+  if (b.g.E == 0) return AA_OK;
+  size_t smem = sizeof(T) * (256 * size_t(b.g.num_bessels + 1) + size_t(b.g.num_bessels) * b.g.S0);
+  hipLaunchKernelGGL(edge_backward_kernel<T>, dim3((unsigned)((b.g.E + 255) / 256)), dim3(256), smem, stream, b);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template <typename T>
+int launch_readout_reduce(const ReadoutArgs& a, hipStream_t stream) {
+  if (a.N == 0) return AA_OK;
+  hipLaunchKernelGGL(readout_reduce_kernel<T>, dim3((unsigned)((a.N + 3) / 4)), dim3(256), 0, stream, a);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template <typename T>
+int launch_readout_backward(const ReadoutArgs& a, hipStream_t stream) {
+  if (a.E == 0) return AA_OK;
+  int64_t total = a.E * a.H;
+  unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(readout_backward_kernel<T>, dim3(blocks), dim3(256), 0, stream, a);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+#define AA_INST(T)                                                              \
+  template int launch_edge_prologue<T>(const EdgeGeomArgs&, hipStream_t);      \
+  template int launch_edge_backward<T>(const EdgeBwdArgs&, hipStream_t);       \
+  template int launch_readout_reduce<T>(const ReadoutArgs&, hipStream_t);      \
+  template int launch_readout_backward<T>(const ReadoutArgs&, hipStream_t);
+AA_INST(float)
+AA_INST(double)
+
+}  // namespace aa

@@ -1,0 +1,702 @@
+// Orchestration of the whole Allegro hot path behind the C ABI (include/allegro_amd.h):
+// forward (allegro/model/allegro_models.py:222-297 module chain) and the hand-written reverse pass
+// w.r.t. positions (what ForceStressOutput's autograd does, allegro_models.py:101-103).
+// All kernels are enqueued on the caller's stream; all tensors live in caller-owned HBM buffers.
+#include <algorithm>
+
+#include "aa_common.h"
+
+namespace aa {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+}  // namespace aa
+
+using namespace aa;
+
+// ------------------------------------------------------------------------------------------------
+// TP operator plan (seam B1/B2)
+// ------------------------------------------------------------------------------------------------
+struct aa_tp_plan {
+  aa_dtype dtype;
+  TpLayerDev dev;
+  std::vector<void*> owned;
+};
+
+extern "C" const char* aa_last_error(void) { return g_err.c_str(); }
+extern "C" int aa_version(void) { return 1; }
+
+extern "C" int aa_tp_plan_create(const aa_tp_desc* desc, aa_dtype dtype, aa_tp_plan** out) {
+  AA_REQUIRE(desc && out, "aa_tp_plan_create: null argument");
+  AA_REQUIRE(dtype == AA_F32 || dtype == AA_F64, "aa_tp_plan_create: bad dtype");
+  aa_tp_plan* p = new aa_tp_plan();
+  p->dtype = dtype;
+  int rc = build_tp_layer(*desc, &p->dev, &p->owned);
+  if (rc) {
+    for (void* q : p->owned) (void)hipFree(q);
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return AA_OK;
+}
+
+extern "C" void aa_tp_plan_destroy(aa_tp_plan* plan) {
+  if (!plan) return;
+  for (void* q : plan->owned) (void)hipFree(q);
+  delete plan;
+}
+
+extern "C" int aa_tp_forward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2,
+                             const void* weights, const int32_t* rowptr, const int32_t* eids, double scatter_factor,
+                             void* x2s, void* out, aa_stream stream) {
+  AA_REQUIRE(plan && x1 && x2 && weights && rowptr && x2s && out, "aa_tp_forward: null argument");
+  TpLayerFwdArgs a{};
+  a.E = E;
+  a.N = N;
+  a.rowptr = rowptr;
+  a.eids = eids;
+  a.x1.dense = x1;
+  a.x2.dense = x2;
+  a.weights = weights;
+  a.scatter_factor = scatter_factor;
+  a.x2s = x2s;
+  a.out = out;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return plan->dtype == AA_F32 ? launch_tp_layer_fwd<float>(plan->dev, a, s) : launch_tp_layer_fwd<double>(plan->dev, a, s);
+}
+
+extern "C" int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,
+                              const void* weights, const int32_t* rowptr, const int32_t* eids, double scatter_factor,
+                              const void* gout, void* gx1, void* gx2, aa_stream stream) {
+  AA_REQUIRE(plan && x1 && x2s && weights && rowptr && gout && gx1 && gx2, "aa_tp_backward: null argument");
+  TpLayerBwdArgs a{};
+  a.E = E;
+  a.N = N;
+  a.rowptr = rowptr;
+  a.eids = eids;
+  a.x1.dense = x1;
+  a.weights = weights;
+  a.scatter_factor = scatter_factor;
+  a.x2s = x2s;
+  a.gout = gout;
+  a.g1.dense = gx1;
+  a.g2.dense = gx2;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return plan->dtype == AA_F32 ? launch_tp_layer_bwd<float>(plan->dev, a, s) : launch_tp_layer_bwd<double>(plan->dev, a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// model plan
+// ------------------------------------------------------------------------------------------------
+struct MlpLayout {
+  std::vector<int> dims;        // d_0 .. d_n
+  std::vector<size_t> w, wt;    // blob offsets (elements) of W_i [d_i,d_{i+1}] and its transpose
+};
+
+struct aa_model_plan {
+  aa_model_config cfg;
+  int D, R, W, SL1;  // SH dim, irreps, env weight numel, S*(L+1)
+  std::vector<std::vector<int32_t>> keep_i32;
+  std::vector<std::vector<double>> keep_f64;
+  std::vector<TpLayerDev> layers;
+  std::vector<void*> owned;
+  // weight blob layout (element offsets)
+  size_t o_rmax, o_bessel, o_cemb, o_nemb, o_basis, o_g0, o_g0t, o_ro_last, o_scales, o_shifts, n_elems;
+  size_t o_tpw[AA_MAX_LAYERS];
+  MlpLayout embed, readout;          // readout: only the GEMM layers (all but the final ->1 layer)
+  MlpLayout latent[AA_MAX_LAYERS];
+  int ro_last_dim;                   // input dim of the final readout linear
+  size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
+};
+
+static std::vector<int> mlp_dims(int in, int depth, int width, int out) {
+  std::vector<int> d{in};
+  for (int i = 0; i < depth; ++i) d.push_back(width);
+  d.push_back(out);
+  return d;
+}
+
+extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out) {
+  AA_REQUIRE(cfg && out, "aa_model_plan_create: null argument");
+  AA_REQUIRE(cfg->dtype == AA_F32 || cfg->dtype == AA_F64, "model: bad dtype");
+  AA_REQUIRE(cfg->l_max >= 1 && cfg->l_max <= 3, "model: l_max must be 1..3");
+  AA_REQUIRE(cfg->num_layers >= 1 && cfg->num_layers <= AA_MAX_LAYERS, "model: num_layers out of range");
+  AA_REQUIRE(cfg->embed_mlp_depth + 1 <= AA_MAX_MLP_LAYERS && cfg->latent_mlp_depth + 1 <= AA_MAX_MLP_LAYERS &&
+                 cfg->readout_mlp_depth + 1 <= AA_MAX_MLP_LAYERS,
+             "model: MLP too deep");
+  AA_REQUIRE(cfg->num_types > 0 && cfg->num_bessels > 0 && cfg->num_bessels <= 16 && cfg->embed_dim % 2 == 0,
+             "model: bad embedding sizes");
+  aa_model_plan* p = new aa_model_plan();
+  p->cfg = *cfg;
+  const int L = cfg->num_layers, S = cfg->num_scalar, u = cfg->num_tensor;
+  p->R = cfg->l_max + 1;
+  p->D = p->R * p->R;
+  p->W = p->R * u;
+  p->SL1 = S * (L + 1);
+  auto bail = [&](int rc) {
+    for (void* q : p->owned) (void)hipFree(q);
+    delete p;
+    return rc;
+  };
+  p->layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const aa_tp_desc& d = cfg->tps[l];
+    bool ok = d.mul == u && d.d2 == p->D && (l == 0 ? d.d1 == p->D : d.d1 == cfg->tps[l - 1].dout) &&
+              (l == L - 1 ? d.dout >= 1 : true);
+    if (!ok) return bail(fail(AA_ERR_INVALID, "model: tensor-product layer dims are inconsistent"));
+    int rc = build_tp_layer(d, &p->layers[l], &p->owned);
+    if (rc) return bail(rc);
+    // the plan must not keep pointers into the caller's descriptor arrays
+    p->cfg.tps[l].nz_i = p->cfg.tps[l].nz_j = p->cfg.tps[l].nz_k = p->cfg.tps[l].nz_path = nullptr;
+    p->cfg.tps[l].nz_val = nullptr;
+  }
+  // weight blob layout
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t r = o;
+    o += (n + 63) / 64 * 64;
+    return r;
+  };
+  const int T = cfg->num_types, B = cfg->num_bessels, S0 = cfg->embed_dim;
+  p->o_rmax = take(size_t(T) * T);
+  p->o_bessel = take(B);
+  p->o_cemb = take(size_t(T) * S0 / 2);
+  p->o_nemb = take(size_t(T) * S0 / 2);
+  p->o_basis = take(size_t(B) * S0);
+  auto lay = [&](MlpLayout& m, const std::vector<int>& dims, int nlayers) {
+    m.dims = dims;
+    for (int i = 0; i < nlayers; ++i) {
+      m.w.push_back(take(size_t(dims[i]) * dims[i + 1]));
+      m.wt.push_back(take(size_t(dims[i]) * dims[i + 1]));
+    }
+  };
+  lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
+  p->o_g0 = take(size_t(S) * (S + 2 * p->W));
+  p->o_g0t = take(size_t(S) * (S + 2 * p->W));
+  for (int l = 0; l < L; ++l) {
+    int in = S * (l + 1) + u, outd = S + (l < L - 1 ? p->W : 0);
+    lay(p->latent[l], mlp_dims(in, cfg->latent_mlp_depth, cfg->latent_mlp_width, outd), cfg->latent_mlp_depth + 1);
+    p->o_tpw[l] = take(size_t(cfg->tps[l].coupling ? u : 1) * cfg->tps[l].num_paths);
+  }
+  {
+    std::vector<int> rd = mlp_dims(p->SL1, cfg->readout_mlp_depth, cfg->readout_mlp_width, 1);
+    lay(p->readout, rd, cfg->readout_mlp_depth);  // all but the last layer
+    p->ro_last_dim = rd[rd.size() - 2];
+    p->o_ro_last = take(p->ro_last_dim);
+  }
+  p->o_scales = take(T);
+  p->o_shifts = take(T);
+  p->n_elems = o;
+  *out = p;
+  return AA_OK;
+}
+
+extern "C" void aa_model_plan_destroy(aa_model_plan* plan) {
+  if (!plan) return;
+  for (void* q : plan->owned) (void)hipFree(q);
+  delete plan;
+}
+
+extern "C" size_t aa_model_weights_bytes(const aa_model_plan* plan) { return plan ? plan->n_elems * plan->esize() : 0; }
+
+// alpha_i of nequip ScalarMLPFunction: c_prev / sqrt(fan_in | fan_out)
+static double mlp_alpha(const aa_model_config& c, int layer, int din, int dout) {
+  double norm = layer == 0 ? 1.0 : c.act_const;
+  return norm / std::sqrt(double(c.forward_weight_init ? din : dout));
+}
+
+extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_weights* raw, void* dev_blob,
+                                     size_t blob_bytes, aa_stream stream) {
+  AA_REQUIRE(p && raw && dev_blob, "aa_model_pack_weights: null argument");
+  AA_REQUIRE(blob_bytes >= aa_model_weights_bytes(p), "aa_model_pack_weights: blob too small");
+  const aa_model_config& c = p->cfg;
+  const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, T = c.num_types, B = c.num_bessels, S0 = c.embed_dim;
+  const int W = p->W;
+  std::vector<double> h(p->n_elems, 0.0);
+  auto copy = [&](size_t off, const double* src, size_t n, double scale) {
+    for (size_t i = 0; i < n; ++i) h[off + i] = src[i] * scale;
+  };
+  AA_REQUIRE(raw->rmax_recip && raw->bessel_weights && raw->center_embed && raw->neighbor_embed && raw->basis_linear &&
+                 raw->env_embed_linear && raw->first_proj,
+             "pack: missing embedding weights");
+  copy(p->o_rmax, raw->rmax_recip, size_t(T) * T, 1.0);
+  copy(p->o_bessel, raw->bessel_weights, B, 1.0);
+  copy(p->o_cemb, raw->center_embed, size_t(T) * S0 / 2, 1.0);
+  copy(p->o_nemb, raw->neighbor_embed, size_t(T) * S0 / 2, 1.0);
+  copy(p->o_basis, raw->basis_linear, size_t(B) * S0, mlp_alpha(c, 0, B, S0));
+  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers) -> bool {
+    for (int i = 0; i < nlayers; ++i) {
+      if (!ws[i]) return false;
+      int din = m.dims[i], dout = m.dims[i + 1];
+      double al = mlp_alpha(c, i, din, dout);
+      for (int r = 0; r < din; ++r)
+        for (int q = 0; q < dout; ++q) {
+          double v = ws[i][size_t(r) * dout + q] * al;
+          h[m.w[i] + size_t(r) * dout + q] = v;
+          h[m.wt[i] + size_t(q) * din + r] = v;
+        }
+    }
+    return true;
+  };
+  AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1), "pack: missing scalar_embed_mlp weights");
+  {
+    // fused first stage: [ two_body (first_proj[:, :S]) | w0 (env_embed_linear) | env_w0 (first_proj[:, S:]) ]
+    const int NG = S + 2 * W;
+    double a_env = mlp_alpha(c, 0, S, W), a_proj = mlp_alpha(c, 0, S, S + W);
+    for (int r = 0; r < S; ++r)
+      for (int q = 0; q < NG; ++q) {
+        double v;
+        if (q < S)
+          v = raw->first_proj[size_t(r) * (S + W) + q] * a_proj;
+        else if (q < S + W)
+          v = raw->env_embed_linear[size_t(r) * W + (q - S)] * a_env;
+        else
+          v = raw->first_proj[size_t(r) * (S + W) + (q - W)] * a_proj;
+        h[p->o_g0 + size_t(r) * NG + q] = v;
+        h[p->o_g0t + size_t(q) * S + r] = v;
+      }
+  }
+  for (int l = 0; l < L; ++l) {
+    AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1), "pack: missing latent weights");
+    AA_REQUIRE(raw->tp_weights[l], "pack: missing tp weights");
+    copy(p->o_tpw[l], raw->tp_weights[l], size_t(c.tps[l].coupling ? u : 1) * c.tps[l].num_paths, 1.0);
+  }
+  AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth), "pack: missing readout weights");
+  {
+    const double* wl = raw->readout[c.readout_mlp_depth];
+    AA_REQUIRE(wl, "pack: missing readout weights");
+    copy(p->o_ro_last, wl, p->ro_last_dim, mlp_alpha(c, c.readout_mlp_depth, p->ro_last_dim, 1));
+  }
+  if (c.has_scales) {
+    AA_REQUIRE(raw->scales, "pack: missing scales");
+    copy(p->o_scales, raw->scales, T, 1.0);
+  }
+  if (c.has_shifts) {
+    AA_REQUIRE(raw->shifts, "pack: missing shifts");
+    copy(p->o_shifts, raw->shifts, T, 1.0);
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c.dtype == AA_F64) {
+    AA_CHECK_HIP(hipMemcpyAsync(dev_blob, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
+  } else {
+    std::vector<float> hf(h.begin(), h.end());
+    AA_CHECK_HIP(hipMemcpyAsync(dev_blob, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
+  }
+  AA_CHECK_HIP(hipStreamSynchronize(s));  // host staging vectors die at return
+  return AA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_scal, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last;
+  size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
+  size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
+  size_t lat_h[AA_MAX_LAYERS][AA_MAX_MLP_LAYERS], g_lat_h[AA_MAX_MLP_LAYERS];
+  size_t ro_h[AA_MAX_MLP_LAYERS], g_ro_h[AA_MAX_MLP_LAYERS];
+  size_t g_tf[2];
+  size_t total;
+};
+
+static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, int with_forces) {
+  Workspace w{};
+  const aa_model_config& c = p->cfg;
+  const size_t es = p->esize();
+  size_t o = 0;
+  auto take = [&](size_t elems) {
+    size_t r = o;
+    o += (elems * es + 255) / 256 * 256;
+    return r;
+  };
+  const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, S0 = c.embed_dim;
+  const size_t Ez = size_t(E), Nz = size_t(N);
+  w.vec = take(Ez * 4);
+  w.sh = take(Ez * p->D);
+  w.emb0 = take(Ez * S0);
+  for (int i = 0; i < c.embed_mlp_depth; ++i) w.se_h[i] = take(Ez * c.embed_mlp_width);
+  w.emb = take(Ez * S);
+  w.w0 = take(Ez * p->W);
+  w.fcat = take(Ez * p->SL1);
+  size_t dmax = 1;
+  for (int l = 0; l < L; ++l) {
+    w.envw[l] = take(Ez * p->W);
+    w.x2s[l] = take(Nz * u * p->D);
+    if (l < L - 1) {
+      w.tf[l] = take(Ez * u * c.tps[l].dout);
+      dmax = std::max(dmax, size_t(c.tps[l].dout));
+    }
+    w.scal[l] = take(Ez * u);
+    for (int i = 0; i < c.latent_mlp_depth; ++i) w.lat_h[l][i] = take(Ez * c.latent_mlp_width);
+  }
+  for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
+  if (with_forces) {
+    w.g_fcat = take(Ez * p->SL1);
+    for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
+    for (int i = 0; i < c.latent_mlp_depth; ++i) w.g_lat_h[i] = take(Ez * c.latent_mlp_width);
+    w.g_scal = take(Ez * u);
+    w.g_envw = take(Ez * p->W);
+    w.g_w0 = take(Ez * p->W);
+    if (L > 1) {
+      w.g_tf[0] = take(Ez * u * dmax);
+      w.g_tf[1] = L > 2 ? take(Ez * u * dmax) : w.g_tf[0];
+    }
+    w.g_emb = take(Ez * S);
+    for (int i = 0; i < c.embed_mlp_depth; ++i) w.g_se_h[i] = take(Ez * c.embed_mlp_width);
+    w.g_emb0 = take(Ez * S0);
+    w.g_sh = take(Ez * p->D);
+  }
+  w.total = o;
+  return w;
+}
+
+extern "C" size_t aa_model_workspace_bytes(const aa_model_plan* plan, int64_t N, int64_t E, int with_forces) {
+  if (!plan) return 0;
+  return layout_workspace(plan, N, E, with_forces).total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pipeline
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+inline Seg seg(void* p, int ld, int n) { return Seg{p, ld, n}; }
+
+template <typename T>
+struct Runner {
+  const aa_model_plan* p;
+  const T* wts;
+  char* ws;
+  Workspace w;
+  int64_t E, N;
+  hipStream_t stream;
+
+  T* buf(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+  const T* wt(size_t off) const { return wts + off; }
+
+  int gemm(const SegList& a, int act_a, const T* B, int K, int Nn, const SegList& c, const int* accum, const SegList* z) {
+    GemmArgs g{};
+    g.M = E;
+    g.K = K;
+    g.N = Nn;
+    g.a = a;
+    g.B = B;
+    g.c = c;
+    for (int i = 0; i < 3; ++i) g.c_accum[i] = accum ? accum[i] : 0;
+    g.has_z = z ? 1 : 0;
+    if (z) g.z = *z;
+    g.act_a = act_a;
+    return launch_gemm<T>(g, stream);
+  }
+
+  // forward of a ScalarMLPFunction: hidden pre-activations to h[i]; final linear output to `out`
+  int mlp_fwd(const MlpLayout& m, int nlayers, const SegList& in, const size_t* h, const SegList& out) {
+    SegList a = in;
+    for (int i = 0; i < nlayers; ++i) {
+      SegList c;
+      if (i < nlayers - 1) {
+        c.count = 1;
+        c.s[0] = seg(buf(h[i]), m.dims[i + 1], m.dims[i + 1]);
+      } else {
+        c = out;
+      }
+      if (int rc = gemm(a, i > 0, wt(m.w[i]), m.dims[i], m.dims[i + 1], c, nullptr, nullptr)) return rc;
+      a = c;
+    }
+    return AA_OK;
+  }
+
+  // reverse: g_out (grad of final output) -> g_in (with per-segment accumulate flags)
+  int mlp_bwd(const MlpLayout& m, int nlayers, const SegList& g_out, const size_t* h, const size_t* g_h,
+              const SegList& g_in, const int* g_in_accum) {
+    SegList a = g_out;
+    for (int i = nlayers - 1; i >= 0; --i) {
+      SegList c, z;
+      const int* acc = nullptr;
+      const SegList* zp = nullptr;
+      if (i > 0) {
+        c.count = 1;
+        c.s[0] = seg(buf(g_h[i - 1]), m.dims[i], m.dims[i]);
+        z.count = 1;
+        z.s[0] = seg(buf(h[i - 1]), m.dims[i], m.dims[i]);
+        zp = &z;
+      } else {
+        c = g_in;
+        acc = g_in_accum;
+      }
+      if (int rc = gemm(a, 0, wt(m.wt[i]), m.dims[i + 1], m.dims[i], c, acc, zp)) return rc;
+      a = c;
+    }
+    return AA_OK;
+  }
+
+  EdgeGeomArgs geom(const aa_graph* g, const void* pos) const {
+    const aa_model_config& c = p->cfg;
+    EdgeGeomArgs a{};
+    a.E = E;
+    a.N = N;
+    a.center = g->center;
+    a.nbr = g->nbr;
+    a.types = g->types;
+    a.pos = pos;
+    a.shift_vec = g->shift_vec;
+    a.num_types = c.num_types;
+    a.num_bessels = c.num_bessels;
+    a.l_max = c.l_max;
+    a.S0 = c.embed_dim;
+    a.poly_p = c.poly_p;
+    a.rmax_recip = wt(p->o_rmax);
+    a.bessel_w = wt(p->o_bessel);
+    a.center_embed = wt(p->o_cemb);
+    a.neighbor_embed = wt(p->o_nemb);
+    a.basis_w = wt(p->o_basis);
+    a.vec = buf(w.vec);
+    a.sh = buf(w.sh);
+    a.emb0 = buf(w.emb0);
+    return a;
+  }
+
+  ReadoutArgs readout_args(const aa_graph* g, void* atom_energy) const {
+    const aa_model_config& c = p->cfg;
+    ReadoutArgs r{};
+    r.E = E;
+    r.N = N;
+    r.rowptr = g->rowptr;
+    r.center = g->center;
+    r.types = g->types;
+    if (c.readout_mlp_depth > 0) {
+      r.h = buf(w.ro_h[c.readout_mlp_depth - 1]);
+      r.ld = c.readout_mlp_width;
+      r.H = c.readout_mlp_width;
+      r.act = 1;
+    } else {
+      r.h = buf(w.fcat);
+      r.ld = p->SL1;
+      r.H = p->SL1;
+      r.act = 0;
+    }
+    r.w = wt(p->o_ro_last);
+    r.factor = 1.0 / std::sqrt(2.0 * c.avg_num_neighbors);
+    r.scales = c.has_scales ? wt(p->o_scales) : nullptr;
+    r.shifts = c.has_shifts ? wt(p->o_shifts) : nullptr;
+    r.atom_energy = atom_energy;
+    return r;
+  }
+
+  TpOperand implicit(size_t w_off) const {
+    TpOperand o{};
+    o.sh = buf(w.sh);
+    o.ld_sh = p->D;
+    o.w = buf(w_off);
+    o.ldw = p->W;
+    return o;
+  }
+
+  int forward(const aa_graph* g, const void* pos, void* atom_energy) {
+    const aa_model_config& c = p->cfg;
+    const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
+    // 1-2: geometry, SH, radial-chemical embedding
+    if (int rc = launch_edge_prologue<T>(geom(g, pos), stream)) return rc;
+    // 3: scalar_embed_mlp
+    {
+      SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
+      SegList out{1, {seg(buf(w.emb), S, S)}};
+      if (int rc = mlp_fwd(p->embed, c.embed_mlp_depth + 1, in, w.se_h, out)) return rc;
+    }
+    // 4+5a: env_embed_linear and first_layer_env_embed_projection as ONE GEMM (tensorembed.py:89, _allegro.py:251)
+    {
+      SegList in{1, {seg(buf(w.emb), S, S)}};
+      SegList out{3, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W), seg(buf(w.envw[0]), W, W)}};
+      if (int rc = gemm(in, 0, wt(p->o_g0), S, S + 2 * W, out, nullptr, nullptr)) return rc;
+    }
+    // 5: layers
+    const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
+    for (int l = 0; l < L; ++l) {
+      TpLayerFwdArgs a{};
+      a.E = E;
+      a.N = N;
+      a.rowptr = g->rowptr;
+      if (l == 0)
+        a.x1 = implicit(w.w0);
+      else
+        a.x1.dense = buf(w.tf[l - 1]);
+      a.x2 = implicit(w.envw[l]);
+      a.weights = wt(p->o_tpw[l]);
+      a.scatter_factor = sfac;
+      a.x2s = buf(w.x2s[l]);
+      a.out = l < L - 1 ? buf(w.tf[l]) : nullptr;
+      a.scal = buf(w.scal[l]);
+      a.ld_scal = u;
+      if (int rc = launch_tp_layer_fwd<T>(p->layers[l], a, stream)) return rc;
+      SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
+      SegList out;
+      out.count = l < L - 1 ? 2 : 1;
+      out.s[0] = seg(buf(w.fcat) + S * (l + 1), SL1, S);
+      if (l < L - 1) out.s[1] = seg(buf(w.envw[l + 1]), W, W);
+      if (int rc = mlp_fwd(p->latent[l], c.latent_mlp_depth + 1, in, w.lat_h[l], out)) return rc;
+    }
+    // 6: edge readout GEMM layers, 7-8: last linear + edge sum + per-type scale/shift
+    if (c.readout_mlp_depth > 0) {
+      SegList a{1, {seg(buf(w.fcat), SL1, SL1)}};
+      for (int i = 0; i < c.readout_mlp_depth; ++i) {
+        SegList cs{1, {seg(buf(w.ro_h[i]), c.readout_mlp_width, c.readout_mlp_width)}};
+        if (int rc = gemm(a, i > 0, wt(p->readout.w[i]), p->readout.dims[i], p->readout.dims[i + 1], cs, nullptr, nullptr))
+          return rc;
+        a = cs;
+      }
+    }
+    return launch_readout_reduce<T>(readout_args(g, atom_energy), stream);
+  }
+
+  int backward(const aa_graph* g, const void* pos, void* forces) {
+    const aa_model_config& c = p->cfg;
+    const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
+    AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * sizeof(T), stream));
+    AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
+    // readout
+    {
+      ReadoutArgs r = readout_args(g, nullptr);
+      if (c.readout_mlp_depth > 0) {
+        r.g_h = buf(w.g_ro_h[c.readout_mlp_depth - 1]);
+        if (int rc = launch_readout_backward<T>(r, stream)) return rc;
+        SegList a{1, {seg(r.g_h, c.readout_mlp_width, c.readout_mlp_width)}};
+        for (int i = c.readout_mlp_depth - 1; i >= 0; --i) {
+          SegList cs, z;
+          const SegList* zp = nullptr;
+          if (i > 0) {
+            cs = SegList{1, {seg(buf(w.g_ro_h[i - 1]), c.readout_mlp_width, c.readout_mlp_width)}};
+            z = SegList{1, {seg(buf(w.ro_h[i - 1]), c.readout_mlp_width, c.readout_mlp_width)}};
+            zp = &z;
+          } else {
+            cs = SegList{1, {seg(buf(w.g_fcat), SL1, SL1)}};
+          }
+          if (int rc = gemm(a, 0, wt(p->readout.wt[i]), p->readout.dims[i + 1], p->readout.dims[i], cs, nullptr, zp))
+            return rc;
+          a = cs;
+        }
+      } else {
+        r.g_h = buf(w.g_fcat);
+        if (int rc = launch_readout_backward<T>(r, stream)) return rc;
+      }
+    }
+    const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
+    for (int l = L - 1; l >= 0; --l) {
+      // latent MLP reverse
+      SegList go;
+      go.count = l < L - 1 ? 2 : 1;
+      go.s[0] = seg(buf(w.g_fcat) + S * (l + 1), SL1, S);
+      if (l < L - 1) go.s[1] = seg(buf(w.g_envw), W, W);
+      SegList gi{2, {seg(buf(w.g_fcat), SL1, S * (l + 1)), seg(buf(w.g_scal), u, u)}};
+      int acc[3] = {1, 0, 0};
+      if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc)) return rc;
+      // tensor-product layer reverse
+      TpLayerBwdArgs a{};
+      a.E = E;
+      a.N = N;
+      a.rowptr = g->rowptr;
+      if (l == 0)
+        a.x1 = implicit(w.w0);
+      else
+        a.x1.dense = buf(w.tf[l - 1]);
+      a.x2 = implicit(w.envw[l]);
+      a.weights = wt(p->o_tpw[l]);
+      a.scatter_factor = sfac;
+      a.x2s = buf(w.x2s[l]);
+      a.gout = l < L - 1 ? buf(w.g_tf[l & 1]) : nullptr;
+      a.gscal = buf(w.g_scal);
+      a.ld_gscal = u;
+      if (l == 0) {
+        a.g1.gw = buf(w.g_w0);
+        a.g1.ldgw = W;
+        a.g1.gsh = buf(w.g_sh);
+        a.g1.ld_gsh = p->D;
+      } else {
+        a.g1.dense = buf(w.g_tf[(l - 1) & 1]);
+      }
+      a.g2.gw = buf(w.g_envw);
+      a.g2.ldgw = W;
+      a.g2.gsh = buf(w.g_sh);
+      a.g2.ld_gsh = p->D;
+      if (int rc = launch_tp_layer_bwd<T>(p->layers[l], a, stream)) return rc;
+    }
+    // fused first stage reverse
+    {
+      SegList go{3, {seg(buf(w.g_fcat), SL1, S), seg(buf(w.g_w0), W, W), seg(buf(w.g_envw), W, W)}};
+      SegList gi{1, {seg(buf(w.g_emb), S, S)}};
+      if (int rc = gemm(go, 0, wt(p->o_g0t), S + 2 * W, S, gi, nullptr, nullptr)) return rc;
+    }
+    // scalar_embed_mlp reverse
+    {
+      SegList go{1, {seg(buf(w.g_emb), S, S)}};
+      SegList gi{1, {seg(buf(w.g_emb0), c.embed_dim, c.embed_dim)}};
+      if (int rc = mlp_bwd(p->embed, c.embed_mlp_depth + 1, go, w.se_h, w.g_se_h, gi, nullptr)) return rc;
+    }
+    EdgeBwdArgs eb{};
+    eb.g = geom(g, pos);
+    eb.g_emb0 = buf(w.g_emb0);
+    eb.g_sh = buf(w.g_sh);
+    eb.forces = forces;
+    return launch_edge_backward<T>(eb, stream);
+  }
+};
+
+template <typename T>
+int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g, const void* pos, void* workspace,
+              size_t ws_bytes, void* atom_energy, void* forces, hipStream_t stream) {
+  Runner<T> r;
+  r.p = p;
+  r.wts = static_cast<const T*>(dev_weights);
+  r.ws = static_cast<char*>(workspace);
+  r.E = g->num_edges;
+  r.N = g->num_atoms;
+  r.stream = stream;
+  r.w = layout_workspace(p, r.N, r.E, forces != nullptr);
+  if (r.w.total > ws_bytes) return fail(AA_ERR_WORKSPACE, "aa_model_energy_forces: workspace too small");
+  if (int rc = r.forward(g, pos, atom_energy)) return rc;
+  if (forces) return r.backward(g, pos, forces);
+  return AA_OK;
+}
+}  // namespace
+
+extern "C" int aa_model_energy_forces(const aa_model_plan* plan, const void* dev_weights, const aa_graph* graph,
+                                      const void* pos, void* workspace, size_t workspace_bytes, void* atom_energy,
+                                      void* forces, aa_stream stream) {
+  AA_REQUIRE(plan && dev_weights && graph && pos && atom_energy, "aa_model_energy_forces: null argument");
+  AA_REQUIRE(graph->num_atoms >= 0 && graph->num_edges >= 0 && graph->num_edges < (int64_t(1) << 31),
+             "aa_model_energy_forces: graph too large for int32 edge ids");
+  AA_REQUIRE(graph->num_edges == 0 || (graph->center && graph->nbr), "aa_model_energy_forces: null edge arrays");
+  AA_REQUIRE(graph->rowptr && graph->types, "aa_model_energy_forces: null rowptr/types");
+  AA_REQUIRE(workspace || workspace_bytes == 0, "aa_model_energy_forces: null workspace");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plan->cfg.dtype == AA_F32)
+    return run_model<float>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s);
+  return run_model<double>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s);
+}
+
+extern "C" int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t N, int64_t E, const void* workspace,
+                                  const void** ptr, int64_t* ld) {
+  AA_REQUIRE(plan && name && workspace && ptr && ld, "aa_model_debug_tap: null argument");
+  Workspace w = layout_workspace(plan, N, E, 0);
+  const char* base = static_cast<const char*>(workspace);
+  std::string n(name);
+  if (n == "edge_attrs") {
+    *ptr = base + w.sh;
+    *ld = plan->D;
+  } else if (n == "edge_embedding") {
+    *ptr = base + w.emb;
+    *ld = plan->cfg.num_scalar;
+  } else if (n == "edge_features") {
+    *ptr = base + w.fcat;
+    *ld = plan->SL1;
+  } else if (n == "emb0") {
+    *ptr = base + w.emb0;
+    *ld = plan->cfg.embed_dim;
+  } else {
+    return fail(AA_ERR_INVALID, "aa_model_debug_tap: unknown tap");
+  }
+  return int(*ld);
+}

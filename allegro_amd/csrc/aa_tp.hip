@@ -1,0 +1,369 @@
+// Strided Clebsch-Gordan tensor-product layer of the Allegro hot path (gfx950), general
+// (table-driven) form: any irreps, any multiplicity, both weight modes, fp32/fp64.
+//
+// One workgroup owns one center atom's edge segment (edges are center-sorted), which fuses what the
+// reference does in three full passes over [E,u,d] (allegro/nn/_strided/_contract.py:195-205:
+// scale, scatter-sum by center, index_select with the SAME index) with the contraction (:213-251):
+//   phase 1  x2s[ch,j] = f * sum_{e in segment} x2[e,ch,j]        -> LDS (+ saved for the backward)
+//   phase 2  out[e,ch,k] = sum_paths W[ch,p] * sum_nz c_nz x1[e,ch,i] x2s[ch,j]
+// x1/x2 may be "implicit" weighted spherical harmonics  sh[e,i] * w[e,ch,irrep(i)]
+// (MakeWeightedChannels, allegro/nn/_strided/_channels.py:44-57) so that [E,u,D] env tensors are
+// never written to HBM.  The sparse non-zeros of w3j replace the dense [z,u,i,j,k] product of
+// _contract.py:236-241 (186 KB/edge at l_max=2).
+//
+// Lane mapping: thread <-> (edge, channel) pair; per-thread operand rows live in LDS with an odd row
+// stride (conflict-free ds_read_b32), the CG table is wave-uniform (scalar loads).
+#include <algorithm>
+#include <tuple>
+
+#include "aa_common.h"
+
+namespace aa {
+
+__device__ __forceinline__ float entry_val(const TpEntry& e, float) { return e.val_f; }
+__device__ __forceinline__ double entry_val(const TpEntry& e, double) { return e.val_d; }
+
+__host__ __device__ inline int odd_pad(int d) { return d | 1; }
+
+template <typename T>
+__device__ __forceinline__ T load_operand(const TpOperand& op, int64_t e, int ch, int i, int u, int d, int R) {
+  if (op.dense) return static_cast<const T*>(op.dense)[(e * u + ch) * d + i];
+  return static_cast<const T*>(op.sh)[e * op.ld_sh + i] * static_cast<const T*>(op.w)[e * op.ldw + ch * R + sh_l_of(i)];
+}
+
+// sum `v` over the channels of one edge into LDS slot *dst (dst is per (edge, component)).
+template <typename T>
+__device__ __forceinline__ void channel_reduce_add(T v, T* dst, bool wave_uniform, bool active) {
+  if (wave_uniform) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0 && active) atomicAdd(dst, v);
+  } else {
+    if (active) atomicAdd(dst, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tp_layer_fwd_kernel(TpLayerDev L, TpLayerFwdArgs a) {
+  const int u = L.mul, d1 = L.d1, d2 = L.d2, dout = L.dout, P = L.num_paths;
+  const int d1p = odd_pad(d1), d2p = odd_pad(d2);
+  const int R2 = a.x2.dense ? 0 : sh_l_of(d2 - 1) + 1;
+  const int R1 = a.x1.dense ? 0 : sh_l_of(d1 - 1) + 1;
+  T* sX2 = reinterpret_cast<T*>(aa_smem);  // [u][d2p]
+  T* sX1 = sX2 + u * d2p;                  // [256][d1p]
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+  const int deg = end - beg;
+  const T sf = T(a.scatter_factor);
+
+  // phase 1: scaled segment sum of the env operand
+  for (int idx = tid; idx < u * d2; idx += 256) {
+    int ch = idx / d2, j = idx % d2;
+    T acc = T(0);
+    for (int s = beg; s < end; ++s) {
+      int64_t e = a.eids ? a.eids[s] : s;
+      acc += load_operand<T>(a.x2, e, ch, j, u, d2, R2);
+    }
+    acc *= sf;
+    sX2[ch * d2p + j] = acc;
+    static_cast<T*>(a.x2s)[(n * u + ch) * d2 + j] = acc;
+  }
+  __syncthreads();
+
+  // phase 2: contraction per (edge, channel)
+  const T* W = static_cast<const T*>(a.weights);
+  const int npairs = deg * u;
+  for (int q0 = 0; q0 < npairs; q0 += 256) {
+    int q = q0 + tid;
+    if (q >= npairs) continue;  // no collectives below
+    int el = q / u, ch = q % u;
+    int64_t e = a.eids ? a.eids[beg + el] : (beg + el);
+    T* x1 = sX1 + tid * d1p;
+    for (int i = 0; i < d1; ++i) x1[i] = load_operand<T>(a.x1, e, ch, i, u, d1, R1);
+    const T* x2 = sX2 + ch * d2p;
+    T cur = T(0);
+    for (int gi = 0; gi < L.fwd.num_groups; ++gi) {
+      TpGroup grp = L.fwd.groups[gi];
+      T acc = T(0);
+      for (int nz = grp.begin; nz < grp.end; ++nz) {
+        TpEntry en = L.fwd.entries[nz];
+        acc += entry_val(en, T(0)) * x1[en.a] * x2[en.b];
+      }
+      if (grp.end > grp.begin) {
+        cur += (L.coupling ? W[ch * P + grp.path] : W[grp.path]) * acc;
+      }
+      bool last = (gi + 1 == L.fwd.num_groups) || (L.fwd.groups[gi + 1].out_idx != grp.out_idx);
+      if (last) {
+        if (a.out) static_cast<T*>(a.out)[(e * u + ch) * dout + grp.out_idx] = cur;
+        if (a.scal && grp.out_idx == 0) static_cast<T*>(a.scal)[e * a.ld_scal + ch] = cur;
+        cur = T(0);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tp_layer_bwd_kernel(TpLayerDev L, TpLayerBwdArgs a, int EC) {
+  const int u = L.mul, d1 = L.d1, d2 = L.d2, dout = L.dout, P = L.num_paths;
+  const int d1p = odd_pad(d1), d2p = odd_pad(d2), dop = odd_pad(dout);
+  const int R1 = a.x1.dense ? 0 : sh_l_of(d1 - 1) + 1;
+  const int R2 = a.x2.dense ? 0 : sh_l_of(d2 - 1) + 1;
+  const int Dsh = d1 > d2 ? d1 : d2;  // row width of the sh-gradient staging
+  T* sX2 = reinterpret_cast<T*>(aa_smem);  // [u][d2p]   x2s of this atom
+  T* sG2 = sX2 + u * d2p;                  // [u][d2p]   grad wrt x2s (accumulated over the segment)
+  T* sX1 = sG2 + u * d2p;                  // [256][d1p]
+  T* sGo = sX1 + 256 * d1p;                // [256][dop]
+  T* sGY = sGo + 256 * dop;                // [EC][Dsh]
+  const int tid = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+  const int deg = end - beg;
+  const T sf = T(a.scatter_factor);
+  const bool wave_uniform = (u % 64) == 0;
+  const T* W = static_cast<const T*>(a.weights);
+
+  for (int idx = tid; idx < u * d2; idx += 256) {
+    int ch = idx / d2, j = idx % d2;
+    sX2[ch * d2p + j] = static_cast<const T*>(a.x2s)[(n * u + ch) * d2 + j];
+    sG2[ch * d2p + j] = T(0);
+  }
+  __syncthreads();
+
+  const int npairs = deg * u;
+  const bool need_gsh1 = (!a.x1.dense) && a.g1.gsh;
+  for (int q0 = 0; q0 < npairs; q0 += 256) {
+    if (need_gsh1) {
+      for (int idx = tid; idx < EC * Dsh; idx += 256) sGY[idx] = T(0);
+      __syncthreads();
+    }
+    int q = q0 + tid;
+    bool active = q < npairs;
+    int el = active ? q / u : 0, ch = active ? q % u : 0;
+    int el0 = q0 / u;
+    int64_t e = active ? (a.eids ? a.eids[beg + el] : (beg + el)) : 0;
+    T* x1 = sX1 + tid * d1p;
+    T* go = sGo + tid * dop;
+    if (active) {
+      for (int i = 0; i < d1; ++i) x1[i] = load_operand<T>(a.x1, e, ch, i, u, d1, R1);
+      for (int k = 0; k < dout; ++k) go[k] = a.gout ? static_cast<const T*>(a.gout)[(e * u + ch) * dout + k] : T(0);
+      if (a.gscal) go[0] += static_cast<const T*>(a.gscal)[e * a.ld_gscal + ch];
+    } else {
+      for (int i = 0; i < d1; ++i) x1[i] = T(0);
+      for (int k = 0; k < dout; ++k) go[k] = T(0);
+    }
+    const T* x2 = sX2 + ch * d2p;
+    // ---- grad wrt x1: g1[i] = sum W * c * gout[k] * x2s[j]
+    {
+      T cur = T(0), gw_acc = T(0);
+      int r_cur = 0;
+      for (int gi = 0; gi < L.bx1.num_groups; ++gi) {
+        TpGroup grp = L.bx1.groups[gi];
+        T acc = T(0);
+        for (int nz = grp.begin; nz < grp.end; ++nz) {
+          TpEntry en = L.bx1.entries[nz];
+          acc += entry_val(en, T(0)) * go[en.a] * x2[en.b];
+        }
+        if (grp.end > grp.begin) cur += (L.coupling ? W[ch * P + grp.path] : W[grp.path]) * acc;
+        bool last = (gi + 1 == L.bx1.num_groups) || (L.bx1.groups[gi + 1].out_idx != grp.out_idx);
+        if (last) {
+          int i = grp.out_idx;
+          if (a.g1.dense) {
+            if (active) static_cast<T*>(a.g1.dense)[(e * u + ch) * d1 + i] = cur;
+          } else if (a.g1.gw) {
+            // implicit x1 = sh[e,i] * w[e,ch,r(i)]
+            int r = sh_l_of(i);
+            if (r != r_cur) {
+              if (active) static_cast<T*>(a.g1.gw)[e * a.g1.ldgw + ch * R1 + r_cur] = gw_acc;
+              gw_acc = T(0);
+              r_cur = r;
+            }
+            T shv = active ? static_cast<const T*>(a.x1.sh)[e * a.x1.ld_sh + i] : T(0);
+            T wv = active ? static_cast<const T*>(a.x1.w)[e * a.x1.ldw + ch * R1 + r] : T(0);
+            gw_acc += cur * shv;
+            if (need_gsh1) channel_reduce_add<T>(cur * wv, sGY + (el - el0) * Dsh + i, wave_uniform, active);
+          }
+          cur = T(0);
+        }
+      }
+      if (!a.g1.dense && a.g1.gw && active) static_cast<T*>(a.g1.gw)[e * a.g1.ldgw + ch * R1 + r_cur] = gw_acc;
+    }
+    // ---- grad wrt x2s: g2[j] = sum W * c * gout[k] * x1[i], summed over the segment
+    {
+      T cur = T(0);
+      for (int gi = 0; gi < L.bx2.num_groups; ++gi) {
+        TpGroup grp = L.bx2.groups[gi];
+        T acc = T(0);
+        for (int nz = grp.begin; nz < grp.end; ++nz) {
+          TpEntry en = L.bx2.entries[nz];
+          acc += entry_val(en, T(0)) * go[en.a] * x1[en.b];
+        }
+        if (grp.end > grp.begin) cur += (L.coupling ? W[ch * P + grp.path] : W[grp.path]) * acc;
+        bool last = (gi + 1 == L.bx2.num_groups) || (L.bx2.groups[gi + 1].out_idx != grp.out_idx);
+        if (last) {
+          if (active) atomicAdd(&sG2[ch * d2p + grp.out_idx], cur);
+          cur = T(0);
+        }
+      }
+    }
+    if (need_gsh1) {
+      __syncthreads();
+      int ne = (q0 + 256 < npairs ? q0 + 256 : npairs);
+      int el1 = (ne - 1) / u;  // last edge touched in this chunk
+      for (int idx = tid; idx < (el1 - el0 + 1) * d1; idx += 256) {
+        int le = idx / d1, i = idx % d1;
+        int64_t ee = a.eids ? a.eids[beg + el0 + le] : (beg + el0 + le);
+        static_cast<T*>(a.g1.gsh)[ee * a.g1.ld_gsh + i] += sGY[le * Dsh + i];
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C: adjoint of (scale, segment-sum, gather): every edge of the segment receives f * g_x2s
+  if (a.g2.dense) {
+    for (int idx = tid; idx < deg * u * d2; idx += 256) {
+      int el = idx / (u * d2), rem = idx % (u * d2);
+      int ch = rem / d2, j = rem % d2;
+      int64_t e = a.eids ? a.eids[beg + el] : (beg + el);
+      static_cast<T*>(a.g2.dense)[(e * u + ch) * d2 + j] = sf * sG2[ch * d2p + j];
+    }
+  } else if (a.g2.gw) {
+    for (int q0 = 0; q0 < npairs; q0 += 256) {
+      if (a.g2.gsh) {
+        for (int idx = tid; idx < EC * Dsh; idx += 256) sGY[idx] = T(0);
+        __syncthreads();
+      }
+      int q = q0 + tid;
+      bool active = q < npairs;
+      int el = active ? q / u : 0, ch = active ? q % u : 0;
+      int el0 = q0 / u;
+      int64_t e = active ? (a.eids ? a.eids[beg + el] : (beg + el)) : 0;
+      const T* shp = static_cast<const T*>(a.x2.sh) + e * a.x2.ld_sh;
+      const T* wp = static_cast<const T*>(a.x2.w) + e * a.x2.ldw + ch * R2;
+      int j = 0;
+      for (int r = 0; r < R2; ++r) {
+        T acc = T(0);
+        T wv = active ? wp[r] : T(0);
+        for (int m = 0; m < 2 * r + 1; ++m, ++j) {
+          T g = sf * sG2[ch * d2p + j];
+          acc += (active ? shp[j] : T(0)) * g;
+          if (a.g2.gsh) channel_reduce_add<T>(wv * g, sGY + (el - el0) * Dsh + j, wave_uniform, active);
+        }
+        if (active) static_cast<T*>(a.g2.gw)[e * a.g2.ldgw + ch * R2 + r] = acc;
+      }
+      if (a.g2.gsh) {
+        __syncthreads();
+        int ne = (q0 + 256 < npairs ? q0 + 256 : npairs);
+        int el1 = (ne - 1) / u;
+        for (int idx = tid; idx < (el1 - el0 + 1) * d2; idx += 256) {
+          int le = idx / d2, jj = idx % d2;
+          int64_t ee = a.eids ? a.eids[beg + el0 + le] : (beg + el0 + le);
+          static_cast<T*>(a.g2.gsh)[ee * a.g2.ld_gsh + jj] += sGY[le * Dsh + jj];
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tables
+// ---------------------------------------------------------------------------------------------
+static int upload_table(const std::vector<std::tuple<int, int, int, int, double>>& ents_in /*out,path,a,b,val*/,
+                        int num_out, TpTable* tab, std::vector<void*>* owned) {
+  auto ents = ents_in;
+  std::sort(ents.begin(), ents.end());
+  std::vector<TpGroup> groups;
+  std::vector<TpEntry> entries;
+  size_t pos = 0;
+  for (int c = 0; c < num_out; ++c) {
+    bool any = false;
+    while (pos < ents.size() && std::get<0>(ents[pos]) == c) {
+      int p = std::get<1>(ents[pos]);
+      TpGroup g{c, p, (int)entries.size(), 0};
+      while (pos < ents.size() && std::get<0>(ents[pos]) == c && std::get<1>(ents[pos]) == p) {
+        TpEntry en;
+        en.a = std::get<2>(ents[pos]);
+        en.b = std::get<3>(ents[pos]);
+        en.val_d = std::get<4>(ents[pos]);
+        en.val_f = (float)en.val_d;
+        entries.push_back(en);
+        ++pos;
+      }
+      g.end = (int)entries.size();
+      groups.push_back(g);
+      any = true;
+    }
+    if (!any) groups.push_back(TpGroup{c, 0, (int)entries.size(), (int)entries.size()});  // zero output
+  }
+  void *dg = nullptr, *de = nullptr;
+  AA_CHECK_HIP(hipMalloc(&dg, sizeof(TpGroup) * std::max<size_t>(groups.size(), 1)));
+  owned->push_back(dg);
+  AA_CHECK_HIP(hipMalloc(&de, sizeof(TpEntry) * std::max<size_t>(entries.size(), 1)));
+  owned->push_back(de);
+  AA_CHECK_HIP(hipMemcpy(dg, groups.data(), sizeof(TpGroup) * groups.size(), hipMemcpyHostToDevice));
+  AA_CHECK_HIP(hipMemcpy(de, entries.data(), sizeof(TpEntry) * entries.size(), hipMemcpyHostToDevice));
+  tab->num_groups = (int)groups.size();
+  tab->groups = static_cast<const TpGroup*>(dg);
+  tab->entries = static_cast<const TpEntry*>(de);
+  return AA_OK;
+}
+
+int build_tp_layer(const aa_tp_desc& d, TpLayerDev* out, std::vector<void*>* owned) {
+  AA_REQUIRE(d.mul > 0 && d.d1 > 0 && d.d2 > 0 && d.dout > 0 && d.num_paths > 0 && d.nnz > 0, "tp desc: bad dims");
+  std::vector<std::tuple<int, int, int, int, double>> f, b1, b2;
+  for (int n = 0; n < d.nnz; ++n) {
+    int i = d.nz_i[n], j = d.nz_j[n], k = d.nz_k[n], p = d.nz_path[n];
+    AA_REQUIRE(i >= 0 && i < d.d1 && j >= 0 && j < d.d2 && k >= 0 && k < d.dout && p >= 0 && p < d.num_paths,
+               "tp desc: index out of range");
+    double v = d.nz_val[n];
+    f.emplace_back(k, p, i, j, v);
+    b1.emplace_back(i, p, k, j, v);
+    b2.emplace_back(j, p, k, i, v);
+  }
+  out->mul = d.mul;
+  out->d1 = d.d1;
+  out->d2 = d.d2;
+  out->dout = d.dout;
+  out->num_paths = d.num_paths;
+  out->coupling = d.coupling;
+  if (int rc = upload_table(f, d.dout, &out->fwd, owned)) return rc;
+  if (int rc = upload_table(b1, d.d1, &out->bx1, owned)) return rc;
+  if (int rc = upload_table(b2, d.d2, &out->bx2, owned)) return rc;
+  return AA_OK;
+}
+
+template <typename T>
+int launch_tp_layer_fwd(const TpLayerDev& L, const TpLayerFwdArgs& a, hipStream_t stream) {
+  if (a.N == 0) return AA_OK;
+  size_t smem = sizeof(T) * (size_t(L.mul) * odd_pad(L.d2) + 256 * size_t(odd_pad(L.d1)));
+  AA_REQUIRE(smem <= 160 * 1024, "tp fwd: LDS budget exceeded (mul*d2 too large)");
+  AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_layer_fwd_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(tp_layer_fwd_kernel<T>, dim3((unsigned)a.N), dim3(256), smem, stream, L, a);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template <typename T>
+int launch_tp_layer_bwd(const TpLayerDev& L, const TpLayerBwdArgs& a, hipStream_t stream) {
+  if (a.N == 0) return AA_OK;
+  int EC = (256 + L.mul - 1) / L.mul + 1;
+  int Dsh = std::max(L.d1, L.d2);
+  size_t smem = sizeof(T) * (2 * size_t(L.mul) * odd_pad(L.d2) + 256 * size_t(odd_pad(L.d1)) +
+                             256 * size_t(odd_pad(L.dout)) + size_t(EC) * Dsh);
+  AA_REQUIRE(smem <= 160 * 1024, "tp bwd: LDS budget exceeded");
+  AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_layer_bwd_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(tp_layer_bwd_kernel<T>, dim3((unsigned)a.N), dim3(256), smem, stream, L, a, EC);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template int launch_tp_layer_fwd<float>(const TpLayerDev&, const TpLayerFwdArgs&, hipStream_t);
+template int launch_tp_layer_fwd<double>(const TpLayerDev&, const TpLayerFwdArgs&, hipStream_t);
+template int launch_tp_layer_bwd<float>(const TpLayerDev&, const TpLayerBwdArgs&, hipStream_t);
+template int launch_tp_layer_bwd<double>(const TpLayerDev&, const TpLayerBwdArgs&, hipStream_t);
+
+}  // namespace aa

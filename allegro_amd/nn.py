@@ -1,0 +1,598 @@
+"""Host-side mirror of the reference's operator / module interface for the hot path.
+
+* `HipContracter`  -- same constructor, parameters (`weights`), persistent buffer (`w3j`) and
+  `forward(x1, x2, idxs, scatter_dim_size)` contract as `allegro.nn._strided.Contracter`
+  (allegro/nn/_strided/_contract.py:33-211), backed by the HIP tensor-product operator.
+* `HipAllegroModel` -- same hyper-parameters and the same `state_dict` keys as
+  `allegro.model.AllegroModel` (allegro/model/allegro_models.py:101-103,112-300), so
+  `hip_model.load_state_dict(reference_model.state_dict())` is the drop-in step
+  (the reference's own modifier swap relies on exactly that, _contract.py:277).  `forward(data)`
+  returns `atomic_energy`, `total_energy`, `forces` computed by one C-ABI call
+  (`aa_model_energy_forces`): forward and the hand-written reverse pass, all in HIP.
+
+PyTorch is used for device memory, streams and parameter bookkeeping only.  There is no CPU
+fallback: on a tensor that is not on a GPU these modules raise.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, o3
+
+_TORCH2AA = {torch.float32: _lib.AA_F32, torch.float64: _lib.AA_F64}
+
+
+def silu_second_moment_const() -> float:
+    """normalize2mom constant of SiLU, 1/sqrt(E_{z~N(0,1)}[silu(z)^2]), by quadrature."""
+    z = np.linspace(-12.0, 12.0, 240001)
+    w = np.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+    f = (z / (1.0 + np.exp(-z))) ** 2 * w
+    return 1.0 / math.sqrt(float(np.sum((f[1:] + f[:-1]) * 0.5 * (z[1] - z[0]))))
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def _require_gpu(lib: _lib.AllegroLib, t: torch.Tensor, what: str):
+    if not t.is_cuda and not lib.is_emulation:
+        raise _lib.AllegroError(f"{what}: tensors must live on the GPU (got {t.device}); there is no CPU fallback")
+
+
+# ------------------------------------------------------------------------------------------------
+# irreps logic of the Allegro layer stack
+# ------------------------------------------------------------------------------------------------
+def allegro_layer_irreps(l_max: int, parity: bool, num_layers: int) -> List[o3.Irreps]:
+    """Per-layer tensor-track irreps: forward reachability then backward pruning.
+    Mirrors allegro/nn/_allegro.py:101-160 (and the allowed set of allegro_models.py:76-86).
+    Returns tps_irreps[0..L]: input irreps of layer l = [l], output = [l+1]."""
+    env = o3.Irreps.spherical_harmonics(l_max, p=-1)
+    if parity:
+        allowed = o3.Irreps([(1, (l, p)) for l in range(l_max + 1) for p in (1, -1)])
+    else:
+        allowed = env
+    arg = env
+    tps = [arg]
+    for layer in range(num_layers):
+        ir_out = o3.Irreps([(1, (0, 1))]) if layer == num_layers - 1 else allowed
+        ir_out = o3.Irreps([(m, ir) for m, ir in ir_out if o3.tp_path_exists(arg, env, ir)])
+        arg = ir_out
+        tps.append(ir_out)
+    out = tps[-1]
+    new = [out]
+    for arg in reversed(tps[:-1]):
+        keep = []
+        for m, arg_ir in arg:
+            if any(any(i in out for i in arg_ir * env_ir) for _, env_ir in env):
+                keep.append((m, arg_ir))
+        out = o3.Irreps(keep)
+        new.append(out)
+    tps = list(reversed(new))
+    assert tps[-1].lmax == 0
+    return tps
+
+
+def build_w3j(irreps_in1: o3.Irreps, irreps_in2: o3.Irreps, irreps_out: o3.Irreps,
+              instructions: Optional[Sequence[Tuple[int, int, int]]] = None, irrep_normalization="component"):
+    """The dense `w3j` buffer exactly as Contracter.__init__ lays it out (_contract.py:48-168):
+    instructions enumerated in (i_out, i_1, i_2) loop order, values x sqrt(2 l_out + 1), [p,i,k] when
+    ij-diagonal else [p,i,j,k], path dim squeezed when there is a single path."""
+    if instructions is None:
+        instructions = []
+        for i_out, (_, ir_out) in enumerate(irreps_out):
+            for i_1, (_, ir_1) in enumerate(irreps_in1):
+                for i_2, (_, ir_2) in enumerate(irreps_in2):
+                    if ir_out in (ir_1 * ir_2):
+                        instructions.append((i_1, i_2, i_out))
+    assert len(instructions) > 0, "No TP paths available"
+    o1, o2, oo = irreps_in1.offsets(), irreps_in2.offsets(), irreps_out.offsets()
+    d1, d2, dout = irreps_in1.dim, irreps_in2.dim, irreps_out.dim
+    blocks = []
+    for (i_1, i_2, i_out) in instructions:
+        ir1, ir2, iro = irreps_in1[i_1][1], irreps_in2[i_2][1], irreps_out[i_out][1]
+        assert ir1.p * ir2.p == iro.p and abs(ir1.l - ir2.l) <= iro.l <= ir1.l + ir2.l
+        w = o3.wigner_3j(ir1.l, ir2.l, iro.l)
+        if irrep_normalization == "component":
+            w = w * math.sqrt(2 * iro.l + 1)
+        elif irrep_normalization is not None:
+            raise NotImplementedError(irrep_normalization)
+        blocks.append((o1[i_1], o2[i_2], oo[i_out], w))
+    diag = d1 == d2 and all(
+        all(o_a + i == o_b + j for i, j, _ in zip(*np.nonzero(w))) for o_a, o_b, _, w in blocks)
+    P = len(instructions)
+    if diag:
+        w3j = np.zeros((P, d1, dout))
+        for p, (a, b, c, w) in enumerate(blocks):
+            for i, j, k in zip(*np.nonzero(w)):
+                w3j[p, a + i, c + k] = w[i, j, k]
+    else:
+        w3j = np.zeros((P, d1, d2, dout))
+        for p, (a, b, c, w) in enumerate(blocks):
+            w3j[p, a:a + w.shape[0], b:b + w.shape[1], c:c + w.shape[2]] = w
+    if P == 1:
+        w3j = w3j[0]
+    return w3j, list(instructions), bool(diag), (d1, d2, dout)
+
+
+def w3j_to_desc(w3j: torch.Tensor, mul: int, dims: Tuple[int, int, int], num_paths: int, diag: bool, coupling: bool):
+    """Sparse non-zeros of a (possibly squeezed) w3j buffer -> C descriptor."""
+    d1, d2, dout = dims
+    w = w3j.detach().to("cpu", torch.float64).numpy()
+    if num_paths == 1:
+        w = w[None]
+    if diag:
+        p, i, k = np.nonzero(w)
+        j = i
+        val = w[p, i, k]
+    else:
+        p, i, j, k = np.nonzero(w)
+        val = w[p, i, j, k]
+    return _lib.make_tp_desc(mul, d1, d2, dout, num_paths, coupling, i, j, k, p, val)
+
+
+# ------------------------------------------------------------------------------------------------
+# segment bookkeeping
+# ------------------------------------------------------------------------------------------------
+def segments_from_index(idxs: torch.Tensor, num_segments: int):
+    """rowptr[int32, N+1] and (if idxs is not sorted) the stable sort permutation eids[int32, E]."""
+    idxs = idxs.reshape(-1)
+    is_sorted = bool((idxs[1:] >= idxs[:-1]).all()) if idxs.numel() > 1 else True
+    eids = None
+    if not is_sorted:
+        eids = torch.argsort(idxs, stable=True).to(torch.int32)
+    counts = torch.bincount(idxs, minlength=num_segments)
+    rowptr = torch.zeros(num_segments + 1, dtype=torch.int32, device=idxs.device)
+    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return rowptr, eids
+
+
+# ------------------------------------------------------------------------------------------------
+# Contracter (seam B1/B2)
+# ------------------------------------------------------------------------------------------------
+class _TpFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x1, x2, weights, rowptr, eids, num_atoms, scatter_factor):
+        lib = mod._get_lib()
+        _require_gpu(lib, x1, "HipContracter")
+        x1c, x2c, wc = x1.contiguous(), x2.contiguous(), weights.detach().contiguous()
+        E = x1c.shape[0]
+        out = torch.empty((E, mod.mul, mod.base_dim_out), dtype=x1.dtype, device=x1.device)
+        x2s = torch.empty((num_atoms, mod.mul, mod.base_dim2), dtype=x1.dtype, device=x1.device)
+        plan = mod._plan(x1.dtype)
+        lib.tp_forward(plan, E, num_atoms, x1c.data_ptr(), x2c.data_ptr(), wc.data_ptr(), rowptr.data_ptr(),
+                       eids.data_ptr() if eids is not None else None, scatter_factor, x2s.data_ptr(), out.data_ptr(),
+                       _stream_ptr(x1))
+        ctx.mod, ctx.num_atoms, ctx.scatter_factor = mod, num_atoms, scatter_factor
+        ctx.save_for_backward(x1c, x2s, wc, rowptr, eids if eids is not None else torch.empty(0))
+        ctx.has_eids = eids is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        mod = ctx.mod
+        x1c, x2s, wc, rowptr, eids = ctx.saved_tensors
+        lib = mod._get_lib()
+        gout = gout.contiguous()
+        E = x1c.shape[0]
+        gx1 = torch.empty_like(x1c)
+        gx2 = torch.empty((E, mod.mul, mod.base_dim2), dtype=x1c.dtype, device=x1c.device)
+        lib.tp_backward(mod._plan(x1c.dtype), E, ctx.num_atoms, x1c.data_ptr(), x2s.data_ptr(), wc.data_ptr(),
+                        rowptr.data_ptr(), eids.data_ptr() if ctx.has_eids else None, ctx.scatter_factor,
+                        gout.data_ptr(), gx1.data_ptr(), gx2.data_ptr(), _stream_ptr(x1c))
+        # no weight gradient: inference/force path only, like the reference's own accelerated op
+        # (allegro/nn/_strided/_flashallegro.py:660)
+        return None, gx1, gx2, None, None, None, None, None
+
+
+class HipContracter(torch.nn.Module):
+    """Drop-in for `Contracter` (allegro/nn/_strided/_contract.py:11-251) on the HIP operator."""
+
+    def __init__(self, irreps_in1, irreps_in2, irreps_out, mul: int, instructions=None,
+                 path_channel_coupling: bool = True, scatter_factor: Optional[float] = None,
+                 irrep_normalization: str = "component"):
+        super().__init__()
+        self.irreps_in1, self.irreps_in2, self.irreps_out = o3.Irreps(irreps_in1), o3.Irreps(irreps_in2), o3.Irreps(irreps_out)
+        for irr in (self.irreps_in1, self.irreps_in2, self.irreps_out):
+            assert all(m == 1 for m, _ in irr)
+        assert mul > 0
+        self.mul = mul
+        self.scatter_factor = scatter_factor
+        self.irrep_normalization = irrep_normalization
+        self.path_channel_coupling = path_channel_coupling
+        w3j, instr, diag, (d1, d2, dout) = build_w3j(self.irreps_in1, self.irreps_in2, self.irreps_out, instructions,
+                                                      irrep_normalization)
+        self.instructions = instructions
+        self.num_paths = len(instr)
+        self.w3j_is_ij_diagonal = diag
+        self.base_dim1, self.base_dim2, self.base_dim_out = d1, d2, dout
+        self.register_buffer("w3j", torch.tensor(w3j, dtype=torch.get_default_dtype()))
+        shape = (mul,) if path_channel_coupling else tuple()
+        if self.num_paths > 1:
+            shape = shape + (self.num_paths,)
+        self.weights = torch.nn.Parameter(torch.empty(shape).uniform_(-math.sqrt(3), math.sqrt(3)))
+        self._plans: Dict[torch.dtype, int] = {}
+        self._keep = []
+        self._bound_lib: Optional[_lib.AllegroLib] = None
+
+    def _get_lib(self) -> _lib.AllegroLib:
+        return self._bound_lib if self._bound_lib is not None else _lib.load()
+
+    def _bind_library(self, lib: _lib.AllegroLib):
+        """(tests) bind an explicitly loaded library instead of the default gfx950 one."""
+        self._bound_lib = lib
+        self._plans.clear()
+
+    def _plan(self, dtype) -> int:
+        if dtype not in self._plans:
+            desc, keep = w3j_to_desc(self.w3j, self.mul, (self.base_dim1, self.base_dim2, self.base_dim_out),
+                                     self.num_paths, self.w3j_is_ij_diagonal, self.path_channel_coupling)
+            self._keep.append(keep)
+            self._plans[dtype] = self._get_lib().tp_plan_create(desc, _TORCH2AA[dtype])
+        return self._plans[dtype]
+
+    def forward(self, x1, x2, idxs, scatter_dim_size):
+        if isinstance(scatter_dim_size, torch.Tensor):
+            scatter_dim_size = int(scatter_dim_size.reshape(-1)[0])
+        x1 = x1.reshape(-1, self.mul, self.base_dim1)
+        x2 = x2.reshape(-1, self.mul, self.base_dim2)
+        rowptr, eids = segments_from_index(idxs, scatter_dim_size)
+        sf = 1.0 if self.scatter_factor is None else float(self.scatter_factor)
+        return _TpFunction.apply(self, x1, x2, self.weights, rowptr, eids, scatter_dim_size, sf)
+
+    def _contract(self, x1, x2):
+        """Contraction only (seam B1, _contract.py:213): every edge is its own segment."""
+        E = x1.shape[0]
+        rowptr = torch.arange(E + 1, dtype=torch.int32, device=x1.device)
+        return _TpFunction.apply(self, x1, x2, self.weights, rowptr, None, E, 1.0)
+
+    def extra_repr(self):
+        return f"{self.irreps_in1} x {self.irreps_in2} -> {self.irreps_out} | {self.mul} channels | {self.num_paths} paths"
+
+    def __del__(self):
+        try:
+            for h in self._plans.values():
+                self._get_lib().tp_plan_destroy(h)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# whole model
+# ------------------------------------------------------------------------------------------------
+class _Node(torch.nn.Module):
+    """Plain container used to reproduce the reference's state_dict key hierarchy."""
+
+
+def _ensure_path(root: torch.nn.Module, dotted: str) -> Tuple[torch.nn.Module, str]:
+    parts = dotted.split(".")
+    node = root
+    for name in parts[:-1]:
+        if not hasattr(node, name):
+            node.add_module(name, _Node())
+        node = getattr(node, name)
+    return node, parts[-1]
+
+
+class PreparedGraph:
+    """Device-resident center-sorted CSR view of an edge list (the `aa_graph` struct)."""
+
+    def __init__(self, edge_index: torch.Tensor, atom_types: torch.Tensor, num_atoms: int,
+                 shift_vec: Optional[torch.Tensor] = None):
+        center = edge_index[0]
+        self.perm = None
+        if center.numel() > 1 and not bool((center[1:] >= center[:-1]).all()):
+            self.perm = torch.argsort(center, stable=True)
+            edge_index = edge_index[:, self.perm]
+            if shift_vec is not None:
+                shift_vec = shift_vec[self.perm]
+        self.num_atoms, self.num_edges = int(num_atoms), int(edge_index.shape[1])
+        self.center = edge_index[0].to(torch.int32).contiguous()
+        self.nbr = edge_index[1].to(torch.int32).contiguous()
+        counts = torch.bincount(edge_index[0], minlength=num_atoms)
+        self.rowptr = torch.zeros(num_atoms + 1, dtype=torch.int32, device=edge_index.device)
+        self.rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        self.types = atom_types.reshape(-1).to(torch.int32).contiguous()
+        self.shift_vec = None if shift_vec is None else shift_vec.contiguous()
+
+    def c_struct(self) -> _lib.Graph:
+        return _lib.Graph(self.num_atoms, self.num_edges, self.center.data_ptr(), self.nbr.data_ptr(),
+                          self.rowptr.data_ptr(), self.types.data_ptr(),
+                          self.shift_vec.data_ptr() if self.shift_vec is not None else None)
+
+
+class HipAllegroModel(torch.nn.Module):
+    """Energy + forces of an Allegro model through the HIP hot path.
+
+    Constructor arguments follow `allegro.model.AllegroModel` (allegro_models.py:112-147); only the
+    Bessel two-body embedding (`allegro.nn.TwoBodyBesselScalarEmbed`) and SiLU MLPs are supported.
+    """
+
+    def __init__(self, *, type_names: Sequence[str], r_max: float, l_max: int, num_layers: int = 2,
+                 num_scalar_features: int = 64, num_tensor_features: int = 16, parity: bool = True,
+                 radial_chemical_embed: Optional[dict] = None, radial_chemical_embed_dim: Optional[int] = None,
+                 per_edge_type_cutoff: Optional[dict] = None,
+                 scalar_embed_mlp_hidden_layers_depth: int = 1, scalar_embed_mlp_hidden_layers_width: int = 64,
+                 scalar_embed_mlp_nonlinearity: Optional[str] = "silu",
+                 allegro_mlp_hidden_layers_depth: int = 1, allegro_mlp_hidden_layers_width: int = 64,
+                 allegro_mlp_nonlinearity: Optional[str] = "silu", tp_path_channel_coupling: bool = True,
+                 readout_mlp_hidden_layers_depth: int = 1, readout_mlp_hidden_layers_width: int = 32,
+                 readout_mlp_nonlinearity: Optional[str] = "silu", avg_num_neighbors: Optional[float] = None,
+                 weight_individual_irreps: bool = True, per_type_energy_scales=None, per_type_energy_shifts=None,
+                 per_type_energy_scales_trainable: bool = False, per_type_energy_shifts_trainable: bool = False,
+                 pair_potential=None, forward_normalize: bool = True, seed: Optional[int] = None,
+                 model_dtype: str = "float32", compile_mode: Optional[str] = None):
+        super().__init__()
+        assert avg_num_neighbors is not None, "`avg_num_neighbors` must be set for Allegro models"
+        if pair_potential is not None:
+            raise NotImplementedError("pair potentials are outside the hot path (DESIGN.md, out of scope)")
+        if not weight_individual_irreps:
+            raise NotImplementedError("weight_individual_irreps=False is not supported by the HIP path")
+        for nl, depth in ((scalar_embed_mlp_nonlinearity, scalar_embed_mlp_hidden_layers_depth),
+                          (allegro_mlp_nonlinearity, allegro_mlp_hidden_layers_depth),
+                          (readout_mlp_nonlinearity, readout_mlp_hidden_layers_depth)):
+            if depth > 0 and nl != "silu":
+                raise NotImplementedError("only SiLU MLPs are implemented in the HIP path")
+        rce = dict(radial_chemical_embed or {})
+        tgt = rce.pop("_target_", "allegro.nn.TwoBodyBesselScalarEmbed")
+        if not tgt.endswith("TwoBodyBesselScalarEmbed"):
+            raise NotImplementedError(f"radial_chemical_embed {tgt} is outside the hot path (SURVEY.md §2 row 10-11)")
+        if rce.get("bessel_trainable", False):
+            raise NotImplementedError("trainable Bessel roots are a training feature (out of scope)")
+        self.dtype = {"float32": torch.float32, "float64": torch.float64}[model_dtype]
+        self.type_names = list(type_names)
+        T = len(self.type_names)
+        S, u, L = num_scalar_features, num_tensor_features, num_layers
+        S0 = S if radial_chemical_embed_dim is None else radial_chemical_embed_dim
+        B = int(rce.get("num_bessels", 8))
+        self.hparams = dict(r_max=float(r_max), l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
+                            embed_dim=S0, num_bessels=B, poly_p=float(rce.get("polynomial_cutoff_p", 6)),
+                            embed_depth=scalar_embed_mlp_hidden_layers_depth, embed_width=scalar_embed_mlp_hidden_layers_width,
+                            latent_depth=allegro_mlp_hidden_layers_depth, latent_width=allegro_mlp_hidden_layers_width,
+                            readout_depth=readout_mlp_hidden_layers_depth, readout_width=readout_mlp_hidden_layers_width,
+                            coupling=bool(tp_path_channel_coupling), avg_num_neighbors=float(avg_num_neighbors),
+                            forward_normalize=bool(forward_normalize), parity=bool(parity))
+        if seed is not None:
+            torch.manual_seed(seed)
+        dt = self.dtype
+        self.func = _Node()
+        rng_u = lambda *shape: torch.empty(*shape, dtype=dt).uniform_(-math.sqrt(3), math.sqrt(3))  # noqa: E731
+
+        def add(key, tensor, kind):
+            node, leaf = _ensure_path(self.func, key)
+            if kind == "param":
+                node.register_parameter(leaf, torch.nn.Parameter(tensor))
+            else:
+                node.register_buffer(leaf, tensor)
+
+        # edge_norm (nequip EdgeLengthNormalizer): per-type-pair cutoffs
+        rmax = torch.full((T, T), float(r_max), dtype=dt)
+        if per_edge_type_cutoff is not None:
+            for ci, cn in enumerate(self.type_names):
+                if cn not in per_edge_type_cutoff:
+                    continue
+                v = per_edge_type_cutoff[cn]
+                for ni, nn_ in enumerate(self.type_names):
+                    if isinstance(v, dict):
+                        if nn_ in v:
+                            rmax[ci, ni] = float(v[nn_])
+                    else:
+                        rmax[ci, ni] = float(v)
+        add("edge_norm.rmax_recip", 1.0 / rmax, "buffer")
+        add("radial_chemical_embed.bessel_encode.bessel_weights",
+            (torch.linspace(1.0, B, B, dtype=dt) * math.pi).unsqueeze(0), "buffer")
+        add("radial_chemical_embed.type_embed.center_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
+        add("radial_chemical_embed.type_embed.neighbor_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
+        add("radial_chemical_embed.type_embed.basis_linear.mlp.0.weight", rng_u(B, S0), "param")
+
+        def add_mlp(prefix, dims):
+            for i, (a, b) in enumerate(zip(dims, dims[1:])):
+                add(f"{prefix}.{i}.weight", rng_u(a, b), "param")
+
+        R = l_max + 1
+        W = R * u
+        self._embed_dims = [S0] + [scalar_embed_mlp_hidden_layers_width] * scalar_embed_mlp_hidden_layers_depth + [S]
+        add_mlp("scalar_embed_mlp.mlp.mlp", self._embed_dims)
+        add_mlp("tensor_embed.env_embed_linear.mlp", [S, W])
+        add_mlp("allegro.first_layer_env_embed_projection.mlp", [S, S + W])
+        self.tps_irreps = allegro_layer_irreps(l_max, parity, L)
+        env = o3.Irreps.spherical_harmonics(l_max, p=-1)
+        self._tp_meta = []
+        for l in range(L):
+            lat_dims = [S * (l + 1) + u] + [allegro_mlp_hidden_layers_width] * allegro_mlp_hidden_layers_depth + \
+                       [S + (W if l < L - 1 else 0)]
+            add_mlp(f"allegro.latents.{l}.mlp", lat_dims)
+        for l in range(L):
+            w3j, instr, diag, dims = build_w3j(self.tps_irreps[l], env, self.tps_irreps[l + 1])
+            P = len(instr)
+            shape = ((u,) if tp_path_channel_coupling else tuple()) + ((P,) if P > 1 else tuple())
+            add(f"allegro.tps.{l}.weights", rng_u(*shape) if len(shape) else rng_u(1).reshape(()), "param")
+            add(f"allegro.tps.{l}.w3j", torch.tensor(w3j, dtype=dt), "buffer")
+            self._tp_meta.append(dict(num_paths=P, diag=diag, dims=dims))
+        ro_dims = [S * (L + 1)] + [readout_mlp_hidden_layers_width] * readout_mlp_hidden_layers_depth + [1]
+        add_mlp("edge_readout.mlp.mlp", ro_dims)
+
+        def per_type(v):
+            if v is None:
+                return None
+            if isinstance(v, dict):
+                v = [v[t] for t in self.type_names]
+            t = torch.as_tensor(v, dtype=dt).reshape(-1)
+            return t.expand(T).clone() if t.numel() == 1 else t
+
+        sc, sh = per_type(per_type_energy_scales), per_type(per_type_energy_shifts)
+        self.has_scales, self.has_shifts = sc is not None, sh is not None
+        if sc is not None:
+            add("per_type_energy_scale_shift.scales", sc, "param")
+        if sh is not None:
+            add("per_type_energy_scale_shift.shifts", sh, "param")
+        for p in self.parameters():
+            p.requires_grad_(False)  # inference/force path: no weight gradients (like _flashallegro.py:660)
+        self._bound_lib: Optional[_lib.AllegroLib] = None
+        self._plan_handle = None
+        self._plan_keep = None
+        self._blob: Optional[torch.Tensor] = None
+        self._blob_key = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._graph_cache: Tuple[Optional[tuple], Optional[PreparedGraph]] = (None, None)
+
+    # -- library / plan -------------------------------------------------------------------------
+    def _get_lib(self) -> _lib.AllegroLib:
+        return self._bound_lib if self._bound_lib is not None else _lib.load()
+
+    def _bind_library(self, lib: _lib.AllegroLib):
+        """(tests) bind an explicitly loaded library instead of the default gfx950 one."""
+        self._bound_lib = lib
+        self._plan_handle = None
+        self._blob = None
+
+    def _sd(self) -> Dict[str, torch.Tensor]:
+        return {k[len("func."):]: v for k, v in self.state_dict().items()}
+
+    def _ensure_plan(self):
+        if self._plan_handle is not None:
+            return
+        hp = self.hparams
+        cfg = _lib.ModelConfig()
+        cfg.dtype = _TORCH2AA[self.dtype]
+        cfg.num_types = len(self.type_names)
+        cfg.num_bessels, cfg.poly_p = hp["num_bessels"], hp["poly_p"]
+        cfg.l_max, cfg.num_layers = hp["l_max"], hp["num_layers"]
+        cfg.num_scalar, cfg.num_tensor, cfg.embed_dim = hp["num_scalar_features"], hp["num_tensor_features"], hp["embed_dim"]
+        cfg.embed_mlp_depth, cfg.embed_mlp_width = hp["embed_depth"], hp["embed_width"]
+        cfg.latent_mlp_depth, cfg.latent_mlp_width = hp["latent_depth"], hp["latent_width"]
+        cfg.readout_mlp_depth, cfg.readout_mlp_width = hp["readout_depth"], hp["readout_width"]
+        cfg.forward_weight_init = int(hp["forward_normalize"])
+        cfg.avg_num_neighbors = hp["avg_num_neighbors"]
+        cfg.act_const = silu_second_moment_const()
+        cfg.has_scales, cfg.has_shifts = int(self.has_scales), int(self.has_shifts)
+        keep = []
+        sd = self._sd()
+        for l in range(hp["num_layers"]):
+            m = self._tp_meta[l]
+            desc, k = w3j_to_desc(sd[f"allegro.tps.{l}.w3j"], hp["num_tensor_features"], m["dims"], m["num_paths"],
+                                  m["diag"], hp["coupling"])
+            cfg.tps[l] = desc
+            keep.append(k)
+        self._plan_handle = self._get_lib().model_plan_create(cfg)
+        self._plan_keep = (cfg, keep)
+
+    def _ensure_weights(self, device):
+        key = (str(device), tuple(int(p._version) for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
+        if self._blob is not None and self._blob_key == key:
+            return
+        lib = self._get_lib()
+        hp = self.hparams
+        sd = {k: v.detach().to("cpu", torch.float64).contiguous() for k, v in self._sd().items()}
+        keep = []
+
+        def ptr(t):
+            a = np.ascontiguousarray(t.numpy().reshape(-1))
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+
+        raw = _lib.RawWeights()
+        T = len(self.type_names)
+        rr = sd["edge_norm.rmax_recip"]
+        raw.rmax_recip = ptr(rr.expand(T, T).contiguous() if rr.numel() == 1 else rr)
+        raw.bessel_weights = ptr(sd["radial_chemical_embed.bessel_encode.bessel_weights"])
+        raw.center_embed = ptr(sd["radial_chemical_embed.type_embed.center_embed.weight"])
+        raw.neighbor_embed = ptr(sd["radial_chemical_embed.type_embed.neighbor_embed.weight"])
+        raw.basis_linear = ptr(sd["radial_chemical_embed.type_embed.basis_linear.mlp.0.weight"])
+        for i in range(hp["embed_depth"] + 1):
+            raw.embed_mlp[i] = ptr(sd[f"scalar_embed_mlp.mlp.mlp.{i}.weight"])
+        raw.env_embed_linear = ptr(sd["tensor_embed.env_embed_linear.mlp.0.weight"])
+        raw.first_proj = ptr(sd["allegro.first_layer_env_embed_projection.mlp.0.weight"])
+        for l in range(hp["num_layers"]):
+            for i in range(hp["latent_depth"] + 1):
+                raw.latent[l][i] = ptr(sd[f"allegro.latents.{l}.mlp.{i}.weight"])
+            raw.tp_weights[l] = ptr(sd[f"allegro.tps.{l}.weights"])
+        for i in range(hp["readout_depth"] + 1):
+            raw.readout[i] = ptr(sd[f"edge_readout.mlp.mlp.{i}.weight"])
+        if self.has_scales:
+            raw.scales = ptr(sd["per_type_energy_scale_shift.scales"])
+        if self.has_shifts:
+            raw.shifts = ptr(sd["per_type_energy_scale_shift.shifts"])
+        nbytes = lib.lib.aa_model_weights_bytes(self._plan_handle)
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        lib.check(lib.lib.aa_model_pack_weights(self._plan_handle, C.byref(raw), blob.data_ptr(), nbytes, stream),
+                  "aa_model_pack_weights")
+        self._blob, self._blob_key = blob, key
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        # w3j buffers may have changed: rebuild device tables lazily
+        if self._plan_handle is not None:
+            self._get_lib().model_plan_destroy(self._plan_handle)
+            self._plan_handle = None
+        self._blob = None
+        return out
+
+    # -- evaluation -----------------------------------------------------------------------------
+    def prepare_graph(self, edge_index, atom_types, num_atoms, shift_vec=None) -> PreparedGraph:
+        return PreparedGraph(edge_index, atom_types, num_atoms, shift_vec)
+
+    def energy_forces(self, pos: torch.Tensor, graph: PreparedGraph, with_forces: bool = True):
+        """One pass of the hot path: returns (atom_energy [N], forces [N,3] | None)."""
+        lib = self._get_lib()
+        _require_gpu(lib, pos, "HipAllegroModel")
+        assert pos.dtype == self.dtype, f"positions must be {self.dtype}"
+        self._ensure_plan()
+        self._ensure_weights(pos.device)
+        N, E = graph.num_atoms, graph.num_edges
+        need = lib.lib.aa_model_workspace_bytes(self._plan_handle, N, E, int(with_forces))
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != pos.device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=pos.device)
+        pos = pos.detach().contiguous()
+        e_atom = torch.empty(N, dtype=self.dtype, device=pos.device)
+        forces = torch.empty((N, 3), dtype=self.dtype, device=pos.device) if with_forces else None
+        g = graph.c_struct()
+        lib.check(lib.lib.aa_model_energy_forces(self._plan_handle, self._blob.data_ptr(), C.byref(g), pos.data_ptr(),
+                                                 self._workspace.data_ptr(), self._workspace.numel(), e_atom.data_ptr(),
+                                                 forces.data_ptr() if with_forces else None, _stream_ptr(pos)),
+                  "aa_model_energy_forces")
+        return e_atom, forces
+
+    def debug_tap(self, name: str, graph: PreparedGraph) -> torch.Tensor:
+        lib = self._get_lib()
+        ptr, ld = C.c_void_p(), C.c_int64()
+        rc = lib.lib.aa_model_debug_tap(self._plan_handle, name.encode(), graph.num_atoms, graph.num_edges,
+                                        self._workspace.data_ptr(), C.byref(ptr), C.byref(ld))
+        if rc < 0:
+            lib.check(rc, "aa_model_debug_tap")
+        off = (ptr.value - self._workspace.data_ptr()) // self._workspace.element_size()
+        esz = 4 if self.dtype == torch.float32 else 8
+        flat = self._workspace[off: off + graph.num_edges * ld.value * esz].view(self.dtype)
+        return flat.view(graph.num_edges, ld.value).clone()
+
+    def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """AtomicDataDict in, AtomicDataDict out (keys: pos, edge_index, atom_types [, cell, edge_cell_shift, batch])."""
+        pos = data["pos"]
+        ei = data["edge_index"]
+        key = (ei.data_ptr(), tuple(ei.shape), int(ei._version), pos.shape[0])
+        if self._graph_cache[0] != key:
+            shift_vec = None
+            if "edge_cell_shift" in data and "cell" in data:
+                shift_vec = (data["edge_cell_shift"].to(self.dtype) @ data["cell"].view(3, 3).to(self.dtype))
+            self._graph_cache = (key, PreparedGraph(ei, data["atom_types"], pos.shape[0], shift_vec))
+        graph = self._graph_cache[1]
+        e_atom, forces = self.energy_forces(pos.to(self.dtype), graph, with_forces=True)
+        out = dict(data)
+        out["atomic_energy"] = e_atom.unsqueeze(-1)
+        if "batch" in data:
+            nf = int(data["batch"].max()) + 1
+            out["total_energy"] = torch.zeros(nf, 1, dtype=self.dtype, device=pos.device).index_add_(0, data["batch"], e_atom.unsqueeze(-1))
+        else:
+            out["total_energy"] = e_atom.sum().reshape(1, 1)
+        out["forces"] = forces
+        return out
+
+    def __del__(self):
+        try:
+            if self._plan_handle is not None:
+                self._get_lib().model_plan_destroy(self._plan_handle)
+        except Exception:
+            pass

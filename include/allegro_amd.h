@@ -1,0 +1,164 @@
+/* allegro_amd.h -- C ABI of the MI355X (gfx950) Allegro hot path.
+ *
+ * Boundary rules: plain pointers and sizes only (no torch types); every tensor
+ * buffer -- inputs, outputs, workspace, packed weights -- is owned by the CALLER and lives in
+ * device memory (HBM); the library allocates only the small immutable CG tables owned by a plan
+ * handle; all work is enqueued on the caller's hipStream_t; functions return 0 on success and a
+ * negative code otherwise (never throw); aa_last_error() gives the message for the calling thread.
+ *
+ * The reference (mir-group/allegro) has NO native interface; its accelerator seams are Python
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it stands behind.
+ */
+#ifndef ALLEGRO_AMD_H
+#define ALLEGRO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* aa_stream; /* hipStream_t */
+
+typedef enum { AA_F32 = 0, AA_F64 = 1 } aa_dtype;
+
+enum {
+  AA_OK = 0,
+  AA_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+  AA_ERR_WORKSPACE = -2, /* caller workspace too small */
+  AA_ERR_HIP = -3        /* a HIP runtime call failed */
+};
+
+#define AA_MAX_LAYERS 4
+#define AA_MAX_MLP_LAYERS 4
+
+const char* aa_last_error(void);
+int aa_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Tensor-product operator  (seam B1/B2)
+ *    replaces allegro/nn/_strided/_contract.py:185-251 (Contracter.forward / ._contract); the
+ *    descriptor carries what Contracter.__init__ builds at :53-177.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t mul;            /* u: strided channel count                     (_contract.py:75)   */
+  int32_t d1, d2, dout;   /* base dims of in1, in2, out                   (_contract.py:72-74)*/
+  int32_t num_paths;      /* p                                            (_contract.py:76)   */
+  int32_t coupling;       /* 1: weights [u,p] ("uuup"), 0: weights [p]    (_contract.py:172)  */
+  int32_t nnz;            /* non-zeros of the (norm-folded) w3j buffer    (_contract.py:95-119)*/
+  const int32_t* nz_i;    /* [nnz] index into in1  (for ij-diagonal w3j: j == i)               */
+  const int32_t* nz_j;    /* [nnz] index into in2                                              */
+  const int32_t* nz_k;    /* [nnz] index into out                                              */
+  const int32_t* nz_path; /* [nnz] path of the entry                                           */
+  const double* nz_val;   /* [nnz] w3j value (already x sqrt(2 l_out+1), _contract.py:110,115) */
+} aa_tp_desc;
+
+typedef struct aa_tp_plan aa_tp_plan;
+
+/* host arrays in `desc` are copied; tables are uploaded to the current device */
+int aa_tp_plan_create(const aa_tp_desc* desc, aa_dtype dtype, aa_tp_plan** out);
+void aa_tp_plan_destroy(aa_tp_plan* plan);
+
+/* Contracter.forward (_contract.py:185-211) on a center-sorted segment layout:
+ *   x2s[n] = scatter_factor * sum_{s in [rowptr[n],rowptr[n+1])} x2[eid(s)]   (:195-204)
+ *   out[e] = contract(x1[e], x2s[center(e)])                                  (:205-211)
+ * eids (nullable): sorted position -> edge id, for callers whose `idxs` are not sorted
+ * (tests/nn/test_contract_kernels.py:95-97).  x1:[E,u,d1] x2:[E,u,d2] out:[E,u,dout],
+ * weights: [u,p] or [p] (device), x2s: [N,u,d2] caller buffer (kept for the backward). */
+int aa_tp_forward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2,
+                  const void* weights, const int32_t* rowptr, const int32_t* eids,
+                  double scatter_factor, void* x2s, void* out, aa_stream stream);
+
+/* input gradients of the above (the reference's accelerated path also returns no weight grad,
+ * _flashallegro.py:660): gx1:[E,u,d1], gx2:[E,u,d2]. */
+int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,
+                   const void* weights, const int32_t* rowptr, const int32_t* eids,
+                   double scatter_factor, const void* gout, void* gx1, void* gx2, aa_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Whole hot path: forward + forces  (seam B3 + ForceStressOutput)
+ *    replaces the module chain of allegro/model/allegro_models.py:222-297 wrapped by
+ *    ForceStressOutput (:101-103): two-body embedding -> SH tensor embed (tensorembed.py:85-96)
+ *    -> Allegro_Module.forward (_allegro.py:237-301) -> edge readout -> EdgewiseReduce
+ *    (edgewise.py:40-60) -> per-type scale/shift, and its reverse pass w.r.t. positions.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t dtype;           /* aa_dtype                                                        */
+  int32_t num_types;
+  int32_t num_bessels;     /* scalarembed.py:22                                               */
+  double poly_p;           /* polynomial cutoff exponent, scalarembed.py:24                   */
+  int32_t l_max;           /* 1..3                                                            */
+  int32_t num_layers;      /* L, _allegro.py:24                                               */
+  int32_t num_scalar;      /* S, _allegro.py:25                                               */
+  int32_t num_tensor;      /* u, _allegro.py:26                                               */
+  int32_t embed_dim;       /* S0 = radial_chemical_embed_dim, allegro_models.py:160-164        */
+  int32_t embed_mlp_depth, embed_mlp_width;     /* allegro_models.py:175-176                  */
+  int32_t latent_mlp_depth, latent_mlp_width;   /* allegro_models.py:205-206                  */
+  int32_t readout_mlp_depth, readout_mlp_width; /* allegro_models.py:233-234                  */
+  int32_t forward_weight_init;                  /* allegro_models.py:146                      */
+  double avg_num_neighbors;                     /* _allegro.py:182; allegro_models.py:245     */
+  double act_const;        /* normalize2mom constant of SiLU used by ScalarMLPFunction        */
+  int32_t has_scales, has_shifts;               /* allegro_models.py:251-260                  */
+  aa_tp_desc tps[AA_MAX_LAYERS];                /* one per layer, _allegro.py:172-183         */
+} aa_model_config;
+
+/* Raw parameters in the reference's own state_dict layout, HOST memory, float64.
+ * MLP weights are [in,out] row-major, one pointer per linear layer. */
+typedef struct {
+  const double* rmax_recip;      /* [T,T]   edge_norm.rmax_recip                              */
+  const double* bessel_weights;  /* [B]     radial_chemical_embed.bessel_encode.bessel_weights*/
+  const double* center_embed;    /* [T,S0/2] ...type_embed.center_embed.weight               */
+  const double* neighbor_embed;  /* [T,S0/2] ...type_embed.neighbor_embed.weight             */
+  const double* basis_linear;    /* [B,S0]  ...type_embed.basis_linear.mlp.0.weight          */
+  const double* embed_mlp[AA_MAX_MLP_LAYERS];   /* scalar_embed_mlp.mlp.mlp.{i}.weight        */
+  const double* env_embed_linear;               /* [S,W] tensor_embed.env_embed_linear        */
+  const double* first_proj;                     /* [S,S+W] allegro.first_layer_env_embed_projection */
+  const double* latent[AA_MAX_LAYERS][AA_MAX_MLP_LAYERS]; /* allegro.latents.{l}.mlp.{i}.weight */
+  const double* tp_weights[AA_MAX_LAYERS];      /* allegro.tps.{l}.weights                    */
+  const double* readout[AA_MAX_MLP_LAYERS];     /* edge_readout.mlp.mlp.{i}.weight            */
+  const double* scales;          /* [T] or NULL                                               */
+  const double* shifts;          /* [T] or NULL                                               */
+} aa_model_raw_weights;
+
+typedef struct {
+  int64_t num_atoms;       /* N (real + ghost rows of pos)                                     */
+  int64_t num_edges;       /* E directed edges, sorted by center                               */
+  const int32_t* center;   /* [E] edge_index[0]                                                */
+  const int32_t* nbr;      /* [E] edge_index[1]                                                */
+  const int32_t* rowptr;   /* [N+1] CSR over centers                                           */
+  const int32_t* types;    /* [N]                                                              */
+  const void* shift_vec;   /* [E,3] cartesian periodic shift (model dtype) or NULL (ghost layout,
+                              allegro/_compile.py:28-63)                                       */
+} aa_graph;
+
+typedef struct aa_model_plan aa_model_plan;
+
+int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);
+void aa_model_plan_destroy(aa_model_plan* plan);
+
+/* size of the packed device weight blob, and packing (host fp64 -> device model dtype, with the
+ * ScalarMLPFunction normalisation constants folded and the two linear maps of the first stage
+ * fused); call again whenever the parameters change */
+size_t aa_model_weights_bytes(const aa_model_plan* plan);
+int aa_model_pack_weights(const aa_model_plan* plan, const aa_model_raw_weights* raw, void* dev_blob,
+                          size_t blob_bytes, aa_stream stream);
+
+size_t aa_model_workspace_bytes(const aa_model_plan* plan, int64_t num_atoms, int64_t num_edges,
+                                int with_forces);
+
+/* atom_energy: [N] (model dtype); forces: [N,3] or NULL (energy only).  forces are written
+ * (not accumulated); ghost rows receive their own contributions (LAMMPS reverse-communicates). */
+int aa_model_energy_forces(const aa_model_plan* plan, const void* dev_weights, const aa_graph* graph,
+                           const void* pos, void* workspace, size_t workspace_bytes,
+                           void* atom_energy, void* forces, aa_stream stream);
+
+/* debug/parity taps: copy an intermediate of the LAST call out of the workspace layout.
+ * name in {"edge_attrs","edge_embedding","edge_features"}; returns elements per edge or <0 */
+int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t num_atoms, int64_t num_edges,
+                       const void* workspace, const void** ptr, int64_t* ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALLEGRO_AMD_H */

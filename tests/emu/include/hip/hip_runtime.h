@@ -1,0 +1,143 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny CPU emulation of the HIP execution model.
+//
+// Purpose: compile the UNMODIFIED product kernels (allegro_amd/csrc/*.hip) for the host so that
+// indexing / table / segment / MFMA-fragment logic can be exercised by `pytest -m "not gpu"` in a
+// container without a GPU.  It is NOT a product path: allegro_amd/_lib.py only ever loads the
+// gfx950 library and fails loudly without it; this header is found only when tests/emu/build_emu.py
+// puts tests/emu/include first on the include path.
+//
+// Model: one block at a time; every GPU thread is a ucontext fiber; __syncthreads() and the
+// wave-level exchanges (__shfl*, MFMA) are rendezvous points among the fibers of a block / wave.
+// MFMA fragment layouts follow /opt/skills/guides/cdna_hip_programming.md §3:
+//   v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], C/D col=l&31,
+//   row=(r&3)+8*(r>>2)+4*(l>>5).
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu {
+  unsigned x, y, z;
+};
+extern uint3_emu threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+extern unsigned char aa_smem[];  // the single dynamic-LDS symbol used by all kernels
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+
+namespace emu {
+constexpr int WAVE = 64;
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  int wait_kind = 0;  // 0 running, 1 block barrier, 2 wave rendezvous
+};
+struct State {
+  ucontext_t sched;
+  std::vector<Fiber> fibers;
+  int cur = -1;
+  int nthreads = 0;
+  std::function<void()> body;
+  // wave exchange scratch: per wave, per lane, up to 3 x 8 bytes
+  std::vector<double> xchg;  // [nwaves][WAVE][4]
+};
+State& st();
+void yield_block_barrier();
+void wave_rendezvous();
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+inline int lane() { return st().cur % WAVE; }
+inline int wave() { return st().cur / WAVE; }
+inline double* slot(int w, int l) { return &st().xchg[(size_t(w) * WAVE + l) * 4]; }
+}  // namespace emu
+
+#define hipLaunchKernelGGL(kern, grid, block, smem, stream, ...) \
+  emu::launch(dim3(grid), dim3(block), (smem), [=]() { kern(__VA_ARGS__); })
+
+inline void __syncthreads() { emu::yield_block_barrier(); }
+
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+  static_assert(sizeof(T) <= 8, "shfl payload");
+  int l = emu::lane(), w = emu::wave();
+  memcpy(emu::slot(w, l), &v, sizeof(T));
+  emu::wave_rendezvous();
+  int base = (l / width) * width;
+  T r;
+  memcpy(&r, emu::slot(w, base + (src % width)), sizeof(T));
+  emu::wave_rendezvous();
+  return r;
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+  int l = emu::lane();
+  return __shfl(v, (l ^ mask) % width + 0 * width, width);
+}
+template <typename T>
+inline T __shfl_down(T v, int delta, int width = 64) {
+  int l = emu::lane() % width;
+  int src = l + delta < width ? l + delta : l;
+  return __shfl(v, src, width);
+}
+
+typedef float emu_v16f __attribute__((ext_vector_type(16)));
+inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_v16f c, int, int, int) {
+  int l = emu::lane(), w = emu::wave();
+  float ab[2] = {a, b};
+  memcpy(emu::slot(w, l), ab, sizeof(ab));
+  emu::wave_rendezvous();
+  emu_v16f d = c;
+  int j = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) {
+      float av[2], bv[2];
+      memcpy(av, emu::slot(w, i + 32 * k), sizeof(av));  // lane holding A[i][k]
+      memcpy(bv, emu::slot(w, j + 32 * k), sizeof(bv));  // lane holding B[k][j]
+      acc = std::fmaf(av[0], bv[1], acc);
+    }
+    d[r] = acc;
+  }
+  emu::wave_rendezvous();
+  return d;
+}
+
+inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
