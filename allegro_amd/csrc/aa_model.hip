@@ -366,6 +366,25 @@ namespace {
 
 inline Seg seg(void* p, int ld, int n) { return Seg{p, ld, n}; }
 
+// optional per-stage timing with HIP events recorded on the launch stream
+struct StageProfile {
+  std::vector<std::string> names;
+  std::vector<hipEvent_t> events;
+  int mark(const char* name, hipStream_t s) {
+    hipEvent_t e;
+    AA_CHECK_HIP(hipEventCreate(&e));
+    AA_CHECK_HIP(hipEventRecord(e, s));
+    names.emplace_back(name);
+    events.push_back(e);
+    return AA_OK;
+  }
+  void clear() {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    events.clear();
+    names.clear();
+  }
+};
+
 template <typename T>
 struct Runner {
   const aa_model_plan* p;
@@ -374,6 +393,9 @@ struct Runner {
   Workspace w;
   int64_t E, N;
   hipStream_t stream;
+  StageProfile* prof = nullptr;
+
+  int mark(const char* name) { return prof ? prof->mark(name, stream) : AA_OK; }
 
   T* buf(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   const T* wt(size_t off) const { return wts + off; }
@@ -390,7 +412,11 @@ struct Runner {
     g.has_z = z ? 1 : 0;
     if (z) g.z = *z;
     g.act_a = act_a;
-    return launch_gemm<T>(g, stream);
+    if (int rc = launch_gemm<T>(g, stream)) return rc;
+    if (!prof) return AA_OK;
+    char nm[32];
+    snprintf(nm, sizeof(nm), "gemm_%dx%d", K, Nn);
+    return mark(nm);
   }
 
   // forward of a ScalarMLPFunction: hidden pre-activations to h[i]; final linear output to `out`
@@ -500,7 +526,9 @@ struct Runner {
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
     // 1-2: geometry, SH, radial-chemical embedding
+    if (int rc = mark("begin")) return rc;
     if (int rc = launch_edge_prologue<T>(geom(g, pos), stream)) return rc;
+    if (int rc = mark("edge_prologue")) return rc;
     // 3: scalar_embed_mlp
     {
       SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
@@ -532,6 +560,7 @@ struct Runner {
       a.scal = buf(w.scal[l]);
       a.ld_scal = u;
       if (int rc = launch_tp_layer_fwd<T>(p->layers[l], a, stream)) return rc;
+      if (int rc = mark("tp_layer_fwd")) return rc;
       SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
       SegList out;
       out.count = l < L - 1 ? 2 : 1;
@@ -549,7 +578,8 @@ struct Runner {
         a = cs;
       }
     }
-    return launch_readout_reduce<T>(readout_args(g, atom_energy), stream);
+    if (int rc = launch_readout_reduce<T>(readout_args(g, atom_energy), stream)) return rc;
+    return mark("readout_reduce");
   }
 
   int backward(const aa_graph* g, const void* pos, void* forces) {
@@ -557,12 +587,14 @@ struct Runner {
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
     AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * sizeof(T), stream));
     AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
+    if (int rc = mark("memset")) return rc;
     // readout
     {
       ReadoutArgs r = readout_args(g, nullptr);
       if (c.readout_mlp_depth > 0) {
         r.g_h = buf(w.g_ro_h[c.readout_mlp_depth - 1]);
         if (int rc = launch_readout_backward<T>(r, stream)) return rc;
+        if (int rc = mark("readout_backward")) return rc;
         SegList a{1, {seg(r.g_h, c.readout_mlp_width, c.readout_mlp_width)}};
         for (int i = c.readout_mlp_depth - 1; i >= 0; --i) {
           SegList cs, z;
@@ -581,6 +613,7 @@ struct Runner {
       } else {
         r.g_h = buf(w.g_fcat);
         if (int rc = launch_readout_backward<T>(r, stream)) return rc;
+        if (int rc = mark("readout_backward")) return rc;
       }
     }
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
@@ -622,6 +655,7 @@ struct Runner {
       a.g2.gsh = buf(w.g_sh);
       a.g2.ld_gsh = p->D;
       if (int rc = launch_tp_layer_bwd<T>(p->layers[l], a, stream)) return rc;
+      if (int rc = mark("tp_layer_bwd")) return rc;
     }
     // fused first stage reverse
     {
@@ -640,14 +674,16 @@ struct Runner {
     eb.g_emb0 = buf(w.g_emb0);
     eb.g_sh = buf(w.g_sh);
     eb.forces = forces;
-    return launch_edge_backward<T>(eb, stream);
+    if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
+    return mark("edge_backward");
   }
 };
 
 template <typename T>
 int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g, const void* pos, void* workspace,
-              size_t ws_bytes, void* atom_energy, void* forces, hipStream_t stream) {
+              size_t ws_bytes, void* atom_energy, void* forces, hipStream_t stream, StageProfile* prof = nullptr) {
   Runner<T> r;
+  r.prof = prof;
   r.p = p;
   r.wts = static_cast<const T*>(dev_weights);
   r.ws = static_cast<char*>(workspace);
@@ -675,6 +711,36 @@ extern "C" int aa_model_energy_forces(const aa_model_plan* plan, const void* dev
   if (plan->cfg.dtype == AA_F32)
     return run_model<float>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s);
   return run_model<double>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s);
+}
+
+extern "C" int aa_model_energy_forces_profiled(const aa_model_plan* plan, const void* dev_weights, const aa_graph* graph,
+                                               const void* pos, void* workspace, size_t workspace_bytes,
+                                               void* atom_energy, void* forces, aa_stream stream, int max_stages,
+                                               float* stage_ms, char* stage_names /* [max_stages][32] */,
+                                               int* num_stages) {
+  AA_REQUIRE(plan && dev_weights && graph && pos && atom_energy && stage_ms && stage_names && num_stages,
+             "aa_model_energy_forces_profiled: null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  StageProfile prof;
+  int rc = plan->cfg.dtype == AA_F32
+               ? run_model<float>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s, &prof)
+               : run_model<double>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s, &prof);
+  if (rc == AA_OK) {
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = fail(AA_ERR_HIP, "profile: stream sync failed");
+  }
+  int n = 0;
+  if (rc == AA_OK) {
+    for (size_t i = 1; i < prof.events.size() && n < max_stages; ++i, ++n) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, prof.events[i - 1], prof.events[i]);
+      stage_ms[n] = ms;
+      snprintf(stage_names + 32 * n, 32, "%s", prof.names[i].c_str());
+    }
+  }
+  *num_stages = n;
+  prof.clear();
+  return rc;
 }
 
 extern "C" int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t N, int64_t E, const void* workspace,

@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""Benchmark of the Allegro hot path (forward + forces) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|c5]
+
+A "step" is one pass of the hot path (energies + forces of every atom) over one synthetic periodic
+box held resident in HBM; the neighbor list / CSR build is outside the timed region.
+Metric (BASELINE.json): edge tensor-products/s = E * L / t_step; ns/day = 0.0864 / t_step[s] at 1 fs.
+Default workload: C4, the 10^5-atom bulk-Si box of the metric (97 336 atoms, 2 725 408 directed edges,
+l_max=2, 2 layers, 64 features, fp32).  With --gpus N > 1 the SAME box is atom-block decomposed over N
+ranks (strong scaling) with one RCCL all-reduce of the force array per step.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from allegro_amd import graph as G  # noqa: E402
+from allegro_amd.dist import partition_atoms  # noqa: E402
+from allegro_amd.nn import HipAllegroModel, PreparedGraph  # noqa: E402
+
+BESSEL = {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8, "polynomial_cutoff_p": 6}
+PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_F64_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+
+
+def si_model_cfg(avg_nn=28.0):
+    return dict(type_names=["Si"], r_max=5.0, l_max=2, parity=True, num_layers=2, num_scalar_features=64,
+                num_tensor_features=64, radial_chemical_embed=dict(BESSEL), radial_chemical_embed_dim=64,
+                scalar_embed_mlp_hidden_layers_depth=1, scalar_embed_mlp_hidden_layers_width=64,
+                allegro_mlp_hidden_layers_depth=1, allegro_mlp_hidden_layers_width=64,
+                readout_mlp_hidden_layers_depth=1, readout_mlp_hidden_layers_width=64, avg_num_neighbors=avg_nn,
+                tp_path_channel_coupling=True, seed=456)
+
+
+def water_model_cfg(avg_nn):
+    return dict(type_names=["O", "H"], r_max=5.0, l_max=3, parity=True, num_layers=3, num_scalar_features=128,
+                num_tensor_features=128, radial_chemical_embed=dict(BESSEL), radial_chemical_embed_dim=128,
+                scalar_embed_mlp_hidden_layers_depth=1, scalar_embed_mlp_hidden_layers_width=128,
+                allegro_mlp_hidden_layers_depth=1, allegro_mlp_hidden_layers_width=128,
+                readout_mlp_hidden_layers_depth=1, readout_mlp_hidden_layers_width=128, avg_num_neighbors=avg_nn,
+                tp_path_channel_coupling=True, seed=456)
+
+
+WORKLOADS = {
+    "c2": dict(kind="si", cells=2, dtype="float32", desc="Si 2^3 cells (64 atoms), l_max=2, L=2, u=64"),
+    "c3": dict(kind="si", cells=11, dtype="float32", desc="bulk Si 11^3 cells (10 648 atoms), r_cut 5 A, l_max=2, L=2, u=64"),
+    "c4": dict(kind="si", cells=23, dtype="float32", desc="bulk Si 23^3 cells (97 336 atoms), r_cut 5 A, l_max=2, L=2, u=64"),
+    "c5": dict(kind="water", side=22, box=66.9 * 22 / 21.544, dtype="float64",
+               desc="water box (~3x10^4 atoms, 2 species), r_cut 5 A, l_max=3, L=3, u=128, fp64"),
+}
+
+
+def make_workload(name):
+    w = WORKLOADS[name]
+    if w["kind"] == "si":
+        g = G.make_si_graph(w["cells"])
+        cfg = si_model_cfg(g.num_edges / g.num_atoms)
+    else:
+        g = G.make_water_graph(w["side"], w["box"])
+        cfg = water_model_cfg(g.num_edges / g.num_atoms)
+    cfg["model_dtype"] = w["dtype"]
+    return g, cfg
+
+
+def gemm_sequence_flops(stage_names, E):
+    """flops of every 'gemm_KxN' stage: 2*E*K*N."""
+    out = []
+    for n in stage_names:
+        if n.startswith("gemm_"):
+            k, nn = n[5:].split("x")
+            out.append(2.0 * E * int(k) * int(nn))
+        else:
+            out.append(0.0)
+    return out
+
+
+def profile_stages(model, pos, graph):
+    lib = model._get_lib()
+    model.energy_forces(pos, graph)  # make sure plan/weights/workspace exist
+    max_stages = 128
+    ms = (C.c_float * max_stages)()
+    names = C.create_string_buffer(32 * max_stages)
+    n = C.c_int(0)
+    e_atom = torch.empty(graph.num_atoms, dtype=model.dtype, device=pos.device)
+    forces = torch.empty((graph.num_atoms, 3), dtype=model.dtype, device=pos.device)
+    g = graph.c_struct()
+    fn = lib.lib.aa_model_energy_forces_profiled
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    acc = {}
+    reps = 5
+    for _ in range(reps):
+        rc = fn(model._plan_handle, model._blob.data_ptr(), C.byref(g), pos.data_ptr(), model._workspace.data_ptr(),
+                model._workspace.numel(), e_atom.data_ptr(), forces.data_ptr(),
+                torch.cuda.current_stream(pos.device).cuda_stream, max_stages, ms, names, C.byref(n))
+        lib.check(rc, "aa_model_energy_forces_profiled")
+        for i in range(n.value):
+            nm = names.raw[32 * i: 32 * i + 32].split(b"\0")[0].decode()
+            acc.setdefault(i, [nm, 0.0])[1] += ms[i] / reps
+    return [(v[0], v[1]) for _, v in sorted(acc.items())]
+
+
+def roofline_from_stages(stages, E, N, cfg, dtype):
+    """Aggregate per kernel symbol; report the dominant one against its roofline.
+    Algorithmic work per launch: GEMM 2*K*N flop/edge; TP layers: bytes of their operands."""
+    u, S, L, l_max = cfg["num_tensor_features"], cfg["num_scalar_features"], cfg["num_layers"], cfg["l_max"]
+    es = 4 if dtype == "float32" else 8
+    D, W = (l_max + 1) ** 2, (l_max + 1) * u
+    by_sym = {}
+    for name, ms in stages:
+        sym = "gemm" if name.startswith("gemm_") else name
+        d = by_sym.setdefault(sym, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+        d["ms"] += ms
+        d["launches"] += 1
+        if sym == "gemm":
+            k, n = (int(x) for x in name[5:].split("x"))
+            d["flops"] += 2.0 * E * k * n
+            d["bytes"] += es * (E * (k + n) + k * n)
+        elif sym == "tp_layer_fwd":
+            # reads x1 (implicit: w [E,W] | dense [E,u,D]), env weights [E,W], sh; writes out [E,u,D] + scalars
+            d["bytes"] += es * E * (W + W + D + u * D + u)
+        elif sym == "tp_layer_bwd":
+            d["bytes"] += es * E * (2 * W + D + 2 * u * D + u + 2 * W + D)
+    dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+    sym, d = dom
+    t = d["ms"] * 1e-3 / max(d["launches"], 1)
+    if sym == "gemm":
+        peak = PEAK_F32_TFLOPS if dtype == "float32" else PEAK_F64_TFLOPS
+        ach = d["flops"] / max(d["launches"], 1) / t / 1e12
+        roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None)
+    else:
+        ach = d["bytes"] / max(d["launches"], 1) / t / 1e9
+        roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None)
+    roof["kernel"] = sym
+    roof["avg_launch_ms"] = d["ms"] / max(d["launches"], 1)
+    roof["launches_per_step"] = d["launches"]
+    table = {k: dict(ms=round(v["ms"], 4), launches=v["launches"]) for k, v in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])}
+    return roof, table
+
+
+def cpu_baseline(g: G.Graph, cfg, model, target_edges=12000, reps=3):
+    """The oracle restatement (a port: kind='port') timed on this host's cores on a bounded sample:
+    the first contiguous block of center atoms holding ~target_edges edges (exact by strict locality)."""
+    from oracle import restatement as R
+
+    dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k[len("func."):]: v.detach().cpu() for k, v in model.state_dict().items()}
+    rowptr = G.csr_from_sorted_centers(g.edge_index[0], g.num_atoms)
+    a1 = int(np.searchsorted(rowptr, target_edges, side="left"))
+    a1 = max(1, min(a1, g.num_atoms))
+    e1 = int(rowptr[a1])
+    pos = torch.tensor(g.pos, dtype=dtype)
+    ei = torch.tensor(g.edge_index[:, :e1])
+    types = torch.tensor(g.types)
+    sv = torch.tensor(g.shift_vec()[:e1], dtype=dtype) if g.cell_shift is not None else None
+    ocfg = dict(cfg)
+    R.allegro_energy_forces(ocfg, sd, pos, ei, types, sv)  # warm-up
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        R.allegro_energy_forces(ocfg, sd, pos, ei, types, sv)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    L = cfg["num_layers"]
+    return dict(value=e1 * L / t, unit="edge-TP/s", cores=cores, kind="port",
+                sample=f"first {a1} center atoms / {e1} edges of the same box, oracle/restatement.py eager PyTorch CPU "
+                       f"{cfg['model_dtype']}, median of {reps}, {t * 1e3:.0f} ms per pass")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    g, cfg = make_workload(args.workload)
+    dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
+    model = HipAllegroModel(**cfg).to(dev)
+    N, E, L = g.num_atoms, g.num_edges, cfg["num_layers"]
+    rowptr = G.csr_from_sorted_centers(g.edge_index[0], N)
+    cuts = partition_atoms(rowptr, world)
+    a0, a1 = cuts[rank], cuts[rank + 1]
+    e0, e1 = int(rowptr[a0]), int(rowptr[a1])
+    ei_local = torch.tensor(g.edge_index[:, e0:e1], device=dev)
+    sv = g.shift_vec()
+    sv_local = torch.tensor(sv[e0:e1], dtype=dtype, device=dev) if sv is not None else None
+    pos = torch.tensor(g.pos, dtype=dtype, device=dev)
+    types = torch.tensor(g.types, device=dev)
+    graph = PreparedGraph(ei_local, types, N, sv_local)
+
+    def step():
+        e_atom, forces = model.energy_forces(pos, graph)
+        if dist is not None:
+            dist.all_reduce(forces)  # ghost-atom force contributions: one RCCL all-reduce over xGMI
+        return e_atom, forces
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        t_step = ms_per_step * 1e-3
+        line = {
+            "metric": "edge tensor-products/sec (forward+force)",
+            "value": E * L / t_step,
+            "unit": "edge-TP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "atoms": N, "edges": E,
+                       "edges_per_s": E / t_step, "ns_per_day_at_1fs": 0.0864 / t_step,
+                       "parallelism": f"atom-block x{world}" if world > 1 else "single GPU",
+                       "weights": "random init (reference initialisers), seed 456"},
+        }
+        if not args.no_profile:
+            stages = profile_stages(model, pos, graph)
+            roof, table = roofline_from_stages(stages, e1 - e0, N, cfg, cfg["model_dtype"])
+            line["roofline"] = roof
+            line["stage_ms"] = table
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(g, cfg, model)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,11 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+typedef int hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 

@@ -1,0 +1,61 @@
+"""CPU: the UNMODIFIED HIP kernel sources, compiled against the test-only fiber emulation of the HIP
+execution model (tests/emu), checked against the reference's golden vectors.  This exercises the
+kernel logic (indexing, CG tables, segments, MFMA fragment mapping, hand-written backward) without a
+GPU; the GPU parity tests proper are in test_hip_*.py (-m gpu)."""
+import pytest
+import torch
+
+from tests.golden_utils import load_contract_cases, load_model_fixture
+from tests.hip_utils import emu_lib, fixture_data, model_from_fixture
+from allegro_amd.nn import HipContracter
+
+
+@pytest.mark.parametrize("name,dtype,tol", [
+    ("t_coupled", torch.float64, 1e-9), ("t_coupled", torch.float32, 5e-5), ("t_uncoupled", torch.float64, 1e-9),
+    ("t_peredge", torch.float64, 1e-9), ("c5_small", torch.float64, 1e-9), ("c1_L1", torch.float32, 5e-5)])
+def test_model_matches_reference_golden(name, dtype, tol):
+    fx = load_model_fixture(name, dtype)
+    m = model_from_fixture(fx, dtype, emu_lib())
+    data, sv = fixture_data(fx, dtype)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    e, f = m.energy_forces(data["pos"], g)
+    ref = fx["out"]
+    for got, want in ((e, ref["atomic_energy"].reshape(-1)), (f, ref["forces"])):
+        scale = max(1.0, float(want.abs().max()))
+        assert (got - want).abs().max().item() <= tol * scale
+
+
+def test_model_unsorted_edges_and_dict_interface():
+    fx = load_model_fixture("t_coupled", torch.float64)
+    m = model_from_fixture(fx, torch.float64, emu_lib())
+    data, sv = fixture_data(fx, torch.float64)
+    perm = torch.randperm(data["edge_index"].shape[1], generator=torch.Generator().manual_seed(0))
+    g = m.prepare_graph(data["edge_index"][:, perm], data["atom_types"], data["pos"].shape[0], sv[perm])
+    e, f = m.energy_forces(data["pos"], g)
+    assert (f - fx["out"]["forces"]).abs().max() < 1e-8
+    assert (e - fx["out"]["atomic_energy"].reshape(-1)).abs().max() < 1e-8
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 1e-5)])
+def test_contracter_matches_reference_cases(dtype, tol):
+    """Shapes/tolerances of the reference's own kernel test (tests/nn/test_contract_kernels.py:93-134)."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        for c in load_contract_cases():
+            m = c["meta"]
+            mod = HipContracter(m["irreps_in1"], m["irreps_in2"], m["irreps_out"], m["mul"],
+                                path_channel_coupling=m["coupling"], scatter_factor=m["scatter_factor"])
+            assert mod.w3j_is_ij_diagonal == m["ij_diagonal"] and mod.num_paths == m["num_paths"]
+            # the product's own Wigner-3j construction reproduces the reference buffer
+            assert (mod.w3j.double() - torch.tensor(c["w3j"])).abs().max() < 1e-6
+            mod.load_state_dict({"weights": torch.tensor(c["weights"]).to(dtype), "w3j": torch.tensor(c["w3j"]).to(dtype)})
+            mod._bind_library(emu_lib())
+            x1 = torch.tensor(c["x1"]).to(dtype).requires_grad_(True)
+            x2 = torch.tensor(c["x2"]).to(dtype).requires_grad_(True)
+            y = mod(x1, x2, torch.tensor(c["idxs"]), torch.tensor([m["num_atoms"]]))
+            g1, g2 = torch.autograd.grad(y, [x1, x2], torch.tensor(c["gout"]).to(dtype))
+            for got, want in ((y, c["out"]), (g1, c["gx1"]), (g2, c["gx2"])):
+                assert (got.double() - torch.tensor(want)).abs().max().item() < tol
+    finally:
+        torch.set_default_dtype(old)

@@ -1,0 +1,197 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) vs the reference's golden vectors, vs the
+oracle restatement on the same seeded inputs, and size-independent properties at BASELINE sizes."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_utils import MODEL_FIXTURES, load_model_fixture
+from tests.hip_utils import fixture_data, model_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+# the reference's own whole-model tolerances (tests/model/test_allegro.py:72-74), relative to output scale
+TOL = {torch.float64: 1e-9, torch.float32: 5e-5}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _run(fx, dtype, dev):
+    m = model_from_fixture(fx, dtype, device=dev)
+    data, sv = fixture_data(fx, dtype, dev)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    e, f = m.energy_forces(data["pos"], g)
+    torch.cuda.synchronize()
+    return m, g, e.cpu(), f.cpu()
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_energy_forces_match_reference_golden(name, dtype, dev):
+    fx = load_model_fixture(name, dtype)
+    _, _, e, f = _run(fx, dtype, dev)
+    ref = fx["out"]
+    for got, want, what in ((e, ref["atomic_energy"].reshape(-1), "E_i"), (f, ref["forces"], "F")):
+        scale = max(1.0, float(want.abs().max()))
+        err = (got - want).abs().max().item()
+        assert err <= TOL[dtype] * scale, f"{name} {what}: {err:.3e} > {TOL[dtype] * scale:.3e}"
+
+
+def test_c2_forces_within_1e4_eV_per_A(dev):
+    """north_star: forces within 1e-4 eV/A of the reference (fp32, BASELINE config 1)."""
+    fx = load_model_fixture("c2", torch.float32)
+    _, _, e, f = _run(fx, torch.float32, dev)
+    assert (f - fx["out"]["forces"]).abs().max().item() < 1e-4
+    # also against the fp64 reference
+    fx64 = load_model_fixture("c2", torch.float64)
+    assert (f.double() - fx64["out"]["forces"]).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("name,dtype", [("c2", torch.float32), ("t_coupled", torch.float64), ("c5_small", torch.float64)])
+def test_intermediates_match_oracle(name, dtype, dev):
+    from oracle import restatement as R
+
+    fx = load_model_fixture(name, dtype)
+    m, g, _, _ = _run(fx, dtype, dev)
+    _, inter = R.allegro_energy(fx["cfg"], fx["sd"], fx["pos"], fx["edge_index"], fx["types"], fx["shift_vec"],
+                                return_intermediates=True)
+    for tap in ("edge_attrs", "emb0", "edge_embedding", "edge_features"):
+        got = m.debug_tap(tap, g).cpu()
+        want = inter[tap]
+        scale = max(1.0, float(want.abs().max()))
+        assert (got - want).abs().max().item() <= TOL[dtype] * scale, tap
+
+
+def test_unsorted_edge_list_is_sorted_internally(dev):
+    fx = load_model_fixture("t_coupled", torch.float64)
+    m = model_from_fixture(fx, torch.float64, device=dev)
+    data, sv = fixture_data(fx, torch.float64, dev)
+    perm = torch.randperm(data["edge_index"].shape[1], generator=torch.Generator().manual_seed(1)).to(dev)
+    g = m.prepare_graph(data["edge_index"][:, perm], data["atom_types"], data["pos"].shape[0], sv[perm])
+    e, f = m.energy_forces(data["pos"], g)
+    assert (f.cpu() - fx["out"]["forces"]).abs().max() < 1e-8
+
+
+def test_ghost_layout_matches_pbc_layout(dev):
+    """pair_allegro tensor contract (allegro/_compile.py:28-63): ghosts appended, no cell; ghost rows carry
+    the force contributions LAMMPS would reverse-communicate -- folded back they equal the PBC forces."""
+    from allegro_amd import graph as G
+
+    fx = load_model_fixture("c2", torch.float64)
+    m = model_from_fixture(fx, torch.float64, device=dev)
+    g = G.make_si_graph(2)
+    assert np.allclose(g.pos, fx["pos"].numpy())
+    gg = G.to_ghost_layout(g)
+    pos = torch.tensor(gg.pos, device=dev)
+    pg = m.prepare_graph(torch.tensor(gg.edge_index, device=dev), torch.tensor(gg.types, device=dev), gg.num_atoms)
+    e, f = m.energy_forces(pos, pg)
+    e, f = e.cpu(), f.cpu()
+    n = gg.n_local
+    outside = np.abs(g.cell_shift).sum(-1) != 0
+    src = torch.tensor(g.edge_index[1][outside])
+    folded = f[:n].clone().index_add_(0, src, f[n:])
+    assert (folded - fx["out"]["forces"]).abs().max() < 1e-9
+    assert (e[:n] - fx["out"]["atomic_energy"].reshape(-1)).abs().max() < 1e-9
+
+
+def test_finite_difference_forces_fp64(dev):
+    fx = load_model_fixture("t_coupled", torch.float64)
+    m = model_from_fixture(fx, torch.float64, device=dev)
+    data, sv = fixture_data(fx, torch.float64, dev)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    pos = data["pos"]
+    _, f = m.energy_forces(pos, g)
+    h = 1e-5
+    for (a, c) in [(0, 0), (3, 1), (11, 2), (20, 0)]:
+        p1, p2 = pos.clone(), pos.clone()
+        p1[a, c] += h
+        p2[a, c] -= h
+        e1, _ = m.energy_forces(p1, g, with_forces=False)
+        e1 = e1.sum().item()
+        e2, _ = m.energy_forces(p2, g, with_forces=False)
+        e2 = e2.sum().item()
+        fd = -(e1 - e2) / (2 * h)
+        assert abs(fd - f[a, c].item()) < 1e-6 * max(1.0, abs(fd))
+
+
+# ---------------------------------------------------------------------------------- BASELINE sizes
+def _big(dev, cells=11):
+    import bench
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+
+    g = G.make_si_graph(cells)
+    cfg = bench.si_model_cfg(g.num_edges / g.num_atoms)
+    cfg["model_dtype"] = "float32"
+    m = HipAllegroModel(**cfg).to(dev)
+    return g, cfg, m
+
+
+def test_c3_properties_and_oracle_sample(dev):
+    """BASELINE config 2 (10 648 atoms / 298 144 edges): size-independent properties + oracle on a sample."""
+    from oracle import restatement as R
+    from allegro_amd import graph as G
+
+    g, cfg, m = _big(dev, 11)
+    pos = torch.tensor(g.pos, dtype=torch.float32, device=dev)
+    ei = torch.tensor(g.edge_index, device=dev)
+    types = torch.tensor(g.types, device=dev)
+    sv = torch.tensor(g.shift_vec(), dtype=torch.float32, device=dev)
+    pg = m.prepare_graph(ei, types, g.num_atoms, sv)
+    e, f = m.energy_forces(pos, pg)
+    e, f = e.cpu().double(), f.cpu().double()
+    fscale = f.abs().max().item()
+    assert torch.isfinite(e).all() and torch.isfinite(f).all() and fscale > 1e-3
+    # Newton's third law under PBC: net force vanishes
+    assert f.sum(0).abs().max().item() < 1e-3 * fscale * math.sqrt(g.num_atoms)
+    # translation invariance
+    e2, f2 = m.energy_forces(pos + torch.tensor([0.3, -1.1, 2.7], device=dev), pg)
+    assert (e2.cpu().double() - e).abs().max().item() < 5e-4 * max(1.0, e.abs().max().item())
+    assert (f2.cpu().double() - f).abs().max().item() < 5e-4 * fscale
+    # atom-block decomposition (what each GPU does at N>1): partial passes sum to the whole
+    rowptr = G.csr_from_sorted_centers(g.edge_index[0], g.num_atoms)
+    cut = g.num_atoms // 3
+    ec = int(rowptr[cut])
+    fa = torch.zeros_like(f)
+    ea = torch.zeros_like(e)
+    for (lo, hi, a0, a1) in ((0, ec, 0, cut), (ec, g.num_edges, cut, g.num_atoms)):
+        pgp = m.prepare_graph(ei[:, lo:hi], types, g.num_atoms, sv[lo:hi])
+        ep, fp = m.energy_forces(pos, pgp)
+        fa += fp.cpu().double()
+        ea[a0:a1] = ep.cpu().double()[a0:a1]
+    assert (fa - f).abs().max().item() < 1e-4 * fscale
+    assert (ea - e).abs().max().item() < 1e-5 * max(1.0, e.abs().max().item())
+    # oracle on a contiguous sample of center atoms (exact by strict locality)
+    a1 = 200
+    e1 = int(rowptr[a1])
+    sd = {k[len("func."):]: v.detach().cpu() for k, v in m.state_dict().items()}
+    ocfg = dict(cfg)
+    out = R.allegro_energy_forces(ocfg, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()},
+                                  torch.tensor(g.pos), torch.tensor(g.edge_index[:, :e1]), torch.tensor(g.types),
+                                  torch.tensor(g.shift_vec()[:e1]))
+    assert (out["atomic_energy"].reshape(-1)[:a1] - e[:a1]).abs().max().item() < 5e-5 * max(1.0, e.abs().max().item())
+    pgs = m.prepare_graph(ei[:, :e1], types, g.num_atoms, sv[:e1])
+    _, fs = m.energy_forces(pos, pgs)
+    assert (fs.cpu().double() - out["forces"]).abs().max().item() < 1e-4 * max(1.0, fscale)
+
+
+def test_rotation_equivariance_fp64(dev):
+    """Energies invariant, forces covariant under a random rotation + inversion (small periodic cell rotated
+    together with its shift vectors)."""
+    fx = load_model_fixture("c2", torch.float64)
+    m = model_from_fixture(fx, torch.float64, device=dev)
+    data, sv = fixture_data(fx, torch.float64, dev)
+    g0 = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    e0, f0 = m.energy_forces(data["pos"], g0)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(5)))
+    q = -q  # include an inversion
+    q = q.to(dev)
+    g1 = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv @ q.T)
+    e1, f1 = m.energy_forces(data["pos"] @ q.T, g1)
+    assert (e1 - e0).abs().max().item() < 1e-9
+    assert (f1 - f0 @ q.T).abs().max().item() < 1e-9

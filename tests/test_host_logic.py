@@ -1,0 +1,63 @@
+"""CPU: host-side logic -- irreps bookkeeping, Wigner 3j, graph construction, ghost layout, partition."""
+import numpy as np
+import pytest
+import torch
+
+from allegro_amd import graph as G
+from allegro_amd import o3
+from allegro_amd.nn import allegro_layer_irreps, build_w3j
+
+
+def test_layer_irreps_match_survey_table():
+    # SURVEY.md §8 table (derived from allegro/nn/_allegro.py:101-160)
+    t = allegro_layer_irreps(2, True, 2)
+    assert [x.dim for x in t] == [9, 9, 1]
+    t = allegro_layer_irreps(3, True, 3)
+    assert [x.dim for x in t] == [16, 31, 16, 1]
+    t = allegro_layer_irreps(1, True, 1)
+    assert [x.dim for x in t] == [4, 1]
+
+
+@pytest.mark.parametrize("lmax,L,paths,nnz,diag", [(1, 2, [4, 2], [10, 4], [False, True]),
+                                                  (2, 2, [11, 3], [83, 9], [False, True]),
+                                                  (3, 3, [34, 34, 4], [611, 611, 16], [False, False, True])])
+def test_paths_and_nnz_match_survey_table(lmax, L, paths, nnz, diag):
+    t = allegro_layer_irreps(lmax, True, L)
+    env = o3.Irreps.spherical_harmonics(lmax)
+    for l in range(L):
+        w3j, instr, d, dims = build_w3j(t[l], env, t[l + 1])
+        assert len(instr) == paths[l] and int((w3j != 0).sum()) == nnz[l] and d == diag[l]
+
+
+def test_wigner_identities():
+    for l in range(4):
+        w = o3.wigner_3j(l, l, 0)
+        assert np.allclose(w[:, :, 0], np.eye(2 * l + 1) / np.sqrt(2 * l + 1))
+    for (a, b, c), n in {(1, 1, 0): 3, (1, 1, 1): 6, (1, 1, 2): 11, (2, 2, 2): 25, (1, 2, 3): 21}.items():
+        w = o3.wigner_3j(a, b, c)
+        assert abs(np.linalg.norm(w) - 1) < 1e-12 and int((w != 0).sum()) == n
+
+
+def test_si_box_and_ghost_layout():
+    g = G.make_si_graph(2)
+    assert g.num_atoms == 64 and g.num_edges == 64 * 28 and G.is_center_sorted(g.edge_index[0])
+    r = g.pos[g.edge_index[1]] - g.pos[g.edge_index[0]] + g.shift_vec()
+    d = np.linalg.norm(r, axis=1)
+    assert d.max() < 5.0
+    gg = G.to_ghost_layout(g)
+    r2 = gg.pos[gg.edge_index[1]] - gg.pos[gg.edge_index[0]]
+    # reference property (tests/utils/test_compile_utils.py:7-18): same multiset of edge lengths
+    assert np.allclose(np.sort(np.linalg.norm(r2, axis=1)), np.sort(d))
+    assert gg.n_local == 64 and G.is_center_sorted(gg.edge_index[0])
+
+
+def test_partition_covers_all_edges():
+    import bench
+
+    g = G.make_si_graph(3)
+    rowptr = G.csr_from_sorted_centers(g.edge_index[0], g.num_atoms)
+    for parts in (1, 2, 4, 8):
+        cuts = bench.partition_atoms(rowptr, parts)
+        assert cuts[0] == 0 and cuts[-1] == g.num_atoms and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        sizes = [rowptr[b] - rowptr[a] for a, b in zip(cuts, cuts[1:])]
+        assert sum(sizes) == g.num_edges and max(sizes) - min(sizes) <= 2 * 28
