@@ -164,6 +164,58 @@ int launch_tp_layer_bwd(const TpLayerDev& L, const TpLayerBwdArgs& a, hipStream_
 
 int build_tp_layer(const aa_tp_desc& d, TpLayerDev* out, std::vector<void*>* owned);
 
+// ---- specialised (compile-time CG table) layer kernels, channel-minor layouts (aa_tp_spec.hip)
+struct TpSpecFwdArgs {
+  int64_t E, N;
+  const int32_t* rowptr;
+  int u;
+  const void* sh;        // [E, ld_sh]
+  int ld_sh;
+  const void* w_x1;      // implicit x1 weights [E, ld_w1] laid out [R][u], or nullptr
+  int ld_w1;
+  const void* x1_dense;  // [E][D1][u] or nullptr
+  const void* w_env;     // env weights [E, ld_we] laid out [R][u]
+  int ld_we;
+  const void* weights;   // [u,P] or [P]
+  int coupling;
+  double sf;
+  void* x2s;             // [N][D2][u]
+  void* out;             // [E][DOUT][u] or nullptr
+  void* scal;            // [E, ld_scal] or nullptr
+  int ld_scal;
+};
+struct TpSpecBwdArgs {
+  int64_t E, N;
+  const int32_t* rowptr;
+  int u;
+  const void* sh;
+  int ld_sh;
+  const void* w_x1;
+  int ld_w1;
+  const void* x1_dense;
+  const void* w_env;
+  int ld_we;
+  const void* weights;
+  int coupling;
+  double sf;
+  const void* x2s;       // saved [N][D2][u]
+  const void* gout;      // [E][DOUT][u] or nullptr
+  const void* gscal;     // [E, ld_gscal] or nullptr
+  int ld_gscal;
+  void* g_x1_dense;      // [E][D1][u] or nullptr
+  void* g_w1;            // [E, ld_gw1] ([R][u]) written
+  int ld_gw1;
+  void* g_wenv;          // [E, ld_gwe] ([R][u]) written
+  int ld_gwe;
+  void* gsh;             // [E, ld_gsh] accumulated
+  int ld_gsh;
+};
+int find_spec_sig(const aa_tp_desc& d);  // signature id or -1
+template <typename T>
+int launch_tp_spec_fwd(int sig, const TpSpecFwdArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream);
+
 // ----------------------------------------------------------------------------------------------
 // edge prologue / epilogue / readout reduce
 // ----------------------------------------------------------------------------------------------

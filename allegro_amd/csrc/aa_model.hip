@@ -110,6 +110,8 @@ struct aa_model_plan {
   MlpLayout embed, readout;          // readout: only the GEMM layers (all but the final ->1 layer)
   MlpLayout latent[AA_MAX_LAYERS];
   int ro_last_dim;                   // input dim of the final readout linear
+  int spec_sig[AA_MAX_LAYERS];       // generated-signature id per layer, or -1
+  bool use_spec;                     // all layers specialised -> channel-minor internal layouts
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
 };
 
@@ -150,9 +152,15 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     if (!ok) return bail(fail(AA_ERR_INVALID, "model: tensor-product layer dims are inconsistent"));
     int rc = build_tp_layer(d, &p->layers[l], &p->owned);
     if (rc) return bail(rc);
+    p->spec_sig[l] = find_spec_sig(d);
     // the plan must not keep pointers into the caller's descriptor arrays
     p->cfg.tps[l].nz_i = p->cfg.tps[l].nz_j = p->cfg.tps[l].nz_k = p->cfg.tps[l].nz_path = nullptr;
     p->cfg.tps[l].nz_val = nullptr;
+  }
+  {
+    const char* e = getenv("AA_TP_GENERIC");
+    p->use_spec = !(e && e[0] == '1');
+    for (int l = 0; l < L; ++l) p->use_spec = p->use_spec && p->spec_sig[l] >= 0;
   }
   // weight blob layout
   size_t o = 0;
@@ -228,21 +236,27 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   copy(p->o_cemb, raw->center_embed, size_t(T) * S0 / 2, 1.0);
   copy(p->o_nemb, raw->neighbor_embed, size_t(T) * S0 / 2, 1.0);
   copy(p->o_basis, raw->basis_linear, size_t(B) * S0, mlp_alpha(c, 0, B, S0));
-  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers) -> bool {
+  // env-weight columns: reference layout [u][R] (_channels.py:46-51); the specialised kernels want [R][u]
+  const int Rr = p->R;
+  auto env_col = [&](int q) { return p->use_spec ? (q % u) * Rr + q / u : q; };  // packed col q <- reference col
+  // pack an MLP; if env_off >= 0 the LAST layer's columns [env_off, env_off+W) are env weights
+  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off) -> bool {
     for (int i = 0; i < nlayers; ++i) {
       if (!ws[i]) return false;
       int din = m.dims[i], dout = m.dims[i + 1];
       double al = mlp_alpha(c, i, din, dout);
       for (int r = 0; r < din; ++r)
         for (int q = 0; q < dout; ++q) {
-          double v = ws[i][size_t(r) * dout + q] * al;
+          int src = q;
+          if (i == nlayers - 1 && env_off >= 0 && q >= env_off && q < env_off + W) src = env_off + env_col(q - env_off);
+          double v = ws[i][size_t(r) * dout + src] * al;
           h[m.w[i] + size_t(r) * dout + q] = v;
           h[m.wt[i] + size_t(q) * din + r] = v;
         }
     }
     return true;
   };
-  AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1), "pack: missing scalar_embed_mlp weights");
+  AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1, -1), "pack: missing scalar_embed_mlp weights");
   {
     // fused first stage: [ two_body (first_proj[:, :S]) | w0 (env_embed_linear) | env_w0 (first_proj[:, S:]) ]
     const int NG = S + 2 * W;
@@ -253,19 +267,20 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
         if (q < S)
           v = raw->first_proj[size_t(r) * (S + W) + q] * a_proj;
         else if (q < S + W)
-          v = raw->env_embed_linear[size_t(r) * W + (q - S)] * a_env;
+          v = raw->env_embed_linear[size_t(r) * W + env_col(q - S)] * a_env;
         else
-          v = raw->first_proj[size_t(r) * (S + W) + (q - W)] * a_proj;
+          v = raw->first_proj[size_t(r) * (S + W) + S + env_col(q - S - W)] * a_proj;
         h[p->o_g0 + size_t(r) * NG + q] = v;
         h[p->o_g0t + size_t(q) * S + r] = v;
       }
   }
   for (int l = 0; l < L; ++l) {
-    AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1), "pack: missing latent weights");
+    AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, l < L - 1 ? S : -1),
+               "pack: missing latent weights");
     AA_REQUIRE(raw->tp_weights[l], "pack: missing tp weights");
     copy(p->o_tpw[l], raw->tp_weights[l], size_t(c.tps[l].coupling ? u : 1) * c.tps[l].num_paths, 1.0);
   }
-  AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth), "pack: missing readout weights");
+  AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1), "pack: missing readout weights");
   {
     const double* wl = raw->readout[c.readout_mlp_depth];
     AA_REQUIRE(wl, "pack: missing readout weights");
@@ -544,6 +559,32 @@ struct Runner {
     // 5: layers
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
     for (int l = 0; l < L; ++l) {
+      if (p->use_spec) {
+        TpSpecFwdArgs a{};
+        a.E = E;
+        a.N = N;
+        a.rowptr = g->rowptr;
+        a.u = u;
+        a.sh = buf(w.sh);
+        a.ld_sh = p->D;
+        if (l == 0) {
+          a.w_x1 = buf(w.w0);
+          a.ld_w1 = W;
+        } else {
+          a.x1_dense = buf(w.tf[l - 1]);
+        }
+        a.w_env = buf(w.envw[l]);
+        a.ld_we = W;
+        a.weights = wt(p->o_tpw[l]);
+        a.coupling = c.tps[l].coupling;
+        a.sf = sfac;
+        a.x2s = buf(w.x2s[l]);
+        a.out = l < L - 1 ? buf(w.tf[l]) : nullptr;
+        a.scal = buf(w.scal[l]);
+        a.ld_scal = u;
+        if (int rc = launch_tp_spec_fwd<T>(p->spec_sig[l], a, stream)) return rc;
+        if (int rc = mark("tp_spec_fwd")) return rc;
+      } else {
       TpLayerFwdArgs a{};
       a.E = E;
       a.N = N;
@@ -561,6 +602,7 @@ struct Runner {
       a.ld_scal = u;
       if (int rc = launch_tp_layer_fwd<T>(p->layers[l], a, stream)) return rc;
       if (int rc = mark("tp_layer_fwd")) return rc;
+      }
       SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
       SegList out;
       out.count = l < L - 1 ? 2 : 1;
@@ -627,6 +669,40 @@ struct Runner {
       int acc[3] = {1, 0, 0};
       if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc)) return rc;
       // tensor-product layer reverse
+      if (p->use_spec) {
+        TpSpecBwdArgs a{};
+        a.E = E;
+        a.N = N;
+        a.rowptr = g->rowptr;
+        a.u = u;
+        a.sh = buf(w.sh);
+        a.ld_sh = p->D;
+        if (l == 0) {
+          a.w_x1 = buf(w.w0);
+          a.ld_w1 = W;
+          a.g_w1 = buf(w.g_w0);
+          a.ld_gw1 = W;
+        } else {
+          a.x1_dense = buf(w.tf[l - 1]);
+          a.g_x1_dense = buf(w.g_tf[(l - 1) & 1]);
+        }
+        a.w_env = buf(w.envw[l]);
+        a.ld_we = W;
+        a.weights = wt(p->o_tpw[l]);
+        a.coupling = c.tps[l].coupling;
+        a.sf = sfac;
+        a.x2s = buf(w.x2s[l]);
+        a.gout = l < L - 1 ? buf(w.g_tf[l & 1]) : nullptr;
+        a.gscal = buf(w.g_scal);
+        a.ld_gscal = u;
+        a.g_wenv = buf(w.g_envw);
+        a.ld_gwe = W;
+        a.gsh = buf(w.g_sh);
+        a.ld_gsh = p->D;
+        if (int rc = launch_tp_spec_bwd<T>(p->spec_sig[l], a, stream)) return rc;
+        if (int rc = mark("tp_spec_bwd")) return rc;
+        continue;
+      }
       TpLayerBwdArgs a{};
       a.E = E;
       a.N = N;

@@ -1,0 +1,336 @@
+// Specialised tensor-product layer kernels (gfx950): compile-time Clebsch-Gordan tables
+// (aa_cg_gen.h), operands in registers, lane = channel, one wave per center atom (x u/64).
+//
+// Same math as aa_tp.hip (reference: allegro/nn/_strided/_contract.py:185-251 fused with the env
+// weighting of allegro/nn/_strided/_channels.py:44-57), selected by the model pipeline when the
+// layer's w3j buffer equals a generated signature and u is 16/32/64/128/256.  Internal layouts are
+// channel-minor so every global access of a wave is one contiguous 256-B row:
+//   env / x1 weights  [E][R][u]     tensor features [E][d][u]     x2s [N][D][u]
+// A wave walks its atom's edge segment twice (segment sum, then contraction) with everything in
+// VGPRs: no LDS, no barriers, no atomics in the forward; deterministic summation order.
+#include "aa_cg_gen.h"
+#include "aa_common.h"
+
+namespace aa {
+
+namespace {
+
+struct LaneMap {
+  int64_t atom;
+  int ch;
+  int width;    // lanes cooperating on one atom-slice (min(u,64))
+  bool valid;
+  bool leader;  // lane 0 of its group
+};
+
+__device__ __forceinline__ LaneMap lane_map(int u, int64_t N) {
+  LaneMap m;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (u >= 64) {
+    const int wpa = u >> 6;
+    m.atom = int64_t(blockIdx.x) * (4 / wpa) + wave / wpa;
+    m.ch = (wave % wpa) * 64 + lane;
+    m.width = 64;
+    m.leader = lane == 0;
+  } else {
+    const int apw = 64 / u;
+    m.atom = (int64_t(blockIdx.x) * 4 + wave) * apw + lane / u;
+    m.ch = lane % u;
+    m.width = u;
+    m.leader = (lane % u) == 0;
+  }
+  m.valid = m.atom < N;
+  return m;
+}
+
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int width) {
+  for (int m = width >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    int o = __shfl_xor(v, m);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int LMAX>
+__device__ __forceinline__ constexpr int r_of(int i) {
+  return i < 1 ? 0 : (i < 4 ? 1 : (i < 9 ? 2 : 3));
+}
+
+}  // namespace
+
+template <class Sig, typename T>
+__global__ __launch_bounds__(256) void tp_spec_fwd_kernel(TpSpecFwdArgs a) {
+  constexpr int D1 = Sig::D1, D2 = Sig::D2, DOUT = Sig::DOUT, P = Sig::P, R = Sig::LMAX + 1;
+  const int u = a.u;
+  const LaneMap m = lane_map(u, a.N);
+  int beg = 0, end = 0;
+  if (m.valid) {
+    beg = a.rowptr[m.atom];
+    end = a.rowptr[m.atom + 1];
+  }
+  const int ch = m.ch;
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* wenv = static_cast<const T*>(a.w_env);
+  // ---- phase 1: x2s[j] = f * sum_e sh[e,j] * w_env[e, r(j), ch]        (_contract.py:195-204)
+  T x2s[D2];
+#pragma unroll
+  for (int j = 0; j < D2; ++j) x2s[j] = T(0);
+  for (int s = beg; s < end; ++s) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    const T* we = wenv + int64_t(s) * a.ld_we + ch;
+    T wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = we[r * u];
+#pragma unroll
+    for (int j = 0; j < D2; ++j) x2s[j] += y[j] * wr[r_of<0>(j)];
+  }
+  const T sf = T(a.sf);
+#pragma unroll
+  for (int j = 0; j < D2; ++j) x2s[j] *= sf;
+  if (m.valid) {
+    T* xo = static_cast<T*>(a.x2s) + m.atom * D2 * int64_t(u) + ch;
+#pragma unroll
+    for (int j = 0; j < D2; ++j) xo[int64_t(j) * u] = x2s[j];
+  }
+  // ---- path weights of this channel
+  T w[P];
+  {
+    const T* W = static_cast<const T*>(a.weights);
+#pragma unroll
+    for (int p = 0; p < P; ++p) w[p] = a.coupling ? W[ch * P + p] : W[p];
+  }
+  // ---- phase 2: contraction per edge                                     (_contract.py:213-251)
+  for (int s = beg; s < end; ++s) {
+    T x1[D1];
+    if (a.x1_dense) {
+      const T* xp = static_cast<const T*>(a.x1_dense) + int64_t(s) * D1 * u + ch;
+#pragma unroll
+      for (int i = 0; i < D1; ++i) x1[i] = xp[int64_t(i) * u];
+    } else {
+      const T* y = sh + int64_t(s) * a.ld_sh;
+      const T* w1 = static_cast<const T*>(a.w_x1) + int64_t(s) * a.ld_w1 + ch;
+      T wr[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) wr[r] = w1[r * u];
+#pragma unroll
+      for (int i = 0; i < D1; ++i) x1[i] = y[i] * wr[r_of<0>(i)];
+    }
+    T out[DOUT];
+    Sig::template fwd<T>(x1, x2s, w, out);
+    if (a.out) {
+      T* op = static_cast<T*>(a.out) + int64_t(s) * DOUT * u + ch;
+#pragma unroll
+      for (int k = 0; k < DOUT; ++k) op[int64_t(k) * u] = out[k];
+    }
+    if (a.scal) static_cast<T*>(a.scal)[int64_t(s) * a.ld_scal + ch] = out[0];
+  }
+}
+
+template <class Sig, typename T>
+__global__ __launch_bounds__(256) void tp_spec_bwd_kernel(TpSpecBwdArgs a) {
+  constexpr int D1 = Sig::D1, D2 = Sig::D2, DOUT = Sig::DOUT, P = Sig::P, R = Sig::LMAX + 1;
+  const int u = a.u;
+  const LaneMap m = lane_map(u, a.N);
+  int beg = 0, end = 0;
+  if (m.valid) {
+    beg = a.rowptr[m.atom];
+    end = a.rowptr[m.atom + 1];
+  }
+  const int deg = end - beg;
+  const int maxdeg = u >= 64 ? deg : wave_max(deg);  // all lanes of a wave iterate together (shuffles below)
+  const int ch = m.ch;
+  const bool multi_wave = u > 64;
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* wenv = static_cast<const T*>(a.w_env);
+  T* gsh = static_cast<T*>(a.gsh);
+  T x2s[D2], g2acc[D2];
+  {
+    const T* xi = static_cast<const T*>(a.x2s) + (m.valid ? m.atom : 0) * D2 * int64_t(u) + ch;
+#pragma unroll
+    for (int j = 0; j < D2; ++j) {
+      x2s[j] = m.valid ? xi[int64_t(j) * u] : T(0);
+      g2acc[j] = T(0);
+    }
+  }
+  T w[P];
+  {
+    const T* W = static_cast<const T*>(a.weights);
+#pragma unroll
+    for (int p = 0; p < P; ++p) w[p] = a.coupling ? W[ch * P + p] : W[p];
+  }
+  // ---- pass 1: per edge, grad wrt x1 and accumulation of grad wrt x2s
+  for (int it = 0; it < maxdeg; ++it) {
+    const bool act = it < deg;
+    const int64_t s = act ? beg + it : 0;
+    const T* y = sh + s * a.ld_sh;
+    T x1[D1], wr1[R];
+    if (a.x1_dense) {
+      const T* xp = static_cast<const T*>(a.x1_dense) + s * D1 * u + ch;
+#pragma unroll
+      for (int i = 0; i < D1; ++i) x1[i] = act ? xp[int64_t(i) * u] : T(0);
+    } else {
+      const T* w1 = static_cast<const T*>(a.w_x1) + s * a.ld_w1 + ch;
+#pragma unroll
+      for (int r = 0; r < R; ++r) wr1[r] = act ? w1[r * u] : T(0);
+#pragma unroll
+      for (int i = 0; i < D1; ++i) x1[i] = y[i] * wr1[r_of<0>(i)];
+    }
+    T go[DOUT];
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) go[k] = T(0);
+    if (act) {
+      if (a.gout) {
+        const T* gp = static_cast<const T*>(a.gout) + s * DOUT * u + ch;
+#pragma unroll
+        for (int k = 0; k < DOUT; ++k) go[k] = gp[int64_t(k) * u];
+      }
+      if (a.gscal) go[0] += static_cast<const T*>(a.gscal)[s * a.ld_gscal + ch];
+    }
+    T g1[D1];
+    Sig::template bx1<T>(go, x2s, w, g1);
+    if (a.g_x1_dense) {
+      if (act) {
+        T* gp = static_cast<T*>(a.g_x1_dense) + s * D1 * u + ch;
+#pragma unroll
+        for (int i = 0; i < D1; ++i) gp[int64_t(i) * u] = g1[i];
+      }
+    } else {
+      // adjoint of x1 = sh[e,i] * w1[e, r(i), ch]
+      T gw[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) gw[r] = T(0);
+#pragma unroll
+      for (int i = 0; i < D1; ++i) gw[r_of<0>(i)] += g1[i] * y[i];
+      if (act) {
+        T* gwp = static_cast<T*>(a.g_w1) + s * a.ld_gw1 + ch;
+#pragma unroll
+        for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
+      }
+#pragma unroll
+      for (int i = 0; i < D1; ++i) {
+        T v = group_sum<T>(act ? g1[i] * wr1[r_of<0>(i)] : T(0), m.width);
+        if (m.leader && act) {
+          if (multi_wave)
+            atomicAdd(&gsh[s * a.ld_gsh + i], v);
+          else
+            gsh[s * a.ld_gsh + i] += v;
+        }
+      }
+    }
+    T g2[D2];
+    Sig::template bx2<T>(go, x1, w, g2);
+#pragma unroll
+    for (int j = 0; j < D2; ++j) g2acc[j] += g2[j];
+  }
+  // ---- pass 2: adjoint of (scale, segment-sum, gather) and of the env weighting
+  const T sf = T(a.sf);
+#pragma unroll
+  for (int j = 0; j < D2; ++j) g2acc[j] *= sf;
+  for (int it = 0; it < maxdeg; ++it) {
+    const bool act = it < deg;
+    const int64_t s = act ? beg + it : 0;
+    const T* y = sh + s * a.ld_sh;
+    const T* we = wenv + s * a.ld_we + ch;
+    T wr[R], gw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      wr[r] = act ? we[r * u] : T(0);
+      gw[r] = T(0);
+    }
+#pragma unroll
+    for (int j = 0; j < D2; ++j) gw[r_of<0>(j)] += y[j] * g2acc[j];
+    if (act) {
+      T* gwp = static_cast<T*>(a.g_wenv) + s * a.ld_gwe + ch;
+#pragma unroll
+      for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
+    }
+#pragma unroll
+    for (int j = 0; j < D2; ++j) {
+      T v = group_sum<T>(act ? wr[r_of<0>(j)] * g2acc[j] : T(0), m.width);
+      if (m.leader && act) {
+        if (multi_wave)
+          atomicAdd(&gsh[s * a.ld_gsh + j], v);
+        else
+          gsh[s * a.ld_gsh + j] += v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+int find_spec_sig(const aa_tp_desc& d) {
+  if (d.mul < 1 || d.mul > 256 || (d.mul & (d.mul - 1)) != 0) return -1;  // power of two <= 256
+  for (int sgi = 0; sgi < cg::kNumSigs; ++sgi) {
+    const cg::SigInfo& s = cg::kSigs[sgi];
+    if (s.d1 != d.d1 || s.d2 != d.d2 || s.dout != d.dout || s.num_paths != d.num_paths || s.nnz != d.nnz) continue;
+    // compare as sets of (i,j,k,p) -> val
+    bool ok = true;
+    for (int n = 0; n < d.nnz && ok; ++n) {
+      bool found = false;
+      for (int q = 0; q < s.nnz; ++q) {
+        if (s.nz[q][0] == d.nz_i[n] && s.nz[q][1] == d.nz_j[n] && s.nz[q][2] == d.nz_k[n] && s.nz[q][3] == d.nz_path[n]) {
+          found = std::fabs(s.val[q] - d.nz_val[n]) <= 1e-6 * std::max(1.0, std::fabs(s.val[q]));
+          break;
+        }
+      }
+      ok = found;
+    }
+    if (ok) return sgi;
+  }
+  return -1;
+}
+
+static unsigned spec_grid(int u, int64_t N) {
+  int64_t atoms_per_block = u >= 64 ? 4 / (u / 64) : 4 * (64 / u);
+  return (unsigned)((N + atoms_per_block - 1) / atoms_per_block);
+}
+
+template <typename T>
+int launch_tp_spec_fwd(int sig, const TpSpecFwdArgs& a, hipStream_t stream) {
+  if (a.N == 0) return AA_OK;
+  dim3 grid(spec_grid(a.u, a.N));
+  switch (sig) {
+#define AA_CASE(ID, SIG)                                                                     \
+  case ID:                                                                                   \
+    hipLaunchKernelGGL((tp_spec_fwd_kernel<cg::SIG, T>), grid, dim3(256), 0, stream, a);     \
+    break;
+    AA_FOREACH_SIG(AA_CASE)
+#undef AA_CASE
+    default:
+      return fail(AA_ERR_INVALID, "tp spec fwd: unknown signature");
+  }
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template <typename T>
+int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
+  if (a.N == 0) return AA_OK;
+  dim3 grid(spec_grid(a.u, a.N));
+  switch (sig) {
+#define AA_CASE(ID, SIG)                                                                     \
+  case ID:                                                                                   \
+    hipLaunchKernelGGL((tp_spec_bwd_kernel<cg::SIG, T>), grid, dim3(256), 0, stream, a);     \
+    break;
+    AA_FOREACH_SIG(AA_CASE)
+#undef AA_CASE
+    default:
+      return fail(AA_ERR_INVALID, "tp spec bwd: unknown signature");
+  }
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template int launch_tp_spec_fwd<float>(int, const TpSpecFwdArgs&, hipStream_t);
+template int launch_tp_spec_fwd<double>(int, const TpSpecFwdArgs&, hipStream_t);
+template int launch_tp_spec_bwd<float>(int, const TpSpecBwdArgs&, hipStream_t);
+template int launch_tp_spec_bwd<double>(int, const TpSpecBwdArgs&, hipStream_t);
+
+}  // namespace aa
