@@ -180,6 +180,124 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 MFMA kernel v2 -- wave-independent row tiles.
+//   * each WAVE owns 32 consecutive rows (edges); its A tile [32 x K] is loaded from HBM exactly once
+//     (16-B loads, activation applied) into a wave-private LDS region with row stride K+4 words, which
+//     makes the MFMA operand fetch 4 conflict-free ds_read_b128 per 32-deep k chunk;
+//   * the k index inside a chunk is permuted (lane half h supplies k = 16h + s at step s) so that every
+//     lane reads 16 CONTIGUOUS floats of its row; B is pre-permuted the same way on the host into
+//     fragment order, so a lane streams its B operand with 4 x 16-B loads per chunk from L2;
+//   * a wave loops over all N in pairs of 32-column tiles (2 accumulators share the A fragment), so A is
+//     never re-read and there is no block-level synchronisation after the tile load.
+// ---------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bool seglist_vec4_ok(const SegList& sl) {
+  for (int s = 0; s < sl.count; ++s)
+    if ((sl.s[s].n & 3) || (sl.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(sl.s[s].p) & 15)) return false;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g, int Kp, int wpb) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int LDA = Kp + 4;
+  float* As = reinterpret_cast<float*>(aa_smem) + size_t(wv) * 32 * LDA;
+  const int64_t m0 = (int64_t(blockIdx.x) * wpb + wv) * 32;
+  const bool vec = seglist_vec4_ok(g.a);
+  // ---- stage this wave's 32 x Kp tile
+  const int k4n = Kp >> 2;
+  for (int idx = lane; idx < 32 * k4n; idx += 64) {
+    int row = idx / k4n, k = (idx % k4n) << 2;
+    int64_t gm = m0 + row;
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (gm < g.M && k < g.K) {
+      if (vec) {
+        int c = k;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          if (s < g.a.count) {
+            if (c >= 0 && c < g.a.s[s].n) {
+              v = *reinterpret_cast<const v4f*>(static_cast<const float*>(g.a.s[s].p) + gm * g.a.s[s].ld + c);
+              c = -1;
+            } else if (c >= 0) {
+              c -= g.a.s[s].n;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (k + q < g.K) v[q] = seg_load<float>(g.a, gm, k + q);
+      }
+      if (g.act_a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+      }
+    }
+    *reinterpret_cast<v4f*>(As + row * LDA + k) = v;
+  }
+  __syncthreads();
+  const int KC = Kp >> 5;
+  const int NT = (g.N + 31) >> 5;
+  const v4f* Bp = static_cast<const v4f*>(g.Bp);
+  const float* arow = As + (lane & 31) * LDA + (lane >> 5) * 16;
+  for (int nt = 0; nt < NT; nt += 2) {
+    const bool two = nt + 1 < NT;
+    v16f acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.f;
+      acc1[r] = 0.f;
+    }
+    for (int kc = 0; kc < KC; ++kc) {
+      v4f a[4], b0[4], b1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(arow + kc * 32 + q * 4);
+      const v4f* bp0 = Bp + ((size_t(nt) * KC + kc) * 64 + lane) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b0[q] = bp0[q];
+      if (two) {
+        const v4f* bp1 = Bp + ((size_t(nt + 1) * KC + kc) * 64 + lane) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1[q] = bp1[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b0[q][e], acc0, 0, 0, 0);
+          if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b1[q][e], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      int64_t gm = m0 + row;
+      if (gm < g.M) {
+        int gn = nt * 32 + (lane & 31);
+        if (gn < g.N) seg_store<float>(g, gm, gn, acc0[r]);
+        gn += 32;
+        if (two && gn < g.N) seg_store<float>(g, gm, gn, acc1[r]);
+      }
+    }
+  }
+}
+
+size_t gemm_packed_elems(int K, int N) { return size_t((N + 31) / 32) * size_t((K + 31) / 32) * 64 * 16; }
+
+// out[nt][kc][lane][s] = B[kc*32 + (lane>>5)*16 + s][nt*32 + (lane&31)]   (zero padded)
+void gemm_pack_b(const double* B, int K, int N, double* out) {
+  const int NT = (N + 31) / 32, KC = (K + 31) / 32;
+  for (int nt = 0; nt < NT; ++nt)
+    for (int kc = 0; kc < KC; ++kc)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 16; ++s) {
+          int k = kc * 32 + (lane >> 5) * 16 + s, n = nt * 32 + (lane & 31);
+          out[((size_t(nt) * KC + kc) * 64 + lane) * 16 + s] = (k < K && n < N) ? B[size_t(k) * N + n] : 0.0;
+        }
+}
+
 static int check_args(const GemmArgs& g) {
   int ka = 0, nc = 0;
   for (int s = 0; s < g.a.count; ++s) ka += g.a.s[s].n;
@@ -206,10 +324,26 @@ template <>
 int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
   if (g.M == 0) return AA_OK;
   if (int rc = check_args(g)) return rc;
+  static int v1_only = -1;
+  if (v1_only < 0) {
+    const char* e = getenv("AA_GEMM_V1");
+    v1_only = (e && e[0] == '1') ? 1 : 0;
+  }
   if (force_valu()) {
     dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
     size_t smem = sizeof(float) * (GV_BK * GV_LDA + GV_BK * GV_BN);
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
+  } else if (g.Bp && !v1_only) {
+    const int Kp = (g.K + 31) / 32 * 32;
+    const size_t per_wave = sizeof(float) * 32 * size_t(Kp + 4);
+    int wpb = 4;
+    while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
+    dim3 grid((unsigned)((g.M + 32 * wpb - 1) / (32 * wpb)));
+    size_t smem = per_wave * wpb;
+    if (smem > 64 * 1024)
+      AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_f32_v2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(gemm_mfma_f32_v2_kernel, grid, dim3(64 * wpb), smem, stream, g, Kp, wpb);
   } else {
     dim3 grid((unsigned)((g.M + GM_BM - 1) / GM_BM), (unsigned)((g.N + GM_BN - 1) / GM_BN));
     size_t smem = sizeof(float) * (GM_BK * GM_LDA + GM_BK * GM_BN);

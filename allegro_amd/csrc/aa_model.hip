@@ -95,6 +95,7 @@ extern "C" int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, cons
 struct MlpLayout {
   std::vector<int> dims;        // d_0 .. d_n
   std::vector<size_t> w, wt;    // blob offsets (elements) of W_i [d_i,d_{i+1}] and its transpose
+  std::vector<size_t> wp, wtp;  // the same two matrices in MFMA fragment order (aa_gemm.hip v2)
 };
 
 struct aa_model_plan {
@@ -105,7 +106,7 @@ struct aa_model_plan {
   std::vector<TpLayerDev> layers;
   std::vector<void*> owned;
   // weight blob layout (element offsets)
-  size_t o_rmax, o_bessel, o_cemb, o_nemb, o_basis, o_g0, o_g0t, o_ro_last, o_scales, o_shifts, n_elems;
+  size_t o_rmax, o_bessel, o_cemb, o_nemb, o_basis, o_g0, o_g0t, o_g0p, o_g0tp, o_ro_last, o_scales, o_shifts, n_elems;
   size_t o_tpw[AA_MAX_LAYERS];
   MlpLayout embed, readout;          // readout: only the GEMM layers (all but the final ->1 layer)
   MlpLayout latent[AA_MAX_LAYERS];
@@ -161,6 +162,9 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     const char* e = getenv("AA_TP_GENERIC");
     p->use_spec = !(e && e[0] == '1');
     for (int l = 0; l < L; ++l) p->use_spec = p->use_spec && p->spec_sig[l] >= 0;
+    // fp64 at l_max=3 does not fit the register file (256 VGPR + 256 AGPR + 1.9 KB scratch per lane, and
+    // wrong results on hardware in round 1): keep it on the general LDS-table kernels for now
+    if (cfg->dtype == AA_F64 && cfg->l_max >= 3) p->use_spec = false;
   }
   // weight blob layout
   size_t o = 0;
@@ -180,11 +184,15 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     for (int i = 0; i < nlayers; ++i) {
       m.w.push_back(take(size_t(dims[i]) * dims[i + 1]));
       m.wt.push_back(take(size_t(dims[i]) * dims[i + 1]));
+      m.wp.push_back(take(gemm_packed_elems(dims[i], dims[i + 1])));
+      m.wtp.push_back(take(gemm_packed_elems(dims[i + 1], dims[i])));
     }
   };
   lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
   p->o_g0 = take(size_t(S) * (S + 2 * p->W));
   p->o_g0t = take(size_t(S) * (S + 2 * p->W));
+  p->o_g0p = take(gemm_packed_elems(S, S + 2 * p->W));
+  p->o_g0tp = take(gemm_packed_elems(S + 2 * p->W, S));
   for (int l = 0; l < L; ++l) {
     int in = S * (l + 1) + u, outd = S + (l < L - 1 ? p->W : 0);
     lay(p->latent[l], mlp_dims(in, cfg->latent_mlp_depth, cfg->latent_mlp_width, outd), cfg->latent_mlp_depth + 1);
@@ -253,6 +261,8 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
           h[m.w[i] + size_t(r) * dout + q] = v;
           h[m.wt[i] + size_t(q) * din + r] = v;
         }
+      gemm_pack_b(&h[m.w[i]], din, dout, &h[m.wp[i]]);
+      gemm_pack_b(&h[m.wt[i]], dout, din, &h[m.wtp[i]]);
     }
     return true;
   };
@@ -273,6 +283,8 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
         h[p->o_g0 + size_t(r) * NG + q] = v;
         h[p->o_g0t + size_t(q) * S + r] = v;
       }
+    gemm_pack_b(&h[p->o_g0], S, NG, &h[p->o_g0p]);
+    gemm_pack_b(&h[p->o_g0t], NG, S, &h[p->o_g0tp]);
   }
   for (int l = 0; l < L; ++l) {
     AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, l < L - 1 ? S : -1),
@@ -415,13 +427,15 @@ struct Runner {
   T* buf(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   const T* wt(size_t off) const { return wts + off; }
 
-  int gemm(const SegList& a, int act_a, const T* B, int K, int Nn, const SegList& c, const int* accum, const SegList* z) {
+  int gemm(const SegList& a, int act_a, const T* B, const T* Bp, int K, int Nn, const SegList& c, const int* accum,
+           const SegList* z) {
     GemmArgs g{};
     g.M = E;
     g.K = K;
     g.N = Nn;
     g.a = a;
     g.B = B;
+    g.Bp = Bp;
     g.c = c;
     for (int i = 0; i < 3; ++i) g.c_accum[i] = accum ? accum[i] : 0;
     g.has_z = z ? 1 : 0;
@@ -445,7 +459,7 @@ struct Runner {
       } else {
         c = out;
       }
-      if (int rc = gemm(a, i > 0, wt(m.w[i]), m.dims[i], m.dims[i + 1], c, nullptr, nullptr)) return rc;
+      if (int rc = gemm(a, i > 0, wt(m.w[i]), wt(m.wp[i]), m.dims[i], m.dims[i + 1], c, nullptr, nullptr)) return rc;
       a = c;
     }
     return AA_OK;
@@ -469,7 +483,7 @@ struct Runner {
         c = g_in;
         acc = g_in_accum;
       }
-      if (int rc = gemm(a, 0, wt(m.wt[i]), m.dims[i + 1], m.dims[i], c, acc, zp)) return rc;
+      if (int rc = gemm(a, 0, wt(m.wt[i]), wt(m.wtp[i]), m.dims[i + 1], m.dims[i], c, acc, zp)) return rc;
       a = c;
     }
     return AA_OK;
@@ -554,7 +568,7 @@ struct Runner {
     {
       SegList in{1, {seg(buf(w.emb), S, S)}};
       SegList out{3, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W), seg(buf(w.envw[0]), W, W)}};
-      if (int rc = gemm(in, 0, wt(p->o_g0), S, S + 2 * W, out, nullptr, nullptr)) return rc;
+      if (int rc = gemm(in, 0, wt(p->o_g0), wt(p->o_g0p), S, S + 2 * W, out, nullptr, nullptr)) return rc;
     }
     // 5: layers
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
@@ -615,7 +629,8 @@ struct Runner {
       SegList a{1, {seg(buf(w.fcat), SL1, SL1)}};
       for (int i = 0; i < c.readout_mlp_depth; ++i) {
         SegList cs{1, {seg(buf(w.ro_h[i]), c.readout_mlp_width, c.readout_mlp_width)}};
-        if (int rc = gemm(a, i > 0, wt(p->readout.w[i]), p->readout.dims[i], p->readout.dims[i + 1], cs, nullptr, nullptr))
+        if (int rc = gemm(a, i > 0, wt(p->readout.w[i]), wt(p->readout.wp[i]), p->readout.dims[i], p->readout.dims[i + 1], cs,
+                          nullptr, nullptr))
           return rc;
         a = cs;
       }
@@ -648,7 +663,8 @@ struct Runner {
           } else {
             cs = SegList{1, {seg(buf(w.g_fcat), SL1, SL1)}};
           }
-          if (int rc = gemm(a, 0, wt(p->readout.wt[i]), p->readout.dims[i + 1], p->readout.dims[i], cs, nullptr, zp))
+          if (int rc = gemm(a, 0, wt(p->readout.wt[i]), wt(p->readout.wtp[i]), p->readout.dims[i + 1], p->readout.dims[i], cs,
+                            nullptr, zp))
             return rc;
           a = cs;
         }
@@ -737,7 +753,7 @@ struct Runner {
     {
       SegList go{3, {seg(buf(w.g_fcat), SL1, S), seg(buf(w.g_w0), W, W), seg(buf(w.g_envw), W, W)}};
       SegList gi{1, {seg(buf(w.g_emb), S, S)}};
-      if (int rc = gemm(go, 0, wt(p->o_g0t), S + 2 * W, S, gi, nullptr, nullptr)) return rc;
+      if (int rc = gemm(go, 0, wt(p->o_g0t), wt(p->o_g0tp), S + 2 * W, S, gi, nullptr, nullptr)) return rc;
     }
     // scalar_embed_mlp reverse
     {
