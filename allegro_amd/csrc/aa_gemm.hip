@@ -199,6 +199,52 @@ __device__ __forceinline__ bool seglist_vec4_ok(const SegList& sl) {
   return true;
 }
 
+// destination of one output column, resolved once per 32-column tile (not per element)
+struct ColDst {
+  float* c;
+  const float* z;
+  int ld, zld, accum, valid;
+};
+__device__ __forceinline__ ColDst resolve_col(const GemmArgs& g, int gn) {
+  ColDst d;
+  d.c = nullptr;
+  d.z = nullptr;
+  d.ld = d.zld = d.accum = d.valid = 0;
+  int c = gn;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const bool live = s < g.c.count;
+    const bool in = live && !d.valid && c >= 0 && c < g.c.s[s].n && gn < g.N;
+    if (in) {
+      d.c = static_cast<float*>(g.c.s[s].p) + c;
+      d.ld = g.c.s[s].ld;
+      d.accum = g.c_accum[s];
+      if (g.has_z) {
+        d.z = static_cast<const float*>(g.z.s[s].p) + c;
+        d.zld = g.z.s[s].ld;
+      }
+      d.valid = 1;
+    }
+    if (live) c -= g.c.s[s].n;
+  }
+  return d;
+}
+__device__ __forceinline__ void store_tile(const ColDst& d, const v16f& acc, int64_t m0, int64_t M, int lane) {
+  if (!d.valid) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int64_t gm = m0 + row;
+    if (gm < M) {
+      float v = acc[r];
+      if (d.z) v *= dsilu(d.z[gm * d.zld]);
+      float* p = d.c + gm * d.ld;
+      if (d.accum) v += *p;
+      *p = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g, int Kp, int wpb) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int LDA = Kp + 4;
@@ -214,16 +260,15 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g, int K
     if (gm < g.M && k < g.K) {
       if (vec) {
         int c = k;
+        bool done = false;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-          if (s < g.a.count) {
-            if (c >= 0 && c < g.a.s[s].n) {
-              v = *reinterpret_cast<const v4f*>(static_cast<const float*>(g.a.s[s].p) + gm * g.a.s[s].ld + c);
-              c = -1;
-            } else if (c >= 0) {
-              c -= g.a.s[s].n;
-            }
+          const bool live = s < g.a.count;
+          if (live && !done && c < g.a.s[s].n) {
+            v = *reinterpret_cast<const v4f*>(static_cast<const float*>(g.a.s[s].p) + gm * g.a.s[s].ld + c);
+            done = true;
           }
+          if (live) c -= g.a.s[s].n;
         }
       } else {
 #pragma unroll
@@ -240,47 +285,72 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g, int K
   __syncthreads();
   const int KC = Kp >> 5;
   const int NT = (g.N + 31) >> 5;
-  const v4f* Bp = static_cast<const v4f*>(g.Bp);
+  const v4f* Bp = static_cast<const v4f*>(g.Bp) + size_t(lane) * 4;
   const float* arow = As + (lane & 31) * LDA + (lane >> 5) * 16;
-  for (int nt = 0; nt < NT; nt += 2) {
-    const bool two = nt + 1 < NT;
+  const size_t tile_stride = size_t(KC) * 64 * 4;  // v4f units between consecutive n-tiles
+  int nt = 0;
+  // ---- pairs of 32-column tiles sharing the A fragment; next chunk's operands are fetched into a second
+  //      register set before the current chunk's 32 MFMAs issue
+  for (; nt + 1 < NT; nt += 2) {
     v16f acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       acc0[r] = 0.f;
       acc1[r] = 0.f;
     }
+    const v4f* bp0 = Bp + size_t(nt) * tile_stride;
+    const v4f* bp1 = bp0 + tile_stride;
+    v4f a[4], b0[4], b1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = *reinterpret_cast<const v4f*>(arow + q * 4);
+      b0[q] = bp0[q];
+      b1[q] = bp1[q];
+    }
     for (int kc = 0; kc < KC; ++kc) {
-      v4f a[4], b0[4], b1[4];
+      v4f an[4], b0n[4], b1n[4];
+      const int kn = kc + 1 < KC ? kc + 1 : kc;  // last iteration re-reads its own chunk (harmless)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(arow + kc * 32 + q * 4);
-      const v4f* bp0 = Bp + ((size_t(nt) * KC + kc) * 64 + lane) * 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) b0[q] = bp0[q];
-      if (two) {
-        const v4f* bp1 = Bp + ((size_t(nt + 1) * KC + kc) * 64 + lane) * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b1[q] = bp1[q];
+      for (int q = 0; q < 4; ++q) {
+        an[q] = *reinterpret_cast<const v4f*>(arow + kn * 32 + q * 4);
+        b0n[q] = bp0[size_t(kn) * 256 + q];
+        b1n[q] = bp1[size_t(kn) * 256 + q];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b0[q][e], acc0, 0, 0, 0);
-          if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b1[q][e], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b1[q][e], acc1, 0, 0, 0);
         }
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      int64_t gm = m0 + row;
-      if (gm < g.M) {
-        int gn = nt * 32 + (lane & 31);
-        if (gn < g.N) seg_store<float>(g, gm, gn, acc0[r]);
-        gn += 32;
-        if (two && gn < g.N) seg_store<float>(g, gm, gn, acc1[r]);
+      for (int q = 0; q < 4; ++q) {
+        a[q] = an[q];
+        b0[q] = b0n[q];
+        b1[q] = b1n[q];
       }
     }
+    store_tile(resolve_col(g, nt * 32 + (lane & 31)), acc0, m0, g.M, lane);
+    store_tile(resolve_col(g, nt * 32 + 32 + (lane & 31)), acc1, m0, g.M, lane);
+  }
+  if (nt < NT) {  // odd tail tile
+    v16f acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+    const v4f* bp0 = Bp + size_t(nt) * tile_stride;
+    for (int kc = 0; kc < KC; ++kc) {
+      v4f a[4], b0[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = *reinterpret_cast<const v4f*>(arow + kc * 32 + q * 4);
+        b0[q] = bp0[size_t(kc) * 256 + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b0[q][e], acc0, 0, 0, 0);
+    }
+    store_tile(resolve_col(g, nt * 32 + (lane & 31)), acc0, m0, g.M, lane);
   }
 }
 
