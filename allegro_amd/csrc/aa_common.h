@@ -211,7 +211,8 @@ struct TpSpecBwdArgs {
   int ld_gw1;
   void* g_wenv;          // [E, ld_gwe] ([R][u]) written
   int ld_gwe;
-  void* gsh;             // [E, ld_gsh] accumulated
+  void* gsh_x1;          // [E, ld_gsh] grad of sh through the x1 operand (written; atomically added if u > 64)
+  void* gsh_env;         // [E, ld_gsh] grad of sh through the env operand (written; atomically added if u > 64)
   int ld_gsh;
 };
 int find_spec_sig(const aa_tp_desc& d);  // signature id or -1
@@ -245,7 +246,8 @@ int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream);
 struct EdgeBwdArgs {
   EdgeGeomArgs g;
   const void* g_emb0;  // [E,S0]
-  const void* g_sh;    // [E,D]
+  const void* g_sh;    // [num_gsh][E,D] slices, summed here
+  int num_gsh;
   void* forces;        // [N,3] (pre-zeroed; accumulated with atomics)
 };
 template <typename T>

@@ -203,6 +203,10 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
     T gY[16];
     const T* gsh = static_cast<const T*>(b.g_sh) + e * D;
     for (int m = 0; m < D; ++m) gY[m] = gsh[m];
+    for (int sl = 1; sl < b.num_gsh; ++sl) {
+      const T* g2 = gsh + int64_t(sl) * a.E * D;
+      for (int m = 0; m < D; ++m) gY[m] += g2[m];
+    }
     T gx, gy, gz;
     sh_grad<T>(a.l_max, nx, ny, nz, gY, gx, gy, gz);
     T dot = gx * nx + gy * ny + gz * nz;

@@ -180,24 +180,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// fp32 MFMA kernel v2 -- wave-independent row tiles.
-//   * each WAVE owns 32 consecutive rows (edges); its A tile [32 x K] is loaded from HBM exactly once
-//     (16-B loads, activation applied) into a wave-private LDS region with row stride K+4 words, which
-//     makes the MFMA operand fetch 4 conflict-free ds_read_b128 per 32-deep k chunk;
-//   * the k index inside a chunk is permuted (lane half h supplies k = 16h + s at step s) so that every
-//     lane reads 16 CONTIGUOUS floats of its row; B is pre-permuted the same way on the host into
-//     fragment order, so a lane streams its B operand with 4 x 16-B loads per chunk from L2;
-//   * a wave loops over all N in pairs of 32-column tiles (2 accumulators share the A fragment), so A is
-//     never re-read and there is no block-level synchronisation after the tile load.
-// ---------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ bool seglist_vec4_ok(const SegList& sl) {
-  for (int s = 0; s < sl.count; ++s)
-    if ((sl.s[s].n & 3) || (sl.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(sl.s[s].p) & 15)) return false;
-  return true;
-}
 
 // destination of one output column, resolved once per 32-column tile (not per element)
 struct ColDst {
@@ -245,52 +228,72 @@ __device__ __forceinline__ void store_tile(const ColDst& d, const v16f& acc, int
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g, int Kp, int wpb) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int LDA = Kp + 4;
-  float* As = reinterpret_cast<float*>(aa_smem) + size_t(wv) * 32 * LDA;
-  const int64_t m0 = (int64_t(blockIdx.x) * wpb + wv) * 32;
-  const bool vec = seglist_vec4_ok(g.a);
-  // ---- stage this wave's 32 x Kp tile
-  const int k4n = Kp >> 2;
-  for (int idx = lane; idx < 32 * k4n; idx += 64) {
-    int row = idx / k4n, k = (idx % k4n) << 2;
-    int64_t gm = m0 + row;
-    v4f v = {0.f, 0.f, 0.f, 0.f};
-    if (gm < g.M && k < g.K) {
-      if (vec) {
-        int c = k;
-        bool done = false;
+// ---------------------------------------------------------------------------------------------
+// fp32 MFMA kernel v3 -- no LDS.  Each wave owns 32 rows.  With the k index permuted inside every
+// 32-deep chunk (lane half h supplies k = 16h + s at MFMA step s; B is pre-permuted on the host the
+// same way), lane (i, h) needs A[row i][chunk*32 + 16h .. +15]: 64 contiguous bytes of its own row,
+// fetched straight into VGPRs with 4 x 16-B loads -- every A element is loaded (and activated) by exactly
+// one lane, nothing is staged, nothing is synchronised, occupancy is bounded by registers only.
+// Column tiles are processed in pairs sharing the A fragment; the next chunk's operands are fetched into
+// a second register set before the current chunk's 32 MFMAs issue.
+// Requires every A segment width to be a multiple of 16 and 16-B aligned rows (else the v1 kernel runs).
+// ---------------------------------------------------------------------------------------------
+struct RowSrc {  // per-lane source of one 16-float half-chunk
+  const float* p;  // nullptr -> zeros
+};
+
+__device__ __forceinline__ bool seglist_frag_ok(const SegList& sl) {
+  for (int s = 0; s < sl.count; ++s)
+    if ((sl.s[s].n & 15) || (sl.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(sl.s[s].p) & 15)) return false;
+  return true;
+}
+
+// pointer to A[gm][k .. k+15] (k multiple of 16) or nullptr when out of range
+__device__ __forceinline__ const float* a_half_ptr(const GemmArgs& g, int64_t gm, int k) {
+  const float* out = nullptr;
+  if (gm < g.M && k < g.K) {
+    int c = k;
+    bool done = false;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const bool live = s < g.a.count;
-          if (live && !done && c < g.a.s[s].n) {
-            v = *reinterpret_cast<const v4f*>(static_cast<const float*>(g.a.s[s].p) + gm * g.a.s[s].ld + c);
-            done = true;
-          }
-          if (live) c -= g.a.s[s].n;
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (k + q < g.K) v[q] = seg_load<float>(g.a, gm, k + q);
+    for (int s = 0; s < 3; ++s) {
+      const bool live = s < g.a.count;
+      if (live && !done && c < g.a.s[s].n) {
+        out = static_cast<const float*>(g.a.s[s].p) + gm * g.a.s[s].ld + c;
+        done = true;
       }
-      if (g.act_a) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
-      }
+      if (live) c -= g.a.s[s].n;
     }
-    *reinterpret_cast<v4f*>(As + row * LDA + k) = v;
   }
-  __syncthreads();
-  const int KC = Kp >> 5;
+  return out;
+}
+
+__device__ __forceinline__ void load_a_frag(const GemmArgs& g, int64_t gm, int k, v4f* a) {
+  const float* p = a_half_ptr(g, gm, k);
+  if (p) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = reinterpret_cast<const v4f*>(p)[q];
+    if (g.act_a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[q][e] = silu(a[q][e]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
+  const int64_t gm = m0 + (lane & 31);
+  const int kh = (lane >> 5) * 16;
+  const int KC = (g.K + 31) >> 5;
   const int NT = (g.N + 31) >> 5;
   const v4f* Bp = static_cast<const v4f*>(g.Bp) + size_t(lane) * 4;
-  const float* arow = As + (lane & 31) * LDA + (lane >> 5) * 16;
   const size_t tile_stride = size_t(KC) * 64 * 4;  // v4f units between consecutive n-tiles
   int nt = 0;
-  // ---- pairs of 32-column tiles sharing the A fragment; next chunk's operands are fetched into a second
-  //      register set before the current chunk's 32 MFMAs issue
   for (; nt + 1 < NT; nt += 2) {
     v16f acc0, acc1;
 #pragma unroll
@@ -301,18 +304,18 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g, int K
     const v4f* bp0 = Bp + size_t(nt) * tile_stride;
     const v4f* bp1 = bp0 + tile_stride;
     v4f a[4], b0[4], b1[4];
+    load_a_frag(g, gm, kh, a);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      a[q] = *reinterpret_cast<const v4f*>(arow + q * 4);
       b0[q] = bp0[q];
       b1[q] = bp1[q];
     }
     for (int kc = 0; kc < KC; ++kc) {
       v4f an[4], b0n[4], b1n[4];
-      const int kn = kc + 1 < KC ? kc + 1 : kc;  // last iteration re-reads its own chunk (harmless)
+      const int kn = kc + 1 < KC ? kc + 1 : kc;  // the last iteration re-reads its own chunk (harmless)
+      load_a_frag(g, gm, kn * 32 + kh, an);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        an[q] = *reinterpret_cast<const v4f*>(arow + kn * 32 + q * 4);
         b0n[q] = bp0[size_t(kn) * 256 + q];
         b1n[q] = bp1[size_t(kn) * 256 + q];
       }
@@ -338,17 +341,25 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v2_kernel(GemmArgs g, int K
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
     const v4f* bp0 = Bp + size_t(nt) * tile_stride;
-    for (int kc = 0; kc < KC; ++kc) {
-      v4f a[4], b0[4];
+    v4f a[4], b0[4];
+    load_a_frag(g, gm, kh, a);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a[q] = *reinterpret_cast<const v4f*>(arow + kc * 32 + q * 4);
-        b0[q] = bp0[size_t(kc) * 256 + q];
-      }
+    for (int q = 0; q < 4; ++q) b0[q] = bp0[q];
+    for (int kc = 0; kc < KC; ++kc) {
+      v4f an[4], b0n[4];
+      const int kn = kc + 1 < KC ? kc + 1 : kc;
+      load_a_frag(g, gm, kn * 32 + kh, an);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b0n[q] = bp0[size_t(kn) * 256 + q];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b0[q][e], acc0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = an[q];
+        b0[q] = b0n[q];
+      }
     }
     store_tile(resolve_col(g, nt * 32 + (lane & 31)), acc0, m0, g.M, lane);
   }
@@ -366,6 +377,12 @@ void gemm_pack_b(const double* B, int K, int N, double* out) {
           int k = kc * 32 + (lane >> 5) * 16 + s, n = nt * 32 + (lane & 31);
           out[((size_t(nt) * KC + kc) * 64 + lane) * 16 + s] = (k < K && n < N) ? B[size_t(k) * N + n] : 0.0;
         }
+}
+
+static bool seglist_frag_ok_host(const SegList& sl) {
+  for (int s = 0; s < sl.count; ++s)
+    if ((sl.s[s].n & 15) || (sl.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(sl.s[s].p) & 15)) return false;
+  return true;
 }
 
 static int check_args(const GemmArgs& g) {
@@ -403,17 +420,9 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
     size_t smem = sizeof(float) * (GV_BK * GV_LDA + GV_BK * GV_BN);
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
-  } else if (g.Bp && !v1_only) {
-    const int Kp = (g.K + 31) / 32 * 32;
-    const size_t per_wave = sizeof(float) * 32 * size_t(Kp + 4);
-    int wpb = 4;
-    while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
-    dim3 grid((unsigned)((g.M + 32 * wpb - 1) / (32 * wpb)));
-    size_t smem = per_wave * wpb;
-    if (smem > 64 * 1024)
-      AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_f32_v2_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(gemm_mfma_f32_v2_kernel, grid, dim3(64 * wpb), smem, stream, g, Kp, wpb);
+  } else if (g.Bp && !v1_only && seglist_frag_ok_host(g.a)) {
+    dim3 grid((unsigned)((g.M + 127) / 128));
+    hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel, grid, dim3(256), 0, stream, g);
   } else {
     dim3 grid((unsigned)((g.M + GM_BM - 1) / GM_BM), (unsigned)((g.N + GM_BN - 1) / GM_BN));
     size_t smem = sizeof(float) * (GM_BK * GM_LDA + GM_BK * GM_BN);

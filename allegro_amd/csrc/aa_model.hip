@@ -375,7 +375,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     w.g_emb = take(Ez * S);
     for (int i = 0; i < c.embed_mlp_depth; ++i) w.g_se_h[i] = take(Ez * c.embed_mlp_width);
     w.g_emb0 = take(Ez * S0);
-    w.g_sh = take(Ez * p->D);
+    w.g_sh = take(Ez * p->D * (L + 1));  // slot 0: x1 path of layer 0; slot l+1: env path of layer l
   }
   w.total = o;
   return w;
@@ -642,7 +642,10 @@ struct Runner {
   int backward(const aa_graph* g, const void* pos, void* forces) {
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
-    AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * sizeof(T), stream));
+    // spec path with u <= 64 writes every g_sh slot with plain stores; otherwise slots are accumulated into
+    const bool gsh_stores = p->use_spec && u <= 64;
+    const int num_gsh = p->use_spec ? L + 1 : 1;
+    if (!gsh_stores) AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * num_gsh * sizeof(T), stream));
     AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
     if (int rc = mark("memset")) return rc;
     // readout
@@ -713,7 +716,8 @@ struct Runner {
         a.ld_gscal = u;
         a.g_wenv = buf(w.g_envw);
         a.ld_gwe = W;
-        a.gsh = buf(w.g_sh);
+        a.gsh_x1 = buf(w.g_sh);
+        a.gsh_env = buf(w.g_sh) + size_t(l + 1) * size_t(E) * p->D;
         a.ld_gsh = p->D;
         if (int rc = launch_tp_spec_bwd<T>(p->spec_sig[l], a, stream)) return rc;
         if (int rc = mark("tp_spec_bwd")) return rc;
@@ -765,6 +769,7 @@ struct Runner {
     eb.g = geom(g, pos);
     eb.g_emb0 = buf(w.g_emb0);
     eb.g_sh = buf(w.g_sh);
+    eb.num_gsh = p->use_spec ? L + 1 : 1;
     eb.forces = forces;
     if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
     return mark("edge_backward");

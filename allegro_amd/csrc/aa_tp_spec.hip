@@ -58,6 +58,57 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+// Sum D (<=16) per-lane values over the 64 lanes of a wave with a reduce-scatter butterfly
+// (8+4+2+1+1+1 = 17 shuffles instead of 6*D) and store total k to dst[k].
+template <typename T, int D>
+__device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, bool atomic) {
+  static_assert(D <= 16, "at most 16 values");
+  const int lane = threadIdx.x & 63;
+  T x[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) x[k] = k < D ? v[k] : T(0);
+  T y[8], z[4], q[2];
+  {
+    const bool hi = lane & 32;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      T recv = __shfl_xor(hi ? x[k] : x[k + 8], 32);
+      y[k] = (hi ? x[k + 8] : x[k]) + recv;
+    }
+  }
+  {
+    const bool hi = lane & 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T recv = __shfl_xor(hi ? y[k] : y[k + 4], 16);
+      z[k] = (hi ? y[k + 4] : y[k]) + recv;
+    }
+  }
+  {
+    const bool hi = lane & 8;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      T recv = __shfl_xor(hi ? z[k] : z[k + 2], 8);
+      q[k] = (hi ? z[k + 2] : z[k]) + recv;
+    }
+  }
+  T r;
+  {
+    const bool hi = lane & 4;
+    T recv = __shfl_xor(hi ? q[0] : q[1], 4);
+    r = (hi ? q[1] : q[0]) + recv;
+  }
+  r += __shfl_xor(r, 2);
+  r += __shfl_xor(r, 1);
+  const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+  if ((lane & 3) == 0 && idx < D && act) {
+    if (atomic)
+      atomicAdd(&dst[idx], r);
+    else
+      dst[idx] = r;
+  }
+}
+
 template <int LMAX>
 __device__ __forceinline__ constexpr int r_of(int i) {
   return i < 1 ? 0 : (i < 4 ? 1 : (i < 9 ? 2 : 3));
@@ -149,7 +200,8 @@ __global__ __launch_bounds__(256) void tp_spec_bwd_kernel(TpSpecBwdArgs a) {
   const bool multi_wave = u > 64;
   const T* sh = static_cast<const T*>(a.sh);
   const T* wenv = static_cast<const T*>(a.w_env);
-  T* gsh = static_cast<T*>(a.gsh);
+  T* gsh1 = static_cast<T*>(a.gsh_x1);
+  T* gsh2 = static_cast<T*>(a.gsh_env);
   T x2s[D2], g2acc[D2];
   {
     const T* xi = static_cast<const T*>(a.x2s) + (m.valid ? m.atom : 0) * D2 * int64_t(u) + ch;
@@ -213,14 +265,21 @@ __global__ __launch_bounds__(256) void tp_spec_bwd_kernel(TpSpecBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
       }
+      if (m.width == 64 && D1 <= 16) {
+        T gy[D1 <= 16 ? D1 : 1];
 #pragma unroll
-      for (int i = 0; i < D1; ++i) {
-        T v = group_sum<T>(act ? g1[i] * wr1[r_of<0>(i)] : T(0), m.width);
-        if (m.leader && act) {
-          if (multi_wave)
-            atomicAdd(&gsh[s * a.ld_gsh + i], v);
-          else
-            gsh[s * a.ld_gsh + i] += v;
+        for (int i = 0; i < (D1 <= 16 ? D1 : 1); ++i) gy[i] = act ? g1[i] * wr1[r_of<0>(i)] : T(0);
+        wave_sum_store<T, (D1 <= 16 ? D1 : 1)>(gy, gsh1 + s * a.ld_gsh, act, multi_wave);
+      } else {
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+          T v = group_sum<T>(act ? g1[i] * wr1[r_of<0>(i)] : T(0), m.width);
+          if (m.leader && act) {
+            if (multi_wave)
+              atomicAdd(&gsh1[s * a.ld_gsh + i], v);
+            else
+              gsh1[s * a.ld_gsh + i] = v;
+          }
         }
       }
     }
@@ -251,14 +310,21 @@ __global__ __launch_bounds__(256) void tp_spec_bwd_kernel(TpSpecBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
     }
+    if (m.width == 64) {
+      T gy[D2];
 #pragma unroll
-    for (int j = 0; j < D2; ++j) {
-      T v = group_sum<T>(act ? wr[r_of<0>(j)] * g2acc[j] : T(0), m.width);
-      if (m.leader && act) {
-        if (multi_wave)
-          atomicAdd(&gsh[s * a.ld_gsh + j], v);
-        else
-          gsh[s * a.ld_gsh + j] += v;
+      for (int j = 0; j < D2; ++j) gy[j] = act ? wr[r_of<0>(j)] * g2acc[j] : T(0);
+      wave_sum_store<T, D2>(gy, gsh2 + s * a.ld_gsh, act, multi_wave);
+    } else {
+#pragma unroll
+      for (int j = 0; j < D2; ++j) {
+        T v = group_sum<T>(act ? wr[r_of<0>(j)] * g2acc[j] : T(0), m.width);
+        if (m.leader && act) {
+          if (multi_wave)
+            atomicAdd(&gsh2[s * a.ld_gsh + j], v);
+          else
+            gsh2[s * a.ld_gsh + j] = v;
+        }
       }
     }
   }

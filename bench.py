@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print every launch of one step with its HIP-event time")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,6 +274,9 @@ def main():
             roof, table = roofline_from_stages(stages, e1 - e0, N, cfg, cfg["model_dtype"])
             line["roofline"] = roof
             line["stage_ms"] = table
+            if args.stages:
+                for nm, ms in stages:
+                    print(f"[stage] {nm:24s} {ms * 1e3:9.1f} us", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, cfg, model)
         print(json.dumps(line), flush=True)
