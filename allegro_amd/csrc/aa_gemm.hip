@@ -284,15 +284,86 @@ __device__ __forceinline__ void load_a_frag(const GemmArgs& g, int64_t gm, int k
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g) {
+// destination of 4 consecutive output features of one row (a 16-B store), resolved per tile group
+struct Dst4 {
+  float* c;
+  const float* z;
+  int accum, nvalid;  // nvalid: how many of the 4 features exist (0..4)
+};
+__device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0) {
+  Dst4 d;
+  d.c = nullptr;
+  d.z = nullptr;
+  d.accum = 0;
+  d.nvalid = 0;
+  if (gm >= g.M || f0 >= g.N) return d;
+  int c = f0;
+  bool done = false;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const bool live = s < g.c.count;
+    if (live && !done && c < g.c.s[s].n) {
+      d.c = static_cast<float*>(g.c.s[s].p) + gm * g.c.s[s].ld + c;
+      d.accum = g.c_accum[s];
+      if (g.has_z) d.z = static_cast<const float*>(g.z.s[s].p) + gm * g.z.s[s].ld + c;
+      d.nvalid = g.c.s[s].n - c < 4 ? g.c.s[s].n - c : 4;
+      done = true;
+    }
+    if (live) c -= g.c.s[s].n;
+  }
+  return d;
+}
+
+// acc holds C^T: column = row index (edge) lane&31, feature = n0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
+__device__ __forceinline__ void store_tile_t(const GemmArgs& g, const v16f& acc, int64_t gm, int n0, int lane, bool vec_ok) {
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int f0 = n0 + 8 * gq + 4 * (lane >> 5);
+    const Dst4 d = resolve4(g, gm, f0);
+    if (d.nvalid == 0) continue;
+    v4f v = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
+    if (vec_ok && d.nvalid == 4) {
+      if (d.z) {
+        const v4f z = *reinterpret_cast<const v4f*>(d.z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dsilu(z[e]);
+      }
+      if (d.accum) {
+        const v4f o = *reinterpret_cast<const v4f*>(d.c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += o[e];
+      }
+      *reinterpret_cast<v4f*>(d.c) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < d.nvalid) {
+          float x = v[e];
+          if (d.z) x *= dsilu(d.z[e]);
+          if (d.accum) x += d.c[e];
+          d.c[e] = x;
+        }
+    }
+  }
+}
+
+// KCR > 0: K <= 32*KCR and the row's activation fragments stay in registers for all column tiles;
+// KCR == 0: fragments are streamed (and double-buffered) per k chunk.
+template <int KCR>
+__global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int vec_ok) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
   const int kh = (lane >> 5) * 16;
   const int KC = (g.K + 31) >> 5;
   const int NT = (g.N + 31) >> 5;
-  const v4f* Bp = static_cast<const v4f*>(g.Bp) + size_t(lane) * 4;
-  const size_t tile_stride = size_t(KC) * 64 * 4;  // v4f units between consecutive n-tiles
+  const v4f* Wp = static_cast<const v4f*>(g.Bp) + size_t(lane) * 4;
+  const size_t tile_stride = size_t(KC) * 64 * 4;  // v4f units between consecutive feature tiles
+  v4f xr[KCR > 0 ? KCR : 1][4];
+  if (KCR > 0) {
+#pragma unroll
+    for (int kc = 0; kc < KCR; ++kc) load_a_frag(g, gm, kc * 32 + kh, xr[kc]);
+  }
   int nt = 0;
   for (; nt + 1 < NT; nt += 2) {
     v16f acc0, acc1;
@@ -301,67 +372,78 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g) {
       acc0[r] = 0.f;
       acc1[r] = 0.f;
     }
-    const v4f* bp0 = Bp + size_t(nt) * tile_stride;
-    const v4f* bp1 = bp0 + tile_stride;
-    v4f a[4], b0[4], b1[4];
-    load_a_frag(g, gm, kh, a);
+    const v4f* wp0 = Wp + size_t(nt) * tile_stride;
+    const v4f* wp1 = wp0 + tile_stride;
+    if (KCR > 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      b0[q] = bp0[q];
-      b1[q] = bp1[q];
-    }
-    for (int kc = 0; kc < KC; ++kc) {
-      v4f an[4], b0n[4], b1n[4];
-      const int kn = kc + 1 < KC ? kc + 1 : kc;  // the last iteration re-reads its own chunk (harmless)
-      load_a_frag(g, gm, kn * 32 + kh, an);
+      for (int kc = 0; kc < KCR; ++kc) {
+        if (kc < KC) {
+          v4f w0[4], w1[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            w0[q] = wp0[size_t(kc) * 256 + q];
+            w1[q] = wp1[size_t(kc) * 256 + q];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[q][e], xr[kc][q][e], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[q][e], xr[kc][q][e], acc1, 0, 0, 0);
+            }
+        }
+      }
+    } else {
+      v4f x[4], w0[4], w1[4];
+      load_a_frag(g, gm, kh, x);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        b0n[q] = bp0[size_t(kn) * 256 + q];
-        b1n[q] = bp1[size_t(kn) * 256 + q];
+        w0[q] = wp0[q];
+        w1[q] = wp1[q];
       }
+      for (int kc = 0; kc < KC; ++kc) {
+        v4f xn[4], w0n[4], w1n[4];
+        const int kn = kc + 1 < KC ? kc + 1 : kc;  // the last iteration re-reads its own chunk (harmless)
+        load_a_frag(g, gm, kn * 32 + kh, xn);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b0[q][e], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b1[q][e], acc1, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+          w0n[q] = wp0[size_t(kn) * 256 + q];
+          w1n[q] = wp1[size_t(kn) * 256 + q];
         }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a[q] = an[q];
-        b0[q] = b0n[q];
-        b1[q] = b1n[q];
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[q][e], x[q][e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[q][e], x[q][e], acc1, 0, 0, 0);
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x[q] = xn[q];
+          w0[q] = w0n[q];
+          w1[q] = w1n[q];
+        }
       }
     }
-    store_tile(resolve_col(g, nt * 32 + (lane & 31)), acc0, m0, g.M, lane);
-    store_tile(resolve_col(g, nt * 32 + 32 + (lane & 31)), acc1, m0, g.M, lane);
+    store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
+    store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok);
   }
   if (nt < NT) {  // odd tail tile
     v16f acc0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
-    const v4f* bp0 = Bp + size_t(nt) * tile_stride;
-    v4f a[4], b0[4];
-    load_a_frag(g, gm, kh, a);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) b0[q] = bp0[q];
+    const v4f* wp0 = Wp + size_t(nt) * tile_stride;
     for (int kc = 0; kc < KC; ++kc) {
-      v4f an[4], b0n[4];
-      const int kn = kc + 1 < KC ? kc + 1 : kc;
-      load_a_frag(g, gm, kn * 32 + kh, an);
+      v4f x[4], w0[4];
+      load_a_frag(g, gm, kc * 32 + kh, x);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b0n[q] = bp0[size_t(kn) * 256 + q];
+      for (int q = 0; q < 4; ++q) w0[q] = wp0[size_t(kc) * 256 + q];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b0[q][e], acc0, 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a[q] = an[q];
-        b0[q] = b0n[q];
-      }
+        for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[q][e], x[q][e], acc0, 0, 0, 0);
     }
-    store_tile(resolve_col(g, nt * 32 + (lane & 31)), acc0, m0, g.M, lane);
+    store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
   }
 }
 
@@ -422,7 +504,19 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
   } else if (g.Bp && !v1_only && seglist_frag_ok_host(g.a)) {
     dim3 grid((unsigned)((g.M + 127) / 128));
-    hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel, grid, dim3(256), 0, stream, g);
+    // 16-B epilogue accesses need every C/Z segment to be 4-column granular and 16-B aligned
+    int vec_ok = 1;
+    for (int s = 0; s < g.c.count; ++s) {
+      if ((g.c.s[s].n & 3) || (g.c.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.c.s[s].p) & 15)) vec_ok = 0;
+      if (g.has_z && ((g.z.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.z.s[s].p) & 15))) vec_ok = 0;
+    }
+    const int KC = (g.K + 31) / 32;
+    if (KC <= 2)
+      hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<2>, grid, dim3(256), 0, stream, g, vec_ok);
+    else if (KC <= 4)
+      hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<4>, grid, dim3(256), 0, stream, g, vec_ok);
+    else
+      hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<0>, grid, dim3(256), 0, stream, g, vec_ok);
   } else {
     dim3 grid((unsigned)((g.M + GM_BM - 1) / GM_BM), (unsigned)((g.N + GM_BN - 1) / GM_BN));
     size_t smem = sizeof(float) * (GM_BK * GM_LDA + GM_BK * GM_BN);
