@@ -215,6 +215,47 @@ struct TpSpecBwdArgs {
   void* gsh_env;         // [E, ld_gsh] grad of sh through the env operand (written; atomically added if u > 64)
   int ld_gsh;
 };
+// 2-layer stacks ("chain"): the layer-1 kernels recompute tf1 = TP0(sh*w0, x2s0) per edge in registers and
+// the layer-0 reverse kernel recomputes d_tf1 from (d_scal1, x2s1), so [E,u,D] tensors never touch HBM.
+struct TpChainArgs {
+  int64_t E, N;
+  const int32_t* rowptr;
+  int u;
+  const void* sh;
+  int ld_sh;
+  const void* w0;       // layer-0 x1 weights [E][R][u]
+  int ld_w0;
+  const void* wenv0;    // layer-0 env weights (reverse of layer 0 only)
+  int ld_we0;
+  const void* wenv1;    // layer-1 env weights
+  int ld_we1;
+  const void* weights0; // path weights [u,P0] / [P0]
+  const void* weights1;
+  int coupling;
+  double sf;
+  const void* x2s0;     // [N][D][u] (saved by the layer-0 forward)
+  void* x2s1;           // [N][D][u] written by fwd_last, read by the reverse kernels
+  void* scal1;          // fwd_last output [E, ld_scal]
+  int ld_scal;
+  const void* gscal0;   // [E, ld_gscal] (bwd_first)
+  const void* gscal1;   // [E, ld_gscal]
+  int ld_gscal;
+  void* g_w0;           // bwd_first outputs
+  int ld_gw0;
+  void* g_wenv;         // env-weight grad of the layer being reversed
+  int ld_gwe;
+  void* gsh_x1;         // [E, ld_gsh]
+  void* gsh_env;
+  int ld_gsh;
+};
+int find_chain_pair(int sig0, int sig1);  // pair id or -1
+template <typename T>
+int launch_tp_chain_fwd_last(int pair, const TpChainArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_chain_bwd_last(int pair, const TpChainArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_chain_bwd_first(int pair, const TpChainArgs& a, hipStream_t stream);
+
 int find_spec_sig(const aa_tp_desc& d);  // signature id or -1
 template <typename T>
 int launch_tp_spec_fwd(int sig, const TpSpecFwdArgs& a, hipStream_t stream);

@@ -375,14 +375,25 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int v
     const v4f* wp0 = Wp + size_t(nt) * tile_stride;
     const v4f* wp1 = wp0 + tile_stride;
     if (KCR > 0) {
+      // weights of step (pair, kc+1) are fetched while the 32 MFMAs of step (pair, kc) issue; the first
+      // chunk of the NEXT pair is fetched during the last chunk of this one
+      v4f w0[4], w1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        w0[q] = wp0[q];
+        w1[q] = wp1[q];
+      }
 #pragma unroll
       for (int kc = 0; kc < KCR; ++kc) {
         if (kc < KC) {
-          v4f w0[4], w1[4];
+          v4f w0n[4], w1n[4];
+          const bool more = kc + 1 < KC;
+          const v4f* n0p = more ? wp0 + size_t(kc + 1) * 256 : wp0;
+          const v4f* n1p = more ? wp1 + size_t(kc + 1) * 256 : wp1;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            w0[q] = wp0[size_t(kc) * 256 + q];
-            w1[q] = wp1[size_t(kc) * 256 + q];
+            w0n[q] = n0p[q];
+            w1n[q] = n1p[q];
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -391,6 +402,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int v
               acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[q][e], xr[kc][q][e], acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[q][e], xr[kc][q][e], acc1, 0, 0, 0);
             }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            w0[q] = w0n[q];
+            w1[q] = w1n[q];
+          }
         }
       }
     } else {

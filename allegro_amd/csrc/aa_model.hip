@@ -113,6 +113,7 @@ struct aa_model_plan {
   int ro_last_dim;                   // input dim of the final readout linear
   int spec_sig[AA_MAX_LAYERS];       // generated-signature id per layer, or -1
   bool use_spec;                     // all layers specialised -> channel-minor internal layouts
+  int chain_pair;                    // >= 0: 2-layer stack on the chain kernels (no [E,u,D] tensors in HBM)
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
 };
 
@@ -165,6 +166,9 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     // fp64 at l_max=3 does not fit the register file (256 VGPR + 256 AGPR + 1.9 KB scratch per lane, and
     // wrong results on hardware in round 1): keep it on the general LDS-table kernels for now
     if (cfg->dtype == AA_F64 && cfg->l_max >= 3) p->use_spec = false;
+    p->chain_pair = -1;
+    const char* nc = getenv("AA_TP_NOCHAIN");
+    if (p->use_spec && L == 2 && !(nc && nc[0] == '1')) p->chain_pair = find_chain_pair(p->spec_sig[0], p->spec_sig[1]);
   }
   // weight blob layout
   size_t o = 0;
@@ -321,7 +325,8 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_scal, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last;
+  size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
   size_t lat_h[AA_MAX_LAYERS][AA_MAX_MLP_LAYERS], g_lat_h[AA_MAX_MLP_LAYERS];
@@ -353,7 +358,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   for (int l = 0; l < L; ++l) {
     w.envw[l] = take(Ez * p->W);
     w.x2s[l] = take(Nz * u * p->D);
-    if (l < L - 1) {
+    if (l < L - 1 && p->chain_pair < 0) {
       w.tf[l] = take(Ez * u * c.tps[l].dout);
       dmax = std::max(dmax, size_t(c.tps[l].dout));
     }
@@ -365,10 +370,10 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     w.g_fcat = take(Ez * p->SL1);
     for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
     for (int i = 0; i < c.latent_mlp_depth; ++i) w.g_lat_h[i] = take(Ez * c.latent_mlp_width);
-    w.g_scal = take(Ez * u);
+    for (int l = 0; l < L; ++l) w.g_scal[l] = take(Ez * u);
     w.g_envw = take(Ez * p->W);
     w.g_w0 = take(Ez * p->W);
-    if (L > 1) {
+    if (L > 1 && p->chain_pair < 0) {
       w.g_tf[0] = take(Ez * u * dmax);
       w.g_tf[1] = L > 2 ? take(Ez * u * dmax) : w.g_tf[0];
     }
@@ -542,6 +547,36 @@ struct Runner {
     return r;
   }
 
+  TpChainArgs chain_args(const aa_graph* g) const {
+    const aa_model_config& c = p->cfg;
+    TpChainArgs a{};
+    a.E = E;
+    a.N = N;
+    a.rowptr = g->rowptr;
+    a.u = c.num_tensor;
+    a.sh = buf(w.sh);
+    a.ld_sh = p->D;
+    a.w0 = buf(w.w0);
+    a.ld_w0 = p->W;
+    a.wenv0 = buf(w.envw[0]);
+    a.ld_we0 = p->W;
+    a.wenv1 = buf(w.envw[1]);
+    a.ld_we1 = p->W;
+    a.weights0 = wt(p->o_tpw[0]);
+    a.weights1 = wt(p->o_tpw[1]);
+    a.coupling = c.tps[0].coupling;
+    a.sf = 1.0 / std::sqrt(c.avg_num_neighbors);
+    a.x2s0 = buf(w.x2s[0]);
+    a.x2s1 = buf(w.x2s[1]);
+    a.scal1 = buf(w.scal[1]);
+    a.ld_scal = c.num_tensor;
+    a.ld_gscal = c.num_tensor;
+    a.ld_gw0 = p->W;
+    a.ld_gwe = p->W;
+    a.ld_gsh = p->D;
+    return a;
+  }
+
   TpOperand implicit(size_t w_off) const {
     TpOperand o{};
     o.sh = buf(w.sh);
@@ -573,7 +608,10 @@ struct Runner {
     // 5: layers
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
     for (int l = 0; l < L; ++l) {
-      if (p->use_spec) {
+      if (p->chain_pair >= 0 && l == 1) {
+        if (int rc = launch_tp_chain_fwd_last<T>(p->chain_pair, chain_args(g), stream)) return rc;
+        if (int rc = mark("tp_chain_fwd_last")) return rc;
+      } else if (p->use_spec) {
         TpSpecFwdArgs a{};
         a.E = E;
         a.N = N;
@@ -593,7 +631,7 @@ struct Runner {
         a.coupling = c.tps[l].coupling;
         a.sf = sfac;
         a.x2s = buf(w.x2s[l]);
-        a.out = l < L - 1 ? buf(w.tf[l]) : nullptr;
+        a.out = (l < L - 1 && p->chain_pair < 0) ? buf(w.tf[l]) : nullptr;
         a.scal = buf(w.scal[l]);
         a.ld_scal = u;
         if (int rc = launch_tp_spec_fwd<T>(p->spec_sig[l], a, stream)) return rc;
@@ -684,10 +722,27 @@ struct Runner {
       go.count = l < L - 1 ? 2 : 1;
       go.s[0] = seg(buf(w.g_fcat) + S * (l + 1), SL1, S);
       if (l < L - 1) go.s[1] = seg(buf(w.g_envw), W, W);
-      SegList gi{2, {seg(buf(w.g_fcat), SL1, S * (l + 1)), seg(buf(w.g_scal), u, u)}};
+      SegList gi{2, {seg(buf(w.g_fcat), SL1, S * (l + 1)), seg(buf(w.g_scal[l]), u, u)}};
       int acc[3] = {1, 0, 0};
       if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc)) return rc;
       // tensor-product layer reverse
+      if (p->chain_pair >= 0) {
+        TpChainArgs a = chain_args(g);
+        a.gscal0 = buf(w.g_scal[0]);
+        a.gscal1 = buf(w.g_scal[1]);
+        a.g_w0 = buf(w.g_w0);
+        a.g_wenv = buf(w.g_envw);
+        a.gsh_x1 = buf(w.g_sh);
+        a.gsh_env = buf(w.g_sh) + size_t(l + 1) * size_t(E) * p->D;
+        if (l == 1) {
+          if (int rc = launch_tp_chain_bwd_last<T>(p->chain_pair, a, stream)) return rc;
+          if (int rc = mark("tp_chain_bwd_last")) return rc;
+        } else {
+          if (int rc = launch_tp_chain_bwd_first<T>(p->chain_pair, a, stream)) return rc;
+          if (int rc = mark("tp_chain_bwd_first")) return rc;
+        }
+        continue;
+      }
       if (p->use_spec) {
         TpSpecBwdArgs a{};
         a.E = E;
@@ -712,7 +767,7 @@ struct Runner {
         a.sf = sfac;
         a.x2s = buf(w.x2s[l]);
         a.gout = l < L - 1 ? buf(w.g_tf[l & 1]) : nullptr;
-        a.gscal = buf(w.g_scal);
+        a.gscal = buf(w.g_scal[l]);
         a.ld_gscal = u;
         a.g_wenv = buf(w.g_envw);
         a.ld_gwe = W;
@@ -736,7 +791,7 @@ struct Runner {
       a.scatter_factor = sfac;
       a.x2s = buf(w.x2s[l]);
       a.gout = l < L - 1 ? buf(w.g_tf[l & 1]) : nullptr;
-      a.gscal = buf(w.g_scal);
+      a.gscal = buf(w.g_scal[l]);
       a.ld_gscal = u;
       if (l == 0) {
         a.g1.gw = buf(w.g_w0);

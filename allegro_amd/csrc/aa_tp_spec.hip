@@ -330,6 +330,297 @@ __global__ __launch_bounds__(256) void tp_spec_bwd_kernel(TpSpecBwdArgs a) {
   }
 }
 
+static unsigned spec_grid(int u, int64_t N) {
+  int64_t atoms_per_block = u >= 64 ? 4 / (u / 64) : 4 * (64 / u);
+  return (unsigned)((N + atoms_per_block - 1) / atoms_per_block);
+}
+
+// =============================================================================================
+// chain kernels for 2-layer stacks (Sig0: layer 0 with implicit x1, Sig1: last layer, DOUT == 1)
+// =============================================================================================
+namespace {
+template <class Sig0, typename T>
+__device__ __forceinline__ void chain_tf1(const T* y, const T* w0p, int u, bool act, const T* x2s0, const T* wp0, T* x1,
+                                          T* wr0, T* tf1) {
+  constexpr int R = Sig0::LMAX + 1;
+#pragma unroll
+  for (int r = 0; r < R; ++r) wr0[r] = act ? w0p[r * u] : T(0);
+#pragma unroll
+  for (int i = 0; i < Sig0::D1; ++i) x1[i] = y[i] * wr0[r_of<0>(i)];
+  Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void reduce_store(const T* gy, T* dst, const LaneMap& m, bool act, bool multi_wave) {
+  if (m.width == 64) {
+    wave_sum_store<T, D>(gy, dst, act, multi_wave);
+  } else {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      T v = group_sum<T>(gy[j], m.width);
+      if (m.leader && act) {
+        if (multi_wave)
+          atomicAdd(&dst[j], v);
+        else
+          dst[j] = v;
+      }
+    }
+  }
+}
+}  // namespace
+
+template <class Sig0, class Sig1, typename T>
+__global__ __launch_bounds__(256) void tp_chain_fwd_last_kernel(TpChainArgs a) {
+  static_assert(Sig1::DOUT == 1 && Sig0::DOUT == Sig1::D1 && Sig0::D2 == Sig1::D2, "chain signature mismatch");
+  constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
+  const int u = a.u;
+  const LaneMap m = lane_map(u, a.N);
+  int beg = 0, end = 0;
+  if (m.valid) {
+    beg = a.rowptr[m.atom];
+    end = a.rowptr[m.atom + 1];
+  }
+  const int ch = m.ch;
+  const T* sh = static_cast<const T*>(a.sh);
+  T x2s1[D], x2s0[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) x2s1[j] = T(0);
+  for (int s = beg; s < end; ++s) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    const T* we = static_cast<const T*>(a.wenv1) + int64_t(s) * a.ld_we1 + ch;
+    T wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = we[r * u];
+#pragma unroll
+    for (int j = 0; j < D; ++j) x2s1[j] += y[j] * wr[r_of<0>(j)];
+  }
+  const T sf = T(a.sf);
+  {
+    const int64_t base = (m.valid ? m.atom : 0) * D * int64_t(u) + ch;
+    const T* xi = static_cast<const T*>(a.x2s0) + base;
+    T* xo = static_cast<T*>(a.x2s1) + base;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s1[j] *= sf;
+      x2s0[j] = m.valid ? xi[int64_t(j) * u] : T(0);
+      if (m.valid) xo[int64_t(j) * u] = x2s1[j];
+    }
+  }
+  T wp0[Sig0::P], wp1[Sig1::P];
+  {
+    const T* W0 = static_cast<const T*>(a.weights0);
+    const T* W1 = static_cast<const T*>(a.weights1);
+#pragma unroll
+    for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[ch * Sig0::P + p] : W0[p];
+#pragma unroll
+    for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[ch * Sig1::P + p] : W1[p];
+  }
+  for (int s = beg; s < end; ++s) {
+    T x1[Sig0::D1], wr0[R], tf1[Sig0::DOUT], out[1];
+    chain_tf1<Sig0, T>(sh + int64_t(s) * a.ld_sh, static_cast<const T*>(a.w0) + int64_t(s) * a.ld_w0 + ch, u, true, x2s0, wp0,
+                       x1, wr0, tf1);
+    Sig1::template fwd<T>(tf1, x2s1, wp1, out);
+    static_cast<T*>(a.scal1)[int64_t(s) * a.ld_scal + ch] = out[0];
+  }
+}
+
+template <class Sig0, class Sig1, typename T>
+__global__ __launch_bounds__(256) void tp_chain_bwd_last_kernel(TpChainArgs a) {
+  constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
+  const int u = a.u;
+  const LaneMap m = lane_map(u, a.N);
+  int beg = 0, end = 0;
+  if (m.valid) {
+    beg = a.rowptr[m.atom];
+    end = a.rowptr[m.atom + 1];
+  }
+  const int deg = end - beg;
+  const int maxdeg = u >= 64 ? deg : wave_max(deg);
+  const int ch = m.ch;
+  const bool multi_wave = u > 64;
+  const T* sh = static_cast<const T*>(a.sh);
+  T x2s0[D], g2acc[D];
+  {
+    const T* xi = static_cast<const T*>(a.x2s0) + (m.valid ? m.atom : 0) * D * int64_t(u) + ch;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s0[j] = m.valid ? xi[int64_t(j) * u] : T(0);
+      g2acc[j] = T(0);
+    }
+  }
+  T wp0[Sig0::P], wp1[Sig1::P];
+  {
+    const T* W0 = static_cast<const T*>(a.weights0);
+    const T* W1 = static_cast<const T*>(a.weights1);
+#pragma unroll
+    for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[ch * Sig0::P + p] : W0[p];
+#pragma unroll
+    for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[ch * Sig1::P + p] : W1[p];
+  }
+  // pass 1: g2acc[j] = sum_e bx2_1(d_scal1[e], tf1[e])
+  for (int s = beg; s < end; ++s) {
+    T x1[Sig0::D1], wr0[R], tf1[Sig0::DOUT], go[1], g2[D];
+    chain_tf1<Sig0, T>(sh + int64_t(s) * a.ld_sh, static_cast<const T*>(a.w0) + int64_t(s) * a.ld_w0 + ch, u, true, x2s0, wp0,
+                       x1, wr0, tf1);
+    go[0] = static_cast<const T*>(a.gscal1)[int64_t(s) * a.ld_gscal + ch];
+    Sig1::template bx2<T>(go, tf1, wp1, g2);
+#pragma unroll
+    for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+  }
+  const T sf = T(a.sf);
+#pragma unroll
+  for (int j = 0; j < D; ++j) g2acc[j] *= sf;
+  // pass 2: adjoint of (scale, segment-sum, gather) and of the env weighting
+  for (int it = 0; it < maxdeg; ++it) {
+    const bool act = it < deg;
+    const int64_t s = act ? beg + it : 0;
+    const T* y = sh + s * a.ld_sh;
+    const T* we = static_cast<const T*>(a.wenv1) + s * a.ld_we1 + ch;
+    T wr[R], gw[R], gy[D];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      wr[r] = act ? we[r * u] : T(0);
+      gw[r] = T(0);
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gw[r_of<0>(j)] += y[j] * g2acc[j];
+      gy[j] = act ? wr[r_of<0>(j)] * g2acc[j] : T(0);
+    }
+    if (act) {
+      T* gwp = static_cast<T*>(a.g_wenv) + s * a.ld_gwe + ch;
+#pragma unroll
+      for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
+    }
+    reduce_store<T, D>(gy, static_cast<T*>(a.gsh_env) + s * a.ld_gsh, m, act, multi_wave);
+  }
+}
+
+template <class Sig0, class Sig1, typename T>
+__global__ __launch_bounds__(256) void tp_chain_bwd_first_kernel(TpChainArgs a) {
+  constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
+  const int u = a.u;
+  const LaneMap m = lane_map(u, a.N);
+  int beg = 0, end = 0;
+  if (m.valid) {
+    beg = a.rowptr[m.atom];
+    end = a.rowptr[m.atom + 1];
+  }
+  const int deg = end - beg;
+  const int maxdeg = u >= 64 ? deg : wave_max(deg);
+  const int ch = m.ch;
+  const bool multi_wave = u > 64;
+  const T* sh = static_cast<const T*>(a.sh);
+  T x2s0[D], x2s1[D], g2acc[D];
+  {
+    const int64_t base = (m.valid ? m.atom : 0) * D * int64_t(u) + ch;
+    const T* x0 = static_cast<const T*>(a.x2s0) + base;
+    const T* x1p = static_cast<const T*>(a.x2s1) + base;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s0[j] = m.valid ? x0[int64_t(j) * u] : T(0);
+      x2s1[j] = m.valid ? x1p[int64_t(j) * u] : T(0);
+      g2acc[j] = T(0);
+    }
+  }
+  T wp0[Sig0::P], wp1[Sig1::P];
+  {
+    const T* W0 = static_cast<const T*>(a.weights0);
+    const T* W1 = static_cast<const T*>(a.weights1);
+#pragma unroll
+    for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[ch * Sig0::P + p] : W0[p];
+#pragma unroll
+    for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[ch * Sig1::P + p] : W1[p];
+  }
+  for (int it = 0; it < maxdeg; ++it) {
+    const bool act = it < deg;
+    const int64_t s = act ? beg + it : 0;
+    const T* y = sh + s * a.ld_sh;
+    const T* w0p = static_cast<const T*>(a.w0) + s * a.ld_w0 + ch;
+    T x1[D1], wr0[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr0[r] = act ? w0p[r * u] : T(0);
+#pragma unroll
+    for (int i = 0; i < D1; ++i) x1[i] = y[i] * wr0[r_of<0>(i)];
+    // d_tf1 = bx1 of the last layer, recomputed from d_scal1 and x2s1 (never stored)
+    T gn[1], go[DOUT];
+    gn[0] = act ? static_cast<const T*>(a.gscal1)[s * a.ld_gscal + ch] : T(0);
+    Sig1::template bx1<T>(gn, x2s1, wp1, go);
+    if (act) go[0] += static_cast<const T*>(a.gscal0)[s * a.ld_gscal + ch];
+    T g1[D1], g2[D];
+    Sig0::template bx1<T>(go, x2s0, wp0, g1);
+    Sig0::template bx2<T>(go, x1, wp0, g2);
+#pragma unroll
+    for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+    T gw[R], gy[D1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) gw[r] = T(0);
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+      gw[r_of<0>(i)] += g1[i] * y[i];
+      gy[i] = act ? g1[i] * wr0[r_of<0>(i)] : T(0);
+    }
+    if (act) {
+      T* gwp = static_cast<T*>(a.g_w0) + s * a.ld_gw0 + ch;
+#pragma unroll
+      for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
+    }
+    reduce_store<T, D1>(gy, static_cast<T*>(a.gsh_x1) + s * a.ld_gsh, m, act, multi_wave);
+  }
+  const T sf = T(a.sf);
+#pragma unroll
+  for (int j = 0; j < D; ++j) g2acc[j] *= sf;
+  for (int it = 0; it < maxdeg; ++it) {
+    const bool act = it < deg;
+    const int64_t s = act ? beg + it : 0;
+    const T* y = sh + s * a.ld_sh;
+    const T* we = static_cast<const T*>(a.wenv0) + s * a.ld_we0 + ch;
+    T wr[R], gw[R], gy[D];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      wr[r] = act ? we[r * u] : T(0);
+      gw[r] = T(0);
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gw[r_of<0>(j)] += y[j] * g2acc[j];
+      gy[j] = act ? wr[r_of<0>(j)] * g2acc[j] : T(0);
+    }
+    if (act) {
+      T* gwp = static_cast<T*>(a.g_wenv) + s * a.ld_gwe + ch;
+#pragma unroll
+      for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
+    }
+    reduce_store<T, D>(gy, static_cast<T*>(a.gsh_env) + s * a.ld_gsh, m, act, multi_wave);
+  }
+}
+
+// (layer-0 signature, last-layer signature) pairs of 2-layer stacks at l_max = 1, 2, 3
+#define AA_FOREACH_CHAIN(X) X(0, Sig1, Sig0) X(1, Sig5, Sig4) X(2, Sig9, Sig8)
+int find_chain_pair(int sig0, int sig1) {
+  if (sig0 == 1 && sig1 == 0) return 0;
+  if (sig0 == 5 && sig1 == 4) return 1;
+  if (sig0 == 9 && sig1 == 8) return 2;
+  return -1;
+}
+
+#define AA_CHAIN_LAUNCHER(NAME)                                                                          \
+  template <typename T>                                                                                  \
+  int launch_##NAME(int pair, const TpChainArgs& a, hipStream_t stream) {                                \
+    if (a.N == 0) return AA_OK;                                                                          \
+    dim3 grid(spec_grid(a.u, a.N));                                                                      \
+    switch (pair) {                                                                                      \
+      case 0: hipLaunchKernelGGL((NAME##_kernel<cg::Sig1, cg::Sig0, T>), grid, dim3(256), 0, stream, a); break; \
+      case 1: hipLaunchKernelGGL((NAME##_kernel<cg::Sig5, cg::Sig4, T>), grid, dim3(256), 0, stream, a); break; \
+      case 2: hipLaunchKernelGGL((NAME##_kernel<cg::Sig9, cg::Sig8, T>), grid, dim3(256), 0, stream, a); break; \
+      default: return fail(AA_ERR_INVALID, #NAME ": unknown chain pair");                                \
+    }                                                                                                    \
+    AA_CHECK_HIP(hipGetLastError());                                                                     \
+    return AA_OK;                                                                                        \
+  }                                                                                                      \
+  template int launch_##NAME<float>(int, const TpChainArgs&, hipStream_t);                               \
+  template int launch_##NAME<double>(int, const TpChainArgs&, hipStream_t);
+
 // ---------------------------------------------------------------------------------------------
 int find_spec_sig(const aa_tp_desc& d) {
   if (d.mul < 1 || d.mul > 256 || (d.mul & (d.mul - 1)) != 0) return -1;  // power of two <= 256
@@ -353,10 +644,6 @@ int find_spec_sig(const aa_tp_desc& d) {
   return -1;
 }
 
-static unsigned spec_grid(int u, int64_t N) {
-  int64_t atoms_per_block = u >= 64 ? 4 / (u / 64) : 4 * (64 / u);
-  return (unsigned)((N + atoms_per_block - 1) / atoms_per_block);
-}
 
 template <typename T>
 int launch_tp_spec_fwd(int sig, const TpSpecFwdArgs& a, hipStream_t stream) {
@@ -393,6 +680,10 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
+
+AA_CHAIN_LAUNCHER(tp_chain_fwd_last)
+AA_CHAIN_LAUNCHER(tp_chain_bwd_last)
+AA_CHAIN_LAUNCHER(tp_chain_bwd_first)
 
 template int launch_tp_spec_fwd<float>(int, const TpSpecFwdArgs&, hipStream_t);
 template int launch_tp_spec_fwd<double>(int, const TpSpecFwdArgs&, hipStream_t);
