@@ -109,6 +109,9 @@ __device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, boo
   }
 }
 
+// wave-uniform value -> SGPR (so that addresses derived from it use the scalar memory path)
+__device__ __forceinline__ int uniform_if(bool uni, int v) { return uni ? __builtin_amdgcn_readfirstlane(v) : v; }
+
 template <int LMAX>
 __device__ __forceinline__ constexpr int r_of(int i) {
   return i < 1 ? 0 : (i < 4 ? 1 : (i < 9 ? 2 : 3));
@@ -369,6 +372,16 @@ __device__ __forceinline__ void reduce_store(const T* gy, T* dst, const LaneMap&
 }
 }  // namespace
 
+// per-edge operands fetched one edge ahead (software pipelining: the loads of edge s+1 are in flight
+// while edge s is being contracted)
+template <typename T, int D, int R>
+struct EdgeIn {
+  T y[D];
+  T wa[R];
+  T wb[R];
+  T g0, g1;
+};
+
 template <class Sig0, class Sig1, typename T>
 __global__ __launch_bounds__(256) void tp_chain_fwd_last_kernel(TpChainArgs a) {
   static_assert(Sig1::DOUT == 1 && Sig0::DOUT == Sig1::D1 && Sig0::D2 == Sig1::D2, "chain signature mismatch");
@@ -380,14 +393,20 @@ __global__ __launch_bounds__(256) void tp_chain_fwd_last_kernel(TpChainArgs a) {
     beg = a.rowptr[m.atom];
     end = a.rowptr[m.atom + 1];
   }
+  const bool uni = u >= 64;
+  beg = uniform_if(uni, beg);
+  end = uniform_if(uni, end);
   const int ch = m.ch;
   const T* sh = static_cast<const T*>(a.sh);
+  const T* w0g = static_cast<const T*>(a.w0) + ch;
+  const T* we1 = static_cast<const T*>(a.wenv1) + ch;
   T x2s1[D], x2s0[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) x2s1[j] = T(0);
+#pragma unroll 4
   for (int s = beg; s < end; ++s) {
     const T* y = sh + int64_t(s) * a.ld_sh;
-    const T* we = static_cast<const T*>(a.wenv1) + int64_t(s) * a.ld_we1 + ch;
+    const T* we = we1 + int64_t(s) * a.ld_we1;
     T wr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wr[r] = we[r * u];
@@ -415,12 +434,27 @@ __global__ __launch_bounds__(256) void tp_chain_fwd_last_kernel(TpChainArgs a) {
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[ch * Sig1::P + p] : W1[p];
   }
-  for (int s = beg; s < end; ++s) {
-    T x1[Sig0::D1], wr0[R], tf1[Sig0::DOUT], out[1];
-    chain_tf1<Sig0, T>(sh + int64_t(s) * a.ld_sh, static_cast<const T*>(a.w0) + int64_t(s) * a.ld_w0 + ch, u, true, x2s0, wp0,
-                       x1, wr0, tf1);
-    Sig1::template fwd<T>(tf1, x2s1, wp1, out);
-    static_cast<T*>(a.scal1)[int64_t(s) * a.ld_scal + ch] = out[0];
+  auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    const T* w0p = w0g + int64_t(s) * a.ld_w0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) in.y[j] = y[j];
+#pragma unroll
+    for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * u];
+  };
+  if (beg < end) {
+    EdgeIn<T, D, R> cur, nxt;
+    fetch(beg, cur);
+    for (int s = beg; s < end; ++s) {
+      fetch(s + 1 < end ? s + 1 : s, nxt);
+      T x1[Sig0::D1], tf1[Sig0::DOUT], out[1];
+#pragma unroll
+      for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
+      Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
+      Sig1::template fwd<T>(tf1, x2s1, wp1, out);
+      static_cast<T*>(a.scal1)[int64_t(s) * a.ld_scal + ch] = out[0];
+      cur = nxt;
+    }
   }
 }
 
@@ -434,11 +468,17 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_last_kernel(TpChainArgs a) {
     beg = a.rowptr[m.atom];
     end = a.rowptr[m.atom + 1];
   }
+  const bool uni = u >= 64;
+  beg = uniform_if(uni, beg);
+  end = uniform_if(uni, end);
   const int deg = end - beg;
-  const int maxdeg = u >= 64 ? deg : wave_max(deg);
+  const int maxdeg = uni ? deg : wave_max(deg);
   const int ch = m.ch;
   const bool multi_wave = u > 64;
   const T* sh = static_cast<const T*>(a.sh);
+  const T* w0g = static_cast<const T*>(a.w0) + ch;
+  const T* we1 = static_cast<const T*>(a.wenv1) + ch;
+  const T* gs1 = static_cast<const T*>(a.gscal1) + ch;
   T x2s0[D], g2acc[D];
   {
     const T* xi = static_cast<const T*>(a.x2s0) + (m.valid ? m.atom : 0) * D * int64_t(u) + ch;
@@ -458,14 +498,32 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_last_kernel(TpChainArgs a) {
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[ch * Sig1::P + p] : W1[p];
   }
   // pass 1: g2acc[j] = sum_e bx2_1(d_scal1[e], tf1[e])
-  for (int s = beg; s < end; ++s) {
-    T x1[Sig0::D1], wr0[R], tf1[Sig0::DOUT], go[1], g2[D];
-    chain_tf1<Sig0, T>(sh + int64_t(s) * a.ld_sh, static_cast<const T*>(a.w0) + int64_t(s) * a.ld_w0 + ch, u, true, x2s0, wp0,
-                       x1, wr0, tf1);
-    go[0] = static_cast<const T*>(a.gscal1)[int64_t(s) * a.ld_gscal + ch];
-    Sig1::template bx2<T>(go, tf1, wp1, g2);
+  {
+    auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
+      const T* y = sh + int64_t(s) * a.ld_sh;
+      const T* w0p = w0g + int64_t(s) * a.ld_w0;
 #pragma unroll
-    for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+      for (int j = 0; j < D; ++j) in.y[j] = y[j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * u];
+      in.g1 = gs1[int64_t(s) * a.ld_gscal];
+    };
+    if (beg < end) {
+      EdgeIn<T, D, R> cur, nxt;
+      fetch(beg, cur);
+      for (int s = beg; s < end; ++s) {
+        fetch(s + 1 < end ? s + 1 : s, nxt);
+        T x1[Sig0::D1], tf1[Sig0::DOUT], go[1], g2[D];
+#pragma unroll
+        for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
+        Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
+        go[0] = cur.g1;
+        Sig1::template bx2<T>(go, tf1, wp1, g2);
+#pragma unroll
+        for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+        cur = nxt;
+      }
+    }
   }
   const T sf = T(a.sf);
 #pragma unroll
@@ -475,7 +533,7 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_last_kernel(TpChainArgs a) {
     const bool act = it < deg;
     const int64_t s = act ? beg + it : 0;
     const T* y = sh + s * a.ld_sh;
-    const T* we = static_cast<const T*>(a.wenv1) + s * a.ld_we1 + ch;
+    const T* we = we1 + s * a.ld_we1;
     T wr[R], gw[R], gy[D];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -506,11 +564,17 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_first_kernel(TpChainArgs a) 
     beg = a.rowptr[m.atom];
     end = a.rowptr[m.atom + 1];
   }
+  const bool uni = u >= 64;
+  beg = uniform_if(uni, beg);
+  end = uniform_if(uni, end);
   const int deg = end - beg;
-  const int maxdeg = u >= 64 ? deg : wave_max(deg);
+  const int maxdeg = uni ? deg : wave_max(deg);
   const int ch = m.ch;
   const bool multi_wave = u > 64;
   const T* sh = static_cast<const T*>(a.sh);
+  const T* w0g = static_cast<const T*>(a.w0) + ch;
+  const T* gs0 = static_cast<const T*>(a.gscal0) + ch;
+  const T* gs1 = static_cast<const T*>(a.gscal1) + ch;
   T x2s0[D], x2s1[D], g2acc[D];
   {
     const int64_t base = (m.valid ? m.atom : 0) * D * int64_t(u) + ch;
@@ -532,49 +596,63 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_first_kernel(TpChainArgs a) 
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[ch * Sig1::P + p] : W1[p];
   }
-  for (int it = 0; it < maxdeg; ++it) {
-    const bool act = it < deg;
-    const int64_t s = act ? beg + it : 0;
-    const T* y = sh + s * a.ld_sh;
-    const T* w0p = static_cast<const T*>(a.w0) + s * a.ld_w0 + ch;
-    T x1[D1], wr0[R];
+  {
+    auto fetch = [&](int64_t s, bool act, EdgeIn<T, D, R>& in) {
+      const T* y = sh + s * a.ld_sh;
+      const T* w0p = w0g + s * a.ld_w0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) wr0[r] = act ? w0p[r * u] : T(0);
+      for (int j = 0; j < D; ++j) in.y[j] = y[j];
 #pragma unroll
-    for (int i = 0; i < D1; ++i) x1[i] = y[i] * wr0[r_of<0>(i)];
-    // d_tf1 = bx1 of the last layer, recomputed from d_scal1 and x2s1 (never stored)
-    T gn[1], go[DOUT];
-    gn[0] = act ? static_cast<const T*>(a.gscal1)[s * a.ld_gscal + ch] : T(0);
-    Sig1::template bx1<T>(gn, x2s1, wp1, go);
-    if (act) go[0] += static_cast<const T*>(a.gscal0)[s * a.ld_gscal + ch];
-    T g1[D1], g2[D];
-    Sig0::template bx1<T>(go, x2s0, wp0, g1);
-    Sig0::template bx2<T>(go, x1, wp0, g2);
+      for (int r = 0; r < R; ++r) in.wa[r] = act ? w0p[r * u] : T(0);
+      in.g0 = act ? gs0[s * a.ld_gscal] : T(0);
+      in.g1 = act ? gs1[s * a.ld_gscal] : T(0);
+    };
+    EdgeIn<T, D, R> cur, nxt;
+    fetch(0 < deg ? beg : 0, 0 < deg, cur);
+    for (int it = 0; it < maxdeg; ++it) {
+      const bool act = it < deg;
+      const int64_t s = act ? beg + it : 0;
+      const bool actn = it + 1 < deg;
+      fetch(actn ? beg + it + 1 : 0, actn, nxt);
+      T x1[D1];
 #pragma unroll
-    for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
-    T gw[R], gy[D1];
+      for (int i = 0; i < D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
+      // d_tf1 = bx1 of the last layer, recomputed from d_scal1 and x2s1 (never stored)
+      T gn[1], go[DOUT];
+      gn[0] = cur.g1;
+      Sig1::template bx1<T>(gn, x2s1, wp1, go);
+      go[0] += cur.g0;
+      T g1[D1], g2[D];
+      Sig0::template bx1<T>(go, x2s0, wp0, g1);
+      Sig0::template bx2<T>(go, x1, wp0, g2);
 #pragma unroll
-    for (int r = 0; r < R; ++r) gw[r] = T(0);
+      for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+      T gw[R], gy[D1];
 #pragma unroll
-    for (int i = 0; i < D1; ++i) {
-      gw[r_of<0>(i)] += g1[i] * y[i];
-      gy[i] = act ? g1[i] * wr0[r_of<0>(i)] : T(0);
+      for (int r = 0; r < R; ++r) gw[r] = T(0);
+#pragma unroll
+      for (int i = 0; i < D1; ++i) {
+        gw[r_of<0>(i)] += g1[i] * cur.y[i];
+        gy[i] = act ? g1[i] * cur.wa[r_of<0>(i)] : T(0);
+      }
+      if (act) {
+        T* gwp = static_cast<T*>(a.g_w0) + s * a.ld_gw0 + ch;
+#pragma unroll
+        for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
+      }
+      reduce_store<T, D1>(gy, static_cast<T*>(a.gsh_x1) + s * a.ld_gsh, m, act, multi_wave);
+      cur = nxt;
     }
-    if (act) {
-      T* gwp = static_cast<T*>(a.g_w0) + s * a.ld_gw0 + ch;
-#pragma unroll
-      for (int r = 0; r < R; ++r) gwp[r * u] = gw[r];
-    }
-    reduce_store<T, D1>(gy, static_cast<T*>(a.gsh_x1) + s * a.ld_gsh, m, act, multi_wave);
   }
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
+  const T* we0 = static_cast<const T*>(a.wenv0) + ch;
   for (int it = 0; it < maxdeg; ++it) {
     const bool act = it < deg;
     const int64_t s = act ? beg + it : 0;
     const T* y = sh + s * a.ld_sh;
-    const T* we = static_cast<const T*>(a.wenv0) + s * a.ld_we0 + ch;
+    const T* we = we0 + s * a.ld_we0;
     T wr[R], gw[R], gy[D];
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -141,6 +141,7 @@ inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_v16f 
   return d;
 }
 
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on wave-uniform values
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
