@@ -82,6 +82,7 @@ struct GemmArgs {
   SegList a;       // K split
   const void* B;   // [K,N] row-major
   const void* Bp;  // optional: B in MFMA fragment order [ceil(N/32)][ceil(K/32)][64 lanes][16] (f32 fast path)
+  const void* Bq;  // optional: the same fragments split into 3 bf16 levels (bf16x3 path, aa_gemm.hip)
   SegList c;       // N split
   int c_accum[3];  // per C segment: 1 -> +=
   int has_z;       // multiply result by dsilu(z) (z split like c)
@@ -93,6 +94,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream);
 // element count of the fragment-ordered copy of a [K,N] matrix, and the host-side packer
 size_t gemm_packed_elems(int K, int N);
 void gemm_pack_b(const double* B, int K, int N, double* out);
+size_t gemm_bf16x3_words(int K, int N);
+void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out);
 
 // ----------------------------------------------------------------------------------------------
 // Sparse trilinear (Clebsch-Gordan) tables on device

@@ -463,6 +463,172 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int v
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores by exact 3-way splitting ("bf16x3").
+// Every fp32 value is the exact sum of three bf16 numbers (x = x1 + x2 + x3: 3 x 8 significand bits,
+// obtained by truncation and exact residuals).  x*w is reproduced to ~2^-24 by the 6 leading cross
+// products x1w1, x1w2, x2w1, x1w3, x2w2, x3w1, each exact in fp32 and accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs (K=16, 32 cycles/SIMD) replace sixteen fp32 MFMAs (K=2,
+// 64 cycles) per 32-deep chunk and tile pair: 2.7x less matrix-pipe time at fp32-class accuracy.
+// Same data flow as v3: activation fragments straight from global (64 contiguous bytes per lane and
+// chunk), weights pre-split and pre-permuted on the host, swapped operands, 16-B epilogue accesses.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+
+// 16 floats -> three levels of 8 packed bf16 pairs (element 2q in the low half, 2q+1 in the high half)
+__device__ __forceinline__ void split3_pack(const v4f* a, u32x4* lv1, u32x4* lv2, u32x4* lv3) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    u32x4 o1, o2, o3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h1[2], h2[2], h3[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = half * 8 + q * 2 + e;
+        const float x = a[idx >> 2][idx & 3];
+        h1[e] = f2u(x) & 0xFFFF0000u;
+        const float r = x - u2f(h1[e]);
+        h2[e] = f2u(r) & 0xFFFF0000u;
+        const float r2 = r - u2f(h2[e]);
+        h3[e] = f2u(r2) & 0xFFFF0000u;
+      }
+      o1[q] = (h1[0] >> 16) | h1[1];
+      o2[q] = (h2[0] >> 16) | h2[1];
+      o3[q] = (h3[0] >> 16) | h3[1];
+    }
+    lv1[half] = o1;
+    lv2[half] = o2;
+    lv3[half] = o3;
+  }
+}
+
+__device__ __forceinline__ v16f mma_bf16(const u32x4& w, const u32x4& x, v16f acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+
+// one 32-deep chunk of one tile: 2 k-halves x 6 cross products
+__device__ __forceinline__ v16f chunk_bf16x3(const u32x4* w /*[3][2]*/, const u32x4* x1, const u32x4* x2, const u32x4* x3,
+                                             v16f acc) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    acc = mma_bf16(w[4 + half], x1[half], acc);  // w3 x1
+    acc = mma_bf16(w[2 + half], x2[half], acc);  // w2 x2
+    acc = mma_bf16(w[0 + half], x3[half], acc);  // w1 x3
+    acc = mma_bf16(w[2 + half], x1[half], acc);  // w2 x1
+    acc = mma_bf16(w[0 + half], x2[half], acc);  // w1 x2
+    acc = mma_bf16(w[0 + half], x1[half], acc);  // w1 x1
+  }
+  return acc;
+}
+
+// weights: Wq[tile][chunk][lane][level 0..2][half 0..1] as u32x4 (6 x 16 B per lane and chunk)
+template <int KCR>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x4* __restrict__ Wq, int vec_ok) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
+  const int64_t gm = m0 + (lane & 31);
+  const int kh = (lane >> 5) * 16;
+  const int KC = (g.K + 31) >> 5;
+  const int NT = (g.N + 31) >> 5;
+  const u32x4* Wl = Wq + size_t(lane) * 6;
+  const size_t chunk_stride = 64 * 6;                    // u32x4 units between chunks
+  const size_t tile_stride = size_t(KC) * chunk_stride;  // between feature tiles
+  u32x4 xr1[KCR > 0 ? KCR : 1][2], xr2[KCR > 0 ? KCR : 1][2], xr3[KCR > 0 ? KCR : 1][2];
+  if (KCR > 0) {
+#pragma unroll
+    for (int kc = 0; kc < KCR; ++kc) {
+      v4f a[4];
+      load_a_frag(g, gm, kc * 32 + kh, a);
+      split3_pack(a, xr1[kc], xr2[kc], xr3[kc]);
+    }
+  }
+  for (int nt = 0; nt < NT; nt += 2) {
+    const bool two = nt + 1 < NT;
+    v16f acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = 0.f;
+      acc1[r] = 0.f;
+    }
+    const u32x4* wp0 = Wl + size_t(nt) * tile_stride;
+    const u32x4* wp1 = Wl + size_t(two ? nt + 1 : nt) * tile_stride;
+    if (KCR > 0) {
+#pragma unroll
+      for (int kc = 0; kc < KCR; ++kc) {
+        if (kc < KC) {
+          u32x4 w0[6], w1[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            w0[q] = wp0[size_t(kc) * chunk_stride + q];
+            w1[q] = wp1[size_t(kc) * chunk_stride + q];
+          }
+          acc0 = chunk_bf16x3(w0, xr1[kc], xr2[kc], xr3[kc], acc0);
+          acc1 = chunk_bf16x3(w1, xr1[kc], xr2[kc], xr3[kc], acc1);
+        }
+      }
+    } else {
+      v4f a[4];
+      load_a_frag(g, gm, kh, a);
+      for (int kc = 0; kc < KC; ++kc) {
+        u32x4 x1[2], x2[2], x3[2], w0[6], w1[6];
+        split3_pack(a, x1, x2, x3);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          w0[q] = wp0[size_t(kc) * chunk_stride + q];
+          w1[q] = wp1[size_t(kc) * chunk_stride + q];
+        }
+        const int kn = kc + 1 < KC ? kc + 1 : kc;
+        load_a_frag(g, gm, kn * 32 + kh, a);  // next chunk's activations in flight during the MFMAs
+        acc0 = chunk_bf16x3(w0, x1, x2, x3, acc0);
+        acc1 = chunk_bf16x3(w1, x1, x2, x3, acc1);
+      }
+    }
+    store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
+    if (two) store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok);
+  }
+}
+
+// element count (32-bit words) of the split weight copy, and the host-side packer (from the fp32 matrix)
+size_t gemm_bf16x3_words(int K, int N) { return size_t((N + 31) / 32) * size_t((K + 31) / 32) * 64 * 24; }
+void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out) {
+  const int NT = (N + 31) / 32, KC = (K + 31) / 32;
+  auto trunc = [](float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    return u & 0xFFFF0000u;
+  };
+  auto tof = [](unsigned u) {
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+  };
+  for (int nt = 0; nt < NT; ++nt)
+    for (int kc = 0; kc < KC; ++kc)
+      for (int lane = 0; lane < 64; ++lane) {
+        unsigned* o = out + ((size_t(nt) * KC + kc) * 64 + lane) * 24;  // [level][half][4 words]
+        for (int half = 0; half < 2; ++half)
+          for (int q = 0; q < 4; ++q) {
+            unsigned h[3][2];
+            for (int e = 0; e < 2; ++e) {
+              int s = half * 8 + q * 2 + e;
+              int k = kc * 32 + (lane >> 5) * 16 + s, n = nt * 32 + (lane & 31);
+              float x = (k < K && n < N) ? B[size_t(k) * N + n] : 0.f;
+              h[0][e] = trunc(x);
+              float r = x - tof(h[0][e]);
+              h[1][e] = trunc(r);
+              float r2 = r - tof(h[1][e]);
+              h[2][e] = trunc(r2);
+            }
+            for (int lv = 0; lv < 3; ++lv) o[(lv * 2 + half) * 4 + q] = (h[lv][0] >> 16) | h[lv][1];
+          }
+      }
+}
+
 size_t gemm_packed_elems(int K, int N) { return size_t((N + 31) / 32) * size_t((K + 31) / 32) * 64 * 16; }
 
 // out[nt][kc][lane][s] = B[kc*32 + (lane>>5)*16 + s][nt*32 + (lane&31)]   (zero padded)
@@ -527,7 +693,20 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
       if (g.has_z && ((g.z.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.z.s[s].p) & 15))) vec_ok = 0;
     }
     const int KC = (g.K + 31) / 32;
-    if (KC <= 2)
+    static int no_split = -1;
+    if (no_split < 0) {
+      const char* e = getenv("AA_GEMM_FP32_MFMA");
+      no_split = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (g.Bq && !no_split) {
+      const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
+      if (KC <= 2)
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, grid, dim3(256), 0, stream, g, Wq, vec_ok);
+      else if (KC <= 4)
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, grid, dim3(256), 0, stream, g, Wq, vec_ok);
+      else
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, dim3(256), 0, stream, g, Wq, vec_ok);
+    } else if (KC <= 2)
       hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<2>, grid, dim3(256), 0, stream, g, vec_ok);
     else if (KC <= 4)
       hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<4>, grid, dim3(256), 0, stream, g, vec_ok);

@@ -95,7 +95,8 @@ extern "C" int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, cons
 struct MlpLayout {
   std::vector<int> dims;        // d_0 .. d_n
   std::vector<size_t> w, wt;    // blob offsets (elements) of W_i [d_i,d_{i+1}] and its transpose
-  std::vector<size_t> wp, wtp;  // the same two matrices in MFMA fragment order (aa_gemm.hip v2)
+  std::vector<size_t> wp, wtp;  // the same two matrices in MFMA fragment order (aa_gemm.hip v3)
+  std::vector<size_t> wq, wtq;  // ... and split into 3 bf16 levels (bf16x3 path; fp32 plans only)
 };
 
 struct aa_model_plan {
@@ -106,7 +107,7 @@ struct aa_model_plan {
   std::vector<TpLayerDev> layers;
   std::vector<void*> owned;
   // weight blob layout (element offsets)
-  size_t o_rmax, o_bessel, o_cemb, o_nemb, o_basis, o_g0, o_g0t, o_g0p, o_g0tp, o_ro_last, o_scales, o_shifts, n_elems;
+  size_t o_rmax, o_bessel, o_cemb, o_nemb, o_basis, o_g0, o_g0t, o_g0p, o_g0tp, o_g0q, o_g0tq, o_ro_last, o_scales, o_shifts, n_elems;
   size_t o_tpw[AA_MAX_LAYERS];
   MlpLayout embed, readout;          // readout: only the GEMM layers (all but the final ->1 layer)
   MlpLayout latent[AA_MAX_LAYERS];
@@ -190,6 +191,8 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
       m.wt.push_back(take(size_t(dims[i]) * dims[i + 1]));
       m.wp.push_back(take(gemm_packed_elems(dims[i], dims[i + 1])));
       m.wtp.push_back(take(gemm_packed_elems(dims[i + 1], dims[i])));
+      m.wq.push_back(take(gemm_bf16x3_words(dims[i], dims[i + 1])));
+      m.wtq.push_back(take(gemm_bf16x3_words(dims[i + 1], dims[i])));
     }
   };
   lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
@@ -197,6 +200,8 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_g0t = take(size_t(S) * (S + 2 * p->W));
   p->o_g0p = take(gemm_packed_elems(S, S + 2 * p->W));
   p->o_g0tp = take(gemm_packed_elems(S + 2 * p->W, S));
+  p->o_g0q = take(gemm_bf16x3_words(S, S + 2 * p->W));
+  p->o_g0tq = take(gemm_bf16x3_words(S + 2 * p->W, S));
   for (int l = 0; l < L; ++l) {
     int in = S * (l + 1) + u, outd = S + (l < L - 1 ? p->W : 0);
     lay(p->latent[l], mlp_dims(in, cfg->latent_mlp_depth, cfg->latent_mlp_width, outd), cfg->latent_mlp_depth + 1);
@@ -315,6 +320,21 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
   } else {
     std::vector<float> hf(h.begin(), h.end());
+    // bf16x3 copies are derived from the ROUNDED fp32 matrices (bit patterns stored in float slots)
+    auto splitw = [&](size_t w_off, int K, int N, size_t q_off) {
+      gemm_pack_bf16x3(&hf[w_off], K, N, reinterpret_cast<unsigned*>(&hf[q_off]));
+    };
+    auto split_mlp = [&](const MlpLayout& m, int nlayers) {
+      for (int i = 0; i < nlayers; ++i) {
+        splitw(m.w[i], m.dims[i], m.dims[i + 1], m.wq[i]);
+        splitw(m.wt[i], m.dims[i + 1], m.dims[i], m.wtq[i]);
+      }
+    };
+    split_mlp(p->embed, c.embed_mlp_depth + 1);
+    splitw(p->o_g0, S, S + 2 * W, p->o_g0q);
+    splitw(p->o_g0t, S + 2 * W, S, p->o_g0tq);
+    for (int l = 0; l < L; ++l) split_mlp(p->latent[l], c.latent_mlp_depth + 1);
+    split_mlp(p->readout, c.readout_mlp_depth);
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
   }
   AA_CHECK_HIP(hipStreamSynchronize(s));  // host staging vectors die at return
@@ -432,8 +452,8 @@ struct Runner {
   T* buf(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   const T* wt(size_t off) const { return wts + off; }
 
-  int gemm(const SegList& a, int act_a, const T* B, const T* Bp, int K, int Nn, const SegList& c, const int* accum,
-           const SegList* z) {
+  int gemm(const SegList& a, int act_a, const T* B, const T* Bp, const T* Bq, int K, int Nn, const SegList& c,
+           const int* accum, const SegList* z) {
     GemmArgs g{};
     g.M = E;
     g.K = K;
@@ -441,6 +461,7 @@ struct Runner {
     g.a = a;
     g.B = B;
     g.Bp = Bp;
+    g.Bq = sizeof(T) == 4 ? Bq : nullptr;
     g.c = c;
     for (int i = 0; i < 3; ++i) g.c_accum[i] = accum ? accum[i] : 0;
     g.has_z = z ? 1 : 0;
@@ -464,7 +485,7 @@ struct Runner {
       } else {
         c = out;
       }
-      if (int rc = gemm(a, i > 0, wt(m.w[i]), wt(m.wp[i]), m.dims[i], m.dims[i + 1], c, nullptr, nullptr)) return rc;
+      if (int rc = gemm(a, i > 0, wt(m.w[i]), wt(m.wp[i]), wt(m.wq[i]), m.dims[i], m.dims[i + 1], c, nullptr, nullptr)) return rc;
       a = c;
     }
     return AA_OK;
@@ -488,7 +509,7 @@ struct Runner {
         c = g_in;
         acc = g_in_accum;
       }
-      if (int rc = gemm(a, 0, wt(m.wt[i]), wt(m.wtp[i]), m.dims[i + 1], m.dims[i], c, acc, zp)) return rc;
+      if (int rc = gemm(a, 0, wt(m.wt[i]), wt(m.wtp[i]), wt(m.wtq[i]), m.dims[i + 1], m.dims[i], c, acc, zp)) return rc;
       a = c;
     }
     return AA_OK;
@@ -603,7 +624,7 @@ struct Runner {
     {
       SegList in{1, {seg(buf(w.emb), S, S)}};
       SegList out{3, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W), seg(buf(w.envw[0]), W, W)}};
-      if (int rc = gemm(in, 0, wt(p->o_g0), wt(p->o_g0p), S, S + 2 * W, out, nullptr, nullptr)) return rc;
+      if (int rc = gemm(in, 0, wt(p->o_g0), wt(p->o_g0p), wt(p->o_g0q), S, S + 2 * W, out, nullptr, nullptr)) return rc;
     }
     // 5: layers
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
@@ -667,7 +688,7 @@ struct Runner {
       SegList a{1, {seg(buf(w.fcat), SL1, SL1)}};
       for (int i = 0; i < c.readout_mlp_depth; ++i) {
         SegList cs{1, {seg(buf(w.ro_h[i]), c.readout_mlp_width, c.readout_mlp_width)}};
-        if (int rc = gemm(a, i > 0, wt(p->readout.w[i]), wt(p->readout.wp[i]), p->readout.dims[i], p->readout.dims[i + 1], cs,
+        if (int rc = gemm(a, i > 0, wt(p->readout.w[i]), wt(p->readout.wp[i]), wt(p->readout.wq[i]), p->readout.dims[i], p->readout.dims[i + 1], cs,
                           nullptr, nullptr))
           return rc;
         a = cs;
@@ -704,7 +725,7 @@ struct Runner {
           } else {
             cs = SegList{1, {seg(buf(w.g_fcat), SL1, SL1)}};
           }
-          if (int rc = gemm(a, 0, wt(p->readout.wt[i]), wt(p->readout.wtp[i]), p->readout.dims[i + 1], p->readout.dims[i], cs,
+          if (int rc = gemm(a, 0, wt(p->readout.wt[i]), wt(p->readout.wtp[i]), wt(p->readout.wtq[i]), p->readout.dims[i + 1], p->readout.dims[i], cs,
                             nullptr, zp))
             return rc;
           a = cs;
@@ -812,7 +833,7 @@ struct Runner {
     {
       SegList go{3, {seg(buf(w.g_fcat), SL1, S), seg(buf(w.g_w0), W, W), seg(buf(w.g_envw), W, W)}};
       SegList gi{1, {seg(buf(w.g_emb), S, S)}};
-      if (int rc = gemm(go, 0, wt(p->o_g0t), wt(p->o_g0tp), S + 2 * W, S, gi, nullptr, nullptr)) return rc;
+      if (int rc = gemm(go, 0, wt(p->o_g0t), wt(p->o_g0tp), wt(p->o_g0tq), S + 2 * W, S, gi, nullptr, nullptr)) return rc;
     }
     // scalar_embed_mlp reverse
     {

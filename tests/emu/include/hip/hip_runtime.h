@@ -141,6 +141,31 @@ inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_v16f 
   return d;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=8*(l>>5)+e] and B[k=8*(l>>5)+e][j=l&31], e=0..7
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_v16f c, int, int, int) {
+  int l = emu::lane(), w = emu::wave();
+  // 2 x 16 bytes per lane -> the 4-double slot
+  memcpy(emu::slot(w, l), &a, 16);
+  memcpy(reinterpret_cast<char*>(emu::slot(w, l)) + 16, &b, 16);
+  emu::wave_rendezvous();
+  emu_v16f d = c;
+  int j = l & 31;
+  auto bf = [](unsigned short h) { unsigned u = unsigned(h) << 16; float f; memcpy(&f, &u, 4); return f; };
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int h = 0; h < 2; ++h) {
+      unsigned short av[8], bv[8];
+      memcpy(av, emu::slot(w, i + 32 * h), 16);
+      memcpy(bv, reinterpret_cast<char*>(emu::slot(w, j + 32 * h)) + 16, 16);
+      for (int e = 0; e < 8; ++e) acc += bf(av[e]) * bf(bv[e]);
+    }
+    d[r] = acc;
+  }
+  emu::wave_rendezvous();
+  return d;
+}
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on wave-uniform values
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
