@@ -112,11 +112,18 @@ def profile_stages(model, pos, graph):
 
 
 def roofline_from_stages(stages, E, N, cfg, dtype):
-    """Aggregate per kernel symbol; report the dominant one against its roofline.
-    Algorithmic work per launch: GEMM 2*K*N flop/edge; TP layers: bytes of their operands."""
+    """Aggregate the per-launch HIP-event times per kernel symbol and report the dominant symbol against
+    its roofline.  Algorithmic work per launch: GEMM 2*K*N flop and (K+N) elements per
+    edge; tensor-product kernels: the operand rows they must read/write per edge."""
     u, S, L, l_max = cfg["num_tensor_features"], cfg["num_scalar_features"], cfg["num_layers"], cfg["l_max"]
     es = 4 if dtype == "float32" else 8
     D, W = (l_max + 1) ** 2, (l_max + 1) * u
+    tp_bytes = {  # elements per edge (+ per-atom x2s rows)
+        "tp_layer_fwd": 2 * W + D + u * D + u, "tp_layer_bwd": 4 * W + 2 * D + 2 * u * D + u,
+        "tp_spec_fwd": 2 * W + D + u, "tp_spec_bwd": 4 * W + 3 * D + 2 * u * D + u,
+        "tp_chain_fwd_last": 2 * W + D + u, "tp_chain_bwd_last": 3 * W + 2 * D + u,
+        "tp_chain_bwd_first": 4 * W + 3 * D + 2 * u,
+    }
     by_sym = {}
     for name, ms in stages:
         sym = "gemm" if name.startswith("gemm_") else name
@@ -127,22 +134,19 @@ def roofline_from_stages(stages, E, N, cfg, dtype):
             k, n = (int(x) for x in name[5:].split("x"))
             d["flops"] += 2.0 * E * k * n
             d["bytes"] += es * (E * (k + n) + k * n)
-        elif sym == "tp_layer_fwd":
-            # reads x1 (implicit: w [E,W] | dense [E,u,D]), env weights [E,W], sh; writes out [E,u,D] + scalars
-            d["bytes"] += es * E * (W + W + D + u * D + u)
-        elif sym == "tp_layer_bwd":
-            d["bytes"] += es * E * (2 * W + D + 2 * u * D + u + 2 * W + D)
-    dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-    sym, d = dom
+        elif sym in tp_bytes:
+            d["bytes"] += es * (E * tp_bytes[sym] + 2 * N * u * D)
+    sym, d = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
     t = d["ms"] * 1e-3 / max(d["launches"], 1)
     if sym == "gemm":
         peak = PEAK_F32_TFLOPS if dtype == "float32" else PEAK_F64_TFLOPS
         ach = d["flops"] / max(d["launches"], 1) / t / 1e12
         roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None)
+        roof["algorithmic_GBps"] = d["bytes"] / max(d["launches"], 1) / t / 1e9
     else:
         ach = d["bytes"] / max(d["launches"], 1) / t / 1e9
         roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None)
-    roof["kernel"] = sym
+    roof["kernel"] = {"gemm": "gemm_bf16x3_kernel / gemm_mfma_f32_v3_kernel (all scalar-MLP GEMM launches of a step)"}.get(sym, sym)
     roof["avg_launch_ms"] = d["ms"] / max(d["launches"], 1)
     roof["launches_per_step"] = d["launches"]
     table = {k: dict(ms=round(v["ms"], 4), launches=v["launches"]) for k, v in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])}
