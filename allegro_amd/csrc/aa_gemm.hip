@@ -511,19 +511,23 @@ __device__ __forceinline__ v16f mma_bf16(const u32x4& w, const u32x4& x, v16f ac
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
 
-// one 32-deep chunk of one tile: 2 k-halves x 6 cross products
-__device__ __forceinline__ v16f chunk_bf16x3(const u32x4* w /*[3][2]*/, const u32x4* x1, const u32x4* x2, const u32x4* x3,
-                                             v16f acc) {
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    acc = mma_bf16(w[4 + half], x1[half], acc);  // w3 x1
-    acc = mma_bf16(w[2 + half], x2[half], acc);  // w2 x2
-    acc = mma_bf16(w[0 + half], x3[half], acc);  // w1 x3
-    acc = mma_bf16(w[2 + half], x1[half], acc);  // w2 x1
-    acc = mma_bf16(w[0 + half], x2[half], acc);  // w1 x2
-    acc = mma_bf16(w[0 + half], x1[half], acc);  // w1 x1
-  }
-  return acc;
+// one 32-deep chunk of a tile pair: 2 k-halves x 6 cross products per tile, issued round-robin over FOUR
+// independent accumulator chains (tile 0/1 x k-half 0/1) so that no MFMA waits for its predecessor
+// (back-to-back dependent bf16 MFMAs were 57 % issue stalls in the first version, profiles/r01_*)
+__device__ __forceinline__ void chunk_pair_bf16x3(const u32x4* w0, const u32x4* w1, const u32x4* x1, const u32x4* x2,
+                                                  const u32x4* x3, v16f& a00, v16f& a01, v16f& a10, v16f& a11) {
+#define AA_STEP(WL, XL)                      \
+  a00 = mma_bf16(w0[2 * WL + 0], XL[0], a00); \
+  a10 = mma_bf16(w1[2 * WL + 0], XL[0], a10); \
+  a01 = mma_bf16(w0[2 * WL + 1], XL[1], a01); \
+  a11 = mma_bf16(w1[2 * WL + 1], XL[1], a11);
+  AA_STEP(2, x1)  // w3 x1
+  AA_STEP(1, x2)  // w2 x2
+  AA_STEP(0, x3)  // w1 x3
+  AA_STEP(1, x1)  // w2 x1
+  AA_STEP(0, x2)  // w1 x2
+  AA_STEP(0, x1)  // w1 x1
+#undef AA_STEP
 }
 
 // weights: Wq[tile][chunk][lane][level 0..2][half 0..1] as u32x4 (6 x 16 B per lane and chunk)
@@ -549,11 +553,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
   }
   for (int nt = 0; nt < NT; nt += 2) {
     const bool two = nt + 1 < NT;
-    v16f acc0, acc1;
+    v16f a00, a01, a10, a11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      acc0[r] = 0.f;
-      acc1[r] = 0.f;
+      a00[r] = 0.f;
+      a01[r] = 0.f;
+      a10[r] = 0.f;
+      a11[r] = 0.f;
     }
     const u32x4* wp0 = Wl + size_t(nt) * tile_stride;
     const u32x4* wp1 = Wl + size_t(two ? nt + 1 : nt) * tile_stride;
@@ -567,8 +573,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
             w0[q] = wp0[size_t(kc) * chunk_stride + q];
             w1[q] = wp1[size_t(kc) * chunk_stride + q];
           }
-          acc0 = chunk_bf16x3(w0, xr1[kc], xr2[kc], xr3[kc], acc0);
-          acc1 = chunk_bf16x3(w1, xr1[kc], xr2[kc], xr3[kc], acc1);
+          chunk_pair_bf16x3(w0, w1, xr1[kc], xr2[kc], xr3[kc], a00, a01, a10, a11);
         }
       }
     } else {
@@ -584,9 +589,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
         }
         const int kn = kc + 1 < KC ? kc + 1 : kc;
         load_a_frag(g, gm, kn * 32 + kh, a);  // next chunk's activations in flight during the MFMAs
-        acc0 = chunk_bf16x3(w0, x1, x2, x3, acc0);
-        acc1 = chunk_bf16x3(w1, x1, x2, x3, acc1);
+        chunk_pair_bf16x3(w0, w1, x1, x2, x3, a00, a01, a10, a11);
       }
+    }
+    v16f acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = a00[r] + a01[r];
+      acc1[r] = a10[r] + a11[r];
     }
     store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
     if (two) store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok);
