@@ -511,16 +511,15 @@ __device__ __forceinline__ v16f mma_bf16(const u32x4& w, const u32x4& x, v16f ac
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
 
-// one 32-deep chunk of a tile pair: 2 k-halves x 6 cross products per tile, issued round-robin over FOUR
-// independent accumulator chains (tile 0/1 x k-half 0/1) so that no MFMA waits for its predecessor
-// (back-to-back dependent bf16 MFMAs were 57 % issue stalls in the first version, profiles/r01_*)
+// one 32-deep chunk of a tile pair: 2 k-halves x 6 cross products per tile; the two tiles' accumulator
+// chains are interleaved so consecutive MFMAs are independent
 __device__ __forceinline__ void chunk_pair_bf16x3(const u32x4* w0, const u32x4* w1, const u32x4* x1, const u32x4* x2,
-                                                  const u32x4* x3, v16f& a00, v16f& a01, v16f& a10, v16f& a11) {
-#define AA_STEP(WL, XL)                      \
-  a00 = mma_bf16(w0[2 * WL + 0], XL[0], a00); \
-  a10 = mma_bf16(w1[2 * WL + 0], XL[0], a10); \
-  a01 = mma_bf16(w0[2 * WL + 1], XL[1], a01); \
-  a11 = mma_bf16(w1[2 * WL + 1], XL[1], a11);
+                                                  const u32x4* x3, v16f& acc0, v16f& acc1) {
+#define AA_STEP(WL, XL)                          \
+  acc0 = mma_bf16(w0[2 * WL + 0], XL[0], acc0);  \
+  acc1 = mma_bf16(w1[2 * WL + 0], XL[0], acc1);  \
+  acc0 = mma_bf16(w0[2 * WL + 1], XL[1], acc0);  \
+  acc1 = mma_bf16(w1[2 * WL + 1], XL[1], acc1);
   AA_STEP(2, x1)  // w3 x1
   AA_STEP(1, x2)  // w2 x2
   AA_STEP(0, x3)  // w1 x3
@@ -530,7 +529,9 @@ __device__ __forceinline__ void chunk_pair_bf16x3(const u32x4* w0, const u32x4* 
 #undef AA_STEP
 }
 
-// weights: Wq[tile][chunk][lane][level 0..2][half 0..1] as u32x4 (6 x 16 B per lane and chunk)
+// weights: Wq[tile][chunk][lane][level 0..2][half 0..1] as u32x4 (6 x 16 B per lane and chunk).
+// Software pipeline: the weight fragments of step (pair, chunk)+1 are in flight while the 24 MFMAs of the
+// current step issue (also across tile-pair boundaries); streamed activations are fetched two chunks ahead.
 template <int KCR>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x4* __restrict__ Wq, int vec_ok) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
   const u32x4* Wl = Wq + size_t(lane) * 6;
   const size_t chunk_stride = 64 * 6;                    // u32x4 units between chunks
   const size_t tile_stride = size_t(KC) * chunk_stride;  // between feature tiles
+  auto wptr = [&](int tile, int kc) { return Wl + size_t(tile < NT ? tile : NT - 1) * tile_stride + size_t(kc) * chunk_stride; };
   u32x4 xr1[KCR > 0 ? KCR : 1][2], xr2[KCR > 0 ? KCR : 1][2], xr3[KCR > 0 ? KCR : 1][2];
   if (KCR > 0) {
 #pragma unroll
@@ -551,52 +553,74 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
       split3_pack(a, xr1[kc], xr2[kc], xr3[kc]);
     }
   }
+  u32x4 wc0[6], wc1[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    wc0[q] = wptr(0, 0)[q];
+    wc1[q] = wptr(1, 0)[q];
+  }
   for (int nt = 0; nt < NT; nt += 2) {
     const bool two = nt + 1 < NT;
-    v16f a00, a01, a10, a11;
+    v16f acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      a00[r] = 0.f;
-      a01[r] = 0.f;
-      a10[r] = 0.f;
-      a11[r] = 0.f;
+      acc0[r] = 0.f;
+      acc1[r] = 0.f;
     }
-    const u32x4* wp0 = Wl + size_t(nt) * tile_stride;
-    const u32x4* wp1 = Wl + size_t(two ? nt + 1 : nt) * tile_stride;
     if (KCR > 0) {
 #pragma unroll
       for (int kc = 0; kc < KCR; ++kc) {
         if (kc < KC) {
-          u32x4 w0[6], w1[6];
+          const bool last = kc + 1 >= KC;
+          const int nnt = last ? nt + 2 : nt, nkc = last ? 0 : kc + 1;
+          u32x4 wn0[6], wn1[6];
+          const u32x4* p0 = wptr(nnt, nkc);
+          const u32x4* p1 = wptr(nnt + 1, nkc);
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
-            w0[q] = wp0[size_t(kc) * chunk_stride + q];
-            w1[q] = wp1[size_t(kc) * chunk_stride + q];
+            wn0[q] = p0[q];
+            wn1[q] = p1[q];
           }
-          chunk_pair_bf16x3(w0, w1, xr1[kc], xr2[kc], xr3[kc], a00, a01, a10, a11);
+          chunk_pair_bf16x3(wc0, wc1, xr1[kc], xr2[kc], xr3[kc], acc0, acc1);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            wc0[q] = wn0[q];
+            wc1[q] = wn1[q];
+          }
         }
       }
     } else {
-      v4f a[4];
-      load_a_frag(g, gm, kh, a);
+      v4f a0[4], a1[4];
+      load_a_frag(g, gm, kh, a0);
+      load_a_frag(g, gm, (KC > 1 ? 32 : 0) + kh, a1);
       for (int kc = 0; kc < KC; ++kc) {
-        u32x4 x1[2], x2[2], x3[2], w0[6], w1[6];
-        split3_pack(a, x1, x2, x3);
+        v4f a2[4];
+        const int k2 = kc + 2 < KC ? kc + 2 : KC - 1;
+        load_a_frag(g, gm, k2 * 32 + kh, a2);  // two chunks ahead
+        const bool last = kc + 1 >= KC;
+        const int nnt = last ? nt + 2 : nt, nkc = last ? 0 : kc + 1;
+        u32x4 wn0[6], wn1[6];
+        const u32x4* p0 = wptr(nnt, nkc);
+        const u32x4* p1 = wptr(nnt + 1, nkc);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          w0[q] = wp0[size_t(kc) * chunk_stride + q];
-          w1[q] = wp1[size_t(kc) * chunk_stride + q];
+          wn0[q] = p0[q];
+          wn1[q] = p1[q];
         }
-        const int kn = kc + 1 < KC ? kc + 1 : kc;
-        load_a_frag(g, gm, kn * 32 + kh, a);  // next chunk's activations in flight during the MFMAs
-        chunk_pair_bf16x3(w0, w1, x1, x2, x3, a00, a01, a10, a11);
-      }
-    }
-    v16f acc0, acc1;
+        u32x4 x1[2], x2[2], x3[2];
+        split3_pack(a0, x1, x2, x3);
+        chunk_pair_bf16x3(wc0, wc1, x1, x2, x3, acc0, acc1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc0[r] = a00[r] + a01[r];
-      acc1[r] = a10[r] + a11[r];
+        for (int q = 0; q < 4; ++q) {
+          a0[q] = a1[q];
+          a1[q] = a2[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          wc0[q] = wn0[q];
+          wc1[q] = wn1[q];
+        }
+      }
     }
     store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
     if (two) store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok);
