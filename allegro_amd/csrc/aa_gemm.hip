@@ -347,6 +347,49 @@ __device__ __forceinline__ void store_tile_t(const GemmArgs& g, const v16f& acc,
   }
 }
 
+// Epilogue of a tile pair through a wave-private LDS patch [32 rows][64 + 4 features]: the accumulators are
+// written in MFMA order (lane = row, 4 consecutive features per register group) and read back so that 16
+// consecutive lanes cover one 256-B row segment -> z loads, accumulate loads and stores are full-line
+// accesses (the direct epilogue issued 32-B partial-line writes: 64x448 spent 155 of 269 us in its stores).
+constexpr int EP_LD = 68;  // floats per patch row
+__device__ __forceinline__ void store_pair_lds(const GemmArgs& g, const v16f& acc0, const v16f& acc1, bool two, float* patch,
+                                               int64_t m0, int n0, int lane) {
+  const int row = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    *reinterpret_cast<v4f*>(patch + row * EP_LD + 8 * gq + 4 * h) =
+        v4f{acc0[4 * gq], acc0[4 * gq + 1], acc0[4 * gq + 2], acc0[4 * gq + 3]};
+    if (two)
+      *reinterpret_cast<v4f*>(patch + row * EP_LD + 32 + 8 * gq + 4 * h) =
+          v4f{acc1[4 * gq], acc1[4 * gq + 1], acc1[4 * gq + 2], acc1[4 * gq + 3]};
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int c4 = (lane & 15) * 4;  // feature offset inside the pair
+  const int f0 = n0 + c4;
+  const bool col_ok = (c4 < 32 || two) && f0 < g.N;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = it * 4 + (lane >> 4);
+    const int64_t gm = m0 + r;
+    if (!col_ok) continue;
+    const Dst4 d = resolve4(g, gm, f0);
+    if (d.nvalid != 4) continue;  // (segments are 4-granular on this path)
+    v4f v = *reinterpret_cast<const v4f*>(patch + r * EP_LD + c4);
+    if (d.z) {
+      const v4f z = *reinterpret_cast<const v4f*>(d.z);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= dsilu(z[e]);
+    }
+    if (d.accum) {
+      const v4f o = *reinterpret_cast<const v4f*>(d.c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += o[e];
+    }
+    *reinterpret_cast<v4f*>(d.c) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // KCR > 0: K <= 32*KCR and the row's activation fragments stay in registers for all column tiles;
 // KCR == 0: fragments are streamed (and double-buffered) per k chunk.
 template <int KCR>
@@ -533,7 +576,7 @@ __device__ __forceinline__ void chunk_pair_bf16x3(const u32x4* w0, const u32x4* 
 // Software pipeline: the weight fragments of step (pair, chunk)+1 are in flight while the 24 MFMAs of the
 // current step issue (also across tile-pair boundaries); streamed activations are fetched two chunks ahead.
 template <int KCR>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x4* __restrict__ Wq, int vec_ok) {
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x4* __restrict__ Wq, int vec_ok, int dbg) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
@@ -581,7 +624,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
             wn0[q] = p0[q];
             wn1[q] = p1[q];
           }
-          chunk_pair_bf16x3(wc0, wc1, xr1[kc], xr2[kc], xr3[kc], acc0, acc1);
+          if (!(dbg & 2)) chunk_pair_bf16x3(wc0, wc1, xr1[kc], xr2[kc], xr3[kc], acc0, acc1);
+          else acc0[0] += u2f(wc0[0][0]) + u2f(wc1[5][3]) + u2f(xr1[kc][0][0]);
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
             wc0[q] = wn0[q];
@@ -594,9 +638,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
       load_a_frag(g, gm, kh, a0);
       load_a_frag(g, gm, (KC > 1 ? 32 : 0) + kh, a1);
       for (int kc = 0; kc < KC; ++kc) {
-        v4f a2[4];
-        const int k2 = kc + 2 < KC ? kc + 2 : KC - 1;
-        load_a_frag(g, gm, k2 * 32 + kh, a2);  // two chunks ahead
+        // L2-resident weights are requested BEFORE the HBM activations: loads return in order, so the other
+        // way round every step would wait a full HBM latency for its weights
         const bool last = kc + 1 >= KC;
         const int nnt = last ? nt + 2 : nt, nkc = last ? 0 : kc + 1;
         u32x4 wn0[6], wn1[6];
@@ -607,9 +650,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
           wn0[q] = p0[q];
           wn1[q] = p1[q];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        v4f a2[4];
+        const int k2 = kc + 2 < KC ? kc + 2 : KC - 1;
+        load_a_frag(g, gm, k2 * 32 + kh, a2);  // two chunks ahead
+        __builtin_amdgcn_sched_barrier(0);
         u32x4 x1[2], x2[2], x3[2];
         split3_pack(a0, x1, x2, x3);
-        chunk_pair_bf16x3(wc0, wc1, x1, x2, x3, acc0, acc1);
+        if (!(dbg & 2)) chunk_pair_bf16x3(wc0, wc1, x1, x2, x3, acc0, acc1);
+        else acc0[0] += u2f(wc0[0][0]) + u2f(wc1[5][3]) + u2f(x1[0][0]) + u2f(x3[1][3]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           a0[q] = a1[q];
@@ -622,8 +671,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
         }
       }
     }
-    store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
-    if (two) store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok);
+    if (dbg & 1) {  // timing experiment: keep the results live without the epilogue traffic
+      if (acc0[3] == 1.2345e-30f && acc1[7] == 9.87e-31f) store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
+      continue;
+    }
+    if (vec_ok && !(dbg & 4)) {
+      store_pair_lds(g, acc0, acc1, two, reinterpret_cast<float*>(aa_smem) + wv * 32 * EP_LD, m0, nt * 32, lane);
+    } else {
+      store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
+      if (two) store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok);
+    }
   }
 }
 
@@ -732,14 +789,19 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
       const char* e = getenv("AA_GEMM_FP32_MFMA");
       no_split = (e && e[0] == '1') ? 1 : 0;
     }
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("AA_GEMM_DBG");  // timing experiments only: bit0 skip stores, bit1 skip MFMAs
+      dbg = e ? atoi(e) : 0;
+    }
     if (g.Bq && !no_split) {
       const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
       if (KC <= 2)
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, grid, dim3(256), 0, stream, g, Wq, vec_ok);
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, grid, dim3(256), sizeof(float) * 4 * 32 * EP_LD, stream, g, Wq, vec_ok, dbg);
       else if (KC <= 4)
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, grid, dim3(256), 0, stream, g, Wq, vec_ok);
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<4>, grid, dim3(256), sizeof(float) * 4 * 32 * EP_LD, stream, g, Wq, vec_ok, dbg);
       else
-        hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, dim3(256), 0, stream, g, Wq, vec_ok);
+        hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, dim3(256), sizeof(float) * 4 * 32 * EP_LD, stream, g, Wq, vec_ok, dbg);
     } else if (KC <= 2)
       hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<2>, grid, dim3(256), 0, stream, g, vec_ok);
     else if (KC <= 4)

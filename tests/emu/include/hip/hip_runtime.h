@@ -166,6 +166,8 @@ inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8
   emu::wave_rendezvous();
   return d;
 }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_wave_barrier() { emu::wave_rendezvous(); }  // fibers of a wave run one after another here
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on wave-uniform values
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
