@@ -88,6 +88,8 @@ struct GemmArgs {
   int has_z;       // multiply result by dsilu(z) (z split like c)
   SegList z;
   int act_a;       // apply silu to A on load
+  int has_add;     // result += add (before the dsilu(z) factor); split like c
+  SegList add;
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -252,6 +254,34 @@ struct TpChainArgs {
   int ld_gsh;
 };
 int find_chain_pair(int sig0, int sig1);  // pair id or -1
+
+// "Moments" variant of the chain kernels (u == 64): the env weights are a LINEAR image of a per-edge scalar
+// vector a[e,:] (layer 0: the two-body embedding; layer l>0: silu of the previous latent hidden layer), and they
+// enter only through the per-atom sum  x2s[n,j,ch] = f * sum_e sh[e,j] * (a[e,:] @ Wenv)[r(j),ch]
+// (allegro/nn/_allegro.py:251-258,263,289-294 + allegro/nn/_strided/_contract.py:195-205).  Summing first,
+//     M[n,j,k] = sum_e sh[e,j] * a[e,k],      x2s[n,j,ch] = f * sum_k M[n,j,k] * Wenv[k, r(j), ch],
+// is exact by linearity and removes every [E, R*u] env tensor (and its gradient) from HBM.
+struct TpMomArgs {
+  TpChainArgs c;        // wenv0/wenv1/g_wenv are unused here
+  const void* a0;       // layer-0 env input  [E, ld_a0]  (EDGE_EMBEDDING; no activation)
+  int ld_a0, ka0;
+  const void* a1;       // layer-1 env input  [E, ld_a1]  (pre-activation of latent 0's hidden layer; silu applied)
+  int ld_a1, ka1;
+  const void* wk0;      // Wenv of layer 0 as [ka][R][u]  (alpha folded)
+  const void* wt0;      //                  and [R][u][ka]
+  const void* wk1;
+  const void* wt1;
+  void* g_a;            // reverse kernels: grad wrt the env input of the layer being reversed [E, ld_ga]
+  int ld_ga;
+};
+template <typename T>
+int launch_tp_mom_fwd_first(int pair, const TpMomArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_mom_fwd_last(int pair, const TpMomArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_mom_bwd_last(int pair, const TpMomArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_mom_bwd_first(int pair, const TpMomArgs& a, hipStream_t stream);
 template <typename T>
 int launch_tp_chain_fwd_last(int pair, const TpChainArgs& a, hipStream_t stream);
 template <typename T>

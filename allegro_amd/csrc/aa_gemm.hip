@@ -35,6 +35,7 @@ __device__ __forceinline__ void seg_store(const GemmArgs& g, int64_t row, int co
   for (int s = 0; s < 3; ++s) {
     if (s < g.c.count) {
       if (c < g.c.s[s].n) {
+        if (g.has_add) v += static_cast<const T*>(g.add.s[s].p)[row * g.add.s[s].ld + c];
         if (g.has_z) {
           T z = static_cast<const T*>(g.z.s[s].p)[row * g.z.s[s].ld + c];
           v *= dsilu(z);
@@ -288,12 +289,14 @@ __device__ __forceinline__ void load_a_frag(const GemmArgs& g, int64_t gm, int k
 struct Dst4 {
   float* c;
   const float* z;
+  const float* add;
   int accum, nvalid;  // nvalid: how many of the 4 features exist (0..4)
 };
 __device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0) {
   Dst4 d;
   d.c = nullptr;
   d.z = nullptr;
+  d.add = nullptr;
   d.accum = 0;
   d.nvalid = 0;
   if (gm >= g.M || f0 >= g.N) return d;
@@ -306,6 +309,7 @@ __device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0) 
       d.c = static_cast<float*>(g.c.s[s].p) + gm * g.c.s[s].ld + c;
       d.accum = g.c_accum[s];
       if (g.has_z) d.z = static_cast<const float*>(g.z.s[s].p) + gm * g.z.s[s].ld + c;
+      if (g.has_add) d.add = static_cast<const float*>(g.add.s[s].p) + gm * g.add.s[s].ld + c;
       d.nvalid = g.c.s[s].n - c < 4 ? g.c.s[s].n - c : 4;
       done = true;
     }
@@ -323,6 +327,11 @@ __device__ __forceinline__ void store_tile_t(const GemmArgs& g, const v16f& acc,
     if (d.nvalid == 0) continue;
     v4f v = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
     if (vec_ok && d.nvalid == 4) {
+      if (d.add) {
+        const v4f ad = *reinterpret_cast<const v4f*>(d.add);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += ad[e];
+      }
       if (d.z) {
         const v4f z = *reinterpret_cast<const v4f*>(d.z);
 #pragma unroll
@@ -339,6 +348,7 @@ __device__ __forceinline__ void store_tile_t(const GemmArgs& g, const v16f& acc,
       for (int e = 0; e < 4; ++e)
         if (e < d.nvalid) {
           float x = v[e];
+          if (d.add) x += d.add[e];
           if (d.z) x *= dsilu(d.z[e]);
           if (d.accum) x += d.c[e];
           d.c[e] = x;
@@ -375,6 +385,11 @@ __device__ __forceinline__ void store_pair_lds(const GemmArgs& g, const v16f& ac
     const Dst4 d = resolve4(g, gm, f0);
     if (d.nvalid != 4) continue;  // (segments are 4-granular on this path)
     v4f v = *reinterpret_cast<const v4f*>(patch + r * EP_LD + c4);
+    if (d.add) {
+      const v4f ad = *reinterpret_cast<const v4f*>(d.add);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += ad[e];
+    }
     if (d.z) {
       const v4f z = *reinterpret_cast<const v4f*>(d.z);
 #pragma unroll
@@ -739,6 +754,11 @@ static int check_args(const GemmArgs& g) {
   for (int s = 0; s < g.a.count; ++s) ka += g.a.s[s].n;
   for (int s = 0; s < g.c.count; ++s) nc += g.c.s[s].n;
   if (ka != g.K || nc != g.N) return fail(AA_ERR_INVALID, "gemm: segment widths do not sum to K/N");
+  if (g.has_add) {
+    if (g.add.count != g.c.count) return fail(AA_ERR_INVALID, "gemm: add/c segment mismatch");
+    for (int s = 0; s < g.c.count; ++s)
+      if (g.add.s[s].n != g.c.s[s].n) return fail(AA_ERR_INVALID, "gemm: add/c segment mismatch");
+  }
   if (g.has_z) {
     if (g.z.count != g.c.count) return fail(AA_ERR_INVALID, "gemm: z/c segment mismatch");
     for (int s = 0; s < g.c.count; ++s)
@@ -776,6 +796,7 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     for (int s = 0; s < g.c.count; ++s) {
       if ((g.c.s[s].n & 3) || (g.c.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.c.s[s].p) & 15)) vec_ok = 0;
       if (g.has_z && ((g.z.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.z.s[s].p) & 15))) vec_ok = 0;
+      if (g.has_add && ((g.add.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.add.s[s].p) & 15))) vec_ok = 0;
     }
     const int KC = (g.K + 31) / 32;
     static int no_split = -1;
@@ -786,7 +807,7 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     static int direct_epi = -1;
     if (direct_epi < 0) {
       const char* e = getenv("AA_GEMM_DIRECT_EPILOGUE");  // A/B switch: 16-B per-lane epilogue without the LDS transpose
-      direct_epi = (e && e[0] == '1') ? 1 : 0;
+      direct_epi = (e && e[0] == '0') ? 0 : 1;  // default: direct (the LDS-transposed variant measured slower)
     }
     if (g.Bq && !no_split) {
       const u32x4* Wq = static_cast<const u32x4*>(g.Bq);

@@ -115,6 +115,9 @@ struct aa_model_plan {
   int spec_sig[AA_MAX_LAYERS];       // generated-signature id per layer, or -1
   bool use_spec;                     // all layers specialised -> channel-minor internal layouts
   int chain_pair;                    // >= 0: 2-layer stack on the chain kernels (no [E,u,D] tensors in HBM)
+  bool env_mom;                      // chain + moments: no [E,R*u] env tensors either (TpMomArgs in aa_common.h)
+  int ng0;                           // output width of the fused first-stage GEMM
+  size_t o_wk[2], o_wt[2];           // Wenv of layer l as [ka][R][u] and [R][u][ka]
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
 };
 
@@ -170,6 +173,11 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     p->chain_pair = -1;
     const char* nc = getenv("AA_TP_NOCHAIN");
     if (p->use_spec && L == 2 && !(nc && nc[0] == '1')) p->chain_pair = find_chain_pair(p->spec_sig[0], p->spec_sig[1]);
+    const char* nm = getenv("AA_TP_NOMOM");
+    const int Dsh = (cfg->l_max + 1) * (cfg->l_max + 1);
+    p->env_mom = p->chain_pair >= 0 && u == 64 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
+                 (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) &&
+                 (cfg->dtype == AA_F32 ? 4 : 8) * 4 * Dsh * (128 + 64) <= 64 * 1024 && !(nm && nm[0] == '1');
   }
   // weight blob layout
   size_t o = 0;
@@ -196,14 +204,21 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     }
   };
   lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
-  p->o_g0 = take(size_t(S) * (S + 2 * p->W));
-  p->o_g0t = take(size_t(S) * (S + 2 * p->W));
-  p->o_g0p = take(gemm_packed_elems(S, S + 2 * p->W));
-  p->o_g0tp = take(gemm_packed_elems(S + 2 * p->W, S));
-  p->o_g0q = take(gemm_bf16x3_words(S, S + 2 * p->W));
-  p->o_g0tq = take(gemm_bf16x3_words(S + 2 * p->W, S));
+  p->ng0 = p->env_mom ? S + p->W : S + 2 * p->W;
+  p->o_g0 = take(size_t(S) * p->ng0);
+  p->o_g0t = take(size_t(S) * p->ng0);
+  p->o_g0p = take(gemm_packed_elems(S, p->ng0));
+  p->o_g0tp = take(gemm_packed_elems(p->ng0, S));
+  p->o_g0q = take(gemm_bf16x3_words(S, p->ng0));
+  p->o_g0tq = take(gemm_bf16x3_words(p->ng0, S));
+  if (p->env_mom) {
+    p->o_wk[0] = take(size_t(S) * p->W);
+    p->o_wt[0] = take(size_t(S) * p->W);
+    p->o_wk[1] = take(size_t(cfg->latent_mlp_width) * p->W);
+    p->o_wt[1] = take(size_t(cfg->latent_mlp_width) * p->W);
+  }
   for (int l = 0; l < L; ++l) {
-    int in = S * (l + 1) + u, outd = S + (l < L - 1 ? p->W : 0);
+    int in = S * (l + 1) + u, outd = S + ((l < L - 1 && !p->env_mom) ? p->W : 0);
     lay(p->latent[l], mlp_dims(in, cfg->latent_mlp_depth, cfg->latent_mlp_width, outd), cfg->latent_mlp_depth + 1);
     p->o_tpw[l] = take(size_t(cfg->tps[l].coupling ? u : 1) * cfg->tps[l].num_paths);
   }
@@ -257,16 +272,19 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   const int Rr = p->R;
   auto env_col = [&](int q) { return p->use_spec ? (q % u) * Rr + q / u : q; };  // packed col q <- reference col
   // pack an MLP; if env_off >= 0 the LAST layer's columns [env_off, env_off+W) are env weights
-  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off) -> bool {
+  // raw_last_width: true column count of the LAST layer in the state_dict (>= packed width when the env columns
+  // are split off for the moments path); alpha always follows the reference's full layer shape
+  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off, int raw_last_width = -1) -> bool {
     for (int i = 0; i < nlayers; ++i) {
       if (!ws[i]) return false;
       int din = m.dims[i], dout = m.dims[i + 1];
-      double al = mlp_alpha(c, i, din, dout);
+      int raw_w = (i == nlayers - 1 && raw_last_width > 0) ? raw_last_width : dout;
+      double al = mlp_alpha(c, i, din, raw_w);
       for (int r = 0; r < din; ++r)
         for (int q = 0; q < dout; ++q) {
           int src = q;
           if (i == nlayers - 1 && env_off >= 0 && q >= env_off && q < env_off + W) src = env_off + env_col(q - env_off);
-          double v = ws[i][size_t(r) * dout + src] * al;
+          double v = ws[i][size_t(r) * raw_w + src] * al;
           h[m.w[i] + size_t(r) * dout + q] = v;
           h[m.wt[i] + size_t(q) * din + r] = v;
         }
@@ -278,7 +296,8 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1, -1), "pack: missing scalar_embed_mlp weights");
   {
     // fused first stage: [ two_body (first_proj[:, :S]) | w0 (env_embed_linear) | env_w0 (first_proj[:, S:]) ]
-    const int NG = S + 2 * W;
+    // (moments path: the env_w0 columns are not part of the GEMM; they become Wenv of layer 0 below)
+    const int NG = p->ng0;
     double a_env = mlp_alpha(c, 0, S, W), a_proj = mlp_alpha(c, 0, S, S + W);
     for (int r = 0; r < S; ++r)
       for (int q = 0; q < NG; ++q) {
@@ -296,10 +315,26 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     gemm_pack_b(&h[p->o_g0t], NG, S, &h[p->o_g0tp]);
   }
   for (int l = 0; l < L; ++l) {
-    AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, l < L - 1 ? S : -1),
+    AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, (l < L - 1 && !p->env_mom) ? S : -1,
+                        S + (l < L - 1 ? W : 0)),
                "pack: missing latent weights");
     AA_REQUIRE(raw->tp_weights[l], "pack: missing tp weights");
     copy(p->o_tpw[l], raw->tp_weights[l], size_t(c.tps[l].coupling ? u : 1) * c.tps[l].num_paths, 1.0);
+  }
+  if (p->env_mom) {
+    // Wenv_l[k][r][ch] (and its [r][ch][k] transpose) from the reference's [k][S + ch*R + r] columns
+    auto fill = [&](int l, const double* rawm, int ka, int raw_w, double al) {
+      for (int k = 0; k < ka; ++k)
+        for (int r = 0; r < Rr; ++r)
+          for (int ch = 0; ch < u; ++ch) {
+            double v = rawm[size_t(k) * raw_w + S + ch * Rr + r] * al;
+            h[p->o_wk[l] + (size_t(k) * Rr + r) * u + ch] = v;
+            h[p->o_wt[l] + (size_t(r) * u + ch) * ka + k] = v;
+          }
+    };
+    fill(0, raw->first_proj, S, S + W, mlp_alpha(c, 0, S, S + W));
+    const int dl = c.latent_mlp_depth;  // index of latent 0's last layer
+    fill(1, raw->latent[0][dl], c.latent_mlp_width, S + W, mlp_alpha(c, dl, c.latent_mlp_width, S + W));
   }
   AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1), "pack: missing readout weights");
   {
@@ -331,8 +366,8 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       }
     };
     split_mlp(p->embed, c.embed_mlp_depth + 1);
-    splitw(p->o_g0, S, S + 2 * W, p->o_g0q);
-    splitw(p->o_g0t, S + 2 * W, S, p->o_g0tq);
+    splitw(p->o_g0, S, p->ng0, p->o_g0q);
+    splitw(p->o_g0t, p->ng0, S, p->o_g0tq);
     for (int l = 0; l < L; ++l) split_mlp(p->latent[l], c.latent_mlp_depth + 1);
     split_mlp(p->readout, c.readout_mlp_depth);
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
@@ -345,7 +380,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -376,7 +411,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   w.fcat = take(Ez * p->SL1);
   size_t dmax = 1;
   for (int l = 0; l < L; ++l) {
-    w.envw[l] = take(Ez * p->W);
+    if (!p->env_mom) w.envw[l] = take(Ez * p->W);
     w.x2s[l] = take(Nz * u * p->D);
     if (l < L - 1 && p->chain_pair < 0) {
       w.tf[l] = take(Ez * u * c.tps[l].dout);
@@ -391,7 +426,8 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
     for (int i = 0; i < c.latent_mlp_depth; ++i) w.g_lat_h[i] = take(Ez * c.latent_mlp_width);
     for (int l = 0; l < L; ++l) w.g_scal[l] = take(Ez * u);
-    w.g_envw = take(Ez * p->W);
+    if (!p->env_mom) w.g_envw = take(Ez * p->W);
+    if (p->env_mom) w.g_aenv = take(Ez * size_t(std::max(S, c.latent_mlp_width)));
     w.g_w0 = take(Ez * p->W);
     if (L > 1 && p->chain_pair < 0) {
       w.g_tf[0] = take(Ez * u * dmax);
@@ -453,7 +489,7 @@ struct Runner {
   const T* wt(size_t off) const { return wts + off; }
 
   int gemm(const SegList& a, int act_a, const T* B, const T* Bp, const T* Bq, int K, int Nn, const SegList& c,
-           const int* accum, const SegList* z) {
+           const int* accum, const SegList* z, const SegList* add = nullptr) {
     GemmArgs g{};
     g.M = E;
     g.K = K;
@@ -467,6 +503,8 @@ struct Runner {
     g.has_z = z ? 1 : 0;
     if (z) g.z = *z;
     g.act_a = act_a;
+    g.has_add = add ? 1 : 0;
+    if (add) g.add = *add;
     if (int rc = launch_gemm<T>(g, stream)) return rc;
     if (!prof) return AA_OK;
     char nm[32];
@@ -492,8 +530,9 @@ struct Runner {
   }
 
   // reverse: g_out (grad of final output) -> g_in (with per-segment accumulate flags)
+  // add_last: optional extra gradient wrt the ACTIVATED last hidden layer (moments path), added before silu'
   int mlp_bwd(const MlpLayout& m, int nlayers, const SegList& g_out, const size_t* h, const size_t* g_h,
-              const SegList& g_in, const int* g_in_accum) {
+              const SegList& g_in, const int* g_in_accum, const SegList* add_last = nullptr) {
     SegList a = g_out;
     for (int i = nlayers - 1; i >= 0; --i) {
       SegList c, z;
@@ -509,7 +548,8 @@ struct Runner {
         c = g_in;
         acc = g_in_accum;
       }
-      if (int rc = gemm(a, 0, wt(m.wt[i]), wt(m.wtp[i]), wt(m.wtq[i]), m.dims[i + 1], m.dims[i], c, acc, zp)) return rc;
+      const SegList* addp = (add_last && i == nlayers - 1 && i > 0) ? add_last : nullptr;
+      if (int rc = gemm(a, 0, wt(m.wt[i]), wt(m.wtp[i]), wt(m.wtq[i]), m.dims[i + 1], m.dims[i], c, acc, zp, addp)) return rc;
       a = c;
     }
     return AA_OK;
@@ -598,6 +638,24 @@ struct Runner {
     return a;
   }
 
+  TpMomArgs mom_args(const aa_graph* g) const {
+    const aa_model_config& c = p->cfg;
+    TpMomArgs m{};
+    m.c = chain_args(g);
+    m.c.wenv0 = m.c.wenv1 = nullptr;
+    m.a0 = buf(w.emb);
+    m.ld_a0 = c.num_scalar;
+    m.ka0 = c.num_scalar;
+    m.a1 = buf(w.lat_h[0][c.latent_mlp_depth - 1]);
+    m.ld_a1 = c.latent_mlp_width;
+    m.ka1 = c.latent_mlp_width;
+    m.wk0 = wt(p->o_wk[0]);
+    m.wt0 = wt(p->o_wt[0]);
+    m.wk1 = wt(p->o_wk[1]);
+    m.wt1 = wt(p->o_wt[1]);
+    return m;
+  }
+
   TpOperand implicit(size_t w_off) const {
     TpOperand o{};
     o.sh = buf(w.sh);
@@ -624,12 +682,23 @@ struct Runner {
     {
       SegList in{1, {seg(buf(w.emb), S, S)}};
       SegList out{3, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W), seg(buf(w.envw[0]), W, W)}};
-      if (int rc = gemm(in, 0, wt(p->o_g0), wt(p->o_g0p), wt(p->o_g0q), S, S + 2 * W, out, nullptr, nullptr)) return rc;
+      if (p->env_mom) out.count = 2;
+      if (int rc = gemm(in, 0, wt(p->o_g0), wt(p->o_g0p), wt(p->o_g0q), S, p->ng0, out, nullptr, nullptr)) return rc;
     }
     // 5: layers
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
     for (int l = 0; l < L; ++l) {
-      if (p->chain_pair >= 0 && l == 1) {
+      if (p->env_mom) {
+        TpMomArgs m = mom_args(g);
+        if (l == 0) {
+          m.c.scal1 = buf(w.scal[0]);  // the first-layer kernel writes its scalars through this field
+          if (int rc = launch_tp_mom_fwd_first<T>(p->chain_pair, m, stream)) return rc;
+          if (int rc = mark("tp_mom_fwd_first")) return rc;
+        } else {
+          if (int rc = launch_tp_mom_fwd_last<T>(p->chain_pair, m, stream)) return rc;
+          if (int rc = mark("tp_mom_fwd_last")) return rc;
+        }
+      } else if (p->chain_pair >= 0 && l == 1) {
         if (int rc = launch_tp_chain_fwd_last<T>(p->chain_pair, chain_args(g), stream)) return rc;
         if (int rc = mark("tp_chain_fwd_last")) return rc;
       } else if (p->use_spec) {
@@ -678,9 +747,9 @@ struct Runner {
       }
       SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
       SegList out;
-      out.count = l < L - 1 ? 2 : 1;
+      out.count = (l < L - 1 && !p->env_mom) ? 2 : 1;
       out.s[0] = seg(buf(w.fcat) + S * (l + 1), SL1, S);
-      if (l < L - 1) out.s[1] = seg(buf(w.envw[l + 1]), W, W);
+      if (l < L - 1 && !p->env_mom) out.s[1] = seg(buf(w.envw[l + 1]), W, W);
       if (int rc = mlp_fwd(p->latent[l], c.latent_mlp_depth + 1, in, w.lat_h[l], out)) return rc;
     }
     // 6: edge readout GEMM layers, 7-8: last linear + edge sum + per-type scale/shift
@@ -740,13 +809,34 @@ struct Runner {
     for (int l = L - 1; l >= 0; --l) {
       // latent MLP reverse
       SegList go;
-      go.count = l < L - 1 ? 2 : 1;
+      go.count = (l < L - 1 && !p->env_mom) ? 2 : 1;
       go.s[0] = seg(buf(w.g_fcat) + S * (l + 1), SL1, S);
-      if (l < L - 1) go.s[1] = seg(buf(w.g_envw), W, W);
+      if (l < L - 1 && !p->env_mom) go.s[1] = seg(buf(w.g_envw), W, W);
+      SegList aenv{1, {seg(p->env_mom ? buf(w.g_aenv) : nullptr, c.latent_mlp_width, c.latent_mlp_width)}};
+      const SegList* addp = (p->env_mom && l < L - 1) ? &aenv : nullptr;
       SegList gi{2, {seg(buf(w.g_fcat), SL1, S * (l + 1)), seg(buf(w.g_scal[l]), u, u)}};
       int acc[3] = {1, 0, 0};
-      if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc)) return rc;
+      if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc, addp)) return rc;
       // tensor-product layer reverse
+      if (p->env_mom) {
+        TpMomArgs m = mom_args(g);
+        m.c.gscal0 = buf(w.g_scal[0]);
+        m.c.gscal1 = buf(w.g_scal[1]);
+        m.c.g_w0 = buf(w.g_w0);
+        m.c.gsh_x1 = buf(w.g_sh);
+        m.c.gsh_env = buf(w.g_sh) + size_t(l + 1) * size_t(E) * p->D;
+        m.g_a = buf(w.g_aenv);
+        if (l == 1) {
+          m.ld_ga = c.latent_mlp_width;
+          if (int rc = launch_tp_mom_bwd_last<T>(p->chain_pair, m, stream)) return rc;
+          if (int rc = mark("tp_mom_bwd_last")) return rc;
+        } else {
+          m.ld_ga = S;
+          if (int rc = launch_tp_mom_bwd_first<T>(p->chain_pair, m, stream)) return rc;
+          if (int rc = mark("tp_mom_bwd_first")) return rc;
+        }
+        continue;
+      }
       if (p->chain_pair >= 0) {
         TpChainArgs a = chain_args(g);
         a.gscal0 = buf(w.g_scal[0]);
@@ -832,8 +922,12 @@ struct Runner {
     // fused first stage reverse
     {
       SegList go{3, {seg(buf(w.g_fcat), SL1, S), seg(buf(w.g_w0), W, W), seg(buf(w.g_envw), W, W)}};
+      if (p->env_mom) go.count = 2;
       SegList gi{1, {seg(buf(w.g_emb), S, S)}};
-      if (int rc = gemm(go, 0, wt(p->o_g0t), wt(p->o_g0tp), wt(p->o_g0tq), S + 2 * W, S, gi, nullptr, nullptr)) return rc;
+      SegList aenv{1, {seg(p->env_mom ? buf(w.g_aenv) : nullptr, S, S)}};
+      if (int rc = gemm(go, 0, wt(p->o_g0t), wt(p->o_g0tp), wt(p->o_g0tq), p->ng0, S, gi, nullptr, nullptr,
+                        p->env_mom ? &aenv : nullptr))
+        return rc;
     }
     // scalar_embed_mlp reverse
     {

@@ -673,6 +673,357 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_first_kernel(TpChainArgs a) 
   }
 }
 
+// =============================================================================================
+// moments kernels (u == 64, one wave per atom): see TpMomArgs in aa_common.h
+// =============================================================================================
+namespace {
+constexpr int kMaxKa = 128;
+
+// M[j][k] = sum_e sh[e,j] * act(a[e,k]) into wave-private LDS sM[D][ka], then
+// x2s[j] (this lane's channel) = f * sum_k M[j][k] * Wk[k][r(j)][ch]
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_x2s(const T* sh, int ld_sh, const T* a, int ld_a, int ka, bool act, const T* Wk, int beg,
+                                        int end, T sf, int lane, T* sM, T* x2s) {
+  for (int kb = 0; kb < ka; kb += 64) {
+    T m[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) m[j] = T(0);
+#pragma unroll 4
+    for (int s = beg; s < end; ++s) {
+      T av = a[int64_t(s) * ld_a + kb + lane];
+      if (act) av = silu(av);
+      const T* y = sh + int64_t(s) * ld_sh;
+#pragma unroll
+      for (int j = 0; j < D; ++j) m[j] += y[j] * av;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) sM[j * ka + kb + lane] = m[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < D; ++j) x2s[j] = T(0);
+#pragma unroll 4
+  for (int k = 0; k < ka; ++k) {
+    T wv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wv[r] = Wk[(int64_t(k) * R + r) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < D; ++j) x2s[j] += sM[j * ka + k] * wv[r_of<0>(j)];
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) x2s[j] *= sf;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// GM[j] (k = kb + lane) = sum_ch g[j][ch] * Wt[r(j)][ch][k]   (g already carries the scatter factor)
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_gm(const T* sG, const T* Wt, int ka, int kb, int lane, T* gm) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) gm[j] = T(0);
+#pragma unroll 4
+  for (int ch = 0; ch < 64; ++ch) {
+    T wv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wv[r] = Wt[(int64_t(r) * 64 + ch) * ka + kb + lane];
+#pragma unroll
+    for (int j = 0; j < D; ++j) gm[j] += sG[j * 64 + ch] * wv[r_of<0>(j)];
+  }
+}
+
+// adjoint of the moments for every edge of the segment:
+//   d_a[e,k] = sum_j sh[e,j] * GM[j][k]        d_sh[e,j] = sum_k act(a[e,k]) * GM[j][k]
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const T* a, int ld_a, int ka, bool act,
+                                                   const T* g2acc, const T* Wt, int beg, int end, int lane, T* sG, T* g_a,
+                                                   int ld_ga, T* gsh, int ld_gsh) {
+#pragma unroll
+  for (int j = 0; j < D; ++j) sG[j * 64 + lane] = g2acc[j];
+  __builtin_amdgcn_wave_barrier();
+  T gm0[D], gm1[D];
+  mom_gm<T, D, R>(sG, Wt, ka, 0, lane, gm0);
+  if (ka > 64) mom_gm<T, D, R>(sG, Wt, ka, 64, lane, gm1);
+  for (int s = beg; s < end; ++s) {
+    const T* y = sh + int64_t(s) * ld_sh;
+    T a0v = a[int64_t(s) * ld_a + lane], a1v = T(0);
+    if (act) a0v = silu(a0v);
+    T d0 = T(0), d1 = T(0), gy[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      d0 += y[j] * gm0[j];
+      gy[j] = a0v * gm0[j];
+    }
+    g_a[int64_t(s) * ld_ga + lane] = d0;
+    if (ka > 64) {
+      a1v = a[int64_t(s) * ld_a + 64 + lane];
+      if (act) a1v = silu(a1v);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        d1 += y[j] * gm1[j];
+        gy[j] += a1v * gm1[j];
+      }
+      g_a[int64_t(s) * ld_ga + 64 + lane] = d1;
+    }
+    wave_sum_store<T, D>(gy, gsh + int64_t(s) * ld_gsh, true, false);
+  }
+}
+}  // namespace
+
+template <class Sig0, typename T>
+__global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
+  const TpChainArgs& a = ma.c;
+  constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
+  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64);
+  if (atom >= a.N) return;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  const T* sh = static_cast<const T*>(a.sh);
+  T x2s0[D];
+  mom_x2s<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, static_cast<const T*>(ma.wk0), beg, end,
+                   T(a.sf), lane, sM, x2s0);
+  {
+    T* xo = static_cast<T*>(const_cast<void*>(a.x2s0)) + atom * D * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < D; ++j) xo[int64_t(j) * 64] = x2s0[j];
+  }
+  T wp0[Sig0::P];
+  {
+    const T* W0 = static_cast<const T*>(a.weights0);
+#pragma unroll
+    for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[lane * Sig0::P + p] : W0[p];
+  }
+  const T* w0g = static_cast<const T*>(a.w0) + lane;
+  auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    const T* w0p = w0g + int64_t(s) * a.ld_w0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) in.y[j] = y[j];
+#pragma unroll
+    for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
+  };
+  if (beg < end) {
+    EdgeIn<T, D, R> cur, nxt;
+    fetch(beg, cur);
+    for (int s = beg; s < end; ++s) {
+      fetch(s + 1 < end ? s + 1 : s, nxt);
+      T x1[Sig0::D1], tf1[Sig0::DOUT];
+#pragma unroll
+      for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
+      Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
+      static_cast<T*>(a.scal1)[int64_t(s) * a.ld_scal + lane] = tf1[0];  // (scal1 field carries layer-0 scalars here)
+      cur = nxt;
+    }
+  }
+}
+
+template <class Sig0, class Sig1, typename T>
+__global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
+  const TpChainArgs& a = ma.c;
+  constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
+  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64);
+  if (atom >= a.N) return;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  const T* sh = static_cast<const T*>(a.sh);
+  T x2s1[D], x2s0[D];
+  mom_x2s<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, static_cast<const T*>(ma.wk1), beg, end,
+                   T(a.sf), lane, sM, x2s1);
+  {
+    const int64_t base = atom * D * 64 + lane;
+    const T* xi = static_cast<const T*>(a.x2s0) + base;
+    T* xo = static_cast<T*>(a.x2s1) + base;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s0[j] = xi[int64_t(j) * 64];
+      xo[int64_t(j) * 64] = x2s1[j];
+    }
+  }
+  T wp0[Sig0::P], wp1[Sig1::P];
+  {
+    const T* W0 = static_cast<const T*>(a.weights0);
+    const T* W1 = static_cast<const T*>(a.weights1);
+#pragma unroll
+    for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[lane * Sig0::P + p] : W0[p];
+#pragma unroll
+    for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
+  }
+  const T* w0g = static_cast<const T*>(a.w0) + lane;
+  auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    const T* w0p = w0g + int64_t(s) * a.ld_w0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) in.y[j] = y[j];
+#pragma unroll
+    for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
+  };
+  if (beg < end) {
+    EdgeIn<T, D, R> cur, nxt;
+    fetch(beg, cur);
+    for (int s = beg; s < end; ++s) {
+      fetch(s + 1 < end ? s + 1 : s, nxt);
+      T x1[Sig0::D1], tf1[Sig0::DOUT], out[1];
+#pragma unroll
+      for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
+      Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
+      Sig1::template fwd<T>(tf1, x2s1, wp1, out);
+      static_cast<T*>(a.scal1)[int64_t(s) * a.ld_scal + lane] = out[0];
+      cur = nxt;
+    }
+  }
+}
+
+template <class Sig0, class Sig1, typename T>
+__global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
+  const TpChainArgs& a = ma.c;
+  constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
+  T* sG = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64) + D * kMaxKa;
+  if (atom >= a.N) return;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* w0g = static_cast<const T*>(a.w0) + lane;
+  const T* gs1 = static_cast<const T*>(a.gscal1) + lane;
+  T x2s0[D], g2acc[D];
+  {
+    const T* xi = static_cast<const T*>(a.x2s0) + atom * D * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s0[j] = xi[int64_t(j) * 64];
+      g2acc[j] = T(0);
+    }
+  }
+  T wp0[Sig0::P], wp1[Sig1::P];
+  {
+    const T* W0 = static_cast<const T*>(a.weights0);
+    const T* W1 = static_cast<const T*>(a.weights1);
+#pragma unroll
+    for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[lane * Sig0::P + p] : W0[p];
+#pragma unroll
+    for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
+  }
+  {
+    auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
+      const T* y = sh + int64_t(s) * a.ld_sh;
+      const T* w0p = w0g + int64_t(s) * a.ld_w0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) in.y[j] = y[j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
+      in.g1 = gs1[int64_t(s) * a.ld_gscal];
+    };
+    if (beg < end) {
+      EdgeIn<T, D, R> cur, nxt;
+      fetch(beg, cur);
+      for (int s = beg; s < end; ++s) {
+        fetch(s + 1 < end ? s + 1 : s, nxt);
+        T x1[Sig0::D1], tf1[Sig0::DOUT], go[1], g2[D];
+#pragma unroll
+        for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
+        Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
+        go[0] = cur.g1;
+        Sig1::template bx2<T>(go, tf1, wp1, g2);
+#pragma unroll
+        for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+        cur = nxt;
+      }
+    }
+  }
+  const T sf = T(a.sf);
+#pragma unroll
+  for (int j = 0; j < D; ++j) g2acc[j] *= sf;
+  mom_backward_edges<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, g2acc,
+                              static_cast<const T*>(ma.wt1), beg, end, lane, sG, static_cast<T*>(ma.g_a), ma.ld_ga,
+                              static_cast<T*>(a.gsh_env), a.ld_gsh);
+}
+
+template <class Sig0, class Sig1, typename T>
+__global__ __launch_bounds__(256) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
+  const TpChainArgs& a = ma.c;
+  constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
+  T* sG = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64) + D * kMaxKa;
+  if (atom >= a.N) return;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* w0g = static_cast<const T*>(a.w0) + lane;
+  const T* gs0 = static_cast<const T*>(a.gscal0) + lane;
+  const T* gs1 = static_cast<const T*>(a.gscal1) + lane;
+  T x2s0[D], x2s1[D], g2acc[D];
+  {
+    const int64_t base = atom * D * 64 + lane;
+    const T* x0 = static_cast<const T*>(a.x2s0) + base;
+    const T* x1p = static_cast<const T*>(a.x2s1) + base;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s0[j] = x0[int64_t(j) * 64];
+      x2s1[j] = x1p[int64_t(j) * 64];
+      g2acc[j] = T(0);
+    }
+  }
+  T wp0[Sig0::P], wp1[Sig1::P];
+  {
+    const T* W0 = static_cast<const T*>(a.weights0);
+    const T* W1 = static_cast<const T*>(a.weights1);
+#pragma unroll
+    for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[lane * Sig0::P + p] : W0[p];
+#pragma unroll
+    for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
+  }
+  {
+    auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
+      const T* y = sh + int64_t(s) * a.ld_sh;
+      const T* w0p = w0g + int64_t(s) * a.ld_w0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) in.y[j] = y[j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
+      in.g0 = gs0[int64_t(s) * a.ld_gscal];
+      in.g1 = gs1[int64_t(s) * a.ld_gscal];
+    };
+    if (beg < end) {
+      EdgeIn<T, D, R> cur, nxt;
+      fetch(beg, cur);
+      for (int s = beg; s < end; ++s) {
+        fetch(s + 1 < end ? s + 1 : s, nxt);
+        T x1[D1];
+#pragma unroll
+        for (int i = 0; i < D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
+        T gn[1], go[DOUT];
+        gn[0] = cur.g1;
+        Sig1::template bx1<T>(gn, x2s1, wp1, go);  // d_tf1, recomputed (never stored)
+        go[0] += cur.g0;
+        T g1[D1], g2[D];
+        Sig0::template bx1<T>(go, x2s0, wp0, g1);
+        Sig0::template bx2<T>(go, x1, wp0, g2);
+#pragma unroll
+        for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+        T gw[R], gy[D1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) gw[r] = T(0);
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+          gw[r_of<0>(i)] += g1[i] * cur.y[i];
+          gy[i] = g1[i] * cur.wa[r_of<0>(i)];
+        }
+        T* gwp = static_cast<T*>(a.g_w0) + int64_t(s) * a.ld_gw0 + lane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) gwp[r * 64] = gw[r];
+        wave_sum_store<T, D1>(gy, static_cast<T*>(a.gsh_x1) + int64_t(s) * a.ld_gsh, true, false);
+        cur = nxt;
+      }
+    }
+  }
+  const T sf = T(a.sf);
+#pragma unroll
+  for (int j = 0; j < D; ++j) g2acc[j] *= sf;
+  mom_backward_edges<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, g2acc,
+                              static_cast<const T*>(ma.wt0), beg, end, lane, sG, static_cast<T*>(ma.g_a), ma.ld_ga,
+                              static_cast<T*>(a.gsh_env), a.ld_gsh);
+}
+
 // (layer-0 signature, last-layer signature) pairs of 2-layer stacks at l_max = 1, 2, 3
 #define AA_FOREACH_CHAIN(X) X(0, Sig1, Sig0) X(1, Sig5, Sig4) X(2, Sig9, Sig8)
 int find_chain_pair(int sig0, int sig1) {
@@ -758,6 +1109,33 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
+
+#define AA_MOM_LAUNCHER(NAME, K1, K2, K3)                                                                 \
+  template <typename T>                                                                                  \
+  int launch_##NAME(int pair, const TpMomArgs& a, hipStream_t stream) {                                  \
+    if (a.c.N == 0) return AA_OK;                                                                        \
+    if (a.c.u != 64 || a.ka0 > kMaxKa || a.ka1 > kMaxKa || (a.ka0 & 63) || (a.ka1 & 63))                \
+      return fail(AA_ERR_INVALID, #NAME ": needs u == 64 and env-input widths of 64 or 128");            \
+    dim3 grid((unsigned)((a.c.N + 3) / 4));                                                              \
+    const int dpair = pair == 0 ? 4 : (pair == 1 ? 9 : 16);                                              \
+    size_t smem = sizeof(T) * 4 * dpair * (kMaxKa + 64);                                                 \
+    if (smem > 64 * 1024) return fail(AA_ERR_INVALID, #NAME ": LDS patch too large for this dtype/l_max"); \
+    switch (pair) {                                                                                      \
+      case 0: hipLaunchKernelGGL((NAME##_kernel<K1, T>), grid, dim3(256), smem, stream, a); break;       \
+      case 1: hipLaunchKernelGGL((NAME##_kernel<K2, T>), grid, dim3(256), smem, stream, a); break;       \
+      case 2: hipLaunchKernelGGL((NAME##_kernel<K3, T>), grid, dim3(256), smem, stream, a); break;       \
+      default: return fail(AA_ERR_INVALID, #NAME ": unknown chain pair");                                \
+    }                                                                                                    \
+    AA_CHECK_HIP(hipGetLastError());                                                                     \
+    return AA_OK;                                                                                        \
+  }                                                                                                      \
+  template int launch_##NAME<float>(int, const TpMomArgs&, hipStream_t);                                 \
+  template int launch_##NAME<double>(int, const TpMomArgs&, hipStream_t);
+#define AA_COMMA ,
+AA_MOM_LAUNCHER(tp_mom_fwd_first, cg::Sig1, cg::Sig5, cg::Sig9)
+AA_MOM_LAUNCHER(tp_mom_fwd_last, cg::Sig1 AA_COMMA cg::Sig0, cg::Sig5 AA_COMMA cg::Sig4, cg::Sig9 AA_COMMA cg::Sig8)
+AA_MOM_LAUNCHER(tp_mom_bwd_last, cg::Sig1 AA_COMMA cg::Sig0, cg::Sig5 AA_COMMA cg::Sig4, cg::Sig9 AA_COMMA cg::Sig8)
+AA_MOM_LAUNCHER(tp_mom_bwd_first, cg::Sig1 AA_COMMA cg::Sig0, cg::Sig5 AA_COMMA cg::Sig4, cg::Sig9 AA_COMMA cg::Sig8)
 
 AA_CHAIN_LAUNCHER(tp_chain_fwd_last)
 AA_CHAIN_LAUNCHER(tp_chain_bwd_last)
