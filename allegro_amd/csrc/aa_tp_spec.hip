@@ -768,16 +768,45 @@ __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const
 }
 }  // namespace
 
+// ---- packed two-edge evaluation: the straight-line CG code is instantiated on 2-vectors (edge s and s+1 in
+// the two halves), which the compiler maps to v_pk_fma_f32 / v_pk_mul_f32; x2s and the path weights stay scalar
+template <typename T>
+struct Pk;
+template <>
+struct Pk<float> {
+  typedef float type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Pk<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+
+template <typename T, int D, int R>
+struct EdgeIn2 {
+  typename Pk<T>::type y[D];
+  typename Pk<T>::type wa[R];
+  typename Pk<T>::type g0, g1;
+};
+
+// common prologue of the moments kernels
+#define AA_MOM_PROLOGUE(DVAL)                                                                                          \
+  const TpChainArgs& a = ma.c;                                                                                         \
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;                                                            \
+  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;                                                                   \
+  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * (DVAL) * (kMaxKa + 64);                                         \
+  T* sG = sM + (DVAL) * kMaxKa;                                                                                        \
+  (void)sG;                                                                                                            \
+  (void)sM;                                                                                                            \
+  if (atom >= a.N) return;                                                                                             \
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]); \
+  const T* sh = static_cast<const T*>(a.sh);                                                                           \
+  const T* w0g = static_cast<const T*>(a.w0) + lane;
+
 template <class Sig0, typename T>
 __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
-  const TpChainArgs& a = ma.c;
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
-  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64);
-  if (atom >= a.N) return;
-  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
-  const T* sh = static_cast<const T*>(a.sh);
+  typedef typename Pk<T>::type T2;
+  AA_MOM_PROLOGUE(D)
   T x2s0[D];
   mom_x2s<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, static_cast<const T*>(ma.wk0), beg, end,
                    T(a.sf), lane, sM, x2s0);
@@ -792,25 +821,29 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[lane * Sig0::P + p] : W0[p];
   }
-  const T* w0g = static_cast<const T*>(a.w0) + lane;
-  auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
-    const T* y = sh + int64_t(s) * a.ld_sh;
-    const T* w0p = w0g + int64_t(s) * a.ld_w0;
+  auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
+    const int sb = s + 1 < end ? s + 1 : s;
+    const T* ya = sh + int64_t(s) * a.ld_sh;
+    const T* yb = sh + int64_t(sb) * a.ld_sh;
+    const T* wa = w0g + int64_t(s) * a.ld_w0;
+    const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-    for (int j = 0; j < D; ++j) in.y[j] = y[j];
+    for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
 #pragma unroll
-    for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
   };
   if (beg < end) {
-    EdgeIn<T, D, R> cur, nxt;
+    EdgeIn2<T, D, R> cur, nxt;
     fetch(beg, cur);
-    for (int s = beg; s < end; ++s) {
-      fetch(s + 1 < end ? s + 1 : s, nxt);
-      T x1[Sig0::D1], tf1[Sig0::DOUT];
+    T* sc = static_cast<T*>(a.scal1) + lane;  // (scal1 field carries the layer-0 scalars here)
+    for (int s = beg; s < end; s += 2) {
+      fetch(s + 2 < end ? s + 2 : s, nxt);
+      T2 x1[Sig0::D1], tf1[Sig0::DOUT];
 #pragma unroll
       for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
-      Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
-      static_cast<T*>(a.scal1)[int64_t(s) * a.ld_scal + lane] = tf1[0];  // (scal1 field carries layer-0 scalars here)
+      Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
+      sc[int64_t(s) * a.ld_scal] = tf1[0][0];
+      if (s + 1 < end) sc[int64_t(s + 1) * a.ld_scal] = tf1[0][1];
       cur = nxt;
     }
   }
@@ -818,14 +851,9 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
 
 template <class Sig0, class Sig1, typename T>
 __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
-  const TpChainArgs& a = ma.c;
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
-  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64);
-  if (atom >= a.N) return;
-  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
-  const T* sh = static_cast<const T*>(a.sh);
+  typedef typename Pk<T>::type T2;
+  AA_MOM_PROLOGUE(D)
   T x2s1[D], x2s0[D];
   mom_x2s<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, static_cast<const T*>(ma.wk1), beg, end,
                    T(a.sf), lane, sM, x2s1);
@@ -848,26 +876,30 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
-  const T* w0g = static_cast<const T*>(a.w0) + lane;
-  auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
-    const T* y = sh + int64_t(s) * a.ld_sh;
-    const T* w0p = w0g + int64_t(s) * a.ld_w0;
+  auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
+    const int sb = s + 1 < end ? s + 1 : s;
+    const T* ya = sh + int64_t(s) * a.ld_sh;
+    const T* yb = sh + int64_t(sb) * a.ld_sh;
+    const T* wa = w0g + int64_t(s) * a.ld_w0;
+    const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-    for (int j = 0; j < D; ++j) in.y[j] = y[j];
+    for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
 #pragma unroll
-    for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
   };
   if (beg < end) {
-    EdgeIn<T, D, R> cur, nxt;
+    EdgeIn2<T, D, R> cur, nxt;
     fetch(beg, cur);
-    for (int s = beg; s < end; ++s) {
-      fetch(s + 1 < end ? s + 1 : s, nxt);
-      T x1[Sig0::D1], tf1[Sig0::DOUT], out[1];
+    T* sc = static_cast<T*>(a.scal1) + lane;
+    for (int s = beg; s < end; s += 2) {
+      fetch(s + 2 < end ? s + 2 : s, nxt);
+      T2 x1[Sig0::D1], tf1[Sig0::DOUT], out[1];
 #pragma unroll
       for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
-      Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
-      Sig1::template fwd<T>(tf1, x2s1, wp1, out);
-      static_cast<T*>(a.scal1)[int64_t(s) * a.ld_scal + lane] = out[0];
+      Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
+      Sig1::template fwd4<T2, T2, T, T>(tf1, x2s1, wp1, out);
+      sc[int64_t(s) * a.ld_scal] = out[0][0];
+      if (s + 1 < end) sc[int64_t(s + 1) * a.ld_scal] = out[0][1];
       cur = nxt;
     }
   }
@@ -875,15 +907,9 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
 
 template <class Sig0, class Sig1, typename T>
 __global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
-  const TpChainArgs& a = ma.c;
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
-  T* sG = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64) + D * kMaxKa;
-  if (atom >= a.N) return;
-  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
-  const T* sh = static_cast<const T*>(a.sh);
-  const T* w0g = static_cast<const T*>(a.w0) + lane;
+  typedef typename Pk<T>::type T2;
+  AA_MOM_PROLOGUE(D)
   const T* gs1 = static_cast<const T*>(a.gscal1) + lane;
   T x2s0[D], g2acc[D];
   {
@@ -904,28 +930,33 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
   {
-    auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
-      const T* y = sh + int64_t(s) * a.ld_sh;
-      const T* w0p = w0g + int64_t(s) * a.ld_w0;
+    auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
+      const bool vb = s + 1 < end;
+      const int sb = vb ? s + 1 : s;
+      const T* ya = sh + int64_t(s) * a.ld_sh;
+      const T* yb = sh + int64_t(sb) * a.ld_sh;
+      const T* wa = w0g + int64_t(s) * a.ld_w0;
+      const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-      for (int j = 0; j < D; ++j) in.y[j] = y[j];
+      for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
 #pragma unroll
-      for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
-      in.g1 = gs1[int64_t(s) * a.ld_gscal];
+      for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
+      const T gb = gs1[int64_t(sb) * a.ld_gscal];
+      in.g1 = T2{gs1[int64_t(s) * a.ld_gscal], vb ? gb : T(0)};  // a padded second edge contributes nothing
     };
     if (beg < end) {
-      EdgeIn<T, D, R> cur, nxt;
+      EdgeIn2<T, D, R> cur, nxt;
       fetch(beg, cur);
-      for (int s = beg; s < end; ++s) {
-        fetch(s + 1 < end ? s + 1 : s, nxt);
-        T x1[Sig0::D1], tf1[Sig0::DOUT], go[1], g2[D];
+      for (int s = beg; s < end; s += 2) {
+        fetch(s + 2 < end ? s + 2 : s, nxt);
+        T2 x1[Sig0::D1], tf1[Sig0::DOUT], go[1], g2[D];
 #pragma unroll
         for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
-        Sig0::template fwd<T>(x1, x2s0, wp0, tf1);
+        Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
         go[0] = cur.g1;
-        Sig1::template bx2<T>(go, tf1, wp1, g2);
+        Sig1::template bx24<T2, T2, T2, T>(go, tf1, wp1, g2);
 #pragma unroll
-        for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
+        for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
         cur = nxt;
       }
     }
@@ -940,15 +971,9 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
 
 template <class Sig0, class Sig1, typename T>
 __global__ __launch_bounds__(256) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
-  const TpChainArgs& a = ma.c;
   constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;
-  T* sG = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * (kMaxKa + 64) + D * kMaxKa;
-  if (atom >= a.N) return;
-  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
-  const T* sh = static_cast<const T*>(a.sh);
-  const T* w0g = static_cast<const T*>(a.w0) + lane;
+  typedef typename Pk<T>::type T2;
+  AA_MOM_PROLOGUE(D)
   const T* gs0 = static_cast<const T*>(a.gscal0) + lane;
   const T* gs1 = static_cast<const T*>(a.gscal1) + lane;
   T x2s0[D], x2s1[D], g2acc[D];
@@ -973,45 +998,60 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
   {
-    auto fetch = [&](int s, EdgeIn<T, D, R>& in) {
-      const T* y = sh + int64_t(s) * a.ld_sh;
-      const T* w0p = w0g + int64_t(s) * a.ld_w0;
+    auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
+      const bool vb = s + 1 < end;
+      const int sb = vb ? s + 1 : s;
+      const T* ya = sh + int64_t(s) * a.ld_sh;
+      const T* yb = sh + int64_t(sb) * a.ld_sh;
+      const T* wa = w0g + int64_t(s) * a.ld_w0;
+      const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-      for (int j = 0; j < D; ++j) in.y[j] = y[j];
+      for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
 #pragma unroll
-      for (int r = 0; r < R; ++r) in.wa[r] = w0p[r * 64];
-      in.g0 = gs0[int64_t(s) * a.ld_gscal];
-      in.g1 = gs1[int64_t(s) * a.ld_gscal];
+      for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
+      const T g0b = gs0[int64_t(sb) * a.ld_gscal], g1b = gs1[int64_t(sb) * a.ld_gscal];
+      in.g0 = T2{gs0[int64_t(s) * a.ld_gscal], vb ? g0b : T(0)};
+      in.g1 = T2{gs1[int64_t(s) * a.ld_gscal], vb ? g1b : T(0)};
     };
     if (beg < end) {
-      EdgeIn<T, D, R> cur, nxt;
+      EdgeIn2<T, D, R> cur, nxt;
       fetch(beg, cur);
-      for (int s = beg; s < end; ++s) {
-        fetch(s + 1 < end ? s + 1 : s, nxt);
-        T x1[D1];
+      T* gw0 = static_cast<T*>(a.g_w0) + lane;
+      T* gsx = static_cast<T*>(a.gsh_x1);
+      for (int s = beg; s < end; s += 2) {
+        fetch(s + 2 < end ? s + 2 : s, nxt);
+        const bool vb = s + 1 < end;
+        T2 x1[D1];
 #pragma unroll
         for (int i = 0; i < D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
-        T gn[1], go[DOUT];
+        T2 gn[1], go[DOUT];
         gn[0] = cur.g1;
-        Sig1::template bx1<T>(gn, x2s1, wp1, go);  // d_tf1, recomputed (never stored)
+        Sig1::template bx14<T2, T2, T, T>(gn, x2s1, wp1, go);  // d_tf1, recomputed (never stored)
         go[0] += cur.g0;
-        T g1[D1], g2[D];
-        Sig0::template bx1<T>(go, x2s0, wp0, g1);
-        Sig0::template bx2<T>(go, x1, wp0, g2);
+        T2 g1[D1], g2[D];
+        Sig0::template bx14<T2, T2, T, T>(go, x2s0, wp0, g1);
+        Sig0::template bx24<T2, T2, T2, T>(go, x1, wp0, g2);
 #pragma unroll
-        for (int j = 0; j < D; ++j) g2acc[j] += g2[j];
-        T gw[R], gy[D1];
+        for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
+        T2 gw[R];
+        T gya[D1], gyb[D1];
 #pragma unroll
-        for (int r = 0; r < R; ++r) gw[r] = T(0);
+        for (int r = 0; r < R; ++r) gw[r] = T2{T(0), T(0)};
 #pragma unroll
         for (int i = 0; i < D1; ++i) {
           gw[r_of<0>(i)] += g1[i] * cur.y[i];
-          gy[i] = g1[i] * cur.wa[r_of<0>(i)];
+          const T2 t = g1[i] * cur.wa[r_of<0>(i)];
+          gya[i] = t[0];
+          gyb[i] = t[1];
         }
-        T* gwp = static_cast<T*>(a.g_w0) + int64_t(s) * a.ld_gw0 + lane;
 #pragma unroll
-        for (int r = 0; r < R; ++r) gwp[r * 64] = gw[r];
-        wave_sum_store<T, D1>(gy, static_cast<T*>(a.gsh_x1) + int64_t(s) * a.ld_gsh, true, false);
+        for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * 64] = gw[r][0];
+        wave_sum_store<T, D1>(gya, gsx + int64_t(s) * a.ld_gsh, true, false);
+        if (vb) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) gw0[int64_t(s + 1) * a.ld_gw0 + r * 64] = gw[r][1];
+          wave_sum_store<T, D1>(gyb, gsx + int64_t(s + 1) * a.ld_gsh, true, false);
+        }
         cur = nxt;
       }
     }
