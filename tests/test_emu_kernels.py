@@ -59,3 +59,34 @@ def test_contracter_matches_reference_cases(dtype, tol):
                 assert (got.double() - torch.tensor(want)).abs().max().item() < tol
     finally:
         torch.set_default_dtype(old)
+
+
+def test_moments_packed_path_ragged_degrees_vs_oracle():
+    """u=64 / S=64 routes to the moments + packed two-edge kernels; ragged segments (odd degrees, an isolated
+    atom) exercise the padded second edge.  Checked against the oracle restatement in fp64."""
+    import numpy as np
+
+    from oracle import restatement as R
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(0, 7.5, size=(14, 3))
+    pos[13] = [30.0, 30.0, 30.0]  # isolated: degree 0
+    cell = np.eye(3) * 60.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
+    deg = np.bincount(ei[0], minlength=14)
+    assert (deg % 2 == 1).any() and deg[13] == 0 and ei.shape[1] > 20
+    cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=2, num_layers=2, num_scalar_features=64, num_tensor_features=64,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               radial_chemical_embed_dim=16, scalar_embed_mlp_hidden_layers_width=32, allegro_mlp_hidden_layers_width=64,
+               readout_mlp_hidden_layers_width=32, avg_num_neighbors=float(deg.mean()), seed=11, model_dtype="float64")
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    types = torch.tensor(rng.integers(0, 2, size=14))
+    g = m.prepare_graph(torch.tensor(ei), types, 14, torch.tensor(shift @ cell))
+    e, f = m.energy_forces(torch.tensor(pos), g)
+    sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, torch.tensor(shift @ cell))
+    assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9 * max(1.0, float(ref["atomic_energy"].abs().max()))
+    assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))
