@@ -93,6 +93,29 @@ struct GemmArgs {
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
+
+// Fused chain of up to 3 linear layers (fp32 via bf16x3): the 64-wide output of layer i stays in the MFMA
+// accumulators and is consumed as (the trailing 64 inputs of) layer i+1.  Each layer is a GemmArgs (A segments
+// may be empty) plus chaining flags.
+struct ChainLayer {
+  GemmArgs g;        // M, K (incl. 64 chained inputs if use_prev), N, a (global inputs), Bq, c/z/add (a C segment with
+                     // p == nullptr is computed but not stored), act_a
+  int use_prev;      // append the previous layer's kept 64 features as the last two k chunks
+  int keep_tile;     // first of the two output tiles kept for the next layer, or -1
+  int keep_act;      // silu on the kept values
+  int a_mode;        // 1: A[e,k] = ro_factor * scale(type(center e)) * ro_w[k] * silu'(a[e,k])  (readout reverse)
+};
+struct ChainArgs {
+  int64_t M;
+  int nlayers;
+  ChainLayer L[3];
+  const void* ro_w;      // a_mode 1 extras
+  double ro_factor;
+  const void* ro_scales; // [T] or nullptr
+  const int32_t* types;
+  const int32_t* center;
+};
+int launch_gemm_chain(const ChainArgs& c, hipStream_t stream);  // fp32 only
 // element count of the fragment-ordered copy of a [K,N] matrix, and the host-side packer
 size_t gemm_packed_elems(int K, int N);
 void gemm_pack_b(const double* B, int K, int N, double* out);

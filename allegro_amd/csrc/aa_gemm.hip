@@ -306,7 +306,7 @@ __device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0) 
   for (int s = 0; s < 3; ++s) {
     const bool live = s < g.c.count;
     if (live && !done && c < g.c.s[s].n) {
-      d.c = static_cast<float*>(g.c.s[s].p) + gm * g.c.s[s].ld + c;
+      d.c = g.c.s[s].p ? static_cast<float*>(g.c.s[s].p) + gm * g.c.s[s].ld + c : nullptr;
       d.accum = g.c_accum[s];
       if (g.has_z) d.z = static_cast<const float*>(g.z.s[s].p) + gm * g.z.s[s].ld + c;
       if (g.has_add) d.add = static_cast<const float*>(g.add.s[s].p) + gm * g.add.s[s].ld + c;
@@ -521,6 +521,27 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int v
   }
 }
 
+// "accumulator order" k-permutation used by the bf16x3 kernels: element s (0..15) of lane half h in chunk c is
+// feature k = 32c + 8*(s>>2) + 4h + (s&3) -- exactly the feature a lane holds in accumulator register s of the
+// swapped-operand C layout, so a layer's accumulators can be fed to the next layer's MFMAs without any data
+// movement (gemm_chain_bf16x3_kernel).  From global memory it is four 16-B pieces of the lane's own row.
+__device__ __forceinline__ void load_a_frag_acc(const GemmArgs& g, int64_t gm, int chunk, int h, v4f* a) {
+  const float* p = a_half_ptr(g, gm, chunk * 32);  // pointer to A[gm][32*chunk] (segments are 32-granular here)
+  if (p) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(p + 8 * q + 4 * h);
+    if (g.act_a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[q][e] = silu(a[q][e]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = v4f{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 GEMM on the bf16 matrix cores by exact 3-way splitting ("bf16x3").
 // Every fp32 value is the exact sum of three bf16 numbers (x = x1 + x2 + x3: 3 x 8 significand bits,
@@ -595,7 +616,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
-  const int kh = (lane >> 5) * 16;
+  const int hh = lane >> 5;
   const int KC = (g.K + 31) >> 5;
   const int NT = (g.N + 31) >> 5;
   const u32x4* Wl = Wq + size_t(lane) * 6;
@@ -607,7 +628,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
 #pragma unroll
     for (int kc = 0; kc < KCR; ++kc) {
       v4f a[4];
-      load_a_frag(g, gm, kc * 32 + kh, a);
+      load_a_frag_acc(g, gm, kc, hh, a);
       split3_pack(a, xr1[kc], xr2[kc], xr3[kc]);
     }
   }
@@ -649,8 +670,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
       }
     } else {
       v4f a0[4], a1[4];
-      load_a_frag(g, gm, kh, a0);
-      load_a_frag(g, gm, (KC > 1 ? 32 : 0) + kh, a1);
+      load_a_frag_acc(g, gm, 0, hh, a0);
+      load_a_frag_acc(g, gm, KC > 1 ? 1 : 0, hh, a1);
       for (int kc = 0; kc < KC; ++kc) {
         // L2-resident weights are requested BEFORE the HBM activations: loads return in order, so the other
         // way round every step would wait a full HBM latency for its weights
@@ -667,7 +688,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
         __builtin_amdgcn_sched_barrier(0);
         v4f a2[4];
         const int k2 = kc + 2 < KC ? kc + 2 : KC - 1;
-        load_a_frag(g, gm, k2 * 32 + kh, a2);  // two chunks ahead
+        load_a_frag_acc(g, gm, k2, hh, a2);  // two chunks ahead
         __builtin_amdgcn_sched_barrier(0);
         u32x4 x1[2], x2[2], x3[2];
         split3_pack(a0, x1, x2, x3);
@@ -693,6 +714,187 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused chain of linear layers (see ChainArgs in aa_common.h).  One wave = 32 edges; a layer's 64 kept output
+// features stay in accumulator registers (optionally activated) and are split into bf16 levels as the last
+// two k chunks of the next layer -- the hidden activations of the reference's ScalarMLPFunction chains never
+// travel through HBM except for the one store of the pre-activation that the reverse pass needs.
+// ---------------------------------------------------------------------------------------------
+struct XSplit {
+  u32x4 l1[2], l2[2], l3[2];
+};
+__device__ __forceinline__ void xsplit_from_acc(const v16f& acc, XSplit& x) {
+  v4f a[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  split3_pack(a, x.l1, x.l2, x.l3);
+}
+
+// epilogue values of one tile in accumulator layout: (acc + add) * silu'(z); valid mask per 4-group returned
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, v16f& acc, int64_t gm, int n0, int lane, Dst4* dst) {
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int f0 = n0 + 8 * gq + 4 * (lane >> 5);
+    const Dst4 d = resolve4(g, gm, f0);
+    dst[gq] = d;
+    if (d.nvalid == 0) continue;
+    if (d.add) {
+      const v4f ad = *reinterpret_cast<const v4f*>(d.add);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * gq + e] += ad[e];
+    }
+    if (d.z) {
+      const v4f z = *reinterpret_cast<const v4f*>(d.z);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * gq + e] *= dsilu(z[e]);
+    }
+  }
+}
+__device__ __forceinline__ void tile_store(const v16f& acc, const Dst4* dst) {
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const Dst4& d = dst[gq];
+    if (d.nvalid == 0 || d.c == nullptr) continue;
+    v4f v = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
+    if (d.accum) {
+      const v4f o = *reinterpret_cast<const v4f*>(d.c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += o[e];
+    }
+    *reinterpret_cast<v4f*>(d.c) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
+  const int64_t gm = m0 + (lane & 31);
+  const int hh = lane >> 5;
+  const bool row_ok = gm < c.M;
+  v16f kept0, kept1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    kept0[r] = 0.f;
+    kept1[r] = 0.f;
+  }
+  for (int li = 0; li < c.nlayers; ++li) {
+    const ChainLayer& L = c.L[li];
+    const GemmArgs& g = L.g;
+    const int KCg = (g.K - (L.use_prev ? 64 : 0) + 31) >> 5;  // chunks coming from global memory
+    const int KC = KCg + (L.use_prev ? 2 : 0);
+    const int NT = (g.N + 31) >> 5;
+    const u32x4* Wl = static_cast<const u32x4*>(g.Bq) + size_t(lane) * 6;
+    const size_t chunk_stride = 64 * 6, tile_stride = size_t(KC) * chunk_stride;
+    XSplit xp[2];
+    if (L.use_prev) {
+      xsplit_from_acc(kept0, xp[0]);
+      xsplit_from_acc(kept1, xp[1]);
+    }
+    // readout-reverse transform factor of this row
+    float rofac = 0.f;
+    if (L.a_mode == 1 && row_ok) {
+      rofac = float(c.ro_factor);
+      if (c.ro_scales) rofac *= static_cast<const float*>(c.ro_scales)[c.types[c.center[gm]]];
+    }
+    v16f nk0, nk1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      nk0[r] = 0.f;
+      nk1[r] = 0.f;
+    }
+    for (int nt = 0; nt < NT; nt += 2) {
+      const bool two = nt + 1 < NT;
+      v16f acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[r] = 0.f;
+        acc1[r] = 0.f;
+      }
+      const u32x4* wp0 = Wl + size_t(nt) * tile_stride;
+      const u32x4* wp1 = Wl + size_t(two ? nt + 1 : nt) * tile_stride;
+      for (int kc = 0; kc < KCg; ++kc) {
+        u32x4 w0[6], w1[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          w0[q] = wp0[size_t(kc) * chunk_stride + q];
+          w1[q] = wp1[size_t(kc) * chunk_stride + q];
+        }
+        v4f a[4];
+        if (L.a_mode == 1) {
+          const float* p = a_half_ptr(g, gm, kc * 32);
+          const float* rw = static_cast<const float*>(c.ro_w) + kc * 32;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f hv = p ? *reinterpret_cast<const v4f*>(p + 8 * q + 4 * hh) : v4f{0.f, 0.f, 0.f, 0.f};
+            const v4f wv4 = *reinterpret_cast<const v4f*>(rw + 8 * q + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[q][e] = p ? rofac * wv4[e] * dsilu(hv[e]) : 0.f;
+          }
+        } else {
+          load_a_frag_acc(g, gm, kc, hh, a);
+        }
+        XSplit x;
+        split3_pack(a, x.l1, x.l2, x.l3);
+        chunk_pair_bf16x3(w0, w1, x.l1, x.l2, x.l3, acc0, acc1);
+      }
+      if (L.use_prev) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          u32x4 w0[6], w1[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            w0[q] = wp0[size_t(KCg + t) * chunk_stride + q];
+            w1[q] = wp1[size_t(KCg + t) * chunk_stride + q];
+          }
+          chunk_pair_bf16x3(w0, w1, xp[t].l1, xp[t].l2, xp[t].l3, acc0, acc1);
+        }
+      }
+      Dst4 d0[4], d1[4];
+      tile_epilogue(g, acc0, gm, nt * 32, lane, d0);
+      tile_store(acc0, d0);
+      if (two) {
+        tile_epilogue(g, acc1, gm, nt * 32 + 32, lane, d1);
+        tile_store(acc1, d1);
+      }
+      if (nt == L.keep_tile) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          nk0[r] = L.keep_act ? silu(acc0[r]) : acc0[r];
+          nk1[r] = L.keep_act ? silu(acc1[r]) : acc1[r];
+        }
+      }
+    }
+    kept0 = nk0;
+    kept1 = nk1;
+  }
+}
+
+int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
+  if (c.M == 0) return AA_OK;
+  for (int li = 0; li < c.nlayers; ++li) {
+    const ChainLayer& L = c.L[li];
+    const GemmArgs& g = L.g;
+    int ka = 0, nc = 0;
+    for (int s = 0; s < g.a.count; ++s) {
+      ka += g.a.s[s].n;
+      if ((g.a.s[s].n & 31) || (g.a.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.a.s[s].p) & 15))
+        return fail(AA_ERR_INVALID, "gemm chain: A segments must be 32-column granular and 16-B aligned");
+    }
+    for (int s = 0; s < g.c.count; ++s) {
+      nc += g.c.s[s].n;
+      if ((g.c.s[s].n & 3) || (g.c.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.c.s[s].p) & 15))
+        return fail(AA_ERR_INVALID, "gemm chain: C segments must be 4-column granular and 16-B aligned");
+    }
+    if (ka + (L.use_prev ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
+    if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 > g.N)) return fail(AA_ERR_INVALID, "gemm chain: bad keep_tile");
+    if (L.use_prev && (li == 0 || c.L[li - 1].keep_tile < 0)) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
+  }
+  dim3 grid((unsigned)((c.M + 127) / 128));
+  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), 0, stream, c);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
 // element count (32-bit words) of the split weight copy, and the host-side packer (from the fp32 matrix)
 size_t gemm_bf16x3_words(int K, int N) { return size_t((N + 31) / 32) * size_t((K + 31) / 32) * 64 * 24; }
 void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out) {
@@ -716,7 +918,7 @@ void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out) {
             unsigned h[3][2];
             for (int e = 0; e < 2; ++e) {
               int s = half * 8 + q * 2 + e;
-              int k = kc * 32 + (lane >> 5) * 16 + s, n = nt * 32 + (lane & 31);
+              int k = kc * 32 + 8 * (s >> 2) + 4 * (lane >> 5) + (s & 3), n = nt * 32 + (lane & 31);  // accumulator order
               float x = (k < K && n < N) ? B[size_t(k) * N + n] : 0.f;
               h[0][e] = trunc(x);
               float r = x - tof(h[0][e]);
@@ -809,7 +1011,9 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
       const char* e = getenv("AA_GEMM_DIRECT_EPILOGUE");  // A/B switch: 16-B per-lane epilogue without the LDS transpose
       direct_epi = (e && e[0] == '0') ? 0 : 1;  // default: direct (the LDS-transposed variant measured slower)
     }
-    if (g.Bq && !no_split) {
+    bool seg32 = true;
+    for (int q = 0; q < g.a.count; ++q) seg32 = seg32 && (g.a.s[q].n % 32 == 0);
+    if (g.Bq && !no_split && seg32) {
       const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
       const bool lds = vec_ok && !direct_epi;
       const size_t smem = lds ? sizeof(float) * 4 * 32 * EP_LD : 0;

@@ -116,6 +116,7 @@ struct aa_model_plan {
   bool use_spec;                     // all layers specialised -> channel-minor internal layouts
   int chain_pair;                    // >= 0: 2-layer stack on the chain kernels (no [E,u,D] tensors in HBM)
   bool env_mom;                      // chain + moments: no [E,R*u] env tensors either (TpMomArgs in aa_common.h)
+  bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[2], o_wt[2];           // Wenv of layer l as [ka][R][u] and [R][u][ka]
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
@@ -204,6 +205,15 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     }
   };
   lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
+  {
+    const char* ncg = getenv("AA_GEMM_NOCHAIN");
+    const char* f32 = getenv("AA_GEMM_FP32_MFMA");
+    const char* vl = getenv("AA_GEMM_VALU");
+    p->chain_gemm = p->env_mom && cfg->dtype == AA_F32 && S == 64 && cfg->embed_mlp_depth == 1 &&
+                    cfg->embed_mlp_width == 64 && cfg->latent_mlp_depth == 1 && cfg->latent_mlp_width == 64 &&
+                    cfg->readout_mlp_depth == 1 && cfg->readout_mlp_width == 64 && cfg->embed_dim % 32 == 0 &&
+                    !(ncg && ncg[0] == '1') && !(f32 && f32[0] == '1') && !(vl && vl[0] == '1');
+  }
   p->ng0 = p->env_mom ? S + p->W : S + 2 * p->W;
   p->o_g0 = take(size_t(S) * p->ng0);
   p->o_g0t = take(size_t(S) * p->ng0);
@@ -638,6 +648,39 @@ struct Runner {
     return a;
   }
 
+  // ---- fused GEMM chains (plan->chain_gemm) -------------------------------------------------------------
+  static ChainLayer chain_layer(int64_t M, const SegList& a, int act_a, const void* Bq, int K, int Nn, const SegList& c,
+                                const int* accum, const SegList* z, const SegList* add, int use_prev, int keep_tile,
+                                int keep_act) {
+    ChainLayer L{};
+    L.g.M = M;
+    L.g.K = K;
+    L.g.N = Nn;
+    L.g.a = a;
+    L.g.Bq = Bq;
+    L.g.c = c;
+    for (int i = 0; i < 3; ++i) L.g.c_accum[i] = accum ? accum[i] : 0;
+    L.g.has_z = z ? 1 : 0;
+    if (z) L.g.z = *z;
+    L.g.has_add = add ? 1 : 0;
+    if (add) L.g.add = *add;
+    L.g.act_a = act_a;
+    L.use_prev = use_prev;
+    L.keep_tile = keep_tile;
+    L.keep_act = keep_act;
+    return L;
+  }
+  int run_chain(ChainArgs& ca, const char* tag) {
+    ca.M = E;
+    if (int rc = launch_gemm_chain(ca, stream)) return rc;
+    if (!prof) return AA_OK;
+    char nm[32];
+    int o = snprintf(nm, sizeof(nm), "gc");
+    for (int i = 0; i < ca.nlayers && o < 28; ++i) o += snprintf(nm + o, sizeof(nm) - o, "_%dx%d", ca.L[i].g.K, ca.L[i].g.N);
+    (void)tag;
+    return mark(nm);
+  }
+
   TpMomArgs mom_args(const aa_graph* g) const {
     const aa_model_config& c = p->cfg;
     TpMomArgs m{};
@@ -672,6 +715,20 @@ struct Runner {
     if (int rc = mark("begin")) return rc;
     if (int rc = launch_edge_prologue<T>(geom(g, pos), stream)) return rc;
     if (int rc = mark("edge_prologue")) return rc;
+    const SegList none{0, {}};
+    if (p->chain_gemm) {
+      // 3 + 4 + 5a as ONE kernel: emb0 -> h_e -> emb -> [two_body | w0]; hidden layers stay in registers
+      ChainArgs ca{};
+      ca.nlayers = 3;
+      SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
+      SegList c0{1, {seg(buf(w.se_h[0]), 64, 64)}};
+      SegList c1{1, {seg(buf(w.emb), S, S)}};
+      SegList c2{2, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W)}};
+      ca.L[0] = chain_layer(E, in, 0, wt(p->embed.wq[0]), c.embed_dim, 64, c0, nullptr, nullptr, nullptr, 0, 0, 1);
+      ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wq[1]), 64, S, c1, nullptr, nullptr, nullptr, 1, 0, 0);
+      ca.L[2] = chain_layer(E, none, 0, wt(p->o_g0q), 64, p->ng0, c2, nullptr, nullptr, nullptr, 1, -1, 0);
+      if (int rc = run_chain(ca, "F1")) return rc;
+    } else {
     // 3: scalar_embed_mlp
     {
       SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
@@ -684,6 +741,7 @@ struct Runner {
       SegList out{3, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W), seg(buf(w.envw[0]), W, W)}};
       if (p->env_mom) out.count = 2;
       if (int rc = gemm(in, 0, wt(p->o_g0), wt(p->o_g0p), wt(p->o_g0q), S, p->ng0, out, nullptr, nullptr)) return rc;
+    }
     }
     // 5: layers
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
@@ -745,6 +803,26 @@ struct Runner {
       if (int rc = launch_tp_layer_fwd<T>(p->layers[l], a, stream)) return rc;
       if (int rc = mark("tp_layer_fwd")) return rc;
       }
+      if (p->chain_gemm) {
+        ChainArgs ca{};
+        SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
+        SegList ch{1, {seg(buf(w.lat_h[l][0]), 64, 64)}};
+        SegList cl{1, {seg(buf(w.fcat) + S * (l + 1), SL1, S)}};
+        ca.L[0] = chain_layer(E, in, 0, wt(p->latent[l].wq[0]), S * (l + 1) + u, 64, ch, nullptr, nullptr, nullptr, 0, 0, 1);
+        if (l < L - 1) {
+          ca.nlayers = 2;
+          ca.L[1] = chain_layer(E, none, 0, wt(p->latent[l].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, -1, 0);
+        } else {
+          // last latent + the readout's GEMM layer: lat_{L-1} stays in registers as the tail of the readout input
+          ca.nlayers = 3;
+          SegList fin{1, {seg(buf(w.fcat), SL1, S * L)}};
+          SegList cr{1, {seg(buf(w.ro_h[0]), 64, 64)}};
+          ca.L[1] = chain_layer(E, none, 0, wt(p->latent[l].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, 0, 0);
+          ca.L[2] = chain_layer(E, fin, 0, wt(p->readout.wq[0]), S * L + 64, 64, cr, nullptr, nullptr, nullptr, 1, -1, 0);
+        }
+        if (int rc = run_chain(ca, "F2")) return rc;
+        continue;
+      }
       SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
       SegList out;
       out.count = (l < L - 1 && !p->env_mom) ? 2 : 1;
@@ -753,7 +831,7 @@ struct Runner {
       if (int rc = mlp_fwd(p->latent[l], c.latent_mlp_depth + 1, in, w.lat_h[l], out)) return rc;
     }
     // 6: edge readout GEMM layers, 7-8: last linear + edge sum + per-type scale/shift
-    if (c.readout_mlp_depth > 0) {
+    if (c.readout_mlp_depth > 0 && !p->chain_gemm) {
       SegList a{1, {seg(buf(w.fcat), SL1, SL1)}};
       for (int i = 0; i < c.readout_mlp_depth; ++i) {
         SegList cs{1, {seg(buf(w.ro_h[i]), c.readout_mlp_width, c.readout_mlp_width)}};
@@ -776,6 +854,29 @@ struct Runner {
     if (!gsh_stores) AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * num_gsh * sizeof(T), stream));
     AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
     if (int rc = mark("memset")) return rc;
+    const SegList none{0, {}};
+    if (p->chain_gemm) {
+      // readout reverse + last latent reverse in ONE kernel; d_lat_{L-1} and d_h never leave registers
+      ReadoutArgs r = readout_args(g, nullptr);
+      ChainArgs ca{};
+      ca.nlayers = 3;
+      ca.ro_w = r.w;
+      ca.ro_factor = r.factor;
+      ca.ro_scales = r.scales;
+      ca.types = g->types;
+      ca.center = g->center;
+      SegList in{1, {seg(buf(w.ro_h[0]), 64, 64)}};
+      SegList c0{2, {seg(buf(w.g_fcat), SL1, S * L), seg(nullptr, 64, S)}};
+      SegList cn{1, {seg(nullptr, 64, 64)}};
+      SegList z1{1, {seg(buf(w.lat_h[L - 1][0]), 64, 64)}};
+      SegList c2{2, {seg(buf(w.g_fcat), SL1, S * L), seg(buf(w.g_scal[L - 1]), u, u)}};
+      int acc2[3] = {1, 0, 0};
+      ca.L[0] = chain_layer(E, in, 0, wt(p->readout.wtq[0]), 64, S * (L + 1), c0, nullptr, nullptr, nullptr, 0, (S * L) / 32, 0);
+      ca.L[0].a_mode = 1;
+      ca.L[1] = chain_layer(E, none, 0, wt(p->latent[L - 1].wtq[1]), S, 64, cn, nullptr, &z1, nullptr, 1, 0, 0);
+      ca.L[2] = chain_layer(E, none, 0, wt(p->latent[L - 1].wtq[0]), 64, S * L + u, c2, acc2, nullptr, nullptr, 1, -1, 0);
+      if (int rc = run_chain(ca, "B3")) return rc;
+    } else
     // readout
     {
       ReadoutArgs r = readout_args(g, nullptr);
@@ -808,6 +909,21 @@ struct Runner {
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
     for (int l = L - 1; l >= 0; --l) {
       // latent MLP reverse
+      if (p->chain_gemm && l == L - 1) {
+        // (already done inside the readout chain above)
+      } else if (p->chain_gemm) {
+        ChainArgs ca{};
+        ca.nlayers = 2;
+        SegList in{1, {seg(buf(w.g_fcat) + S * (l + 1), SL1, S)}};
+        SegList cn{1, {seg(nullptr, 64, 64)}};
+        SegList zz{1, {seg(buf(w.lat_h[l][0]), 64, 64)}};
+        SegList ad{1, {seg(buf(w.g_aenv), 64, 64)}};
+        SegList c1{2, {seg(buf(w.g_fcat), SL1, S * (l + 1)), seg(buf(w.g_scal[l]), u, u)}};
+        int acc1[3] = {1, 0, 0};
+        ca.L[0] = chain_layer(E, in, 0, wt(p->latent[l].wtq[1]), S, 64, cn, nullptr, &zz, &ad, 0, 0, 0);
+        ca.L[1] = chain_layer(E, none, 0, wt(p->latent[l].wtq[0]), 64, S * (l + 1) + u, c1, acc1, nullptr, nullptr, 1, -1, 0);
+        if (int rc = run_chain(ca, "B2")) return rc;
+      } else {
       SegList go;
       go.count = (l < L - 1 && !p->env_mom) ? 2 : 1;
       go.s[0] = seg(buf(w.g_fcat) + S * (l + 1), SL1, S);
@@ -817,6 +933,7 @@ struct Runner {
       SegList gi{2, {seg(buf(w.g_fcat), SL1, S * (l + 1)), seg(buf(w.g_scal[l]), u, u)}};
       int acc[3] = {1, 0, 0};
       if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc, addp)) return rc;
+      }
       // tensor-product layer reverse
       if (p->env_mom) {
         TpMomArgs m = mom_args(g);
@@ -919,6 +1036,20 @@ struct Runner {
       if (int rc = launch_tp_layer_bwd<T>(p->layers[l], a, stream)) return rc;
       if (int rc = mark("tp_layer_bwd")) return rc;
     }
+    if (p->chain_gemm) {
+      // first-stage reverse + scalar_embed_mlp reverse in ONE kernel
+      ChainArgs ca{};
+      ca.nlayers = 3;
+      SegList in{2, {seg(buf(w.g_fcat), SL1, S), seg(buf(w.g_w0), W, W)}};
+      SegList cn{1, {seg(nullptr, 64, 64)}};
+      SegList ad{1, {seg(buf(w.g_aenv), S, S)}};
+      SegList zz{1, {seg(buf(w.se_h[0]), 64, 64)}};
+      SegList ce{1, {seg(buf(w.g_emb0), c.embed_dim, c.embed_dim)}};
+      ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0tq), p->ng0, S, cn, nullptr, nullptr, &ad, 0, 0, 0);
+      ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wtq[1]), S, 64, cn, nullptr, &zz, nullptr, 1, 0, 0);
+      ca.L[2] = chain_layer(E, none, 0, wt(p->embed.wtq[0]), 64, c.embed_dim, ce, nullptr, nullptr, nullptr, 1, -1, 0);
+      if (int rc = run_chain(ca, "B1")) return rc;
+    } else {
     // fused first stage reverse
     {
       SegList go{3, {seg(buf(w.g_fcat), SL1, S), seg(buf(w.g_w0), W, W), seg(buf(w.g_envw), W, W)}};
@@ -934,6 +1065,7 @@ struct Runner {
       SegList go{1, {seg(buf(w.g_emb), S, S)}};
       SegList gi{1, {seg(buf(w.g_emb0), c.embed_dim, c.embed_dim)}};
       if (int rc = mlp_bwd(p->embed, c.embed_mlp_depth + 1, go, w.se_h, w.g_se_h, gi, nullptr)) return rc;
+    }
     }
     EdgeBwdArgs eb{};
     eb.g = geom(g, pos);
