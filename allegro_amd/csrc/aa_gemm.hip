@@ -730,38 +730,35 @@ __device__ __forceinline__ void xsplit_from_acc(const v16f& acc, XSplit& x) {
   split3_pack(a, x.l1, x.l2, x.l3);
 }
 
-// epilogue values of one tile in accumulator layout: (acc + add) * silu'(z); valid mask per 4-group returned
-__device__ __forceinline__ void tile_epilogue(const GemmArgs& g, v16f& acc, int64_t gm, int n0, int lane, Dst4* dst) {
+// epilogue of one tile in accumulator layout, in place: acc <- (acc + add) * silu'(z), then stored (=|+=) unless
+// the destination segment is a "computed only" (null) segment
+__device__ __forceinline__ void tile_epilogue_store(const GemmArgs& g, v16f& acc, int64_t gm, int n0, int lane) {
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const int f0 = n0 + 8 * gq + 4 * (lane >> 5);
     const Dst4 d = resolve4(g, gm, f0);
-    dst[gq] = d;
     if (d.nvalid == 0) continue;
+    v4f v = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
     if (d.add) {
       const v4f ad = *reinterpret_cast<const v4f*>(d.add);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[4 * gq + e] += ad[e];
+      for (int e = 0; e < 4; ++e) v[e] += ad[e];
     }
     if (d.z) {
       const v4f z = *reinterpret_cast<const v4f*>(d.z);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[4 * gq + e] *= dsilu(z[e]);
+      for (int e = 0; e < 4; ++e) v[e] *= dsilu(z[e]);
     }
-  }
-}
-__device__ __forceinline__ void tile_store(const v16f& acc, const Dst4* dst) {
 #pragma unroll
-  for (int gq = 0; gq < 4; ++gq) {
-    const Dst4& d = dst[gq];
-    if (d.nvalid == 0 || d.c == nullptr) continue;
-    v4f v = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
-    if (d.accum) {
-      const v4f o = *reinterpret_cast<const v4f*>(d.c);
+    for (int e = 0; e < 4; ++e) acc[4 * gq + e] = v[e];
+    if (d.c) {
+      if (d.accum) {
+        const v4f o = *reinterpret_cast<const v4f*>(d.c);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += o[e];
+        for (int e = 0; e < 4; ++e) v[e] += o[e];
+      }
+      *reinterpret_cast<v4f*>(d.c) = v;
     }
-    *reinterpret_cast<v4f*>(d.c) = v;
   }
 }
 
@@ -785,13 +782,7 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
     const int NT = (g.N + 31) >> 5;
     const u32x4* Wl = static_cast<const u32x4*>(g.Bq) + size_t(lane) * 6;
     const size_t chunk_stride = 64 * 6, tile_stride = size_t(KC) * chunk_stride;
-    XSplit xp[2];
-    if (L.use_prev) {
-      xsplit_from_acc(kept0, xp[0]);
-      xsplit_from_acc(kept1, xp[1]);
-    }
-    // readout-reverse transform factor of this row
-    float rofac = 0.f;
+    float rofac = 0.f;  // readout-reverse transform factor of this row
     if (L.a_mode == 1 && row_ok) {
       rofac = float(c.ro_factor);
       if (c.ro_scales) rofac *= static_cast<const float*>(c.ro_scales)[c.types[c.center[gm]]];
@@ -812,7 +803,7 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
       }
       const u32x4* wp0 = Wl + size_t(nt) * tile_stride;
       const u32x4* wp1 = Wl + size_t(two ? nt + 1 : nt) * tile_stride;
-      for (int kc = 0; kc < KCg; ++kc) {
+      for (int kc = 0; kc < KC; ++kc) {
         u32x4 w0[6], w1[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -820,7 +811,14 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
           w1[q] = wp1[size_t(kc) * chunk_stride + q];
         }
         v4f a[4];
-        if (L.a_mode == 1) {
+        if (kc >= KCg) {
+          // chained chunk: the previous layer's accumulators ARE this layer's operand (same k order)
+          const bool first = kc == KCg;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[q][e] = first ? kept0[4 * q + e] : kept1[4 * q + e];
+        } else if (L.a_mode == 1) {
           const float* p = a_half_ptr(g, gm, kc * 32);
           const float* rw = static_cast<const float*>(c.ro_w) + kc * 32;
 #pragma unroll
@@ -833,29 +831,12 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
         } else {
           load_a_frag_acc(g, gm, kc, hh, a);
         }
-        XSplit x;
-        split3_pack(a, x.l1, x.l2, x.l3);
-        chunk_pair_bf16x3(w0, w1, x.l1, x.l2, x.l3, acc0, acc1);
+        u32x4 x1[2], x2[2], x3[2];
+        split3_pack(a, x1, x2, x3);
+        chunk_pair_bf16x3(w0, w1, x1, x2, x3, acc0, acc1);
       }
-      if (L.use_prev) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          u32x4 w0[6], w1[6];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            w0[q] = wp0[size_t(KCg + t) * chunk_stride + q];
-            w1[q] = wp1[size_t(KCg + t) * chunk_stride + q];
-          }
-          chunk_pair_bf16x3(w0, w1, xp[t].l1, xp[t].l2, xp[t].l3, acc0, acc1);
-        }
-      }
-      Dst4 d0[4], d1[4];
-      tile_epilogue(g, acc0, gm, nt * 32, lane, d0);
-      tile_store(acc0, d0);
-      if (two) {
-        tile_epilogue(g, acc1, gm, nt * 32 + 32, lane, d1);
-        tile_store(acc1, d1);
-      }
+      tile_epilogue_store(g, acc0, gm, nt * 32, lane);
+      if (two) tile_epilogue_store(g, acc1, gm, nt * 32 + 32, lane);
       if (nt == L.keep_tile) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
