@@ -793,6 +793,41 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
       nk0[r] = 0.f;
       nk1[r] = 0.f;
     }
+    // operand fragment of chunk kc: global (plain / readout-reverse transform) or the chained accumulators
+    auto build_a = [&](int kc, v4f* a) {
+      if (kc >= KCg) {
+        const bool first = kc == KCg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[q][e] = first ? kept0[4 * q + e] : kept1[4 * q + e];
+      } else if (L.a_mode == 1) {
+        const float* p = a_half_ptr(g, gm, kc * 32);
+        const float* rw = static_cast<const float*>(c.ro_w) + kc * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f hv = p ? *reinterpret_cast<const v4f*>(p + 8 * q + 4 * hh) : v4f{0.f, 0.f, 0.f, 0.f};
+          const v4f wv4 = *reinterpret_cast<const v4f*>(rw + 8 * q + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[q][e] = p ? rofac * wv4[e] * dsilu(hv[e]) : 0.f;
+        }
+      } else {
+        load_a_frag_acc(g, gm, kc, hh, a);
+      }
+    };
+    // few k chunks but several tile pairs: split the operands once, not once per pair
+    const bool pre = KC <= 2 && NT > 2;
+    u32x4 ps1[2][2], ps2[2][2], ps3[2][2];
+    if (pre) {
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        if (kc < KC) {
+          v4f a[4];
+          build_a(kc, a);
+          split3_pack(a, ps1[kc], ps2[kc], ps3[kc]);
+        }
+      }
+    }
     for (int nt = 0; nt < NT; nt += 2) {
       const bool two = nt + 1 < NT;
       v16f acc0, acc1;
@@ -803,37 +838,33 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
       }
       const u32x4* wp0 = Wl + size_t(nt) * tile_stride;
       const u32x4* wp1 = Wl + size_t(two ? nt + 1 : nt) * tile_stride;
-      for (int kc = 0; kc < KC; ++kc) {
-        u32x4 w0[6], w1[6];
+      if (pre) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          w0[q] = wp0[size_t(kc) * chunk_stride + q];
-          w1[q] = wp1[size_t(kc) * chunk_stride + q];
-        }
-        v4f a[4];
-        if (kc >= KCg) {
-          // chained chunk: the previous layer's accumulators ARE this layer's operand (same k order)
-          const bool first = kc == KCg;
+        for (int kc = 0; kc < 2; ++kc) {
+          if (kc < KC) {
+            u32x4 w0[6], w1[6];
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[q][e] = first ? kept0[4 * q + e] : kept1[4 * q + e];
-        } else if (L.a_mode == 1) {
-          const float* p = a_half_ptr(g, gm, kc * 32);
-          const float* rw = static_cast<const float*>(c.ro_w) + kc * 32;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const v4f hv = p ? *reinterpret_cast<const v4f*>(p + 8 * q + 4 * hh) : v4f{0.f, 0.f, 0.f, 0.f};
-            const v4f wv4 = *reinterpret_cast<const v4f*>(rw + 8 * q + 4 * hh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[q][e] = p ? rofac * wv4[e] * dsilu(hv[e]) : 0.f;
+            for (int q = 0; q < 6; ++q) {
+              w0[q] = wp0[size_t(kc) * chunk_stride + q];
+              w1[q] = wp1[size_t(kc) * chunk_stride + q];
+            }
+            chunk_pair_bf16x3(w0, w1, ps1[kc], ps2[kc], ps3[kc], acc0, acc1);
           }
-        } else {
-          load_a_frag_acc(g, gm, kc, hh, a);
         }
-        u32x4 x1[2], x2[2], x3[2];
-        split3_pack(a, x1, x2, x3);
-        chunk_pair_bf16x3(w0, w1, x1, x2, x3, acc0, acc1);
+      } else {
+        for (int kc = 0; kc < KC; ++kc) {
+          u32x4 w0[6], w1[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            w0[q] = wp0[size_t(kc) * chunk_stride + q];
+            w1[q] = wp1[size_t(kc) * chunk_stride + q];
+          }
+          v4f a[4];
+          build_a(kc, a);
+          u32x4 x1[2], x2[2], x3[2];
+          split3_pack(a, x1, x2, x3);
+          chunk_pair_bf16x3(w0, w1, x1, x2, x3, acc0, acc1);
+        }
       }
       tile_epilogue_store(g, acc0, gm, nt * 32, lane);
       if (two) tile_epilogue_store(g, acc1, gm, nt * 32 + 32, lane);
