@@ -787,12 +787,6 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
       rofac = float(c.ro_factor);
       if (c.ro_scales) rofac *= static_cast<const float*>(c.ro_scales)[c.types[c.center[gm]]];
     }
-    v16f nk0, nk1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      nk0[r] = 0.f;
-      nk1[r] = 0.f;
-    }
     // operand fragment of chunk kc: global (plain / readout-reverse transform) or the chained accumulators
     auto build_a = [&](int kc, v4f* a) {
       if (kc >= KCg) {
@@ -852,6 +846,9 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
           }
         }
       } else {
+        // the next chunk's operand fragment is requested before the current chunk's MFMAs issue
+        v4f a0[4];
+        build_a(0, a0);
         for (int kc = 0; kc < KC; ++kc) {
           u32x4 w0[6], w1[6];
 #pragma unroll
@@ -859,25 +856,25 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
             w0[q] = wp0[size_t(kc) * chunk_stride + q];
             w1[q] = wp1[size_t(kc) * chunk_stride + q];
           }
-          v4f a[4];
-          build_a(kc, a);
+          v4f a1[4];
+          build_a(kc + 1 < KC ? kc + 1 : kc, a1);
           u32x4 x1[2], x2[2], x3[2];
-          split3_pack(a, x1, x2, x3);
+          split3_pack(a0, x1, x2, x3);
           chunk_pair_bf16x3(w0, w1, x1, x2, x3, acc0, acc1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a0[q] = a1[q];
         }
       }
       tile_epilogue_store(g, acc0, gm, nt * 32, lane);
       if (two) tile_epilogue_store(g, acc1, gm, nt * 32 + 32, lane);
-      if (nt == L.keep_tile) {
+      if (nt == L.keep_tile) {  // (the kept pair is the last pair of its layer: nothing reads the old kept tiles any more)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          nk0[r] = L.keep_act ? silu(acc0[r]) : acc0[r];
-          nk1[r] = L.keep_act ? silu(acc1[r]) : acc1[r];
+          kept0[r] = L.keep_act ? silu(acc0[r]) : acc0[r];
+          kept1[r] = L.keep_act ? silu(acc1[r]) : acc1[r];
         }
       }
     }
-    kept0 = nk0;
-    kept1 = nk1;
   }
 }
 
@@ -898,7 +895,8 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
         return fail(AA_ERR_INVALID, "gemm chain: C segments must be 4-column granular and 16-B aligned");
     }
     if (ka + (L.use_prev ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
-    if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 > g.N)) return fail(AA_ERR_INVALID, "gemm chain: bad keep_tile");
+    if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 != g.N))
+      return fail(AA_ERR_INVALID, "gemm chain: the kept 64 features must be the last tile pair of the layer");
     if (L.use_prev && (li == 0 || c.L[li - 1].keep_tile < 0)) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
   }
   dim3 grid((unsigned)((c.M + 127) / 128));
