@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
   const int hh = lane >> 5;
   const int KC = (g.K + 31) >> 5;
   const int NT = (g.N + 31) >> 5;
-  const u32x4* Wl = Wq + size_t(lane) * 6;
+  const u32x4* Wl = Wq + lane;  // fragments are stored [tile][chunk][q][lane]
   const size_t chunk_stride = 64 * 6;                    // u32x4 units between chunks
   const size_t tile_stride = size_t(KC) * chunk_stride;  // between feature tiles
   auto wptr = [&](int tile, int kc) { return Wl + size_t(tile < NT ? tile : NT - 1) * tile_stride + size_t(kc) * chunk_stride; };
@@ -635,8 +635,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
   u32x4 wc0[6], wc1[6];
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
-    wc0[q] = wptr(0, 0)[q];
-    wc1[q] = wptr(1, 0)[q];
+    wc0[q] = wptr(0, 0)[q * 64];
+    wc1[q] = wptr(1, 0)[q * 64];
   }
   for (int nt = 0; nt < NT; nt += 2) {
     const bool two = nt + 1 < NT;
@@ -657,8 +657,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
           const u32x4* p1 = wptr(nnt + 1, nkc);
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
-            wn0[q] = p0[q];
-            wn1[q] = p1[q];
+            wn0[q] = p0[q * 64];
+            wn1[q] = p1[q * 64];
           }
           chunk_pair_bf16x3(wc0, wc1, xr1[kc], xr2[kc], xr3[kc], acc0, acc1);
 #pragma unroll
@@ -682,8 +682,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
         const u32x4* p1 = wptr(nnt + 1, nkc);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          wn0[q] = p0[q];
-          wn1[q] = p1[q];
+          wn0[q] = p0[q * 64];
+          wn1[q] = p1[q * 64];
         }
         __builtin_amdgcn_sched_barrier(0);
         v4f a2[4];
@@ -762,7 +762,14 @@ __device__ __forceinline__ void tile_epilogue_store(const GemmArgs& g, v16f& acc
   }
 }
 
+// Weights of one step (tile pair x 32-deep chunk: 2 x 6 x 64 fragments of 16 B = 12 KB) are staged through LDS
+// by the whole block (the four waves run the same layer/tile/chunk sequence on different rows): one L2 fetch
+// instead of four, the next step's weights are in flight while this step's MFMAs issue (double buffer, one
+// barrier per step), and the MFMA operands are read just in time with conflict-free ds_read_b128.
+constexpr int kWStep = 2 * 6 * 64;  // u32x4 per staged step
+
 __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
+  u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);  // [2][kWStep]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
@@ -780,13 +787,28 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
     const int KCg = (g.K - (L.use_prev ? 64 : 0) + 31) >> 5;  // chunks coming from global memory
     const int KC = KCg + (L.use_prev ? 2 : 0);
     const int NT = (g.N + 31) >> 5;
-    const u32x4* Wl = static_cast<const u32x4*>(g.Bq) + size_t(lane) * 6;
+    const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
     const size_t chunk_stride = 64 * 6, tile_stride = size_t(KC) * chunk_stride;
     float rofac = 0.f;  // readout-reverse transform factor of this row
     if (L.a_mode == 1 && row_ok) {
       rofac = float(c.ro_factor);
       if (c.ro_scales) rofac *= static_cast<const float*>(c.ro_scales)[c.types[c.center[gm]]];
     }
+    // block-cooperative staging: thread t moves elements t, t+256, t+512 of the 768-element step
+    auto stage_load = [&](int nt, int kc, u32x4* r) {
+      const int t1 = nt + 1 < NT ? nt + 1 : nt;
+      const u32x4* s0 = Wq + size_t(nt) * tile_stride + size_t(kc) * chunk_stride;
+      const u32x4* s1 = Wq + size_t(t1) * tile_stride + size_t(kc) * chunk_stride;
+      r[0] = s0[tid];
+      r[1] = tid < 128 ? s0[256 + tid] : s1[tid - 128];
+      r[2] = s1[128 + tid];
+    };
+    auto stage_write = [&](int b, const u32x4* r) {
+      u32x4* d = wbuf + b * kWStep;
+      d[tid] = r[0];
+      d[256 + tid] = r[1];
+      d[512 + tid] = r[2];
+    };
     // operand fragment of chunk kc: global (plain / readout-reverse transform) or the chained accumulators
     auto build_a = [&](int kc, v4f* a) {
       if (kc >= KCg) {
@@ -809,6 +831,45 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
         load_a_frag_acc(g, gm, kc, hh, a);
       }
     };
+    // 24 MFMAs of one step; weight levels are read from LDS just in time (level l is reused by 3-l products)
+    auto mma_step = [&](int b, const u32x4* x1, const u32x4* x2, const u32x4* x3, v16f& acc0, v16f& acc1) {
+      const u32x4* w = wbuf + b * kWStep + lane;
+#define AA_W(T_, Q_) w[((T_)*6 + (Q_)) * 64]
+      {
+        const u32x4 a0 = AA_W(0, 4), b0 = AA_W(1, 4), a1 = AA_W(0, 5), b1 = AA_W(1, 5);  // level 3
+        acc0 = mma_bf16(a0, x1[0], acc0);
+        acc1 = mma_bf16(b0, x1[0], acc1);
+        acc0 = mma_bf16(a1, x1[1], acc0);
+        acc1 = mma_bf16(b1, x1[1], acc1);
+      }
+      {
+        const u32x4 a0 = AA_W(0, 2), b0 = AA_W(1, 2), a1 = AA_W(0, 3), b1 = AA_W(1, 3);  // level 2
+        acc0 = mma_bf16(a0, x2[0], acc0);
+        acc1 = mma_bf16(b0, x2[0], acc1);
+        acc0 = mma_bf16(a1, x2[1], acc0);
+        acc1 = mma_bf16(b1, x2[1], acc1);
+        acc0 = mma_bf16(a0, x1[0], acc0);
+        acc1 = mma_bf16(b0, x1[0], acc1);
+        acc0 = mma_bf16(a1, x1[1], acc0);
+        acc1 = mma_bf16(b1, x1[1], acc1);
+      }
+      {
+        const u32x4 a0 = AA_W(0, 0), b0 = AA_W(1, 0), a1 = AA_W(0, 1), b1 = AA_W(1, 1);  // level 1
+        acc0 = mma_bf16(a0, x3[0], acc0);
+        acc1 = mma_bf16(b0, x3[0], acc1);
+        acc0 = mma_bf16(a1, x3[1], acc0);
+        acc1 = mma_bf16(b1, x3[1], acc1);
+        acc0 = mma_bf16(a0, x2[0], acc0);
+        acc1 = mma_bf16(b0, x2[0], acc1);
+        acc0 = mma_bf16(a1, x2[1], acc0);
+        acc1 = mma_bf16(b1, x2[1], acc1);
+        acc0 = mma_bf16(a0, x1[0], acc0);
+        acc1 = mma_bf16(b0, x1[0], acc1);
+        acc0 = mma_bf16(a1, x1[1], acc0);
+        acc1 = mma_bf16(b1, x1[1], acc1);
+      }
+#undef AA_W
+    };
     // few k chunks but several tile pairs: split the operands once, not once per pair
     const bool pre = KC <= 2 && NT > 2;
     u32x4 ps1[2][2], ps2[2][2], ps3[2][2];
@@ -822,6 +883,14 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
         }
       }
     }
+    // first step of the layer
+    int step = 0;
+    {
+      u32x4 r[3];
+      stage_load(0, 0, r);
+      stage_write(0, r);
+    }
+    __syncthreads();
     for (int nt = 0; nt < NT; nt += 2) {
       const bool two = nt + 1 < NT;
       v16f acc0, acc1;
@@ -830,39 +899,38 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
         acc0[r] = 0.f;
         acc1[r] = 0.f;
       }
-      const u32x4* wp0 = Wl + size_t(nt) * tile_stride;
-      const u32x4* wp1 = Wl + size_t(two ? nt + 1 : nt) * tile_stride;
       if (pre) {
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
           if (kc < KC) {
-            u32x4 w0[6], w1[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-              w0[q] = wp0[size_t(kc) * chunk_stride + q];
-              w1[q] = wp1[size_t(kc) * chunk_stride + q];
-            }
-            chunk_pair_bf16x3(w0, w1, ps1[kc], ps2[kc], ps3[kc], acc0, acc1);
+            const bool lastc = kc + 1 >= KC;
+            const bool has_next = !(lastc && nt + 2 >= NT);
+            u32x4 r[3];
+            if (has_next) stage_load(lastc ? nt + 2 : nt, lastc ? 0 : kc + 1, r);
+            mma_step(step & 1, ps1[kc], ps2[kc], ps3[kc], acc0, acc1);
+            if (has_next) stage_write((step + 1) & 1, r);
+            __syncthreads();
+            ++step;
           }
         }
       } else {
-        // the next chunk's operand fragment is requested before the current chunk's MFMAs issue
         v4f a0[4];
         build_a(0, a0);
         for (int kc = 0; kc < KC; ++kc) {
-          u32x4 w0[6], w1[6];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            w0[q] = wp0[size_t(kc) * chunk_stride + q];
-            w1[q] = wp1[size_t(kc) * chunk_stride + q];
-          }
+          const bool lastc = kc + 1 >= KC;
+          const bool has_next = !(lastc && nt + 2 >= NT);
+          u32x4 r[3];
+          if (has_next) stage_load(lastc ? nt + 2 : nt, lastc ? 0 : kc + 1, r);
           v4f a1[4];
-          build_a(kc + 1 < KC ? kc + 1 : kc, a1);
+          build_a(lastc ? kc : kc + 1, a1);  // next chunk's operand in flight during this step's MFMAs
           u32x4 x1[2], x2[2], x3[2];
           split3_pack(a0, x1, x2, x3);
-          chunk_pair_bf16x3(w0, w1, x1, x2, x3, acc0, acc1);
+          mma_step(step & 1, x1, x2, x3, acc0, acc1);
 #pragma unroll
           for (int q = 0; q < 4; ++q) a0[q] = a1[q];
+          if (has_next) stage_write((step + 1) & 1, r);
+          __syncthreads();
+          ++step;
         }
       }
       tile_epilogue_store(g, acc0, gm, nt * 32, lane);
@@ -900,7 +968,7 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
     if (L.use_prev && (li == 0 || c.L[li - 1].keep_tile < 0)) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
   }
   dim3 grid((unsigned)((c.M + 127) / 128));
-  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), 0, stream, c);
+  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), sizeof(u32x4) * 2 * kWStep, stream, c);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
@@ -922,7 +990,7 @@ void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out) {
   for (int nt = 0; nt < NT; ++nt)
     for (int kc = 0; kc < KC; ++kc)
       for (int lane = 0; lane < 64; ++lane) {
-        unsigned* o = out + ((size_t(nt) * KC + kc) * 64 + lane) * 24;  // [level][half][4 words]
+        unsigned* o = out + (size_t(nt) * KC + kc) * 64 * 24 + size_t(lane) * 4;  // [q = level*2+half][lane][4 words]
         for (int half = 0; half < 2; ++half)
           for (int q = 0; q < 4; ++q) {
             unsigned h[3][2];
@@ -936,7 +1004,7 @@ void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out) {
               float r2 = r - tof(h[1][e]);
               h[2][e] = trunc(r2);
             }
-            for (int lv = 0; lv < 3; ++lv) o[(lv * 2 + half) * 4 + q] = (h[lv][0] >> 16) | h[lv][1];
+            for (int lv = 0; lv < 3; ++lv) o[size_t(lv * 2 + half) * 64 * 4 + q] = (h[lv][0] >> 16) | h[lv][1];
           }
       }
 }

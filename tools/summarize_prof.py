@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KEYS = ("gemm_bf16x3_kernel<0", "gemm_bf16x3_kernel<2", "gemm_bf16x3_kernel<4", "gemm_mfma_f32_v3_kernel<0>", "gemm_mfma_f32_v3_kernel<2>", "gemm_mfma_f32_v3_kernel<4>", "gemm_mfma_f32_kernel",
+KEYS = ("gemm_chain_bf16x3", "gemm_bf16x3_kernel<0", "gemm_bf16x3_kernel<2", "gemm_bf16x3_kernel<4", "gemm_mfma_f32_v3_kernel<0>", "gemm_mfma_f32_v3_kernel<2>", "gemm_mfma_f32_v3_kernel<4>", "gemm_mfma_f32_kernel",
         "gemm_valu", "tp_mom_fwd_first", "tp_mom_fwd_last", "tp_mom_bwd_last", "tp_mom_bwd_first", "tp_chain_fwd_last", "tp_chain_bwd_last", "tp_chain_bwd_first", "tp_spec_fwd", "tp_spec_bwd",
         "tp_layer_fwd", "tp_layer_bwd", "edge_prologue", "edge_backward", "readout_reduce", "readout_backward",
         "fused_")
