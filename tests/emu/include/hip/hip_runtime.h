@@ -166,6 +166,8 @@ inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8
   emu::wave_rendezvous();
   return d;
 }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_wave_barrier() { emu::wave_rendezvous(); }  // fibers of a wave run one after another here
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on wave-uniform values
