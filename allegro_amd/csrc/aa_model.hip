@@ -468,18 +468,23 @@ inline Seg seg(void* p, int ld, int n) { return Seg{p, ld, n}; }
 struct StageProfile {
   std::vector<std::string> names;
   std::vector<hipEvent_t> events;
-  int mark(const char* name, hipStream_t s) {
+  std::vector<double> bytes, flops;  // algorithmic HBM bytes / flops of the launch that ended at this mark
+  int mark(const char* name, hipStream_t s, double by, double fl) {
     hipEvent_t e;
     AA_CHECK_HIP(hipEventCreate(&e));
     AA_CHECK_HIP(hipEventRecord(e, s));
     names.emplace_back(name);
     events.push_back(e);
+    bytes.push_back(by);
+    flops.push_back(fl);
     return AA_OK;
   }
   void clear() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     events.clear();
     names.clear();
+    bytes.clear();
+    flops.clear();
   }
 };
 
@@ -493,7 +498,25 @@ struct Runner {
   hipStream_t stream;
   StageProfile* prof = nullptr;
 
-  int mark(const char* name) { return prof ? prof->mark(name, stream) : AA_OK; }
+  // per_edge / per_atom: operand elements the launch must move (each distinct operand row once); see DESIGN.md §5
+  int mark(const char* name, double per_edge = 0, double per_atom = 0, double flops = 0) {
+    return prof ? prof->mark(name, stream, sizeof(T) * (per_edge * double(E) + per_atom * double(N)), flops) : AA_OK;
+  }
+  static double seg_elems(const SegList& s) {
+    double n = 0;
+    for (int i = 0; i < s.count; ++i)
+      if (s.s[i].p) n += s.s[i].n;
+    return n;
+  }
+  // A read + C written (+ accumulated segments re-read) + Z + add operands of one GEMM, elements per row
+  static double gemm_row_elems(const GemmArgs& g, bool a_from_hbm) {
+    double n = (a_from_hbm ? seg_elems(g.a) : 0) + seg_elems(g.c);
+    for (int i = 0; i < g.c.count; ++i)
+      if (g.c.s[i].p && g.c_accum[i]) n += g.c.s[i].n;
+    if (g.has_z) n += seg_elems(g.z);
+    if (g.has_add) n += seg_elems(g.add);
+    return n;
+  }
 
   T* buf(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   const T* wt(size_t off) const { return wts + off; }
@@ -519,7 +542,7 @@ struct Runner {
     if (!prof) return AA_OK;
     char nm[32];
     snprintf(nm, sizeof(nm), "gemm_%dx%d", K, Nn);
-    return mark(nm);
+    return mark(nm, gemm_row_elems(g, true), 0, 2.0 * double(E) * K * Nn);
   }
 
   // forward of a ScalarMLPFunction: hidden pre-activations to h[i]; final linear output to `out`
@@ -676,9 +699,14 @@ struct Runner {
     if (!prof) return AA_OK;
     char nm[32];
     int o = snprintf(nm, sizeof(nm), "gc");
-    for (int i = 0; i < ca.nlayers && o < 28; ++i) o += snprintf(nm + o, sizeof(nm) - o, "_%dx%d", ca.L[i].g.K, ca.L[i].g.N);
+    double elems = 0, fl = 0;
+    for (int i = 0; i < ca.nlayers; ++i) {
+      if (o < 28) o += snprintf(nm + o, sizeof(nm) - o, "_%dx%d", ca.L[i].g.K, ca.L[i].g.N);
+      elems += gemm_row_elems(ca.L[i].g, true);  // a is an empty list for use_prev layers (kept tile in registers)
+      fl += 2.0 * double(E) * ca.L[i].g.K * ca.L[i].g.N;
+    }
     (void)tag;
-    return mark(nm);
+    return mark(nm, elems, 0, fl);
   }
 
   TpMomArgs mom_args(const aa_graph* g) const {
@@ -713,8 +741,9 @@ struct Runner {
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
     // 1-2: geometry, SH, radial-chemical embedding
     if (int rc = mark("begin")) return rc;
+    const double idx2 = 8.0 / sizeof(T);  // center + nbr ids, in elements
     if (int rc = launch_edge_prologue<T>(geom(g, pos), stream)) return rc;
-    if (int rc = mark("edge_prologue")) return rc;
+    if (int rc = mark("edge_prologue", idx2 + 6 + (g->shift_vec ? 3 : 0) + 4 + p->D + c.embed_dim)) return rc;
     const SegList none{0, {}};
     if (p->chain_gemm) {
       // 3 + 4 + 5a as ONE kernel: emb0 -> h_e -> emb -> [two_body | w0]; hidden layers stay in registers
@@ -751,14 +780,14 @@ struct Runner {
         if (l == 0) {
           m.c.scal1 = buf(w.scal[0]);  // the first-layer kernel writes its scalars through this field
           if (int rc = launch_tp_mom_fwd_first<T>(p->chain_pair, m, stream)) return rc;
-          if (int rc = mark("tp_mom_fwd_first")) return rc;
+          if (int rc = mark("tp_mom_fwd_first", p->D + m.ka0 + W + u, double(p->D) * u)) return rc;
         } else {
           if (int rc = launch_tp_mom_fwd_last<T>(p->chain_pair, m, stream)) return rc;
-          if (int rc = mark("tp_mom_fwd_last")) return rc;
+          if (int rc = mark("tp_mom_fwd_last", p->D + m.ka1 + W + u, 2.0 * p->D * u)) return rc;
         }
       } else if (p->chain_pair >= 0 && l == 1) {
         if (int rc = launch_tp_chain_fwd_last<T>(p->chain_pair, chain_args(g), stream)) return rc;
-        if (int rc = mark("tp_chain_fwd_last")) return rc;
+        if (int rc = mark("tp_chain_fwd_last", 2 * W + p->D + u, 2.0 * p->D * u)) return rc;
       } else if (p->use_spec) {
         TpSpecFwdArgs a{};
         a.E = E;
@@ -783,7 +812,7 @@ struct Runner {
         a.scal = buf(w.scal[l]);
         a.ld_scal = u;
         if (int rc = launch_tp_spec_fwd<T>(p->spec_sig[l], a, stream)) return rc;
-        if (int rc = mark("tp_spec_fwd")) return rc;
+        if (int rc = mark("tp_spec_fwd", 2 * W + p->D + u, 2.0 * p->D * u)) return rc;
       } else {
       TpLayerFwdArgs a{};
       a.E = E;
@@ -801,7 +830,7 @@ struct Runner {
       a.scal = buf(w.scal[l]);
       a.ld_scal = u;
       if (int rc = launch_tp_layer_fwd<T>(p->layers[l], a, stream)) return rc;
-      if (int rc = mark("tp_layer_fwd")) return rc;
+      if (int rc = mark("tp_layer_fwd", 2 * W + p->D + u * p->D + u, 2.0 * p->D * u)) return rc;
       }
       if (p->chain_gemm) {
         ChainArgs ca{};
@@ -842,7 +871,7 @@ struct Runner {
       }
     }
     if (int rc = launch_readout_reduce<T>(readout_args(g, atom_energy), stream)) return rc;
-    return mark("readout_reduce");
+    return mark("readout_reduce", p->chain_gemm || c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1, 1);
   }
 
   int backward(const aa_graph* g, const void* pos, void* forces) {
@@ -853,7 +882,7 @@ struct Runner {
     const int num_gsh = p->use_spec ? L + 1 : 1;
     if (!gsh_stores) AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * num_gsh * sizeof(T), stream));
     AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
-    if (int rc = mark("memset")) return rc;
+    if (int rc = mark("memset", gsh_stores ? 0 : p->D * num_gsh, 3)) return rc;
     const SegList none{0, {}};
     if (p->chain_gemm) {
       // readout reverse + last latent reverse in ONE kernel; d_lat_{L-1} and d_h never leave registers
@@ -883,7 +912,7 @@ struct Runner {
       if (c.readout_mlp_depth > 0) {
         r.g_h = buf(w.g_ro_h[c.readout_mlp_depth - 1]);
         if (int rc = launch_readout_backward<T>(r, stream)) return rc;
-        if (int rc = mark("readout_backward")) return rc;
+        if (int rc = mark("readout_backward", 2.0 * (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1))) return rc;
         SegList a{1, {seg(r.g_h, c.readout_mlp_width, c.readout_mlp_width)}};
         for (int i = c.readout_mlp_depth - 1; i >= 0; --i) {
           SegList cs, z;
@@ -903,7 +932,7 @@ struct Runner {
       } else {
         r.g_h = buf(w.g_fcat);
         if (int rc = launch_readout_backward<T>(r, stream)) return rc;
-        if (int rc = mark("readout_backward")) return rc;
+        if (int rc = mark("readout_backward", 2.0 * (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1))) return rc;
       }
     }
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
@@ -946,11 +975,11 @@ struct Runner {
         if (l == 1) {
           m.ld_ga = c.latent_mlp_width;
           if (int rc = launch_tp_mom_bwd_last<T>(p->chain_pair, m, stream)) return rc;
-          if (int rc = mark("tp_mom_bwd_last")) return rc;
+          if (int rc = mark("tp_mom_bwd_last", p->D + W + u + 2 * m.ka1 + p->D, double(p->D) * u)) return rc;
         } else {
           m.ld_ga = S;
           if (int rc = launch_tp_mom_bwd_first<T>(p->chain_pair, m, stream)) return rc;
-          if (int rc = mark("tp_mom_bwd_first")) return rc;
+          if (int rc = mark("tp_mom_bwd_first", p->D + 2 * W + 2 * u + 2 * m.ka0 + 2 * p->D, 2.0 * p->D * u)) return rc;
         }
         continue;
       }
@@ -964,10 +993,10 @@ struct Runner {
         a.gsh_env = buf(w.g_sh) + size_t(l + 1) * size_t(E) * p->D;
         if (l == 1) {
           if (int rc = launch_tp_chain_bwd_last<T>(p->chain_pair, a, stream)) return rc;
-          if (int rc = mark("tp_chain_bwd_last")) return rc;
+          if (int rc = mark("tp_chain_bwd_last", 3 * W + 2 * p->D + u, 2.0 * p->D * u)) return rc;
         } else {
           if (int rc = launch_tp_chain_bwd_first<T>(p->chain_pair, a, stream)) return rc;
-          if (int rc = mark("tp_chain_bwd_first")) return rc;
+          if (int rc = mark("tp_chain_bwd_first", 4 * W + 3 * p->D + 2 * u, 2.0 * p->D * u)) return rc;
         }
         continue;
       }
@@ -1003,7 +1032,7 @@ struct Runner {
         a.gsh_env = buf(w.g_sh) + size_t(l + 1) * size_t(E) * p->D;
         a.ld_gsh = p->D;
         if (int rc = launch_tp_spec_bwd<T>(p->spec_sig[l], a, stream)) return rc;
-        if (int rc = mark("tp_spec_bwd")) return rc;
+        if (int rc = mark("tp_spec_bwd", 4 * W + 3 * p->D + 2 * u * p->D + u, 2.0 * p->D * u)) return rc;
         continue;
       }
       TpLayerBwdArgs a{};
@@ -1034,7 +1063,7 @@ struct Runner {
       a.g2.gsh = buf(w.g_sh);
       a.g2.ld_gsh = p->D;
       if (int rc = launch_tp_layer_bwd<T>(p->layers[l], a, stream)) return rc;
-      if (int rc = mark("tp_layer_bwd")) return rc;
+      if (int rc = mark("tp_layer_bwd", 4 * W + 2 * p->D + 2 * u * p->D + u, 2.0 * p->D * u)) return rc;
     }
     if (p->chain_gemm) {
       // first-stage reverse + scalar_embed_mlp reverse in ONE kernel
@@ -1074,7 +1103,7 @@ struct Runner {
     eb.num_gsh = p->use_spec ? L + 1 : 1;
     eb.forces = forces;
     if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
-    return mark("edge_backward");
+    return mark("edge_backward", 8.0 / sizeof(T) + 4 + c.embed_dim + double(num_gsh) * p->D + 6);
   }
 };
 
@@ -1116,7 +1145,7 @@ extern "C" int aa_model_energy_forces_profiled(const aa_model_plan* plan, const 
                                                const void* pos, void* workspace, size_t workspace_bytes,
                                                void* atom_energy, void* forces, aa_stream stream, int max_stages,
                                                float* stage_ms, char* stage_names /* [max_stages][32] */,
-                                               int* num_stages) {
+                                               int* num_stages, double* stage_bytes, double* stage_flops) {
   AA_REQUIRE(plan && dev_weights && graph && pos && atom_energy && stage_ms && stage_names && num_stages,
              "aa_model_energy_forces_profiled: null argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1135,6 +1164,8 @@ extern "C" int aa_model_energy_forces_profiled(const aa_model_plan* plan, const 
       (void)hipEventElapsedTime(&ms, prof.events[i - 1], prof.events[i]);
       stage_ms[n] = ms;
       snprintf(stage_names + 32 * n, 32, "%s", prof.names[i].c_str());
+      if (stage_bytes) stage_bytes[n] = prof.bytes[i];
+      if (stage_flops) stage_flops[n] = prof.flops[i];
     }
   }
   *num_stages = n;

@@ -86,10 +86,14 @@ def gemm_sequence_flops(stage_names, E):
 
 
 def profile_stages(model, pos, graph):
+    """[(kernel-launch name, ms, algorithmic bytes, flops)] of one forward+force pass, averaged over 5 passes:
+    HIP events recorded by the library on the launch stream around every kernel (aa_model_energy_forces_profiled)."""
     lib = model._get_lib()
     model.energy_forces(pos, graph)  # make sure plan/weights/workspace exist
     max_stages = 128
     ms = (C.c_float * max_stages)()
+    by = (C.c_double * max_stages)()
+    fl = (C.c_double * max_stages)()
     names = C.create_string_buffer(32 * max_stages)
     n = C.c_int(0)
     e_atom = torch.empty(graph.num_atoms, dtype=model.dtype, device=pos.device)
@@ -97,59 +101,51 @@ def profile_stages(model, pos, graph):
     g = graph.c_struct()
     fn = lib.lib.aa_model_energy_forces_profiled
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     acc = {}
     reps = 5
     for _ in range(reps):
         rc = fn(model._plan_handle, model._blob.data_ptr(), C.byref(g), pos.data_ptr(), model._workspace.data_ptr(),
                 model._workspace.numel(), e_atom.data_ptr(), forces.data_ptr(),
-                torch.cuda.current_stream(pos.device).cuda_stream, max_stages, ms, names, C.byref(n))
+                torch.cuda.current_stream(pos.device).cuda_stream, max_stages, ms, names, C.byref(n), by, fl)
         lib.check(rc, "aa_model_energy_forces_profiled")
         for i in range(n.value):
             nm = names.raw[32 * i: 32 * i + 32].split(b"\0")[0].decode()
-            acc.setdefault(i, [nm, 0.0])[1] += ms[i] / reps
-    return [(v[0], v[1]) for _, v in sorted(acc.items())]
+            acc.setdefault(i, [nm, 0.0, by[i], fl[i]])[1] += ms[i] / reps
+    return [tuple(v) for _, v in sorted(acc.items())]
 
 
-def roofline_from_stages(stages, E, N, cfg, dtype):
-    """Aggregate the per-launch HIP-event times per kernel symbol and report the dominant symbol against
-    its roofline.  Algorithmic work per launch: GEMM 2*K*N flop and (K+N) elements per
-    edge; tensor-product kernels: the operand rows they must read/write per edge."""
-    u, S, L, l_max = cfg["num_tensor_features"], cfg["num_scalar_features"], cfg["num_layers"], cfg["l_max"]
-    es = 4 if dtype == "float32" else 8
-    D, W = (l_max + 1) ** 2, (l_max + 1) * u
-    tp_bytes = {  # elements per edge (+ per-atom x2s rows)
-        "tp_layer_fwd": 2 * W + D + u * D + u, "tp_layer_bwd": 4 * W + 2 * D + 2 * u * D + u,
-        "tp_spec_fwd": 2 * W + D + u, "tp_spec_bwd": 4 * W + 3 * D + 2 * u * D + u,
-        "tp_chain_fwd_last": 2 * W + D + u, "tp_chain_bwd_last": 3 * W + 2 * D + u,
-        "tp_chain_bwd_first": 4 * W + 3 * D + 2 * u,
-    }
+# kernel symbol behind each stage-name prefix
+_SYMBOLS = (("gc_", "gemm_chain_bf16x3_kernel"), ("gemm_", "gemm_bf16x3_kernel"))
+
+
+def roofline_from_stages(stages, dtype):
+    """Aggregate the per-launch HIP-event times per kernel symbol and report the dominant symbol against its
+    roofline.  Algorithmic work per launch comes from the library: every distinct operand
+    row read or written once; 2*M*K*N flop per GEMM layer.  All kernels of this path are HBM-bound at their
+    algorithmic intensity (the fused GEMM chains run at <= 28 flop/B against a ridge of ~20 fp32 / ~300 bf16
+    flop/B; their bf16x3 MFMA time at peak is below the HBM time), so `bound` is "hbm"; the GEMM symbols also
+    report their fp32-equivalent TFLOP/s."""
     by_sym = {}
-    for name, ms in stages:
-        sym = "gemm" if name.startswith("gemm_") else name
+    for name, ms, nbytes, flops in stages:
+        sym = next((s for pre, s in _SYMBOLS if name.startswith(pre)), name)
         d = by_sym.setdefault(sym, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
         d["ms"] += ms
         d["launches"] += 1
-        if sym == "gemm":
-            k, n = (int(x) for x in name[5:].split("x"))
-            d["flops"] += 2.0 * E * k * n
-            d["bytes"] += es * (E * (k + n) + k * n)
-        elif sym in tp_bytes:
-            d["bytes"] += es * (E * tp_bytes[sym] + 2 * N * u * D)
+        d["flops"] += flops
+        d["bytes"] += nbytes
     sym, d = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-    t = d["ms"] * 1e-3 / max(d["launches"], 1)
-    if sym == "gemm":
-        peak = PEAK_F32_TFLOPS if dtype == "float32" else PEAK_F64_TFLOPS
-        ach = d["flops"] / max(d["launches"], 1) / t / 1e12
-        roof = dict(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None)
-        roof["algorithmic_GBps"] = d["bytes"] / max(d["launches"], 1) / t / 1e9
-    else:
-        ach = d["bytes"] / max(d["launches"], 1) / t / 1e9
-        roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None)
-    roof["kernel"] = {"gemm": "gemm_bf16x3_kernel / gemm_mfma_f32_v3_kernel (all scalar-MLP GEMM launches of a step)"}.get(sym, sym)
-    roof["avg_launch_ms"] = d["ms"] / max(d["launches"], 1)
-    roof["launches_per_step"] = d["launches"]
-    table = {k: dict(ms=round(v["ms"], 4), launches=v["launches"]) for k, v in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])}
+    n = max(d["launches"], 1)
+    t = d["ms"] * 1e-3 / n
+    ach = d["bytes"] / n / t / 1e9
+    roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
+                kernel=sym, avg_launch_ms=d["ms"] / n, launches_per_step=d["launches"],
+                algorithmic_bytes_per_launch=d["bytes"] / n)
+    if d["flops"] > 0:
+        roof["fp32_equiv_TFLOPs"] = d["flops"] / n / t / 1e12
+        roof["mfma_bf16_TFLOPs"] = (6.0 if dtype == "float32" else 1.0) * d["flops"] / n / t / 1e12
+    table = {k: dict(ms=round(v["ms"], 4), launches=v["launches"], GBps=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1))
+             for k, v in sorted(by_sym.items(), key=lambda kv: -kv[1]["ms"])}
     return roof, table
 
 
@@ -314,12 +310,13 @@ def main():
         }
         if not args.no_profile:
             stages = profile_stages(model, pos, graph)
-            roof, table = roofline_from_stages(stages, e1 - e0, N, cfg, cfg["model_dtype"])
+            roof, table = roofline_from_stages(stages, cfg["model_dtype"])
             line["roofline"] = roof
             line["stage_ms"] = table
             if args.stages:
-                for nm, ms in stages:
-                    print(f"[stage] {nm:24s} {ms * 1e3:9.1f} us", file=sys.stderr)
+                for nm, ms, nb, fl in stages:
+                    print(f"[stage] {nm:24s} {ms * 1e3:9.1f} us {nb / max(ms, 1e-9) / 1e6:8.0f} GB/s (algorithmic)"
+                          f"{fl / max(ms, 1e-9) / 1e9:8.1f} TFLOP/s", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, cfg, model)
         if world == 1 and args.gpu_reference:

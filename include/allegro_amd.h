@@ -155,11 +155,14 @@ int aa_model_energy_forces(const aa_model_plan* plan, const void* dev_weights, c
 
 /* same as aa_model_energy_forces, additionally timing every kernel launch of the pass with HIP events
  * recorded on `stream` (synchronises the stream before returning).  stage_names is a
- * [max_stages][32] char buffer; stage i is the i-th launch, named after its kernel. */
+ * [max_stages][32] char buffer; stage i is the i-th launch, named after its kernel.  stage_bytes /
+ * stage_flops (each [max_stages], may be NULL) receive the launch's ALGORITHMIC work: every distinct
+ * operand row it must read or write once, and 2*M*K*N per GEMM layer. */
 int aa_model_energy_forces_profiled(const aa_model_plan* plan, const void* dev_weights, const aa_graph* graph,
                                     const void* pos, void* workspace, size_t workspace_bytes,
                                     void* atom_energy, void* forces, aa_stream stream, int max_stages,
-                                    float* stage_ms, char* stage_names, int* num_stages);
+                                    float* stage_ms, char* stage_names, int* num_stages, double* stage_bytes,
+                                    double* stage_flops);
 
 /* debug/parity taps: copy an intermediate of the LAST call out of the workspace layout.
  * name in {"edge_attrs","edge_embedding","edge_features"}; returns elements per edge or <0 */
