@@ -762,114 +762,204 @@ __device__ __forceinline__ void tile_epilogue_store(const GemmArgs& g, v16f& acc
   }
 }
 
+// Device-side form of a chain: every segment list is resolved on the host into one pointer per 32-column
+// chunk (operands) / 32-feature tile (destinations), so the kernel's inner code is branch-free pointer
+// arithmetic.  (Chains require 32-column-granular segments; the model's chain path has 64-granular ones.)
+constexpr int kChainMaxBlocks = 12;  // 32-wide chunks / tiles per layer
+struct ChainTileDev {
+  float* c;          // destination of the tile (row 0), nullptr: computed only
+  const float* z;    // silu' factor operand or nullptr
+  const float* add;  // addend or nullptr
+  int ldc, ldz, ldadd, accum;
+};
+struct ChainLayerDev {
+  const u32x4* Wq;
+  int KCg, KC, NT;  // k chunks from global memory, total k chunks (+2 chained), output tiles
+  int keep_tile, keep_act, a_mode, pad_;
+  const float* a[kChainMaxBlocks];
+  int lda[kChainMaxBlocks];
+  ChainTileDev t[kChainMaxBlocks];
+};
+struct ChainDev {
+  int64_t M;
+  int nlayers;
+  float ro_factor;
+  const float* ro_w;
+  const float* ro_scales;
+  const int32_t* types;
+  const int32_t* center;
+  ChainLayerDev L[3];
+};
+
 // Weights of one step (tile pair x 32-deep chunk: 2 x 6 x 64 fragments of 16 B = 12 KB) are staged through LDS
 // by the whole block (the four waves run the same layer/tile/chunk sequence on different rows): one L2 fetch
-// instead of four, the next step's weights are in flight while this step's MFMAs issue (double buffer, one
-// barrier per step), and the MFMA operands are read just in time with conflict-free ds_read_b128.
+// instead of four, the next step's weights -- also across layer boundaries -- are in flight while this step's
+// MFMAs issue (double buffer, one barrier per step), and the MFMA operands are read just in time with
+// conflict-free ds_read_b128.  Operand rows are loaded one step ahead, also across tile-pair and layer
+// boundaries; rows beyond M are clamped for loads and masked for stores.
 constexpr int kWStep = 2 * 6 * 64;  // u32x4 per staged step
 
-__global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
+__global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);  // [2][kWStep]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
   const int hh = lane >> 5;
   const bool row_ok = gm < c.M;
+  const int64_t gmc = row_ok ? gm : c.M - 1;
   v16f kept0, kept1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     kept0[r] = 0.f;
     kept1[r] = 0.f;
   }
-  for (int li = 0; li < c.nlayers; ++li) {
-    const ChainLayer& L = c.L[li];
-    const GemmArgs& g = L.g;
-    const int KCg = (g.K - (L.use_prev ? 64 : 0) + 31) >> 5;  // chunks coming from global memory
-    const int KC = KCg + (L.use_prev ? 2 : 0);
-    const int NT = (g.N + 31) >> 5;
-    const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
-    const size_t chunk_stride = 64 * 6, tile_stride = size_t(KC) * chunk_stride;
-    float rofac = 0.f;  // readout-reverse transform factor of this row
-    if (L.a_mode == 1 && row_ok) {
-      rofac = float(c.ro_factor);
-      if (c.ro_scales) rofac *= static_cast<const float*>(c.ro_scales)[c.types[c.center[gm]]];
+  float rofac = c.ro_factor;  // readout-reverse transform factor of this row
+  if (c.ro_scales) rofac *= c.ro_scales[c.types[c.center[gmc]]];
+
+  // block-cooperative staging: thread t moves elements t, t+256, t+512 of the 768-element step
+  auto stage_load = [&](const ChainLayerDev& L, int nt, int kc, u32x4* r) {
+    const size_t chunk_stride = 64 * 6, tile_stride = size_t(L.KC) * chunk_stride;
+    const int t1 = nt + 1 < L.NT ? nt + 1 : nt;
+    const u32x4* s0 = L.Wq + size_t(nt) * tile_stride + size_t(kc) * chunk_stride;
+    const u32x4* s1 = L.Wq + size_t(t1) * tile_stride + size_t(kc) * chunk_stride;
+    r[0] = s0[tid];
+    r[1] = tid < 128 ? s0[256 + tid] : s1[tid - 128];
+    r[2] = s1[128 + tid];
+  };
+  auto stage_write = [&](int b, const u32x4* r) {
+    u32x4* d = wbuf + b * kWStep;
+    d[tid] = r[0];
+    d[256 + tid] = r[1];
+    d[512 + tid] = r[2];
+  };
+  // raw operand rows of global chunk kc (four 16-B pieces of the lane's row, accumulator-order k)
+  auto load_a = [&](const ChainLayerDev& L, int kc, v4f* a) {
+    const float* p = L.a[kc] + gmc * L.lda[kc] + 4 * hh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
+  };
+  // raw -> operand (readout-reverse transform of a_mode 1)
+  auto finish_a = [&](const ChainLayerDev& L, int kc, v4f* a) {
+    if (L.a_mode == 1) {
+      const float* rw = c.ro_w + kc * 32 + 4 * hh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f wv4 = *reinterpret_cast<const v4f*>(rw + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[q][e] = rofac * wv4[e] * dsilu(a[q][e]);
+      }
     }
-    // block-cooperative staging: thread t moves elements t, t+256, t+512 of the 768-element step
-    auto stage_load = [&](int nt, int kc, u32x4* r) {
-      const int t1 = nt + 1 < NT ? nt + 1 : nt;
-      const u32x4* s0 = Wq + size_t(nt) * tile_stride + size_t(kc) * chunk_stride;
-      const u32x4* s1 = Wq + size_t(t1) * tile_stride + size_t(kc) * chunk_stride;
-      r[0] = s0[tid];
-      r[1] = tid < 128 ? s0[256 + tid] : s1[tid - 128];
-      r[2] = s1[128 + tid];
-    };
-    auto stage_write = [&](int b, const u32x4* r) {
-      u32x4* d = wbuf + b * kWStep;
-      d[tid] = r[0];
-      d[256 + tid] = r[1];
-      d[512 + tid] = r[2];
-    };
-    // operand fragment of chunk kc: global (plain / readout-reverse transform) or the chained accumulators
-    auto build_a = [&](int kc, v4f* a) {
-      if (kc >= KCg) {
-        const bool first = kc == KCg;
+  };
+  auto kept_a = [&](bool first, v4f* a) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[q][e] = first ? kept0[4 * q + e] : kept1[4 * q + e];
-      } else if (L.a_mode == 1) {
-        const float* p = a_half_ptr(g, gm, kc * 32);
-        const float* rw = static_cast<const float*>(c.ro_w) + kc * 32;
+      for (int e = 0; e < 4; ++e) a[q][e] = first ? kept0[4 * q + e] : kept1[4 * q + e];
+  };
+  // 24 MFMAs of one step; weight levels are read from LDS just in time (level l is reused by 3-l products)
+  auto mma_step = [&](int b, const u32x4* x1, const u32x4* x2, const u32x4* x3, v16f& acc0, v16f& acc1) {
+    const u32x4* w = wbuf + b * kWStep + lane;
+#define AA_W(T_, Q_) w[((T_)*6 + (Q_)) * 64]
+    {
+      const u32x4 a0 = AA_W(0, 4), b0 = AA_W(1, 4), a1 = AA_W(0, 5), b1 = AA_W(1, 5);  // level 3
+      acc0 = mma_bf16(a0, x1[0], acc0);
+      acc1 = mma_bf16(b0, x1[0], acc1);
+      acc0 = mma_bf16(a1, x1[1], acc0);
+      acc1 = mma_bf16(b1, x1[1], acc1);
+    }
+    {
+      const u32x4 a0 = AA_W(0, 2), b0 = AA_W(1, 2), a1 = AA_W(0, 3), b1 = AA_W(1, 3);  // level 2
+      acc0 = mma_bf16(a0, x2[0], acc0);
+      acc1 = mma_bf16(b0, x2[0], acc1);
+      acc0 = mma_bf16(a1, x2[1], acc0);
+      acc1 = mma_bf16(b1, x2[1], acc1);
+      acc0 = mma_bf16(a0, x1[0], acc0);
+      acc1 = mma_bf16(b0, x1[0], acc1);
+      acc0 = mma_bf16(a1, x1[1], acc0);
+      acc1 = mma_bf16(b1, x1[1], acc1);
+    }
+    {
+      const u32x4 a0 = AA_W(0, 0), b0 = AA_W(1, 0), a1 = AA_W(0, 1), b1 = AA_W(1, 1);  // level 1
+      acc0 = mma_bf16(a0, x3[0], acc0);
+      acc1 = mma_bf16(b0, x3[0], acc1);
+      acc0 = mma_bf16(a1, x3[1], acc0);
+      acc1 = mma_bf16(b1, x3[1], acc1);
+      acc0 = mma_bf16(a0, x2[0], acc0);
+      acc1 = mma_bf16(b0, x2[0], acc1);
+      acc0 = mma_bf16(a1, x2[1], acc0);
+      acc1 = mma_bf16(b1, x2[1], acc1);
+      acc0 = mma_bf16(a0, x1[0], acc0);
+      acc1 = mma_bf16(b0, x1[0], acc1);
+      acc0 = mma_bf16(a1, x1[1], acc0);
+      acc1 = mma_bf16(b1, x1[1], acc1);
+    }
+#undef AA_W
+  };
+  // epilogue of one tile in accumulator layout, in place: acc <- (acc + add) * silu'(z), then stored (=|+=).
+  // All operand loads of the tile are issued together (one memory latency per tile, not one per 16-B group).
+  auto epilogue = [&](const ChainTileDev& d, v16f& acc) {
+    const bool has_add = d.add != nullptr, has_z = d.z != nullptr, has_old = d.c != nullptr && d.accum;
+    {
+      v4f ad[4], zz[4];
+      if (has_add) {
+        const float* p = d.add + gmc * d.ldadd + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ad[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
+      }
+      if (has_z) {
+        const float* p = d.z + gmc * d.ldz + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zz[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
+      }
+      if (has_add) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += ad[r >> 2][r & 3];
+      }
+      if (has_z) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= dsilu(zz[r >> 2][r & 3]);
+      }
+    }
+    if (d.c != nullptr && row_ok) {
+      float* p = d.c + gm * d.ldc + 4 * hh;
+      if (has_old) {  // (no tile of the model's chains has both an accumulated destination and add / z operands)
+        v4f old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const v4f hv = p ? *reinterpret_cast<const v4f*>(p + 8 * q + 4 * hh) : v4f{0.f, 0.f, 0.f, 0.f};
-          const v4f wv4 = *reinterpret_cast<const v4f*>(rw + 8 * q + 4 * hh);
+          v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[q][e] = p ? rofac * wv4[e] * dsilu(hv[e]) : 0.f;
+          for (int e = 0; e < 4; ++e) v[e] += old[q][e];
+          *reinterpret_cast<v4f*>(p + 8 * q) = v;
         }
       } else {
-        load_a_frag_acc(g, gm, kc, hh, a);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(p + 8 * q) = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
       }
-    };
-    // 24 MFMAs of one step; weight levels are read from LDS just in time (level l is reused by 3-l products)
-    auto mma_step = [&](int b, const u32x4* x1, const u32x4* x2, const u32x4* x3, v16f& acc0, v16f& acc1) {
-      const u32x4* w = wbuf + b * kWStep + lane;
-#define AA_W(T_, Q_) w[((T_)*6 + (Q_)) * 64]
-      {
-        const u32x4 a0 = AA_W(0, 4), b0 = AA_W(1, 4), a1 = AA_W(0, 5), b1 = AA_W(1, 5);  // level 3
-        acc0 = mma_bf16(a0, x1[0], acc0);
-        acc1 = mma_bf16(b0, x1[0], acc1);
-        acc0 = mma_bf16(a1, x1[1], acc0);
-        acc1 = mma_bf16(b1, x1[1], acc1);
-      }
-      {
-        const u32x4 a0 = AA_W(0, 2), b0 = AA_W(1, 2), a1 = AA_W(0, 3), b1 = AA_W(1, 3);  // level 2
-        acc0 = mma_bf16(a0, x2[0], acc0);
-        acc1 = mma_bf16(b0, x2[0], acc1);
-        acc0 = mma_bf16(a1, x2[1], acc0);
-        acc1 = mma_bf16(b1, x2[1], acc1);
-        acc0 = mma_bf16(a0, x1[0], acc0);
-        acc1 = mma_bf16(b0, x1[0], acc1);
-        acc0 = mma_bf16(a1, x1[1], acc0);
-        acc1 = mma_bf16(b1, x1[1], acc1);
-      }
-      {
-        const u32x4 a0 = AA_W(0, 0), b0 = AA_W(1, 0), a1 = AA_W(0, 1), b1 = AA_W(1, 1);  // level 1
-        acc0 = mma_bf16(a0, x3[0], acc0);
-        acc1 = mma_bf16(b0, x3[0], acc1);
-        acc0 = mma_bf16(a1, x3[1], acc0);
-        acc1 = mma_bf16(b1, x3[1], acc1);
-        acc0 = mma_bf16(a0, x2[0], acc0);
-        acc1 = mma_bf16(b0, x2[0], acc1);
-        acc0 = mma_bf16(a1, x2[1], acc0);
-        acc1 = mma_bf16(b1, x2[1], acc1);
-        acc0 = mma_bf16(a0, x1[0], acc0);
-        acc1 = mma_bf16(b0, x1[0], acc1);
-        acc0 = mma_bf16(a1, x1[1], acc0);
-        acc1 = mma_bf16(b1, x1[1], acc1);
-      }
-#undef AA_W
-    };
+    }
+  };
+
+  int step = 0;
+  {
+    u32x4 r[3];
+    stage_load(c.L[0], 0, 0, r);
+    stage_write(0, r);
+  }
+  // operand of the next streamed step, loaded one step ahead (valid when a_pref)
+  v4f a0[4];
+  bool a_pref = false;
+  if (c.L[0].KCg > 0 && !(c.L[0].KC <= 2 && c.L[0].NT > 2)) {
+    load_a(c.L[0], 0, a0);
+    a_pref = true;
+  }
+  __syncthreads();
+  for (int li = 0; li < c.nlayers; ++li) {
+    const ChainLayerDev& L = c.L[li];
+    const int KCg = L.KCg, KC = L.KC, NT = L.NT;
+    const bool last_layer = li + 1 >= c.nlayers;
+    const ChainLayerDev& Ln = c.L[last_layer ? li : li + 1];
+    const bool next_streams = !last_layer && Ln.KCg > 0 && !(Ln.KC <= 2 && Ln.NT > 2);
     // few k chunks but several tile pairs: split the operands once, not once per pair
     const bool pre = KC <= 2 && NT > 2;
     u32x4 ps1[2][2], ps2[2][2], ps3[2][2];
@@ -878,21 +968,19 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
       for (int kc = 0; kc < 2; ++kc) {
         if (kc < KC) {
           v4f a[4];
-          build_a(kc, a);
+          if (kc >= KCg) {
+            kept_a(kc == KCg, a);
+          } else {
+            load_a(L, kc, a);
+            finish_a(L, kc, a);
+          }
           split3_pack(a, ps1[kc], ps2[kc], ps3[kc]);
         }
       }
     }
-    // first step of the layer
-    int step = 0;
-    {
-      u32x4 r[3];
-      stage_load(0, 0, r);
-      stage_write(0, r);
-    }
-    __syncthreads();
     for (int nt = 0; nt < NT; nt += 2) {
       const bool two = nt + 1 < NT;
+      const bool last_pair = nt + 2 >= NT;
       v16f acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -904,9 +992,14 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
         for (int kc = 0; kc < 2; ++kc) {
           if (kc < KC) {
             const bool lastc = kc + 1 >= KC;
-            const bool has_next = !(lastc && nt + 2 >= NT);
+            const bool layer_end = lastc && last_pair;
+            const bool has_next = !(layer_end && last_layer);
             u32x4 r[3];
-            if (has_next) stage_load(lastc ? nt + 2 : nt, lastc ? 0 : kc + 1, r);
+            if (has_next) stage_load(layer_end ? Ln : L, layer_end ? 0 : (lastc ? nt + 2 : nt), (layer_end || lastc) ? 0 : kc + 1, r);
+            if (layer_end && next_streams) {
+              load_a(Ln, 0, a0);
+              a_pref = true;
+            }
             mma_step(step & 1, ps1[kc], ps2[kc], ps3[kc], acc0, acc1);
             if (has_next) stage_write((step + 1) & 1, r);
             __syncthreads();
@@ -914,27 +1007,48 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
           }
         }
       } else {
-        v4f a0[4];
-        build_a(0, a0);
         for (int kc = 0; kc < KC; ++kc) {
           const bool lastc = kc + 1 >= KC;
-          const bool has_next = !(lastc && nt + 2 >= NT);
+          const bool layer_end = lastc && last_pair;
+          const bool has_next = !(layer_end && last_layer);
           u32x4 r[3];
-          if (has_next) stage_load(lastc ? nt + 2 : nt, lastc ? 0 : kc + 1, r);
-          v4f a1[4];
-          build_a(lastc ? kc : kc + 1, a1);  // next chunk's operand in flight during this step's MFMAs
-          u32x4 x1[2], x2[2], x3[2];
-          split3_pack(a0, x1, x2, x3);
-          mma_step(step & 1, x1, x2, x3, acc0, acc1);
+          if (has_next) stage_load(layer_end ? Ln : L, layer_end ? 0 : (lastc ? nt + 2 : nt), (layer_end || lastc) ? 0 : kc + 1, r);
+          // this step's operand: prefetched rows, or the chained accumulators
+          v4f a[4];
+          if (kc >= KCg) {
+            kept_a(kc == KCg, a);
+          } else {
+            if (!a_pref) load_a(L, kc, a0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) a0[q] = a1[q];
+            for (int q = 0; q < 4; ++q) a[q] = a0[q];
+            finish_a(L, kc, a);
+          }
+          // next streamed step's rows in flight during this step's MFMAs (next chunk / next pair / next layer)
+          a_pref = false;
+          if (!lastc) {
+            if (kc + 1 < KCg) {
+              load_a(L, kc + 1, a0);
+              a_pref = true;
+            }
+          } else if (!last_pair) {
+            if (KCg > 0) {
+              load_a(L, 0, a0);
+              a_pref = true;
+            }
+          } else if (next_streams) {
+            load_a(Ln, 0, a0);
+            a_pref = true;
+          }
+          u32x4 x1[2], x2[2], x3[2];
+          split3_pack(a, x1, x2, x3);
+          mma_step(step & 1, x1, x2, x3, acc0, acc1);
           if (has_next) stage_write((step + 1) & 1, r);
           __syncthreads();
           ++step;
         }
       }
-      tile_epilogue_store(g, acc0, gm, nt * 32, lane);
-      if (two) tile_epilogue_store(g, acc1, gm, nt * 32 + 32, lane);
+      epilogue(L.t[nt], acc0);
+      if (two) epilogue(L.t[nt + 1], acc1);
       if (nt == L.keep_tile) {  // (the kept pair is the last pair of its layer: nothing reads the old kept tiles any more)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -948,27 +1062,71 @@ __global__ __launch_bounds__(256) void gemm_chain_bf16x3_kernel(ChainArgs c) {
 
 int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
   if (c.M == 0) return AA_OK;
+  ChainDev d{};
+  d.M = c.M;
+  d.nlayers = c.nlayers;
+  d.ro_factor = float(c.ro_factor);
+  d.ro_w = static_cast<const float*>(c.ro_w);
+  d.ro_scales = static_cast<const float*>(c.ro_scales);
+  d.types = c.types;
+  d.center = c.center;
+  if (c.nlayers < 1 || c.nlayers > 3) return fail(AA_ERR_INVALID, "gemm chain: 1..3 layers");
   for (int li = 0; li < c.nlayers; ++li) {
     const ChainLayer& L = c.L[li];
     const GemmArgs& g = L.g;
-    int ka = 0, nc = 0;
+    ChainLayerDev& D = d.L[li];
+    int ka = 0, nc = 0, nchunk = 0, ntile = 0;
+    if (g.act_a) return fail(AA_ERR_INVALID, "gemm chain: act_a is not supported");
     for (int s = 0; s < g.a.count; ++s) {
-      ka += g.a.s[s].n;
-      if ((g.a.s[s].n & 31) || (g.a.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.a.s[s].p) & 15))
+      const Seg& sg = g.a.s[s];
+      if ((sg.n & 31) || (sg.ld & 3) || (reinterpret_cast<uintptr_t>(sg.p) & 15) || !sg.p)
         return fail(AA_ERR_INVALID, "gemm chain: A segments must be 32-column granular and 16-B aligned");
+      for (int k = 0; k < sg.n; k += 32) {
+        if (nchunk >= kChainMaxBlocks) return fail(AA_ERR_INVALID, "gemm chain: too many k chunks");
+        D.a[nchunk] = static_cast<const float*>(sg.p) + k;
+        D.lda[nchunk] = sg.ld;
+        ++nchunk;
+      }
+      ka += sg.n;
     }
+    if (g.has_z && g.z.count != g.c.count) return fail(AA_ERR_INVALID, "gemm chain: z must be split like c");
+    if (g.has_add && g.add.count != g.c.count) return fail(AA_ERR_INVALID, "gemm chain: add must be split like c");
     for (int s = 0; s < g.c.count; ++s) {
-      nc += g.c.s[s].n;
-      if ((g.c.s[s].n & 3) || (g.c.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.c.s[s].p) & 15))
-        return fail(AA_ERR_INVALID, "gemm chain: C segments must be 4-column granular and 16-B aligned");
+      const Seg& sg = g.c.s[s];
+      if ((sg.n & 31) || (sg.ld & 3) || (reinterpret_cast<uintptr_t>(sg.p) & 15))
+        return fail(AA_ERR_INVALID, "gemm chain: C segments must be 32-column granular and 16-B aligned");
+      if (g.has_z && (g.z.s[s].n != sg.n || (g.z.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.z.s[s].p) & 15) || !g.z.s[s].p))
+        return fail(AA_ERR_INVALID, "gemm chain: bad z segment");
+      if (g.has_add && (g.add.s[s].n != sg.n || (g.add.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.add.s[s].p) & 15) || !g.add.s[s].p))
+        return fail(AA_ERR_INVALID, "gemm chain: bad add segment");
+      for (int k = 0; k < sg.n; k += 32) {
+        if (ntile >= kChainMaxBlocks) return fail(AA_ERR_INVALID, "gemm chain: too many output tiles");
+        ChainTileDev& t = D.t[ntile];
+        t.c = sg.p ? static_cast<float*>(sg.p) + k : nullptr;
+        t.ldc = sg.ld;
+        t.accum = g.c_accum[s];
+        t.z = g.has_z ? static_cast<const float*>(g.z.s[s].p) + k : nullptr;
+        t.ldz = g.has_z ? g.z.s[s].ld : 0;
+        t.add = g.has_add ? static_cast<const float*>(g.add.s[s].p) + k : nullptr;
+        t.ldadd = g.has_add ? g.add.s[s].ld : 0;
+        ++ntile;
+      }
+      nc += sg.n;
     }
     if (ka + (L.use_prev ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
     if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 != g.N))
       return fail(AA_ERR_INVALID, "gemm chain: the kept 64 features must be the last tile pair of the layer");
     if (L.use_prev && (li == 0 || c.L[li - 1].keep_tile < 0)) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
+    D.Wq = static_cast<const u32x4*>(g.Bq);
+    D.KCg = nchunk;
+    D.KC = nchunk + (L.use_prev ? 2 : 0);
+    D.NT = ntile;
+    D.keep_tile = L.keep_tile;
+    D.keep_act = L.keep_act;
+    D.a_mode = L.a_mode;
   }
   dim3 grid((unsigned)((c.M + 127) / 128));
-  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), sizeof(u32x4) * 2 * kWStep, stream, c);
+  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), sizeof(u32x4) * 2 * kWStep, stream, d);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
