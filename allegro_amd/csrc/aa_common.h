@@ -303,6 +303,7 @@ struct TpMomArgs {
   const void* wt1;
   void* g_a;            // reverse kernels: grad wrt the env input of the layer being reversed [E, ld_ga]
   int ld_ga;
+  int ka_lds;           // row stride of the wave-private moment patch in LDS (set by the launcher: max(ka0, ka1))
 };
 template <typename T>
 int launch_tp_mom_fwd_first(int pair, const TpMomArgs& a, hipStream_t stream);

@@ -165,25 +165,63 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
   for (int idx = tid; idx < B * S0; idx += 256) sWb[idx] = static_cast<const T*>(a.basis_w)[idx];
   __syncthreads();
   // phase 1: t[le][n] = sum_c g_emb0[e][c] * type_embed[c] * Wb[n][c]
-  for (int idx = tid; idx < 256 * B; idx += 256) {
-    int le = idx / B, nb = idx % B;
-    int64_t e = e0 + le;
-    T acc = T(0);
-    if (e < a.E) {
-      int ti = a.types[a.center[e]], tj = a.types[a.nbr[e]];
-      const T* g = static_cast<const T*>(b.g_emb0) + e * S0;
-      for (int c = 0; c < S0; ++c) {
-        T te = c < half ? cemb[ti * half + c] : nemb[tj * half + (c - half)];
-        acc += g[c] * te * sWb[nb * S0 + c];
+  if ((S0 & 7) == 0 && B <= kMaxBessel) {
+    // 8 lanes per edge, each owning S0/8 consecutive columns: a wave reads 8 whole rows per pass (coalesced);
+    // the B partial sums are then combined across the 8 lanes
+    const int cols = S0 >> 3, sub = tid & 7;
+    for (int base = 0; base < 256; base += 32) {
+      const int le = base + (tid >> 3);
+      const int64_t e = e0 + le;
+      T part[kMaxBessel];
+#pragma unroll
+      for (int nb = 0; nb < kMaxBessel; ++nb) part[nb] = T(0);
+      if (e < a.E) {
+        const int ti = a.types[a.center[e]], tj = a.types[a.nbr[e]];
+        const T* g = static_cast<const T*>(b.g_emb0) + e * S0 + sub * cols;
+        for (int cc = 0; cc < cols; ++cc) {
+          const int c = sub * cols + cc;
+          const T te = c < half ? cemb[ti * half + c] : nemb[tj * half + (c - half)];
+          const T gv = g[cc] * te;
+#pragma unroll
+          for (int nb = 0; nb < kMaxBessel; ++nb)
+            if (nb < B) part[nb] += gv * sWb[nb * S0 + c];
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < kMaxBessel; ++nb) {
+        if (nb < B) {
+          T v = part[nb];
+          v += __shfl_xor(v, 1);
+          v += __shfl_xor(v, 2);
+          v += __shfl_xor(v, 4);
+          if (sub == (nb & 7)) sT[le * (B + 1) + nb] = v;
+        }
       }
     }
-    sT[le * (B + 1) + nb] = acc;
+  } else {
+    for (int idx = tid; idx < 256 * B; idx += 256) {
+      int le = idx / B, nb = idx % B;
+      int64_t e = e0 + le;
+      T acc = T(0);
+      if (e < a.E) {
+        int ti = a.types[a.center[e]], tj = a.types[a.nbr[e]];
+        const T* g = static_cast<const T*>(b.g_emb0) + e * S0;
+        for (int c = 0; c < S0; ++c) {
+          T te = c < half ? cemb[ti * half + c] : nemb[tj * half + (c - half)];
+          acc += g[c] * te * sWb[nb * S0 + c];
+        }
+      }
+      sT[le * (B + 1) + nb] = acc;
+    }
   }
   __syncthreads();
   // phase 2: per edge chain rule to the edge vector, then scatter to both atoms
   int64_t e = e0 + tid;
+  int ci = -1;  // center of this lane's edge (-1: no edge)
+  T fx = T(0), fy = T(0), fz = T(0);
   if (e < a.E) {
     int i = a.center[e], j = a.nbr[e];
+    ci = i;
     const T* vec = static_cast<const T*>(a.vec) + 4 * e;
     T nx = vec[0], ny = vec[1], nz = vec[2], r = vec[3];
     int ti = a.types[i], tj = a.types[j];
@@ -215,13 +253,35 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
     T dy = dEdr * ny + (gy - dot * ny) * inv;
     T dz = dEdr * nz + (gz - dot * nz) * inv;
     // r_ij = pos_j - pos_i : dE/dpos_j = +d, dE/dpos_i = -d ; F = -dE/dpos
+    fx = dx;
+    fy = dy;
+    fz = dz;
     T* F = static_cast<T*>(b.forces);
-    atomicAdd(&F[3 * int64_t(i)], dx);
-    atomicAdd(&F[3 * int64_t(i) + 1], dy);
-    atomicAdd(&F[3 * int64_t(i) + 2], dz);
     atomicAdd(&F[3 * int64_t(j)], -dx);
     atomicAdd(&F[3 * int64_t(j) + 1], -dy);
     atomicAdd(&F[3 * int64_t(j) + 2], -dz);
+  }
+  // center-atom contributions: the edges are sorted by center, so the lanes of a wave hold runs of equal centers;
+  // a segmented shuffle sum leaves one atomic per run instead of one per edge (same-address atomics serialise)
+  {
+    const int lane = tid & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int ko = __shfl_down(ci, off);
+      const T ox = __shfl_down(fx, off), oy = __shfl_down(fy, off), oz = __shfl_down(fz, off);
+      if (lane + off < 64 && ko == ci) {
+        fx += ox;
+        fy += oy;
+        fz += oz;
+      }
+    }
+    const int kp = __shfl_up(ci, 1);
+    if (ci >= 0 && (lane == 0 || kp != ci)) {
+      T* F = static_cast<T*>(b.forces);
+      atomicAdd(&F[3 * int64_t(ci)], fx);
+      atomicAdd(&F[3 * int64_t(ci) + 1], fy);
+      atomicAdd(&F[3 * int64_t(ci) + 2], fz);
+    }
   }
 }
 

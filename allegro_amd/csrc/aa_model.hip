@@ -178,7 +178,8 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     const int Dsh = (cfg->l_max + 1) * (cfg->l_max + 1);
     p->env_mom = p->chain_pair >= 0 && u == 64 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
                  (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) &&
-                 (cfg->dtype == AA_F32 ? 4 : 8) * 4 * Dsh * (128 + 64) <= 64 * 1024 && !(nm && nm[0] == '1');
+                 (cfg->dtype == AA_F32 ? 4 : 8) * 4 * Dsh * (std::max(S, cfg->latent_mlp_width) + 64 + 64) <= 160 * 1024 &&
+                 !(nm && nm[0] == '1');
   }
   // weight blob layout
   size_t o = 0;

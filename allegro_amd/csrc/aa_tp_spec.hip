@@ -675,10 +675,253 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_first_kernel(TpChainArgs a) 
 
 // =============================================================================================
 // moments kernels (u == 64, one wave per atom): see TpMomArgs in aa_common.h
+//
+// Every loop over the atom's edge segment is software-pipelined by hand: the rows of the NEXT batch / edge
+// pair are requested before the current one is consumed, so a wave always has several KB in flight instead of
+// paying one memory latency per edge (these kernels are latency-, not bandwidth- or VALU-bound).  The spherical
+// harmonics of the segment are staged once in wave-private LDS, pair-interleaved, so that the packed two-edge
+// math reads them as 2-vectors.
 // =============================================================================================
 namespace {
 constexpr int kMaxKa = 128;
+constexpr int kSegCap = 64;  // edges of a segment staged per pass (longer segments are walked in chunks of this size)
+constexpr int kPB = 8;       // edge pairs per load batch in the moment loops
 
+template <typename T>
+struct Pk;
+template <>
+struct Pk<float> {
+  typedef float type __attribute__((ext_vector_type(2)));
+};
+template <>
+struct Pk<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+
+// stage sh[cb..ce) as sY[(pair*D + j)*2 + half]; an odd tail repeats the last edge, and pairs up to the next
+// multiple of kPB are zero-filled (so batch loops need no bounds checks on the harmonics)
+template <typename T, int D>
+__device__ __forceinline__ void stage_sh(const T* sh, int ld_sh, int cb, int ce, int lane, T* sY) {
+  const int n = ce - cb;
+  const int npad = (n + 1) & ~1;
+  const int nfill = ((((n + 1) >> 1) + kPB - 1) / kPB) * kPB * 2;
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < nfill * D; i += 64) {
+    const int e = i / D, j = i - e * D;
+    const int es = e < n ? e : n - 1;
+    const T v = sh[int64_t(cb + es) * ld_sh + j];
+    sY[((e >> 1) * D + j) * 2 + (e & 1)] = e < npad ? v : T(0);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// per-pair env-input values for channel block kb: {a[s][kb+lane], a[s+1][kb+lane]}, zero beyond the segment
+template <typename T>
+__device__ __forceinline__ void load_a_batch(const T* a, int ld_a, int kb, bool act, int s0, int ce, int lane,
+                                             typename Pk<T>::type* v) {
+  typedef typename Pk<T>::type T2;
+#pragma unroll
+  for (int i = 0; i < kPB; ++i) {
+    const int e0 = s0 + 2 * i, e1 = e0 + 1;
+    const int c0 = e0 < ce ? e0 : ce - 1, c1 = e1 < ce ? e1 : ce - 1;
+    T x0 = a[int64_t(c0) * ld_a + kb + lane], x1 = a[int64_t(c1) * ld_a + kb + lane];
+    if (act) {
+      x0 = silu(x0);
+      x1 = silu(x1);
+    }
+    v[i] = T2{e0 < ce ? x0 : T(0), e1 < ce ? x1 : T(0)};
+  }
+}
+
+// sM[j][kb + lane] (+)= sum over the staged chunk of sh[e,j] * act(a[e, kb + lane])
+template <typename T, int D>
+__device__ __forceinline__ void mom_accumulate(const T* a, int ld_a, int ka, int ka_lds, bool act, int cb, int ce, bool first,
+                                               int lane, const T* sY, T* sM) {
+  typedef typename Pk<T>::type T2;
+  const T2* sY2 = reinterpret_cast<const T2*>(sY);
+  const int np = (ce - cb + 1) >> 1;
+  for (int kb = 0; kb < ka; kb += 64) {
+    T2 m2[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) m2[j] = T2{T(0), T(0)};
+    T2 cur[kPB], nxt[kPB];
+    load_a_batch<T>(a, ld_a, kb, act, cb, ce, lane, cur);
+    for (int q0 = 0; q0 < np; q0 += kPB) {
+      load_a_batch<T>(a, ld_a, kb, act, cb + 2 * (q0 + kPB), ce, lane, nxt);
+#pragma unroll
+      for (int i = 0; i < kPB; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) m2[j] += sY2[(q0 + i) * D + j] * cur[i];
+      }
+#pragma unroll
+      for (int i = 0; i < kPB; ++i) cur[i] = nxt[i];
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const T v = m2[j][0] + m2[j][1];
+      T* d = sM + j * ka_lds + kb + lane;
+      *d = first ? v : *d + v;
+    }
+  }
+}
+
+// x2s[j] (this lane's channel) = f * sum_k M[j][k] * Wk[k][r(j)][ch]; weight rows are fetched 8 k ahead
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_project(const T* sM, int ka, int ka_lds, const T* Wk, T sf, int lane, T* x2s) {
+  constexpr int KB = 8;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < D; ++j) x2s[j] = T(0);
+  T wc[KB][R], wn[KB][R];
+  auto loadw = [&](int k0, T(*w)[R]) {
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int k = k0 + i < ka ? k0 + i : ka - 1;
+#pragma unroll
+      for (int r = 0; r < R; ++r) w[i][r] = Wk[(int64_t(k) * R + r) * 64 + lane];
+    }
+  };
+  loadw(0, wc);
+  for (int k0 = 0; k0 < ka; k0 += KB) {
+    loadw(k0 + KB, wn);
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) x2s[j] += sM[j * ka_lds + k0 + i] * wc[i][r_of<0>(j)];
+    }
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+      for (int r = 0; r < R; ++r) wc[i][r] = wn[i][r];
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) x2s[j] *= sf;
+  __builtin_amdgcn_wave_barrier();
+}
+
+// GM[j] (k = kb + lane) = sum_ch g[j][ch] * Wt[r(j)][ch][k]   (g already carries the scatter factor)
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_gm(const T* sG, const T* Wt, int ka, int kb, int lane, T* gm) {
+  constexpr int CB = 8;
+#pragma unroll
+  for (int j = 0; j < D; ++j) gm[j] = T(0);
+  T wc[CB][R], wn[CB][R];
+  auto loadw = [&](int c0, T(*w)[R]) {
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int ch = c0 + i < 64 ? c0 + i : 63;
+#pragma unroll
+      for (int r = 0; r < R; ++r) w[i][r] = Wt[(int64_t(r) * 64 + ch) * ka + kb + lane];
+    }
+  };
+  loadw(0, wc);
+  for (int c0 = 0; c0 < 64; c0 += CB) {
+    loadw(c0 + CB, wn);
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) gm[j] += sG[j * 64 + c0 + i] * wc[i][r_of<0>(j)];
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+      for (int r = 0; r < R; ++r) wc[i][r] = wn[i][r];
+  }
+}
+
+// adjoint of the moments for every edge of the segment:
+//   d_a[e,k] = sum_j sh[e,j] * GM[j][k]        d_sh[e,j] = sum_k act(a[e,k]) * GM[j][k]
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const T* a, int ld_a, int ka, bool act,
+                                                   const T* g2acc, const T* Wt, int beg, int end, int lane, T* sG, T* sY,
+                                                   int& staged_cb, T* g_a, int ld_ga, T* gsh, int ld_gsh) {
+  typedef typename Pk<T>::type T2;
+  constexpr int B = 4;  // pairs per batch here (two channel blocks may be live)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < D; ++j) sG[j * 64 + lane] = g2acc[j];
+  __builtin_amdgcn_wave_barrier();
+  T gm0[D], gm1[D];
+  mom_gm<T, D, R>(sG, Wt, ka, 0, lane, gm0);
+  const bool two = ka > 64;
+  if (two) mom_gm<T, D, R>(sG, Wt, ka, 64, lane, gm1);
+  const T2* sY2 = reinterpret_cast<const T2*>(sY);
+  auto loadb = [&](int s0, int ce, T2* v0, T2* v1) {
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int e0 = s0 + 2 * i, e1 = e0 + 1;
+      const int c0 = e0 < ce ? e0 : ce - 1, c1 = e1 < ce ? e1 : ce - 1;
+      T x0 = a[int64_t(c0) * ld_a + lane], x1 = a[int64_t(c1) * ld_a + lane];
+      if (act) {
+        x0 = silu(x0);
+        x1 = silu(x1);
+      }
+      v0[i] = T2{x0, x1};
+      if (two) {
+        T z0 = a[int64_t(c0) * ld_a + 64 + lane], z1 = a[int64_t(c1) * ld_a + 64 + lane];
+        if (act) {
+          z0 = silu(z0);
+          z1 = silu(z1);
+        }
+        v1[i] = T2{z0, z1};
+      }
+    }
+  };
+  for (int cb = beg; cb < end; cb += kSegCap) {
+    const int ce = cb + kSegCap < end ? cb + kSegCap : end;
+    if (staged_cb != cb) {
+      stage_sh<T, D>(sh, ld_sh, cb, ce, lane, sY);
+      staged_cb = cb;
+    }
+    T2 c0v[B], c1v[B], n0v[B], n1v[B];
+    loadb(cb, ce, c0v, c1v);
+    for (int s0 = cb; s0 < ce; s0 += 2 * B) {
+      loadb(s0 + 2 * B, ce, n0v, n1v);
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        const int s = s0 + 2 * i;
+        if (s < ce) {
+          const bool vb = s + 1 < ce;
+          const T2* y = sY2 + ((s - cb) >> 1) * D;
+          T2 d0 = T2{T(0), T(0)}, d1 = T2{T(0), T(0)}, gy[D];
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            const T2 yj = y[j];
+            d0 += yj * gm0[j];
+            gy[j] = c0v[i] * gm0[j];
+            if (two) {
+              d1 += yj * gm1[j];
+              gy[j] += c1v[i] * gm1[j];
+            }
+          }
+          T ga[D], gb[D];
+#pragma unroll
+          for (int j = 0; j < D; ++j) {
+            ga[j] = gy[j][0];
+            gb[j] = gy[j][1];
+          }
+          g_a[int64_t(s) * ld_ga + lane] = d0[0];
+          if (two) g_a[int64_t(s) * ld_ga + 64 + lane] = d1[0];
+          wave_sum_store<T, D>(ga, gsh + int64_t(s) * ld_gsh, true, false);
+          if (vb) {
+            g_a[int64_t(s + 1) * ld_ga + lane] = d0[1];
+            if (two) g_a[int64_t(s + 1) * ld_ga + 64 + lane] = d1[1];
+            wave_sum_store<T, D>(gb, gsh + int64_t(s + 1) * ld_gsh, true, false);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        c0v[i] = n0v[i];
+        c1v[i] = n1v[i];
+      }
+    }
+  }
+}
+
+// ---- forward kernels: harmonics through the scalar path (SGPR operands), one pair of edges ahead.  They run
+// at 4-5 waves/SIMD and within ~20% of the achievable HBM rate; the LDS-staged, deeper-pipelined form used by the
+// reverse kernels costs them occupancy (measured slower), so they keep this leaner shape.
 // M[j][k] = sum_e sh[e,j] * act(a[e,k]) into wave-private LDS sM[D][ka], then
 // x2s[j] (this lane's channel) = f * sum_k M[j][k] * Wk[k][r(j)][ch]
 template <typename T, int D, int R>
@@ -715,72 +958,6 @@ __device__ __forceinline__ void mom_x2s(const T* sh, int ld_sh, const T* a, int 
   __builtin_amdgcn_wave_barrier();
 }
 
-// GM[j] (k = kb + lane) = sum_ch g[j][ch] * Wt[r(j)][ch][k]   (g already carries the scatter factor)
-template <typename T, int D, int R>
-__device__ __forceinline__ void mom_gm(const T* sG, const T* Wt, int ka, int kb, int lane, T* gm) {
-#pragma unroll
-  for (int j = 0; j < D; ++j) gm[j] = T(0);
-#pragma unroll 4
-  for (int ch = 0; ch < 64; ++ch) {
-    T wv[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) wv[r] = Wt[(int64_t(r) * 64 + ch) * ka + kb + lane];
-#pragma unroll
-    for (int j = 0; j < D; ++j) gm[j] += sG[j * 64 + ch] * wv[r_of<0>(j)];
-  }
-}
-
-// adjoint of the moments for every edge of the segment:
-//   d_a[e,k] = sum_j sh[e,j] * GM[j][k]        d_sh[e,j] = sum_k act(a[e,k]) * GM[j][k]
-template <typename T, int D, int R>
-__device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const T* a, int ld_a, int ka, bool act,
-                                                   const T* g2acc, const T* Wt, int beg, int end, int lane, T* sG, T* g_a,
-                                                   int ld_ga, T* gsh, int ld_gsh) {
-#pragma unroll
-  for (int j = 0; j < D; ++j) sG[j * 64 + lane] = g2acc[j];
-  __builtin_amdgcn_wave_barrier();
-  T gm0[D], gm1[D];
-  mom_gm<T, D, R>(sG, Wt, ka, 0, lane, gm0);
-  if (ka > 64) mom_gm<T, D, R>(sG, Wt, ka, 64, lane, gm1);
-  for (int s = beg; s < end; ++s) {
-    const T* y = sh + int64_t(s) * ld_sh;
-    T a0v = a[int64_t(s) * ld_a + lane], a1v = T(0);
-    if (act) a0v = silu(a0v);
-    T d0 = T(0), d1 = T(0), gy[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      d0 += y[j] * gm0[j];
-      gy[j] = a0v * gm0[j];
-    }
-    g_a[int64_t(s) * ld_ga + lane] = d0;
-    if (ka > 64) {
-      a1v = a[int64_t(s) * ld_a + 64 + lane];
-      if (act) a1v = silu(a1v);
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        d1 += y[j] * gm1[j];
-        gy[j] += a1v * gm1[j];
-      }
-      g_a[int64_t(s) * ld_ga + 64 + lane] = d1;
-    }
-    wave_sum_store<T, D>(gy, gsh + int64_t(s) * ld_gsh, true, false);
-  }
-}
-}  // namespace
-
-// ---- packed two-edge evaluation: the straight-line CG code is instantiated on 2-vectors (edge s and s+1 in
-// the two halves), which the compiler maps to v_pk_fma_f32 / v_pk_mul_f32; x2s and the path weights stay scalar
-template <typename T>
-struct Pk;
-template <>
-struct Pk<float> {
-  typedef float type __attribute__((ext_vector_type(2)));
-};
-template <>
-struct Pk<double> {
-  typedef double type __attribute__((ext_vector_type(2)));
-};
-
 template <typename T, int D, int R>
 struct EdgeIn2 {
   typename Pk<T>::type y[D];
@@ -788,19 +965,78 @@ struct EdgeIn2 {
   typename Pk<T>::type g0, g1;
 };
 
+
+// per-pair operands of the contraction loops that come from HBM (the harmonics come from LDS)
+template <typename T, int R>
+struct PairIn {
+  typename Pk<T>::type wa[R];
+  typename Pk<T>::type g0, g1;
+};
+}  // namespace
+
 // common prologue of the moments kernels
 #define AA_MOM_PROLOGUE(DVAL)                                                                                          \
   const TpChainArgs& a = ma.c;                                                                                         \
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;                                                            \
   const int64_t atom = int64_t(blockIdx.x) * 4 + wv;                                                                   \
-  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * (DVAL) * (kMaxKa + 64);                                         \
-  T* sG = sM + (DVAL) * kMaxKa;                                                                                        \
+  const int ka_lds = ma.ka_lds;                                                                                        \
+  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * (DVAL) * (ka_lds + 64 + kSegCap);                               \
+  T* sG = sM + (DVAL) * ka_lds;                                                                                        \
+  T* sY = sG + (DVAL) * 64;                                                                                            \
+  const T2* sY2 = reinterpret_cast<const T2*>(sY);                                                                     \
   (void)sG;                                                                                                            \
   (void)sM;                                                                                                            \
+  (void)sY2;                                                                                                           \
   if (atom >= a.N) return;                                                                                             \
   const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]); \
   const T* sh = static_cast<const T*>(a.sh);                                                                           \
-  const T* w0g = static_cast<const T*>(a.w0) + lane;
+  const T* w0g = static_cast<const T*>(a.w0) + lane;                                                                   \
+  int staged_cb = -1;
+
+// moments of the whole segment -> x2s (leaves the LAST chunk staged in sY)
+#define AA_MOM_X2S(AIN, LDA, KA, ACT, WK, OUT)                                                                         \
+  {                                                                                                                    \
+    if (beg >= end) {                                                                                                  \
+      for (int kb = 0; kb < (KA); kb += 64)                                                                            \
+        for (int j = 0; j < D; ++j) sM[j * ka_lds + kb + lane] = T(0);                                                 \
+    }                                                                                                                  \
+    for (int cb = beg; cb < end; cb += kSegCap) {                                                                      \
+      const int ce = cb + kSegCap < end ? cb + kSegCap : end;                                                          \
+      stage_sh<T, D>(sh, a.ld_sh, cb, ce, lane, sY);                                                                   \
+      staged_cb = cb;                                                                                                  \
+      mom_accumulate<T, D>(static_cast<const T*>(AIN), LDA, KA, ka_lds, ACT, cb, ce, cb == beg, lane, sY, sM);         \
+    }                                                                                                                  \
+    mom_project<T, D, R>(sM, KA, ka_lds, static_cast<const T*>(WK), T(a.sf), lane, OUT);                               \
+  }
+
+// loop over the segment in staged chunks and edge pairs, with the HBM operands of the pair after next in flight:
+// fetch(s, ce, PairIn&) requests the rows of pair (s, s+1) (clamped to the chunk), body(s, vb, y, cur) consumes
+template <typename T, int D, int R, int AHEAD, class F, class B>
+__device__ __forceinline__ void mom_pair_loop(const T* sh, int ld_sh, int beg, int end, int lane, T* sY, int& staged_cb,
+                                              F&& fetch, B&& body) {
+  typedef typename Pk<T>::type T2;
+  const T2* sY2 = reinterpret_cast<const T2*>(sY);
+  for (int cb = beg; cb < end; cb += kSegCap) {
+    const int ce = cb + kSegCap < end ? cb + kSegCap : end;
+    if (staged_cb != cb) {
+      stage_sh<T, D>(sh, ld_sh, cb, ce, lane, sY);
+      staged_cb = cb;
+    }
+    PairIn<T, R> cur, nx1, nx2;
+    fetch(cb, ce, cur);
+    if (AHEAD == 2) fetch(cb + 2, ce, nx1);
+    for (int s = cb; s < ce; s += 2) {
+      if (AHEAD == 2) {
+        fetch(s + 4, ce, nx2);
+      } else {
+        fetch(s + 2, ce, nx1);
+      }
+      body(s, s + 1 < ce, sY2 + ((s - cb) >> 1) * D, cur);
+      cur = nx1;
+      if (AHEAD == 2) nx1 = nx2;
+    }
+  }
+}
 
 template <class Sig0, typename T>
 __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
@@ -929,48 +1165,35 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
-  {
-    auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
-      const bool vb = s + 1 < end;
-      const int sb = vb ? s + 1 : s;
-      const T* ya = sh + int64_t(s) * a.ld_sh;
-      const T* yb = sh + int64_t(sb) * a.ld_sh;
-      const T* wa = w0g + int64_t(s) * a.ld_w0;
-      const T* wb = w0g + int64_t(sb) * a.ld_w0;
+  auto fetch = [&](int s, int ce, PairIn<T, R>& in) {
+    const int sa = s < ce ? s : ce - 1, sb = s + 1 < ce ? s + 1 : ce - 1;
+    const T* wa = w0g + int64_t(sa) * a.ld_w0;
+    const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-      for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
+    const T ga = gs1[int64_t(sa) * a.ld_gscal], gb = gs1[int64_t(sb) * a.ld_gscal];
+    in.g1 = T2{ga, s + 1 < ce ? gb : T(0)};  // a padded second edge contributes nothing
+  };
+  mom_pair_loop<T, D, R, 2>(sh, a.ld_sh, beg, end, lane, sY, staged_cb, fetch, [&](int s, bool vb, const T2* y, const PairIn<T, R>& cur) {
+    T2 x1[Sig0::D1], tf1[Sig0::DOUT], go[1], g2[D];
 #pragma unroll
-      for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
-      const T gb = gs1[int64_t(sb) * a.ld_gscal];
-      in.g1 = T2{gs1[int64_t(s) * a.ld_gscal], vb ? gb : T(0)};  // a padded second edge contributes nothing
-    };
-    if (beg < end) {
-      EdgeIn2<T, D, R> cur, nxt;
-      fetch(beg, cur);
-      for (int s = beg; s < end; s += 2) {
-        fetch(s + 2 < end ? s + 2 : s, nxt);
-        T2 x1[Sig0::D1], tf1[Sig0::DOUT], go[1], g2[D];
+    for (int i = 0; i < Sig0::D1; ++i) x1[i] = y[i] * cur.wa[r_of<0>(i)];
+    Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
+    go[0] = cur.g1;
+    Sig1::template bx24<T2, T2, T2, T>(go, tf1, wp1, g2);
 #pragma unroll
-        for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
-        Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
-        go[0] = cur.g1;
-        Sig1::template bx24<T2, T2, T2, T>(go, tf1, wp1, g2);
-#pragma unroll
-        for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
-        cur = nxt;
-      }
-    }
-  }
+    for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
+  });
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
   mom_backward_edges<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, g2acc,
-                              static_cast<const T*>(ma.wt1), beg, end, lane, sG, static_cast<T*>(ma.g_a), ma.ld_ga,
-                              static_cast<T*>(a.gsh_env), a.ld_gsh);
+                              static_cast<const T*>(ma.wt1), beg, end, lane, sG, sY, staged_cb, static_cast<T*>(ma.g_a),
+                              ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
 
 template <class Sig0, class Sig1, typename T>
-__global__ __launch_bounds__(256) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
   AA_MOM_PROLOGUE(D)
@@ -997,71 +1220,59 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
-  {
-    auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
-      const bool vb = s + 1 < end;
-      const int sb = vb ? s + 1 : s;
-      const T* ya = sh + int64_t(s) * a.ld_sh;
-      const T* yb = sh + int64_t(sb) * a.ld_sh;
-      const T* wa = w0g + int64_t(s) * a.ld_w0;
-      const T* wb = w0g + int64_t(sb) * a.ld_w0;
+  auto fetch = [&](int s, int ce, PairIn<T, R>& in) {
+    const int sa = s < ce ? s : ce - 1, sb = s + 1 < ce ? s + 1 : ce - 1;
+    const T* wa = w0g + int64_t(sa) * a.ld_w0;
+    const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-      for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
+    const bool vb2 = s + 1 < ce;
+    const T g0a = gs0[int64_t(sa) * a.ld_gscal], g0b = gs0[int64_t(sb) * a.ld_gscal];
+    const T g1a = gs1[int64_t(sa) * a.ld_gscal], g1b = gs1[int64_t(sb) * a.ld_gscal];
+    in.g0 = T2{g0a, vb2 ? g0b : T(0)};
+    in.g1 = T2{g1a, vb2 ? g1b : T(0)};
+  };
+  T* gw0 = static_cast<T*>(a.g_w0) + lane;
+  T* gsx = static_cast<T*>(a.gsh_x1);
+  mom_pair_loop<T, D, R, 1>(sh, a.ld_sh, beg, end, lane, sY, staged_cb, fetch, [&](int s, bool vb, const T2* y, const PairIn<T, R>& cur) {
+    T2 x1[D1];
 #pragma unroll
-      for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
-      const T g0b = gs0[int64_t(sb) * a.ld_gscal], g1b = gs1[int64_t(sb) * a.ld_gscal];
-      in.g0 = T2{gs0[int64_t(s) * a.ld_gscal], vb ? g0b : T(0)};
-      in.g1 = T2{gs1[int64_t(s) * a.ld_gscal], vb ? g1b : T(0)};
-    };
-    if (beg < end) {
-      EdgeIn2<T, D, R> cur, nxt;
-      fetch(beg, cur);
-      T* gw0 = static_cast<T*>(a.g_w0) + lane;
-      T* gsx = static_cast<T*>(a.gsh_x1);
-      for (int s = beg; s < end; s += 2) {
-        fetch(s + 2 < end ? s + 2 : s, nxt);
-        const bool vb = s + 1 < end;
-        T2 x1[D1];
+    for (int i = 0; i < D1; ++i) x1[i] = y[i] * cur.wa[r_of<0>(i)];
+    T2 gn[1], go[DOUT];
+    gn[0] = cur.g1;
+    Sig1::template bx14<T2, T2, T, T>(gn, x2s1, wp1, go);  // d_tf1, recomputed (never stored)
+    go[0] += cur.g0;
+    T2 g1[D1], g2[D];
+    Sig0::template bx14<T2, T2, T, T>(go, x2s0, wp0, g1);
+    Sig0::template bx24<T2, T2, T2, T>(go, x1, wp0, g2);
 #pragma unroll
-        for (int i = 0; i < D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
-        T2 gn[1], go[DOUT];
-        gn[0] = cur.g1;
-        Sig1::template bx14<T2, T2, T, T>(gn, x2s1, wp1, go);  // d_tf1, recomputed (never stored)
-        go[0] += cur.g0;
-        T2 g1[D1], g2[D];
-        Sig0::template bx14<T2, T2, T, T>(go, x2s0, wp0, g1);
-        Sig0::template bx24<T2, T2, T2, T>(go, x1, wp0, g2);
+    for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
+    T2 gw[R];
+    T gya[D1], gyb[D1];
 #pragma unroll
-        for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
-        T2 gw[R];
-        T gya[D1], gyb[D1];
+    for (int r = 0; r < R; ++r) gw[r] = T2{T(0), T(0)};
 #pragma unroll
-        for (int r = 0; r < R; ++r) gw[r] = T2{T(0), T(0)};
-#pragma unroll
-        for (int i = 0; i < D1; ++i) {
-          gw[r_of<0>(i)] += g1[i] * cur.y[i];
-          const T2 t = g1[i] * cur.wa[r_of<0>(i)];
-          gya[i] = t[0];
-          gyb[i] = t[1];
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * 64] = gw[r][0];
-        wave_sum_store<T, D1>(gya, gsx + int64_t(s) * a.ld_gsh, true, false);
-        if (vb) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) gw0[int64_t(s + 1) * a.ld_gw0 + r * 64] = gw[r][1];
-          wave_sum_store<T, D1>(gyb, gsx + int64_t(s + 1) * a.ld_gsh, true, false);
-        }
-        cur = nxt;
-      }
+    for (int i = 0; i < D1; ++i) {
+      gw[r_of<0>(i)] += g1[i] * y[i];
+      const T2 t = g1[i] * cur.wa[r_of<0>(i)];
+      gya[i] = t[0];
+      gyb[i] = t[1];
     }
-  }
+#pragma unroll
+    for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * 64] = gw[r][0];
+    wave_sum_store<T, D1>(gya, gsx + int64_t(s) * a.ld_gsh, true, false);
+    if (vb) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) gw0[int64_t(s + 1) * a.ld_gw0 + r * 64] = gw[r][1];
+      wave_sum_store<T, D1>(gyb, gsx + int64_t(s + 1) * a.ld_gsh, true, false);
+    }
+  });
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
   mom_backward_edges<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, g2acc,
-                              static_cast<const T*>(ma.wt0), beg, end, lane, sG, static_cast<T*>(ma.g_a), ma.ld_ga,
-                              static_cast<T*>(a.gsh_env), a.ld_gsh);
+                              static_cast<const T*>(ma.wt0), beg, end, lane, sG, sY, staged_cb, static_cast<T*>(ma.g_a),
+                              ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
 
 // (layer-0 signature, last-layer signature) pairs of 2-layer stacks at l_max = 1, 2, 3
@@ -1158,12 +1369,19 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
       return fail(AA_ERR_INVALID, #NAME ": needs u == 64 and env-input widths of 64 or 128");            \
     dim3 grid((unsigned)((a.c.N + 3) / 4));                                                              \
     const int dpair = pair == 0 ? 4 : (pair == 1 ? 9 : 16);                                              \
-    size_t smem = sizeof(T) * 4 * dpair * (kMaxKa + 64);                                                 \
-    if (smem > 64 * 1024) return fail(AA_ERR_INVALID, #NAME ": LDS patch too large for this dtype/l_max"); \
+    TpMomArgs b = a;                                                                                     \
+    b.ka_lds = a.ka0 > a.ka1 ? a.ka0 : a.ka1;                                                            \
+    size_t smem = sizeof(T) * 4 * dpair * (b.ka_lds + 64 + kSegCap);                                     \
+    if (smem > 160 * 1024) return fail(AA_ERR_INVALID, #NAME ": LDS patch too large for this dtype/l_max"); \
+    if (smem > 64 * 1024) {                                                                              \
+      const void* fn = pair == 0 ? (const void*)NAME##_kernel<K1, T>                                     \
+                                 : (pair == 1 ? (const void*)NAME##_kernel<K2, T> : (const void*)NAME##_kernel<K3, T>); \
+      AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));      \
+    }                                                                                                    \
     switch (pair) {                                                                                      \
-      case 0: hipLaunchKernelGGL((NAME##_kernel<K1, T>), grid, dim3(256), smem, stream, a); break;       \
-      case 1: hipLaunchKernelGGL((NAME##_kernel<K2, T>), grid, dim3(256), smem, stream, a); break;       \
-      case 2: hipLaunchKernelGGL((NAME##_kernel<K3, T>), grid, dim3(256), smem, stream, a); break;       \
+      case 0: hipLaunchKernelGGL((NAME##_kernel<K1, T>), grid, dim3(256), smem, stream, b); break;       \
+      case 1: hipLaunchKernelGGL((NAME##_kernel<K2, T>), grid, dim3(256), smem, stream, b); break;       \
+      case 2: hipLaunchKernelGGL((NAME##_kernel<K3, T>), grid, dim3(256), smem, stream, b); break;       \
       default: return fail(AA_ERR_INVALID, #NAME ": unknown chain pair");                                \
     }                                                                                                    \
     AA_CHECK_HIP(hipGetLastError());                                                                     \

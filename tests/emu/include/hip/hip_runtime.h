@@ -118,6 +118,13 @@ inline T __shfl_down(T v, int delta, int width = 64) {
   return __shfl(v, src, width);
 }
 
+template <typename T>
+inline T __shfl_up(T v, int delta, int width = 64) {
+  int l = emu::lane() % width;
+  int src = l - delta >= 0 ? l - delta : l;
+  return __shfl(v, src, width);
+}
+
 typedef float emu_v16f __attribute__((ext_vector_type(16)));
 inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_v16f c, int, int, int) {
   int l = emu::lane(), w = emu::wave();

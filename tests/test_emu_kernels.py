@@ -90,3 +90,34 @@ def test_moments_packed_path_ragged_degrees_vs_oracle():
     ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, torch.tensor(shift @ cell))
     assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9 * max(1.0, float(ref["atomic_energy"].abs().max()))
     assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))
+
+
+def test_moments_path_long_segments_vs_oracle():
+    """Degrees above the 64-edge staging chunk of the moments kernels (and odd): every atom of a dense cluster sees
+    all 68 others, so each segment is walked in two staged chunks (64 + 5 edges, padded last pair)."""
+    import numpy as np
+
+    from oracle import restatement as R
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+
+    rng = np.random.default_rng(9)
+    grid = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(3), indexing="ij"), -1).reshape(-1, 3)[:70]
+    pos = grid * 0.52 + rng.uniform(-0.05, 0.05, size=(70, 3)) + 20.0
+    cell = np.eye(3) * 60.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
+    deg = np.bincount(ei[0], minlength=70)
+    assert deg.min() == 69 and deg.max() == 69
+    cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=2, num_layers=2, num_scalar_features=64, num_tensor_features=64,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               radial_chemical_embed_dim=32, scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=64,
+               readout_mlp_hidden_layers_width=64, avg_num_neighbors=69.0, seed=3, model_dtype="float64")
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    types = torch.tensor(rng.integers(0, 2, size=70))
+    g = m.prepare_graph(torch.tensor(ei), types, 70, torch.tensor(shift @ cell))
+    e, f = m.energy_forces(torch.tensor(pos), g)
+    sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, torch.tensor(shift @ cell))
+    assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9 * max(1.0, float(ref["atomic_energy"].abs().max()))
+    assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))
