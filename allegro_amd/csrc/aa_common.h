@@ -42,6 +42,28 @@ constexpr int kThreads = 256;
 // SiLU and its derivative.  fp64: exact forms.  fp32: v_exp_f32 + v_rcp_f32 (1-2 ulp each) instead of the IEEE
 // division / accurate expf sequences, which cost ~15 VALU instructions per element (768 v_div_* in the first
 // fused-chain kernel) -- the difference is ~1e-7 relative, far inside the reference's 5e-5 model tolerance.
+// ---- cross-lane exchange primitives of gfx950 used by the wave reductions (VALU only, no LDS traffic).
+// v_permlane32_swap / v_permlane16_swap exchange the upper half (odd 16-lane rows) of `a` with the lower half
+// (even rows) of `b`.  They are issued as inline ISA: the compiler builtin of ROCm 7.2 returns the first result
+// for both outputs.  (The CPU emulator that tests/ compile these sources with supplies its own versions.)
+#ifdef AA_EMU_LANE_OPS
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) { aa_emu_permlane_swap(a, b, 32); }
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) { aa_emu_permlane_swap(a, b, 16); }
+#else
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+#endif
+// DPP lane pattern applied to v (fused by the compiler into the consuming VALU op)
+constexpr int kDppRowRor8 = 0x128, kDppRowRor4 = 0x124, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ double sigmoid_(double x) { return 1.0 / (1.0 + exp(-x)); }
 __device__ __forceinline__ float sigmoid_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));

@@ -59,7 +59,9 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // Sum D (<=16) per-lane values over the 64 lanes of a wave with a reduce-scatter butterfly
-// (8+4+2+1+1+1 = 17 shuffles instead of 6*D) and store total k to dst[k].
+// (8+4+2+1+1+1 = 17 exchange steps instead of 6*D) and store total k to dst[k].
+// fp32: the exchanges are v_permlane32/16_swap (no selects needed: the swap leaves each half holding exactly the
+// two addends it keeps) and DPP-fused adds -- ~35 VALU instructions, no LDS.  fp64: shuffles.
 template <typename T, int D>
 __device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, bool atomic) {
   static_assert(D <= 16, "at most 16 values");
@@ -67,39 +69,70 @@ __device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, boo
   T x[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) x[k] = k < D ? v[k] : T(0);
-  T y[8], z[4], q[2];
-  {
-    const bool hi = lane & 32;
+  T r;
+  if constexpr (sizeof(T) == 4) {
+    float y[8], z[4], q[2];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      T recv = __shfl_xor(hi ? x[k] : x[k + 8], 32);
-      y[k] = (hi ? x[k + 8] : x[k]) + recv;
+      float a = x[k], b = x[k + 8];
+      permlane32_swap(a, b);  // lower half: {x_lo[k], x_hi[k]}, upper half: {x_lo[k+8], x_hi[k+8]}
+      y[k] = a + b;
     }
-  }
-  {
-    const bool hi = lane & 16;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      T recv = __shfl_xor(hi ? y[k] : y[k + 4], 16);
-      z[k] = (hi ? y[k + 4] : y[k]) + recv;
+      float a = y[k], b = y[k + 4];
+      permlane16_swap(a, b);
+      z[k] = a + b;
     }
-  }
-  {
-    const bool hi = lane & 8;
+    {
+      const bool hi = lane & 8;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      T recv = __shfl_xor(hi ? z[k] : z[k + 2], 8);
-      q[k] = (hi ? z[k + 2] : z[k]) + recv;
+      for (int k = 0; k < 2; ++k) {
+        const float send = hi ? z[k] : z[k + 2], keep = hi ? z[k + 2] : z[k];
+        q[k] = keep + dpp_move<kDppRowRor8>(send);
+      }
     }
+    {
+      const bool hi = lane & 4;
+      const float send = hi ? q[0] : q[1], keep = hi ? q[1] : q[0];
+      r = keep + dpp_move<kDppHalfMirror>(send);
+    }
+    r += dpp_move<kDppQuad1032>(r);
+    r += dpp_move<kDppQuad2301>(r);
+  } else {
+    T y[8], z[4], q[2];
+    {
+      const bool hi = lane & 32;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        T recv = __shfl_xor(hi ? x[k] : x[k + 8], 32);
+        y[k] = (hi ? x[k + 8] : x[k]) + recv;
+      }
+    }
+    {
+      const bool hi = lane & 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        T recv = __shfl_xor(hi ? y[k] : y[k + 4], 16);
+        z[k] = (hi ? y[k + 4] : y[k]) + recv;
+      }
+    }
+    {
+      const bool hi = lane & 8;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        T recv = __shfl_xor(hi ? z[k] : z[k + 2], 8);
+        q[k] = (hi ? z[k + 2] : z[k]) + recv;
+      }
+    }
+    {
+      const bool hi = lane & 4;
+      T recv = __shfl_xor(hi ? q[0] : q[1], 4);
+      r = (hi ? q[1] : q[0]) + recv;
+    }
+    r += __shfl_xor(r, 2);
+    r += __shfl_xor(r, 1);
   }
-  T r;
-  {
-    const bool hi = lane & 4;
-    T recv = __shfl_xor(hi ? q[0] : q[1], 4);
-    r = (hi ? q[1] : q[0]) + recv;
-  }
-  r += __shfl_xor(r, 2);
-  r += __shfl_xor(r, 1);
   const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
   if ((lane & 3) == 0 && idx < D && act) {
     if (atomic)

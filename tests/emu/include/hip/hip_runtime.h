@@ -125,6 +125,26 @@ inline T __shfl_up(T v, int delta, int width = 64) {
   return __shfl(v, src, width);
 }
 
+// gfx950 lane-exchange primitives (aa_common.h issues them as inline ISA on the device)
+#define AA_EMU_LANE_OPS 1
+// swap the upper half (odd `width`-lane rows) of a with the lower half (even rows) of b
+inline void aa_emu_permlane_swap(float& a, float& b, int width) {
+  const int l = emu::lane();
+  const bool odd = (l / width) & 1;
+  const float ga = __shfl(a, odd ? l : l + width);  // even rows read a of the partner odd row
+  const float gb = __shfl(b, odd ? l - width : l);  // odd rows read b of the partner even row
+  if (odd) a = gb; else b = ga;
+}
+inline int __builtin_amdgcn_update_dpp(int, int v, int ctrl, int, int, bool) {
+  const int l = emu::lane();
+  int src = l;
+  if (ctrl >= 0x121 && ctrl <= 0x12F) src = (l & ~15) | ((l + (ctrl - 0x120)) & 15);  // row_ror: lane i reads i+n (mod 16)
+  else if (ctrl == 0x141) src = (l & ~7) | (7 - (l & 7));                             // row_half_mirror
+  else if (ctrl >= 0 && ctrl <= 0xFF) src = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);  // quad_perm
+  else abort();
+  return __shfl(v, src);
+}
+
 typedef float emu_v16f __attribute__((ext_vector_type(16)));
 inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_v16f c, int, int, int) {
   int l = emu::lane(), w = emu::wave();
