@@ -788,6 +788,7 @@ struct ChainDev {
   const float* ro_scales;
   const int32_t* types;
   const int32_t* center;
+  int ro_n;  // entries of ro_w used by a_mode-1 layers
   ChainLayerDev L[3];
 };
 
@@ -815,6 +816,8 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
   }
   float rofac = c.ro_factor;  // readout-reverse transform factor of this row
   if (c.ro_scales) rofac *= c.ro_scales[c.types[c.center[gmc]]];
+  float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);  // [ro_n] last readout weights (a_mode 1)
+  for (int i = tid; i < c.ro_n; i += 256) sRo[i] = c.ro_w[i];
 
   // block-cooperative staging: thread t moves elements t, t+256, t+512 of the 768-element step
   auto stage_load = [&](const ChainLayerDev& L, int nt, int kc, u32x4* r) {
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
   // raw -> operand (readout-reverse transform of a_mode 1)
   auto finish_a = [&](const ChainLayerDev& L, int kc, v4f* a) {
     if (L.a_mode == 1) {
-      const float* rw = c.ro_w + kc * 32 + 4 * hh;
+      const float* rw = sRo + kc * 32 + 4 * hh;  // (LDS copy: no vector-memory access inside a step's control flow)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const v4f wv4 = *reinterpret_cast<const v4f*>(rw + 8 * q);
@@ -940,26 +943,35 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
     }
   };
 
+  // Every step issues the same vector-memory sequence -- 3 weight-staging loads, then 4 operand-row loads -- on
+  // every control path (targets are chosen with scalar selects; a step with nothing to prefetch re-reads layer
+  // 0's first chunk, an L2 hit).  With conditional loads the compiler's s_waitcnt placement has to assume the
+  // worst path and drains the operand prefetch together with the staging loads, which serialises a full memory
+  // latency into every step.
+  const float* const dummy_a = c.L[0].a[0];
+  const int dummy_lda = c.L[0].lda[0];
+  auto load_rows = [&](const float* base, int ld, v4f* a) {
+    const float* p = base + gmc * ld + 4 * hh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
+  };
+  auto streams = [&](const ChainLayerDev& X) { return X.KCg > 0 && !(X.KC <= 2 && X.NT > 2); };
   int step = 0;
   {
     u32x4 r[3];
     stage_load(c.L[0], 0, 0, r);
     stage_write(0, r);
   }
-  // operand of the next streamed step, loaded one step ahead (valid when a_pref)
+  // operand rows of the next streamed step, always loaded one step ahead
   v4f a0[4];
-  bool a_pref = false;
-  if (c.L[0].KCg > 0 && !(c.L[0].KC <= 2 && c.L[0].NT > 2)) {
-    load_a(c.L[0], 0, a0);
-    a_pref = true;
-  }
+  load_rows(dummy_a, dummy_lda, a0);  // (layer 0, chunk 0: the first streamed operand when layer 0 streams)
   __syncthreads();
   for (int li = 0; li < c.nlayers; ++li) {
     const ChainLayerDev& L = c.L[li];
     const int KCg = L.KCg, KC = L.KC, NT = L.NT;
     const bool last_layer = li + 1 >= c.nlayers;
     const ChainLayerDev& Ln = c.L[last_layer ? li : li + 1];
-    const bool next_streams = !last_layer && Ln.KCg > 0 && !(Ln.KC <= 2 && Ln.NT > 2);
+    const bool next_streams = !last_layer && streams(Ln);
     // few k chunks but several tile pairs: split the operands once, not once per pair
     const bool pre = KC <= 2 && NT > 2;
     u32x4 ps1[2][2], ps2[2][2], ps3[2][2];
@@ -987,65 +999,55 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
         acc0[r] = 0.f;
         acc1[r] = 0.f;
       }
-      if (pre) {
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-          if (kc < KC) {
-            const bool lastc = kc + 1 >= KC;
-            const bool layer_end = lastc && last_pair;
-            const bool has_next = !(layer_end && last_layer);
-            u32x4 r[3];
-            if (has_next) stage_load(layer_end ? Ln : L, layer_end ? 0 : (lastc ? nt + 2 : nt), (layer_end || lastc) ? 0 : kc + 1, r);
-            if (layer_end && next_streams) {
-              load_a(Ln, 0, a0);
-              a_pref = true;
-            }
-            mma_step(step & 1, ps1[kc], ps2[kc], ps3[kc], acc0, acc1);
-            if (has_next) stage_write((step + 1) & 1, r);
-            __syncthreads();
-            ++step;
-          }
-        }
-      } else {
-        for (int kc = 0; kc < KC; ++kc) {
-          const bool lastc = kc + 1 >= KC;
-          const bool layer_end = lastc && last_pair;
-          const bool has_next = !(layer_end && last_layer);
-          u32x4 r[3];
-          if (has_next) stage_load(layer_end ? Ln : L, layer_end ? 0 : (lastc ? nt + 2 : nt), (layer_end || lastc) ? 0 : kc + 1, r);
-          // this step's operand: prefetched rows, or the chained accumulators
-          v4f a[4];
+      const int nkc = pre ? (KC < 2 ? KC : 2) : KC;
+      for (int kc = 0; kc < nkc; ++kc) {
+        const bool lastc = kc + 1 >= KC;
+        const bool layer_end = lastc && last_pair;
+        const bool kernel_end = layer_end && last_layer;
+        // next step's weights (the last step of the kernel re-stages its own: uniform instruction stream)
+        u32x4 r[3];
+        stage_load(layer_end && !kernel_end ? Ln : L, (layer_end && !kernel_end) ? 0 : (lastc && !kernel_end ? nt + 2 : nt),
+                   (lastc && !kernel_end) ? 0 : (kernel_end ? kc : kc + 1), r);
+        // this step's operand: prefetched rows, the chained accumulators, or the pre-split registers
+        v4f a[4];
+        if (!pre) {
           if (kc >= KCg) {
             kept_a(kc == KCg, a);
           } else {
-            if (!a_pref) load_a(L, kc, a0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = a0[q];
             finish_a(L, kc, a);
           }
-          // next streamed step's rows in flight during this step's MFMAs (next chunk / next pair / next layer)
-          a_pref = false;
-          if (!lastc) {
-            if (kc + 1 < KCg) {
-              load_a(L, kc + 1, a0);
-              a_pref = true;
-            }
-          } else if (!last_pair) {
-            if (KCg > 0) {
-              load_a(L, 0, a0);
-              a_pref = true;
-            }
-          } else if (next_streams) {
-            load_a(Ln, 0, a0);
-            a_pref = true;
+        }
+        // rows of the next streamed step (next chunk / next pair / next layer), in flight during this step's MFMAs
+        {
+          const float* tp = dummy_a;
+          int tl = dummy_lda;
+          if (!pre && !lastc && kc + 1 < KCg) {
+            tp = L.a[kc + 1];
+            tl = L.lda[kc + 1];
+          } else if (!pre && lastc && !last_pair && KCg > 0) {
+            tp = L.a[0];
+            tl = L.lda[0];
+          } else if (layer_end && next_streams) {
+            tp = Ln.a[0];
+            tl = Ln.lda[0];
           }
+          load_rows(tp, tl, a0);
+        }
+        if (pre) {
+          if (kc == 0)
+            mma_step(step & 1, ps1[0], ps2[0], ps3[0], acc0, acc1);
+          else
+            mma_step(step & 1, ps1[1], ps2[1], ps3[1], acc0, acc1);
+        } else {
           u32x4 x1[2], x2[2], x3[2];
           split3_pack(a, x1, x2, x3);
           mma_step(step & 1, x1, x2, x3, acc0, acc1);
-          if (has_next) stage_write((step + 1) & 1, r);
-          __syncthreads();
-          ++step;
         }
+        stage_write((step + 1) & 1, r);
+        __syncthreads();
+        ++step;
       }
       epilogue(L.t[nt], acc0);
       if (two) epilogue(L.t[nt + 1], acc1);
@@ -1124,9 +1126,13 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
     D.keep_tile = L.keep_tile;
     D.keep_act = L.keep_act;
     D.a_mode = L.a_mode;
+    if (L.a_mode == 1) {
+      if (!c.ro_w) return fail(AA_ERR_INVALID, "gemm chain: a_mode 1 needs ro_w");
+      d.ro_n = std::max(d.ro_n, nchunk * 32);
+    }
   }
   dim3 grid((unsigned)((c.M + 127) / 128));
-  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), sizeof(u32x4) * 2 * kWStep, stream, d);
+  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), sizeof(u32x4) * 2 * kWStep + sizeof(float) * 32 * kChainMaxBlocks, stream, d);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }

@@ -65,13 +65,18 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ a, 
   for (int q = 0; q < 4; ++q) a0[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
   for (int kc = 0; kc < KC; ++kc) {
     u32x4 r[3];
-    if (V >= 3) {
+    if (V == 3 || V == 4) {
       r[0] = wq[tid]; r[1] = wq[256 + tid]; r[2] = wq[512 + tid];
     }
     v4f a1[4];
     const int nk = kc + 1 < KC ? kc + 1 : kc;
+    if (V >= 4) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a1[q] = *reinterpret_cast<const v4f*>(p + nk * 32 + 8 * q);
+      for (int q = 0; q < 4; ++q) a1[q] = a0[q] + v4f{1.f, 1.f, 1.f, 1.f};
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a1[q] = *reinterpret_cast<const v4f*>(p + nk * 32 + 8 * q);
+    }
     if (V == 0) {
       if (gm < M) {
 #pragma unroll
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ a, 
             acc1[h * 4 + e] += u2f(x3[h][e]);
           }
       } else {
-        const u32x4* w = wbuf + ((V >= 3 ? (kc & 1) : 0) * 768) + lane;
+        const u32x4* w = wbuf + (((V == 3 || V == 4) ? (kc & 1) : 0) * 768) + lane;
 #define W_(T_, Q_) w[((T_)*6 + (Q_)) * 64]
         {
           const u32x4 p0 = W_(0, 4), q0 = W_(1, 4), p1 = W_(0, 5), q1 = W_(1, 5);
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ a, 
           acc0 = mma(p0, x1[0], acc0); acc1 = mma(q0, x1[0], acc1); acc0 = mma(p1, x1[1], acc0); acc1 = mma(q1, x1[1], acc1);
         }
 #undef W_
-        if (V >= 3) {
+        if (V == 3 || V == 4) {
           u32x4* d = wbuf + ((kc + 1) & 1) * 768;
           d[tid] = r[0]; d[256 + tid] = r[1]; d[512 + tid] = r[2];
           __syncthreads();
@@ -172,6 +177,8 @@ int main() {
   RUN(2, 3, 72 * 1024, 192, "v2 + 24 MFMA/chunk, W in LDS, no barrier, write 192")
   RUN(3, 1, 72 * 1024, 64, "v3 + W re-staged per chunk + barrier, write 64")
   RUN(3, 3, 72 * 1024, 192, "v3 + W re-staged per chunk + barrier, write 192")
+  RUN(4, 1, 72 * 1024, 64, "v4 register operands (no A loads), W re-staged + barrier, w64")
+  RUN(5, 1, 72 * 1024, 64, "v5 register operands, W resident, no barrier, write 64")
   RUN(3, 3, 48 * 1024, 192, "v3 ... 3 blocks/CU")
   RUN(3, 3, 36 * 1024, 192, "v3 ... 4 blocks/CU")
   RUN(2, 3, 36 * 1024, 192, "v2 ... 4 blocks/CU")
