@@ -133,6 +133,8 @@ struct ChainLayer {
   int keep_tile;     // first of the two output tiles kept for the next layer, or -1
   int keep_act;      // silu on the kept values
   int a_mode;        // 1: A[e,k] = ro_factor * scale(type(center e)) * ro_w[k] * silu'(a[e,k])  (readout reverse)
+  void* edge_sum_out;  // [M] or nullptr: out[e] = sum_c silu(C[e,c]) * ro_w[c] of this (64-wide) layer -- the last linear
+                       // readout layer folded into the epilogue, so the edge sum reads 4 B/edge instead of a row
 };
 struct ChainArgs {
   int64_t M;
@@ -391,6 +393,7 @@ struct ReadoutArgs {
   const void* shifts;  // [T] or nullptr
   void* atom_energy;   // [N]
   void* g_h;           // bwd: [E,H] written
+  const void* edge_sum;  // [E] or nullptr: per-edge values already contracted with w (then h/w/act are unused)
 };
 template <typename T>
 int launch_readout_reduce(const ReadoutArgs& a, hipStream_t stream);

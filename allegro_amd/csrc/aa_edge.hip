@@ -294,6 +294,9 @@ __global__ __launch_bounds__(256) void readout_reduce_kernel(ReadoutArgs a) {
   if (n < a.N) {
     int beg = a.rowptr[n], end = a.rowptr[n + 1];
     const T* w = static_cast<const T*>(a.w);
+    if (a.edge_sum) {
+      for (int s = beg + lane; s < end; s += 64) acc += static_cast<const T*>(a.edge_sum)[s];
+    } else
     for (int c = lane; c < a.H; c += 64) {
       T wc = w[c];
       for (int s = beg; s < end; ++s) {

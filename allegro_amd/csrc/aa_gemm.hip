@@ -776,6 +776,7 @@ struct ChainLayerDev {
   const u32x4* Wq;
   int KCg, KC, NT;  // k chunks from global memory, total k chunks (+2 chained), output tiles
   int keep_tile, keep_act, a_mode, pad_;
+  float* edge_sum_out;
   const float* a[kChainMaxBlocks];
   int lda[kChainMaxBlocks];
   ChainTileDev t[kChainMaxBlocks];
@@ -1051,6 +1052,19 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
       }
       epilogue(L.t[nt], acc0);
       if (two) epilogue(L.t[nt + 1], acc1);
+      if (L.edge_sum_out) {  // (64-wide layer: this is its only tile pair)
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const v4f w0v = *reinterpret_cast<const v4f*>(sRo + 8 * q + 4 * hh);
+          const v4f w1v = *reinterpret_cast<const v4f*>(sRo + 32 + 8 * q + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part += silu(acc0[4 * q + e]) * w0v[e] + silu(acc1[4 * q + e]) * w1v[e];
+        }
+        float t = part, o = part;
+        permlane32_swap(t, o);  // both lane halves of a row: own + partner
+        if (row_ok && hh == 0) L.edge_sum_out[gm] = t + o;
+      }
       if (nt == L.keep_tile) {  // (the kept pair is the last pair of its layer: nothing reads the old kept tiles any more)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1129,6 +1143,11 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
     if (L.a_mode == 1) {
       if (!c.ro_w) return fail(AA_ERR_INVALID, "gemm chain: a_mode 1 needs ro_w");
       d.ro_n = std::max(d.ro_n, nchunk * 32);
+    }
+    D.edge_sum_out = static_cast<float*>(L.edge_sum_out);
+    if (L.edge_sum_out) {
+      if (!c.ro_w || g.N != 64) return fail(AA_ERR_INVALID, "gemm chain: edge_sum_out needs ro_w and a 64-wide layer");
+      d.ro_n = std::max(d.ro_n, 64);
     }
   }
   dim3 grid((unsigned)((c.M + 127) / 128));

@@ -411,7 +411,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -452,6 +452,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     for (int i = 0; i < c.latent_mlp_depth; ++i) w.lat_h[l][i] = take(Ez * c.latent_mlp_width);
   }
   for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
+  if (p->chain_gemm) w.e_edge = take(Ez);
   if (with_forces) {
     w.g_fcat = take(Ez * p->SL1);
     for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
@@ -659,6 +660,7 @@ struct Runner {
     r.scales = c.has_scales ? wt(p->o_scales) : nullptr;
     r.shifts = c.has_shifts ? wt(p->o_shifts) : nullptr;
     r.atom_energy = atom_energy;
+    r.edge_sum = (p->chain_gemm && atom_energy) ? buf(w.e_edge) : nullptr;  // written by the forward readout chain
     return r;
   }
 
@@ -869,6 +871,8 @@ struct Runner {
           SegList cr{1, {seg(buf(w.ro_h[0]), 64, 64)}};
           ca.L[1] = chain_layer(E, none, 0, wt(p->latent[l].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, 0, 0);
           ca.L[2] = chain_layer(E, fin, 0, wt(p->readout.wq[0]), S * L + 64, 64, cr, nullptr, nullptr, nullptr, 1, -1, 0);
+          ca.L[2].edge_sum_out = buf(w.e_edge);  // last linear readout layer folded into the epilogue
+          ca.ro_w = wt(p->o_ro_last);
         }
         if (int rc = run_chain(ca, "F2")) return rc;
         continue;
@@ -892,7 +896,7 @@ struct Runner {
       }
     }
     if (int rc = launch_readout_reduce<T>(readout_args(g, atom_energy), stream)) return rc;
-    return mark("readout_reduce", p->chain_gemm || c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1, 1);
+    return mark("readout_reduce", p->chain_gemm ? 1 : (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1), 1);
   }
 
   int backward(const aa_graph* g, const void* pos, void* forces) {

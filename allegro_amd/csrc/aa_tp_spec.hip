@@ -1022,6 +1022,9 @@ struct PairIn {
   (void)sY2;                                                                                                           \
   if (atom >= a.N) return;                                                                                             \
   const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]); \
+  /* an atom without edges (isolated, or owned by another rank of an atom-block partition) has nothing to        \
+     contribute or receive: its x2s rows are only ever read by its own (absent) edges */                           \
+  if (beg >= end) return;                                                                                              \
   const T* sh = static_cast<const T*>(a.sh);                                                                           \
   const T* w0g = static_cast<const T*>(a.w0) + lane;                                                                   \
   int staged_cb = -1;
