@@ -151,63 +151,156 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
   }
 }
 
+// phase 1 of edge_backward for 8 Bessel functions and COLS = S0/8 columns per lane.  8 lanes share an edge; each keeps
+// its COLS x 8 slice of the basis weights in REGISTERS for the whole block (no LDS reads in the inner product), the
+// row pieces of 4 passes are requested before the first is used, and the 8 partial sums per lane are combined over
+// the 8 lanes with a DPP reduce-scatter (7 exchanges; fp64: shuffles) that leaves lane `sub` with Bessel index `sub`.
+template <typename T, int COLS>
+__device__ __forceinline__ void edge_bwd_phase1_b8(const EdgeBwdArgs& b, int64_t e0, int tid, const int* sTy, const T* sEmb, T* sT) {
+  const EdgeGeomArgs& a = b.g;
+  constexpr int S0 = COLS * 8, half = S0 / 2, B = 8;
+  const int sub = tid & 7;
+  T w[COLS][B];
+  {
+    const T* wb = static_cast<const T*>(a.basis_w);  // [B][S0]
+#pragma unroll
+    for (int cc = 0; cc < COLS; ++cc)
+#pragma unroll
+      for (int nb = 0; nb < B; ++nb) w[cc][nb] = wb[nb * S0 + sub * COLS + cc];
+  }
+#pragma unroll
+  for (int pb = 0; pb < 8; pb += 4) {
+    T g[4][COLS];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int le = (pb + ps) * 32 + (tid >> 3);
+      const int64_t e = e0 + le < a.E ? e0 + le : a.E - 1;
+      const T* gp = static_cast<const T*>(b.g_emb0) + e * S0 + sub * COLS;
+#pragma unroll
+      for (int cc = 0; cc < COLS; ++cc) g[ps][cc] = gp[cc];
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int le = (pb + ps) * 32 + (tid >> 3);
+      const int ty = sTy[le];  // ti | tj << 16, or -1 beyond the edge list
+      const int tyc = ty >= 0 ? ty : 0;
+      // columns [sub*COLS, +COLS) lie entirely in the center half (sub < 4) or the neighbor half of the embedding
+      const T* te = sub < 4 ? sEmb + (tyc & 0xffff) * half + sub * COLS : sEmb + a.num_types * half + (tyc >> 16) * half + (sub - 4) * COLS;
+      T part[B];
+#pragma unroll
+      for (int nb = 0; nb < B; ++nb) part[nb] = T(0);
+#pragma unroll
+      for (int cc = 0; cc < COLS; ++cc) {
+        const T gv = ty >= 0 ? g[ps][cc] * te[cc] : T(0);
+#pragma unroll
+        for (int nb = 0; nb < B; ++nb) part[nb] += gv * w[cc][nb];
+      }
+      T r;
+      if constexpr (sizeof(T) == 4) {
+        float y[4], z[2];
+        {
+          const bool hi = sub & 4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float send = hi ? part[k] : part[k + 4], keep = hi ? part[k + 4] : part[k];
+            y[k] = keep + dpp_move<kDppHalfMirror>(send);
+          }
+        }
+        {
+          const bool hi = sub & 2;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float send = hi ? y[k] : y[k + 2], keep = hi ? y[k + 2] : y[k];
+            z[k] = keep + dpp_move<kDppQuad2301>(send);
+          }
+        }
+        {
+          const bool hi = sub & 1;
+          const float send = hi ? z[0] : z[1], keep = hi ? z[1] : z[0];
+          r = keep + dpp_move<kDppQuad1032>(send);
+        }
+      } else {
+        T y[4], z[2];
+        {
+          const bool hi = sub & 4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const T recv = __shfl_xor(hi ? part[k] : part[k + 4], 4);
+            y[k] = (hi ? part[k + 4] : part[k]) + recv;
+          }
+        }
+        {
+          const bool hi = sub & 2;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const T recv = __shfl_xor(hi ? y[k] : y[k + 2], 2);
+            z[k] = (hi ? y[k + 2] : y[k]) + recv;
+          }
+        }
+        {
+          const bool hi = sub & 1;
+          const T recv = __shfl_xor(hi ? z[0] : z[1], 1);
+          r = (hi ? z[1] : z[0]) + recv;
+        }
+      }
+      sT[le * (B + 1) + sub] = r;  // lane `sub` ends up with Bessel index sub = 4*bit2 + 2*bit1 + bit0
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
   const EdgeGeomArgs& a = b.g;
   const int B = a.num_bessels, S0 = a.S0, D = (a.l_max + 1) * (a.l_max + 1), Tn = a.num_types;
-  T* sT = reinterpret_cast<T*>(aa_smem);  // [256][B+1]  dE/d(bessel_n * cutoff)
-  T* sWb = sT + 256 * (B + 1);            // [B][S0]
+  T* sT = reinterpret_cast<T*>(aa_smem);          // [256][B+1]  dE/d(bessel_n * cutoff)
+  T* sWb = sT + 256 * (B + 1);                    // [B][S0] (general path only)
+  T* sEmb = sWb + size_t(S0) * kMaxBessel;        // [2][Tn][S0/2] center / neighbor type embeddings
+  int* sTy = reinterpret_cast<int*>(sEmb + size_t(Tn) * S0);  // [256] ti | tj << 16
   const int tid = threadIdx.x;
   const int64_t e0 = int64_t(blockIdx.x) * 256;
   const int half = S0 / 2;
   const T* cemb = static_cast<const T*>(a.center_embed);
   const T* nemb = static_cast<const T*>(a.neighbor_embed);
-  for (int idx = tid; idx < B * S0; idx += 256) sWb[idx] = static_cast<const T*>(a.basis_w)[idx];
+  const bool fast = (S0 == 16 || S0 == 32 || S0 == 64) && B == 8 && Tn < 32768;
+  // this lane's own edge (used again in phase 2)
+  const int64_t e = e0 + tid;
+  int ci = -1, cj = -1, ti = 0, tj = 0;  // ci: center of this lane's edge (-1: no edge)
+  if (e < a.E) {
+    ci = a.center[e];
+    cj = a.nbr[e];
+    ti = a.types[ci];
+    tj = a.types[cj];
+  }
+  if (fast) {
+    for (int idx = tid; idx < Tn * half; idx += 256) {
+      sEmb[idx] = cemb[idx];
+      sEmb[Tn * half + idx] = nemb[idx];
+    }
+    sTy[tid] = ci >= 0 ? (ti | (tj << 16)) : -1;
+  } else {
+    for (int idx = tid; idx < B * S0; idx += 256) sWb[idx] = static_cast<const T*>(a.basis_w)[idx];
+  }
   __syncthreads();
   // phase 1: t[le][n] = sum_c g_emb0[e][c] * type_embed[c] * Wb[n][c]
-  if ((S0 & 7) == 0 && B <= kMaxBessel) {
+  if (fast) {
     // 8 lanes per edge, each owning S0/8 consecutive columns: a wave reads 8 whole rows per pass (coalesced);
     // the B partial sums are then combined across the 8 lanes
-    const int cols = S0 >> 3, sub = tid & 7;
-    for (int base = 0; base < 256; base += 32) {
-      const int le = base + (tid >> 3);
-      const int64_t e = e0 + le;
-      T part[kMaxBessel];
-#pragma unroll
-      for (int nb = 0; nb < kMaxBessel; ++nb) part[nb] = T(0);
-      if (e < a.E) {
-        const int ti = a.types[a.center[e]], tj = a.types[a.nbr[e]];
-        const T* g = static_cast<const T*>(b.g_emb0) + e * S0 + sub * cols;
-        for (int cc = 0; cc < cols; ++cc) {
-          const int c = sub * cols + cc;
-          const T te = c < half ? cemb[ti * half + c] : nemb[tj * half + (c - half)];
-          const T gv = g[cc] * te;
-#pragma unroll
-          for (int nb = 0; nb < kMaxBessel; ++nb)
-            if (nb < B) part[nb] += gv * sWb[nb * S0 + c];
-        }
-      }
-#pragma unroll
-      for (int nb = 0; nb < kMaxBessel; ++nb) {
-        if (nb < B) {
-          T v = part[nb];
-          v += __shfl_xor(v, 1);
-          v += __shfl_xor(v, 2);
-          v += __shfl_xor(v, 4);
-          if (sub == (nb & 7)) sT[le * (B + 1) + nb] = v;
-        }
-      }
-    }
+    if (S0 == 64)
+      edge_bwd_phase1_b8<T, 8>(b, e0, tid, sTy, sEmb, sT);
+    else if (S0 == 32)
+      edge_bwd_phase1_b8<T, 4>(b, e0, tid, sTy, sEmb, sT);
+    else
+      edge_bwd_phase1_b8<T, 2>(b, e0, tid, sTy, sEmb, sT);
   } else {
     for (int idx = tid; idx < 256 * B; idx += 256) {
       int le = idx / B, nb = idx % B;
-      int64_t e = e0 + le;
+      int64_t el = e0 + le;
       T acc = T(0);
-      if (e < a.E) {
-        int ti = a.types[a.center[e]], tj = a.types[a.nbr[e]];
-        const T* g = static_cast<const T*>(b.g_emb0) + e * S0;
+      if (el < a.E) {
+        int t_i = a.types[a.center[el]], t_j = a.types[a.nbr[el]];
+        const T* g = static_cast<const T*>(b.g_emb0) + el * S0;
         for (int c = 0; c < S0; ++c) {
-          T te = c < half ? cemb[ti * half + c] : nemb[tj * half + (c - half)];
+          T te = c < half ? cemb[t_i * half + c] : nemb[t_j * half + (c - half)];
           acc += g[c] * te * sWb[nb * S0 + c];
         }
       }
@@ -216,15 +309,11 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
   }
   __syncthreads();
   // phase 2: per edge chain rule to the edge vector, then scatter to both atoms
-  int64_t e = e0 + tid;
-  int ci = -1;  // center of this lane's edge (-1: no edge)
   T fx = T(0), fy = T(0), fz = T(0);
   if (e < a.E) {
-    int i = a.center[e], j = a.nbr[e];
-    ci = i;
+    const int j = cj;
     const T* vec = static_cast<const T*>(a.vec) + 4 * e;
     T nx = vec[0], ny = vec[1], nz = vec[2], r = vec[3];
-    int ti = a.types[i], tj = a.types[j];
     T recip = static_cast<const T*>(a.rmax_recip)[ti * Tn + tj];
     T x = r * recip;
     T f, df;
@@ -342,7 +431,8 @@ int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_edge_backward(const EdgeBwdArgs& b, hipStream_t stream) {
   if (b.g.E == 0) return AA_OK;
-  size_t smem = sizeof(T) * (256 * size_t(b.g.num_bessels + 1) + size_t(b.g.num_bessels) * b.g.S0);
+  size_t smem = sizeof(T) * (256 * size_t(b.g.num_bessels + 1) + size_t(kMaxBessel) * b.g.S0 + size_t(b.g.num_types) * b.g.S0) + sizeof(int) * 256;
+  if (smem > 64 * 1024) return fail(AA_ERR_INVALID, "edge_backward: too many types / embedding columns for the LDS tables");
   hipLaunchKernelGGL(edge_backward_kernel<T>, dim3((unsigned)((b.g.E + 255) / 256)), dim3(256), smem, stream, b);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
