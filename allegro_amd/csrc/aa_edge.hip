@@ -140,6 +140,27 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
   const int half = S0 / 2;
   const T* cemb = static_cast<const T*>(a.center_embed);
   const T* nemb = static_cast<const T*>(a.neighbor_embed);
+  if (S0 == 64 && B <= kMaxBessel) {
+    // a wave writes one 256-B row per iteration; the lane's column is fixed, so its basis weights live in registers
+    const int c = tid & 63;
+    T wreg[kMaxBessel];
+#pragma unroll
+    for (int nb = 0; nb < kMaxBessel; ++nb) wreg[nb] = nb < B ? sWb[nb * S0 + c] : T(0);
+    const T* tab = c < half ? cemb + c : nemb + (c - half);
+    const int tsel = c < half ? 0 : 1;
+#pragma unroll 4
+    for (int le = tid >> 6; le < 256; le += 4) {
+      const int64_t e = e0 + le;
+      if (e >= a.E) break;
+      T basis = T(0);
+#pragma unroll
+      for (int nb = 0; nb < kMaxBessel; ++nb)
+        if (nb < B) basis += sB[le * (B + 1) + nb] * wreg[nb];
+      const T te = tab[sTy[2 * le + tsel] * half];
+      static_cast<T*>(a.emb0)[e * S0 + c] = te * basis;
+    }
+    return;
+  }
   for (int idx = tid; idx < 256 * S0; idx += 256) {
     int le = idx / S0, c = idx % S0;
     int64_t e = e0 + le;
@@ -151,10 +172,6 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
   }
 }
 
-// phase 1 of edge_backward for 8 Bessel functions and COLS = S0/8 columns per lane.  8 lanes share an edge; each keeps
-// its COLS x 8 slice of the basis weights in REGISTERS for the whole block (no LDS reads in the inner product), the
-// row pieces of 4 passes are requested before the first is used, and the 8 partial sums per lane are combined over
-// the 8 lanes with a DPP reduce-scatter (7 exchanges; fp64: shuffles) that leaves lane `sub` with Bessel index `sub`.
 template <typename T, int COLS>
 __device__ __forceinline__ void edge_bwd_phase1_b8(const EdgeBwdArgs& b, int64_t e0, int tid, const int* sTy, const T* sEmb, T* sT) {
   const EdgeGeomArgs& a = b.g;
