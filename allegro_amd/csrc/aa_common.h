@@ -57,6 +57,26 @@ __device__ __forceinline__ void permlane16_swap(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 #endif
+// four independent swaps in one block (one pair of hazard nops for all of them)
+#ifdef AA_EMU_LANE_OPS
+__device__ __forceinline__ void permlane32_swap4(float* a, float* b) {
+  for (int i = 0; i < 4; ++i) aa_emu_permlane_swap(a[i], b[i], 32);
+}
+__device__ __forceinline__ void permlane16_swap4(float* a, float* b) {
+  for (int i = 0; i < 4; ++i) aa_emu_permlane_swap(a[i], b[i], 16);
+}
+#else
+__device__ __forceinline__ void permlane32_swap4(float* a, float* b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
+      "v_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+__device__ __forceinline__ void permlane16_swap4(float* a, float* b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\t"
+      "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+#endif
 // DPP lane pattern applied to v (fused by the compiler into the consuming VALU op)
 constexpr int kDppRowRor8 = 0x128, kDppRowRor4 = 0x124, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
 template <int CTRL>

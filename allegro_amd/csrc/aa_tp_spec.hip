@@ -142,6 +142,71 @@ __device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, boo
   }
 }
 
+// Two independent D-value sums (the two edges of a pair) in one pass: the butterflies are interleaved so that each
+// one's dependent exchange -> add chain hides the other's latency, and the permlane swaps are issued four to a block.
+template <typename T, int D>
+__device__ __forceinline__ void wave_sum_store2(const T* va, const T* vb, T* dsta, T* dstb, bool acta, bool actb) {
+  static_assert(D <= 16, "at most 16 values");
+  if constexpr (sizeof(T) != 4) {
+    wave_sum_store<T, D>(va, dsta, acta, false);
+    wave_sum_store<T, D>(vb, dstb, actb, false);
+  } else {
+    const int lane = threadIdx.x & 63;
+    float xa[16], xb[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      xa[k] = k < D ? va[k] : 0.f;
+      xb[k] = k < D ? vb[k] : 0.f;
+    }
+    float ya[8], yb[8], za[4], zb[4], qa[2], qb[2];
+    // bit 5: {x[k], x[k+8]} -> y[k]
+    permlane32_swap4(xa, xa + 8);
+    permlane32_swap4(xb, xb + 8);
+    permlane32_swap4(xa + 4, xa + 12);
+    permlane32_swap4(xb + 4, xb + 12);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ya[k] = xa[k] + xa[k + 8];
+      yb[k] = xb[k] + xb[k + 8];
+    }
+    // bit 4
+    permlane16_swap4(ya, ya + 4);
+    permlane16_swap4(yb, yb + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      za[k] = ya[k] + ya[k + 4];
+      zb[k] = yb[k] + yb[k + 4];
+    }
+    {
+      const bool hi = lane & 8;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float sa = hi ? za[k] : za[k + 2], ka_ = hi ? za[k + 2] : za[k];
+        const float sb = hi ? zb[k] : zb[k + 2], kb_ = hi ? zb[k + 2] : zb[k];
+        qa[k] = ka_ + dpp_move<kDppRowRor8>(sa);
+        qb[k] = kb_ + dpp_move<kDppRowRor8>(sb);
+      }
+    }
+    float ra, rb;
+    {
+      const bool hi = lane & 4;
+      const float sa = hi ? qa[0] : qa[1], ka_ = hi ? qa[1] : qa[0];
+      const float sb = hi ? qb[0] : qb[1], kb_ = hi ? qb[1] : qb[0];
+      ra = ka_ + dpp_move<kDppHalfMirror>(sa);
+      rb = kb_ + dpp_move<kDppHalfMirror>(sb);
+    }
+    ra += dpp_move<kDppQuad1032>(ra);
+    rb += dpp_move<kDppQuad1032>(rb);
+    ra += dpp_move<kDppQuad2301>(ra);
+    rb += dpp_move<kDppQuad2301>(rb);
+    const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    if ((lane & 3) == 0 && idx < D) {
+      if (acta) dsta[idx] = ra;
+      if (actb) dstb[idx] = rb;
+    }
+  }
+}
+
 // wave-uniform value -> SGPR (so that addresses derived from it use the scalar memory path)
 __device__ __forceinline__ int uniform_if(bool uni, int v) { return uni ? __builtin_amdgcn_readfirstlane(v) : v; }
 
@@ -935,12 +1000,11 @@ __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const
           }
           g_a[int64_t(s) * ld_ga + lane] = d0[0];
           if (two) g_a[int64_t(s) * ld_ga + 64 + lane] = d1[0];
-          wave_sum_store<T, D>(ga, gsh + int64_t(s) * ld_gsh, true, false);
           if (vb) {
             g_a[int64_t(s + 1) * ld_ga + lane] = d0[1];
             if (two) g_a[int64_t(s + 1) * ld_ga + 64 + lane] = d1[1];
-            wave_sum_store<T, D>(gb, gsh + int64_t(s + 1) * ld_gsh, true, false);
           }
+          wave_sum_store2<T, D>(ga, gb, gsh + int64_t(s) * ld_gsh, gsh + int64_t(s + (vb ? 1 : 0)) * ld_gsh, true, vb);
         }
       }
 #pragma unroll

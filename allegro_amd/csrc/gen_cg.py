@@ -76,6 +76,35 @@ def emit_fn(name, a_name, b_name, out_name, n_out, entries):
     return "\n".join(lines)
 
 
+def emit_bx12(nz, d1, d2):
+    """Fused reverse of both operands: g1[i] = sum w[p] c go[k] x2[j] and g2[j] = sum w[p] c go[k] x1[i] share the
+    factor t = c * (w[p] * go[k]) of every non-zero: 3 multiply-adds per non-zero instead of 4 (+ one product per
+    (k, p) pair).  go / x1 / g1 / g2 may be 2-vectors (packed two-edge evaluation), x2 and w are per-lane scalars."""
+    lines = ["  template <typename TG, typename TX2, typename TW> static __device__ __forceinline__ void "
+             "bx12(const TG* __restrict__ go, const TG* __restrict__ x1, const TX2* __restrict__ x2, "
+             "const TW* __restrict__ w, TG* __restrict__ g1, TG* __restrict__ g2) {"]
+    seen1, seen2 = set(), set()
+    groups = {}
+    for (i, j, k, p, v) in nz:
+        groups.setdefault((k, p), []).append((i, j, v))
+    for (k, p) in sorted(groups):
+        lines.append(f"    {{ const TG gw = go[{k}] * w[{p}];")
+        for (i, j, v) in sorted(groups[(k, p)]):
+            lines.append(f"      {{ const TG t = gw * TW({v!r}); g1[{i}] {'+=' if i in seen1 else '='} t * x2[{j}]; "
+                         f"g2[{j}] {'+=' if j in seen2 else '='} t * x1[{i}]; }}")
+            seen1.add(i)
+            seen2.add(j)
+        lines.append("    }")
+    for i in range(d1):
+        if i not in seen1:
+            lines.append(f"    g1[{i}] = TG(0);")
+    for j in range(d2):
+        if j not in seen2:
+            lines.append(f"    g2[{j}] = TG(0);")
+    lines.append("  }")
+    return "\n".join(lines)
+
+
 def main(out_path=None):
     out_path = out_path or os.path.join(HERE, "aa_cg_gen.h")
     sigs = signatures()
@@ -92,6 +121,7 @@ def main(out_path=None):
         o.append(emit_fn("fwd", "x1", "x2", "out", dout, [(k, p, i, j, v) for (i, j, k, p, v) in nz]))
         o.append(emit_fn("bx1", "go", "x2", "g1", d1, [(i, p, k, j, v) for (i, j, k, p, v) in nz]))
         o.append(emit_fn("bx2", "go", "x1", "g2", d2, [(j, p, k, i, v) for (i, j, k, p, v) in nz]))
+        o.append(emit_bx12(nz, d1, d2))
         o.append("};")
         o.append(f"static const int sig{n}_nz[][4] = {{" + ", ".join(f"{{{i},{j},{k},{p}}}" for (i, j, k, p, v) in nz) + "};")
         o.append(f"static const double sig{n}_val[] = {{" + ", ".join(repr(v) for (i, j, k, p, v) in nz) + "};")
