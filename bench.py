@@ -73,6 +73,38 @@ def make_workload(name):
     return g, cfg
 
 
+def step_roofline(cfg, E, t_step, stages, dtype):
+    """Whole-step figures of SURVEY.md section 8(d).  (1) fully-fused compute bound: algorithmic forward+force flops
+    per edge (GEMM part on the fp32/fp64 MFMA peak, CG/SH/segment-sum part on the vector peak); (2) the HBM time of
+    THIS stage-materialised design: sum of the algorithmic bytes of all launches at 8 TB/s."""
+    S, u, L, l_max = cfg["num_scalar_features"], cfg["num_tensor_features"], cfg["num_layers"], cfg["l_max"]
+    B = cfg["radial_chemical_embed"].get("num_bessels", 8)
+    S0 = cfg.get("radial_chemical_embed_dim", S)
+    Hs = cfg.get("scalar_embed_mlp_hidden_layers_width", S)
+    Ha = cfg.get("allegro_mlp_hidden_layers_width", S)
+    Hr = cfg.get("readout_mlp_hidden_layers_width", S)
+    R, D = l_max + 1, (l_max + 1) ** 2
+    W = R * u
+    fg = B * S0 + S0 * Hs + Hs * S + S * W + S * (S + W) + S * (L + 1) * Hr + Hr
+    for l in range(L):
+        fg += (S * (l + 1) + u) * Ha + Ha * (S + (W if l < L - 1 else 0))
+    fg *= 2.0
+    from allegro_amd.nn import allegro_layer_irreps, build_w3j
+    from allegro_amd import o3
+    t = allegro_layer_irreps(l_max, True, L)
+    env = o3.Irreps.spherical_harmonics(l_max)
+    nnz = [int(np.count_nonzero(build_w3j(t[l], env, t[l + 1])[0])) for l in range(L)]
+    tp = sum(3.0 * n * u for n in nnz)
+    rest = (L + 1) * u * D + 2 * L * u * D + 5 * D
+    f_mfma, f_valu = 2.0 * fg, 3.0 * tp + 2.0 * rest
+    pk_m, pk_v = (PEAK_F32_TFLOPS, PEAK_F32_TFLOPS) if dtype == "float32" else (PEAK_F64_TFLOPS, PEAK_F64_TFLOPS)
+    t_roof = E * (f_mfma / (pk_m * 1e12) + f_valu / (pk_v * 1e12))
+    t_hbm = sum(nb for _, _, nb, _ in stages) / (PEAK_HBM_GBS * 1e9)
+    return dict(flop_per_edge=f_mfma + f_valu, t_roof_fused_compute_ms=t_roof * 1e3, frac_of_fused_compute_roof=t_roof / t_step,
+                algorithmic_bytes_per_edge=sum(nb for _, _, nb, _ in stages) / E, t_hbm_this_design_ms=t_hbm * 1e3,
+                frac_of_hbm_roof_this_design=t_hbm / t_step)
+
+
 def gemm_sequence_flops(stage_names, E):
     """flops of every 'gemm_KxN' stage: 2*E*K*N."""
     out = []
@@ -312,6 +344,7 @@ def main():
             stages = profile_stages(model, pos, graph)
             roof, table = roofline_from_stages(stages, cfg["model_dtype"])
             line["roofline"] = roof
+            line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])
             line["stage_ms"] = table
             if args.stages:
                 for nm, ms, nb, fl in stages:
