@@ -1075,7 +1075,7 @@ struct PairIn {
 #define AA_MOM_PROLOGUE(DVAL)                                                                                          \
   const TpChainArgs& a = ma.c;                                                                                         \
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;                                                            \
-  const int64_t atom = int64_t(blockIdx.x) * 4 + wv;                                                                   \
+  const int64_t atom = int64_t(blockIdx.x) * (blockDim.x >> 6) + wv;                                                   \
   const int ka_lds = ma.ka_lds;                                                                                        \
   T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * (DVAL) * (ka_lds + 64 + kSegCap);                               \
   T* sG = sM + (DVAL) * ka_lds;                                                                                        \
@@ -1467,11 +1467,14 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
     if (a.c.N == 0) return AA_OK;                                                                        \
     if (a.c.u != 64 || a.ka0 > kMaxKa || a.ka1 > kMaxKa || (a.ka0 & 63) || (a.ka1 & 63))                \
       return fail(AA_ERR_INVALID, #NAME ": needs u == 64 and env-input widths of 64 or 128");            \
-    dim3 grid((unsigned)((a.c.N + 3) / 4));                                                              \
+    /* one wave per atom and no inter-wave cooperation: single-wave workgroups give the dispatcher the finest    \
+       granularity (shorter tail on small boxes / per-rank shards) */                                            \
+    static const int wpb = getenv("AA_MOM_WPB") ? std::max(1, std::min(4, atoi(getenv("AA_MOM_WPB")))) : 1;     \
+    dim3 grid((unsigned)((a.c.N + wpb - 1) / wpb));                                                      \
     const int dpair = pair == 0 ? 4 : (pair == 1 ? 9 : 16);                                              \
     TpMomArgs b = a;                                                                                     \
     b.ka_lds = a.ka0 > a.ka1 ? a.ka0 : a.ka1;                                                            \
-    size_t smem = sizeof(T) * 4 * dpair * (b.ka_lds + 64 + kSegCap);                                     \
+    size_t smem = sizeof(T) * wpb * dpair * (b.ka_lds + 64 + kSegCap);                                   \
     if (smem > 160 * 1024) return fail(AA_ERR_INVALID, #NAME ": LDS patch too large for this dtype/l_max"); \
     if (smem > 64 * 1024) {                                                                              \
       const void* fn = pair == 0 ? (const void*)NAME##_kernel<K1, T>                                     \
@@ -1479,9 +1482,9 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
       AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));      \
     }                                                                                                    \
     switch (pair) {                                                                                      \
-      case 0: hipLaunchKernelGGL((NAME##_kernel<K1, T>), grid, dim3(256), smem, stream, b); break;       \
-      case 1: hipLaunchKernelGGL((NAME##_kernel<K2, T>), grid, dim3(256), smem, stream, b); break;       \
-      case 2: hipLaunchKernelGGL((NAME##_kernel<K3, T>), grid, dim3(256), smem, stream, b); break;       \
+      case 0: hipLaunchKernelGGL((NAME##_kernel<K1, T>), grid, dim3(64 * wpb), smem, stream, b); break;       \
+      case 1: hipLaunchKernelGGL((NAME##_kernel<K2, T>), grid, dim3(64 * wpb), smem, stream, b); break;       \
+      case 2: hipLaunchKernelGGL((NAME##_kernel<K3, T>), grid, dim3(64 * wpb), smem, stream, b); break;       \
       default: return fail(AA_ERR_INVALID, #NAME ": unknown chain pair");                                \
     }                                                                                                    \
     AA_CHECK_HIP(hipGetLastError());                                                                     \
