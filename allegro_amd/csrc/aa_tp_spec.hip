@@ -1212,6 +1212,15 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
+  // The last layer contracts to one scalar and layer 0 is linear in x1 for fixed x2s0, so the whole per-edge chain
+  //   scal1[e] = Sig1(Sig0(x1[e], x2s0), x2s1) = sum_a x1[e][a] * B1[a],   B1 = Sig0^T_x1(v, x2s0),  v = dSig1/dtf1 (x2s1)
+  // needs the Clebsch-Gordan contractions once per ATOM (here) instead of once per edge.
+  T B1[Sig0::D1];
+  {
+    T one[1] = {T(1)}, v[Sig1::D1];
+    Sig1::template bx1<T>(one, x2s1, wp1, v);
+    Sig0::template bx1<T>(v, x2s0, wp0, B1);
+  }
   auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
     const int sb = s + 1 < end ? s + 1 : s;
     const T* ya = sh + int64_t(s) * a.ld_sh;
@@ -1229,11 +1238,11 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
     T* sc = static_cast<T*>(a.scal1) + lane;
     for (int s = beg; s < end; s += 2) {
       fetch(s + 2 < end ? s + 2 : s, nxt);
-      T2 x1[Sig0::D1], tf1[Sig0::DOUT], out[1];
+      // scal1[e] = <x1[e], B1>: both layers are linear in x1 once the per-atom vectors are fixed (see B1 above)
+      T2 out[1];
+      out[0] = T2{T(0), T(0)};
 #pragma unroll
-      for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
-      Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
-      Sig1::template fwd4<T2, T2, T, T>(tf1, x2s1, wp1, out);
+      for (int i = 0; i < Sig0::D1; ++i) out[0] += (cur.y[i] * cur.wa[r_of<0>(i)]) * B1[i];
       sc[int64_t(s) * a.ld_scal] = out[0][0];
       if (s + 1 < end) sc[int64_t(s + 1) * a.ld_scal] = out[0][1];
       cur = nxt;
@@ -1242,7 +1251,7 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
 }
 
 template <class Sig0, class Sig1, typename T>
-__global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 3 : 1) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
   AA_MOM_PROLOGUE(D)
@@ -1265,6 +1274,9 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
+  T2 Q1[Sig0::D1];
+#pragma unroll
+  for (int i = 0; i < Sig0::D1; ++i) Q1[i] = T2{T(0), T(0)};
   auto fetch = [&](int s, int ce, PairIn<T, R>& in) {
     const int sa = s < ce ? s : ce - 1, sb = s + 1 < ce ? s + 1 : ce - 1;
     const T* wa = w0g + int64_t(sa) * a.ld_w0;
@@ -1275,15 +1287,18 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
     in.g1 = T2{ga, s + 1 < ce ? gb : T(0)};  // a padded second edge contributes nothing
   };
   mom_pair_loop<T, D, R, 2>(sh, a.ld_sh, beg, end, lane, sY, staged_cb, fetch, [&](int s, bool vb, const T2* y, const PairIn<T, R>& cur) {
-    T2 x1[Sig0::D1], tf1[Sig0::DOUT], go[1], g2[D];
+    // d x2s1 = Sig1^T_x2(1, sum_e g[e] * tf1[e]) and sum_e g[e] * tf1[e] = Sig0(sum_e g[e] * x1[e], x2s0): only the
+    // g-weighted moment of x1 is accumulated per edge; the contractions run once per atom after the loop
 #pragma unroll
-    for (int i = 0; i < Sig0::D1; ++i) x1[i] = y[i] * cur.wa[r_of<0>(i)];
-    Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
-    go[0] = cur.g1;
-    Sig1::template bx24<T2, T2, T2, T>(go, tf1, wp1, g2);
-#pragma unroll
-    for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
+    for (int i = 0; i < Sig0::D1; ++i) Q1[i] += cur.g1 * (y[i] * cur.wa[r_of<0>(i)]);
   });
+  {
+    T q[Sig0::D1], tq[Sig0::DOUT], one[1] = {T(1)};
+#pragma unroll
+    for (int i = 0; i < Sig0::D1; ++i) q[i] = Q1[i][0] + Q1[i][1];
+    Sig0::template fwd<T>(q, x2s0, wp0, tq);
+    Sig1::template bx2<T>(one, tq, wp1, g2acc);
+  }
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
@@ -1293,7 +1308,7 @@ __global__ __launch_bounds__(256) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
 }
 
 template <class Sig0, class Sig1, typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 3 : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
   AA_MOM_PROLOGUE(D)
@@ -1320,6 +1335,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
 #pragma unroll
     for (int p = 0; p < Sig1::P; ++p) wp1[p] = a.coupling ? W1[lane * Sig1::P + p] : W1[p];
   }
+  // per-atom vectors (see the loop body)
+  T vv[DOUT], B1[D1], B0[D1];
+  {
+    T one[1] = {T(1)}, e0[DOUT];
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) e0[k] = k == 0 ? T(1) : T(0);
+    Sig1::template bx1<T>(one, x2s1, wp1, vv);
+    Sig0::template bx1<T>(vv, x2s0, wp0, B1);
+    Sig0::template bx1<T>(e0, x2s0, wp0, B0);
+  }
+  T2 Q1[D1], Q0[D1];
+#pragma unroll
+  for (int i = 0; i < D1; ++i) {
+    Q1[i] = T2{T(0), T(0)};
+    Q0[i] = T2{T(0), T(0)};
+  }
   auto fetch = [&](int s, int ce, PairIn<T, R>& in) {
     const int sa = s < ce ? s : ce - 1, sb = s + 1 < ce ? s + 1 : ce - 1;
     const T* wa = w0g + int64_t(sa) * a.ld_w0;
@@ -1335,38 +1366,45 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
   T* gw0 = static_cast<T*>(a.g_w0) + lane;
   T* gsx = static_cast<T*>(a.gsh_x1);
   mom_pair_loop<T, D, R, 1>(sh, a.ld_sh, beg, end, lane, sY, staged_cb, fetch, [&](int s, bool vb, const T2* y, const PairIn<T, R>& cur) {
-    T2 x1[D1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) x1[i] = y[i] * cur.wa[r_of<0>(i)];
-    T2 gn[1], go[DOUT];
-    gn[0] = cur.g1;
-    Sig1::template bx14<T2, T2, T, T>(gn, x2s1, wp1, go);  // d_tf1, recomputed (never stored)
-    go[0] += cur.g0;
-    T2 g1[D1], g2[D];
-    Sig0::template bx14<T2, T2, T, T>(go, x2s0, wp0, g1);
-    Sig0::template bx24<T2, T2, T2, T>(go, x1, wp0, g2);
-#pragma unroll
-    for (int j = 0; j < D; ++j) g2acc[j] += g2[j][0] + g2[j][1];
+    // go[e] = g1[e] * v + g0[e] * e_0 (v = dSig1/dtf1), so with the per-atom vectors B1 = Sig0^T_x1(v), B0 = Sig0^T_x1(e_0)
+    //   d x1[e] = g1[e] * B1 + g0[e] * B0      and      d x2s0 = Sig0^T_x2(v, sum_e g1 x1) + Sig0^T_x2(e_0, sum_e g0 x1)
     T2 gw[R];
     T gya[D1], gyb[D1];
 #pragma unroll
     for (int r = 0; r < R; ++r) gw[r] = T2{T(0), T(0)};
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
-      gw[r_of<0>(i)] += g1[i] * y[i];
-      const T2 t = g1[i] * cur.wa[r_of<0>(i)];
+      const T2 x1 = y[i] * cur.wa[r_of<0>(i)];
+      Q1[i] += cur.g1 * x1;
+      Q0[i] += cur.g0 * x1;
+      const T2 gx = cur.g1 * B1[i] + cur.g0 * B0[i];
+      gw[r_of<0>(i)] += gx * y[i];
+      const T2 t = gx * cur.wa[r_of<0>(i)];
       gya[i] = t[0];
       gyb[i] = t[1];
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * 64] = gw[r][0];
-    wave_sum_store<T, D1>(gya, gsx + int64_t(s) * a.ld_gsh, true, false);
     if (vb) {
 #pragma unroll
       for (int r = 0; r < R; ++r) gw0[int64_t(s + 1) * a.ld_gw0 + r * 64] = gw[r][1];
-      wave_sum_store<T, D1>(gyb, gsx + int64_t(s + 1) * a.ld_gsh, true, false);
     }
+    wave_sum_store2<T, D1>(gya, gyb, gsx + int64_t(s) * a.ld_gsh, gsx + int64_t(s + (vb ? 1 : 0)) * a.ld_gsh, true, vb);
   });
+  {
+    T q1[D1], q0[D1], ga[D], gb[D], e0[DOUT];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+      q1[i] = Q1[i][0] + Q1[i][1];
+      q0[i] = Q0[i][0] + Q0[i][1];
+    }
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) e0[k] = k == 0 ? T(1) : T(0);
+    Sig0::template bx2<T>(vv, q1, wp0, ga);
+    Sig0::template bx2<T>(e0, q0, wp0, gb);
+#pragma unroll
+    for (int j = 0; j < D; ++j) g2acc[j] = ga[j] + gb[j];
+  }
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
