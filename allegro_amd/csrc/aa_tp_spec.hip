@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 3 : 1) v
 }
 
 template <class Sig0, class Sig1, typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 3 : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
   AA_MOM_PROLOGUE(D)
