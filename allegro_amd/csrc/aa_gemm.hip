@@ -801,7 +801,11 @@ struct ChainDev {
 // boundaries; rows beyond M are clamped for loads and masked for stores.
 constexpr int kWStep = 2 * 6 * 64;  // u32x4 per staged step
 
-__global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
+// PRE: layers with at most two k chunks and more than two output tiles (a chained 64-wide operand feeding a wide
+// layer) split their operand once and reuse it for every tile pair; that costs 48 VGPRs, so the variant without
+// such layers runs at 3 waves/SIMD and the one with them at 2.
+template <bool PRE>
+__global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(ChainDev c) {
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);  // [2][kWStep]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
   };
-  auto streams = [&](const ChainLayerDev& X) { return X.KCg > 0 && !(X.KC <= 2 && X.NT > 2); };
+  auto streams = [&](const ChainLayerDev& X) { return X.KCg > 0 && !(PRE && X.KC <= 2 && X.NT > 2); };
   int step = 0;
   {
     u32x4 r[3];
@@ -974,20 +978,22 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
     const ChainLayerDev& Ln = c.L[last_layer ? li : li + 1];
     const bool next_streams = !last_layer && streams(Ln);
     // few k chunks but several tile pairs: split the operands once, not once per pair
-    const bool pre = KC <= 2 && NT > 2;
-    u32x4 ps1[2][2], ps2[2][2], ps3[2][2];
-    if (pre) {
+    const bool pre = PRE && KC <= 2 && NT > 2;
+    u32x4 ps1[PRE ? 2 : 1][2], ps2[PRE ? 2 : 1][2], ps3[PRE ? 2 : 1][2];
+    if constexpr (PRE) {
+      if (pre) {
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        if (kc < KC) {
-          v4f a[4];
-          if (kc >= KCg) {
-            kept_a(kc == KCg, a);
-          } else {
-            load_a(L, kc, a);
-            finish_a(L, kc, a);
+        for (int kc = 0; kc < 2; ++kc) {
+          if (kc < KC) {
+            v4f a[4];
+            if (kc >= KCg) {
+              kept_a(kc == KCg, a);
+            } else {
+              load_a(L, kc, a);
+              finish_a(L, kc, a);
+            }
+            split3_pack(a, ps1[kc], ps2[kc], ps3[kc]);
           }
-          split3_pack(a, ps1[kc], ps2[kc], ps3[kc]);
         }
       }
     }
@@ -1000,8 +1006,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
         acc0[r] = 0.f;
         acc1[r] = 0.f;
       }
-      const int nkc = pre ? (KC < 2 ? KC : 2) : KC;
-      for (int kc = 0; kc < nkc; ++kc) {
+      for (int kc = 0; kc < KC; ++kc) {
         const bool lastc = kc + 1 >= KC;
         const bool layer_end = lastc && last_pair;
         const bool kernel_end = layer_end && last_layer;
@@ -1009,15 +1014,16 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
         u32x4 r[3];
         stage_load(layer_end && !kernel_end ? Ln : L, (layer_end && !kernel_end) ? 0 : (lastc && !kernel_end ? nt + 2 : nt),
                    (lastc && !kernel_end) ? 0 : (kernel_end ? kc : kc + 1), r);
-        // this step's operand: prefetched rows, the chained accumulators, or the pre-split registers
-        v4f a[4];
+        // this step's operand, split into its three bf16 levels: the prefetched rows or the chained accumulators
+        u32x4 x1[2], x2[2], x3[2];
         if (!pre) {
           if (kc >= KCg) {
+            v4f a[4];
             kept_a(kc == KCg, a);
+            split3_pack(a, x1, x2, x3);
           } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = a0[q];
-            finish_a(L, kc, a);
+            finish_a(L, kc, a0);
+            split3_pack(a0, x1, x2, x3);
           }
         }
         // rows of the next streamed step (next chunk / next pair / next layer), in flight during this step's MFMAs
@@ -1027,7 +1033,7 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
           if (!pre && !lastc && kc + 1 < KCg) {
             tp = L.a[kc + 1];
             tl = L.lda[kc + 1];
-          } else if (!pre && lastc && !last_pair && KCg > 0) {
+          } else if (lastc && !last_pair && KCg > 0 && !pre) {
             tp = L.a[0];
             tl = L.lda[0];
           } else if (layer_end && next_streams) {
@@ -1036,14 +1042,16 @@ __global__ __launch_bounds__(256, 2) void gemm_chain_bf16x3_kernel(ChainDev c) {
           }
           load_rows(tp, tl, a0);
         }
-        if (pre) {
-          if (kc == 0)
-            mma_step(step & 1, ps1[0], ps2[0], ps3[0], acc0, acc1);
-          else
-            mma_step(step & 1, ps1[1], ps2[1], ps3[1], acc0, acc1);
+        if constexpr (PRE) {
+          if (pre) {
+            if (kc == 0)
+              mma_step(step & 1, ps1[0], ps2[0], ps3[0], acc0, acc1);
+            else
+              mma_step(step & 1, ps1[1], ps2[1], ps3[1], acc0, acc1);
+          } else {
+            mma_step(step & 1, x1, x2, x3, acc0, acc1);
+          }
         } else {
-          u32x4 x1[2], x2[2], x3[2];
-          split3_pack(a, x1, x2, x3);
           mma_step(step & 1, x1, x2, x3, acc0, acc1);
         }
         stage_write((step + 1) & 1, r);
@@ -1151,7 +1159,13 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
     }
   }
   dim3 grid((unsigned)((c.M + 127) / 128));
-  hipLaunchKernelGGL(gemm_chain_bf16x3_kernel, grid, dim3(256), sizeof(u32x4) * 2 * kWStep + sizeof(float) * 32 * kChainMaxBlocks, stream, d);
+  bool any_pre = false;
+  for (int li = 0; li < d.nlayers; ++li) any_pre = any_pre || (d.L[li].KC <= 2 && d.L[li].NT > 2);
+  const size_t smem = sizeof(u32x4) * 2 * kWStep + sizeof(float) * 32 * kChainMaxBlocks;
+  if (any_pre)
+    hipLaunchKernelGGL(gemm_chain_bf16x3_kernel<true>, grid, dim3(256), smem, stream, d);
+  else
+    hipLaunchKernelGGL(gemm_chain_bf16x3_kernel<false>, grid, dim3(256), smem, stream, d);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
