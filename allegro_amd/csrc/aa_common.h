@@ -143,7 +143,7 @@ struct GemmArgs {
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 
-// Fused chain of up to 3 linear layers (fp32 via bf16x3): the 64-wide output of layer i stays in the MFMA
+// Fused chain of up to 4 linear layers (fp32 via bf16x3): the 64-wide output of layer i stays in the MFMA
 // accumulators and is consumed as (the trailing 64 inputs of) layer i+1.  Each layer is a GemmArgs (A segments
 // may be empty) plus chaining flags.
 struct ChainLayer {
@@ -159,7 +159,7 @@ struct ChainLayer {
 struct ChainArgs {
   int64_t M;
   int nlayers;
-  ChainLayer L[3];
+  ChainLayer L[4];
   const void* ro_w;      // a_mode 1 extras
   double ro_factor;
   const void* ro_scales; // [T] or nullptr

@@ -790,7 +790,7 @@ struct ChainDev {
   const int32_t* types;
   const int32_t* center;
   int ro_n;  // entries of ro_w used by a_mode-1 layers
-  ChainLayerDev L[3];
+  ChainLayerDev L[4];
 };
 
 // Weights of one step (tile pair x 32-deep chunk: 2 x 6 x 64 fragments of 16 B = 12 KB) are staged through LDS
@@ -1094,7 +1094,9 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
   d.ro_scales = static_cast<const float*>(c.ro_scales);
   d.types = c.types;
   d.center = c.center;
-  if (c.nlayers < 1 || c.nlayers > 3) return fail(AA_ERR_INVALID, "gemm chain: 1..3 layers");
+  if (c.nlayers < 1 || c.nlayers > 4) return fail(AA_ERR_INVALID, "gemm chain: 1..4 layers");
+  bool have_kept = false;
+  static_assert(sizeof(ChainDev) <= 4096, "kernel argument block too large");
   for (int li = 0; li < c.nlayers; ++li) {
     const ChainLayer& L = c.L[li];
     const GemmArgs& g = L.g;
@@ -1140,7 +1142,8 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
     if (ka + (L.use_prev ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
     if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 != g.N))
       return fail(AA_ERR_INVALID, "gemm chain: the kept 64 features must be the last tile pair of the layer");
-    if (L.use_prev && (li == 0 || c.L[li - 1].keep_tile < 0)) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
+    if (L.use_prev && !have_kept) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
+    have_kept = have_kept || L.keep_tile >= 0;  // (kept features stay available until a later layer replaces them)
     D.Wq = static_cast<const u32x4*>(g.Bq);
     D.KCg = nchunk;
     D.KC = nchunk + (L.use_prev ? 2 : 0);

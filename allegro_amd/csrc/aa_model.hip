@@ -107,7 +107,7 @@ struct aa_model_plan {
   std::vector<TpLayerDev> layers;
   std::vector<void*> owned;
   // weight blob layout (element offsets)
-  size_t o_rmax, o_bessel, o_cemb, o_nemb, o_basis, o_g0, o_g0t, o_g0p, o_g0tp, o_g0q, o_g0tq, o_b3a_q, o_b3b_q, o_ro_last, o_scales, o_shifts, n_elems;
+  size_t o_rmax, o_bessel, o_cemb, o_nemb, o_basis, o_g0, o_g0t, o_g0p, o_g0tp, o_g0q, o_g0tq, o_b3a_q, o_b3b_q, o_b3c_q, o_ro_last, o_scales, o_shifts, n_elems;
   size_t o_tpw[AA_MAX_LAYERS];
   MlpLayout embed, readout;          // readout: only the GEMM layers (all but the final ->1 layer)
   MlpLayout latent[AA_MAX_LAYERS];
@@ -239,12 +239,13 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     p->ro_last_dim = rd[rd.size() - 2];
     p->o_ro_last = take(p->ro_last_dim);
   }
-  p->o_b3a_q = p->o_b3b_q = 0;
+  p->o_b3a_q = p->o_b3b_q = p->o_b3c_q = 0;
   if (p->chain_gemm) {
     // merged reverse chain "readout' o latent_{L-1}'" (see Runner::backward): the readout-reverse columns that feed
     // the last latent, and [readout-reverse columns of the earlier features (zero-padded) ; latent-reverse] stacked
     p->o_b3a_q = take(gemm_bf16x3_words(64, S));
-    p->o_b3b_q = take(gemm_bf16x3_words(128, S * L + u));
+    p->o_b3b_q = take(gemm_bf16x3_words(128, S * L));
+    p->o_b3c_q = take(gemm_bf16x3_words(64, u));
   }
   p->o_scales = take(T);
   p->o_shifts = take(T);
@@ -392,14 +393,20 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       const int SL = S * L, SL1 = p->SL1, N2 = SL + c.num_tensor;
       const float* rt = &hf[p->readout.wt[0]];          // [64, SL1]  (transposed first readout layer)
       const float* lt = &hf[p->latent[L - 1].wt[0]];    // [64, N2]   (transposed first layer of the last latent)
-      std::vector<float> a(size_t(64) * S), b(size_t(128) * N2, 0.f);
+      // a: readout-reverse columns feeding the last latent; b: [readout-reverse ; latent-reverse] columns of the
+      // earlier features (d_fcat[:, :SL]); c: latent-reverse columns of the tensor scalars (d_scal)
+      std::vector<float> a(size_t(64) * S), b(size_t(128) * SL), cmat(size_t(64) * c.num_tensor);
       for (int k = 0; k < 64; ++k) {
         for (int n = 0; n < S; ++n) a[size_t(k) * S + n] = rt[size_t(k) * SL1 + SL + n];
-        for (int n = 0; n < SL; ++n) b[size_t(k) * N2 + n] = rt[size_t(k) * SL1 + n];
-        for (int n = 0; n < N2; ++n) b[size_t(64 + k) * N2 + n] = lt[size_t(k) * N2 + n];
+        for (int n = 0; n < SL; ++n) {
+          b[size_t(k) * SL + n] = rt[size_t(k) * SL1 + n];
+          b[size_t(64 + k) * SL + n] = lt[size_t(k) * N2 + n];
+        }
+        for (int n = 0; n < c.num_tensor; ++n) cmat[size_t(k) * c.num_tensor + n] = lt[size_t(k) * N2 + SL + n];
       }
       gemm_pack_bf16x3(a.data(), 64, S, reinterpret_cast<unsigned*>(&hf[p->o_b3a_q]));
-      gemm_pack_bf16x3(b.data(), 128, N2, reinterpret_cast<unsigned*>(&hf[p->o_b3b_q]));
+      gemm_pack_bf16x3(b.data(), 128, SL, reinterpret_cast<unsigned*>(&hf[p->o_b3b_q]));
+      gemm_pack_bf16x3(cmat.data(), 64, c.num_tensor, reinterpret_cast<unsigned*>(&hf[p->o_b3c_q]));
     }
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
   }
@@ -926,12 +933,15 @@ struct Runner {
       // weights [readout' ; latent'] and stores each tile once.
       SegList cn{1, {seg(nullptr, 64, 64)}};
       SegList z1{1, {seg(buf(w.lat_h[L - 1][0]), 64, 64)}};
-      SegList c2{2, {seg(buf(w.g_fcat), SL1, S * L), seg(buf(w.g_scal[L - 1]), u, u)}};
+      SegList c2{1, {seg(buf(w.g_fcat), SL1, S * L)}};
+      SegList c3{1, {seg(buf(w.g_scal[L - 1]), u, u)}};
+      ca.nlayers = 4;
       ca.L[0] = chain_layer(E, in, 0, wt(p->o_b3a_q), 64, S, cn, nullptr, nullptr, nullptr, 0, 0, 0);
       ca.L[0].a_mode = 1;
       ca.L[1] = chain_layer(E, none, 0, wt(p->latent[L - 1].wtq[1]), S, 64, cn, nullptr, &z1, nullptr, 1, 0, 0);
-      ca.L[2] = chain_layer(E, in, 0, wt(p->o_b3b_q), 128, S * L + u, c2, nullptr, nullptr, nullptr, 1, -1, 0);
+      ca.L[2] = chain_layer(E, in, 0, wt(p->o_b3b_q), 128, S * L, c2, nullptr, nullptr, nullptr, 1, -1, 0);
       ca.L[2].a_mode = 1;
+      ca.L[3] = chain_layer(E, none, 0, wt(p->o_b3c_q), 64, u, c3, nullptr, nullptr, nullptr, 1, -1, 0);
       if (int rc = run_chain(ca, "B3")) return rc;
     } else
     // readout
