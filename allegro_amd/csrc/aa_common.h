@@ -349,6 +349,41 @@ struct TpMomArgs {
   int ld_ga;
   int ka_lds;           // row stride of the wave-private moment patch in LDS (set by the launcher: max(ka0, ka1))
 };
+// Per-atom operator form of the tensor-product track for L <= 3 layers, u = 64*m (aa_tp_op.hip)
+struct TpOpArgs {
+  int64_t N, E;
+  const int32_t* rowptr;
+  int u;
+  const void* sh;        // [E, ld_sh]
+  int ld_sh;
+  const void* w0;        // [E][R][u] first-layer x1 weights
+  int ld_w0;
+  int coupling;
+  double sf;             // 1/sqrt(avg_num_neighbors)
+  const void* x2s[3];    // [N][D][u] per layer (written by that layer's forward)
+  const void* tpw[3];    // path weights per layer
+  const void* a;         // env input of the layer being processed [E, ld_a] (silu applied if act)
+  int ld_a, ka, act;
+  const void* wk;        // Wenv as [ka][R][u]
+  const void* wt;        //      and [R][u][ka]
+  void* scal;            // forward: [E, ld_scal]
+  int ld_scal;
+  const void* gscal[3];  // reverse: dE/dscal_m [E, ld_gscal] (m >= layer; all m for layer 0)
+  int ld_gscal;
+  void* q;               // [N][L][D][u] per-atom x1 moments Q_m (written for m = layer, read for m > layer)
+  void* g_w0;            // layer 0 reverse: [E, ld_gw0]
+  int ld_gw0;
+  void* gsh_x1;          // layer 0 reverse: u/64 slots of [E, ld_gsh]
+  void* gsh_env;         // ka/64 slots of [E, ld_gsh]
+  int ld_gsh;
+  void* g_a;             // grad wrt the env input [E, ld_ga]
+  int ld_ga;
+  int ka_lds;
+};
+int find_op_chain(const int* sigs, int num_layers);  // chain id or -1
+template <typename T>
+int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStream_t stream);
+
 template <typename T>
 int launch_tp_mom_fwd_first(int pair, const TpMomArgs& a, hipStream_t stream);
 template <typename T>

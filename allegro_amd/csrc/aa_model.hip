@@ -115,10 +115,11 @@ struct aa_model_plan {
   int spec_sig[AA_MAX_LAYERS];       // generated-signature id per layer, or -1
   bool use_spec;                     // all layers specialised -> channel-minor internal layouts
   int chain_pair;                    // >= 0: 2-layer stack on the chain kernels (no [E,u,D] tensors in HBM)
-  bool env_mom;                      // chain + moments: no [E,R*u] env tensors either (TpMomArgs in aa_common.h)
+  bool env_mom;                      // env weights through per-atom moments: no [E,R*u] env tensors (TpMomArgs / TpOpArgs)
+  int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
   int ng0;                           // output width of the fused first-stage GEMM
-  size_t o_wk[2], o_wt[2];           // Wenv of layer l as [ka][R][u] and [R][u][ka]
+  size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
 };
 
@@ -180,6 +181,24 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
                  (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) &&
                  (cfg->dtype == AA_F32 ? 4 : 8) * 4 * Dsh * (std::max(S, cfg->latent_mlp_width) + 64 + 64) <= 160 * 1024 &&
                  !(nm && nm[0] == '1');
+    // per-atom operator kernels: every standard stack the tuned 2-layer/u=64 kernels above do not cover (and, with
+    // AA_TP_OP=1, those too); they need the channel-minor layouts of the specialised path but none of its kernels,
+    // so fp64 at l_max = 3 is fine here
+    p->tp_op = -1;
+    const char* no_op = getenv("AA_TP_NOOP");
+    const char* force_op = getenv("AA_TP_OP");
+    bool sigs_ok = !(e && e[0] == '1');
+    for (int l = 0; l < L; ++l) sigs_ok = sigs_ok && p->spec_sig[l] >= 0;
+    if (sigs_ok && L >= 2 && L <= 3 && (u % 64) == 0 && u <= 256 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
+        (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) && !(nm && nm[0] == '1') && !(no_op && no_op[0] == '1') &&
+        (!p->env_mom || (force_op && force_op[0] == '1'))) {
+      const int chain = find_op_chain(p->spec_sig, L);
+      if (chain >= 0) {
+        p->tp_op = chain;
+        p->env_mom = true;
+        p->use_spec = true;
+      }
+    }
   }
   // weight blob layout
   size_t o = 0;
@@ -210,7 +229,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     const char* ncg = getenv("AA_GEMM_NOCHAIN");
     const char* f32 = getenv("AA_GEMM_FP32_MFMA");
     const char* vl = getenv("AA_GEMM_VALU");
-    p->chain_gemm = p->env_mom && cfg->dtype == AA_F32 && S == 64 && cfg->embed_mlp_depth == 1 &&
+    p->chain_gemm = p->env_mom && p->tp_op < 0 && cfg->dtype == AA_F32 && S == 64 && cfg->embed_mlp_depth == 1 &&
                     cfg->embed_mlp_width == 64 && cfg->latent_mlp_depth == 1 && cfg->latent_mlp_width == 64 &&
                     cfg->readout_mlp_depth == 1 && cfg->readout_mlp_width == 64 && cfg->embed_dim % 32 == 0 &&
                     !(ncg && ncg[0] == '1') && !(f32 && f32[0] == '1') && !(vl && vl[0] == '1');
@@ -223,10 +242,11 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_g0q = take(gemm_bf16x3_words(S, p->ng0));
   p->o_g0tq = take(gemm_bf16x3_words(p->ng0, S));
   if (p->env_mom) {
-    p->o_wk[0] = take(size_t(S) * p->W);
-    p->o_wt[0] = take(size_t(S) * p->W);
-    p->o_wk[1] = take(size_t(cfg->latent_mlp_width) * p->W);
-    p->o_wt[1] = take(size_t(cfg->latent_mlp_width) * p->W);
+    for (int l = 0; l < L; ++l) {
+      const size_t ka = l == 0 ? S : cfg->latent_mlp_width;
+      p->o_wk[l] = take(ka * p->W);
+      p->o_wt[l] = take(ka * p->W);
+    }
   }
   for (int l = 0; l < L; ++l) {
     int in = S * (l + 1) + u, outd = S + ((l < L - 1 && !p->env_mom) ? p->W : 0);
@@ -352,8 +372,9 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
           }
     };
     fill(0, raw->first_proj, S, S + W, mlp_alpha(c, 0, S, S + W));
-    const int dl = c.latent_mlp_depth;  // index of latent 0's last layer
-    fill(1, raw->latent[0][dl], c.latent_mlp_width, S + W, mlp_alpha(c, dl, c.latent_mlp_width, S + W));
+    const int dl = c.latent_mlp_depth;  // index of a latent's last layer
+    for (int l = 1; l < L; ++l)
+      fill(l, raw->latent[l - 1][dl], c.latent_mlp_width, S + W, mlp_alpha(c, dl, c.latent_mlp_width, S + W));
   }
   AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1), "pack: missing readout weights");
   {
@@ -418,7 +439,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -427,6 +448,18 @@ struct Workspace {
   size_t g_tf[2];
   size_t total;
 };
+
+// [E,D] slots that edge_backward sums into d sh: general kernels 1 (accumulated); specialised L+1; operator kernels one
+// per 64-channel slice for the x1 path plus one per 64-wide block of every layer's env input
+static int num_gsh_slots(const aa_model_plan* p) {
+  const aa_model_config& c = p->cfg;
+  if (p->tp_op >= 0) {
+    int n = c.num_tensor / 64;
+    for (int l = 0; l < c.num_layers; ++l) n += (l == 0 ? c.num_scalar : c.latent_mlp_width) / 64;
+    return n;
+  }
+  return p->use_spec ? c.num_layers + 1 : 1;
+}
 
 static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, int with_forces) {
   Workspace w{};
@@ -451,7 +484,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   for (int l = 0; l < L; ++l) {
     if (!p->env_mom) w.envw[l] = take(Ez * p->W);
     w.x2s[l] = take(Nz * u * p->D);
-    if (l < L - 1 && p->chain_pair < 0) {
+    if (l < L - 1 && p->chain_pair < 0 && !p->env_mom) {
       w.tf[l] = take(Ez * u * c.tps[l].dout);
       dmax = std::max(dmax, size_t(c.tps[l].dout));
     }
@@ -475,7 +508,8 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     w.g_emb = take(Ez * S);
     for (int i = 0; i < c.embed_mlp_depth; ++i) w.g_se_h[i] = take(Ez * c.embed_mlp_width);
     w.g_emb0 = take(Ez * S0);
-    w.g_sh = take(Ez * p->D * (L + 1));  // slot 0: x1 path of layer 0; slot l+1: env path of layer l
+    w.g_sh = take(Ez * p->D * num_gsh_slots(p));  // slot 0: x1 path of layer 0; slot l+1: env path of layer l (see num_gsh_slots)
+    if (p->tp_op >= 0) w.q_op = take(Nz * L * p->D * u);
   }
   w.total = o;
   return w;
@@ -757,6 +791,43 @@ struct Runner {
     return m;
   }
 
+  TpOpArgs op_args(const aa_graph* g, int l) const {
+    const aa_model_config& c = p->cfg;
+    TpOpArgs o{};
+    o.N = N;
+    o.E = E;
+    o.rowptr = g->rowptr;
+    o.u = c.num_tensor;
+    o.sh = buf(w.sh);
+    o.ld_sh = p->D;
+    o.w0 = buf(w.w0);
+    o.ld_w0 = p->W;
+    o.coupling = c.tps[0].coupling;
+    o.sf = 1.0 / std::sqrt(c.avg_num_neighbors);
+    for (int m = 0; m < c.num_layers && m < 3; ++m) {
+      o.x2s[m] = buf(w.x2s[m]);
+      o.tpw[m] = wt(p->o_tpw[m]);
+    }
+    if (l == 0) {
+      o.a = buf(w.emb);
+      o.ld_a = o.ka = c.num_scalar;
+      o.act = 0;
+    } else {
+      o.a = buf(w.lat_h[l - 1][c.latent_mlp_depth - 1]);
+      o.ld_a = o.ka = c.latent_mlp_width;
+      o.act = 1;
+    }
+    o.wk = wt(p->o_wk[l]);
+    o.wt = wt(p->o_wt[l]);
+    o.ld_scal = c.num_tensor;
+    o.ld_gscal = c.num_tensor;
+    o.q = buf(w.q_op);
+    o.ld_gw0 = p->W;
+    o.ld_gsh = p->D;
+    o.ka_lds = std::max(c.num_scalar, c.latent_mlp_width);
+    return o;
+  }
+
   TpOperand implicit(size_t w_off) const {
     TpOperand o{};
     o.sh = buf(w.sh);
@@ -805,7 +876,12 @@ struct Runner {
     // 5: layers
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
     for (int l = 0; l < L; ++l) {
-      if (p->env_mom) {
+      if (p->tp_op >= 0) {
+        TpOpArgs o = op_args(g, l);
+        o.scal = buf(w.scal[l]);
+        if (int rc = launch_tp_op<T>(p->tp_op, l, false, o, stream)) return rc;
+        if (int rc = mark("tp_op_fwd", p->D + o.ka + W + u, double(l + 1) * p->D * u)) return rc;
+      } else if (p->env_mom) {
         TpMomArgs m = mom_args(g);
         if (l == 0) {
           m.c.scal1 = buf(w.scal[0]);  // the first-layer kernel writes its scalars through this field
@@ -910,8 +986,8 @@ struct Runner {
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
     // spec path with u <= 64 writes every g_sh slot with plain stores; otherwise slots are accumulated into
-    const bool gsh_stores = p->use_spec && u <= 64;
-    const int num_gsh = p->use_spec ? L + 1 : 1;
+    const bool gsh_stores = (p->use_spec && u <= 64) || p->tp_op >= 0;
+    const int num_gsh = num_gsh_slots(p);
     if (!gsh_stores) AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * num_gsh * sizeof(T), stream));
     AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
     if (int rc = mark("memset", gsh_stores ? 0 : p->D * num_gsh, 3)) return rc;
@@ -1002,6 +1078,20 @@ struct Runner {
       if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc, addp)) return rc;
       }
       // tensor-product layer reverse
+      if (p->tp_op >= 0) {
+        TpOpArgs o = op_args(g, l);
+        for (int m = 0; m < L; ++m) o.gscal[m] = buf(w.g_scal[m]);
+        o.g_w0 = buf(w.g_w0);
+        o.gsh_x1 = buf(w.g_sh);
+        size_t slot = size_t(u / 64);
+        for (int m = 0; m < l; ++m) slot += size_t(m == 0 ? S : c.latent_mlp_width) / 64;
+        o.gsh_env = buf(w.g_sh) + slot * size_t(E) * p->D;
+        o.g_a = buf(w.g_aenv);
+        o.ld_ga = o.ka;
+        if (int rc = launch_tp_op<T>(p->tp_op, l, true, o, stream)) return rc;
+        if (int rc = mark("tp_op_bwd", p->D + W + u + 2 * o.ka + p->D + (l == 0 ? W + double(L - 1) * u + p->D : 0), double(L) * p->D * u)) return rc;
+        continue;
+      }
       if (p->env_mom) {
         TpMomArgs m = mom_args(g);
         m.c.gscal0 = buf(w.g_scal[0]);
@@ -1138,7 +1228,7 @@ struct Runner {
     eb.g = geom(g, pos);
     eb.g_emb0 = buf(w.g_emb0);
     eb.g_sh = buf(w.g_sh);
-    eb.num_gsh = p->use_spec ? L + 1 : 1;
+    eb.num_gsh = num_gsh_slots(p);
     eb.forces = forces;
     if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
     return mark("edge_backward", 8.0 / sizeof(T) + 4 + c.embed_dim + double(num_gsh) * p->D + 6);

@@ -1,0 +1,397 @@
+// Tensor-product track of an L-layer Allegro stack in "per-atom operator" form (gfx950).
+//
+// For a fixed center atom n and channel ch every layer of the track (allegro/nn/_allegro.py:263-278 +
+// allegro/nn/_strided/_contract.py:195-251) is LINEAR in the incoming edge features once the per-atom sums
+// x2s_i[n] (the scattered, env-weighted harmonics, _contract.py:195-205) are fixed:
+//     tf_{i+1}[e] = Sig_i(tf_i[e], x2s_i[n]) = M_i(n) tf_i[e],      tf_0[e] = x1[e] = Y[e] (.) w0[e]
+// and the track is only ever read through its scalar channel  scal_l[e] = tf_{l+1}[e][0]  (_allegro.py:272-278).
+// Therefore
+//     scal_l[e] = < x1[e], B_l(n) >,     B_l = M_0^T M_1^T ... M_l^T e_0                      (forward)
+//     d x1[e]   = sum_m G_m[e] B_m(n)                                                         (reverse, edges)
+//     d x2s_l   = sum_{m>=l} Sig_l^T_x2( M_{l+1}^T..M_m^T e_0 ,  M_{l-1}..M_0 Q_m ),   Q_m = sum_e G_m[e] x1[e]
+// with G_m = dE/d scal_m.  The Clebsch-Gordan contractions (up to 611 non-zeros each at l_max = 3) are evaluated
+// a handful of times per ATOM; per EDGE only O(D) dot products remain, for any number of layers, and no
+// [E, u, d] tensor-feature array exists at all.  The env weights enter through the moments
+//     x2s_l[n,j,ch] = f * sum_k (sum_e Y[e,j] act(a_l[e,k])) Wenv_l[k, r(j), ch]
+// exactly as in the 2-layer kernels of aa_tp_spec.hip (which remain the tuned path for L = 2, u = 64).
+//
+// Launch: one workgroup per atom, one wave per 64-channel slice (u = 64, 128, ...); lane = channel.
+#include <type_traits>
+
+#include "aa_cg_gen.h"
+#include "aa_common.h"
+#include "aa_wave.h"
+
+namespace aa {
+
+namespace {
+
+constexpr int kOpMaxD = 31;   // widest irreps vector on the track (l_max 3, L 3: 0e+1e+1o+2e+2o+3e+3o)
+constexpr int kOpMaxP = 34;   // most paths of one layer
+constexpr int kOpMaxKa = 128; // widest env input
+
+struct NoSig {};
+template <class A, class B, class C, int N>
+struct SigChain {
+  typedef A S0;
+  typedef B S1;
+  typedef C S2;
+  static constexpr int L = N;
+};
+template <class Ch, int I>
+struct SigAt;
+template <class Ch>
+struct SigAt<Ch, 0> {
+  typedef typename Ch::S0 type;
+};
+template <class Ch>
+struct SigAt<Ch, 1> {
+  typedef typename Ch::S1 type;
+};
+template <class Ch>
+struct SigAt<Ch, 2> {
+  typedef typename Ch::S2 type;
+};
+
+// per-atom operands of layer I for this lane's channel: x2s_I (from HBM) and the path weights
+template <class Sig, typename T>
+__device__ __forceinline__ void load_layer(const TpOpArgs& a, int i, int64_t atom, int ch, T* x2s, T* wp) {
+  const T* xp = static_cast<const T*>(a.x2s[i]) + atom * Sig::D2 * int64_t(a.u) + ch;
+#pragma unroll
+  for (int j = 0; j < Sig::D2; ++j) x2s[j] = xp[int64_t(j) * a.u];
+  const T* W = static_cast<const T*>(a.tpw[i]);
+#pragma unroll
+  for (int p = 0; p < Sig::P; ++p) wp[p] = a.coupling ? W[ch * Sig::P + p] : W[p];
+}
+
+// g <- M_LO^T ... M_HI^T g   (g enters with DOUT_HI entries, leaves with D1_LO entries)
+template <class Ch, int HI, int LO, typename T>
+__device__ __forceinline__ void chain_bx1(const TpOpArgs& a, int64_t atom, int ch, T* g) {
+  if constexpr (HI >= LO) {
+    typedef typename SigAt<Ch, HI>::type S;
+    T x2s[S::D2], wp[S::P], t[S::D1];
+    load_layer<S, T>(a, HI, atom, ch, x2s, wp);
+    S::template bx1<T>(g, x2s, wp, t);
+#pragma unroll
+    for (int i = 0; i < S::D1; ++i) g[i] = t[i];
+    chain_bx1<Ch, HI - 1, LO, T>(a, atom, ch, g);
+  }
+}
+
+// t <- M_HI ... M_LO t   (t enters with D1_LO entries, leaves with DOUT_HI entries)
+template <class Ch, int LO, int HI, typename T>
+__device__ __forceinline__ void chain_fwd(const TpOpArgs& a, int64_t atom, int ch, T* t) {
+  if constexpr (LO <= HI) {
+    typedef typename SigAt<Ch, LO>::type S;
+    T x2s[S::D2], wp[S::P], o[S::DOUT];
+    load_layer<S, T>(a, LO, atom, ch, x2s, wp);
+    S::template fwd<T>(t, x2s, wp, o);
+#pragma unroll
+    for (int k = 0; k < S::DOUT; ++k) t[k] = o[k];
+    chain_fwd<Ch, LO + 1, HI, T>(a, atom, ch, t);
+  }
+}
+
+// B_M = M_0^T .. M_M^T e_0
+template <class Ch, int M, typename T>
+__device__ __forceinline__ void atom_vector(const TpOpArgs& a, int64_t atom, int ch, T* g) {
+#pragma unroll
+  for (int k = 0; k < kOpMaxD; ++k) g[k] = k == 0 ? T(1) : T(0);
+  chain_bx1<Ch, M, 0, T>(a, atom, ch, g);
+}
+
+// term m of d x2s_L:  Sig_L^T_x2( M_{L+1}^T..M_m^T e_0 , M_{L-1}..M_0 q )  accumulated into g2
+template <class Ch, int LI, int M, typename T>
+__device__ __forceinline__ void x2s_grad_term(const TpOpArgs& a, int64_t atom, int ch, const T* q, T* g2) {
+  typedef typename SigAt<Ch, LI>::type S;
+  T t[kOpMaxD], lv[kOpMaxD];
+#pragma unroll
+  for (int k = 0; k < kOpMaxD; ++k) {
+    t[k] = k < SigAt<Ch, 0>::type::D1 ? q[k] : T(0);
+    lv[k] = k == 0 ? T(1) : T(0);
+  }
+  chain_fwd<Ch, 0, LI - 1, T>(a, atom, ch, t);
+  chain_bx1<Ch, M, LI + 1, T>(a, atom, ch, lv);
+  T x2s[S::D2], wp[S::P], o[S::D2];
+  load_layer<S, T>(a, LI, atom, ch, x2s, wp);
+  S::template bx2<T>(lv, t, wp, o);
+#pragma unroll
+  for (int j = 0; j < S::D2; ++j) g2[j] += o[j];
+}
+
+template <class Ch, int LI, int M, typename T>
+__device__ __forceinline__ void x2s_grad_terms(const TpOpArgs& a, int64_t atom, int ch, const T* q_own, T* g2) {
+  if constexpr (M < Ch::L) {
+    constexpr int D = SigAt<Ch, 0>::type::D1;
+    T q[D];
+    if (M == LI) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) q[i] = q_own[i];
+    } else {
+      const T* qp = static_cast<const T*>(a.q) + ((atom * Ch::L + M) * D) * int64_t(a.u) + ch;
+#pragma unroll
+      for (int i = 0; i < D; ++i) q[i] = qp[int64_t(i) * a.u];
+    }
+    x2s_grad_term<Ch, LI, M, T>(a, atom, ch, q, g2);
+    x2s_grad_terms<Ch, LI, M + 1, T>(a, atom, ch, q_own, g2);
+  }
+}
+
+// B_m for m = 0..L-1 into b[m][.]
+template <class Ch, int M, typename T, int D>
+__device__ __forceinline__ void all_atom_vectors(const TpOpArgs& a, int64_t atom, int ch, T (*b)[D]) {
+  if constexpr (M < Ch::L) {
+    T g[kOpMaxD];
+    atom_vector<Ch, M, T>(a, atom, ch, g);
+#pragma unroll
+    for (int i = 0; i < D; ++i) b[M][i] = g[i];
+    all_atom_vectors<Ch, M + 1, T, D>(a, atom, ch, b);
+  }
+}
+
+}  // namespace
+
+// ---- forward of layer LI: x2s_LI from the moments of its env input, B_LI, then scal_LI[e] = <x1[e], B_LI>
+template <class Ch, int LI, typename T>
+__global__ __launch_bounds__(256) void tp_op_fwd_kernel(TpOpArgs a) {
+  typedef typename SigAt<Ch, LI>::type S;
+  constexpr int D = S::D2, R = S::LMAX + 1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = blockIdx.x;
+  const int u = a.u, ch = wv * 64 + lane;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;  // (its x2s rows are only ever read by its own, absent, edges)
+  T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * D * a.ka_lds;  // wave-private [D][ka]
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* av = static_cast<const T*>(a.a);
+  const int ka = a.ka;
+  // moments M[j][k] = sum_e Y[e,j] act(a[e,k])   (every slice recomputes them: they do not depend on the channel)
+  for (int kb = 0; kb < ka; kb += 64) {
+    T m[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) m[j] = T(0);
+#pragma unroll 4
+    for (int s = beg; s < end; ++s) {
+      T x = av[int64_t(s) * a.ld_a + kb + lane];
+      if (a.act) x = silu(x);
+      const T* y = sh + int64_t(s) * a.ld_sh;
+#pragma unroll
+      for (int j = 0; j < D; ++j) m[j] += y[j] * x;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) sM[j * a.ka_lds + kb + lane] = m[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  T x2s[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) x2s[j] = T(0);
+  {
+    const T* Wk = static_cast<const T*>(a.wk) + ch;  // [ka][R][u]
+#pragma unroll 4
+    for (int k = 0; k < ka; ++k) {
+      T wv3[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) wv3[r] = Wk[(int64_t(k) * R + r) * u];
+#pragma unroll
+      for (int j = 0; j < D; ++j) x2s[j] += sM[j * a.ka_lds + k] * wv3[r_of<0>(j)];
+    }
+  }
+  {
+    const T sf = T(a.sf);
+    T* xo = static_cast<T*>(const_cast<void*>(a.x2s[LI])) + atom * D * int64_t(u) + ch;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s[j] *= sf;
+      xo[int64_t(j) * u] = x2s[j];
+    }
+  }
+  // the chain reads x2s_LI back through the same lane's own store (same thread, same address: program order)
+  __threadfence_block();
+  T b[kOpMaxD];
+  atom_vector<Ch, LI, T>(a, atom, ch, b);
+  const T* w0 = static_cast<const T*>(a.w0) + ch;
+  T* sc = static_cast<T*>(a.scal) + ch;
+  constexpr int D1 = SigAt<Ch, 0>::type::D1;
+#pragma unroll 2
+  for (int s = beg; s < end; ++s) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    T wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = w0[int64_t(s) * a.ld_w0 + r * u];
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < D1; ++i) acc += (y[i] * wr[r_of<0>(i)]) * b[i];
+    sc[int64_t(s) * a.ld_scal] = acc;
+  }
+}
+
+// ---- reverse of layer LI
+template <class Ch, int LI, typename T>
+__global__ __launch_bounds__(256) void tp_op_bwd_kernel(TpOpArgs a) {
+  typedef typename SigAt<Ch, LI>::type S;
+  constexpr int D = S::D2, R = S::LMAX + 1, L = Ch::L;
+  constexpr int D1 = SigAt<Ch, 0>::type::D1;
+  static_assert(D1 == D && D <= 16, "x1 and the harmonics share their irreps");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nsl = blockDim.x >> 6;
+  const int64_t atom = blockIdx.x;
+  const int u = a.u, ch = wv * 64 + lane;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;  // (uniform for the whole workgroup: no barrier is skipped by a subset)
+  T* sG = reinterpret_cast<T*>(aa_smem);  // [nsl][D][64]  d x2s_LI of every slice
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* w0 = static_cast<const T*>(a.w0) + ch;
+  const int64_t ED = int64_t(a.E) * a.ld_gsh;
+
+  // per-atom vectors B_m (all layers) for the edge gradients of the first layer's reverse
+  T bm[LI == 0 ? L : 1][D1];
+  if constexpr (LI == 0) all_atom_vectors<Ch, 0, T, D1>(a, atom, ch, bm);
+
+  // edge loop A: Q_LI = sum_e G_LI[e] x1[e]; for LI == 0 also d w0[e] and d Y[e] through x1
+  T q[D1];
+#pragma unroll
+  for (int i = 0; i < D1; ++i) q[i] = T(0);
+  {
+    const T* gl = static_cast<const T*>(a.gscal[LI]) + ch;
+    T* gw0 = static_cast<T*>(a.g_w0) + ch;
+    T* gsx = static_cast<T*>(a.gsh_x1) + int64_t(wv) * ED;  // one slot per slice
+    for (int s = beg; s < end; ++s) {
+      const T* y = sh + int64_t(s) * a.ld_sh;
+      T wr[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) wr[r] = w0[int64_t(s) * a.ld_w0 + r * u];
+      const T g = gl[int64_t(s) * a.ld_gscal];
+#pragma unroll
+      for (int i = 0; i < D1; ++i) q[i] += g * (y[i] * wr[r_of<0>(i)]);
+      if constexpr (LI == 0) {
+        T gm_[L];
+        gm_[0] = g;
+#pragma unroll
+        for (int m = 1; m < L; ++m) gm_[m] = static_cast<const T*>(a.gscal[m])[int64_t(s) * a.ld_gscal + ch];
+        T gw[R], gy[D1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) gw[r] = T(0);
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+          T gx = T(0);
+#pragma unroll
+          for (int m = 0; m < L; ++m) gx += gm_[m] * bm[m][i];
+          gw[r_of<0>(i)] += gx * y[i];
+          gy[i] = gx * wr[r_of<0>(i)];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * u] = gw[r];
+        wave_sum_store<T, D1>(gy, gsx + int64_t(s) * a.ld_gsh, true, false);
+      }
+    }
+  }
+  {
+    T* qp = static_cast<T*>(a.q) + ((atom * L + LI) * D1) * int64_t(u) + ch;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) qp[int64_t(i) * u] = q[i];
+  }
+  // d x2s_LI from all layers m >= LI
+  T g2[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g2[j] = T(0);
+  x2s_grad_terms<Ch, LI, LI, T>(a, atom, ch, q, g2);
+  {
+    const T sf = T(a.sf);
+#pragma unroll
+    for (int j = 0; j < D; ++j) sG[(wv * D + j) * 64 + lane] = g2[j] * sf;
+  }
+  __syncthreads();
+  // adjoint of the moments: k-block b (64 env inputs) belongs to wave b % nsl
+  const T* Wt = static_cast<const T*>(a.wt);  // [R][u][ka]
+  const T* av = static_cast<const T*>(a.a);
+  const int ka = a.ka;
+  for (int blk = wv; blk * 64 < ka; blk += nsl) {
+    const int k = blk * 64 + lane;
+    T gm[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) gm[j] = T(0);
+    for (int c = 0; c < u; ++c) {
+      T w3[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) w3[r] = Wt[(int64_t(r) * u + c) * ka + k];
+      const T* sg = sG + ((c >> 6) * D) * 64 + (c & 63);
+#pragma unroll
+      for (int j = 0; j < D; ++j) gm[j] += sg[j * 64] * w3[r_of<0>(j)];
+    }
+    T* ga = static_cast<T*>(a.g_a) + k;
+    T* gse = static_cast<T*>(a.gsh_env) + int64_t(blk) * ED;  // one slot per k-block
+    for (int s = beg; s < end; ++s) {
+      const T* y = sh + int64_t(s) * a.ld_sh;
+      T x = av[int64_t(s) * a.ld_a + k];
+      if (a.act) x = silu(x);
+      T d = T(0), gy[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        d += y[j] * gm[j];
+        gy[j] = x * gm[j];
+      }
+      ga[int64_t(s) * a.ld_ga] = d;
+      wave_sum_store<T, D>(gy, gse + int64_t(s) * a.ld_gsh, true, false);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (first-layer, ..., last-layer) signatures of the standard stacks, by (l_max, L)
+typedef SigChain<cg::Sig1, cg::Sig0, NoSig, 2> Chain12;
+typedef SigChain<cg::Sig5, cg::Sig4, NoSig, 2> Chain22;
+typedef SigChain<cg::Sig9, cg::Sig8, NoSig, 2> Chain32;
+typedef SigChain<cg::Sig2, cg::Sig3, cg::Sig0, 3> Chain13;
+typedef SigChain<cg::Sig6, cg::Sig7, cg::Sig4, 3> Chain23;
+typedef SigChain<cg::Sig10, cg::Sig11, cg::Sig8, 3> Chain33;
+
+int find_op_chain(const int* sigs, int L) {
+  static const int table[6][4] = {{2, 1, 0, -1}, {2, 5, 4, -1}, {2, 9, 8, -1}, {3, 2, 3, 0}, {3, 6, 7, 4}, {3, 10, 11, 8}};
+  for (int c = 0; c < 6; ++c) {
+    if (table[c][0] != L) continue;
+    bool ok = true;
+    for (int l = 0; l < L; ++l) ok = ok && sigs[l] == table[c][1 + l];
+    if (ok) return c;
+  }
+  return -1;
+}
+
+template <typename T>
+int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStream_t stream) {
+  if (a.N == 0) return AA_OK;
+  if ((a.u & 63) || a.u > 256 || (a.ka & 63) || a.ka > kOpMaxKa || a.ka_lds < a.ka)
+    return fail(AA_ERR_INVALID, "tp_op: needs u = 64..256 in steps of 64 and env widths of 64 or 128");
+  const int nsl = a.u / 64;
+  const int Dsh = chain % 3 == 0 ? 4 : (chain % 3 == 1 ? 9 : 16);
+  const size_t smem = reverse ? sizeof(T) * size_t(nsl) * Dsh * 64 : sizeof(T) * size_t(nsl) * Dsh * a.ka_lds;
+  dim3 grid((unsigned)a.N), block(64 * nsl);
+#define AA_OP_LAUNCH(CH, LI)                                                                          \
+  {                                                                                                   \
+    if (reverse)                                                                                      \
+      hipLaunchKernelGGL((tp_op_bwd_kernel<CH, LI, T>), grid, block, smem, stream, a);                \
+    else                                                                                              \
+      hipLaunchKernelGGL((tp_op_fwd_kernel<CH, LI, T>), grid, block, smem, stream, a);                \
+  }
+#define AA_OP_CHAIN2(CH)                            \
+  if (layer == 0) AA_OP_LAUNCH(CH, 0) else if (layer == 1) AA_OP_LAUNCH(CH, 1) else return fail(AA_ERR_INVALID, "tp_op: bad layer");
+#define AA_OP_CHAIN3(CH)                            \
+  if (layer == 0) AA_OP_LAUNCH(CH, 0) else if (layer == 1) AA_OP_LAUNCH(CH, 1) else if (layer == 2) AA_OP_LAUNCH(CH, 2) else return fail(AA_ERR_INVALID, "tp_op: bad layer");
+  switch (chain) {
+    case 0: AA_OP_CHAIN2(Chain12) break;
+    case 1: AA_OP_CHAIN2(Chain22) break;
+    case 2: AA_OP_CHAIN2(Chain32) break;
+    case 3: AA_OP_CHAIN3(Chain13) break;
+    case 4: AA_OP_CHAIN3(Chain23) break;
+    case 5: AA_OP_CHAIN3(Chain33) break;
+    default: return fail(AA_ERR_INVALID, "tp_op: unknown signature chain");
+  }
+#undef AA_OP_LAUNCH
+#undef AA_OP_CHAIN2
+#undef AA_OP_CHAIN3
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template int launch_tp_op<float>(int, int, bool, const TpOpArgs&, hipStream_t);
+template int launch_tp_op<double>(int, int, bool, const TpOpArgs&, hipStream_t);
+
+}  // namespace aa

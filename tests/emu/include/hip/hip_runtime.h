@@ -93,6 +93,7 @@ inline double* slot(int w, int l) { return &st().xchg[(size_t(w) * WAVE + l) * 4
   emu::launch(dim3(grid), dim3(block), (smem), [=]() { kern(__VA_ARGS__); })
 
 inline void __syncthreads() { emu::yield_block_barrier(); }
+inline void __threadfence_block() {}
 
 template <typename T>
 inline T __shfl(T v, int src, int width = 64) {

@@ -121,3 +121,39 @@ def test_moments_path_long_segments_vs_oracle():
     ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, torch.tensor(shift @ cell))
     assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9 * max(1.0, float(ref["atomic_energy"].abs().max()))
     assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))
+
+
+@pytest.mark.parametrize("l_max,L,u,S,force", [(2, 3, 64, 64, False), (3, 3, 128, 128, False), (2, 2, 128, 64, False),
+                                                (2, 2, 64, 64, True)])
+def test_operator_path_vs_oracle(l_max, L, u, S, force, monkeypatch):
+    """Per-atom operator form of the tensor-product track (aa_tp_op.hip): 3-layer stacks, two 64-channel slices,
+    and (forced) the 2-layer case the tuned kernels normally take.  fp64 against the oracle restatement."""
+    import numpy as np
+
+    from oracle import restatement as R
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+
+    if force:
+        monkeypatch.setenv("AA_TP_OP", "1")
+    rng = np.random.default_rng(5)
+    n = 10
+    pos = rng.uniform(0, 6.5, size=(n, 3))
+    pos[n - 1] = [30.0, 30.0, 30.0]
+    cell = np.eye(3) * 60.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
+    deg = np.bincount(ei[0], minlength=n)
+    assert deg[n - 1] == 0 and ei.shape[1] >= 10
+    cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               radial_chemical_embed_dim=16, scalar_embed_mlp_hidden_layers_width=32, allegro_mlp_hidden_layers_width=S,
+               readout_mlp_hidden_layers_width=32, avg_num_neighbors=float(deg.mean()), seed=11, model_dtype="float64")
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    types = torch.tensor(rng.integers(0, 2, size=n))
+    g = m.prepare_graph(torch.tensor(ei), types, n, torch.tensor(shift @ cell))
+    e, f = m.energy_forces(torch.tensor(pos), g)
+    sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, torch.tensor(shift @ cell))
+    assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9 * max(1.0, float(ref["atomic_energy"].abs().max()))
+    assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))

@@ -278,3 +278,56 @@ def test_fast_path_all_lmax_ragged_and_long_segments_vs_oracle(l_max, dtype, tol
         err_hip = (got.double() - w64).abs().max().item()
         err_cpu32 = (w32.double() - w64).abs().max().item()
         assert err_hip <= 2.0 * err_cpu32 + 1e-5 * scale, (err_hip, err_cpu32, scale)
+
+
+@pytest.mark.parametrize("l_max,L,u,S,dtype,tol,force", [
+    (1, 3, 64, 64, torch.float32, 5e-5, False), (2, 3, 64, 64, torch.float64, 1e-9, False),
+    (3, 3, 128, 128, torch.float64, 1e-9, False), (2, 2, 128, 64, torch.float32, 5e-5, False),
+    (2, 2, 64, 64, torch.float64, 1e-9, True), (3, 3, 64, 128, torch.float32, 5e-5, False)])
+def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, dev, monkeypatch):
+    """aa_tp_op.hip (per-atom operator form of the tensor-product track) on hardware: 3-layer stacks, 64- and
+    128-channel models (one wave per 64-channel slice), all l_max, both dtypes, ragged segments incl. degrees > 64."""
+    from oracle import restatement as R
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+
+    if force:
+        monkeypatch.setenv("AA_TP_OP", "1")
+    rng = np.random.default_rng(31)
+    r_max = 6.0
+    sparse = rng.uniform(0, 10.5, size=(30, 3)) * (r_max / 3.4)
+    grid = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(3), indexing="ij"), -1).reshape(-1, 3)[:70]
+    dense = grid * 1.2 + rng.uniform(-0.05, 0.05, size=(70, 3)) + 40.0
+    pos = np.concatenate([sparse, dense, [[75.0, 75.0, 75.0]]])
+    n = len(pos)
+    cell = np.eye(3) * 120.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, r_max)
+    deg = np.bincount(ei[0], minlength=n)
+    assert deg.max() == 69 and deg[n - 1] == 0
+    name = {torch.float64: "float64", torch.float32: "float32"}[dtype]
+    cfg = dict(type_names=["A", "B"], r_max=r_max, l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               radial_chemical_embed_dim=32, scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=S,
+               readout_mlp_hidden_layers_width=64, avg_num_neighbors=float(deg.mean()), seed=5, model_dtype=name)
+    m = HipAllegroModel(**cfg).to(dev)
+    types = torch.tensor(rng.integers(0, 2, size=n))
+    sv = torch.tensor(shift @ cell, dtype=dtype)
+    g = m.prepare_graph(torch.tensor(ei).to(dev), types.to(dev), n, sv.to(dev))
+    e, f = m.energy_forces(torch.tensor(pos, dtype=dtype, device=dev), g)
+    sd = {k[len("func."):]: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos, dtype=dtype), torch.tensor(ei), types, sv)
+    if dtype == torch.float64:
+        for got, want in ((e.cpu(), ref["atomic_energy"].reshape(-1)), (f.cpu(), ref["forces"])):
+            assert torch.isfinite(got).all()
+            assert (got - want).abs().max().item() <= tol * max(1.0, float(want.abs().max()))
+        return
+    cfg64 = dict(cfg, model_dtype="float64")
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ref64 = R.allegro_energy_forces(cfg64, sd64, torch.tensor(pos), torch.tensor(ei), types, sv.double())
+    for got, w32, w64 in ((e.cpu(), ref["atomic_energy"].reshape(-1), ref64["atomic_energy"].reshape(-1)),
+                          (f.cpu(), ref["forces"], ref64["forces"])):
+        assert torch.isfinite(got).all()
+        scale = max(1.0, float(w64.abs().max()))
+        err_hip = (got.double() - w64).abs().max().item()
+        err_cpu32 = (w32.double() - w64).abs().max().item()
+        assert err_hip <= 2.0 * err_cpu32 + 1e-5 * scale, (err_hip, err_cpu32, scale)
