@@ -181,6 +181,71 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
   }
 }
 
+// fp64 GEMM on the f64 matrix cores (v_mfma_f64_16x16x4_f64): same 64x64x16 LDS tiling and generic segmented
+// loads / epilogue as gemm_valu_kernel, the inner product on MFMA.  Each of the four waves owns a 32x32 sub-tile
+// (2x2 MFMA tiles).  Operand layout: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; result
+// C[i = 4*r + (lane>>4)][j = lane&15], r = 0..3 (probed on hardware: unlike the f32 16x16 layout, register r holds
+// rows 4r..4r+3 across the four 16-lane groups).
+typedef double v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
+  double* As = reinterpret_cast<double*>(aa_smem);  // [BK][LDA]
+  double* Bs = As + GV_BK * GV_LDA;                 // [BK][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wr = wv >> 1, wc = wv & 1;
+  const int64_t m0 = int64_t(blockIdx.x) * GV_BM;
+  const int n0 = blockIdx.y * GV_BN;
+  const double* B = static_cast<const double*>(g.B);
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < g.K; k0 += GV_BK) {
+    for (int idx = tid; idx < GV_BM * GV_BK; idx += 256) {
+      const int m = idx / GV_BK, k = idx % GV_BK;
+      const int64_t gm = m0 + m;
+      const int gk = k0 + k;
+      double v = 0.0;
+      if (gm < g.M && gk < g.K) {
+        v = seg_load<double>(g.a, gm, gk);
+        if (g.act_a) v = silu(v);
+      }
+      As[k * GV_LDA + m] = v;
+    }
+    for (int idx = tid; idx < GV_BK * GV_BN; idx += 256) {
+      const int k = idx / GV_BN, j = idx % GV_BN;
+      const int gk = k0 + k, gn = n0 + j;
+      Bs[idx] = (gk < g.K && gn < g.N) ? B[int64_t(gk) * g.N + gn] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GV_BK; kk += 4) {
+      const int kr = kk + (lane >> 4);
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kr * GV_LDA + wr * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kr * GV_BN + wc * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = n0 + wc * 32 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gm = m0 + wr * 32 + i * 16 + 4 * r + (lane >> 4);
+        if (gm < g.M && gn < g.N) seg_store<double>(g, gm, gn, acc[i][j][r]);
+      }
+    }
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // destination of one output column, resolved once per 32-column tile (not per element)
@@ -1329,7 +1394,10 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   if (int rc = check_args(g)) return rc;
   dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
   size_t smem = sizeof(double) * (GV_BK * GV_LDA + GV_BK * GV_BN);
-  hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
+  if (force_valu())
+    hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
+  else
+    hipLaunchKernelGGL(gemm_mfma_f64_kernel, grid, dim3(256), smem, stream, g);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }

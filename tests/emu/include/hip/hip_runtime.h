@@ -146,6 +146,30 @@ inline int __builtin_amdgcn_update_dpp(int, int v, int ctrl, int, int, bool) {
   return __shfl(v, src);
 }
 
+typedef double emu_v4d __attribute__((ext_vector_type(4)));
+// v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[i = 4*r + (l>>4)][j = l&15] (probed on gfx950)
+inline emu_v4d __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, emu_v4d c, int, int, int) {
+  int l = emu::lane(), w = emu::wave();
+  double ab[2] = {a, b};
+  memcpy(emu::slot(w, l), ab, sizeof(ab));
+  emu::wave_rendezvous();
+  emu_v4d d = c;
+  const int j = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * r + (l >> 4);
+    double acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      double av[2], bv[2];
+      memcpy(av, emu::slot(w, i + 16 * k), sizeof(av));  // lane holding A[i][k]
+      memcpy(bv, emu::slot(w, j + 16 * k), sizeof(bv));  // lane holding B[k][j]
+      acc += av[0] * bv[1];
+    }
+    d[r] = acc;
+  }
+  emu::wave_rendezvous();
+  return d;
+}
+
 typedef float emu_v16f __attribute__((ext_vector_type(16)));
 inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_v16f c, int, int, int) {
   int l = emu::lane(), w = emu::wave();
