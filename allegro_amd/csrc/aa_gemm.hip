@@ -246,6 +246,111 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
     }
 }
 
+// Pipelined variant for the model's shapes (every A segment a multiple of 16 columns wide, 16-B aligned rows):
+// 128 x 64 block tile, 16-deep steps; the next step's global loads are in flight while this step's 32 MFMAs per
+// wave issue, LDS double-buffered (one barrier per step).  Each wave owns 32 rows x 64 columns (2 x 4 MFMA tiles).
+constexpr int G6_BM = 128, G6_BN = 64, G6_BK = 16, G6_LDA = G6_BM + 4;
+typedef double v2d __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
+  double* smem = reinterpret_cast<double*>(aa_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t m0 = int64_t(blockIdx.x) * G6_BM;
+  const int n0 = blockIdx.y * G6_BN;
+  const double* B = static_cast<const double*>(g.B);
+  auto As = [&](int b) { return smem + b * (G6_BK * G6_LDA + G6_BK * G6_BN); };
+  auto Bs = [&](int b) { return As(b) + G6_BK * G6_LDA; };
+  // staging roles: A: thread -> (row = tid >> 1, 8 consecutive k); B: thread -> (k = tid >> 4, 4 consecutive columns)
+  const int ar = tid >> 1, ak = (tid & 1) * 8;
+  const int64_t arow = m0 + ar < g.M ? m0 + ar : g.M - 1;
+  const int bk = tid >> 4, bn = (tid & 15) * 4;
+  v2d ra[4], rb[2];
+  auto load_tiles = [&](int k0) {
+    // the segment holding columns [k0, k0+16): wave-uniform
+    int c = k0;
+    const double* base = nullptr;
+    int ld = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      if (s2 < g.a.count && base == nullptr) {
+        if (c < g.a.s[s2].n) {
+          base = static_cast<const double*>(g.a.s[s2].p) + c;
+          ld = g.a.s[s2].ld;
+        } else {
+          c -= g.a.s[s2].n;
+        }
+      }
+    }
+    const double* ap = base + arow * ld + ak;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = (base && k0 + ak + 2 * q < g.K) ? *reinterpret_cast<const v2d*>(ap + 2 * q) : v2d{0.0, 0.0};
+    const int gk = k0 + bk;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int gn = n0 + bn + 2 * q;
+      rb[q] = (gk < g.K && gn + 1 < g.N) ? *reinterpret_cast<const v2d*>(B + int64_t(gk) * g.N + gn)
+                                          : v2d{(gk < g.K && gn < g.N) ? B[int64_t(gk) * g.N + gn] : 0.0, 0.0};
+    }
+  };
+  auto store_tiles = [&](int b) {
+    double* a_ = As(b);
+    double* b_ = Bs(b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double x0 = ra[q][0], x1 = ra[q][1];
+      if (g.act_a) {
+        x0 = silu(x0);
+        x1 = silu(x1);
+      }
+      a_[(ak + 2 * q) * G6_LDA + ar] = x0;
+      a_[(ak + 2 * q + 1) * G6_LDA + ar] = x1;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<v2d*>(b_ + bk * G6_BN + bn + 2 * q) = rb[q];
+  };
+  v4d acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < g.K; k0 += G6_BK) {
+    const bool more = k0 + G6_BK < g.K;
+    if (more) load_tiles(k0 + G6_BK);
+    const double* a_ = As(buf);
+    const double* b_ = Bs(buf);
+#pragma unroll
+    for (int kk = 0; kk < G6_BK; kk += 4) {
+      const int kr = kk + (lane >> 4);
+      double a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = a_[kr * G6_LDA + wv * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = b_[kr * G6_BN + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gm = m0 + wv * 32 + i * 16 + 4 * r + (lane >> 4);
+        if (gm < g.M && gn < g.N) seg_store<double>(g, gm, gn, acc[i][j][r]);
+      }
+    }
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // destination of one output column, resolved once per 32-column tile (not per element)
@@ -1394,10 +1499,18 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   if (int rc = check_args(g)) return rc;
   dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
   size_t smem = sizeof(double) * (GV_BK * GV_LDA + GV_BK * GV_BN);
-  if (force_valu())
+  bool pipe_ok = (g.N % 2) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+  for (int s2 = 0; s2 < g.a.count; ++s2)
+    pipe_ok = pipe_ok && (g.a.s[s2].n % 16) == 0 && (g.a.s[s2].ld % 2) == 0 && (reinterpret_cast<uintptr_t>(g.a.s[s2].p) & 15) == 0;
+  if (force_valu()) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
-  else
+  } else if (pipe_ok) {
+    dim3 grid6((unsigned)((g.M + G6_BM - 1) / G6_BM), (unsigned)((g.N + G6_BN - 1) / G6_BN));
+    const size_t smem6 = sizeof(double) * 2 * (G6_BK * G6_LDA + G6_BK * G6_BN);
+    hipLaunchKernelGGL(gemm_mfma_f64_pipe_kernel, grid6, dim3(256), smem6, stream, g);
+  } else {
     hipLaunchKernelGGL(gemm_mfma_f64_kernel, grid, dim3(256), smem, stream, g);
+  }
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
