@@ -105,18 +105,6 @@ def step_roofline(cfg, E, t_step, stages, dtype):
                 frac_of_hbm_roof_this_design=t_hbm / t_step)
 
 
-def gemm_sequence_flops(stage_names, E):
-    """flops of every 'gemm_KxN' stage: 2*E*K*N."""
-    out = []
-    for n in stage_names:
-        if n.startswith("gemm_"):
-            k, nn = n[5:].split("x")
-            out.append(2.0 * E * int(k) * int(nn))
-        else:
-            out.append(0.0)
-    return out
-
-
 def profile_stages(model, pos, graph):
     """[(kernel-launch name, ms, algorithmic bytes, flops)] of one forward+force pass, averaged over 5 passes:
     HIP events recorded by the library on the launch stream around every kernel (aa_model_energy_forces_profiled)."""
