@@ -765,7 +765,7 @@ __device__ __forceinline__ void mom_gm(const T* sG, const T* Wt, int ka, int kb,
 
 // adjoint of the moments for every edge of the segment:
 //   d_a[e,k] = sum_j sh[e,j] * GM[j][k]        d_sh[e,j] = sum_k act(a[e,k]) * GM[j][k]
-template <typename T, int D, int R>
+template <typename T, int D, int R, bool KA2>
 __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const T* a, int ld_a, int ka, bool act,
                                                    const T* g2acc, const T* Wt, int beg, int end, int lane, T* sG, T* sY,
                                                    int& staged_cb, T* g_a, int ld_ga, T* gsh, int ld_gsh) {
@@ -777,7 +777,7 @@ __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const
   __builtin_amdgcn_wave_barrier();
   T gm0[D], gm1[D];
   mom_gm<T, D, R>(sG, Wt, ka, 0, lane, gm0);
-  const bool two = ka > 64;
+  const bool two = KA2 && ka > 64;
   if (two) mom_gm<T, D, R>(sG, Wt, ka, 64, lane, gm1);
   const T2* sY2 = reinterpret_cast<const T2*>(sY);
   auto loadb = [&](int s0, int ce, T2* v0, T2* v1) {
@@ -975,7 +975,7 @@ __device__ __forceinline__ void mom_pair_loop(const T* sh, int ld_sh, int beg, i
   }
 }
 
-template <class Sig0, typename T>
+template <class Sig0, typename T, bool KA2>
 __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
   }
 }
 
-template <class Sig0, class Sig1, typename T>
+template <class Sig0, class Sig1, typename T, bool KA2>
 __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
@@ -1087,8 +1087,10 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
   }
 }
 
-template <class Sig0, class Sig1, typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 3 : 1) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
+// KA2: env inputs wider than 64 (two k blocks per lane) -- a compile-time switch because the second block costs the
+// reverse kernels ~50 VGPRs (4 instead of 3 waves/SIMD without it)
+template <class Sig0, class Sig1, typename T, bool KA2>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? (KA2 ? 3 : 4) : 1) void tp_mom_bwd_last_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
   AA_MOM_PROLOGUE(D)
@@ -1139,12 +1141,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 3 : 1) v
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
-  mom_backward_edges<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, g2acc,
+  mom_backward_edges<T, D, R, KA2>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, g2acc,
                               static_cast<const T*>(ma.wt1), beg, end, lane, sG, sY, staged_cb, static_cast<T*>(ma.g_a),
                               ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
 
-template <class Sig0, class Sig1, typename T>
+template <class Sig0, class Sig1, typename T, bool KA2>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
@@ -1245,7 +1247,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
-  mom_backward_edges<T, D, R>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, g2acc,
+  mom_backward_edges<T, D, R, KA2>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, g2acc,
                               static_cast<const T*>(ma.wt0), beg, end, lane, sG, sY, staged_cb, static_cast<T*>(ma.g_a),
                               ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
@@ -1352,14 +1354,21 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
     size_t smem = sizeof(T) * wpb * dpair * (b.ka_lds + 64 + kSegCap);                                   \
     if (smem > 160 * 1024) return fail(AA_ERR_INVALID, #NAME ": LDS patch too large for this dtype/l_max"); \
     if (smem > 64 * 1024) {                                                                              \
-      const void* fn = pair == 0 ? (const void*)NAME##_kernel<K1, T>                                     \
-                                 : (pair == 1 ? (const void*)NAME##_kernel<K2, T> : (const void*)NAME##_kernel<K3, T>); \
+      const void* fn = pair == 0 ? (const void*)NAME##_kernel<K1, T, true>                               \
+                                 : (pair == 1 ? (const void*)NAME##_kernel<K2, T, true> : (const void*)NAME##_kernel<K3, T, true>); \
+      const void* fn1 = pair == 0 ? (const void*)NAME##_kernel<K1, T, false>                             \
+                                  : (pair == 1 ? (const void*)NAME##_kernel<K2, T, false> : (const void*)NAME##_kernel<K3, T, false>); \
       AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));      \
+      AA_CHECK_HIP(hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));     \
     }                                                                                                    \
-    switch (pair) {                                                                                      \
-      case 0: hipLaunchKernelGGL((NAME##_kernel<K1, T>), grid, dim3(64 * wpb), smem, stream, b); break;       \
-      case 1: hipLaunchKernelGGL((NAME##_kernel<K2, T>), grid, dim3(64 * wpb), smem, stream, b); break;       \
-      case 2: hipLaunchKernelGGL((NAME##_kernel<K3, T>), grid, dim3(64 * wpb), smem, stream, b); break;       \
+    const bool wide = b.ka_lds > 64;                                                                     \
+    switch (pair * 2 + (wide ? 1 : 0)) {                                                                 \
+      case 0: hipLaunchKernelGGL((NAME##_kernel<K1, T, false>), grid, dim3(64 * wpb), smem, stream, b); break; \
+      case 1: hipLaunchKernelGGL((NAME##_kernel<K1, T, true>), grid, dim3(64 * wpb), smem, stream, b); break;  \
+      case 2: hipLaunchKernelGGL((NAME##_kernel<K2, T, false>), grid, dim3(64 * wpb), smem, stream, b); break; \
+      case 3: hipLaunchKernelGGL((NAME##_kernel<K2, T, true>), grid, dim3(64 * wpb), smem, stream, b); break;  \
+      case 4: hipLaunchKernelGGL((NAME##_kernel<K3, T, false>), grid, dim3(64 * wpb), smem, stream, b); break; \
+      case 5: hipLaunchKernelGGL((NAME##_kernel<K3, T, true>), grid, dim3(64 * wpb), smem, stream, b); break;  \
       default: return fail(AA_ERR_INVALID, #NAME ": unknown chain pair");                                \
     }                                                                                                    \
     AA_CHECK_HIP(hipGetLastError());                                                                     \
