@@ -139,7 +139,7 @@ def profile_stages(model, pos, graph):
 _SYMBOLS = (("gc_", "gemm_chain_bf16x3_kernel"), ("gemm_", "gemm_bf16x3_kernel"))
 
 
-def roofline_from_stages(stages, dtype):
+def roofline_from_stages(stages, dtype, workload="c4"):
     """Aggregate the per-launch HIP-event times per kernel symbol and report the dominant symbol against its
     roofline.  Algorithmic work per launch comes from the library: every distinct operand
     row read or written once; 2*M*K*N flop per GEMM layer.  All kernels of this path are HBM-bound at their
@@ -161,6 +161,18 @@ def roofline_from_stages(stages, dtype):
     roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
                 kernel=sym, avg_launch_ms=d["ms"] / n, launches_per_step=d["launches"],
                 algorithmic_bytes_per_launch=d["bytes"] / n)
+    # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (tools/profile_gpu.sh ->
+    # tools/pmc_to_json.py, committed under profiles/): rocprofv3 cannot wrap the process from inside, so the last
+    # committed measurement of this workload is attached with its provenance
+    try:
+        pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{workload}.json")))
+        key = next((k for k in pj["per_launch"] if k in sym or sym.startswith(k)), None)
+        if key is not None:
+            e = pj["per_launch"][key]
+            roof["traffic"] = e.get("fetch_bytes", 0.0) + e.get("write_bytes", 0.0)
+            roof["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, mean per launch, {pj['source']}"
+    except (OSError, ValueError, KeyError):
+        pass
     if d["flops"] > 0:
         roof["fp32_equiv_TFLOPs"] = d["flops"] / n / t / 1e12
         roof["mfma_bf16_TFLOPs"] = (6.0 if dtype == "float32" else 1.0) * d["flops"] / n / t / 1e12
@@ -330,7 +342,7 @@ def main():
         }
         if not args.no_profile:
             stages = profile_stages(model, pos, graph)
-            roof, table = roofline_from_stages(stages, cfg["model_dtype"])
+            roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload)
             line["roofline"] = roof
             line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])
             line["stage_ms"] = table
