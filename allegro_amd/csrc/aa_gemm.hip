@@ -970,6 +970,7 @@ struct ChainDev {
 // conflict-free ds_read_b128.  Operand rows are loaded one step ahead, also across tile-pair and layer
 // boundaries; rows beyond M are clamped for loads and masked for stores.
 constexpr int kWStep = 2 * 6 * 64;  // u32x4 per staged step
+constexpr int kEpLd = 36;          // row stride (floats) of the store-transpose patch: 32 + 4 keeps b128 accesses conflict-light
 
 // PRE: layers with at most two k chunks and more than two output tiles (a chained 64-wide operand feeding a wide
 // layer) split their operand once and reuse it for every tile pair; that costs 48 VGPRs, so the variant without
@@ -993,6 +994,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
   if (c.ro_scales) rofac *= c.ro_scales[c.types[c.center[gmc]]];
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);  // [ro_n] last readout weights (a_mode 1)
   for (int i = tid; i < c.ro_n; i += 256) sRo[i] = c.ro_w[i];
+  float* sT = sRo + 32 * kChainMaxBlocks + wv * 32 * kEpLd;  // wave-private [32 rows][kEpLd] store-transpose patch
 
   // block-cooperative staging: thread t moves elements t, t+256, t+512 of the 768-element step
   auto stage_load = [&](const ChainLayerDev& L, int nt, int kc, u32x4* r) {
@@ -1098,23 +1100,36 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
         for (int r = 0; r < 16; ++r) acc[r] *= dsilu(zz[r >> 2][r & 3]);
       }
     }
-    if (d.c != nullptr && row_ok) {
-      float* p = d.c + gm * d.ldc + 4 * hh;
+    if (d.c != nullptr) {
+      // Stores go through a wave-private LDS patch so that every store instruction writes whole 128-B lines
+      // (8 lanes x 16 B per row, 8 rows): in the accumulator layout an instruction would write 32 B of each of 32
+      // lines, and partial-line writes stream ~25 % slower on this memory system (tools/ubench/gemm_steps.hip:
+      // 4.3 vs 5.3 TB/s for a copy).  Tiles are 32 features = one line wide and rows are 128-B aligned here.
+      float* st = sT + (lane & 31) * kEpLd + 4 * hh;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(st + 8 * q) = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+      __builtin_amdgcn_wave_barrier();
+      const int pr = lane >> 3, pc = 4 * (lane & 7);
+      v4f v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const v4f*>(sT + (8 * q + pr) * kEpLd + pc);
+      __builtin_amdgcn_wave_barrier();
+      float* p = d.c + (m0 + pr) * d.ldc + pc;
       if (has_old) {  // (no tile of the model's chains has both an accumulated destination and add / z operands)
         v4f old[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) old[q] = *reinterpret_cast<const v4f*>(p + 8 * q);
-#pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v4f v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += old[q][e];
-          *reinterpret_cast<v4f*>(p + 8 * q) = v;
+          const int64_t rr = m0 + pr + 8 * q < c.M ? m0 + pr + 8 * q : c.M - 1;
+          old[q] = *reinterpret_cast<const v4f*>(d.c + rr * d.ldc + pc);
         }
-      } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(p + 8 * q) = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[q][e] += old[q][e];
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (m0 + pr + 8 * q < c.M) *reinterpret_cast<v4f*>(p + int64_t(8 * q) * d.ldc) = v[q];
     }
   };
 
@@ -1334,7 +1349,7 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
   dim3 grid((unsigned)((c.M + 127) / 128));
   bool any_pre = false;
   for (int li = 0; li < d.nlayers; ++li) any_pre = any_pre || (d.L[li].KC <= 2 && d.L[li].NT > 2);
-  const size_t smem = sizeof(u32x4) * 2 * kWStep + sizeof(float) * 32 * kChainMaxBlocks;
+  const size_t smem = sizeof(u32x4) * 2 * kWStep + sizeof(float) * (32 * kChainMaxBlocks + 4 * 32 * kEpLd);
   if (any_pre)
     hipLaunchKernelGGL(gemm_chain_bf16x3_kernel<true>, grid, dim3(256), smem, stream, d);
   else
