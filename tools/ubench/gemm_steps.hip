@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ a, 
     }
     v4f a1[4];
     const int nk = kc + 1 < KC ? kc + 1 : kc;
-    if (V == 4 || V == 5) {
+    if (V == 4 || V == 5 || V == 7) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) a1[q] = a0[q] + v4f{1.f, 1.f, 1.f, 1.f};
     } else {
@@ -81,6 +81,15 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ a, 
       if (gm < M) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(out + gm * ldo + kc * 32 + 8 * q + 4 * hh) = a0[q];
+      }
+    } else if (V == 7) {
+      // full-line loads AND stores (8 lanes x 16 B per row, 8 rows per instruction): the reference streaming pattern
+      const long row = ((long)blockIdx.x * 4 + wv) * 32 + (lane >> 3);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long rr = row + 8 * q < M ? row + 8 * q : M - 1;
+        const v4f x = *reinterpret_cast<const v4f*>(a + rr * K + kc * 32 + 4 * (lane & 7));
+        if (row + 8 * q < M) *reinterpret_cast<v4f*>(out + (row + 8 * q) * ldo + kc * 32 + 4 * (lane & 7)) = x;
       }
     } else if (V == 6) {
       // same bytes, but every store instruction writes whole 128-B lines: 8 lanes x 16 B per row, 8 rows
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256) void step_kernel(const float* __restrict__ a, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) a0[q] = a1[q];
   }
-  if (V >= 1 && V != 6 && gm < M) {
+  if (V >= 1 && V != 6 && V != 7 && gm < M) {
     // NOUT_TILES tile pairs of output in the accumulator layout (the same accumulators re-stored: traffic only)
 #pragma unroll
     for (int t = 0; t < NOUT_TILES; ++t)
@@ -171,14 +180,16 @@ int main() {
   {                                                                                                                        \
     (void)hipFuncSetAttribute((const void*)step_kernel<V, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
     float ms = time_ms([&] { hipLaunchKernelGGL((step_kernel<V, NT>), grid, block, LDS, 0, a, o, wq, M, K, LDO); });       \
-    const double gb = double(M) * 4 * (K + ((V == 0 || V == 6) ? K : 64 * NT)) / 1e9;                                                 \
+    const double gb = double(M) * 4 * (K + ((V == 0 || V == 6 || V == 7) ? K : 64 * NT)) / 1e9;                                                 \
     printf("%-58s lds %3d KB: %7.3f ms  %7.1f GB/s (read K=%d + write %d cols)\n", WHAT, LDS / 1024, ms, gb / ms * 1e3, K, \
-           (V == 0 || V == 6) ? K : 64 * NT);                                                                              \
+           (V == 0 || V == 6 || V == 7) ? K : 64 * NT);                                                                              \
   }
   RUN(0, 1, 72 * 1024, 192, "v0 copy in fragment pattern")
   RUN(0, 1, 36 * 1024, 192, "v0 copy in fragment pattern (4 waves/SIMD)")
   RUN(6, 1, 72 * 1024, 192, "v6 copy, fragment loads, FULL-LINE stores")
   RUN(6, 1, 36 * 1024, 192, "v6 copy, fragment loads, FULL-LINE stores (4 waves/SIMD)")
+  RUN(7, 1, 72 * 1024, 192, "v7 copy, FULL-LINE loads and stores")
+  RUN(7, 1, 36 * 1024, 192, "v7 copy, FULL-LINE loads and stores (4 waves/SIMD)")
   RUN(1, 1, 72 * 1024, 64, "v1 read + split3 (VALU) + write 64")
   RUN(1, 3, 72 * 1024, 192, "v1 read + split3 (VALU) + write 192")
   RUN(2, 1, 72 * 1024, 64, "v2 + 24 MFMA/chunk, W in LDS, no barrier, write 64")
