@@ -153,6 +153,8 @@ struct ChainLayer {
   int keep_tile;     // first of the two output tiles kept for the next layer, or -1
   int keep_act;      // silu on the kept values
   int a_mode;        // 1: A[e,k] = ro_factor * scale(type(center e)) * ro_w[k] * silu'(a[e,k])  (readout reverse)
+  void* embrev_out;    // [M][8] or nullptr: out[e,n] = sum_c C[e,c] * emb_table[pair(e)][n][c] of this 64-wide layer -- the
+                       // reverse of the two-body basis expansion folded into the epilogue (C itself need not be stored)
   void* edge_sum_out;  // [M] or nullptr: out[e] = sum_c silu(C[e,c]) * ro_w[c] of this (64-wide) layer -- the last linear
                        // readout layer folded into the epilogue, so the edge sum reads 4 B/edge instead of a row
 };
@@ -165,6 +167,9 @@ struct ChainArgs {
   const void* ro_scales; // [T] or nullptr
   const int32_t* types;
   const int32_t* center;
+  const int32_t* nbr;       // embrev_out extras
+  const void* emb_table;    // [T*T][8][64]: type_embed(c | pair) * basis_linear[n][c]  (_edgeembed.py:70-84)
+  int num_types;
 };
 int launch_gemm_chain(const ChainArgs& c, hipStream_t stream);  // fp32 only
 // element count of the fragment-ordered copy of a [K,N] matrix, and the host-side packer
@@ -433,6 +438,7 @@ struct EdgeBwdArgs {
   const void* g_sh;    // [num_gsh][E,D] slices, summed here
   int num_gsh;
   void* forces;        // [N,3] (pre-zeroed; accumulated with atomics)
+  const void* t_in;    // [E,B] or nullptr: dE/d(Bessel x cutoff) already contracted by the producer (then g_emb0 is unused)
 };
 template <typename T>
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t stream);

@@ -298,8 +298,11 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
     for (int idx = tid; idx < B * S0; idx += 256) sWb[idx] = static_cast<const T*>(a.basis_w)[idx];
   }
   __syncthreads();
-  // phase 1: t[le][n] = sum_c g_emb0[e][c] * type_embed[c] * Wb[n][c]
-  if (fast) {
+  // phase 1: t[le][n] = sum_c g_emb0[e][c] * type_embed[c] * Wb[n][c]   (or already done by the producer: t_in)
+  if (b.t_in) {
+    if (e < a.E)
+      for (int nb = 0; nb < B; ++nb) sT[tid * (B + 1) + nb] = static_cast<const T*>(b.t_in)[e * B + nb];
+  } else if (fast) {
     // 8 lanes per edge, each owning S0/8 consecutive columns: a wave reads 8 whole rows per pass (coalesced);
     // the B partial sums are then combined across the 8 lanes
     if (S0 == 64)

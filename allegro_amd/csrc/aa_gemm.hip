@@ -947,6 +947,7 @@ struct ChainLayerDev {
   int KCg, KC, NT;  // k chunks from global memory, total k chunks (+2 chained), output tiles
   int keep_tile, keep_act, a_mode, pad_;
   float* edge_sum_out;
+  float* embrev_out;
   const float* a[kChainMaxBlocks];
   int lda[kChainMaxBlocks];
   ChainTileDev t[kChainMaxBlocks];
@@ -960,6 +961,9 @@ struct ChainDev {
   const int32_t* types;
   const int32_t* center;
   int ro_n;  // entries of ro_w used by a_mode-1 layers
+  const int32_t* nbr;
+  const float* emb_table;  // [T*T][8][64] or nullptr
+  int num_types;
   ChainLayerDev L[4];
 };
 
@@ -975,7 +979,9 @@ constexpr int kEpLd = 36;          // row stride (floats) of the store-transpose
 // PRE: layers with at most two k chunks and more than two output tiles (a chained 64-wide operand feeding a wide
 // layer) split their operand once and reuse it for every tile pair; that costs 48 VGPRs, so the variant without
 // such layers runs at 3 waves/SIMD and the one with them at 2.
-template <bool PRE>
+// EMB: the embrev_out epilogue (reverse of the two-body basis expansion) is compiled in; only the last reverse chain
+// of a step uses it, and it costs registers the other chains should not pay for.
+template <bool PRE, bool EMB>
 __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(ChainDev c) {
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);  // [2][kWStep]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -995,7 +1001,13 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);  // [ro_n] last readout weights (a_mode 1)
   for (int i = tid; i < c.ro_n; i += 256) sRo[i] = c.ro_w[i];
   float* sT = sRo + 32 * kChainMaxBlocks + wv * 32 * kEpLd;  // wave-private [32 rows][kEpLd] store-transpose patch
-
+  // two-body embedding table of this row's type pair (embrev_out)
+  const float* sTab = sRo + 32 * kChainMaxBlocks + 4 * 32 * kEpLd;  // [T*T][8][64]
+  if (EMB && c.emb_table) {
+    float* tab = const_cast<float*>(sTab);
+    for (int i = tid; i < c.num_types * c.num_types * 512; i += 256) tab[i] = c.emb_table[i];
+    sTab += (c.types[c.center[gmc]] * c.num_types + c.types[c.nbr[gmc]]) * 512;
+  }
   // block-cooperative staging: thread t moves elements t, t+256, t+512 of the 768-element step
   auto stage_load = [&](const ChainLayerDev& L, int nt, int kc, u32x4* r) {
     const size_t chunk_stride = 64 * 6, tile_stride = size_t(L.KC) * chunk_stride;
@@ -1245,6 +1257,31 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
       }
       epilogue(L.t[nt], acc0);
       if (two) epilogue(L.t[nt + 1], acc1);
+      if (EMB && L.embrev_out) {  // (64-wide layer: this is its only tile pair)
+        float part[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          float p = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f t0 = *reinterpret_cast<const v4f*>(sTab + n * 64 + 8 * q + 4 * hh);
+            const v4f t1 = *reinterpret_cast<const v4f*>(sTab + n * 64 + 32 + 8 * q + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p += acc0[4 * q + e] * t0[e] + acc1[4 * q + e] * t1[e];
+          }
+          part[n] = p;
+        }
+        float other[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) other[n] = part[n];
+        permlane32_swap4(part, other);
+        permlane32_swap4(part + 4, other + 4);
+        if (row_ok) {  // each lane half stores four of the eight sums of its row
+          const int o4 = 4 * hh;
+          *reinterpret_cast<v4f*>(L.embrev_out + gm * 8 + o4) =
+              v4f{part[o4] + other[o4], part[o4 + 1] + other[o4 + 1], part[o4 + 2] + other[o4 + 2], part[o4 + 3] + other[o4 + 3]};
+        }
+      }
       if (L.edge_sum_out) {  // (64-wide layer: this is its only tile pair)
         float part = 0.f;
 #pragma unroll
@@ -1279,6 +1316,11 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
   d.ro_scales = static_cast<const float*>(c.ro_scales);
   d.types = c.types;
   d.center = c.center;
+  d.nbr = c.nbr;
+  d.emb_table = static_cast<const float*>(c.emb_table);
+  d.num_types = c.num_types;
+  if (c.emb_table && (c.num_types < 1 || c.num_types > 2 || !c.types || !c.center || !c.nbr))
+    return fail(AA_ERR_INVALID, "gemm chain: the embedding table needs 1..2 types and the edge / type arrays");
   if (c.nlayers < 1 || c.nlayers > 4) return fail(AA_ERR_INVALID, "gemm chain: 1..4 layers");
   bool have_kept = false;
   static_assert(sizeof(ChainDev) <= 4096, "kernel argument block too large");
@@ -1340,6 +1382,8 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
       if (!c.ro_w) return fail(AA_ERR_INVALID, "gemm chain: a_mode 1 needs ro_w");
       d.ro_n = std::max(d.ro_n, nchunk * 32);
     }
+    D.embrev_out = static_cast<float*>(L.embrev_out);
+    if (L.embrev_out && (!c.emb_table || g.N != 64)) return fail(AA_ERR_INVALID, "gemm chain: embrev_out needs the table and a 64-wide layer");
     D.edge_sum_out = static_cast<float*>(L.edge_sum_out);
     if (L.edge_sum_out) {
       if (!c.ro_w || g.N != 64) return fail(AA_ERR_INVALID, "gemm chain: edge_sum_out needs ro_w and a 64-wide layer");
@@ -1349,11 +1393,17 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
   dim3 grid((unsigned)((c.M + 127) / 128));
   bool any_pre = false;
   for (int li = 0; li < d.nlayers; ++li) any_pre = any_pre || (d.L[li].KC <= 2 && d.L[li].NT > 2);
-  const size_t smem = sizeof(u32x4) * 2 * kWStep + sizeof(float) * (32 * kChainMaxBlocks + 4 * 32 * kEpLd);
-  if (any_pre)
-    hipLaunchKernelGGL(gemm_chain_bf16x3_kernel<true>, grid, dim3(256), smem, stream, d);
-  else
-    hipLaunchKernelGGL(gemm_chain_bf16x3_kernel<false>, grid, dim3(256), smem, stream, d);
+  const size_t smem = sizeof(u32x4) * 2 * kWStep + sizeof(float) * (32 * kChainMaxBlocks + 4 * 32 * kEpLd) +
+                      (c.emb_table ? sizeof(float) * 512 * c.num_types * c.num_types : 0);
+  bool emb = false;
+  for (int li = 0; li < d.nlayers; ++li) emb = emb || d.L[li].embrev_out != nullptr;
+#define AA_CHAIN_LAUNCH(P_, E_) hipLaunchKernelGGL((gemm_chain_bf16x3_kernel<P_, E_>), grid, dim3(256), smem, stream, d)
+  if (any_pre) {
+    if (emb) AA_CHAIN_LAUNCH(true, true); else AA_CHAIN_LAUNCH(true, false);
+  } else {
+    if (emb) AA_CHAIN_LAUNCH(false, true); else AA_CHAIN_LAUNCH(false, false);
+  }
+#undef AA_CHAIN_LAUNCH
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }

@@ -118,6 +118,9 @@ struct aa_model_plan {
   bool env_mom;                      // env weights through per-atom moments: no [E,R*u] env tensors (TpMomArgs / TpOpArgs)
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
+  bool embed_fused;                  // reverse pass: d(two-body embedding) [E,S0] never materialised, the last reverse chain
+                                     // contracts it back to the 8 basis functions in its epilogue (embrev_out in aa_common.h)
+  size_t o_embtab;                   // [T*T][8][64] type_embed(c | pair) * basis_linear[n][c]
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
@@ -260,6 +263,11 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     p->o_ro_last = take(p->ro_last_dim);
   }
   p->o_b3a_q = p->o_b3b_q = p->o_b3c_q = 0;
+  {
+    const char* nf = getenv("AA_EMBED_NOFUSE");
+    p->embed_fused = p->chain_gemm && T <= 2 && B == 8 && S0 == 64 && !(nf && nf[0] == '1');
+    p->o_embtab = p->embed_fused ? take(size_t(T) * T * 8 * 64) : 0;
+  }
   if (p->chain_gemm) {
     // merged reverse chain "readout' o latent_{L-1}'" (see Runner::backward): the readout-reverse columns that feed
     // the last latent, and [readout-reverse columns of the earlier features (zero-padded) ; latent-reverse] stacked
@@ -390,6 +398,16 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     AA_REQUIRE(raw->shifts, "pack: missing shifts");
     copy(p->o_shifts, raw->shifts, T, 1.0);
   }
+  if (p->embed_fused) {
+    const int half = S0 / 2;
+    for (int ti = 0; ti < T; ++ti)
+      for (int tj = 0; tj < T; ++tj)
+        for (int n = 0; n < B; ++n)
+          for (int cc = 0; cc < S0; ++cc) {
+            const double te = cc < half ? h[p->o_cemb + size_t(ti) * half + cc] : h[p->o_nemb + size_t(tj) * half + (cc - half)];
+            h[p->o_embtab + ((size_t(ti) * T + tj) * B + n) * S0 + cc] = te * h[p->o_basis + size_t(n) * S0 + cc];
+          }
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c.dtype == AA_F64) {
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
@@ -439,7 +457,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, trev;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -493,6 +511,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   }
   for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
   if (p->chain_gemm) w.e_edge = take(Ez);
+  if (p->embed_fused) w.trev = take(Ez * 8);
   if (with_forces) {
     w.g_fcat = take(Ez * p->SL1);
     for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
@@ -1205,6 +1224,16 @@ struct Runner {
       ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0tq), p->ng0, S, cn, nullptr, nullptr, &ad, 0, 0, 0);
       ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wtq[1]), S, 64, cn, nullptr, &zz, nullptr, 1, 0, 0);
       ca.L[2] = chain_layer(E, none, 0, wt(p->embed.wtq[0]), 64, c.embed_dim, ce, nullptr, nullptr, nullptr, 1, -1, 0);
+      if (p->embed_fused) {
+        // d emb0 is contracted straight back to the 8 basis functions in the epilogue and never stored
+        ca.L[2].g.c = SegList{1, {seg(nullptr, c.embed_dim, c.embed_dim)}};
+        ca.L[2].embrev_out = buf(w.trev);
+        ca.emb_table = wt(p->o_embtab);
+        ca.num_types = c.num_types;
+        ca.types = g->types;
+        ca.center = g->center;
+        ca.nbr = g->nbr;
+      }
       if (int rc = run_chain(ca, "B1")) return rc;
     } else {
     // fused first stage reverse
@@ -1230,8 +1259,9 @@ struct Runner {
     eb.g_sh = buf(w.g_sh);
     eb.num_gsh = num_gsh_slots(p);
     eb.forces = forces;
+    if (p->embed_fused) eb.t_in = buf(w.trev);
     if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
-    return mark("edge_backward", 8.0 / sizeof(T) + 4 + c.embed_dim + double(num_gsh) * p->D + 6);
+    return mark("edge_backward", 8.0 / sizeof(T) + 4 + (p->embed_fused ? c.num_bessels : c.embed_dim) + double(num_gsh) * p->D + 6);
   }
 };
 
