@@ -439,7 +439,17 @@ struct EdgeBwdArgs {
   int num_gsh;
   void* forces;        // [N,3] (pre-zeroed; accumulated with atomics)
   const void* t_in;    // [E,B] or nullptr: dE/d(Bessel x cutoff) already contracted by the producer (then g_emb0 is unused)
+  void* dvec;          // [E,4] or nullptr: if set, dE/dr_e is stored here instead of being scattered with atomics
 };
+// F[n] = sum_{e in seg(n)} d[e] - sum_{e: nbr(e) = n} d[e], gathered in a fixed order (deterministic)
+struct ForceGatherArgs {
+  int64_t N;
+  const int32_t *rowptr, *t_rowptr, *t_perm;
+  const void* dvec;  // [E,4]
+  void* forces;      // [N,3]
+};
+template <typename T>
+int launch_force_gather(const ForceGatherArgs& a, hipStream_t stream);
 template <typename T>
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t stream);
 

@@ -365,11 +365,20 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
     fx = dx;
     fy = dy;
     fz = dz;
-    T* F = static_cast<T*>(b.forces);
-    atomicAdd(&F[3 * int64_t(j)], -dx);
-    atomicAdd(&F[3 * int64_t(j) + 1], -dy);
-    atomicAdd(&F[3 * int64_t(j) + 2], -dz);
+    if (b.dvec) {
+      T* dv = static_cast<T*>(b.dvec) + 4 * e;
+      dv[0] = dx;
+      dv[1] = dy;
+      dv[2] = dz;
+      dv[3] = T(0);
+    } else {
+      T* F = static_cast<T*>(b.forces);
+      atomicAdd(&F[3 * int64_t(j)], -dx);
+      atomicAdd(&F[3 * int64_t(j) + 1], -dy);
+      atomicAdd(&F[3 * int64_t(j) + 2], -dz);
+    }
   }
+  if (b.dvec) return;  // force_gather_kernel sums them per atom
   // center-atom contributions: the edges are sorted by center, so the lanes of a wave hold runs of equal centers;
   // a segmented shuffle sum leaves one atomic per run instead of one per edge (same-address atomics serialise)
   {
@@ -391,6 +400,40 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
       atomicAdd(&F[3 * int64_t(ci) + 1], fy);
       atomicAdd(&F[3 * int64_t(ci) + 2], fz);
     }
+  }
+}
+
+// 8 lanes per atom walk its own segment (+d) and its transposed segment (-d) in a fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void force_gather_kernel(ForceGatherArgs a) {
+  const int sub = threadIdx.x & 7;
+  const int64_t n = (int64_t(blockIdx.x) * 256 + threadIdx.x) >> 3;
+  T fx = T(0), fy = T(0), fz = T(0);
+  if (n < a.N) {
+    const T* dv = static_cast<const T*>(a.dvec);
+    for (int e = a.rowptr[n] + sub; e < a.rowptr[n + 1]; e += 8) {
+      fx += dv[4 * int64_t(e)];
+      fy += dv[4 * int64_t(e) + 1];
+      fz += dv[4 * int64_t(e) + 2];
+    }
+    for (int k = a.t_rowptr[n] + sub; k < a.t_rowptr[n + 1]; k += 8) {
+      const int64_t e = a.t_perm[k];
+      fx -= dv[4 * e];
+      fy -= dv[4 * e + 1];
+      fz -= dv[4 * e + 2];
+    }
+  }
+#pragma unroll
+  for (int m = 4; m >= 1; m >>= 1) {
+    fx += __shfl_xor(fx, m);
+    fy += __shfl_xor(fy, m);
+    fz += __shfl_xor(fz, m);
+  }
+  if (n < a.N && sub == 0) {
+    T* F = static_cast<T*>(a.forces) + 3 * n;
+    F[0] = fx;
+    F[1] = fy;
+    F[2] = fz;
   }
 }
 
@@ -459,6 +502,14 @@ int launch_edge_backward(const EdgeBwdArgs& b, hipStream_t stream) {
 }
 
 template <typename T>
+int launch_force_gather(const ForceGatherArgs& a, hipStream_t stream) {
+  if (a.N == 0) return AA_OK;
+  hipLaunchKernelGGL(force_gather_kernel<T>, dim3((unsigned)((a.N * 8 + 255) / 256)), dim3(256), 0, stream, a);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+template <typename T>
 int launch_readout_reduce(const ReadoutArgs& a, hipStream_t stream) {
   if (a.N == 0) return AA_OK;
   hipLaunchKernelGGL(readout_reduce_kernel<T>, dim3((unsigned)((a.N + 3) / 4)), dim3(256), 0, stream, a);
@@ -479,6 +530,7 @@ int launch_readout_backward(const ReadoutArgs& a, hipStream_t stream) {
 #define AA_INST(T)                                                              \
   template int launch_edge_prologue<T>(const EdgeGeomArgs&, hipStream_t);      \
   template int launch_edge_backward<T>(const EdgeBwdArgs&, hipStream_t);       \
+  template int launch_force_gather<T>(const ForceGatherArgs&, hipStream_t);    \
   template int launch_readout_reduce<T>(const ReadoutArgs&, hipStream_t);      \
   template int launch_readout_backward<T>(const ReadoutArgs&, hipStream_t);
 AA_INST(float)

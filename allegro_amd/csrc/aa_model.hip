@@ -457,7 +457,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, trev;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, trev, dvec;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -512,6 +512,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
   if (p->chain_gemm) w.e_edge = take(Ez);
   if (p->embed_fused) w.trev = take(Ez * 8);
+  if (with_forces) w.dvec = take(Ez * 4);
   if (with_forces) {
     w.g_fcat = take(Ez * p->SL1);
     for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
@@ -1008,7 +1009,7 @@ struct Runner {
     const bool gsh_stores = (p->use_spec && u <= 64) || p->tp_op >= 0;
     const int num_gsh = num_gsh_slots(p);
     if (!gsh_stores) AA_CHECK_HIP(hipMemsetAsync(buf(w.g_sh), 0, size_t(E) * p->D * num_gsh * sizeof(T), stream));
-    AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
+    if (!(g->t_rowptr && g->t_perm)) AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
     if (int rc = mark("memset", gsh_stores ? 0 : p->D * num_gsh, 3)) return rc;
     const SegList none{0, {}};
     if (p->chain_gemm) {
@@ -1260,8 +1261,17 @@ struct Runner {
     eb.num_gsh = num_gsh_slots(p);
     eb.forces = forces;
     if (p->embed_fused) eb.t_in = buf(w.trev);
+    const bool gather = g->t_rowptr && g->t_perm;
+    if (gather) eb.dvec = buf(w.dvec);
     if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
-    return mark("edge_backward", 8.0 / sizeof(T) + 4 + (p->embed_fused ? c.num_bessels : c.embed_dim) + double(num_gsh) * p->D + 6);
+    if (int rc = mark("edge_backward", 8.0 / sizeof(T) + 4 + (p->embed_fused ? c.num_bessels : c.embed_dim) + double(num_gsh) * p->D + (gather ? 4 : 6))) return rc;
+    if (gather) {
+      // deterministic force assembly: per atom, own segment minus transposed segment, fixed order (no atomics)
+      ForceGatherArgs fg{N, g->rowptr, g->t_rowptr, g->t_perm, buf(w.dvec), forces};
+      if (int rc = launch_force_gather<T>(fg, stream)) return rc;
+      return mark("force_gather", 8.0 + 4.0 / sizeof(T), 3 + 8.0 / sizeof(T));
+    }
+    return AA_OK;
   }
 };
 

@@ -280,7 +280,7 @@ class PreparedGraph:
     """Device-resident center-sorted CSR view of an edge list (the `aa_graph` struct)."""
 
     def __init__(self, edge_index: torch.Tensor, atom_types: torch.Tensor, num_atoms: int,
-                 shift_vec: Optional[torch.Tensor] = None):
+                 shift_vec: Optional[torch.Tensor] = None, transposed: bool = True):
         center = edge_index[0]
         self.perm = None
         if center.numel() > 1 and not bool((center[1:] >= center[:-1]).all()):
@@ -296,11 +296,20 @@ class PreparedGraph:
         self.rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         self.types = atom_types.reshape(-1).to(torch.int32).contiguous()
         self.shift_vec = None if shift_vec is None else shift_vec.contiguous()
+        # transposed CSR (edges grouped by neighbor): lets the library gather forces per atom in a fixed order
+        # (bit-reproducible); without it neighbor contributions are accumulated with floating-point atomics
+        self.t_perm = self.t_rowptr = None
+        if transposed:
+            self.t_perm = torch.argsort(edge_index[1], stable=True).to(torch.int32).contiguous()
+            self.t_rowptr = torch.zeros(num_atoms + 1, dtype=torch.int32, device=edge_index.device)
+            self.t_rowptr[1:] = torch.cumsum(torch.bincount(edge_index[1], minlength=num_atoms), 0).to(torch.int32)
 
     def c_struct(self) -> _lib.Graph:
         return _lib.Graph(self.num_atoms, self.num_edges, self.center.data_ptr(), self.nbr.data_ptr(),
                           self.rowptr.data_ptr(), self.types.data_ptr(),
-                          self.shift_vec.data_ptr() if self.shift_vec is not None else None)
+                          self.shift_vec.data_ptr() if self.shift_vec is not None else None,
+                          self.t_rowptr.data_ptr() if self.t_rowptr is not None else None,
+                          self.t_perm.data_ptr() if self.t_perm is not None else None)
 
 
 class HipAllegroModel(torch.nn.Module):

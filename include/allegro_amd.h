@@ -130,6 +130,10 @@ typedef struct {
   const int32_t* types;    /* [N]                                                              */
   const void* shift_vec;   /* [E,3] cartesian periodic shift (model dtype) or NULL (ghost layout,
                               allegro/_compile.py:28-63)                                       */
+  /* optional transposed CSR (edge ids grouped by NEIGHBOR atom): with it the forces are gathered per atom in a
+   * fixed order (bit-reproducible, no atomics); NULL/NULL: neighbor contributions use floating-point atomics */
+  const int32_t* t_rowptr; /* [N+1] or NULL                                                    */
+  const int32_t* t_perm;   /* [E] edge ids sorted by neighbor (stable), or NULL                */
 } aa_graph;
 
 typedef struct aa_model_plan aa_model_plan;

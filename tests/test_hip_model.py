@@ -333,3 +333,19 @@ def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, dev, monkeyp
         err_hip = (got.double() - w64).abs().max().item()
         err_cpu32 = (w32.double() - w64).abs().max().item()
         assert err_hip <= 2.0 * err_cpu32 + 1e-5 * scale, (err_hip, err_cpu32, scale)
+
+
+def test_force_gather_is_deterministic_and_matches_atomics(dev):
+    """With the transposed CSR the forces are gathered per atom in a fixed order: bit-identical across runs; the
+    atomic fallback (no transposed CSR) agrees to rounding."""
+    from allegro_amd.nn import PreparedGraph
+
+    fx = load_model_fixture("c2", torch.float32)
+    m, g, _, _ = _run(fx, torch.float32, dev)
+    data, sv = fixture_data(fx, torch.float32, dev)
+    pos = data["pos"]
+    runs = [m.energy_forces(pos, g)[1].clone() for _ in range(3)]
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    g_at = PreparedGraph(data["edge_index"], data["atom_types"], pos.shape[0], sv, transposed=False)
+    f_at = m.energy_forces(pos, g_at)[1]
+    assert (f_at - runs[0]).abs().max().item() <= 2e-5 * max(1.0, float(runs[0].abs().max()))
