@@ -338,17 +338,43 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
     __syncthreads();
     buf ^= 1;
   }
+  // epilogue: a 16-column tile never straddles a C segment here (widths are multiples of 16, checked by the
+  // launcher), so the destination / z / add rows are resolved once per tile, wave-uniformly
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 4; ++j) {
+    const int t0 = n0 + j * 16;
+    if (t0 >= g.N) continue;
+    int cc = t0, si = -1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gn = n0 + j * 16 + (lane & 15);
+    for (int s2 = 0; s2 < 3; ++s2) {
+      if (s2 < g.c.count && si < 0) {
+        if (cc < g.c.s[s2].n)
+          si = s2;
+        else
+          cc -= g.c.s[s2].n;
+      }
+    }
+    if (si < 0) continue;
+    double* cp = static_cast<double*>(g.c.s[si].p);
+    if (!cp) continue;
+    const int ldc = g.c.s[si].ld, col = cc + (lane & 15);
+    const double* zp = g.has_z ? static_cast<const double*>(g.z.s[si].p) : nullptr;
+    const double* ap = g.has_add ? static_cast<const double*>(g.add.s[si].p) : nullptr;
+    const int ldz = g.has_z ? g.z.s[si].ld : 0, lda2 = g.has_add ? g.add.s[si].ld : 0;
+    const bool accum = g.c_accum[si] != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t gm = m0 + wv * 32 + i * 16 + 4 * r + (lane >> 4);
-        if (gm < g.M && gn < g.N) seg_store<double>(g, gm, gn, acc[i][j][r]);
+        if (gm >= g.M) continue;
+        double v = acc[i][j][r];
+        if (ap) v += ap[gm * lda2 + col];
+        if (zp) v *= dsilu(zp[gm * ldz + col]);
+        if (accum) v += cp[gm * ldc + col];
+        cp[gm * ldc + col] = v;
       }
-    }
+  }
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1567,6 +1593,7 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   bool pipe_ok = (g.N % 2) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
   for (int s2 = 0; s2 < g.a.count; ++s2)
     pipe_ok = pipe_ok && (g.a.s[s2].n % 16) == 0 && (g.a.s[s2].ld % 2) == 0 && (reinterpret_cast<uintptr_t>(g.a.s[s2].p) & 15) == 0;
+  for (int s2 = 0; s2 < g.c.count; ++s2) pipe_ok = pipe_ok && (g.c.s[s2].n % 16) == 0;
   if (force_valu()) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok) {
