@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--gpu-reference", action="store_true", help="also time the eager PyTorch-ROCm oracle path on the GPU")
     ap.add_argument("--stages", action="store_true", help="also print every launch of one step with its HIP-event time")
+    ap.add_argument("--emulate-shard", default=None, metavar="R/W",
+                    help="analysis only: run rank R's atom block of a W-way partition on this one GPU (no collective)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,6 +290,10 @@ def main():
     rowptr = G.csr_from_sorted_centers(g.edge_index[0], N)
     cuts = partition_atoms(rowptr, world)
     a0, a1 = cuts[rank], cuts[rank + 1]
+    if args.emulate_shard:
+        er, ew = (int(x) for x in args.emulate_shard.split("/"))
+        cuts = partition_atoms(rowptr, ew)
+        a0, a1 = cuts[er], cuts[er + 1]
     e0, e1 = int(rowptr[a0]), int(rowptr[a1])
     ei_local = torch.tensor(g.edge_index[:, e0:e1], device=dev)
     sv = g.shift_vec()
