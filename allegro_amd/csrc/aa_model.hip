@@ -124,6 +124,21 @@ struct aa_model_plan {
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
+  // optional hipGraph replay of the whole step (aa_model_plan_enable_graph): the launch sequence is captured once per
+  // distinct argument set and replayed with one hipGraphLaunch -- for launch-bound (small) systems
+  struct StepGraph {
+    bool enabled = false;
+    hipStream_t cap_stream = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    struct Key {
+      const void *weights, *pos, *ws, *e, *f, *center, *nbr, *rowptr, *types, *shift, *trow, *tperm;
+      int64_t N, E;
+      size_t wsb;
+      bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
+    } key{};
+  };
+  mutable StepGraph sg;
 };
 
 static std::vector<int> mlp_dims(int in, int depth, int width, int out) {
@@ -282,8 +297,23 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   return AA_OK;
 }
 
+extern "C" int aa_model_plan_enable_graph(aa_model_plan* plan, int on) {
+  AA_REQUIRE(plan, "aa_model_plan_enable_graph: null plan");
+  aa_model_plan::StepGraph& g = plan->sg;
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr;
+  g.graph = nullptr;
+  g.enabled = on != 0;
+  if (g.enabled && !g.cap_stream) AA_CHECK_HIP(hipStreamCreateWithFlags(&g.cap_stream, hipStreamNonBlocking));
+  return AA_OK;
+}
+
 extern "C" void aa_model_plan_destroy(aa_model_plan* plan) {
   if (!plan) return;
+  if (plan->sg.exec) (void)hipGraphExecDestroy(plan->sg.exec);
+  if (plan->sg.graph) (void)hipGraphDestroy(plan->sg.graph);
+  if (plan->sg.cap_stream) (void)hipStreamDestroy(plan->sg.cap_stream);
   for (void* q : plan->owned) (void)hipFree(q);
   delete plan;
 }
@@ -1304,9 +1334,31 @@ extern "C" int aa_model_energy_forces(const aa_model_plan* plan, const void* dev
   AA_REQUIRE(graph->rowptr && graph->types, "aa_model_energy_forces: null rowptr/types");
   AA_REQUIRE(workspace || workspace_bytes == 0, "aa_model_energy_forces: null workspace");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (plan->cfg.dtype == AA_F32)
-    return run_model<float>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s);
-  return run_model<double>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, s);
+  auto run = [&](hipStream_t st) {
+    if (plan->cfg.dtype == AA_F32)
+      return run_model<float>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, st);
+    return run_model<double>(plan, dev_weights, graph, pos, workspace, workspace_bytes, atom_energy, forces, st);
+  };
+  aa_model_plan::StepGraph& sg = plan->sg;
+  if (!sg.enabled) return run(s);
+  const aa_model_plan::StepGraph::Key key{dev_weights,    pos,           workspace,     atom_energy,      forces,          graph->center,
+                                          graph->nbr,     graph->rowptr, graph->types,  graph->shift_vec, graph->t_rowptr, graph->t_perm,
+                                          graph->num_atoms, graph->num_edges, workspace_bytes};
+  if (!sg.exec || !(sg.key == key)) {
+    if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
+    if (sg.graph) (void)hipGraphDestroy(sg.graph);
+    sg.exec = nullptr;
+    sg.graph = nullptr;
+    AA_CHECK_HIP(hipStreamBeginCapture(sg.cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = run(sg.cap_stream);
+    const hipError_t ec = hipStreamEndCapture(sg.cap_stream, &sg.graph);
+    if (rc != AA_OK) return rc;
+    if (ec != hipSuccess) return fail(AA_ERR_HIP, "aa_model_energy_forces: graph capture failed");
+    AA_CHECK_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+    sg.key = key;
+  }
+  AA_CHECK_HIP(hipGraphLaunch(sg.exec, s));
+  return AA_OK;
 }
 
 extern "C" int aa_model_energy_forces_profiled(const aa_model_plan* plan, const void* dev_weights, const aa_graph* graph,

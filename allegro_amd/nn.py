@@ -556,14 +556,31 @@ class HipAllegroModel(torch.nn.Module):
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != pos.device:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=pos.device)
         pos = pos.detach().contiguous()
-        e_atom = torch.empty(N, dtype=self.dtype, device=pos.device)
-        forces = torch.empty((N, 3), dtype=self.dtype, device=pos.device) if with_forces else None
+        if getattr(self, "_hip_graph", False):
+            # replay mode: outputs live in persistent buffers so that every argument of the step keeps its address
+            # (the caller updates `pos` in place and reads the results before the next call)
+            if getattr(self, "_out", None) is None or self._out[0].shape[0] != N or self._out[0].device != pos.device:
+                self._out = (torch.empty(N, dtype=self.dtype, device=pos.device),
+                             torch.empty((N, 3), dtype=self.dtype, device=pos.device))
+            e_atom, forces = self._out[0], (self._out[1] if with_forces else None)
+        else:
+            e_atom = torch.empty(N, dtype=self.dtype, device=pos.device)
+            forces = torch.empty((N, 3), dtype=self.dtype, device=pos.device) if with_forces else None
         g = graph.c_struct()
         lib.check(lib.lib.aa_model_energy_forces(self._plan_handle, self._blob.data_ptr(), C.byref(g), pos.data_ptr(),
                                                  self._workspace.data_ptr(), self._workspace.numel(), e_atom.data_ptr(),
                                                  forces.data_ptr() if with_forces else None, _stream_ptr(pos)),
                   "aa_model_energy_forces")
         return e_atom, forces
+
+    def enable_hip_graph(self, on: bool = True) -> None:
+        """Capture the step's launch sequence into a hipGraph and replay it (aa_model_plan_enable_graph): for
+        launch-bound small systems in MD loops.  `pos` must then be updated in place between calls."""
+        lib = self._get_lib()
+        self._ensure_plan()
+        lib.check(lib.lib.aa_model_plan_enable_graph(self._plan_handle, int(on)), "aa_model_plan_enable_graph")
+        self._hip_graph = bool(on)
+        self._out = None
 
     def debug_tap(self, name: str, graph: PreparedGraph) -> torch.Tensor:
         lib = self._get_lib()

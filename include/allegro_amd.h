@@ -140,6 +140,10 @@ typedef struct aa_model_plan aa_model_plan;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);
 void aa_model_plan_destroy(aa_model_plan* plan);
+/* on != 0: aa_model_energy_forces captures its launch sequence into a hipGraph the first time it sees a set of
+ * arguments (all pointers and sizes) and replays it with one hipGraphLaunch afterwards -- for launch-bound (small)
+ * systems in MD loops whose buffers stay put.  The plan then carries mutable state: one caller thread per plan. */
+int aa_model_plan_enable_graph(aa_model_plan* plan, int on);
 
 /* size of the packed device weight blob, and packing (host fp64 -> device model dtype, with the
  * ScalarMLPFunction normalisation constants folded and the two linear maps of the first stage

@@ -54,6 +54,18 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+// hipGraph API: not emulated (aa_model_plan_enable_graph reports an error under the emulator)
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum { hipStreamNonBlocking = 1, hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned) { return 801; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 801; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return 801; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return 801; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 801; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 typedef int hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return 0; }

@@ -349,3 +349,27 @@ def test_force_gather_is_deterministic_and_matches_atomics(dev):
     g_at = PreparedGraph(data["edge_index"], data["atom_types"], pos.shape[0], sv, transposed=False)
     f_at = m.energy_forces(pos, g_at)[1]
     assert (f_at - runs[0]).abs().max().item() <= 2e-5 * max(1.0, float(runs[0].abs().max()))
+
+
+def test_hip_graph_replay_matches_direct_launches(dev):
+    """aa_model_plan_enable_graph: the captured launch sequence replays bit-identically, follows in-place position
+    updates, and is re-captured when an argument (here: the graph) changes."""
+    fx = load_model_fixture("c2", torch.float32)
+    m, g, _, _ = _run(fx, torch.float32, dev)
+    data, sv = fixture_data(fx, torch.float32, dev)
+    pos = data["pos"].clone()
+    e0, f0 = (t.clone() for t in m.energy_forces(pos, g))
+    m.enable_hip_graph(True)
+    try:
+        for _ in range(3):
+            e1, f1 = m.energy_forces(pos, g)
+            assert torch.equal(e1, e0) and torch.equal(f1, f0)
+        pos.add_(0.01 * torch.randn_like(pos))  # in place: same address, new values
+        e2, f2 = (t.clone() for t in m.energy_forces(pos, g))
+        g2 = m.prepare_graph(data["edge_index"], data["atom_types"], pos.shape[0], sv)  # new buffers -> re-capture
+        e3, f3 = (t.clone() for t in m.energy_forces(pos, g2))
+    finally:
+        m.enable_hip_graph(False)
+    e4, f4 = m.energy_forces(pos, g)
+    assert not torch.equal(f2, f0)
+    assert torch.equal(e2, e4) and torch.equal(f2, f4) and torch.equal(e3, e4) and torch.equal(f3, f4)
