@@ -27,7 +27,6 @@ namespace aa {
 namespace {
 
 constexpr int kOpMaxD = 31;   // widest irreps vector on the track (l_max 3, L 3: 0e+1e+1o+2e+2o+3e+3o)
-constexpr int kOpMaxP = 34;   // most paths of one layer
 constexpr int kOpMaxKa = 128; // widest env input
 
 struct NoSig {};
