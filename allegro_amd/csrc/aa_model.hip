@@ -247,7 +247,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     const char* ncg = getenv("AA_GEMM_NOCHAIN");
     const char* f32 = getenv("AA_GEMM_FP32_MFMA");
     const char* vl = getenv("AA_GEMM_VALU");
-    p->chain_gemm = p->env_mom && p->tp_op < 0 && cfg->dtype == AA_F32 && S == 64 && cfg->embed_mlp_depth == 1 &&
+    p->chain_gemm = p->env_mom && (p->tp_op < 0 || u == 64) && cfg->dtype == AA_F32 && S == 64 && cfg->embed_mlp_depth == 1 &&
                     cfg->embed_mlp_width == 64 && cfg->latent_mlp_depth == 1 && cfg->latent_mlp_width == 64 &&
                     cfg->readout_mlp_depth == 1 && cfg->readout_mlp_width == 64 && cfg->embed_dim % 32 == 0 &&
                     !(ncg && ncg[0] == '1') && !(f32 && f32[0] == '1') && !(vl && vl[0] == '1');
