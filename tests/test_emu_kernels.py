@@ -157,3 +157,22 @@ def test_operator_path_vs_oracle(l_max, L, u, S, force, monkeypatch):
     ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, torch.tensor(shift @ cell))
     assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9 * max(1.0, float(ref["atomic_energy"].abs().max()))
     assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64"])
+def test_graph_without_edges_gives_shifts_and_zero_forces(dt):
+    """Empty edge list (every atom isolated): E_i = per-type shift, F = 0; no kernel may touch an edge."""
+    from allegro_amd.nn import HipAllegroModel
+
+    cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=2, num_layers=2, num_scalar_features=64, num_tensor_features=64,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               radial_chemical_embed_dim=64, scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=64,
+               readout_mlp_hidden_layers_width=64, avg_num_neighbors=10.0, seed=11, model_dtype=dt,
+               per_type_energy_shifts=[1.5, -2.0])
+    tdt = torch.float64 if dt == "float64" else torch.float32
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    pos = torch.tensor([[0.0, 0, 0], [10, 0, 0], [0, 10, 0]], dtype=tdt)
+    g = m.prepare_graph(torch.zeros((2, 0), dtype=torch.long), torch.tensor([0, 1, 0]), 3, None)
+    e, f = m.energy_forces(pos, g)
+    assert e.tolist() == [1.5, -2.0, 1.5] and float(f.abs().max()) == 0.0

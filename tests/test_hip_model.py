@@ -373,3 +373,19 @@ def test_hip_graph_replay_matches_direct_launches(dev):
     e4, f4 = m.energy_forces(pos, g)
     assert not torch.equal(f2, f0)
     assert torch.equal(e2, e4) and torch.equal(f2, f4) and torch.equal(e3, e4) and torch.equal(f3, f4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_graph_without_edges_gives_shifts_and_zero_forces(dtype, dev):
+    from allegro_amd.nn import HipAllegroModel
+
+    cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=2, num_layers=2, num_scalar_features=64, num_tensor_features=64,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               radial_chemical_embed_dim=64, scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=64,
+               readout_mlp_hidden_layers_width=64, avg_num_neighbors=10.0, seed=11,
+               model_dtype={torch.float64: "float64", torch.float32: "float32"}[dtype], per_type_energy_shifts=[1.5, -2.0])
+    m = HipAllegroModel(**cfg).to(dev)
+    pos = torch.tensor([[0.0, 0, 0], [10, 0, 0], [0, 10, 0]], dtype=dtype, device=dev)
+    g = m.prepare_graph(torch.zeros((2, 0), dtype=torch.long, device=dev), torch.tensor([0, 1, 0], device=dev), 3, None)
+    e, f = m.energy_forces(pos, g)
+    assert e.cpu().tolist() == [1.5, -2.0, 1.5] and float(f.abs().max()) == 0.0
