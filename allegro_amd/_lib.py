@@ -81,6 +81,8 @@ class AllegroLib:
         L.aa_model_plan_destroy.restype = None
         L.aa_model_plan_enable_graph.argtypes = [C.c_void_p, C.c_int]
         L.aa_model_plan_enable_graph.restype = C.c_int
+        L.aa_model_virial.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.aa_model_virial.restype = C.c_int
         L.aa_model_weights_bytes.argtypes = [C.c_void_p]
         L.aa_model_weights_bytes.restype = C.c_size_t
         L.aa_model_pack_weights.argtypes = [C.c_void_p, C.POINTER(RawWeights), C.c_void_p, C.c_size_t, C.c_void_p]

@@ -439,8 +439,20 @@ struct EdgeBwdArgs {
   int num_gsh;
   void* forces;        // [N,3] (pre-zeroed; accumulated with atomics)
   const void* t_in;    // [E,B] or nullptr: dE/d(Bessel x cutoff) already contracted by the producer (then g_emb0 is unused)
-  void* dvec;          // [E,4] or nullptr: if set, dE/dr_e is stored here instead of being scattered with atomics
+  void* dvec;          // [E,4] or nullptr: dE/dr_e per edge (always written when set; aa_model_virial reads it too)
+  int gather;          // 1: forces are assembled by force_gather_kernel from dvec; 0: scattered here with atomics
 };
+// W[a][b] = sum_e d[e][a] * r_e[b]   (strain derivative of the energy; r_e = vec[e].xyz * vec[e].w)
+struct VirialArgs {
+  int64_t E;
+  const void* dvec;  // [E,4]
+  const void* vec;   // [E,4] unit vector, length
+  double* partial;   // [kVirialBlocks][9] scratch
+  void* out;         // [9] model dtype
+};
+constexpr int kVirialBlocks = 512;
+template <typename T>
+int launch_virial(const VirialArgs& a, hipStream_t stream);
 // F[n] = sum_{e in seg(n)} d[e] - sum_{e: nbr(e) = n} d[e], gathered in a fixed order (deterministic)
 struct ForceGatherArgs {
   int64_t N;

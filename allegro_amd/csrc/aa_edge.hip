@@ -371,14 +371,15 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
       dv[1] = dy;
       dv[2] = dz;
       dv[3] = T(0);
-    } else {
+    }
+    if (!b.gather) {
       T* F = static_cast<T*>(b.forces);
       atomicAdd(&F[3 * int64_t(j)], -dx);
       atomicAdd(&F[3 * int64_t(j) + 1], -dy);
       atomicAdd(&F[3 * int64_t(j) + 2], -dz);
     }
   }
-  if (b.dvec) return;  // force_gather_kernel sums them per atom
+  if (b.gather) return;  // force_gather_kernel sums them per atom
   // center-atom contributions: the edges are sorted by center, so the lanes of a wave hold runs of equal centers;
   // a segmented shuffle sum leaves one atomic per run instead of one per edge (same-address atomics serialise)
   {
@@ -501,6 +502,50 @@ int launch_edge_backward(const EdgeBwdArgs& b, hipStream_t stream) {
   return AA_OK;
 }
 
+// strain derivative: per-block partial sums in double (fixed order), then one block adds the partials
+template <typename T>
+__global__ __launch_bounds__(256) void virial_partial_kernel(VirialArgs a) {
+  double* sP = reinterpret_cast<double*>(aa_smem);  // [256][9]
+  double w[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) w[k] = 0.0;
+  const T* dv = static_cast<const T*>(a.dvec);
+  const T* vc = static_cast<const T*>(a.vec);
+  for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < a.E; e += int64_t(gridDim.x) * 256) {
+    const double r = double(vc[4 * e + 3]);
+    const double rx = double(vc[4 * e]) * r, ry = double(vc[4 * e + 1]) * r, rz = double(vc[4 * e + 2]) * r;
+    const double dx = double(dv[4 * e]), dy = double(dv[4 * e + 1]), dz = double(dv[4 * e + 2]);
+    w[0] += dx * rx; w[1] += dx * ry; w[2] += dx * rz;
+    w[3] += dy * rx; w[4] += dy * ry; w[5] += dy * rz;
+    w[6] += dz * rx; w[7] += dz * ry; w[8] += dz * rz;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) sP[threadIdx.x * 9 + k] = w[k];
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (int(threadIdx.x) < st)
+      for (int k = 0; k < 9; ++k) sP[threadIdx.x * 9 + k] += sP[(threadIdx.x + st) * 9 + k];
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) a.partial[blockIdx.x * 9 + threadIdx.x] = sP[threadIdx.x];
+}
+template <typename T>
+__global__ __launch_bounds__(64) void virial_final_kernel(VirialArgs a, int nblocks) {
+  if (threadIdx.x < 9) {
+    double s = 0.0;
+    for (int b2 = 0; b2 < nblocks; ++b2) s += a.partial[b2 * 9 + threadIdx.x];
+    static_cast<T*>(a.out)[threadIdx.x] = T(s);
+  }
+}
+template <typename T>
+int launch_virial(const VirialArgs& a, hipStream_t stream) {
+  const int nb = int(std::min<int64_t>(kVirialBlocks, std::max<int64_t>(1, (a.E + 255) / 256)));
+  hipLaunchKernelGGL(virial_partial_kernel<T>, dim3(nb), dim3(256), sizeof(double) * 256 * 9, stream, a);
+  hipLaunchKernelGGL(virial_final_kernel<T>, dim3(1), dim3(64), 0, stream, a, nb);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
 template <typename T>
 int launch_force_gather(const ForceGatherArgs& a, hipStream_t stream) {
   if (a.N == 0) return AA_OK;
@@ -531,6 +576,7 @@ int launch_readout_backward(const ReadoutArgs& a, hipStream_t stream) {
   template int launch_edge_prologue<T>(const EdgeGeomArgs&, hipStream_t);      \
   template int launch_edge_backward<T>(const EdgeBwdArgs&, hipStream_t);       \
   template int launch_force_gather<T>(const ForceGatherArgs&, hipStream_t);    \
+  template int launch_virial<T>(const VirialArgs&, hipStream_t);               \
   template int launch_readout_reduce<T>(const ReadoutArgs&, hipStream_t);      \
   template int launch_readout_backward<T>(const ReadoutArgs&, hipStream_t);
 AA_INST(float)

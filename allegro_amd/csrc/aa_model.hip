@@ -487,7 +487,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, trev, dvec;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, trev, dvec, vir_part;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -542,7 +542,10 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
   if (p->chain_gemm) w.e_edge = take(Ez);
   if (p->embed_fused) w.trev = take(Ez * 8);
-  if (with_forces) w.dvec = take(Ez * 4);
+  if (with_forces) {
+    w.dvec = take(Ez * 4);
+    w.vir_part = take((size_t(kVirialBlocks) * 9 * sizeof(double) + es - 1) / es);
+  }
   if (with_forces) {
     w.g_fcat = take(Ez * p->SL1);
     for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
@@ -1292,7 +1295,8 @@ struct Runner {
     eb.forces = forces;
     if (p->embed_fused) eb.t_in = buf(w.trev);
     const bool gather = g->t_rowptr && g->t_perm;
-    if (gather) eb.dvec = buf(w.dvec);
+    eb.dvec = buf(w.dvec);
+    eb.gather = gather ? 1 : 0;
     if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
     if (int rc = mark("edge_backward", 8.0 / sizeof(T) + 4 + (p->embed_fused ? c.num_bessels : c.embed_dim) + double(num_gsh) * p->D + (gather ? 4 : 6))) return rc;
     if (gather) {
@@ -1391,6 +1395,17 @@ extern "C" int aa_model_energy_forces_profiled(const aa_model_plan* plan, const 
   *num_stages = n;
   prof.clear();
   return rc;
+}
+
+extern "C" int aa_model_virial(const aa_model_plan* plan, const aa_graph* graph, void* workspace, size_t workspace_bytes,
+                               void* virial9, aa_stream stream) {
+  AA_REQUIRE(plan && graph && workspace && virial9, "aa_model_virial: null argument");
+  const Workspace w = layout_workspace(plan, graph->num_atoms, graph->num_edges, 1);
+  if (w.total > workspace_bytes) return fail(AA_ERR_WORKSPACE, "aa_model_virial: workspace too small (was it sized with forces?)");
+  char* base = static_cast<char*>(workspace);
+  VirialArgs a{graph->num_edges, base + w.dvec, base + w.vec, reinterpret_cast<double*>(base + w.vir_part), virial9};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return plan->cfg.dtype == AA_F32 ? launch_virial<float>(a, s) : launch_virial<double>(a, s);
 }
 
 extern "C" int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t N, int64_t E, const void* workspace,

@@ -573,6 +573,16 @@ class HipAllegroModel(torch.nn.Module):
                   "aa_model_energy_forces")
         return e_atom, forces
 
+    def virial(self, graph: PreparedGraph) -> torch.Tensor:
+        """dE/d(strain) [3,3] of the LAST `energy_forces(..., with_forces=True)` call on `graph` (stress = virial / volume,
+        nequip ForceStressOutput; LAMMPS' virial is its negative)."""
+        lib = self._get_lib()
+        out = torch.empty(9, dtype=self.dtype, device=self._workspace.device)
+        g = graph.c_struct()
+        lib.check(lib.lib.aa_model_virial(self._plan_handle, C.byref(g), self._workspace.data_ptr(), self._workspace.numel(),
+                                          out.data_ptr(), _stream_ptr(out)), "aa_model_virial")
+        return out.view(3, 3)
+
     def enable_hip_graph(self, on: bool = True) -> None:
         """Capture the step's launch sequence into a hipGraph and replay it (aa_model_plan_enable_graph): for
         launch-bound small systems in MD loops.  `pos` must then be updated in place between calls."""
@@ -614,6 +624,12 @@ class HipAllegroModel(torch.nn.Module):
         else:
             out["total_energy"] = e_atom.sum().reshape(1, 1)
         out["forces"] = forces
+        if "cell" in data and "batch" not in data:
+            # nequip ForceStressOutput (EXT) conventions: stress = dE/d(strain) / volume, virial = -dE/d(strain)
+            w = self.virial(graph)
+            vol = torch.linalg.det(data["cell"].view(3, 3).to(self.dtype)).abs()
+            out["stress"] = (w / vol).unsqueeze(0)
+            out["virial"] = (-w).unsqueeze(0)
         return out
 
     def __del__(self):

@@ -172,6 +172,12 @@ int aa_model_energy_forces_profiled(const aa_model_plan* plan, const void* dev_w
                                     float* stage_ms, char* stage_names, int* num_stages, double* stage_bytes,
                                     double* stage_flops);
 
+/* strain derivative of the total energy from the per-edge data the LAST aa_model_energy_forces call (with forces)
+ * left in `workspace`:  W[a][b] = dE/d eps_ab = sum_e (dE/dr_e)_a (r_e)_b, 3x3 row-major, model dtype, device memory.
+ * stress = W / volume (nequip ForceStressOutput convention); LAMMPS' virial is -W. */
+int aa_model_virial(const aa_model_plan* plan, const aa_graph* graph, void* workspace, size_t workspace_bytes,
+                    void* virial9, aa_stream stream);
+
 /* debug/parity taps: copy an intermediate of the LAST call out of the workspace layout.
  * name in {"edge_attrs","edge_embedding","edge_features"}; returns elements per edge or <0 */
 int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t num_atoms, int64_t num_edges,

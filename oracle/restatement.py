@@ -207,6 +207,18 @@ def allegro_energy_forces(cfg, sd, pos, edge_index, atom_types, shift_vec=None):
     return {"atomic_energy": e_atom.detach(), "total_energy": e_tot.detach().reshape(1, 1), "forces": -g}
 
 
+def allegro_virial(cfg, sd, pos, edge_index, atom_types, shift_vec=None):
+    """dE_total/d(strain) [3,3]: positions and periodic shift vectors are displaced by x -> x + x @ eps^T and the
+    energy is differentiated at eps = 0 (the strain-displacement construction of nequip's ForceStressOutput -- EXT,
+    restated from memory; stress = this / volume).  Test-only checker for aa_model_virial."""
+    eps = torch.zeros(3, 3, dtype=pos.dtype, requires_grad=True)
+    p2 = pos.detach() + pos.detach() @ eps.T
+    s2 = None if shift_vec is None else shift_vec.detach() + shift_vec.detach() @ eps.T
+    e_tot = allegro_energy(cfg, sd, p2, edge_index, atom_types, s2).sum()
+    (g,) = torch.autograd.grad(e_tot, eps)
+    return g
+
+
 def allegro_energy_forces_chunked(cfg, sd, pos, edge_index, atom_types, shift_vec=None, max_edges: int = 20000):
     """Exact evaluation in contiguous center-atom blocks (strict locality, tests/model/test_allegro.py:68-70):
     every E_i depends only on edges (i, .), so blocks of centers are independent; forces accumulate.

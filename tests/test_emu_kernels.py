@@ -176,3 +176,26 @@ def test_graph_without_edges_gives_shifts_and_zero_forces(dt):
     g = m.prepare_graph(torch.zeros((2, 0), dtype=torch.long), torch.tensor([0, 1, 0]), 3, None)
     e, f = m.energy_forces(pos, g)
     assert e.tolist() == [1.5, -2.0, 1.5] and float(f.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("t_coupled", torch.float64, 1e-9), ("c5_small", torch.float64, 1e-9),
+                                            ("c1_L1", torch.float32, 5e-5)])
+def test_virial_matches_oracle_strain_derivative(name, dtype, tol):
+    """aa_model_virial: W = sum_e dE/dr_e (x) r_e  ==  dE/d(strain) of the oracle (autograd through a strained copy
+    of positions + periodic shifts); symmetric because the energy is rotation invariant."""
+    from oracle import restatement as R
+
+    fx = load_model_fixture(name, dtype)
+    m = model_from_fixture(fx, dtype, emu_lib())
+    data, sv = fixture_data(fx, dtype)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    m.energy_forces(data["pos"], g)
+    w = m.virial(g)
+    cfg = dict(fx["cfg"])
+    cfg["model_dtype"] = "float64"
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in fx["sd"].items()}
+    ref = R.allegro_virial(cfg, sd, fx["pos"].double(), fx["edge_index"], fx["types"],
+                           None if fx["shift_vec"] is None else fx["shift_vec"].double())
+    scale = max(1.0, float(ref.abs().max()))
+    assert (w.double() - ref).abs().max().item() <= tol * scale
+    assert (w - w.T).abs().max().item() <= 10 * tol * scale

@@ -389,3 +389,28 @@ def test_graph_without_edges_gives_shifts_and_zero_forces(dtype, dev):
     g = m.prepare_graph(torch.zeros((2, 0), dtype=torch.long, device=dev), torch.tensor([0, 1, 0], device=dev), 3, None)
     e, f = m.energy_forces(pos, g)
     assert e.cpu().tolist() == [1.5, -2.0, 1.5] and float(f.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("t_coupled", torch.float64, 1e-9), ("c5_small", torch.float64, 1e-9),
+                                            ("c2", torch.float32, 5e-5)])
+def test_virial_matches_oracle_strain_derivative(name, dtype, tol, dev):
+    """aa_model_virial (strain derivative, stress * volume) vs autograd through the oracle with strained positions and
+    shifts; also identical for the gather and the atomic force layouts, and symmetric."""
+    from oracle import restatement as R
+    from allegro_amd.nn import PreparedGraph
+
+    fx = load_model_fixture(name, dtype)
+    m, g, _, _ = _run(fx, dtype, dev)
+    w = m.virial(g).cpu()
+    cfg = dict(fx["cfg"])
+    cfg["model_dtype"] = "float64"
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in fx["sd"].items()}
+    ref = R.allegro_virial(cfg, sd, fx["pos"].double(), fx["edge_index"], fx["types"],
+                           None if fx["shift_vec"] is None else fx["shift_vec"].double())
+    scale = max(1.0, float(ref.abs().max()))
+    assert (w.double() - ref).abs().max().item() <= tol * scale
+    assert (w - w.T).abs().max().item() <= 10 * tol * scale
+    data, sv = fixture_data(fx, dtype, dev)
+    g_at = PreparedGraph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv, transposed=False)
+    m.energy_forces(data["pos"], g_at)
+    assert (m.virial(g_at).cpu() - w).abs().max().item() <= 10 * tol * scale
