@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import _lib, o3
+from . import _lib, ops, o3
 
 _TORCH2AA = {torch.float32: _lib.AA_F32, torch.float64: _lib.AA_F64}
 
@@ -152,41 +152,6 @@ def segments_from_index(idxs: torch.Tensor, num_segments: int):
 # ------------------------------------------------------------------------------------------------
 # Contracter (seam B1/B2)
 # ------------------------------------------------------------------------------------------------
-class _TpFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, mod, x1, x2, weights, rowptr, eids, num_atoms, scatter_factor):
-        lib = mod._get_lib()
-        _require_gpu(lib, x1, "HipContracter")
-        x1c, x2c, wc = x1.contiguous(), x2.contiguous(), weights.detach().contiguous()
-        E = x1c.shape[0]
-        out = torch.empty((E, mod.mul, mod.base_dim_out), dtype=x1.dtype, device=x1.device)
-        x2s = torch.empty((num_atoms, mod.mul, mod.base_dim2), dtype=x1.dtype, device=x1.device)
-        plan = mod._plan(x1.dtype)
-        lib.tp_forward(plan, E, num_atoms, x1c.data_ptr(), x2c.data_ptr(), wc.data_ptr(), rowptr.data_ptr(),
-                       eids.data_ptr() if eids is not None else None, scatter_factor, x2s.data_ptr(), out.data_ptr(),
-                       _stream_ptr(x1))
-        ctx.mod, ctx.num_atoms, ctx.scatter_factor = mod, num_atoms, scatter_factor
-        ctx.save_for_backward(x1c, x2s, wc, rowptr, eids if eids is not None else torch.empty(0))
-        ctx.has_eids = eids is not None
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        mod = ctx.mod
-        x1c, x2s, wc, rowptr, eids = ctx.saved_tensors
-        lib = mod._get_lib()
-        gout = gout.contiguous()
-        E = x1c.shape[0]
-        gx1 = torch.empty_like(x1c)
-        gx2 = torch.empty((E, mod.mul, mod.base_dim2), dtype=x1c.dtype, device=x1c.device)
-        lib.tp_backward(mod._plan(x1c.dtype), E, ctx.num_atoms, x1c.data_ptr(), x2s.data_ptr(), wc.data_ptr(),
-                        rowptr.data_ptr(), eids.data_ptr() if ctx.has_eids else None, ctx.scatter_factor,
-                        gout.data_ptr(), gx1.data_ptr(), gx2.data_ptr(), _stream_ptr(x1c))
-        # no weight gradient: inference/force path only, like the reference's own accelerated op
-        # (allegro/nn/_strided/_flashallegro.py:660)
-        return None, gx1, gx2, None, None, None, None, None
-
-
 class HipContracter(torch.nn.Module):
     """Drop-in for `Contracter` (allegro/nn/_strided/_contract.py:11-251) on the HIP operator."""
 
@@ -216,6 +181,7 @@ class HipContracter(torch.nn.Module):
         self._plans: Dict[torch.dtype, int] = {}
         self._keep = []
         self._bound_lib: Optional[_lib.AllegroLib] = None
+        self._lib_id = 0
 
     def _get_lib(self) -> _lib.AllegroLib:
         return self._bound_lib if self._bound_lib is not None else _lib.load()
@@ -223,6 +189,7 @@ class HipContracter(torch.nn.Module):
     def _bind_library(self, lib: _lib.AllegroLib):
         """(tests) bind an explicitly loaded library instead of the default gfx950 one."""
         self._bound_lib = lib
+        self._lib_id = ops.register_library(lib)
         self._plans.clear()
 
     def _plan(self, dtype) -> int:
@@ -240,13 +207,36 @@ class HipContracter(torch.nn.Module):
         x2 = x2.reshape(-1, self.mul, self.base_dim2)
         rowptr, eids = segments_from_index(idxs, scatter_dim_size)
         sf = 1.0 if self.scatter_factor is None else float(self.scatter_factor)
-        return _TpFunction.apply(self, x1, x2, self.weights, rowptr, eids, scatter_dim_size, sf)
+        return self._op(x1, x2, rowptr, eids, int(scatter_dim_size), sf)
+
+    def _op(self, x1, x2, rowptr, eids, num_atoms: int, scatter_factor: float):
+        """The registered library op (allegro_amd/ops.py); autograd gives the x1/x2 gradients, none for the weights."""
+        _require_gpu(self._get_lib(), x1, "HipContracter")
+        out, _x2s = torch.ops.allegro_amd.tp_forward(x1, x2, self.weights.detach(), rowptr, eids, num_atoms,
+                                                     scatter_factor, self._plan(x1.dtype), self._lib_id,
+                                                     self.base_dim2, self.base_dim_out)
+        return out
 
     def _contract(self, x1, x2):
         """Contraction only (seam B1, _contract.py:213): every edge is its own segment."""
         E = x1.shape[0]
         rowptr = torch.arange(E + 1, dtype=torch.int32, device=x1.device)
-        return _TpFunction.apply(self, x1, x2, self.weights, rowptr, None, E, 1.0)
+        return self._op(x1, x2, rowptr, None, E, 1.0)
+
+    @classmethod
+    def from_contracter(cls, old: torch.nn.Module) -> "HipContracter":
+        """Build from a reference `Contracter` instance (same constructor attributes and state_dict keys,
+        _contract.py:72-76,165-177) -- the `factory` of the reference's `enable_*Contracter` modifiers (:262-279)."""
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(old.w3j.dtype)
+        try:
+            new = cls(irreps_in1=str(old.irreps_in1), irreps_in2=str(old.irreps_in2), irreps_out=str(old.irreps_out),
+                      mul=old.mul, instructions=old.instructions, path_channel_coupling=old.path_channel_coupling,
+                      scatter_factor=old.scatter_factor, irrep_normalization=old.irrep_normalization)
+        finally:
+            torch.set_default_dtype(prev)
+        new.load_state_dict(old.state_dict())
+        return new.to(old.weights.device)
 
     def extra_repr(self):
         return f"{self.irreps_in1} x {self.irreps_in2} -> {self.irreps_out} | {self.mul} channels | {self.num_paths} paths"
@@ -257,6 +247,32 @@ class HipContracter(torch.nn.Module):
                 self._get_lib().tp_plan_destroy(h)
         except Exception:
             pass
+
+
+def replace_submodules(model: torch.nn.Module, target_cls, factory) -> torch.nn.Module:
+    """Recursively replace every instance of `target_cls` by `factory(old)` (nequip.nn.replace_submodules, EXT)."""
+    if isinstance(model, target_cls):
+        return factory(model)
+    for name, child in list(model.named_children()):
+        setattr(model, name, replace_submodules(child, target_cls, factory))
+    return model
+
+
+def enable_HipContracter(model: torch.nn.Module, contracter_cls=None) -> torch.nn.Module:
+    """Model modifier: swap every `Contracter` of `model` for the HIP operator -- the analogue of
+    `Contracter.enable_TritonContracter` (_contract.py:253-282).  `contracter_cls` defaults to any module that
+    carries a Contracter's attributes (so it works on the reference's class without importing it).  Unlike the
+    Triton kernel there is no build-time guard: ij-diagonal, single-path and uncoupled modes are all covered."""
+    if contracter_cls is None:
+        attrs = ("irreps_in1", "irreps_in2", "irreps_out", "mul", "w3j", "weights", "path_channel_coupling")
+
+        class _Duck(type):
+            def __instancecheck__(self, obj):
+                return (not isinstance(obj, HipContracter)) and all(hasattr(obj, a) for a in attrs)
+
+        class contracter_cls(metaclass=_Duck):  # noqa: N801
+            pass
+    return replace_submodules(model, contracter_cls, HipContracter.from_contracter)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,106 @@
+"""`torch.library` registration of the tensor-product operator (SURVEY §8b "operator registration").
+
+The reference registers its accelerated contraction as a functional library op with a fake (meta) kernel and
+`register_autograd` (allegro/nn/_strided/_flashallegro.py:489,533-670) so it composes with `torch.compile` /
+`torch.export`.  The same contract here, around the C ABI (`aa_tp_forward` / `aa_tp_backward`):
+
+    torch.ops.allegro_amd.tp_forward (x1, x2, weights, rowptr, eids?, num_atoms, scatter_factor, plan, lib_id, d2, dout)
+        -> (out [E,u,dout], x2s [N,u,d2])
+    torch.ops.allegro_amd.tp_backward(gout, x1, x2s, weights, rowptr, eids?, num_atoms, scatter_factor, plan, lib_id)
+        -> (gx1 [E,u,d1], gx2 [E,u,d2])
+
+Both are functional (fresh outputs, nothing mutated); all non-tensor arguments are int/float; the backward returns
+`None` for the weights, like the reference's op (`_flashallegro.py:641-666`: input gradients only).  `plan` is the
+`aa_tp_plan*` handle as an integer, `lib_id` selects the loaded library (0 = the gfx950 build; tests register the
+emulation build under another id).  There is no CPU implementation: the ops raise on CPU tensors.
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_LIBS: Dict[int, "_lib.AllegroLib"] = {}
+
+
+def register_library(lib: "_lib.AllegroLib") -> int:
+    """Make `lib` addressable from the ops; returns its id (idempotent)."""
+    for k, v in _LIBS.items():
+        if v is lib:
+            return k
+    k = (max(_LIBS) + 1) if _LIBS else 1
+    _LIBS[k] = lib
+    return k
+
+
+def _resolve(lib_id: int) -> "_lib.AllegroLib":
+    return _lib.load() if lib_id == 0 else _LIBS[lib_id]
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def _check_device(lib, t: torch.Tensor, what: str):
+    if not t.is_cuda and not lib.is_emulation:
+        raise _lib.AllegroError(f"{what}: tensors must live on the GPU (got {t.device}); there is no CPU fallback")
+
+
+@torch.library.custom_op("allegro_amd::tp_forward", mutates_args=())
+def tp_forward(x1: torch.Tensor, x2: torch.Tensor, weights: torch.Tensor, rowptr: torch.Tensor,
+               eids: Optional[torch.Tensor], num_atoms: int, scatter_factor: float, plan: int, lib_id: int,
+               d2: int, dout: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _resolve(lib_id)
+    _check_device(lib, x1, "allegro_amd::tp_forward")
+    x1c, x2c, wc = x1.contiguous(), x2.contiguous(), weights.contiguous()
+    E, u = x1c.shape[0], x1c.shape[1]
+    out = torch.empty((E, u, dout), dtype=x1.dtype, device=x1.device)
+    x2s = torch.empty((num_atoms, u, d2), dtype=x1.dtype, device=x1.device)
+    lib.tp_forward(plan, E, num_atoms, x1c.data_ptr(), x2c.data_ptr(), wc.data_ptr(), rowptr.data_ptr(),
+                   eids.data_ptr() if eids is not None else None, scatter_factor, x2s.data_ptr(), out.data_ptr(),
+                   _stream_ptr(x1))
+    return out, x2s
+
+
+@tp_forward.register_fake
+def _(x1, x2, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id, d2, dout):
+    return x1.new_empty((x1.shape[0], x1.shape[1], dout)), x1.new_empty((num_atoms, x1.shape[1], d2))
+
+
+@torch.library.custom_op("allegro_amd::tp_backward", mutates_args=())
+def tp_backward(gout: torch.Tensor, x1: torch.Tensor, x2s: torch.Tensor, weights: torch.Tensor, rowptr: torch.Tensor,
+                eids: Optional[torch.Tensor], num_atoms: int, scatter_factor: float, plan: int,
+                lib_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    lib = _resolve(lib_id)
+    _check_device(lib, x1, "allegro_amd::tp_backward")
+    goutc, x1c, x2sc, wc = gout.contiguous(), x1.contiguous(), x2s.contiguous(), weights.contiguous()
+    E, u = x1c.shape[0], x1c.shape[1]
+    gx1 = torch.empty_like(x1c)
+    gx2 = torch.empty((E, u, x2sc.shape[2]), dtype=x1.dtype, device=x1.device)
+    lib.tp_backward(plan, E, num_atoms, x1c.data_ptr(), x2sc.data_ptr(), wc.data_ptr(), rowptr.data_ptr(),
+                    eids.data_ptr() if eids is not None else None, scatter_factor, goutc.data_ptr(), gx1.data_ptr(),
+                    gx2.data_ptr(), _stream_ptr(x1))
+    return gx1, gx2
+
+
+@tp_backward.register_fake
+def _(gout, x1, x2s, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id):
+    return torch.empty_like(x1), x1.new_empty((x1.shape[0], x1.shape[1], x2s.shape[2]))
+
+
+def _setup_context(ctx, inputs, output):
+    x1, _x2, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id, _d2, _dout = inputs
+    _out, x2s = output
+    ctx.save_for_backward(x1, x2s, weights, rowptr, eids)
+    ctx.num_atoms, ctx.scatter_factor, ctx.plan, ctx.lib_id = num_atoms, scatter_factor, plan, lib_id
+
+
+def _backward(ctx, gout, _gx2s):
+    x1, x2s, weights, rowptr, eids = ctx.saved_tensors
+    gx1, gx2 = torch.ops.allegro_amd.tp_backward(gout, x1, x2s, weights.detach(), rowptr, eids, ctx.num_atoms,
+                                                 ctx.scatter_factor, ctx.plan, ctx.lib_id)
+    # no weight gradient: inference/force path only (allegro/nn/_strided/_flashallegro.py:660)
+    return gx1, gx2, None, None, None, None, None, None, None, None, None
+
+
+tp_forward.register_autograd(_backward, setup_context=_setup_context)
