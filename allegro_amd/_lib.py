@@ -31,7 +31,8 @@ class ModelConfig(C.Structure):
                 ("latent_mlp_depth", C.c_int32), ("latent_mlp_width", C.c_int32),
                 ("readout_mlp_depth", C.c_int32), ("readout_mlp_width", C.c_int32),
                 ("forward_weight_init", C.c_int32), ("avg_num_neighbors", C.c_double), ("act_const", C.c_double),
-                ("has_scales", C.c_int32), ("has_shifts", C.c_int32), ("tps", TpDesc * AA_MAX_LAYERS)]
+                ("has_scales", C.c_int32), ("has_shifts", C.c_int32), ("tps", TpDesc * AA_MAX_LAYERS),
+                ("embed_kind", C.c_int32), ("spline_span", C.c_int32)]
 
 
 class RawWeights(C.Structure):
@@ -39,7 +40,7 @@ class RawWeights(C.Structure):
                 ("basis_linear", _dp), ("embed_mlp", _dp * AA_MAX_MLP_LAYERS), ("env_embed_linear", _dp),
                 ("first_proj", _dp), ("latent", (_dp * AA_MAX_MLP_LAYERS) * AA_MAX_LAYERS),
                 ("tp_weights", _dp * AA_MAX_LAYERS), ("readout", _dp * AA_MAX_MLP_LAYERS), ("scales", _dp),
-                ("shifts", _dp)]
+                ("shifts", _dp), ("spline_weights", _dp)]
 
 
 class Graph(C.Structure):

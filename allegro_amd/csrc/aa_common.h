@@ -425,6 +425,8 @@ struct EdgeGeomArgs {
   const void* center_embed;    // [T,S0/2]
   const void* neighbor_embed;  // [T,S0/2]
   const void* basis_w;         // [B,S0] (alpha folded)
+  int embed_kind, spline_span; // 1: per-class spline embedding (spline.py), num_bessels = num_splines
+  const void* emb_tab;         // embed_kind 1: [T*T][B][S0] class weights, basis-major
   void* vec;                   // [E,4]  (unit vector xyz, r)
   void* sh;                    // [E,D]
   void* emb0;                  // [E,S0]

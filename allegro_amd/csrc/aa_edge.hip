@@ -89,6 +89,20 @@ __device__ __forceinline__ void cutoff_and_grad(T x, T p, T& f, T& df) {
 
 constexpr int kMaxBessel = 16;
 
+// spline basis of PerClassSpline._get_basis (allegro/nn/spline.py:81-89):
+//   b_s(x) = 0.25 (1 - cos(k (clamp(x, lo_s, lo_s + diff) - lo_s)))^2,  lo_s = (s - span)/n, diff = (span+1)/n, k = 2 pi/diff
+// value and d/dx (zero where the clamp is active)
+template <typename T>
+__device__ __forceinline__ void spline_basis_and_grad(T x, int s, int n, int span, T& bv, T& dbv) {
+  const T lo = T(s - span) / T(n), diff = T(span + 1) / T(n);
+  const T k = T(6.283185307179586476925286766559) / diff;
+  const T xc = x < lo ? lo : (x > lo + diff ? lo + diff : x);
+  const T th = k * (xc - lo);
+  const T omc = T(1) - aa_cos(th);
+  bv = T(0.25) * omc * omc;
+  dbv = (x > lo && x < lo + diff) ? T(0.5) * omc * aa_sin(th) * k : T(0);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
   const int B = a.num_bessels, S0 = a.S0, D = (a.l_max + 1) * (a.l_max + 1), Tn = a.num_types;
@@ -128,15 +142,38 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
       sTy[2 * tid] = ti;
       sTy[2 * tid + 1] = tj;
       T x = r * static_cast<const T*>(a.rmax_recip)[ti * Tn + tj];
-      T f, df;
-      cutoff_and_grad<T>(x, T(a.poly_p), f, df);
-      for (int nb = 0; nb < B; ++nb) {
-        T w = static_cast<const T*>(a.bessel_w)[nb];
-        sB[tid * (B + 1) + nb] = aa_sin(w * x) / x * f;
+      if (a.embed_kind == 1) {
+        for (int nb = 0; nb < B; ++nb) {
+          T bv, dbv;
+          spline_basis_and_grad<T>(x, nb, B, a.spline_span, bv, dbv);
+          sB[tid * (B + 1) + nb] = bv;
+        }
+      } else {
+        T f, df;
+        cutoff_and_grad<T>(x, T(a.poly_p), f, df);
+        for (int nb = 0; nb < B; ++nb) {
+          T w = static_cast<const T*>(a.bessel_w)[nb];
+          sB[tid * (B + 1) + nb] = aa_sin(w * x) / x * f;
+        }
       }
     }
   }
   __syncthreads();
+  if (a.embed_kind == 1) {
+    // emb0[e][c] = sum_s W[class(e)][c][s] b_s(x)  (spline.py:69-79), class = t_center * T + t_neighbor
+    // (scalarembed.py:170); table is basis-major [class][s][c] so a wave reads contiguous rows
+    const T* tab = static_cast<const T*>(a.emb_tab);
+    for (int idx = tid; idx < 256 * S0; idx += 256) {
+      int le = idx / S0, c = idx % S0;
+      int64_t e = e0 + le;
+      if (e >= a.E) break;
+      const T* tc = tab + size_t(sTy[2 * le] * Tn + sTy[2 * le + 1]) * B * S0 + c;
+      T acc = T(0);
+      for (int nb = 0; nb < B; ++nb) acc += sB[le * (B + 1) + nb] * tc[size_t(nb) * S0];
+      static_cast<T*>(a.emb0)[e * S0 + c] = acc;
+    }
+    return;
+  }
   const int half = S0 / 2;
   const T* cemb = static_cast<const T*>(a.center_embed);
   const T* nemb = static_cast<const T*>(a.neighbor_embed);
@@ -278,7 +315,8 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
   const int half = S0 / 2;
   const T* cemb = static_cast<const T*>(a.center_embed);
   const T* nemb = static_cast<const T*>(a.neighbor_embed);
-  const bool fast = (S0 == 16 || S0 == 32 || S0 == 64) && B == 8 && Tn < 32768;
+  const bool spline = a.embed_kind == 1;
+  const bool fast = !spline && (S0 == 16 || S0 == 32 || S0 == 64) && B == 8 && Tn < 32768;
   // this lane's own edge (used again in phase 2)
   const int64_t e = e0 + tid;
   int ci = -1, cj = -1, ti = 0, tj = 0;  // ci: center of this lane's edge (-1: no edge)
@@ -294,7 +332,7 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
       sEmb[Tn * half + idx] = nemb[idx];
     }
     sTy[tid] = ci >= 0 ? (ti | (tj << 16)) : -1;
-  } else {
+  } else if (!spline) {
     for (int idx = tid; idx < B * S0; idx += 256) sWb[idx] = static_cast<const T*>(a.basis_w)[idx];
   }
   __syncthreads();
@@ -311,6 +349,21 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
       edge_bwd_phase1_b8<T, 4>(b, e0, tid, sTy, sEmb, sT);
     else
       edge_bwd_phase1_b8<T, 2>(b, e0, tid, sTy, sEmb, sT);
+  } else if (spline) {
+    // t[le][s] = sum_c g_emb0[e][c] * W[class(e)][c][s]
+    const T* tab = static_cast<const T*>(a.emb_tab);
+    for (int idx = tid; idx < 256 * B; idx += 256) {
+      int le = idx / B, nb = idx % B;
+      int64_t el = e0 + le;
+      T acc = T(0);
+      if (el < a.E) {
+        const int cls = a.types[a.center[el]] * Tn + a.types[a.nbr[el]];
+        const T* g = static_cast<const T*>(b.g_emb0) + el * S0;
+        const T* tc = tab + (size_t(cls) * B + nb) * S0;
+        for (int c = 0; c < S0; ++c) acc += g[c] * tc[c];
+      }
+      sT[le * (B + 1) + nb] = acc;
+    }
   } else {
     for (int idx = tid; idx < 256 * B; idx += 256) {
       int le = idx / B, nb = idx % B;
@@ -336,15 +389,23 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
     T nx = vec[0], ny = vec[1], nz = vec[2], r = vec[3];
     T recip = static_cast<const T*>(a.rmax_recip)[ti * Tn + tj];
     T x = r * recip;
-    T f, df;
-    cutoff_and_grad<T>(x, T(a.poly_p), f, df);
     T dEdx = T(0);
-    for (int nb = 0; nb < B; ++nb) {
-      T w = static_cast<const T*>(a.bessel_w)[nb];
-      T s = aa_sin(w * x), c = aa_cos(w * x);
-      T bv = s / x;
-      T dbv = (w * c * x - s) / (x * x);
-      dEdx += sT[tid * (B + 1) + nb] * (dbv * f + bv * df);
+    if (spline) {
+      for (int nb = 0; nb < B; ++nb) {
+        T bv, dbv;
+        spline_basis_and_grad<T>(x, nb, B, a.spline_span, bv, dbv);
+        dEdx += sT[tid * (B + 1) + nb] * dbv;
+      }
+    } else {
+      T f, df;
+      cutoff_and_grad<T>(x, T(a.poly_p), f, df);
+      for (int nb = 0; nb < B; ++nb) {
+        T w = static_cast<const T*>(a.bessel_w)[nb];
+        T s = aa_sin(w * x), c = aa_cos(w * x);
+        T bv = s / x;
+        T dbv = (w * c * x - s) / (x * x);
+        dEdx += sT[tid * (B + 1) + nb] * (dbv * f + bv * df);
+      }
     }
     T dEdr = dEdx * recip;
     T gY[16];

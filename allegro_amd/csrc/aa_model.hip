@@ -231,6 +231,8 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_cemb = take(size_t(T) * S0 / 2);
   p->o_nemb = take(size_t(T) * S0 / 2);
   p->o_basis = take(size_t(B) * S0);
+  AA_REQUIRE(cfg->embed_kind == 0 || (cfg->embed_kind == 1 && cfg->spline_span >= 0 && cfg->spline_span <= B),
+             "model: embed_kind must be 0 (Bessel) or 1 (spline, 0 <= span <= num_splines)");
   auto lay = [&](MlpLayout& m, const std::vector<int>& dims, int nlayers) {
     m.dims = dims;
     for (int i = 0; i < nlayers; ++i) {
@@ -281,7 +283,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   {
     const char* nf = getenv("AA_EMBED_NOFUSE");
     p->embed_fused = p->chain_gemm && T <= 2 && B == 8 && S0 == 64 && !(nf && nf[0] == '1');
-    p->o_embtab = p->embed_fused ? take(size_t(T) * T * 8 * 64) : 0;
+    p->o_embtab = (p->embed_fused || cfg->embed_kind == 1) ? take(size_t(T) * T * B * S0) : 0;
   }
   if (p->chain_gemm) {
     // merged reverse chain "readout' o latent_{L-1}'" (see Runner::backward): the readout-reverse columns that feed
@@ -337,14 +339,23 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   auto copy = [&](size_t off, const double* src, size_t n, double scale) {
     for (size_t i = 0; i < n; ++i) h[off + i] = src[i] * scale;
   };
-  AA_REQUIRE(raw->rmax_recip && raw->bessel_weights && raw->center_embed && raw->neighbor_embed && raw->basis_linear &&
-                 raw->env_embed_linear && raw->first_proj,
-             "pack: missing embedding weights");
+  AA_REQUIRE(raw->rmax_recip && raw->env_embed_linear && raw->first_proj, "pack: missing embedding weights");
   copy(p->o_rmax, raw->rmax_recip, size_t(T) * T, 1.0);
-  copy(p->o_bessel, raw->bessel_weights, B, 1.0);
-  copy(p->o_cemb, raw->center_embed, size_t(T) * S0 / 2, 1.0);
-  copy(p->o_nemb, raw->neighbor_embed, size_t(T) * S0 / 2, 1.0);
-  copy(p->o_basis, raw->basis_linear, size_t(B) * S0, mlp_alpha(c, 0, B, S0));
+  if (c.embed_kind == 1) {
+    // [class][c][s] (spline.py:69-71) -> basis-major [class][s][c]
+    AA_REQUIRE(raw->spline_weights, "pack: missing spline weights");
+    for (int cls = 0; cls < T * T; ++cls)
+      for (int cc = 0; cc < S0; ++cc)
+        for (int n = 0; n < B; ++n)
+          h[p->o_embtab + (size_t(cls) * B + n) * S0 + cc] = raw->spline_weights[(size_t(cls) * S0 + cc) * B + n];
+  } else {
+    AA_REQUIRE(raw->bessel_weights && raw->center_embed && raw->neighbor_embed && raw->basis_linear,
+               "pack: missing embedding weights");
+    copy(p->o_bessel, raw->bessel_weights, B, 1.0);
+    copy(p->o_cemb, raw->center_embed, size_t(T) * S0 / 2, 1.0);
+    copy(p->o_nemb, raw->neighbor_embed, size_t(T) * S0 / 2, 1.0);
+    copy(p->o_basis, raw->basis_linear, size_t(B) * S0, mlp_alpha(c, 0, B, S0));
+  }
   // env-weight columns: reference layout [u][R] (_channels.py:46-51); the specialised kernels want [R][u]
   const int Rr = p->R;
   auto env_col = [&](int q) { return p->use_spec ? (q % u) * Rr + q / u : q; };  // packed col q <- reference col
@@ -428,7 +439,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     AA_REQUIRE(raw->shifts, "pack: missing shifts");
     copy(p->o_shifts, raw->shifts, T, 1.0);
   }
-  if (p->embed_fused) {
+  if (p->embed_fused && c.embed_kind == 0) {
     const int half = S0 / 2;
     for (int ti = 0; ti < T; ++ti)
       for (int tj = 0; tj < T; ++tj)
@@ -724,6 +735,9 @@ struct Runner {
     a.center_embed = wt(p->o_cemb);
     a.neighbor_embed = wt(p->o_nemb);
     a.basis_w = wt(p->o_basis);
+    a.embed_kind = c.embed_kind;
+    a.spline_span = c.spline_span;
+    a.emb_tab = p->o_embtab ? wt(p->o_embtab) : nullptr;
     a.vec = buf(w.vec);
     a.sh = buf(w.sh);
     a.emb0 = buf(w.emb0);

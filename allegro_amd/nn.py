@@ -362,8 +362,10 @@ class HipAllegroModel(torch.nn.Module):
                 raise NotImplementedError("only SiLU MLPs are implemented in the HIP path")
         rce = dict(radial_chemical_embed or {})
         tgt = rce.pop("_target_", "allegro.nn.TwoBodyBesselScalarEmbed")
-        if not tgt.endswith("TwoBodyBesselScalarEmbed"):
-            raise NotImplementedError(f"radial_chemical_embed {tgt} is outside the hot path (SURVEY.md §2 row 10-11)")
+        self.embed_kind = {"TwoBodyBesselScalarEmbed": 0, "TwoBodySplineScalarEmbed": 1}.get(tgt.rsplit(".", 1)[-1])
+        if self.embed_kind is None:
+            raise NotImplementedError(f"radial_chemical_embed {tgt}: only allegro.nn.TwoBodyBesselScalarEmbed and "
+                                      "allegro.nn.TwoBodySplineScalarEmbed exist in the reference (scalarembed.py)")
         if rce.get("bessel_trainable", False):
             raise NotImplementedError("trainable Bessel roots are a training feature (out of scope)")
         self.dtype = {"float32": torch.float32, "float64": torch.float64}[model_dtype]
@@ -371,9 +373,13 @@ class HipAllegroModel(torch.nn.Module):
         T = len(self.type_names)
         S, u, L = num_scalar_features, num_tensor_features, num_layers
         S0 = S if radial_chemical_embed_dim is None else radial_chemical_embed_dim
-        B = int(rce.get("num_bessels", 8))
+        # number of radial basis functions: Bessel roots (scalarembed.py:22) or splines (:108)
+        B = int(rce.get("num_splines", 16)) if self.embed_kind == 1 else int(rce.get("num_bessels", 8))
+        span = int(rce.get("spline_span", 12))
+        assert self.embed_kind == 0 or 0 <= span <= B, "spline.py:32"
         self.hparams = dict(r_max=float(r_max), l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
                             embed_dim=S0, num_bessels=B, poly_p=float(rce.get("polynomial_cutoff_p", 6)),
+                            spline_span=span,
                             embed_depth=scalar_embed_mlp_hidden_layers_depth, embed_width=scalar_embed_mlp_hidden_layers_width,
                             latent_depth=allegro_mlp_hidden_layers_depth, latent_width=allegro_mlp_hidden_layers_width,
                             readout_depth=readout_mlp_hidden_layers_depth, readout_width=readout_mlp_hidden_layers_width,
@@ -406,11 +412,20 @@ class HipAllegroModel(torch.nn.Module):
                     else:
                         rmax[ci, ni] = float(v)
         add("edge_norm.rmax_recip", 1.0 / rmax, "buffer")
-        add("radial_chemical_embed.bessel_encode.bessel_weights",
-            (torch.linspace(1.0, B, B, dtype=dt) * math.pi).unsqueeze(0), "buffer")
-        add("radial_chemical_embed.type_embed.center_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
-        add("radial_chemical_embed.type_embed.neighbor_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
-        add("radial_chemical_embed.type_embed.basis_linear.mlp.0.weight", rng_u(B, S0), "param")
+        if self.embed_kind == 1:
+            # PerClassSpline (spline.py:43-62) + the init of TwoBodySplineScalarEmbed (scalarembed.py:136-145)
+            lower = torch.arange(-span, B - span, dtype=dt) / B
+            add("radial_chemical_embed.spline.lower", lower, "buffer")
+            add("radial_chemical_embed.spline.upper", lower + (span + 1) / B, "buffer")
+            bound = math.sqrt(3 / span) if forward_normalize else math.sqrt(3 / S0)
+            add("radial_chemical_embed.spline.class_embed.weight",
+                torch.empty(T * T, S0 * B, dtype=dt).uniform_(-bound, bound), "param")
+        else:
+            add("radial_chemical_embed.bessel_encode.bessel_weights",
+                (torch.linspace(1.0, B, B, dtype=dt) * math.pi).unsqueeze(0), "buffer")
+            add("radial_chemical_embed.type_embed.center_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
+            add("radial_chemical_embed.type_embed.neighbor_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
+            add("radial_chemical_embed.type_embed.basis_linear.mlp.0.weight", rng_u(B, S0), "param")
 
         def add_mlp(prefix, dims):
             for i, (a, b) in enumerate(zip(dims, dims[1:])):
@@ -493,6 +508,7 @@ class HipAllegroModel(torch.nn.Module):
         cfg.avg_num_neighbors = hp["avg_num_neighbors"]
         cfg.act_const = silu_second_moment_const()
         cfg.has_scales, cfg.has_shifts = int(self.has_scales), int(self.has_shifts)
+        cfg.embed_kind, cfg.spline_span = self.embed_kind, hp["spline_span"]
         keep = []
         sd = self._sd()
         for l in range(hp["num_layers"]):
@@ -522,10 +538,13 @@ class HipAllegroModel(torch.nn.Module):
         T = len(self.type_names)
         rr = sd["edge_norm.rmax_recip"]
         raw.rmax_recip = ptr(rr.expand(T, T).contiguous() if rr.numel() == 1 else rr)
-        raw.bessel_weights = ptr(sd["radial_chemical_embed.bessel_encode.bessel_weights"])
-        raw.center_embed = ptr(sd["radial_chemical_embed.type_embed.center_embed.weight"])
-        raw.neighbor_embed = ptr(sd["radial_chemical_embed.type_embed.neighbor_embed.weight"])
-        raw.basis_linear = ptr(sd["radial_chemical_embed.type_embed.basis_linear.mlp.0.weight"])
+        if self.embed_kind == 1:
+            raw.spline_weights = ptr(sd["radial_chemical_embed.spline.class_embed.weight"])
+        else:
+            raw.bessel_weights = ptr(sd["radial_chemical_embed.bessel_encode.bessel_weights"])
+            raw.center_embed = ptr(sd["radial_chemical_embed.type_embed.center_embed.weight"])
+            raw.neighbor_embed = ptr(sd["radial_chemical_embed.type_embed.neighbor_embed.weight"])
+            raw.basis_linear = ptr(sd["radial_chemical_embed.type_embed.basis_linear.mlp.0.weight"])
         for i in range(hp["embed_depth"] + 1):
             raw.embed_mlp[i] = ptr(sd[f"scalar_embed_mlp.mlp.mlp.{i}.weight"])
         raw.env_embed_linear = ptr(sd["tensor_embed.env_embed_linear.mlp.0.weight"])

@@ -101,6 +101,10 @@ typedef struct {
   double act_const;        /* normalize2mom constant of SiLU used by ScalarMLPFunction        */
   int32_t has_scales, has_shifts;               /* allegro_models.py:251-260                  */
   aa_tp_desc tps[AA_MAX_LAYERS];                /* one per layer, _allegro.py:172-183         */
+  /* two-body radial/chemical embedding: 0 = TwoBodyBesselScalarEmbed (scalarembed.py:19-81),
+   * 1 = TwoBodySplineScalarEmbed (scalarembed.py:84-175; spline.py): `num_bessels` is then num_splines */
+  int32_t embed_kind;
+  int32_t spline_span;     /* spline.py:27                                                     */
 } aa_model_config;
 
 /* Raw parameters in the reference's own state_dict layout, HOST memory, float64.
@@ -119,6 +123,8 @@ typedef struct {
   const double* readout[AA_MAX_MLP_LAYERS];     /* edge_readout.mlp.mlp.{i}.weight            */
   const double* scales;          /* [T] or NULL                                               */
   const double* shifts;          /* [T] or NULL                                               */
+  const double* spline_weights;  /* embed_kind 1: [T*T, S0, num_splines] radial_chemical_embed.spline.class_embed.weight
+                                    (the Bessel/type-embedding pointers above are then unused and may be NULL) */
 } aa_model_raw_weights;
 
 typedef struct {

@@ -28,6 +28,7 @@ from allegro_amd import graph as G  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 BESSEL = {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8, "polynomial_cutoff_p": 6}
+SPLINE = {"_target_": "allegro.nn.TwoBodySplineScalarEmbed", "num_splines": 8, "spline_span": 6}  # test_allegro.py:60-64
 
 
 def si_cfg(l_max, L, u, S=64, H=64):
@@ -150,9 +151,16 @@ def dump_contract_cases():
     torch.set_default_dtype(torch.float32)
 
 
-def main():
+def main(only=None):
+    """`only`: names of the fixtures to (re)generate (default: all)."""
     import_reference()
     os.makedirs(GOLD, exist_ok=True)
+    all_dump = globals()["dump_model"]
+
+    def dump_model(name, cfg, g):
+        if not only or name in only:
+            all_dump(name, cfg, g)
+
     si = G.make_si_graph(2)
     dump_model("c1_L1", si_cfg(1, 1, 32), si)  # BASELINE config 0 as glossed ("1 layer")
     dump_model("c1_L2", si_cfg(1, 2, 32), si)  # BASELINE config 0 as configs/tutorial.yaml:103-114 says
@@ -161,6 +169,10 @@ def main():
     dump_model("t_coupled", test_cfg(True, False), mol)
     dump_model("t_uncoupled", test_cfg(False, False), mol)
     dump_model("t_peredge", test_cfg(True, True), mol)
+    # the spline two-body embedding of the reference's model test matrix (test_allegro.py:60-64,75-79)
+    dump_model("t_spline", dict(test_cfg(True, False), radial_chemical_embed=dict(SPLINE)), mol)
+    dump_model("t_spline_peredge", dict(test_cfg(False, True), radial_chemical_embed=dict(SPLINE)), mol)
+    dump_model("c2_spline", dict(si_cfg(2, 2, 64), radial_chemical_embed=dict(SPLINE)), si)
     for seed in range(100):  # pick a seed without unphysically close intermolecular contacts
         w = G.make_water_graph(3, 9.9, r_cut=4.0, seed=seed)
         r = w.pos[w.edge_index[1]] - w.pos[w.edge_index[0]] + w.shift_vec()
@@ -168,8 +180,9 @@ def main():
         if d[2 * 2 * 27] > 1.45:  # skip the 2*27 intramolecular O-H bonds (directed: x2); H-H intra is 1.51
             break
     dump_model("c5_small", water_cfg(), w)
-    dump_contract_cases()
+    if not only or "contract_cases" in only:
+        dump_contract_cases()
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

@@ -147,14 +147,25 @@ def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom
         x = (r * recip[et[0], et[1]]).unsqueeze(-1)
     else:
         x = (r * recip.reshape(-1)[0]).unsqueeze(-1)
-    # 2 radial_chemical_embed: Bessel x cutoff -> ProductTypeEmbedding (scalarembed.py:60-81; _edgeembed.py:68-84)
-    bw = sd["radial_chemical_embed.bessel_encode.bessel_weights"]
-    bessel = torch.sin(bw * x) / x * polynomial_cutoff(x, float(cfg.get("polynomial_cutoff_p", 6)))
     et = atom_types[edge_index]
-    type_embed = torch.cat((sd["radial_chemical_embed.type_embed.center_embed.weight"][et[0]],
-                            sd["radial_chemical_embed.type_embed.neighbor_embed.weight"][et[1]]), dim=-1)
-    basis = scalar_mlp(bessel, _mlp_weights(sd, "radial_chemical_embed.type_embed.basis_linear.mlp"), fwi, act_c)
-    emb = type_embed * basis
+    if "radial_chemical_embed.spline.class_embed.weight" in sd:
+        # 2' TwoBodySplineScalarEmbed (scalarembed.py:157-175) -> PerClassSpline.forward (spline.py:64-89)
+        lower, upper = sd["radial_chemical_embed.spline.lower"], sd["radial_chemical_embed.spline.upper"]
+        ns = lower.numel()
+        const = 2 * math.pi / float(upper[0] - lower[0])
+        nx = const * (torch.minimum(torch.maximum(x, lower), upper) - lower)
+        sbasis = 0.25 * (1 - torch.cos(nx)).square()
+        classes = et[0] * len(cfg["type_names"]) + et[1]
+        wsp = sd["radial_chemical_embed.spline.class_embed.weight"][classes].view(classes.shape[0], -1, ns)
+        emb = torch.bmm(wsp, sbasis.unsqueeze(-1)).squeeze(-1)
+    else:
+        # 2 radial_chemical_embed: Bessel x cutoff -> ProductTypeEmbedding (scalarembed.py:60-81; _edgeembed.py:68-84)
+        bw = sd["radial_chemical_embed.bessel_encode.bessel_weights"]
+        bessel = torch.sin(bw * x) / x * polynomial_cutoff(x, float(cfg.get("polynomial_cutoff_p", 6)))
+        type_embed = torch.cat((sd["radial_chemical_embed.type_embed.center_embed.weight"][et[0]],
+                                sd["radial_chemical_embed.type_embed.neighbor_embed.weight"][et[1]]), dim=-1)
+        basis = scalar_mlp(bessel, _mlp_weights(sd, "radial_chemical_embed.type_embed.basis_linear.mlp"), fwi, act_c)
+        emb = type_embed * basis
     inter["emb0"] = emb
     # 3 scalar_embed_mlp (allegro_models.py:173-183)
     emb = scalar_mlp(emb, _mlp_weights(sd, "scalar_embed_mlp.mlp.mlp"), fwi, act_c)

@@ -6,7 +6,8 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MODEL_FIXTURES = ["c1_L1", "c1_L2", "c2", "t_coupled", "t_uncoupled", "t_peredge", "c5_small"]
+MODEL_FIXTURES = ["c1_L1", "c1_L2", "c2", "t_coupled", "t_uncoupled", "t_peredge", "c5_small", "t_spline",
+                  "t_spline_peredge", "c2_spline"]
 
 
 def load_model_fixture(name, dtype=torch.float64):
