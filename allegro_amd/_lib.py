@@ -63,6 +63,11 @@ def make_tp_desc(mul, d1, d2, dout, num_paths, coupling, nz_i, nz_j, nz_k, nz_pa
     return d, arrs + [val]
 
 
+class NlInput(C.Structure):
+    _fields_ = [("num_atoms", C.c_int64), ("pos", C.c_void_p), ("cell", C.c_double * 9), ("pbc", C.c_int32 * 3),
+                ("dtype", C.c_int32), ("r_cut", C.c_double)]
+
+
 class AllegroLib:
     def __init__(self, cdll: C.CDLL, is_emulation: bool = False):
         self.lib = cdll
@@ -84,6 +89,13 @@ class AllegroLib:
         L.aa_model_plan_enable_graph.restype = C.c_int
         L.aa_model_virial.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.aa_model_virial.restype = C.c_int
+        L.aa_nl_workspace_bytes.argtypes = [C.c_int64]
+        L.aa_nl_workspace_bytes.restype = C.c_size_t
+        L.aa_nl_count.argtypes = [C.POINTER(NlInput), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+        L.aa_nl_count.restype = C.c_int
+        L.aa_nl_fill.argtypes = [C.POINTER(NlInput), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_nl_fill.restype = C.c_int
         L.aa_model_weights_bytes.argtypes = [C.c_void_p]
         L.aa_model_weights_bytes.restype = C.c_size_t
         L.aa_model_pack_weights.argtypes = [C.c_void_p, C.POINTER(RawWeights), C.c_void_p, C.c_size_t, C.c_void_p]

@@ -296,7 +296,8 @@ class PreparedGraph:
     """Device-resident center-sorted CSR view of an edge list (the `aa_graph` struct)."""
 
     def __init__(self, edge_index: torch.Tensor, atom_types: torch.Tensor, num_atoms: int,
-                 shift_vec: Optional[torch.Tensor] = None, transposed: bool = True):
+                 shift_vec: Optional[torch.Tensor] = None, transposed: bool = True,
+                 rowptr: Optional[torch.Tensor] = None):
         center = edge_index[0]
         self.perm = None
         if center.numel() > 1 and not bool((center[1:] >= center[:-1]).all()):
@@ -307,9 +308,12 @@ class PreparedGraph:
         self.num_atoms, self.num_edges = int(num_atoms), int(edge_index.shape[1])
         self.center = edge_index[0].to(torch.int32).contiguous()
         self.nbr = edge_index[1].to(torch.int32).contiguous()
-        counts = torch.bincount(edge_index[0], minlength=num_atoms)
-        self.rowptr = torch.zeros(num_atoms + 1, dtype=torch.int32, device=edge_index.device)
-        self.rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        if rowptr is not None:  # already known (device neighbor list)
+            self.rowptr = rowptr.to(torch.int32).contiguous()
+        else:
+            counts = torch.bincount(edge_index[0], minlength=num_atoms)
+            self.rowptr = torch.zeros(num_atoms + 1, dtype=torch.int32, device=edge_index.device)
+            self.rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         self.types = atom_types.reshape(-1).to(torch.int32).contiguous()
         self.shift_vec = None if shift_vec is None else shift_vec.contiguous()
         # transposed CSR (edges grouped by neighbor): lets the library gather forces per atom in a fixed order
@@ -326,6 +330,57 @@ class PreparedGraph:
                           self.shift_vec.data_ptr() if self.shift_vec is not None else None,
                           self.t_rowptr.data_ptr() if self.t_rowptr is not None else None,
                           self.t_perm.data_ptr() if self.t_perm is not None else None)
+
+
+class DeviceNeighborList:
+    """Result of `neighbor_list`: center-sorted edges on the device (`aa_nl_count` / `aa_nl_fill`)."""
+
+    def __init__(self, edge_index, rowptr, cell_shift, shift_vec):
+        self.edge_index, self.rowptr, self.cell_shift, self.shift_vec = edge_index, rowptr, cell_shift, shift_vec
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.edge_index.shape[1])
+
+    def prepare(self, atom_types: torch.Tensor, transposed: bool = True) -> PreparedGraph:
+        return PreparedGraph(self.edge_index, atom_types, self.rowptr.numel() - 1, self.shift_vec, transposed=transposed,
+                             rowptr=self.rowptr)
+
+
+def neighbor_list(pos: torch.Tensor, cell, pbc, r_cut: float, lib: Optional[_lib.AllegroLib] = None) -> DeviceNeighborList:
+    """Cell-list neighbor list on the device the positions live on: every pair/image with |r| < r_cut, edges sorted by
+    center (`r_e = pos[nbr] - pos[center] + cell_shift @ cell`, the `with_edge_vectors_` convention).  Only the edge
+    count crosses to the host (the outputs must be allocated).  `cell`: 3x3, lattice vectors as rows; `pbc`: 3 bools."""
+    lib = lib if lib is not None else _lib.load()
+    _require_gpu(lib, pos, "neighbor_list")
+    assert pos.dtype in _TORCH2AA and pos.dim() == 2 and pos.shape[1] == 3
+    pos = pos.detach().contiguous()
+    N, dev = pos.shape[0], pos.device
+    inp = _lib.NlInput()
+    inp.num_atoms, inp.pos, inp.dtype, inp.r_cut = N, pos.data_ptr(), _TORCH2AA[pos.dtype], float(r_cut)
+    cell_h = torch.as_tensor(cell, dtype=torch.float64).reshape(9).tolist()
+    for q in range(9):
+        inp.cell[q] = cell_h[q]
+    if isinstance(pbc, bool):
+        pbc = (pbc,) * 3
+    for q in range(3):
+        inp.pbc[q] = int(bool(pbc[q]))
+    nbytes = lib.lib.aa_nl_workspace_bytes(N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    n_edges = C.c_int64()
+    stream = _stream_ptr(pos)
+    lib.check(lib.lib.aa_nl_count(C.byref(inp), ws.data_ptr(), nbytes, rowptr.data_ptr(), C.byref(n_edges), stream),
+              "aa_nl_count")
+    E = int(n_edges.value)
+    edge_index = torch.empty((2, E), dtype=torch.int32, device=dev)
+    cell_shift = torch.empty((E, 3), dtype=torch.int32, device=dev)
+    shift_vec = torch.empty((E, 3), dtype=pos.dtype, device=dev)
+    if E > 0:
+        lib.check(lib.lib.aa_nl_fill(C.byref(inp), ws.data_ptr(), nbytes, rowptr.data_ptr(), edge_index[0].data_ptr(),
+                                     edge_index[1].data_ptr(), cell_shift.data_ptr(), shift_vec.data_ptr(), stream),
+                  "aa_nl_fill")
+    return DeviceNeighborList(edge_index, rowptr, cell_shift, shift_vec)
 
 
 class HipAllegroModel(torch.nn.Module):

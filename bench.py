@@ -356,6 +356,29 @@ def main():
                 for nm, ms, nb, fl in stages:
                     print(f"[stage] {nm:24s} {ms * 1e3:9.1f} us {nb / max(ms, 1e-9) / 1e6:8.0f} GB/s (algorithmic)"
                           f"{fl / max(ms, 1e-9) / 1e9:8.1f} TFLOP/s", file=sys.stderr)
+        if world == 1 and g.cell is not None:
+            # reported separately, never part of `value`: the on-device cell-list build of the same graph
+            from allegro_amd.nn import neighbor_list
+
+            ts = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                nl = neighbor_list(pos, g.cell, True, cfg["r_max"])
+                nl_graph = nl.prepare(types)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            # (positions here are in the model dtype: a pair within rounding of r_cut may be classified differently
+            # from the float64 host list the step was timed on, hence a tolerance instead of equality)
+            assert abs(nl.num_edges - E) <= 8, (nl.num_edges, E)
+            line["config"]["neighbor_list_device_ms"] = {"edges": nl.num_edges, "list": None,
+                                                         "list_plus_graph_prep": sorted(ts[1:])[1] * 1e3}
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            neighbor_list(pos, g.cell, True, cfg["r_max"])
+            torch.cuda.synchronize()
+            line["config"]["neighbor_list_device_ms"]["list"] = (time.perf_counter() - t1) * 1e3
+            del nl_graph
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, cfg, model)
         if world == 1 and args.gpu_reference:

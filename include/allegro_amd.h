@@ -189,6 +189,32 @@ int aa_model_virial(const aa_model_plan* plan, const aa_graph* graph, void* work
 int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t num_atoms, int64_t num_edges,
                        const void* workspace, const void** ptr, int64_t* ld);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3. On-device neighbor list (cell list) -> the center-sorted CSR graph above, without leaving the GPU.
+ *    In the reference stack the edge list is built on the host (nequip's neighbor-list transform, EXT) or handed
+ *    over by LAMMPS (pair_allegro); conventions of with_edge_vectors_ (tensorembed.py:86):
+ *        r_e = pos[nbr] - pos[center] + cell_shift_e @ cell,  |r_e| < r_cut,
+ *    every image within r_cut is listed (cells smaller than 2 r_cut included); an atom pairs with itself only
+ *    through a non-zero shift.  Edges come out sorted by center, neighbors in a reproducible order.
+ *    Two phases because E is only known after counting:
+ *      aa_nl_count  bins the atoms, counts, writes rowptr[N+1] (device) and returns E (synchronises the stream);
+ *      aa_nl_fill   writes center/nbr [E] and (optionally) cell_shift int32 [E,3] and shift_vec [E,3] (model dtype)
+ *                   from the state aa_nl_count left in `workspace` (same input, same workspace).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int64_t num_atoms;
+  const void* pos;         /* [N,3] device, `dtype`                                            */
+  double cell[9];          /* lattice vectors as rows (pos = frac @ cell), host values          */
+  int32_t pbc[3];          /* periodic along a, b, c                                           */
+  int32_t dtype;           /* aa_dtype of pos / shift_vec                                      */
+  double r_cut;
+} aa_nl_input;
+size_t aa_nl_workspace_bytes(int64_t num_atoms);
+int aa_nl_count(const aa_nl_input* in, void* workspace, size_t workspace_bytes, int32_t* rowptr, int64_t* num_edges,
+                aa_stream stream);
+int aa_nl_fill(const aa_nl_input* in, void* workspace, size_t workspace_bytes, const int32_t* rowptr, int32_t* center,
+               int32_t* nbr, int32_t* cell_shift, void* shift_vec, aa_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,135 @@
+"""On-device neighbor list (aa_nl_count / aa_nl_fill) against a brute-force image enumeration in numpy float64.
+CPU: the kernels run in the test-only emulation build; `-m gpu`: the same cases on the gfx950 library plus a
+C3-sized box against the host cell list."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from tests.hip_utils import emu_lib
+from allegro_amd.nn import neighbor_list
+
+
+def brute_force(pos, cell, pbc, r_cut):
+    """All (i, j, S) with |pos[j] - pos[i] + S @ cell| < r_cut, (i == j only for S != 0)."""
+    pos, cell = np.asarray(pos, np.float64), np.asarray(cell, np.float64)
+    inv = np.linalg.inv(cell)
+    h = 1.0 / np.linalg.norm(inv, axis=0)
+    frac = pos @ inv
+    span = np.ceil(frac.max(0) - frac.min(0)).astype(int) if len(pos) else np.zeros(3, int)
+    reps = [range(-(int(np.ceil(r_cut / h[a])) + span[a]), int(np.ceil(r_cut / h[a])) + span[a] + 1) if pbc[a] else [0]
+            for a in range(3)]
+    out = set()
+    for S in itertools.product(*reps):
+        d = pos[None, :, :] + (np.array(S) @ cell)[None, None, :] - pos[:, None, :]
+        ii, jj = np.nonzero((d ** 2).sum(-1) < r_cut * r_cut)
+        for i, j in zip(ii, jj):
+            if i != j or any(S):
+                out.add((int(i), int(j)) + tuple(int(s) for s in S))
+    return out
+
+
+def as_set(nl):
+    ei, cs = nl.edge_index.cpu().numpy(), nl.cell_shift.cpu().numpy()
+    return [(int(ei[0, e]), int(ei[1, e])) + tuple(int(s) for s in cs[e]) for e in range(ei.shape[1])]
+
+
+def check(pos, cell, pbc, r_cut, dtype, lib, device="cpu"):
+    p = torch.tensor(pos, dtype=dtype, device=device)
+    nl = neighbor_list(p, cell, pbc, r_cut, lib=lib)
+    got = as_set(nl)
+    assert len(got) == len(set(got)), "duplicate edges"
+    want = brute_force(p.double().cpu().numpy(), cell, pbc, r_cut)
+    assert set(got) == want, (len(got), len(want))
+    ei = nl.edge_index.cpu().long()
+    rp = nl.rowptr.cpu().long()
+    assert bool((ei[0, 1:] >= ei[0, :-1]).all()) if ei.shape[1] > 1 else True
+    assert torch.equal(rp[1:] - rp[:-1], torch.bincount(ei[0], minlength=p.shape[0]))
+    sv = nl.cell_shift.cpu().double() @ torch.tensor(cell, dtype=torch.float64)
+    assert (nl.shift_vec.cpu().double() - sv).abs().max().item() <= (1e-6 if dtype == torch.float32 else 1e-12) * \
+        max(1.0, float(sv.abs().max())) if ei.shape[1] else True
+    return nl
+
+
+CASES = {
+    "orthorhombic": (lambda r: r.uniform(0, 1, (60, 3)) * [13.0, 11.0, 12.0], np.diag([13.0, 11.0, 12.0]), (1, 1, 1), 3.1),
+    "small_box_many_images": (lambda r: r.uniform(0, 1, (5, 3)) * [2.2, 3.0, 7.5], np.diag([2.2, 3.0, 7.5]), (1, 1, 1), 3.4),
+    "triclinic": (lambda r: r.uniform(-0.3, 1.4, (40, 3)) @ np.array([[9.0, 0, 0], [2.5, 8.0, 0], [-1.5, 2.0, 7.0]]),
+                  np.array([[9.0, 0, 0], [2.5, 8.0, 0], [-1.5, 2.0, 7.0]]), (1, 1, 1), 3.0),
+    "slab_with_atoms_outside": (lambda r: r.uniform(-0.4, 1.5, (50, 3)) * [8.0, 9.0, 14.0], np.diag([8.0, 9.0, 14.0]),
+                                (1, 1, 0), 3.2),
+    "molecule_no_pbc": (lambda r: r.uniform(0, 6.0, (20, 3)), np.diag([6.0, 6.0, 6.0]), (0, 0, 0), 2.5),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_device_neighbor_list_matches_brute_force(name, dtype):
+    gen, cell, pbc, rc = CASES[name]
+    pos = gen(np.random.default_rng(7))
+    check(pos, cell, pbc, rc, dtype, emu_lib())
+
+
+def test_no_atoms_and_isolated_atoms():
+    lib = emu_lib()
+    nl = neighbor_list(torch.zeros((0, 3), dtype=torch.float64), np.eye(3) * 5, True, 2.0, lib=lib)
+    assert nl.num_edges == 0 and nl.rowptr.tolist() == [0]
+    nl = neighbor_list(torch.tensor([[0.0, 0, 0], [10.0, 10, 10]], dtype=torch.float64), np.eye(3) * 40, True, 2.0, lib=lib)
+    assert nl.num_edges == 0 and nl.rowptr.tolist() == [0, 0, 0]
+
+
+def test_model_on_device_list_equals_model_on_host_list():
+    """Same energies/forces from the device-built graph and from the host list the fixtures were made with."""
+    from tests.golden_utils import load_model_fixture
+    from tests.hip_utils import fixture_data, model_from_fixture
+    from oracle import make_golden as MG
+
+    fx = load_model_fixture("t_coupled", torch.float64)
+    m = model_from_fixture(fx, torch.float64, emu_lib())
+    data, sv = fixture_data(fx, torch.float64)
+    g = MG.molecule_graph()  # the geometry of the fixture (box 9 A, r_cut 4 A)
+    assert np.allclose(g.pos, data["pos"].numpy())
+    nl = neighbor_list(data["pos"], g.cell, True, 4.0, lib=emu_lib())
+    assert nl.num_edges == data["edge_index"].shape[1]
+    e, f = m.energy_forces(data["pos"], nl.prepare(data["atom_types"]))
+    ref = fx["out"]
+    assert (e - ref["atomic_energy"].reshape(-1)).abs().max().item() < 1e-9
+    assert (f - ref["forces"]).abs().max().item() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_neighbor_list_on_gpu(name):
+    gen, cell, pbc, rc = CASES[name]
+    pos = gen(np.random.default_rng(11))
+    for dtype in (torch.float64, torch.float32):
+        check(pos, cell, pbc, rc, dtype, None, device="cuda:0")
+
+
+@pytest.mark.gpu
+def test_c3_box_on_gpu_matches_host_cell_list_and_model():
+    """10 648-atom Si box (BASELINE config 3): identical edge set to the host list; same model output through it."""
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+    from oracle import make_golden as MG
+
+    dev = torch.device("cuda:0")
+    g = G.make_si_graph(11)
+    pos = torch.tensor(g.pos, dtype=torch.float32, device=dev)
+    nl = neighbor_list(pos, g.cell, True, 5.0)
+    assert nl.num_edges == g.num_edges == 28 * g.num_atoms
+    got = torch.cat((nl.edge_index.long(), nl.cell_shift.long().T), 0).cpu().numpy()
+    want = np.concatenate((g.edge_index, g.cell_shift.T.astype(np.int64)), 0)
+    assert set(map(tuple, got.T)) == set(map(tuple, want.T))
+    nl2 = neighbor_list(pos, g.cell, True, 5.0)
+    assert torch.equal(nl.edge_index, nl2.edge_index) and torch.equal(nl.cell_shift, nl2.cell_shift)  # reproducible
+    cfg = MG.si_cfg(2, 2, 64)
+    cfg["model_dtype"] = "float32"
+    m = HipAllegroModel(**cfg).to(dev)
+    types = torch.zeros(g.num_atoms, dtype=torch.long, device=dev)
+    e1, f1 = m.energy_forces(pos, nl.prepare(types))
+    sv = torch.tensor(g.shift_vec(), dtype=torch.float32, device=dev)
+    e2, f2 = m.energy_forces(pos, m.prepare_graph(torch.tensor(g.edge_index, device=dev), types, g.num_atoms, sv))
+    assert (e1 - e2).abs().max().item() <= 2e-5 * max(1.0, float(e2.abs().max()))
+    assert (f1 - f2).abs().max().item() <= 2e-5 * max(1.0, float(f2.abs().max()))
