@@ -46,7 +46,7 @@ class RawWeights(C.Structure):
 class Graph(C.Structure):
     _fields_ = [("num_atoms", C.c_int64), ("num_edges", C.c_int64), ("center", C.c_void_p), ("nbr", C.c_void_p),
                 ("rowptr", C.c_void_p), ("types", C.c_void_p), ("shift_vec", C.c_void_p),
-                ("t_rowptr", C.c_void_p), ("t_perm", C.c_void_p)]
+                ("t_rowptr", C.c_void_p), ("t_perm", C.c_void_p), ("atom_begin", C.c_int64), ("atom_end", C.c_int64)]
 
 
 class AllegroError(RuntimeError):

@@ -302,7 +302,8 @@ struct TpSpecBwdArgs {
 // 2-layer stacks ("chain"): the layer-1 kernels recompute tf1 = TP0(sh*w0, x2s0) per edge in registers and
 // the layer-0 reverse kernel recomputes d_tf1 from (d_scal1, x2s1), so [E,u,D] tensors never touch HBM.
 struct TpChainArgs {
-  int64_t E, N;
+  int64_t E, N;         // moments kernels: atoms [atom0, N) are processed (N = end of the owned block)
+  int64_t atom0;
   const int32_t* rowptr;
   int u;
   const void* sh;
@@ -356,7 +357,8 @@ struct TpMomArgs {
 };
 // Per-atom operator form of the tensor-product track for L <= 3 layers, u = 64*m (aa_tp_op.hip)
 struct TpOpArgs {
-  int64_t N, E;
+  int64_t N, E;          // atoms [atom0, N) are processed
+  int64_t atom0;
   const int32_t* rowptr;
   int u;
   const void* sh;        // [E, ld_sh]

@@ -133,7 +133,7 @@ struct aa_model_plan {
     hipGraphExec_t exec = nullptr;
     struct Key {
       const void *weights, *pos, *ws, *e, *f, *center, *nbr, *rowptr, *types, *shift, *trow, *tperm;
-      int64_t N, E;
+      int64_t N, E, a0, a1;
       size_t wsb;
       bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
     } key{};
@@ -772,6 +772,10 @@ struct Runner {
     return r;
   }
 
+  // owned-block hint of the graph (per-atom kernels of the fast paths only visit these atoms)
+  int64_t atom_begin(const aa_graph* g) const { return g->atom_end > g->atom_begin ? g->atom_begin : 0; }
+  int64_t atom_end(const aa_graph* g) const { return g->atom_end > g->atom_begin ? g->atom_end : N; }
+
   TpChainArgs chain_args(const aa_graph* g) const {
     const aa_model_config& c = p->cfg;
     TpChainArgs a{};
@@ -844,6 +848,8 @@ struct Runner {
     const aa_model_config& c = p->cfg;
     TpMomArgs m{};
     m.c = chain_args(g);
+    m.c.atom0 = atom_begin(g);
+    m.c.N = atom_end(g);
     m.c.wenv0 = m.c.wenv1 = nullptr;
     m.a0 = buf(w.emb);
     m.ld_a0 = c.num_scalar;
@@ -861,7 +867,8 @@ struct Runner {
   TpOpArgs op_args(const aa_graph* g, int l) const {
     const aa_model_config& c = p->cfg;
     TpOpArgs o{};
-    o.N = N;
+    o.N = atom_end(g);
+    o.atom0 = atom_begin(g);
     o.E = E;
     o.rowptr = g->rowptr;
     o.u = c.num_tensor;
@@ -1350,6 +1357,9 @@ extern "C" int aa_model_energy_forces(const aa_model_plan* plan, const void* dev
              "aa_model_energy_forces: graph too large for int32 edge ids");
   AA_REQUIRE(graph->num_edges == 0 || (graph->center && graph->nbr), "aa_model_energy_forces: null edge arrays");
   AA_REQUIRE(graph->rowptr && graph->types, "aa_model_energy_forces: null rowptr/types");
+  AA_REQUIRE(graph->atom_begin >= 0 && graph->atom_end <= graph->num_atoms &&
+                 (graph->atom_end >= graph->atom_begin || graph->atom_end == 0),
+             "aa_model_energy_forces: atom_begin/atom_end out of range");
   AA_REQUIRE(workspace || workspace_bytes == 0, "aa_model_energy_forces: null workspace");
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto run = [&](hipStream_t st) {
@@ -1361,7 +1371,8 @@ extern "C" int aa_model_energy_forces(const aa_model_plan* plan, const void* dev
   if (!sg.enabled) return run(s);
   const aa_model_plan::StepGraph::Key key{dev_weights,    pos,           workspace,     atom_energy,      forces,          graph->center,
                                           graph->nbr,     graph->rowptr, graph->types,  graph->shift_vec, graph->t_rowptr, graph->t_perm,
-                                          graph->num_atoms, graph->num_edges, workspace_bytes};
+                                          graph->num_atoms, graph->num_edges, graph->atom_begin, graph->atom_end,
+                                          workspace_bytes};
   if (!sg.exec || !(sg.key == key)) {
     if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
     if (sg.graph) (void)hipGraphDestroy(sg.graph);

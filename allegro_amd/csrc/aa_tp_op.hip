@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void tp_op_fwd_kernel(TpOpArgs a) {
   typedef typename SigAt<Ch, LI>::type S;
   constexpr int D = S::D2, R = S::LMAX + 1;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t atom = blockIdx.x;
+  const int64_t atom = a.atom0 + blockIdx.x;
   const int u = a.u, ch = wv * 64 + lane;
   const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
   if (beg >= end) return;  // (its x2s rows are only ever read by its own, absent, edges)
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void tp_op_bwd_kernel(TpOpArgs a) {
   constexpr int D1 = SigAt<Ch, 0>::type::D1;
   static_assert(D1 == D && D <= 16, "x1 and the harmonics share their irreps");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nsl = blockDim.x >> 6;
-  const int64_t atom = blockIdx.x;
+  const int64_t atom = a.atom0 + blockIdx.x;
   const int u = a.u, ch = wv * 64 + lane;
   const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
   if (beg >= end) return;  // (uniform for the whole workgroup: no barrier is skipped by a subset)
@@ -356,13 +356,13 @@ int find_op_chain(const int* sigs, int L) {
 
 template <typename T>
 int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStream_t stream) {
-  if (a.N == 0) return AA_OK;
+  if (a.N <= a.atom0) return AA_OK;
   if ((a.u & 63) || a.u > 256 || (a.ka & 63) || a.ka > kOpMaxKa || a.ka_lds < a.ka)
     return fail(AA_ERR_INVALID, "tp_op: needs u = 64..256 in steps of 64 and env widths of 64 or 128");
   const int nsl = a.u / 64;
   const int Dsh = chain % 3 == 0 ? 4 : (chain % 3 == 1 ? 9 : 16);
   const size_t smem = reverse ? sizeof(T) * size_t(nsl) * Dsh * 64 : sizeof(T) * size_t(nsl) * Dsh * a.ka_lds;
-  dim3 grid((unsigned)a.N), block(64 * nsl);
+  dim3 grid((unsigned)(a.N - a.atom0)), block(64 * nsl);
 #define AA_OP_LAUNCH(CH, LI)                                                                          \
   {                                                                                                   \
     if (reverse)                                                                                      \

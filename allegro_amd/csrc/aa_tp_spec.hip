@@ -911,7 +911,7 @@ struct PairIn {
 #define AA_MOM_PROLOGUE(DVAL)                                                                                          \
   const TpChainArgs& a = ma.c;                                                                                         \
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;                                                            \
-  const int64_t atom = int64_t(blockIdx.x) * (blockDim.x >> 6) + wv;                                                   \
+  const int64_t atom = a.atom0 + int64_t(blockIdx.x) * (blockDim.x >> 6) + wv;                                         \
   const int ka_lds = ma.ka_lds;                                                                                        \
   T* sM = reinterpret_cast<T*>(aa_smem) + size_t(wv) * (DVAL) * (ka_lds + 64 + kSegCap);                               \
   T* sG = sM + (DVAL) * ka_lds;                                                                                        \
@@ -1347,7 +1347,8 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
     /* one wave per atom and no inter-wave cooperation: single-wave workgroups give the dispatcher the finest    \
        granularity (shorter tail on small boxes / per-rank shards) */                                            \
     static const int wpb = getenv("AA_MOM_WPB") ? std::max(1, std::min(4, atoi(getenv("AA_MOM_WPB")))) : 1;     \
-    dim3 grid((unsigned)((a.c.N + wpb - 1) / wpb));                                                      \
+    if (a.c.N <= a.c.atom0) return AA_OK;                                                                \
+    dim3 grid((unsigned)((a.c.N - a.c.atom0 + wpb - 1) / wpb));                                          \
     const int dpair = pair == 0 ? 4 : (pair == 1 ? 9 : 16);                                              \
     TpMomArgs b = a;                                                                                     \
     b.ka_lds = a.ka0 > a.ka1 ? a.ka0 : a.ka1;                                                            \

@@ -316,6 +316,11 @@ class PreparedGraph:
             self.rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
         self.types = atom_types.reshape(-1).to(torch.int32).contiguous()
         self.shift_vec = None if shift_vec is None else shift_vec.contiguous()
+        # block of center atoms that have edges (the owned block of an atom-block partition, allegro_amd/dist.py):
+        # the per-atom kernels only visit it.  One host read at graph-preparation time, none per step.
+        self.atom_begin = self.atom_end = 0
+        if self.num_edges > 0:
+            self.atom_begin, self.atom_end = int(self.center[0]), int(self.center[-1]) + 1
         # transposed CSR (edges grouped by neighbor): lets the library gather forces per atom in a fixed order
         # (bit-reproducible); without it neighbor contributions are accumulated with floating-point atomics
         self.t_perm = self.t_rowptr = None
@@ -329,7 +334,8 @@ class PreparedGraph:
                           self.rowptr.data_ptr(), self.types.data_ptr(),
                           self.shift_vec.data_ptr() if self.shift_vec is not None else None,
                           self.t_rowptr.data_ptr() if self.t_rowptr is not None else None,
-                          self.t_perm.data_ptr() if self.t_perm is not None else None)
+                          self.t_perm.data_ptr() if self.t_perm is not None else None,
+                          self.atom_begin, self.atom_end)
 
 
 class DeviceNeighborList:

@@ -140,6 +140,10 @@ typedef struct {
    * fixed order (bit-reproducible, no atomics); NULL/NULL: neighbor contributions use floating-point atomics */
   const int32_t* t_rowptr; /* [N+1] or NULL                                                    */
   const int32_t* t_perm;   /* [E] edge ids sorted by neighbor (stable), or NULL                */
+  /* optional hint: every center atom that has edges lies in [atom_begin, atom_end) -- the owned block of an
+   * atom-block partition.  Per-atom kernels are then launched over that range only.  0,0 = all atoms.
+   * The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
+  int64_t atom_begin, atom_end;
 } aa_graph;
 
 typedef struct aa_model_plan aa_model_plan;
