@@ -12,6 +12,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_model.hip", "aa_nl.hip"]
 LIB_PATH = os.path.join(HERE, "liballegro_amd.so")
+TORCH_LIB_PATH = os.path.join(HERE, "liballegro_amd_torch.so")  # dispatcher op for torch.export / AOTI / C++ hosts
 
 
 def _stale() -> bool:
@@ -38,5 +39,33 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
+def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
+    """csrc/torch_ops.cpp: plain host C++ (no device code) registering `allegro_amd_native::energy_forces` with the
+    PyTorch dispatcher; links against liballegro_amd.so next to it."""
+    src = os.path.join(CSRC, "torch_ops.cpp")
+    build_library(verbose=verbose)
+    if (not force and os.path.exists(TORCH_LIB_PATH) and
+            os.path.getmtime(TORCH_LIB_PATH) > max(os.path.getmtime(src), os.path.getmtime(LIB_PATH))):
+        return TORCH_LIB_PATH
+    import torch
+
+    tdir = os.path.dirname(torch.__file__)
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-I", os.path.join(tdir, "include"),
+           "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
+           "-I", os.path.join(ROOT, "include"), src, "-o", TORCH_LIB_PATH, "-L", HERE, "-lallegro_amd",
+           "-Wl,-rpath,$ORIGIN", "-L", os.path.join(tdir, "lib"), "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip",
+           "-ltorch_hip", "-Wl,-rpath," + os.path.join(tdir, "lib")]
+    t0 = time.time()
+    if verbose:
+        print("[allegro_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    if verbose:
+        print(f"[allegro_amd.build] built {TORCH_LIB_PATH} in {time.time() - t0:.1f}s", flush=True)
+    return TORCH_LIB_PATH
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv)
+    build_torch_ops(force="--force" in sys.argv)

@@ -1,0 +1,187 @@
+// C++-registered dispatcher op for the whole step -- the form an AOTInductor package / a Python-free host
+// (LAMMPS pair_allegro, which loads nequip-compile'd packages: allegro/_compile.py:10-14,68-74) can call:
+//
+//   allegro_amd_native::energy_forces(Tensor pos, Tensor edge_index, Tensor atom_types, Tensor? shift_vec,
+//                                     Tensor config, Tensor weights) -> (Tensor atom_energy, Tensor forces)
+//
+// Everything the op needs travels as tensors, so it survives torch.export / AOTI packaging: `config` is a CPU int64
+// tensor holding the serialized aa_model_config (hyper-parameters + the Clebsch-Gordan non-zeros of every layer,
+// layout below, written by allegro_amd/export.py), `weights` the packed device blob of aa_model_pack_weights.
+// Plans are cached per config content.  The op is a thin host wrapper over the C ABI (include/allegro_amd.h):
+// it builds the center-sorted CSR view with ATen ops, takes the workspace from the caching allocator and
+// launches on the current stream.  There is no CPU kernel: only a Meta (shape) kernel besides the GPU one.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "allegro_amd.h"
+
+namespace {
+
+constexpr int64_t kMagic = 0x414c4c4547524f31;  // "ALLEGRO1"
+constexpr int kHeader = 26;
+
+struct PlanEntry {
+  aa_model_plan* plan = nullptr;
+  std::vector<std::vector<int32_t>> ints;
+  std::vector<std::vector<double>> vals;
+  ~PlanEntry() {
+    if (plan) aa_model_plan_destroy(plan);
+  }
+};
+
+std::mutex g_mu;
+std::map<std::string, std::unique_ptr<PlanEntry>> g_plans;
+
+double as_double(int64_t bits) {
+  double d;
+  std::memcpy(&d, &bits, 8);
+  return d;
+}
+
+// config layout (int64 words): [magic, dtype, num_types, num_bessels, l_max, num_layers, num_scalar, num_tensor,
+//   embed_dim, embed_mlp_depth, embed_mlp_width, latent_mlp_depth, latent_mlp_width, readout_mlp_depth,
+//   readout_mlp_width, forward_weight_init, has_scales, has_shifts, embed_kind, spline_span,
+//   bits(poly_p), bits(avg_num_neighbors), bits(act_const), 0, 0, 0]  then per layer
+//   [mul, d1, d2, dout, num_paths, coupling, nnz, i[nnz], j[nnz], k[nnz], path[nnz], bits(val)[nnz]]
+const PlanEntry& plan_for(const at::Tensor& config) {
+  TORCH_CHECK(config.device().is_cpu() && config.scalar_type() == at::kLong && config.dim() == 1 && config.is_contiguous(),
+              "allegro_amd: config must be a contiguous CPU int64 vector");
+  const int64_t* w = config.data_ptr<int64_t>();
+  const int64_t n = config.numel();
+  TORCH_CHECK(n >= kHeader && w[0] == kMagic, "allegro_amd: not a serialized model config");
+  std::string key(reinterpret_cast<const char*>(w), size_t(n) * 8);
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_plans.find(key);
+  if (it != g_plans.end()) return *it->second;
+  auto e = std::make_unique<PlanEntry>();
+  aa_model_config c{};
+  c.dtype = int32_t(w[1]);
+  c.num_types = int32_t(w[2]);
+  c.num_bessels = int32_t(w[3]);
+  c.l_max = int32_t(w[4]);
+  c.num_layers = int32_t(w[5]);
+  c.num_scalar = int32_t(w[6]);
+  c.num_tensor = int32_t(w[7]);
+  c.embed_dim = int32_t(w[8]);
+  c.embed_mlp_depth = int32_t(w[9]);
+  c.embed_mlp_width = int32_t(w[10]);
+  c.latent_mlp_depth = int32_t(w[11]);
+  c.latent_mlp_width = int32_t(w[12]);
+  c.readout_mlp_depth = int32_t(w[13]);
+  c.readout_mlp_width = int32_t(w[14]);
+  c.forward_weight_init = int32_t(w[15]);
+  c.has_scales = int32_t(w[16]);
+  c.has_shifts = int32_t(w[17]);
+  c.embed_kind = int32_t(w[18]);
+  c.spline_span = int32_t(w[19]);
+  c.poly_p = as_double(w[20]);
+  c.avg_num_neighbors = as_double(w[21]);
+  c.act_const = as_double(w[22]);
+  TORCH_CHECK(c.num_layers >= 1 && c.num_layers <= AA_MAX_LAYERS, "allegro_amd: bad layer count in config");
+  int64_t o = kHeader;
+  for (int l = 0; l < c.num_layers; ++l) {
+    TORCH_CHECK(o + 7 <= n, "allegro_amd: truncated config");
+    aa_tp_desc& d = c.tps[l];
+    d.mul = int32_t(w[o]);
+    d.d1 = int32_t(w[o + 1]);
+    d.d2 = int32_t(w[o + 2]);
+    d.dout = int32_t(w[o + 3]);
+    d.num_paths = int32_t(w[o + 4]);
+    d.coupling = int32_t(w[o + 5]);
+    d.nnz = int32_t(w[o + 6]);
+    o += 7;
+    TORCH_CHECK(d.nnz >= 0 && o + 5 * int64_t(d.nnz) <= n, "allegro_amd: truncated config");
+    const int32_t** dst[4] = {&d.nz_i, &d.nz_j, &d.nz_k, &d.nz_path};
+    for (int q = 0; q < 4; ++q) {
+      e->ints.emplace_back(d.nnz);
+      for (int t = 0; t < d.nnz; ++t) e->ints.back()[t] = int32_t(w[o + t]);
+      *dst[q] = e->ints.back().data();
+      o += d.nnz;
+    }
+    e->vals.emplace_back(d.nnz);
+    for (int t = 0; t < d.nnz; ++t) e->vals.back()[t] = as_double(w[o + t]);
+    d.nz_val = e->vals.back().data();
+    o += d.nnz;
+  }
+  const int rc = aa_model_plan_create(&c, &e->plan);
+  TORCH_CHECK(rc == 0, "aa_model_plan_create failed (", rc, "): ", aa_last_error());
+  return *(g_plans[key] = std::move(e));
+}
+
+std::tuple<at::Tensor, at::Tensor> energy_forces_gpu(const at::Tensor& pos, const at::Tensor& edge_index,
+                                                     const at::Tensor& atom_types,
+                                                     const std::optional<at::Tensor>& shift_vec, const at::Tensor& config,
+                                                     const at::Tensor& weights) {
+  const PlanEntry& pe = plan_for(config);
+  TORCH_CHECK(pos.is_cuda() && edge_index.is_cuda() && atom_types.is_cuda() && weights.is_cuda(),
+              "allegro_amd::energy_forces: tensors must live on the GPU; there is no CPU fallback");
+  TORCH_CHECK(pos.dim() == 2 && pos.size(1) == 3 && edge_index.dim() == 2 && edge_index.size(0) == 2, "bad shapes");
+  const int64_t N = pos.size(0), E = edge_index.size(1);
+  const int64_t dt = config.data_ptr<int64_t>()[1];
+  TORCH_CHECK(pos.scalar_type() == (dt == AA_F32 ? at::kFloat : at::kDouble), "positions must be in the model dtype");
+  at::Tensor p = pos.contiguous();
+  at::Tensor ei = edge_index.to(at::kLong);
+  std::optional<at::Tensor> sv = shift_vec;
+  if (E > 1) {  // edges must be grouped by center (LAMMPS' i-major lists are); sort stably otherwise
+    const bool sorted = at::all(ei[0].slice(0, 1) >= ei[0].slice(0, 0, E - 1)).item<bool>();
+    if (!sorted) {
+      at::Tensor perm = at::argsort(ei[0], /*stable=*/true, 0, false);
+      ei = ei.index_select(1, perm);
+      if (sv.has_value()) sv = sv->index_select(0, perm);
+    }
+  }
+  auto i32 = pos.options().dtype(at::kInt);
+  at::Tensor center = ei[0].to(at::kInt).contiguous(), nbr = ei[1].to(at::kInt).contiguous();
+  at::Tensor rowptr = at::zeros({N + 1}, i32), trow = at::zeros({N + 1}, i32);
+  rowptr.slice(0, 1).copy_(at::cumsum(at::bincount(ei[0], {}, N), 0));
+  trow.slice(0, 1).copy_(at::cumsum(at::bincount(ei[1], {}, N), 0));
+  at::Tensor tperm = at::argsort(ei[1], /*stable=*/true, 0, false).to(at::kInt).contiguous();
+  at::Tensor types = atom_types.reshape({-1}).to(at::kInt).contiguous();
+  at::Tensor svc;
+  if (sv.has_value()) svc = sv->to(pos.scalar_type()).contiguous();
+  aa_graph g{};
+  g.num_atoms = N;
+  g.num_edges = E;
+  g.center = center.data_ptr<int32_t>();
+  g.nbr = nbr.data_ptr<int32_t>();
+  g.rowptr = rowptr.data_ptr<int32_t>();
+  g.types = types.data_ptr<int32_t>();
+  g.shift_vec = svc.defined() ? svc.data_ptr() : nullptr;
+  g.t_rowptr = trow.data_ptr<int32_t>();
+  g.t_perm = tperm.data_ptr<int32_t>();
+  const size_t wsb = aa_model_workspace_bytes(pe.plan, N, E, 1);
+  at::Tensor ws = at::empty({int64_t(wsb)}, pos.options().dtype(at::kByte));
+  at::Tensor e_atom = at::empty({N}, pos.options()), forces = at::empty({N, 3}, pos.options());
+  TORCH_CHECK(size_t(weights.numel()) * weights.element_size() >= aa_model_weights_bytes(pe.plan),
+              "allegro_amd::energy_forces: weight blob too small for this config");
+  hipStream_t stream = c10::hip::getCurrentHIPStream(pos.get_device()).stream();
+  const int rc = aa_model_energy_forces(pe.plan, weights.data_ptr(), &g, p.data_ptr(), ws.data_ptr(), wsb,
+                                        e_atom.data_ptr(), forces.data_ptr(), stream);
+  TORCH_CHECK(rc == 0, "aa_model_energy_forces failed (", rc, "): ", aa_last_error());
+  return {e_atom, forces};
+}
+
+std::tuple<at::Tensor, at::Tensor> energy_forces_meta(const at::Tensor& pos, const at::Tensor& edge_index,
+                                                      const at::Tensor& atom_types,
+                                                      const std::optional<at::Tensor>& shift_vec, const at::Tensor& config,
+                                                      const at::Tensor& weights) {
+  return {pos.new_empty({pos.size(0)}), pos.new_empty({pos.size(0), 3})};
+}
+
+}  // namespace
+
+TORCH_LIBRARY(allegro_amd_native, m) {
+  m.def(
+      "energy_forces(Tensor pos, Tensor edge_index, Tensor atom_types, Tensor? shift_vec, Tensor config, Tensor weights)"
+      " -> (Tensor, Tensor)");
+}
+TORCH_LIBRARY_IMPL(allegro_amd_native, CUDA, m) { m.impl("energy_forces", &energy_forces_gpu); }
+TORCH_LIBRARY_IMPL(allegro_amd_native, Meta, m) { m.impl("energy_forces", &energy_forces_meta); }

@@ -1,0 +1,70 @@
+"""Export path: the whole step as ONE dispatcher op that `torch.export` / AOTInductor can capture and a Python-free
+host can call.
+
+The reference ships models to LAMMPS by `nequip-compile`-ing them into an AOTInductor package whose tensor contract
+is `[pos, edge_index, atom_types] -> LMP_OUTPUTS` with ghost atoms appended (allegro/_compile.py:10-14,17-65).
+`ExportableAllegro` honours that contract around `allegro_amd_native::energy_forces`
+(allegro_amd/csrc/torch_ops.cpp, registered from C++ so that it exists in any process that loads
+`liballegro_amd_torch.so`): hyper-parameters + Clebsch-Gordan tables travel as a CPU int64 tensor, the packed weights
+as a device byte tensor -- both become constants of the exported program.
+"""
+import ctypes as C
+import struct
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .build import build_torch_ops
+
+_LOADED = False
+_MAGIC = 0x414C4C4547524F31
+
+
+def load_native_ops() -> None:
+    """Loads `liballegro_amd_torch.so` (built in-tree by allegro_amd.build) into the dispatcher."""
+    global _LOADED
+    if not _LOADED:
+        torch.ops.load_library(build_torch_ops(verbose=False))
+        _LOADED = True
+
+
+def _bits(x: float) -> int:
+    return struct.unpack("<q", struct.pack("<d", float(x)))[0]
+
+
+def serialize_config(model) -> torch.Tensor:
+    """`aa_model_config` of a HipAllegroModel as the int64 word stream torch_ops.cpp parses."""
+    model._ensure_plan()
+    cfg, _keep = model._plan_keep
+    w = [_MAGIC, cfg.dtype, cfg.num_types, cfg.num_bessels, cfg.l_max, cfg.num_layers, cfg.num_scalar, cfg.num_tensor,
+         cfg.embed_dim, cfg.embed_mlp_depth, cfg.embed_mlp_width, cfg.latent_mlp_depth, cfg.latent_mlp_width,
+         cfg.readout_mlp_depth, cfg.readout_mlp_width, cfg.forward_weight_init, cfg.has_scales, cfg.has_shifts,
+         cfg.embed_kind, cfg.spline_span, _bits(cfg.poly_p), _bits(cfg.avg_num_neighbors), _bits(cfg.act_const), 0, 0, 0]
+    for l in range(cfg.num_layers):
+        d = cfg.tps[l]
+        w += [d.mul, d.d1, d.d2, d.dout, d.num_paths, d.coupling, d.nnz]
+        for arr in (d.nz_i, d.nz_j, d.nz_k, d.nz_path):
+            w += [int(arr[t]) for t in range(d.nnz)]
+        w += [_bits(d.nz_val[t]) for t in range(d.nnz)]
+    return torch.tensor(w, dtype=torch.int64)
+
+
+class ExportableAllegro(torch.nn.Module):
+    """`forward(pos, edge_index, atom_types[, shift_vec]) -> (atomic_energy [N,1], total_energy [1,1], forces [N,3])`
+    through the C++-registered op; build it from a `HipAllegroModel` whose weights are final."""
+
+    def __init__(self, model, device):
+        super().__init__()
+        load_native_ops()
+        device = torch.device(device)
+        model._ensure_plan()
+        model._ensure_weights(device)
+        self.config = serialize_config(model)  # CPU int64 (a constant of the exported program)
+        self.register_buffer("weights", model._blob.clone())
+
+    def forward(self, pos: torch.Tensor, edge_index: torch.Tensor, atom_types: torch.Tensor,
+                shift_vec: Optional[torch.Tensor] = None):
+        e_atom, forces = torch.ops.allegro_amd_native.energy_forces(pos, edge_index, atom_types, shift_vec, self.config,
+                                                                    self.weights)
+        return e_atom.unsqueeze(-1), e_atom.sum().reshape(1, 1), forces

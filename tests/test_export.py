@@ -1,0 +1,68 @@
+"""Export path: the whole step as one C++-registered dispatcher op behind the pair_allegro tensor
+contract `[pos, edge_index, atom_types] -> (atomic_energy, total_energy, forces)` (allegro/_compile.py:10-14).
+CPU: the extension builds and loads, `torch.export` captures the op through its Meta kernel, and there is no CPU
+kernel to fall back to.  GPU: the op reproduces `HipAllegroModel.energy_forces` (also for an unsorted edge list and
+from a re-loaded exported program)."""
+import io
+
+import pytest
+import torch
+
+from tests.golden_utils import load_model_fixture
+from tests.hip_utils import emu_lib, fixture_data, model_from_fixture
+
+
+def _exportable(name, dtype, device, lib=None):
+    from allegro_amd.export import ExportableAllegro
+
+    fx = load_model_fixture(name, dtype)
+    m = model_from_fixture(fx, dtype, lib, device=device)
+    data, sv = fixture_data(fx, dtype, device)
+    return fx, m, data, sv, ExportableAllegro(m, device)
+
+
+def test_native_op_is_registered_and_exportable():
+    fx, m, data, sv, ex = _exportable("t_coupled", torch.float64, "cpu", emu_lib())
+    schema = str(torch.ops.allegro_amd_native.energy_forces.default._schema)
+    assert "Tensor? shift_vec" in schema and "-> (Tensor, Tensor)" in schema
+    ep = torch.export.export(ex, (data["pos"], data["edge_index"], data["atom_types"], sv))
+    targets = [str(n.target) for n in ep.graph.nodes if n.op == "call_function"]
+    assert any("allegro_amd_native.energy_forces" in t for t in targets), targets
+    outs = [n for n in ep.graph.nodes if n.op == "output"][0].args[0]
+    shapes = [tuple(o.meta["val"].shape) for o in outs]
+    N = data["pos"].shape[0]
+    assert shapes == [(N, 1), (1, 1), (N, 3)]
+    # the program round-trips through the serialized form with its constants (config words, weight blob)
+    buf = io.BytesIO()
+    torch.export.save(ep, buf)
+    buf.seek(0)
+    ep2 = torch.export.load(buf)
+    assert any("allegro_amd_native.energy_forces" in str(n.target) for n in ep2.graph.nodes if n.op == "call_function")
+
+
+def test_native_op_has_no_cpu_kernel():
+    fx, m, data, sv, ex = _exportable("t_coupled", torch.float64, "cpu", emu_lib())
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ex(data["pos"], data["edge_index"], data["atom_types"], sv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype,tol", [("c2", torch.float32, 5e-5), ("t_peredge", torch.float64, 1e-9),
+                                            ("c2_spline", torch.float32, 5e-5)])
+def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol):
+    dev = torch.device("cuda:0")
+    fx, m, data, sv, ex = _exportable(name, dtype, dev)
+    ref = fx["out"]
+    perm = torch.randperm(data["edge_index"].shape[1], generator=torch.Generator().manual_seed(1)).to(dev)
+    for ei, s in ((data["edge_index"], sv), (data["edge_index"][:, perm], None if sv is None else sv[perm])):
+        e_atom, e_tot, f = ex(data["pos"], ei, data["atom_types"], s)
+        for got, want in ((e_atom.cpu().reshape(-1), ref["atomic_energy"].reshape(-1)), (f.cpu(), ref["forces"])):
+            assert (got - want).abs().max().item() <= tol * max(1.0, float(want.abs().max()))
+        assert abs(float(e_tot) - float(ref["atomic_energy"].sum())) <= 10 * tol * max(1.0, abs(float(ref["atomic_energy"].sum())))
+    # exported program, saved and re-loaded, run on the GPU
+    ep = torch.export.export(ex, (data["pos"], data["edge_index"], data["atom_types"], sv))
+    buf = io.BytesIO()
+    torch.export.save(ep, buf)
+    buf.seek(0)
+    e2, _, f2 = torch.export.load(buf).module()(data["pos"], data["edge_index"], data["atom_types"], sv)
+    assert (f2.cpu() - ref["forces"]).abs().max().item() <= tol * max(1.0, float(ref["forces"].abs().max()))
