@@ -2,10 +2,10 @@
 // (LAMMPS pair_allegro, which loads nequip-compile'd packages: allegro/_compile.py:10-14,68-74) can call:
 //
 //   allegro_amd_native::energy_forces(Tensor pos, Tensor edge_index, Tensor atom_types, Tensor? shift_vec,
-//                                     Tensor config, Tensor weights) -> (Tensor atom_energy, Tensor forces)
+//                                     int[] config, Tensor weights) -> (Tensor atom_energy, Tensor forces)
 //
-// Everything the op needs travels as tensors, so it survives torch.export / AOTI packaging: `config` is a CPU int64
-// tensor holding the serialized aa_model_config (hyper-parameters + the Clebsch-Gordan non-zeros of every layer,
+// Everything the op needs travels in its arguments, so it survives torch.export / AOTI packaging: `config` is an int
+// list holding the serialized aa_model_config (hyper-parameters + the Clebsch-Gordan non-zeros of every layer,
 // layout below, written by allegro_amd/export.py), `weights` the packed device blob of aa_model_pack_weights.
 // Plans are cached per config content.  The op is a thin host wrapper over the C ABI (include/allegro_amd.h):
 // it builds the center-sorted CSR view with ATen ops, takes the workspace from the caching allocator and
@@ -51,11 +51,9 @@ double as_double(int64_t bits) {
 //   readout_mlp_width, forward_weight_init, has_scales, has_shifts, embed_kind, spline_span,
 //   bits(poly_p), bits(avg_num_neighbors), bits(act_const), 0, 0, 0]  then per layer
 //   [mul, d1, d2, dout, num_paths, coupling, nnz, i[nnz], j[nnz], k[nnz], path[nnz], bits(val)[nnz]]
-const PlanEntry& plan_for(const at::Tensor& config) {
-  TORCH_CHECK(config.device().is_cpu() && config.scalar_type() == at::kLong && config.dim() == 1 && config.is_contiguous(),
-              "allegro_amd: config must be a contiguous CPU int64 vector");
-  const int64_t* w = config.data_ptr<int64_t>();
-  const int64_t n = config.numel();
+const PlanEntry& plan_for(at::IntArrayRef config) {
+  const int64_t* w = config.data();
+  const int64_t n = int64_t(config.size());
   TORCH_CHECK(n >= kHeader && w[0] == kMagic, "allegro_amd: not a serialized model config");
   std::string key(reinterpret_cast<const char*>(w), size_t(n) * 8);
   std::lock_guard<std::mutex> lock(g_mu);
@@ -118,14 +116,14 @@ const PlanEntry& plan_for(const at::Tensor& config) {
 
 std::tuple<at::Tensor, at::Tensor> energy_forces_gpu(const at::Tensor& pos, const at::Tensor& edge_index,
                                                      const at::Tensor& atom_types,
-                                                     const std::optional<at::Tensor>& shift_vec, const at::Tensor& config,
+                                                     const std::optional<at::Tensor>& shift_vec, at::IntArrayRef config,
                                                      const at::Tensor& weights) {
   const PlanEntry& pe = plan_for(config);
   TORCH_CHECK(pos.is_cuda() && edge_index.is_cuda() && atom_types.is_cuda() && weights.is_cuda(),
               "allegro_amd::energy_forces: tensors must live on the GPU; there is no CPU fallback");
   TORCH_CHECK(pos.dim() == 2 && pos.size(1) == 3 && edge_index.dim() == 2 && edge_index.size(0) == 2, "bad shapes");
   const int64_t N = pos.size(0), E = edge_index.size(1);
-  const int64_t dt = config.data_ptr<int64_t>()[1];
+  const int64_t dt = config[1];
   TORCH_CHECK(pos.scalar_type() == (dt == AA_F32 ? at::kFloat : at::kDouble), "positions must be in the model dtype");
   at::Tensor p = pos.contiguous();
   at::Tensor ei = edge_index.to(at::kLong);
@@ -171,7 +169,7 @@ std::tuple<at::Tensor, at::Tensor> energy_forces_gpu(const at::Tensor& pos, cons
 
 std::tuple<at::Tensor, at::Tensor> energy_forces_meta(const at::Tensor& pos, const at::Tensor& edge_index,
                                                       const at::Tensor& atom_types,
-                                                      const std::optional<at::Tensor>& shift_vec, const at::Tensor& config,
+                                                      const std::optional<at::Tensor>& shift_vec, at::IntArrayRef config,
                                                       const at::Tensor& weights) {
   return {pos.new_empty({pos.size(0)}), pos.new_empty({pos.size(0), 3})};
 }
@@ -180,7 +178,7 @@ std::tuple<at::Tensor, at::Tensor> energy_forces_meta(const at::Tensor& pos, con
 
 TORCH_LIBRARY(allegro_amd_native, m) {
   m.def(
-      "energy_forces(Tensor pos, Tensor edge_index, Tensor atom_types, Tensor? shift_vec, Tensor config, Tensor weights)"
+      "energy_forces(Tensor pos, Tensor edge_index, Tensor atom_types, Tensor? shift_vec, int[] config, Tensor weights)"
       " -> (Tensor, Tensor)");
 }
 TORCH_LIBRARY_IMPL(allegro_amd_native, CUDA, m) { m.impl("energy_forces", &energy_forces_gpu); }

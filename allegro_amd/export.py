@@ -5,7 +5,7 @@ The reference ships models to LAMMPS by `nequip-compile`-ing them into an AOTInd
 is `[pos, edge_index, atom_types] -> LMP_OUTPUTS` with ghost atoms appended (allegro/_compile.py:10-14,17-65).
 `ExportableAllegro` honours that contract around `allegro_amd_native::energy_forces`
 (allegro_amd/csrc/torch_ops.cpp, registered from C++ so that it exists in any process that loads
-`liballegro_amd_torch.so`): hyper-parameters + Clebsch-Gordan tables travel as a CPU int64 tensor, the packed weights
+`liballegro_amd_torch.so`): hyper-parameters + Clebsch-Gordan tables travel as an int list, the packed weights
 as a device byte tensor -- both become constants of the exported program.
 """
 import ctypes as C
@@ -33,8 +33,8 @@ def _bits(x: float) -> int:
     return struct.unpack("<q", struct.pack("<d", float(x)))[0]
 
 
-def serialize_config(model) -> torch.Tensor:
-    """`aa_model_config` of a HipAllegroModel as the int64 word stream torch_ops.cpp parses."""
+def serialize_config(model) -> list:
+    """`aa_model_config` of a HipAllegroModel as the int64 word list torch_ops.cpp parses."""
     model._ensure_plan()
     cfg, _keep = model._plan_keep
     w = [_MAGIC, cfg.dtype, cfg.num_types, cfg.num_bessels, cfg.l_max, cfg.num_layers, cfg.num_scalar, cfg.num_tensor,
@@ -47,7 +47,7 @@ def serialize_config(model) -> torch.Tensor:
         for arr in (d.nz_i, d.nz_j, d.nz_k, d.nz_path):
             w += [int(arr[t]) for t in range(d.nnz)]
         w += [_bits(d.nz_val[t]) for t in range(d.nnz)]
-    return torch.tensor(w, dtype=torch.int64)
+    return [int(v) for v in w]
 
 
 class ExportableAllegro(torch.nn.Module):
@@ -60,7 +60,7 @@ class ExportableAllegro(torch.nn.Module):
         device = torch.device(device)
         model._ensure_plan()
         model._ensure_weights(device)
-        self.config = serialize_config(model)  # CPU int64 (a constant of the exported program)
+        self.config = serialize_config(model)  # int list (a constant of the exported program)
         self.register_buffer("weights", model._blob.clone())
 
     def forward(self, pos: torch.Tensor, edge_index: torch.Tensor, atom_types: torch.Tensor,

@@ -24,7 +24,7 @@ def _exportable(name, dtype, device, lib=None):
 def test_native_op_is_registered_and_exportable():
     fx, m, data, sv, ex = _exportable("t_coupled", torch.float64, "cpu", emu_lib())
     schema = str(torch.ops.allegro_amd_native.energy_forces.default._schema)
-    assert "Tensor? shift_vec" in schema and "-> (Tensor, Tensor)" in schema
+    assert "Tensor? shift_vec" in schema and "int[] config" in schema and "-> (Tensor, Tensor)" in schema
     ep = torch.export.export(ex, (data["pos"], data["edge_index"], data["atom_types"], sv))
     targets = [str(n.target) for n in ep.graph.nodes if n.op == "call_function"]
     assert any("allegro_amd_native.energy_forces" in t for t in targets), targets
