@@ -23,17 +23,43 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+class _BuildLock:
+    """Serialises concurrent builders (the ranks of a multi-GPU launch all import the package at once)."""
+
+    def __enter__(self):
+        import fcntl
+
+        self._f = open(os.path.join(HERE, ".build.lock"), "w")
+        fcntl.flock(self._f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+
+        fcntl.flock(self._f, fcntl.LOCK_UN)
+        self._f.close()
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB_PATH
+    with _BuildLock():
+        if not force and not _stale():  # another process built it while we waited
+            return LIB_PATH
+        return _build_library_locked(verbose)
+
+
+def _build_library_locked(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     t0 = time.time()
     if verbose:
         print("[allegro_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(tmp, LIB_PATH)  # atomic: a concurrently starting process never maps a half-written library
     if verbose:
         print(f"[allegro_amd.build] built {LIB_PATH} in {time.time() - t0:.1f}s", flush=True)
     return LIB_PATH
