@@ -414,3 +414,44 @@ def test_virial_matches_oracle_strain_derivative(name, dtype, tol, dev):
     g_at = PreparedGraph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv, transposed=False)
     m.energy_forces(data["pos"], g_at)
     assert (m.virial(g_at).cpu() - w).abs().max().item() <= 10 * tol * scale
+
+
+@pytest.mark.parametrize("species,embed,dtype,tol", [
+    (2, "Bessel", torch.float32, 5e-5), (3, "Bessel", torch.float32, 5e-5), (2, "Spline", torch.float32, 5e-5),
+    (3, "Spline", torch.float32, 5e-5), (2, "Spline", torch.float64, 1e-9)])
+def test_fast_path_species_and_embedding_variants_vs_oracle(species, embed, dtype, tol, dev):
+    """u = S = S0 = 64, 8 radial functions: with <= 2 species the reverse of the two-body embedding is folded into the
+    last reverse chain through the per-class table (Bessel: type-embedding x basis weights, spline: class weights);
+    with 3 species the stand-alone reverse kernel runs.  Both against the oracle on a ragged periodic graph."""
+    from oracle import restatement as R
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+
+    rng = np.random.default_rng(31)
+    n = 48
+    pos = rng.uniform(0, 11.0, size=(n, 3))
+    cell = np.eye(3) * 11.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, 3.6)
+    deg = np.bincount(ei[0], minlength=n)
+    rce = ({"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8} if embed == "Bessel" else
+           {"_target_": "allegro.nn.TwoBodySplineScalarEmbed", "num_splines": 8, "spline_span": 5})
+    cfg = dict(type_names=["A", "B", "C"][:species], r_max=3.6, l_max=2, num_layers=2, num_scalar_features=64,
+               num_tensor_features=64, radial_chemical_embed=rce, scalar_embed_mlp_hidden_layers_width=64,
+               allegro_mlp_hidden_layers_width=64, readout_mlp_hidden_layers_width=64,
+               per_edge_type_cutoff={"A": 3.6, "B": {"A": 3.2, "B": 3.0}} if species == 2 else None,
+               avg_num_neighbors=float(deg.mean()), seed=17,
+               model_dtype={torch.float64: "float64", torch.float32: "float32"}[dtype])
+    m = HipAllegroModel(**cfg).to(dev)
+    types = torch.tensor(rng.integers(0, species, size=n))
+    sv = torch.tensor(shift @ cell, dtype=dtype)
+    g = m.prepare_graph(torch.tensor(ei).to(dev), types.to(dev), n, sv.to(dev))
+    e, f = m.energy_forces(torch.tensor(pos, dtype=dtype, device=dev), g)
+    w = m.virial(g).cpu()
+    sd = {k[len("func."):]: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos, dtype=dtype), torch.tensor(ei), types, sv)
+    for got, want in ((e.cpu(), ref["atomic_energy"].reshape(-1)), (f.cpu(), ref["forces"])):
+        assert (got - want).abs().max().item() <= tol * max(1.0, float(want.abs().max()))
+    cfg64 = dict(cfg, model_dtype="float64")
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    wref = R.allegro_virial(cfg64, sd64, torch.tensor(pos), torch.tensor(ei), types, sv.double())
+    assert (w.double() - wref).abs().max().item() <= 4 * tol * max(1.0, float(wref.abs().max()))
