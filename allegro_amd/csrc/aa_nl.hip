@@ -30,6 +30,7 @@ struct NlDev {
   int* wrap;        // [N][3]
   double* wpos;     // [N][3] positions wrapped into the cell along periodic directions
   int* counts;      // [N+1]
+  int* scan_tmp;    // [max(cells, atoms) / 4096 + 2]
 };
 
 template <typename T>
@@ -67,14 +68,34 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(NlDev d) {
   d.atom_slot[i] = atomicAdd(&d.cell_count[cid], 1);
 }
 
-// out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); one workgroup, contiguous chunk per thread
-__global__ __launch_bounds__(256) void nl_scan_kernel(const int* in, int* out, int64_t n) {
+// Exclusive prefix sums out[0..n] of in[0..n) (out[n] = total) in three launches: per-block totals (4096 items per
+// workgroup), one workgroup scans the totals, every workgroup scans its own items from its offset.
+constexpr int kScanItems = 16, kScanBlock = 256 * kScanItems;
+
+__global__ __launch_bounds__(256) void nl_scan_totals_kernel(const int* in, int* block_tot, int64_t n) {
   int* sSum = reinterpret_cast<int*>(aa_smem);  // [256]
   const int tid = threadIdx.x;
-  const int64_t chunk = (n + 255) / 256;
-  const int64_t lo = std::min<int64_t>(n, chunk * tid), hi = std::min<int64_t>(n, lo + chunk);
+  const int64_t lo = int64_t(blockIdx.x) * kScanBlock + int64_t(tid) * kScanItems;
   int acc = 0;
-  for (int64_t q = lo; q < hi; ++q) acc += in[q];
+  for (int q = 0; q < kScanItems; ++q)
+    if (lo + q < n) acc += in[lo + q];
+  sSum[tid] = acc;
+  __syncthreads();
+  for (int st = 128; st >= 1; st >>= 1) {
+    if (tid < st) sSum[tid] += sSum[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) block_tot[blockIdx.x] = sSum[0];
+}
+
+// in place: block_tot[b] -> sum of block_tot[0..b); out_total = grand total.  One workgroup, chunk per thread.
+__global__ __launch_bounds__(256) void nl_scan_offsets_kernel(int* block_tot, int nblocks, int* out_total) {
+  int* sSum = reinterpret_cast<int*>(aa_smem);
+  const int tid = threadIdx.x;
+  const int chunk = (nblocks + 255) / 256;
+  const int lo = std::min(nblocks, chunk * tid), hi = std::min(nblocks, lo + chunk);
+  int acc = 0;
+  for (int q = lo; q < hi; ++q) acc += block_tot[q];
   sSum[tid] = acc;
   __syncthreads();
   if (tid == 0) {
@@ -84,15 +105,53 @@ __global__ __launch_bounds__(256) void nl_scan_kernel(const int* in, int* out, i
       sSum[t] = run;
       run += v;
     }
-    out[n] = run;
+    *out_total = run;
   }
   __syncthreads();
   int run = sSum[tid];
-  for (int64_t q = lo; q < hi; ++q) {
-    const int v = in[q];
-    out[q] = run;
+  for (int q = lo; q < hi; ++q) {
+    const int v = block_tot[q];
+    block_tot[q] = run;
     run += v;
   }
+}
+
+__global__ __launch_bounds__(256) void nl_scan_apply_kernel(const int* in, const int* block_off, int* out, int64_t n) {
+  int* sSum = reinterpret_cast<int*>(aa_smem);  // [256]
+  const int tid = threadIdx.x;
+  const int64_t lo = int64_t(blockIdx.x) * kScanBlock + int64_t(tid) * kScanItems;
+  int v[kScanItems];
+  int acc = 0;
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    v[q] = lo + q < n ? in[lo + q] : 0;
+    acc += v[q];
+  }
+  sSum[tid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    int run = block_off[blockIdx.x];
+    for (int t = 0; t < 256; ++t) {
+      const int x = sSum[t];
+      sSum[t] = run;
+      run += x;
+    }
+  }
+  __syncthreads();
+  int run = sSum[tid];
+#pragma unroll
+  for (int q = 0; q < kScanItems; ++q) {
+    if (lo + q < n) out[lo + q] = run;
+    run += v[q];
+  }
+}
+
+// out[n] receives the total; `block_tot` is scratch of (n / 4096 + 1) ints
+void launch_scan(const int* in, int* out, int64_t n, int* block_tot, hipStream_t s) {
+  const int nb = int((n + kScanBlock - 1) / kScanBlock);
+  if (nb > 0) hipLaunchKernelGGL(nl_scan_totals_kernel, dim3(nb), dim3(256), sizeof(int) * 256, s, in, block_tot, n);
+  hipLaunchKernelGGL(nl_scan_offsets_kernel, dim3(1), dim3(256), sizeof(int) * 256, s, block_tot, nb, out + n);
+  if (nb > 0) hipLaunchKernelGGL(nl_scan_apply_kernel, dim3(nb), dim3(256), sizeof(int) * 256, s, in, block_tot, out, n);
 }
 
 __global__ __launch_bounds__(256) void nl_cell_fill_kernel(NlDev d) {
@@ -256,6 +315,7 @@ int plan_nl(const aa_nl_input* in, void* ws, size_t ws_bytes, NlDev& d) {
   d.wrap = reinterpret_cast<int*>(take(sizeof(int) * 3 * N));
   d.wpos = reinterpret_cast<double*>(take(sizeof(double) * 3 * N));
   d.counts = reinterpret_cast<int*>(take(sizeof(int) * (N + 1)));
+  d.scan_tmp = reinterpret_cast<int*>(take(sizeof(int) * (std::max(N, NC) / kScanBlock + 2)));
   return AA_OK;
 }
 
@@ -264,7 +324,8 @@ int plan_nl(const aa_nl_input* in, void* ws, size_t ws_bytes, NlDev& d) {
 extern "C" size_t aa_nl_workspace_bytes(int64_t num_atoms) {
   const size_t N = size_t(std::max<int64_t>(0, num_atoms)), NC = size_t(max_cells(num_atoms));
   return 2 * align_up(sizeof(int) * (NC + 1)) + 3 * align_up(sizeof(int) * N) + align_up(sizeof(int) * 3 * N) +
-         align_up(sizeof(double) * 3 * N) + align_up(sizeof(int) * (N + 1));
+         align_up(sizeof(double) * 3 * N) + align_up(sizeof(int) * (N + 1)) +
+         align_up(sizeof(int) * (std::max(N, NC) / kScanBlock + 2));
 }
 
 extern "C" int aa_nl_count(const aa_nl_input* in, void* workspace, size_t workspace_bytes, int32_t* rowptr,
@@ -281,7 +342,7 @@ extern "C" int aa_nl_count(const aa_nl_input* in, void* workspace, size_t worksp
     else
       hipLaunchKernelGGL(nl_bin_kernel<double>, dim3(nb), dim3(256), 0, s, d);
   }
-  hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(256), sizeof(int) * 256, s, d.cell_count, d.cell_start, int64_t(d.ncells));
+  launch_scan(d.cell_count, d.cell_start, int64_t(d.ncells), d.scan_tmp, s);
   if (d.N > 0) {
     hipLaunchKernelGGL(nl_cell_fill_kernel, dim3(nb), dim3(256), 0, s, d);
     hipLaunchKernelGGL(nl_cell_sort_kernel, dim3((d.ncells + 255) / 256), dim3(256), 0, s, d);
@@ -290,7 +351,7 @@ extern "C" int aa_nl_count(const aa_nl_input* in, void* workspace, size_t worksp
     else
       hipLaunchKernelGGL((nl_pairs_kernel<double, false>), dim3(nb), dim3(256), 0, s, d, nullptr, nullptr, nullptr, nullptr, nullptr);
   }
-  hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(256), sizeof(int) * 256, s, d.counts, rowptr, d.N);
+  launch_scan(d.counts, rowptr, d.N, d.scan_tmp, s);
   AA_CHECK_HIP(hipGetLastError());
   int32_t total = 0;
   AA_CHECK_HIP(hipMemcpyAsync(&total, rowptr + d.N, sizeof(int32_t), hipMemcpyDeviceToHost, s));

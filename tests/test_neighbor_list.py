@@ -133,3 +133,20 @@ def test_c3_box_on_gpu_matches_host_cell_list_and_model():
     e2, f2 = m.energy_forces(pos, m.prepare_graph(torch.tensor(g.edge_index, device=dev), types, g.num_atoms, sv))
     assert (e1 - e2).abs().max().item() <= 2e-5 * max(1.0, float(e2.abs().max()))
     assert (f1 - f2).abs().max().item() <= 2e-5 * max(1.0, float(f2.abs().max()))
+
+
+def test_multi_block_scans_against_host_cell_list():
+    """> 4096 atoms and > 4096 cells (both prefix sums span several workgroups) vs the host KD-tree list."""
+    from allegro_amd import graph as G
+
+    rng = np.random.default_rng(3)
+    box, rc = 60.0, 3.0
+    pos = rng.uniform(0, box, size=(6000, 3))
+    cell = np.eye(3) * box
+    ei, shift = G.neighbor_list_pbc(pos, cell, rc)
+    nl = neighbor_list(torch.tensor(pos), cell, True, rc, lib=emu_lib())
+    assert nl.num_edges == ei.shape[1]
+    got = set(as_set(nl))
+    want = set((int(ei[0, e]), int(ei[1, e])) + tuple(int(s) for s in shift[e]) for e in range(ei.shape[1]))
+    assert got == want
+    assert int(nl.rowptr[-1]) == nl.num_edges and bool((nl.rowptr[1:] >= nl.rowptr[:-1]).all())
