@@ -255,8 +255,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
   double* smem = reinterpret_cast<double*>(aa_smem);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = int64_t(blockIdx.x) * G6_BM;
-  const int n0 = blockIdx.y * G6_BN;
   const double* B = static_cast<const double*>(g.B);
+  // gridDim.y == 1: this workgroup walks ALL column tiles of its 128 rows, so the A rows come from HBM once and from
+  // L2 afterwards (a 2-D grid re-reads A from HBM once per column tile: 8x at N = 512)
+  const int n_tiles = gridDim.y == 1 ? (g.N + G6_BN - 1) / G6_BN : 1;
+  for (int nt = 0; nt < n_tiles; ++nt) {
+  const int n0 = (gridDim.y == 1 ? nt : int(blockIdx.y)) * G6_BN;
   auto As = [&](int b) { return smem + b * (G6_BK * G6_LDA + G6_BK * G6_BN); };
   auto Bs = [&](int b) { return As(b) + G6_BK * G6_LDA; };
   // staging roles: A: thread -> (row = tid >> 1, 8 consecutive k); B: thread -> (k = tid >> 4, 4 consecutive columns)
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
         cp[gm * ldc + col] = v;
       }
   }
+  }  // column tiles
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1598,6 +1603,11 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok) {
     dim3 grid6((unsigned)((g.M + G6_BM - 1) / G6_BM), (unsigned)((g.N + G6_BN - 1) / G6_BN));
+    // enough row tiles to fill the chip on their own: one workgroup per row tile looping over the column tiles
+    // (AA_F64_NLOOP=0: never, 2: always -- tests)
+    const char* ev = getenv("AA_F64_NLOOP");
+    const int f64_loop = ev ? atoi(ev) : 1;
+    if (f64_loop == 2 || (f64_loop == 1 && grid6.x >= 2048)) grid6.y = 1;
     const size_t smem6 = sizeof(double) * 2 * (G6_BK * G6_LDA + G6_BK * G6_BN);
     hipLaunchKernelGGL(gemm_mfma_f64_pipe_kernel, grid6, dim3(256), smem6, stream, g);
   } else {

@@ -201,3 +201,19 @@ def test_virial_matches_oracle_strain_derivative(name, dtype, tol):
     scale = max(1.0, float(ref.abs().max()))
     assert (w.double() - ref).abs().max().item() <= tol * scale
     assert (w - w.T).abs().max().item() <= 10 * tol * scale
+
+
+def test_f64_gemm_column_tile_loop_matches_2d_grid(monkeypatch):
+    """fp64 MFMA GEMM: one workgroup per 128-row tile walking all column tiles (large systems: A comes from HBM once)
+    must equal the 2-D grid launch bit for bit (same arithmetic order)."""
+    fx = load_model_fixture("c5_small", torch.float64)
+    data, sv = fixture_data(fx, torch.float64)
+    outs = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("AA_F64_NLOOP", mode)
+        m = model_from_fixture(fx, torch.float64, emu_lib())
+        g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+        outs.append(m.energy_forces(data["pos"], g))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    want = fx["out"]["forces"]
+    assert (outs[1][1] - want).abs().max().item() <= 1e-9 * max(1.0, float(want.abs().max()))
