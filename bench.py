@@ -181,7 +181,7 @@ def roofline_from_stages(stages, dtype, workload="c4"):
     return roof, table
 
 
-def cpu_baseline(g: G.Graph, cfg, model, target_edges=60000, reps=3):
+def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3):
     """The oracle restatement (a port: kind='port') timed on this host's cores on a bounded sample:
     the first contiguous block of center atoms holding ~target_edges edges, evaluated in chunks of
     <=12k edges (exact by strict locality).  Thread count: min(cores, 32) -- eager PyTorch CPU slows
