@@ -386,6 +386,12 @@ struct TpOpArgs {
   void* g_a;             // grad wrt the env input [E, ld_ga]
   int ld_ga;
   int ka_lds;
+  // split form (bvec != nullptr): the per-atom vectors travel through HBM between a register-heavy per-atom kernel
+  // and lean, high-occupancy edge-streaming kernels
+  void* bvec;            // [N][L][D1][u]  B_m(n) (forward: slot `layer`; layer-0 reverse: all L)
+  void* gmbuf;           // [N][D][ka]     reverse: GM = d x2s . Wenv^T of the layer being reversed
+  void* mbuf;            // [N][D][ka]     forward: moments M = sum_e Y[e] (x) act(a[e]) of the layer being evaluated
+  int num_layers;
 };
 int find_op_chain(const int* sigs, int num_layers);  // chain id or -1
 template <typename T>

@@ -498,7 +498,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, trev, dvec, vir_part;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, bvec_op, gm_op, mom_op, trev, dvec, vir_part;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -557,6 +557,10 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     w.dvec = take(Ez * 4);
     w.vir_part = take((size_t(kVirialBlocks) * 9 * sizeof(double) + es - 1) / es);
   }
+  if (p->tp_op >= 0) {
+    w.bvec_op = take(Nz * L * p->D * u);
+    w.mom_op = take(Nz * p->D * size_t(std::max(c.num_scalar, c.latent_mlp_width)));
+  }
   if (with_forces) {
     w.g_fcat = take(Ez * p->SL1);
     for (int i = 0; i < c.readout_mlp_depth; ++i) w.g_ro_h[i] = take(Ez * c.readout_mlp_width);
@@ -573,7 +577,10 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     for (int i = 0; i < c.embed_mlp_depth; ++i) w.g_se_h[i] = take(Ez * c.embed_mlp_width);
     w.g_emb0 = take(Ez * S0);
     w.g_sh = take(Ez * p->D * num_gsh_slots(p));  // slot 0: x1 path of layer 0; slot l+1: env path of layer l (see num_gsh_slots)
-    if (p->tp_op >= 0) w.q_op = take(Nz * L * p->D * u);
+    if (p->tp_op >= 0) {
+      w.q_op = take(Nz * L * p->D * u);
+      w.gm_op = take(Nz * p->D * size_t(std::max(c.num_scalar, c.latent_mlp_width)));
+    }
   }
   w.total = o;
   return w;
@@ -896,6 +903,14 @@ struct Runner {
     o.ld_scal = c.num_tensor;
     o.ld_gscal = c.num_tensor;
     o.q = buf(w.q_op);
+    o.num_layers = c.num_layers;
+    {
+      // split form (default): per-atom vectors through HBM, edge loops in lean kernels (AA_OP_NOSPLIT=1: fused form)
+      static const bool nosplit = getenv("AA_OP_NOSPLIT") && getenv("AA_OP_NOSPLIT")[0] == '1';
+      o.bvec = (!nosplit && w.bvec_op) ? buf(w.bvec_op) : nullptr;
+      o.gmbuf = (!nosplit && w.bvec_op && w.gm_op) ? buf(w.gm_op) : nullptr;
+      o.mbuf = (!nosplit && w.mom_op) ? buf(w.mom_op) : nullptr;
+    }
     o.ld_gw0 = p->W;
     o.ld_gsh = p->D;
     o.ka_lds = std::max(c.num_scalar, c.latent_mlp_width);

@@ -165,6 +165,12 @@ __global__ __launch_bounds__(256) void tp_op_fwd_kernel(TpOpArgs a) {
   const T* av = static_cast<const T*>(a.a);
   const int ka = a.ka;
   // moments M[j][k] = sum_e Y[e,j] act(a[e,k])   (every slice recomputes them: they do not depend on the channel)
+  if (a.mbuf) {  // split form: tp_op_moments_kernel streamed the edges; fetch this atom's D x ka block
+    const T* mp = static_cast<const T*>(a.mbuf) + (atom * D) * int64_t(ka);
+    for (int kb = 0; kb < ka; kb += 64)
+#pragma unroll
+      for (int j = 0; j < D; ++j) sM[j * a.ka_lds + kb + lane] = mp[int64_t(j) * ka + kb + lane];
+  } else
   for (int kb = 0; kb < ka; kb += 64) {
     T m[D];
 #pragma unroll
@@ -208,9 +214,15 @@ __global__ __launch_bounds__(256) void tp_op_fwd_kernel(TpOpArgs a) {
   __threadfence_block();
   T b[kOpMaxD];
   atom_vector<Ch, LI, T>(a, atom, ch, b);
+  constexpr int D1 = SigAt<Ch, 0>::type::D1;
+  if (a.bvec) {  // split form: tp_op_edge_fwd_kernel streams the edges
+    T* bp = static_cast<T*>(a.bvec) + ((atom * a.num_layers + LI) * D1) * int64_t(u) + ch;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) bp[int64_t(i) * u] = b[i];
+    return;
+  }
   const T* w0 = static_cast<const T*>(a.w0) + ch;
   T* sc = static_cast<T*>(a.scal) + ch;
-  constexpr int D1 = SigAt<Ch, 0>::type::D1;
 #pragma unroll 2
   for (int s = beg; s < end; ++s) {
     const T* y = sh + int64_t(s) * a.ld_sh;
@@ -221,6 +233,226 @@ __global__ __launch_bounds__(256) void tp_op_fwd_kernel(TpOpArgs a) {
 #pragma unroll
     for (int i = 0; i < D1; ++i) acc += (y[i] * wr[r_of<0>(i)]) * b[i];
     sc[int64_t(s) * a.ld_scal] = acc;
+  }
+}
+
+// ---- split form, lean edge-streaming kernels (few registers => many waves per SIMD; the per-atom vectors come
+// ---- from HBM).  One workgroup per atom, one wave per 64-channel slice (edge_env: per 64-wide env-input block).
+template <typename T, int D1, int R>
+__global__ __launch_bounds__(256) void tp_op_edge_fwd_kernel(TpOpArgs a, int layer) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = a.atom0 + blockIdx.x;
+  const int u = a.u, ch = wv * 64 + lane;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;
+  T b[D1];
+  {
+    const T* bp = static_cast<const T*>(a.bvec) + ((atom * a.num_layers + layer) * D1) * int64_t(u) + ch;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) b[i] = bp[int64_t(i) * u];
+  }
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* w0 = static_cast<const T*>(a.w0) + ch;
+  T* sc = static_cast<T*>(a.scal) + ch;
+#pragma unroll 4
+  for (int s = beg; s < end; ++s) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    T wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = w0[int64_t(s) * a.ld_w0 + r * u];
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < D1; ++i) acc += (y[i] * wr[r_of<0>(i)]) * b[i];
+    sc[int64_t(s) * a.ld_scal] = acc;
+  }
+}
+
+// moments M[n][j][k] = sum_e Y[e,j] act(a[e,k]); one wave per 64-wide block of the env input
+template <typename T, int D>
+__global__ __launch_bounds__(256) void tp_op_moments_kernel(TpOpArgs a) {
+  const int lane = threadIdx.x & 63, blk = threadIdx.x >> 6;
+  const int64_t atom = a.atom0 + blockIdx.x;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;
+  const int ka = a.ka, k = blk * 64 + lane;
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* av = static_cast<const T*>(a.a) + k;
+  T m[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) m[j] = T(0);
+#pragma unroll 4
+  for (int s = beg; s < end; ++s) {
+    T x = av[int64_t(s) * a.ld_a];
+    if (a.act) x = silu(x);
+    const T* y = sh + int64_t(s) * a.ld_sh;
+#pragma unroll
+    for (int j = 0; j < D; ++j) m[j] += y[j] * x;
+  }
+  T* mp = static_cast<T*>(a.mbuf) + (atom * D) * int64_t(ka) + k;
+#pragma unroll
+  for (int j = 0; j < D; ++j) mp[int64_t(j) * ka] = m[j];
+}
+
+// Q_layer = sum_e G_layer[e] x1[e]; FIRST (layer 0): also d w0[e] and d Y[e] through x1 with all L gradient streams
+template <typename T, int D1, int R, int L, bool FIRST>
+__global__ __launch_bounds__(256) void tp_op_edge_bwd_kernel(TpOpArgs a, int layer) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = a.atom0 + blockIdx.x;
+  const int u = a.u, ch = wv * 64 + lane;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* w0 = static_cast<const T*>(a.w0) + ch;
+  const int64_t ED = int64_t(a.E) * a.ld_gsh;
+  T bm[FIRST ? L : 1][D1];
+  if constexpr (FIRST) {
+    const T* bp = static_cast<const T*>(a.bvec) + (atom * L * D1) * int64_t(u) + ch;
+#pragma unroll
+    for (int m = 0; m < L; ++m)
+#pragma unroll
+      for (int i = 0; i < D1; ++i) bm[m][i] = bp[int64_t(m * D1 + i) * u];
+  }
+  T q[D1];
+#pragma unroll
+  for (int i = 0; i < D1; ++i) q[i] = T(0);
+  const T* gl = static_cast<const T*>(a.gscal[FIRST ? 0 : 1]) + ch;  // (host passes this layer's stream in slot 1)
+  T* gw0 = static_cast<T*>(a.g_w0) + ch;
+  T* gsx = static_cast<T*>(a.gsh_x1) + int64_t(wv) * ED;
+#pragma unroll 2
+  for (int s = beg; s < end; ++s) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    T wr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wr[r] = w0[int64_t(s) * a.ld_w0 + r * u];
+    const T g = gl[int64_t(s) * a.ld_gscal];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) q[i] += g * (y[i] * wr[r_of<0>(i)]);
+    if constexpr (FIRST) {
+      T gm_[L];
+      gm_[0] = g;
+#pragma unroll
+      for (int m = 1; m < L; ++m) gm_[m] = static_cast<const T*>(a.gscal[m])[int64_t(s) * a.ld_gscal + ch];
+      T gw[R], gy[D1];
+#pragma unroll
+      for (int r = 0; r < R; ++r) gw[r] = T(0);
+#pragma unroll
+      for (int i = 0; i < D1; ++i) {
+        T gx = T(0);
+#pragma unroll
+        for (int m = 0; m < L; ++m) gx += gm_[m] * bm[m][i];
+        gw[r_of<0>(i)] += gx * y[i];
+        gy[i] = gx * wr[r_of<0>(i)];
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * u] = gw[r];
+      wave_sum_store<T, D1>(gy, gsx + int64_t(s) * a.ld_gsh, true, false);
+    }
+  }
+  T* qp = static_cast<T*>(a.q) + ((atom * a.num_layers + layer) * D1) * int64_t(u) + ch;
+#pragma unroll
+  for (int i = 0; i < D1; ++i) qp[int64_t(i) * u] = q[i];
+}
+
+// adjoint of the moments on the edges: d a[e,k] = sum_j Y[e,j] GM[j,k], d Y[e,j] += sum_k act(a[e,k]) GM[j,k]
+template <typename T, int D>
+__global__ __launch_bounds__(256) void tp_op_edge_env_kernel(TpOpArgs a) {
+  const int lane = threadIdx.x & 63, blk = threadIdx.x >> 6;
+  const int64_t atom = a.atom0 + blockIdx.x;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;
+  const int ka = a.ka, k = blk * 64 + lane;
+  const int64_t ED = int64_t(a.E) * a.ld_gsh;
+  T gm[D];
+  {
+    const T* gp = static_cast<const T*>(a.gmbuf) + (atom * D) * int64_t(ka) + k;
+#pragma unroll
+    for (int j = 0; j < D; ++j) gm[j] = gp[int64_t(j) * ka];
+  }
+  const T* sh = static_cast<const T*>(a.sh);
+  const T* av = static_cast<const T*>(a.a);
+  T* ga = static_cast<T*>(a.g_a) + k;
+  T* gse = static_cast<T*>(a.gsh_env) + int64_t(blk) * ED;
+#pragma unroll 2
+  for (int s = beg; s < end; ++s) {
+    const T* y = sh + int64_t(s) * a.ld_sh;
+    T x = av[int64_t(s) * a.ld_a + k];
+    if (a.act) x = silu(x);
+    T d = T(0), gy[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      d += y[j] * gm[j];
+      gy[j] = x * gm[j];
+    }
+    ga[int64_t(s) * a.ld_ga] = d;
+    wave_sum_store<T, D>(gy, gse + int64_t(s) * a.ld_gsh, true, false);
+  }
+}
+
+// ---- split form, register-heavy per-atom kernels of the reverse pass
+template <class Ch, typename T>
+__global__ __launch_bounds__(256) void tp_op_bvecs_kernel(TpOpArgs a) {
+  constexpr int L = Ch::L, D1 = SigAt<Ch, 0>::type::D1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t atom = a.atom0 + blockIdx.x;
+  const int u = a.u, ch = wv * 64 + lane;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;
+  T bm[L][D1];
+  all_atom_vectors<Ch, 0, T, D1>(a, atom, ch, bm);
+  T* bp = static_cast<T*>(a.bvec) + (atom * L * D1) * int64_t(u) + ch;
+#pragma unroll
+  for (int m = 0; m < L; ++m)
+#pragma unroll
+    for (int i = 0; i < D1; ++i) bp[int64_t(m * D1 + i) * u] = bm[m][i];
+}
+
+// d x2s_LI from Q_m (m >= LI, all in HBM) and GM = f * d x2s_LI . Wenv^T  ->  gmbuf
+template <class Ch, int LI, typename T>
+__global__ __launch_bounds__(256) void tp_op_bwd_mid_kernel(TpOpArgs a) {
+  typedef typename SigAt<Ch, LI>::type S;
+  constexpr int D = S::D2, R = S::LMAX + 1, L = Ch::L;
+  constexpr int D1 = SigAt<Ch, 0>::type::D1;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nsl = blockDim.x >> 6;
+  const int64_t atom = a.atom0 + blockIdx.x;
+  const int u = a.u, ch = wv * 64 + lane;
+  const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[atom]), end = __builtin_amdgcn_readfirstlane(a.rowptr[atom + 1]);
+  if (beg >= end) return;
+  T* sG = reinterpret_cast<T*>(aa_smem);  // [nsl][D][64]
+  T q[D1];
+  {
+    const T* qp = static_cast<const T*>(a.q) + ((atom * L + LI) * D1) * int64_t(u) + ch;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) q[i] = qp[int64_t(i) * u];
+  }
+  T g2[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) g2[j] = T(0);
+  x2s_grad_terms<Ch, LI, LI, T>(a, atom, ch, q, g2);
+  {
+    const T sf = T(a.sf);
+#pragma unroll
+    for (int j = 0; j < D; ++j) sG[(wv * D + j) * 64 + lane] = g2[j] * sf;
+  }
+  __syncthreads();
+  const T* Wt = static_cast<const T*>(a.wt);  // [R][u][ka]
+  const int ka = a.ka;
+  for (int blk = wv; blk * 64 < ka; blk += nsl) {
+    const int k = blk * 64 + lane;
+    T gm[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) gm[j] = T(0);
+#pragma unroll 4
+    for (int c = 0; c < u; ++c) {
+      T w3[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) w3[r] = Wt[(int64_t(r) * u + c) * ka + k];
+      const T* sg = sG + ((c >> 6) * D) * 64 + (c & 63);
+#pragma unroll
+      for (int j = 0; j < D; ++j) gm[j] += sg[j * 64] * w3[r_of<0>(j)];
+    }
+    T* gp = static_cast<T*>(a.gmbuf) + (atom * D) * int64_t(ka) + k;
+#pragma unroll
+    for (int j = 0; j < D; ++j) gp[int64_t(j) * ka] = gm[j];
   }
 }
 
@@ -363,12 +595,41 @@ int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStrea
   const int Dsh = chain % 3 == 0 ? 4 : (chain % 3 == 1 ? 9 : 16);
   const size_t smem = reverse ? sizeof(T) * size_t(nsl) * Dsh * 64 : sizeof(T) * size_t(nsl) * Dsh * a.ka_lds;
   dim3 grid((unsigned)(a.N - a.atom0)), block(64 * nsl);
+  const bool split = a.bvec != nullptr && (!reverse || a.gmbuf != nullptr);
+  // split form: [per-atom heavy] -> HBM -> [lean edge streams]; see the kernels above
+#define AA_OP_EDGE(DD, RR, LL)                                                                                  \
+  {                                                                                                             \
+    if (!reverse) {                                                                                             \
+      hipLaunchKernelGGL((tp_op_edge_fwd_kernel<T, DD, RR>), grid, block, 0, stream, a, layer);                 \
+    } else {                                                                                                    \
+      TpOpArgs e = a;                                                                                           \
+      if (layer == 0) {                                                                                         \
+        hipLaunchKernelGGL((tp_op_edge_bwd_kernel<T, DD, RR, LL, true>), grid, block, 0, stream, e, layer);     \
+      } else {                                                                                                  \
+        e.gscal[1] = a.gscal[layer];                                                                            \
+        hipLaunchKernelGGL((tp_op_edge_bwd_kernel<T, DD, RR, LL, false>), grid, block, 0, stream, e, layer);    \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+#define AA_OP_ENV(DD) hipLaunchKernelGGL((tp_op_edge_env_kernel<T, DD>), grid, dim3(a.ka), 0, stream, a);
 #define AA_OP_LAUNCH(CH, LI)                                                                          \
   {                                                                                                   \
-    if (reverse)                                                                                      \
-      hipLaunchKernelGGL((tp_op_bwd_kernel<CH, LI, T>), grid, block, smem, stream, a);                \
-    else                                                                                              \
+    constexpr int DD_ = SigAt<CH, 0>::type::D1, RR_ = SigAt<CH, 0>::type::LMAX + 1, LL_ = CH::L;      \
+    if (!split) {                                                                                     \
+      if (reverse)                                                                                    \
+        hipLaunchKernelGGL((tp_op_bwd_kernel<CH, LI, T>), grid, block, smem, stream, a);              \
+      else                                                                                            \
+        hipLaunchKernelGGL((tp_op_fwd_kernel<CH, LI, T>), grid, block, smem, stream, a);              \
+    } else if (!reverse) {                                                                            \
+      if (a.mbuf) hipLaunchKernelGGL((tp_op_moments_kernel<T, DD_>), grid, dim3(a.ka), 0, stream, a); \
       hipLaunchKernelGGL((tp_op_fwd_kernel<CH, LI, T>), grid, block, smem, stream, a);                \
+      AA_OP_EDGE(DD_, RR_, LL_)                                                                       \
+    } else {                                                                                          \
+      if (LI == 0) hipLaunchKernelGGL((tp_op_bvecs_kernel<CH, T>), grid, block, 0, stream, a);        \
+      AA_OP_EDGE(DD_, RR_, LL_)                                                                       \
+      hipLaunchKernelGGL((tp_op_bwd_mid_kernel<CH, LI, T>), grid, block, smem, stream, a);            \
+      AA_OP_ENV(DD_)                                                                                  \
+    }                                                                                                 \
   }
 #define AA_OP_CHAIN2(CH)                            \
   if (layer == 0) AA_OP_LAUNCH(CH, 0) else if (layer == 1) AA_OP_LAUNCH(CH, 1) else return fail(AA_ERR_INVALID, "tp_op: bad layer");
@@ -384,6 +645,8 @@ int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStrea
     default: return fail(AA_ERR_INVALID, "tp_op: unknown signature chain");
   }
 #undef AA_OP_LAUNCH
+#undef AA_OP_EDGE
+#undef AA_OP_ENV
 #undef AA_OP_CHAIN2
 #undef AA_OP_CHAIN3
   AA_CHECK_HIP(hipGetLastError());
