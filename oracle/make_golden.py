@@ -173,6 +173,12 @@ def main(only=None):
     dump_model("t_spline", dict(test_cfg(True, False), radial_chemical_embed=dict(SPLINE)), mol)
     dump_model("t_spline_peredge", dict(test_cfg(False, True), radial_chemical_embed=dict(SPLINE)), mol)
     dump_model("c2_spline", dict(si_cfg(2, 2, 64), radial_chemical_embed=dict(SPLINE)), si)
+    # the other specialised kernel families, straight from the reference (C2 geometry):
+    dump_model("c2_l3", si_cfg(3, 2, 64), si)                      # moments + chains at l_max = 3
+    dump_model("c2_l1", si_cfg(1, 2, 64), si)                      # ... at l_max = 1
+    dump_model("c2_L3", si_cfg(2, 3, 64), si)                      # 3 layers: per-atom operator path + chains
+    dump_model("c2_u128", si_cfg(2, 2, 128, S=128, H=128), si)     # 128 features: operator path, single-layer GEMMs
+    dump_model("c2_uncoupled", dict(si_cfg(2, 2, 64), tp_path_channel_coupling=False), si)  # p-mode weights
     for seed in range(100):  # pick a seed without unphysically close intermolecular contacts
         w = G.make_water_graph(3, 9.9, r_cut=4.0, seed=seed)
         r = w.pos[w.edge_index[1]] - w.pos[w.edge_index[0]] + w.shift_vec()
