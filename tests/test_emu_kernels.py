@@ -217,3 +217,52 @@ def test_f64_gemm_column_tile_loop_matches_2d_grid(monkeypatch):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     want = fx["out"]["forces"]
     assert (outs[1][1] - want).abs().max().item() <= 1e-9 * max(1.0, float(want.abs().max()))
+
+
+def _tc_model():
+    fx = load_model_fixture("t_coupled", torch.float64)
+    m = model_from_fixture(fx, torch.float64, emu_lib())
+    data, sv = fixture_data(fx, torch.float64)
+    return fx, m, data, sv
+
+
+def test_symmetries_of_the_hip_path():
+    """The invariances the reference's own model tests assert (BaseEnergyModelTests via tests/model/test_allegro.py):
+    permutation equivariance, translation invariance, parity (E even, F odd) -- through the kernels themselves."""
+    fx, m, data, sv = _tc_model()
+    pos, ei, ty = data["pos"], data["edge_index"], data["atom_types"]
+    n = pos.shape[0]
+    e0, f0 = m.energy_forces(pos, m.prepare_graph(ei, ty, n, sv))
+    # permutation of the atoms (edge list relabelled accordingly; it becomes unsorted -> sorted internally)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(4))
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n)
+    e1, f1 = m.energy_forces(pos[perm], m.prepare_graph(inv[ei], ty[perm], n, sv))
+    assert (e1 - e0[perm]).abs().max() < 1e-10 and (f1 - f0[perm]).abs().max() < 1e-10
+    # rigid translation
+    e2, f2 = m.energy_forces(pos + torch.tensor([0.37, -1.2, 2.5], dtype=pos.dtype), m.prepare_graph(ei, ty, n, sv))
+    assert (e2 - e0).abs().max() < 1e-10 and (f2 - f0).abs().max() < 1e-10
+    # inversion through the origin: parity=True model, scalar energy
+    e3, f3 = m.energy_forces(-pos, m.prepare_graph(ei, ty, n, -sv))
+    assert (e3 - e0).abs().max() < 1e-10 and (f3 + f0).abs().max() < 1e-10
+
+
+def test_strict_locality_of_the_hip_path():
+    """tests/model/test_allegro.py:68-70 (`strict_locality`): E_i depends only on atoms inside i's cutoff sphere, and
+    no force acts between atoms that are not neighbors of a common center ... checked by displacing one atom: only
+    the energies of the centers that list it change, and dE_i/dx_j is zero for every other center."""
+    fx, m, data, sv = _tc_model()
+    pos, ei, ty = data["pos"], data["edge_index"], data["atom_types"]
+    n = pos.shape[0]
+    g = m.prepare_graph(ei, ty, n, sv)
+    e0, _ = m.energy_forces(pos, g)
+    j = int(torch.bincount(ei[1], minlength=n).argmin())  # the atom with the fewest centers listing it
+    moved = pos.clone()
+    moved[j] += torch.tensor([0.01, -0.02, 0.015], dtype=pos.dtype)  # small: the neighbor sets stay the same
+    e1, _ = m.energy_forces(moved, g)
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[ei[0][ei[1] == j]] = True   # centers that have j as a neighbor
+    touched[j] = True                   # and j itself (all its own edge vectors move)
+    changed = (e1 - e0).abs() > 1e-13
+    assert not bool((changed & ~touched).any())
+    assert bool(changed[touched].any())
