@@ -150,3 +150,16 @@ def test_multi_block_scans_against_host_cell_list():
     want = set((int(ei[0, e]), int(ei[1, e])) + tuple(int(s) for s in shift[e]) for e in range(ei.shape[1]))
     assert got == want
     assert int(nl.rowptr[-1]) == nl.num_edges and bool((nl.rowptr[1:] >= nl.rowptr[:-1]).all())
+
+
+def test_invalid_inputs_are_reported_not_crashed():
+    from allegro_amd._lib import AllegroError
+
+    lib = emu_lib()
+    pos = torch.zeros((3, 3), dtype=torch.float64)
+    with pytest.raises(AllegroError, match="r_cut"):
+        neighbor_list(pos, np.eye(3) * 5, True, -1.0, lib=lib)
+    with pytest.raises(AllegroError, match="singular"):
+        neighbor_list(pos, np.zeros((3, 3)), True, 2.0, lib=lib)
+    with pytest.raises(AllegroError, match="GPU"):
+        neighbor_list(pos, np.eye(3) * 5, True, 2.0)  # default (gfx950) library: CPU tensors are refused
