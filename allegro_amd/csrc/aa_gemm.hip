@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
 // wave issue, LDS double-buffered (one barrier per step).  Each wave owns 32 rows x 64 columns (2 x 4 MFMA tiles).
 constexpr int G6_BM = 128, G6_BN = 64, G6_BK = 16, G6_LDA = G6_BM + 4;
 typedef double v2d __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
   double* smem = reinterpret_cast<double*>(aa_smem);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = int64_t(blockIdx.x) * G6_BM;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
   const int64_t arow = m0 + ar < g.M ? m0 + ar : g.M - 1;
   const int bk = tid >> 4, bn = (tid & 15) * 4;
   v2d ra[4], rb[2];
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int k0, int nb0) {
     // the segment holding columns [k0, k0+16): wave-uniform
     int c = k0;
     const double* base = nullptr;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
     const int gk = k0 + bk;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int gn = n0 + bn + 2 * q;
+      const int gn = nb0 + bn + 2 * q;
       rb[q] = (gk < g.K && gn + 1 < g.N) ? *reinterpret_cast<const v2d*>(B + int64_t(gk) * g.N + gn)
                                           : v2d{(gk < g.K && gn < g.N) ? B[int64_t(gk) * g.N + gn] : 0.0, 0.0};
     }
@@ -316,13 +316,13 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
-  load_tiles(0);
+  if (nt == 0) load_tiles(0, n0);  // (later column tiles: issued before the previous tile's epilogue, see below)
   store_tiles(0);
   __syncthreads();
   int buf = 0;
   for (int k0 = 0; k0 < g.K; k0 += G6_BK) {
     const bool more = k0 + G6_BK < g.K;
-    if (more) load_tiles(k0 + G6_BK);
+    if (more) load_tiles(k0 + G6_BK, n0);
     const double* a_ = As(buf);
     const double* b_ = Bs(buf);
 #pragma unroll
@@ -342,6 +342,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
     __syncthreads();
     buf ^= 1;
   }
+  // the next column tile's first operands travel while this tile's epilogue runs
+  if (nt + 1 < n_tiles) load_tiles(0, n0 + G6_BN);
   // epilogue: a 16-column tile never straddles a C segment here (widths are multiples of 16, checked by the
   // launcher), so the destination / z / add rows are resolved once per tile, wave-uniformly
 #pragma unroll
