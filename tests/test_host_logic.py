@@ -61,3 +61,20 @@ def test_partition_covers_all_edges():
         assert cuts[0] == 0 and cuts[-1] == g.num_atoms and all(a <= b for a, b in zip(cuts, cuts[1:]))
         sizes = [rowptr[b] - rowptr[a] for a, b in zip(cuts, cuts[1:])]
         assert sum(sizes) == g.num_edges and max(sizes) - min(sizes) <= 2 * 28
+
+
+def test_bench_roofline_accounting_on_synthetic_stages():
+    """bench.py's host-side accounting: the dominant symbol, per-launch algorithmic GB/s and the SURVEY 8(d) step
+    roofline (424 kflop/edge forward+force at the C2-C4 model) from a synthetic stage list."""
+    import bench
+
+    stages = [("gc_64x64_64x64_64x256", 1.0, 4.0e9, 1.0e11), ("gc_128x64_64x64", 0.5, 2.0e9, 0.5e11),
+              ("tp_mom_fwd_first", 0.9, 3.6e9, 0.0), ("edge_prologue", 0.3, 0.9e9, 0.0)]
+    roof, table = bench.roofline_from_stages(stages, "float32", workload="none")
+    assert roof["kernel"] == "gemm_chain_bf16x3_kernel" and roof["launches_per_step"] == 2 and roof["bound"] == "hbm"
+    assert abs(roof["achieved"] - 4000.0) < 1e-6 and abs(roof["frac"] - 0.5) < 1e-9 and roof["traffic"] is None
+    assert abs(roof["fp32_equiv_TFLOPs"] - 100.0) < 1e-6 and list(table)[0] == "gemm_chain_bf16x3_kernel"
+    cfg = bench.si_model_cfg()
+    sr = bench.step_roofline(cfg, 1000, 1e-3, stages, "float32")
+    assert abs(sr["flop_per_edge"] - 423898.0) < 1.0                     # SURVEY 8(d): ~424 kflop/edge
+    assert abs(sr["algorithmic_bytes_per_edge"] - 10.5e9 / 1000) < 1e-3
