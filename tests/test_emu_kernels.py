@@ -266,3 +266,38 @@ def test_strict_locality_of_the_hip_path():
     changed = (e1 - e0).abs() > 1e-13
     assert not bool((changed & ~touched).any())
     assert bool(changed[touched].any())
+
+
+@pytest.mark.parametrize("n,box,L,l_max,dt", [(2, 2.0, 2, 2, "float64"), (3, 2.5, 2, 2, "float64"), (9, 6.0, 2, 2, "float64"),
+                                              (7, 5.0, 3, 2, "float64"), (7, 5.0, 2, 3, "float64"),
+                                              (2, 2.0, 2, 2, "float32"), (9, 6.0, 2, 2, "float32")])
+def test_tiny_graphs_on_the_fast_paths_vs_oracle(n, box, L, l_max, dt):
+    """Fewer edges than one 32-row GEMM tile / one wave (E = 2 ... 28): tile masking, single-edge segments and
+    several periodic images of the same pair, on the 64-wide fast paths (moments + chains, operator path for L = 3)."""
+    from oracle import restatement as R
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+    import numpy as np
+
+    rng = np.random.default_rng(100 + n + L + l_max)
+    rc = 3.0
+    pos = rng.uniform(0, box, size=(n, 3))
+    cell = np.eye(3) * (2 * rc + 0.5)
+    ei, shift = G.neighbor_list_pbc(pos, cell, rc)
+    assert 0 < ei.shape[1] < 32 or n >= 7
+    deg = np.bincount(ei[0], minlength=n)
+    cfg = dict(type_names=["A", "B"], r_max=rc, l_max=l_max, num_layers=L, num_scalar_features=64, num_tensor_features=64,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=64,
+               readout_mlp_hidden_layers_width=64, avg_num_neighbors=max(1.0, float(deg.mean())), seed=3,
+               model_dtype=dt)
+    dtype, tol = (torch.float64, 1e-9) if dt == "float64" else (torch.float32, 5e-5)
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    types = torch.tensor(rng.integers(0, 2, size=n))
+    sv = torch.tensor(shift @ cell, dtype=dtype)
+    e, f = m.energy_forces(torch.tensor(pos, dtype=dtype), m.prepare_graph(torch.tensor(ei), types, n, sv))
+    sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos, dtype=dtype), torch.tensor(ei), types, sv)
+    for got, want in ((e, ref["atomic_energy"].reshape(-1)), (f, ref["forces"])):
+        assert (got - want).abs().max().item() <= tol * max(1.0, float(want.abs().max()))
