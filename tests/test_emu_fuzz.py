@@ -55,3 +55,53 @@ def test_random_configuration_vs_oracle(seed):
     wref = R.allegro_virial(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, sv)
     for got, want in ((e, ref["atomic_energy"].reshape(-1)), (f, ref["forces"]), (w, wref)):
         assert (got - want).abs().max().item() <= 1e-9 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("seed", [1, 3, 8, 13, 20, 22])
+def test_random_fp32_fast_path_configuration_is_as_accurate_as_the_fp32_oracle(seed):
+    """The specialised fp32 paths (64/128-wide: moments or operator TP kernels, bf16x3 GEMM chains or single layers),
+    random species / l_max / layers / embedding: judged against the fp64 oracle on the same (upcast) weights -- the HIP
+    result may not be further from it than the fp32 CPU oracle is (x2 + 1e-5 of the force scale)."""
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(6, 30))
+    rc = float(rng.uniform(2.8, 3.6))
+    box = float(rng.uniform(2 * rc + 0.2, 10.0))
+    k = int(np.ceil(n ** (1 / 3)))
+    grid = np.stack(np.meshgrid(*[np.arange(k)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+    pos = (grid + 0.5 + rng.uniform(-0.25, 0.25, (n, 3))) * (box / k)  # jittered lattice: no unphysically close pairs
+    cell = np.eye(3) * box
+    ei, shift = G.neighbor_list_pbc(pos, cell, rc)
+    assert ei.shape[1] > 0
+    T, l_max, L = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.choice([2, 2, 3]))
+    wide = bool(rng.integers(0, 3) == 0)
+    u = 128 if wide else 64
+    S = 128 if (wide and rng.integers(0, 2)) else 64
+    H = 128 if (wide and rng.integers(0, 2)) else 64
+    spline = bool(rng.integers(0, 2))
+    rce = ({"_target_": "allegro.nn.TwoBodySplineScalarEmbed", "num_splines": 8, "spline_span": 6} if spline else
+           {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8})
+    cfg = dict(type_names=["A", "B", "C"][:T], r_max=rc, l_max=l_max, num_layers=L, num_scalar_features=S,
+               num_tensor_features=u, radial_chemical_embed=rce,
+               radial_chemical_embed_dim=(None if rng.integers(0, 2) else 32), scalar_embed_mlp_hidden_layers_width=64,
+               allegro_mlp_hidden_layers_width=H, readout_mlp_hidden_layers_width=int(rng.choice([32, 64])),
+               tp_path_channel_coupling=bool(rng.integers(0, 4) > 0), avg_num_neighbors=float(max(1, ei.shape[1] / n)),
+               seed=int(seed), model_dtype="float32")
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    types = torch.tensor(rng.integers(0, T, size=n))
+    sv = torch.tensor(shift @ cell, dtype=torch.float32)
+    e, f = m.energy_forces(torch.tensor(pos, dtype=torch.float32), m.prepare_graph(torch.tensor(ei), types, n, sv))
+    sd = {k_[len("func."):]: v.detach() for k_, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos, dtype=torch.float32), torch.tensor(ei), types, sv)
+    sd64 = {k_: (v.double() if v.is_floating_point() else v) for k_, v in sd.items()}
+    ref64 = R.allegro_energy_forces(dict(cfg, model_dtype="float64"), sd64, torch.tensor(pos), torch.tensor(ei), types,
+                                    sv.double())
+    for got, w32, w64 in ((e, ref["atomic_energy"].reshape(-1), ref64["atomic_energy"].reshape(-1)),
+                          (f, ref["forces"], ref64["forces"])):
+        assert torch.isfinite(got).all()
+        scale = max(1.0, float(w64.abs().max()))
+        err_hip = (got.double() - w64).abs().max().item()
+        err_cpu32 = (w32.double() - w64).abs().max().item()
+        assert err_hip <= 2.0 * err_cpu32 + 1e-5 * scale, (err_hip, err_cpu32, scale)
