@@ -105,3 +105,39 @@ def test_random_fp32_fast_path_configuration_is_as_accurate_as_the_fp32_oracle(s
         err_hip = (got.double() - w64).abs().max().item()
         err_cpu32 = (w32.double() - w64).abs().max().item()
         assert err_hip <= 2.0 * err_cpu32 + 1e-5 * scale, (err_hip, err_cpu32, scale)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 7, 11, 19, 23, 31, 42])
+def test_random_irreps_contracter_vs_oracle(seed):
+    """The operator seam (HipContracter = Contracter.forward, _contract.py:185-251) on random irreps of both parities
+    up to l = 3, random multiplicity, both weight modes, unsorted segment indices: output and both input gradients."""
+    from oracle import restatement as R
+    from allegro_amd.nn import HipContracter
+
+    rng = np.random.default_rng(seed)
+    allir = [f"{l}{p}" for l in range(4) for p in "eo"]
+    for _ in range(20):  # redraw until the random irreps admit at least one path
+        def pick(kmax):
+            return " + ".join(rng.choice(allir, size=int(rng.integers(1, kmax + 1)), replace=False))
+
+        i1, i2, io = pick(4), pick(3), pick(4)
+        mul, cpl = int(rng.choice([1, 3, 8, 64])), bool(rng.integers(0, 2))
+        torch.manual_seed(seed)
+        try:
+            c = HipContracter(i1, i2, io, mul=mul, path_channel_coupling=cpl, scatter_factor=float(rng.uniform(0.2, 1.5))).double()
+            break
+        except Exception:
+            continue
+    c._bind_library(emu_lib())
+    E, N = int(rng.integers(1, 40)), int(rng.integers(1, 9))
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.randn(E, mul, c.base_dim1, dtype=torch.float64, generator=g, requires_grad=True)
+    x2 = torch.randn(E, mul, c.base_dim2, dtype=torch.float64, generator=g, requires_grad=True)
+    idxs = torch.randint(0, N, (E,), generator=g)
+    y = c(x1, x2, idxs, N)
+    gy = torch.randn(y.shape, dtype=torch.float64, generator=g)
+    g1, g2 = torch.autograd.grad(y, [x1, x2], gy)
+    yr = R.contracter_forward(x1, x2, idxs, N, c.weights.detach(), c.w3j, cpl, c.scatter_factor)
+    r1, r2 = torch.autograd.grad(yr, [x1, x2], gy)
+    for got, want in ((y, yr), (g1, r1), (g2, r2)):
+        assert (got - want).abs().max().item() < 1e-10
