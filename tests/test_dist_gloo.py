@@ -45,3 +45,38 @@ def test_two_rank_sharding_matches_reference():
         assert p.exitcode == 0
     assert 0 < e_local < 192  # rank 0 really held only a share of the edges
     assert de < 1e-8 and df < 1e-8
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_atom_block_decomposition_is_exact_for_any_rank_count(world):
+    """Single process: the `world` atom blocks of `allegro_amd.dist.local_graph` evaluated one after the other
+    (what the ranks of a multi-GPU job do concurrently) add up to the un-sharded result -- each block carries the
+    owned-atom range hint, so the per-atom kernels only visit its own atoms; fast path (u = S = 64) and the
+    reference's test model."""
+    sys.path.insert(0, ROOT)
+    from allegro_amd.dist import local_graph
+    from tests.golden_utils import load_model_fixture
+    from tests.hip_utils import emu_lib, model_from_fixture
+
+    for name in ("t_coupled", "c2_spline"):
+        dtype = torch.float64 if name == "t_coupled" else torch.float32
+        if name == "c2_spline" and world == 8:
+            continue  # (the emulated 64-wide model is slow: one rank count is enough)
+        fx = load_model_fixture(name, dtype)
+        m = model_from_fixture(fx, dtype, emu_lib())
+        pos = fx["pos"].to(dtype)
+        n = pos.shape[0]
+        sv = None if fx["shift_vec"] is None else fx["shift_vec"].numpy()
+        e_sum, f_sum, edges = torch.zeros(n, dtype=dtype), torch.zeros((n, 3), dtype=dtype), 0
+        for rank in range(world):
+            g, (a0, a1) = local_graph(fx["edge_index"].numpy(), fx["types"].numpy(), n, sv, rank, world, "cpu", dtype)
+            assert g.num_edges == 0 or (g.atom_begin >= a0 and g.atom_end <= a1)
+            e, f = m.energy_forces(pos, g)
+            e_sum[a0:a1] = e[a0:a1]
+            f_sum += f
+            edges += g.num_edges
+        assert edges == fx["edge_index"].shape[1]
+        tol = 1e-8 if dtype == torch.float64 else 5e-5
+        ref = fx["out"]
+        assert (e_sum - ref["atomic_energy"].reshape(-1)).abs().max().item() <= tol * max(1.0, float(ref["atomic_energy"].abs().max()))
+        assert (f_sum - ref["forces"]).abs().max().item() <= tol * max(1.0, float(ref["forces"].abs().max()))
