@@ -10,7 +10,9 @@ out = sys.argv[1]
 KEYS = ("gemm_chain_bf16x3", "gemm_bf16x3_kernel<0", "gemm_bf16x3_kernel<2", "gemm_bf16x3_kernel<4", "gemm_mfma_f32_v3_kernel<0>", "gemm_mfma_f32_v3_kernel<2>", "gemm_mfma_f32_v3_kernel<4>", "gemm_mfma_f32_kernel",
         "gemm_valu", "tp_mom_fwd_first", "tp_mom_fwd_last", "tp_mom_bwd_last", "tp_mom_bwd_first", "tp_chain_fwd_last", "tp_chain_bwd_last", "tp_chain_bwd_first", "tp_spec_fwd", "tp_spec_bwd",
         "tp_layer_fwd", "tp_layer_bwd", "edge_prologue", "edge_backward", "readout_reduce", "readout_backward",
-        "fused_")
+        "tp_op_moments", "tp_op_edge_fwd", "tp_op_edge_bwd", "tp_op_edge_env", "tp_op_bvecs", "tp_op_bwd_mid", "tp_op_fwd",
+        "tp_op_bwd", "gemm_mfma_f64_pipe", "gemm_mfma_f64", "force_gather", "virial_partial", "virial_final", "nl_pairs",
+        "nl_bin", "nl_scan", "nl_cell", "fused_")
 
 
 def short(name):
