@@ -9,14 +9,14 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 CMD="python $ROOT/bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-profile"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD < /dev/null > $OUT/trace.log 2>&1
 echo "trace rc=$?" >> $OUT/trace.log
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
   N=$(echo $C | cut -d' ' -f1)
-  timeout 600 rocprofv3 --pmc $C -d $OUT/pmc_$N -o pmc -- $CMD > $OUT/pmc_$N.log 2>&1
+  timeout 600 rocprofv3 --pmc $C -d $OUT/pmc_$N -o pmc -- $CMD < /dev/null > $OUT/pmc_$N.log 2>&1
   echo "pmc $N rc=$?" >> $OUT/pmc_$N.log
 done
 cd $ROOT
-python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+timeout 120 python tools/summarize_prof.py $OUT < /dev/null > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 find $OUT -name "*.csv" -size +2000k -delete   # keep gpurun_out small (raw traces are not needed)
