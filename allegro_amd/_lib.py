@@ -82,6 +82,10 @@ class AllegroLib:
                                     C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_tp_backward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_tp_weights_workspace_bytes.argtypes = [C.c_void_p, C.c_int64]
+        L.aa_tp_weights_workspace_bytes.restype = C.c_size_t
+        L.aa_tp_backward_weights.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.aa_model_plan_create.argtypes = [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]
         L.aa_model_plan_destroy.argtypes = [C.c_void_p]
         L.aa_model_plan_destroy.restype = None
@@ -126,6 +130,10 @@ class AllegroLib:
     def tp_backward(self, h, E, N, x1, x2s, w, rowptr, eids, sf, gout, gx1, gx2, stream):
         self.check(self.lib.aa_tp_backward(h, E, N, x1, x2s, w, rowptr, eids, sf, gout, gx1, gx2, stream),
                    "aa_tp_backward")
+
+    def tp_backward_weights(self, h, E, N, x1, x2s, rowptr, eids, gout, ws, ws_bytes, gw, stream):
+        self.check(self.lib.aa_tp_backward_weights(h, E, N, x1, x2s, rowptr, eids, gout, ws, ws_bytes, gw, stream),
+                   "aa_tp_backward_weights")
 
     # -- model
     def model_plan_create(self, cfg: ModelConfig) -> int:

@@ -19,8 +19,26 @@ def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "allegro_amd.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _source_deps())
+
+
+def _source_deps():
+    """Files the device library is compiled from (not __pycache__, generators or the host-only torch_ops.cpp)."""
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    return deps + [os.path.join(ROOT, "include", "allegro_amd.h")]
+
+
+def source_hash() -> str:
+    """sha256 over the device sources: identifies the kernels a profile / PMC measurement was taken on
+    (profiles/pmc_traffic_*.json carry it; bench.py attaches measured traffic only when it matches)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in _source_deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 class _BuildLock:
@@ -70,9 +88,20 @@ def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
     PyTorch dispatcher; links against liballegro_amd.so next to it."""
     src = os.path.join(CSRC, "torch_ops.cpp")
     build_library(verbose=verbose)
-    if (not force and os.path.exists(TORCH_LIB_PATH) and
-            os.path.getmtime(TORCH_LIB_PATH) > max(os.path.getmtime(src), os.path.getmtime(LIB_PATH))):
+
+    def fresh():
+        return (os.path.exists(TORCH_LIB_PATH) and
+                os.path.getmtime(TORCH_LIB_PATH) > max(os.path.getmtime(src), os.path.getmtime(LIB_PATH)))
+
+    if not force and fresh():
         return TORCH_LIB_PATH
+    with _BuildLock():  # ranks importing at once: one builds, the others wait and find it fresh
+        if not force and fresh():
+            return TORCH_LIB_PATH
+        return _build_torch_ops_locked(src, verbose)
+
+
+def _build_torch_ops_locked(src: str, verbose: bool) -> str:
     import torch
 
     tdir = os.path.dirname(torch.__file__)
@@ -80,13 +109,14 @@ def build_torch_ops(force: bool = False, verbose: bool = True) -> str:
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
            f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-I", os.path.join(tdir, "include"),
            "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
-           "-I", os.path.join(ROOT, "include"), src, "-o", TORCH_LIB_PATH, "-L", HERE, "-lallegro_amd",
+           "-I", os.path.join(ROOT, "include"), src, "-o", TORCH_LIB_PATH + f".tmp{os.getpid()}", "-L", HERE, "-lallegro_amd",
            "-Wl,-rpath,$ORIGIN", "-L", os.path.join(tdir, "lib"), "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip",
            "-ltorch_hip", "-Wl,-rpath," + os.path.join(tdir, "lib")]
     t0 = time.time()
     if verbose:
         print("[allegro_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(TORCH_LIB_PATH + f".tmp{os.getpid()}", TORCH_LIB_PATH)  # atomic, like the device library
     if verbose:
         print(f"[allegro_amd.build] built {TORCH_LIB_PATH} in {time.time() - t0:.1f}s", flush=True)
     return TORCH_LIB_PATH

@@ -250,6 +250,22 @@ int launch_tp_layer_fwd(const TpLayerDev& L, const TpLayerFwdArgs& a, hipStream_
 template <typename T>
 int launch_tp_layer_bwd(const TpLayerDev& L, const TpLayerBwdArgs& a, hipStream_t stream);
 
+// path-weight gradient of the operator (dense x1, saved x2s); `partial` is caller-provided scratch of
+// tp_layer_wgrad_workspace_elems(L, N) elements
+struct TpLayerWgradArgs {
+  int64_t E, N;
+  const int32_t* rowptr;
+  const int32_t* eids;  // nullable
+  const void* x1;       // [E,u,d1]
+  const void* x2s;      // [N,u,d2] saved by the forward (scatter factor applied)
+  const void* gout;     // [E,u,dout]
+  void* partial;
+  void* gw;             // [u,P] (coupled) or [P]
+};
+size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N);
+template <typename T>
+int launch_tp_layer_wgrad(const TpLayerDev& L, const TpLayerWgradArgs& a, hipStream_t stream);
+
 int build_tp_layer(const aa_tp_desc& d, TpLayerDev* out, std::vector<void*>* owned);
 
 // ---- specialised (compile-time CG table) layer kernels, channel-minor layouts (aa_tp_spec.hip)

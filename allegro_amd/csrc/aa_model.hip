@@ -89,6 +89,32 @@ extern "C" int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, cons
   return plan->dtype == AA_F32 ? launch_tp_layer_bwd<float>(plan->dev, a, s) : launch_tp_layer_bwd<double>(plan->dev, a, s);
 }
 
+extern "C" size_t aa_tp_weights_workspace_bytes(const aa_tp_plan* plan, int64_t N) {
+  if (!plan) return 0;
+  return tp_layer_wgrad_workspace_elems(plan->dev, N) * (plan->dtype == AA_F32 ? 4 : 8);
+}
+
+extern "C" int aa_tp_backward_weights(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,
+                                      const int32_t* rowptr, const int32_t* eids, const void* gout, void* workspace,
+                                      size_t workspace_bytes, void* gweights, aa_stream stream) {
+  AA_REQUIRE(plan && rowptr && gweights, "aa_tp_backward_weights: null argument");
+  AA_REQUIRE(E == 0 || (x1 && x2s && gout), "aa_tp_backward_weights: null tensor");
+  AA_REQUIRE(workspace_bytes >= aa_tp_weights_workspace_bytes(plan, N) && (workspace || workspace_bytes == 0),
+             "aa_tp_backward_weights: workspace too small");
+  TpLayerWgradArgs a{};
+  a.E = E;
+  a.N = N;
+  a.rowptr = rowptr;
+  a.eids = eids;
+  a.x1 = x1;
+  a.x2s = x2s;
+  a.gout = gout;
+  a.partial = workspace;
+  a.gw = gweights;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return plan->dtype == AA_F32 ? launch_tp_layer_wgrad<float>(plan->dev, a, s) : launch_tp_layer_wgrad<double>(plan->dev, a, s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // model plan
 // ------------------------------------------------------------------------------------------------
@@ -1451,9 +1477,14 @@ extern "C" int aa_model_virial(const aa_model_plan* plan, const aa_graph* graph,
 extern "C" int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t N, int64_t E, const void* workspace,
                                   const void** ptr, int64_t* ld) {
   AA_REQUIRE(plan && name && workspace && ptr && ld, "aa_model_debug_tap: null argument");
-  Workspace w = layout_workspace(plan, N, E, 0);
-  const char* base = static_cast<const char*>(workspace);
   std::string n(name);
+  int with_forces = 0;
+  if (n.size() > 2 && n.compare(n.size() - 2, 2, "+f") == 0) {  // layout of a step that computed forces
+    with_forces = 1;
+    n.resize(n.size() - 2);
+  }
+  Workspace w = layout_workspace(plan, N, E, with_forces);
+  const char* base = static_cast<const char*>(workspace);
   if (n == "edge_attrs") {
     *ptr = base + w.sh;
     *ld = plan->D;
@@ -1466,6 +1497,12 @@ extern "C" int aa_model_debug_tap(const aa_model_plan* plan, const char* name, i
   } else if (n == "emb0") {
     *ptr = base + w.emb0;
     *ld = plan->cfg.embed_dim;
+  } else if (n == "vec") {  // [E,4] unit vector, length
+    *ptr = base + w.vec;
+    *ld = 4;
+  } else if (n == "dvec" && with_forces) {  // [E,4] dE/dr_e
+    *ptr = base + w.dvec;
+    *ld = 4;
   } else {
     return fail(AA_ERR_INVALID, "aa_model_debug_tap: unknown tap");
   }

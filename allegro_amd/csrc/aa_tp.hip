@@ -268,6 +268,119 @@ __global__ __launch_bounds__(256) void tp_layer_bwd_kernel(TpLayerDev L, TpLayer
 }
 
 // ---------------------------------------------------------------------------------------------
+// Path-weight gradient (training through the operator seam; the reference's eager Contracter gets it from
+// autograd through `weights`, _contract.py:172-177,219):
+//   gw[ch,p] = sum_e go[e,ch,k] * sum_{nz in (k,p)} c_nz x1[e,ch,i] x2s[center(e),ch,j]      (coupled)
+//   gw[p]    = sum_ch of the above                                                            (uncoupled)
+// Deterministic: every workgroup owns a contiguous range of center atoms and writes one partial [u][P] slab
+// (thread-private accumulators, fixed reduction order inside the block); a second kernel sums the slabs in
+// block order.  No atomics.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWgThreads = 128;
+
+template <typename T>
+__global__ __launch_bounds__(kWgThreads) void tp_layer_wgrad_kernel(TpLayerDev L, TpLayerWgradArgs a, int atoms_per_block) {
+  const int u = L.mul, d1 = L.d1, d2 = L.d2, dout = L.dout, P = L.num_paths;
+  const int d1p = odd_pad(d1), d2p = odd_pad(d2), dop = odd_pad(dout), Pp = odd_pad(P);
+  T* sX2 = reinterpret_cast<T*>(aa_smem);  // [u][d2p]
+  T* sX1 = sX2 + u * d2p;                  // [TPB][d1p]
+  T* sGo = sX1 + kWgThreads * d1p;         // [TPB][dop]
+  T* sW = sGo + kWgThreads * dop;          // [TPB][Pp] thread-private accumulators
+  const int tid = threadIdx.x;
+  const int64_t n0 = int64_t(blockIdx.x) * atoms_per_block;
+  const int64_t n1 = n0 + atoms_per_block < a.N ? n0 + atoms_per_block : a.N;
+  T* part = static_cast<T*>(a.partial) + int64_t(blockIdx.x) * u * P;
+  const int cw = u < kWgThreads ? u : kWgThreads;  // channels handled per pass
+  const int epb = kWgThreads / cw;                 // edges in flight per pass
+  const bool lane_on = tid < epb * cw;
+  for (int cb = 0; cb < u; cb += cw) {
+    const int ch = cb + tid % cw;
+    const bool ch_ok = lane_on && ch < u;
+    for (int p = 0; p < P; ++p) sW[tid * Pp + p] = T(0);
+    for (int64_t n = n0; n < n1; ++n) {
+      const int beg = a.rowptr[n], end = a.rowptr[n + 1];
+      if (beg >= end) continue;  // (uniform over the block)
+      __syncthreads();
+      for (int idx = tid; idx < u * d2; idx += kWgThreads)
+        sX2[(idx / d2) * d2p + idx % d2] = static_cast<const T*>(a.x2s)[n * u * d2 + idx];
+      __syncthreads();
+      for (int s0 = beg; s0 < end; s0 += epb) {
+        const int s = s0 + tid / cw;
+        if (!ch_ok || s >= end) continue;  // no collectives below
+        const int64_t e = a.eids ? a.eids[s] : s;
+        T* x1 = sX1 + tid * d1p;
+        T* go = sGo + tid * dop;
+        for (int i = 0; i < d1; ++i) x1[i] = static_cast<const T*>(a.x1)[(e * u + ch) * d1 + i];
+        for (int k = 0; k < dout; ++k) go[k] = static_cast<const T*>(a.gout)[(e * u + ch) * dout + k];
+        const T* x2 = sX2 + ch * d2p;
+        for (int gi = 0; gi < L.fwd.num_groups; ++gi) {
+          const TpGroup grp = L.fwd.groups[gi];
+          T acc = T(0);
+          for (int nz = grp.begin; nz < grp.end; ++nz) {
+            const TpEntry en = L.fwd.entries[nz];
+            acc += entry_val(en, T(0)) * x1[en.a] * x2[en.b];
+          }
+          if (grp.end > grp.begin) sW[tid * Pp + grp.path] += go[grp.out_idx] * acc;
+        }
+      }
+    }
+    __syncthreads();
+    // fixed-order sum over the epb threads that share a channel
+    if (tid < cw && cb + tid < u) {
+      for (int p = 0; p < P; ++p) {
+        T v = T(0);
+        for (int m = 0; m < epb; ++m) v += sW[(tid + m * cw) * Pp + p];
+        part[(cb + tid) * P + p] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tp_layer_wgrad_reduce_kernel(const T* partial, int nblocks, int u, int P, int coupling, T* gw) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (coupling) {
+    if (idx >= u * P) return;
+    T v = T(0);
+    for (int b = 0; b < nblocks; ++b) v += partial[int64_t(b) * u * P + idx];
+    gw[idx] = v;
+  } else {
+    if (idx >= P) return;
+    T v = T(0);
+    for (int b = 0; b < nblocks; ++b)
+      for (int ch = 0; ch < u; ++ch) v += partial[(int64_t(b) * u + ch) * P + idx];
+    gw[idx] = v;
+  }
+}
+
+static int wgrad_blocks(int64_t N) { return int(std::min<int64_t>(std::max<int64_t>(N, 1), 1024)); }
+
+size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N) { return size_t(wgrad_blocks(N)) * L.mul * L.num_paths; }
+
+template <typename T>
+int launch_tp_layer_wgrad(const TpLayerDev& L, const TpLayerWgradArgs& a, hipStream_t stream) {
+  const int nb = wgrad_blocks(a.N);
+  if (a.N == 0 || a.E == 0) {
+    AA_CHECK_HIP(hipMemsetAsync(a.gw, 0, sizeof(T) * size_t(L.coupling ? L.mul : 1) * L.num_paths, stream));
+    return AA_OK;
+  }
+  const int apb = int((a.N + nb - 1) / nb);
+  size_t smem = sizeof(T) * (size_t(L.mul) * odd_pad(L.d2) +
+                             size_t(kWgThreads) * (odd_pad(L.d1) + odd_pad(L.dout) + odd_pad(L.num_paths)));
+  AA_REQUIRE(smem <= 160 * 1024, "tp wgrad: LDS budget exceeded");
+  AA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_layer_wgrad_kernel<T>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(tp_layer_wgrad_kernel<T>, dim3((unsigned)nb), dim3(kWgThreads), smem, stream, L, a, apb);
+  AA_CHECK_HIP(hipGetLastError());
+  const int nout = (L.coupling ? L.mul : 1) * L.num_paths;
+  hipLaunchKernelGGL(tp_layer_wgrad_reduce_kernel<T>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<const T*>(a.partial), nb, L.mul, L.num_paths, L.coupling, static_cast<T*>(a.gw));
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: tables
 // ---------------------------------------------------------------------------------------------
 static int upload_table(const std::vector<std::tuple<int, int, int, int, double>>& ents_in /*out,path,a,b,val*/,
@@ -365,5 +478,7 @@ template int launch_tp_layer_fwd<float>(const TpLayerDev&, const TpLayerFwdArgs&
 template int launch_tp_layer_fwd<double>(const TpLayerDev&, const TpLayerFwdArgs&, hipStream_t);
 template int launch_tp_layer_bwd<float>(const TpLayerDev&, const TpLayerBwdArgs&, hipStream_t);
 template int launch_tp_layer_bwd<double>(const TpLayerDev&, const TpLayerBwdArgs&, hipStream_t);
+template int launch_tp_layer_wgrad<float>(const TpLayerDev&, const TpLayerWgradArgs&, hipStream_t);
+template int launch_tp_layer_wgrad<double>(const TpLayerDev&, const TpLayerWgradArgs&, hipStream_t);
 
 }  // namespace aa

@@ -2,7 +2,8 @@
 // (LAMMPS pair_allegro, which loads nequip-compile'd packages: allegro/_compile.py:10-14,68-74) can call:
 //
 //   allegro_amd_native::energy_forces(Tensor pos, Tensor edge_index, Tensor atom_types, Tensor? shift_vec,
-//                                     int[] config, Tensor weights) -> (Tensor atom_energy, Tensor forces)
+//                                     int[] config, Tensor weights)
+//       -> (Tensor atom_energy [N], Tensor forces [N,3], Tensor virial [1,3,3])
 //
 // Everything the op needs travels in its arguments, so it survives torch.export / AOTI packaging: `config` is an int
 // list holding the serialized aa_model_config (hyper-parameters + the Clebsch-Gordan non-zeros of every layer,
@@ -11,6 +12,7 @@
 // it builds the center-sorted CSR view with ATen ops, takes the workspace from the caching allocator and
 // launches on the current stream.  There is no CPU kernel: only a Meta (shape) kernel besides the GPU one.
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -51,11 +53,14 @@ double as_double(int64_t bits) {
 //   readout_mlp_width, forward_weight_init, has_scales, has_shifts, embed_kind, spline_span,
 //   bits(poly_p), bits(avg_num_neighbors), bits(act_const), 0, 0, 0]  then per layer
 //   [mul, d1, d2, dout, num_paths, coupling, nnz, i[nnz], j[nnz], k[nnz], path[nnz], bits(val)[nnz]]
-const PlanEntry& plan_for(at::IntArrayRef config) {
+// (a plan owns Clebsch-Gordan tables in the memory of the device that was current when it was created: the cache
+//  key carries the device index and the caller holds a device guard)
+const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
   const int64_t* w = config.data();
   const int64_t n = int64_t(config.size());
   TORCH_CHECK(n >= kHeader && w[0] == kMagic, "allegro_amd: not a serialized model config");
   std::string key(reinterpret_cast<const char*>(w), size_t(n) * 8);
+  key.append(reinterpret_cast<const char*>(&device_index), sizeof(device_index));
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_plans.find(key);
   if (it != g_plans.end()) return *it->second;
@@ -114,13 +119,18 @@ const PlanEntry& plan_for(at::IntArrayRef config) {
   return *(g_plans[key] = std::move(e));
 }
 
-std::tuple<at::Tensor, at::Tensor> energy_forces_gpu(const at::Tensor& pos, const at::Tensor& edge_index,
-                                                     const at::Tensor& atom_types,
-                                                     const std::optional<at::Tensor>& shift_vec, at::IntArrayRef config,
-                                                     const at::Tensor& weights) {
-  const PlanEntry& pe = plan_for(config);
+std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tensor& pos, const at::Tensor& edge_index,
+                                                                 const at::Tensor& atom_types,
+                                                                 const std::optional<at::Tensor>& shift_vec,
+                                                                 at::IntArrayRef config, const at::Tensor& weights) {
   TORCH_CHECK(pos.is_cuda() && edge_index.is_cuda() && atom_types.is_cuda() && weights.is_cuda(),
               "allegro_amd::energy_forces: tensors must live on the GPU; there is no CPU fallback");
+  TORCH_CHECK(edge_index.get_device() == pos.get_device() && atom_types.get_device() == pos.get_device() &&
+                  weights.get_device() == pos.get_device(),
+              "allegro_amd::energy_forces: all tensors must live on the same device");
+  // plan tables, workspace and launches all belong to the device of `pos`, whatever the caller's current device is
+  const c10::hip::HIPGuard device_guard(pos.device());
+  const PlanEntry& pe = plan_for(config, int(pos.get_device()));
   TORCH_CHECK(pos.dim() == 2 && pos.size(1) == 3 && edge_index.dim() == 2 && edge_index.size(0) == 2, "bad shapes");
   const int64_t N = pos.size(0), E = edge_index.size(1);
   const int64_t dt = config[1];
@@ -164,14 +174,19 @@ std::tuple<at::Tensor, at::Tensor> energy_forces_gpu(const at::Tensor& pos, cons
   const int rc = aa_model_energy_forces(pe.plan, weights.data_ptr(), &g, p.data_ptr(), ws.data_ptr(), wsb,
                                         e_atom.data_ptr(), forces.data_ptr(), stream);
   TORCH_CHECK(rc == 0, "aa_model_energy_forces failed (", rc, "): ", aa_last_error());
-  return {e_atom, forces};
+  // strain derivative W = sum_e dE/dr_e (x) r_e from the per-edge data the step left in the workspace; reported in
+  // LAMMPS' / nequip's VIRIAL_KEY convention, virial = -dE/d(strain) (ForceStressOutput, EXT), shape [1,3,3]
+  at::Tensor w9 = at::empty({9}, pos.options());
+  const int rv = aa_model_virial(pe.plan, &g, ws.data_ptr(), wsb, w9.data_ptr(), stream);
+  TORCH_CHECK(rv == 0, "aa_model_virial failed (", rv, "): ", aa_last_error());
+  return {e_atom, forces, w9.neg().reshape({1, 3, 3})};
 }
 
-std::tuple<at::Tensor, at::Tensor> energy_forces_meta(const at::Tensor& pos, const at::Tensor& edge_index,
-                                                      const at::Tensor& atom_types,
-                                                      const std::optional<at::Tensor>& shift_vec, at::IntArrayRef config,
-                                                      const at::Tensor& weights) {
-  return {pos.new_empty({pos.size(0)}), pos.new_empty({pos.size(0), 3})};
+std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_meta(const at::Tensor& pos, const at::Tensor& edge_index,
+                                                                  const at::Tensor& atom_types,
+                                                                  const std::optional<at::Tensor>& shift_vec,
+                                                                  at::IntArrayRef config, const at::Tensor& weights) {
+  return {pos.new_empty({pos.size(0)}), pos.new_empty({pos.size(0), 3}), pos.new_empty({1, 3, 3})};
 }
 
 }  // namespace
@@ -179,7 +194,7 @@ std::tuple<at::Tensor, at::Tensor> energy_forces_meta(const at::Tensor& pos, con
 TORCH_LIBRARY(allegro_amd_native, m) {
   m.def(
       "energy_forces(Tensor pos, Tensor edge_index, Tensor atom_types, Tensor? shift_vec, int[] config, Tensor weights)"
-      " -> (Tensor, Tensor)");
+      " -> (Tensor, Tensor, Tensor)");
 }
 TORCH_LIBRARY_IMPL(allegro_amd_native, CUDA, m) { m.impl("energy_forces", &energy_forces_gpu); }
 TORCH_LIBRARY_IMPL(allegro_amd_native, Meta, m) { m.impl("energy_forces", &energy_forces_meta); }

@@ -51,8 +51,12 @@ def serialize_config(model) -> list:
 
 
 class ExportableAllegro(torch.nn.Module):
-    """`forward(pos, edge_index, atom_types[, shift_vec]) -> (atomic_energy [N,1], total_energy [1,1], forces [N,3])`
-    through the C++-registered op; build it from a `HipAllegroModel` whose weights are final."""
+    """`forward(pos, edge_index, atom_types[, shift_vec]) -> (atomic_energy [N,1], total_energy [1,1], forces [N,3],
+    virial [1,3,3])` -- the `LMP_OUTPUTS` of the reference's `pair_allegro` compile target (allegro/_compile.py:68-74;
+    the key list itself is nequip's, EXT: per-atom energy, total energy, forces, virial) -- through the
+    C++-registered op; build it from a `HipAllegroModel` whose weights are final.  virial = -dE/d(strain)
+    (nequip ForceStressOutput convention, which is also LAMMPS' sign); in the ghost-atom layout it is the sum over
+    the edges handed in, i.e. the local atoms' share, like every other output."""
 
     def __init__(self, model, device):
         super().__init__()
@@ -65,6 +69,6 @@ class ExportableAllegro(torch.nn.Module):
 
     def forward(self, pos: torch.Tensor, edge_index: torch.Tensor, atom_types: torch.Tensor,
                 shift_vec: Optional[torch.Tensor] = None):
-        e_atom, forces = torch.ops.allegro_amd_native.energy_forces(pos, edge_index, atom_types, shift_vec, self.config,
-                                                                    self.weights)
-        return e_atom.unsqueeze(-1), e_atom.sum().reshape(1, 1), forces
+        e_atom, forces, virial = torch.ops.allegro_amd_native.energy_forces(pos, edge_index, atom_types, shift_vec,
+                                                                            self.config, self.weights)
+        return e_atom.unsqueeze(-1), e_atom.sum().reshape(1, 1), forces, virial

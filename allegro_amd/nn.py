@@ -37,6 +37,17 @@ def _stream_ptr(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
 
+def _device_ctx(device):
+    """Make `device` the current HIP device for plan creation / packing / launches (plans and packed weights are
+    device-specific; kernels are enqueued on that device's current stream)."""
+    device = torch.device(device)
+    if device.type == "cuda":
+        return torch.cuda.device(device)
+    import contextlib
+
+    return contextlib.nullcontext()
+
+
 def _require_gpu(lib: _lib.AllegroLib, t: torch.Tensor, what: str):
     if not t.is_cuda and not lib.is_emulation:
         raise _lib.AllegroError(f"{what}: tensors must live on the GPU (got {t.device}); there is no CPU fallback")
@@ -136,10 +147,14 @@ def w3j_to_desc(w3j: torch.Tensor, mul: int, dims: Tuple[int, int, int], num_pat
 # ------------------------------------------------------------------------------------------------
 # segment bookkeeping
 # ------------------------------------------------------------------------------------------------
-def segments_from_index(idxs: torch.Tensor, num_segments: int):
-    """rowptr[int32, N+1] and (if idxs is not sorted) the stable sort permutation eids[int32, E]."""
+def segments_from_index(idxs: torch.Tensor, num_segments: int, assume_sorted: bool = False):
+    """rowptr[int32, N+1] and (if idxs is not sorted) the stable sort permutation eids[int32, E].
+    `assume_sorted=True` skips the sortedness check, i.e. the only device->host synchronisation of this function
+    (the caller vouches that `idxs` is non-decreasing, as the center index of a model's edge list is)."""
     idxs = idxs.reshape(-1)
-    is_sorted = bool((idxs[1:] >= idxs[:-1]).all()) if idxs.numel() > 1 else True
+    is_sorted = True
+    if not assume_sorted and idxs.numel() > 1:
+        is_sorted = bool((idxs[1:] >= idxs[:-1]).all())
     eids = None
     if not is_sorted:
         eids = torch.argsort(idxs, stable=True).to(torch.int32)
@@ -147,6 +162,32 @@ def segments_from_index(idxs: torch.Tensor, num_segments: int):
     rowptr = torch.zeros(num_segments + 1, dtype=torch.int32, device=idxs.device)
     rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
     return rowptr, eids
+
+
+class _SegmentCache:
+    """rowptr / eids of the most recent index tensors, keyed on (storage address, in-place version, length, segment
+    count).  The keyed tensor is kept alive by the entry, so its address cannot be recycled for another tensor
+    while the entry exists.  All Contracters of a model receive the SAME `idxs` tensor in every layer
+    (allegro/nn/_allegro.py:238,268), so one entry serves the whole forward; a handful covers train/val alternation."""
+
+    def __init__(self, capacity: int = 4):
+        self.capacity = capacity
+        self.entries = []  # [(key, idxs_ref, rowptr, eids)]
+
+    def get(self, idxs: torch.Tensor, num_segments: int, assume_sorted: bool):
+        key = (idxs.data_ptr(), int(idxs._version), int(idxs.numel()), int(num_segments), str(idxs.device), bool(assume_sorted))
+        for i, (k, _ref, rowptr, eids) in enumerate(self.entries):
+            if k == key:
+                if i:
+                    self.entries.insert(0, self.entries.pop(i))
+                return rowptr, eids
+        rowptr, eids = segments_from_index(idxs, num_segments, assume_sorted)
+        self.entries.insert(0, (key, idxs, rowptr, eids))
+        del self.entries[self.capacity:]
+        return rowptr, eids
+
+
+_SEGMENTS = _SegmentCache()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -178,10 +219,12 @@ class HipContracter(torch.nn.Module):
         if self.num_paths > 1:
             shape = shape + (self.num_paths,)
         self.weights = torch.nn.Parameter(torch.empty(shape).uniform_(-math.sqrt(3), math.sqrt(3)))
-        self._plans: Dict[torch.dtype, int] = {}
+        self._plans: Dict[tuple, int] = {}  # (dtype, device index) -> aa_tp_plan*
         self._keep = []
         self._bound_lib: Optional[_lib.AllegroLib] = None
         self._lib_id = 0
+        # set True when the caller guarantees center-sorted `idxs` (skips the sortedness check and its host sync)
+        self.assume_sorted_idxs = False
 
     def _get_lib(self) -> _lib.AllegroLib:
         return self._bound_lib if self._bound_lib is not None else _lib.load()
@@ -192,29 +235,37 @@ class HipContracter(torch.nn.Module):
         self._lib_id = ops.register_library(lib)
         self._plans.clear()
 
-    def _plan(self, dtype) -> int:
-        if dtype not in self._plans:
+    def _plan(self, dtype, device=None) -> int:
+        """The plan owns device-resident Clebsch-Gordan tables: one per (dtype, device), created with that device current."""
+        dev = torch.device("cpu") if device is None else torch.device(device)
+        key = (dtype, dev.index if dev.type == "cuda" else -1)
+        if key not in self._plans:
             desc, keep = w3j_to_desc(self.w3j, self.mul, (self.base_dim1, self.base_dim2, self.base_dim_out),
                                      self.num_paths, self.w3j_is_ij_diagonal, self.path_channel_coupling)
             self._keep.append(keep)
-            self._plans[dtype] = self._get_lib().tp_plan_create(desc, _TORCH2AA[dtype])
-        return self._plans[dtype]
+            with _device_ctx(dev):
+                self._plans[key] = self._get_lib().tp_plan_create(desc, _TORCH2AA[dtype])
+        return self._plans[key]
 
     def forward(self, x1, x2, idxs, scatter_dim_size):
         if isinstance(scatter_dim_size, torch.Tensor):
             scatter_dim_size = int(scatter_dim_size.reshape(-1)[0])
         x1 = x1.reshape(-1, self.mul, self.base_dim1)
         x2 = x2.reshape(-1, self.mul, self.base_dim2)
-        rowptr, eids = segments_from_index(idxs, scatter_dim_size)
+        # per-call host sync / bincount / cumsum only on the first layer of the first forward with this index tensor
+        rowptr, eids = _SEGMENTS.get(idxs, scatter_dim_size, self.assume_sorted_idxs)
         sf = 1.0 if self.scatter_factor is None else float(self.scatter_factor)
         return self._op(x1, x2, rowptr, eids, int(scatter_dim_size), sf)
 
     def _op(self, x1, x2, rowptr, eids, num_atoms: int, scatter_factor: float):
-        """The registered library op (allegro_amd/ops.py); autograd gives the x1/x2 gradients, none for the weights."""
+        """The registered library op (allegro_amd/ops.py).  Autograd gives the x1 / x2 gradients and -- when the path
+        weights require grad (training, like the reference's eager and cuEquivariance contracters,
+        _contract.py:172-177) -- the weight gradient from `aa_tp_backward_weights`."""
         _require_gpu(self._get_lib(), x1, "HipContracter")
-        out, _x2s = torch.ops.allegro_amd.tp_forward(x1, x2, self.weights.detach(), rowptr, eids, num_atoms,
-                                                     scatter_factor, self._plan(x1.dtype), self._lib_id,
-                                                     self.base_dim2, self.base_dim_out)
+        with _device_ctx(x1.device):
+            out, _x2s = torch.ops.allegro_amd.tp_forward(x1, x2, self.weights, rowptr, eids, num_atoms,
+                                                         scatter_factor, self._plan(x1.dtype, x1.device), self._lib_id,
+                                                         self.base_dim2, self.base_dim_out)
         return out
 
     def _contract(self, x1, x2):
@@ -258,21 +309,42 @@ def replace_submodules(model: torch.nn.Module, target_cls, factory) -> torch.nn.
     return model
 
 
+class _DuckContracterMeta(type):
+    """isinstance(obj, AnyContracter) <=> obj carries a reference Contracter's attributes and is not already a
+    HipContracter (so the modifier works on the reference's class without importing it)."""
+    _ATTRS = ("irreps_in1", "irreps_in2", "irreps_out", "mul", "w3j", "weights", "path_channel_coupling")
+
+    def __instancecheck__(cls, obj):
+        return (not isinstance(obj, HipContracter)) and all(hasattr(obj, a) for a in cls._ATTRS)
+
+
+class AnyContracter(metaclass=_DuckContracterMeta):
+    pass
+
+
 def enable_HipContracter(model: torch.nn.Module, contracter_cls=None) -> torch.nn.Module:
     """Model modifier: swap every `Contracter` of `model` for the HIP operator -- the analogue of
     `Contracter.enable_TritonContracter` (_contract.py:253-282).  `contracter_cls` defaults to any module that
-    carries a Contracter's attributes (so it works on the reference's class without importing it).  Unlike the
-    Triton kernel there is no build-time guard: ij-diagonal, single-path and uncoupled modes are all covered."""
-    if contracter_cls is None:
-        attrs = ("irreps_in1", "irreps_in2", "irreps_out", "mul", "w3j", "weights", "path_channel_coupling")
+    carries a Contracter's attributes.  Unlike the Triton kernel there is no build-time guard: ij-diagonal,
+    single-path and uncoupled modes are all covered, and so is training mode (weight gradients).
 
-        class _Duck(type):
-            def __instancecheck__(self, obj):
-                return (not isinstance(obj, HipContracter)) and all(hasattr(obj, a) for a in attrs)
+    Discovery through nequip (`nequip.model.modify` in a config, `nequip-compile --modifiers enable_HipContracter`):
+    `allegro_amd._nequip_ext.register()` -- run by the `nequip.extension` entry point of this package's
+    pyproject.toml, like the reference's own `init_always = "allegro"` (pyproject.toml:50-51) -- attaches this
+    function to the reference's `Contracter` as a `@model_modifier(persistent=False) @classmethod`, the exact form of
+    `_contract.py:253-255,284-286`."""
+    return replace_submodules(model, AnyContracter if contracter_cls is None else contracter_cls,
+                              HipContracter.from_contracter)
 
-        class contracter_cls(metaclass=_Duck):  # noqa: N801
-            pass
-    return replace_submodules(model, contracter_cls, HipContracter.from_contracter)
+
+def _enable_HipContracter_classmethod(cls, model):
+    """Body of the classmethod attached to the reference's Contracter (and to HipContracter below): replaces
+    instances of `cls` -- the signature nequip's modifier machinery calls, `_contract.py:255,282`."""
+    target = AnyContracter if cls is HipContracter else cls
+    return replace_submodules(model, target, HipContracter.from_contracter)
+
+
+HipContracter.enable_HipContracter = classmethod(_enable_HipContracter_classmethod)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -532,12 +604,16 @@ class HipAllegroModel(torch.nn.Module):
         for p in self.parameters():
             p.requires_grad_(False)  # inference/force path: no weight gradients (like _flashallegro.py:660)
         self._bound_lib: Optional[_lib.AllegroLib] = None
+        # plans own device-resident tables and the packed weights / workspace are device buffers: one set per device,
+        # `_plan_handle` / `_blob` / `_workspace` always refer to the device of the current call (`_select_device`)
+        self._per_device: Dict[int, dict] = {}
         self._plan_handle = None
         self._plan_keep = None
         self._blob: Optional[torch.Tensor] = None
         self._blob_key = None
         self._workspace: Optional[torch.Tensor] = None
-        self._graph_cache: Tuple[Optional[tuple], Optional[PreparedGraph]] = (None, None)
+        self._cur_dev = None
+        self._graph_cache = None  # (key, keyed tensors kept alive, PreparedGraph structure) of forward()
 
     # -- library / plan -------------------------------------------------------------------------
     def _get_lib(self) -> _lib.AllegroLib:
@@ -545,14 +621,47 @@ class HipAllegroModel(torch.nn.Module):
 
     def _bind_library(self, lib: _lib.AllegroLib):
         """(tests) bind an explicitly loaded library instead of the default gfx950 one."""
+        self._drop_device_state()
         self._bound_lib = lib
-        self._plan_handle = None
-        self._blob = None
+
+    def _drop_device_state(self):
+        self._stash_device_state()
+        for st in self._per_device.values():
+            if st.get("plan") is not None:
+                try:
+                    self._get_lib().model_plan_destroy(st["plan"])
+                except Exception:
+                    pass
+        self._per_device = {}
+        self._plan_handle = self._plan_keep = self._blob = self._blob_key = self._workspace = self._cur_dev = None
+
+    def _stash_device_state(self):
+        if self._cur_dev is not None:
+            self._per_device[self._cur_dev] = dict(plan=self._plan_handle, keep=self._plan_keep, blob=self._blob,
+                                                   blob_key=self._blob_key, ws=self._workspace,
+                                                   hip_graph=getattr(self, "_hip_graph", False), out=getattr(self, "_out", None))
+
+    def _select_device(self, device) -> None:
+        """Switch the per-device state (plan, packed weights, workspace) to `device`."""
+        device = torch.device(device)
+        idx = device.index if device.type == "cuda" and device.index is not None else (
+            torch.cuda.current_device() if device.type == "cuda" else -1)
+        if idx == self._cur_dev:
+            return
+        self._stash_device_state()
+        st = self._per_device.get(idx, {})
+        self._plan_handle, self._plan_keep = st.get("plan"), st.get("keep")
+        self._blob, self._blob_key, self._workspace = st.get("blob"), st.get("blob_key"), st.get("ws")
+        self._hip_graph, self._out = st.get("hip_graph", False), st.get("out")
+        self._cur_dev = idx
 
     def _sd(self) -> Dict[str, torch.Tensor]:
         return {k[len("func."):]: v for k, v in self.state_dict().items()}
 
     def _ensure_plan(self):
+        if self._cur_dev is None:  # first use without tensors (export, enable_hip_graph): the current device
+            self._select_device(torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                                else torch.device("cpu"))
         if self._plan_handle is not None:
             return
         hp = self.hparams
@@ -630,10 +739,7 @@ class HipAllegroModel(torch.nn.Module):
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         # w3j buffers may have changed: rebuild device tables lazily
-        if self._plan_handle is not None:
-            self._get_lib().model_plan_destroy(self._plan_handle)
-            self._plan_handle = None
-        self._blob = None
+        self._drop_device_state()
         return out
 
     # -- evaluation -----------------------------------------------------------------------------
@@ -645,6 +751,11 @@ class HipAllegroModel(torch.nn.Module):
         lib = self._get_lib()
         _require_gpu(lib, pos, "HipAllegroModel")
         assert pos.dtype == self.dtype, f"positions must be {self.dtype}"
+        with _device_ctx(pos.device):
+            return self._energy_forces_on_device(lib, pos, graph, with_forces)
+
+    def _energy_forces_on_device(self, lib, pos, graph, with_forces):
+        self._select_device(pos.device)
         self._ensure_plan()
         self._ensure_weights(pos.device)
         N, E = graph.num_atoms, graph.num_edges
@@ -675,6 +786,10 @@ class HipAllegroModel(torch.nn.Module):
         lib = self._get_lib()
         out = torch.empty(9, dtype=self.dtype, device=self._workspace.device)
         g = graph.c_struct()
+        with _device_ctx(out.device):
+            return self._virial_on_device(lib, g, out)
+
+    def _virial_on_device(self, lib, g, out):
         lib.check(lib.lib.aa_model_virial(self._plan_handle, C.byref(g), self._workspace.data_ptr(), self._workspace.numel(),
                                           out.data_ptr(), _stream_ptr(out)), "aa_model_virial")
         return out.view(3, 3)
@@ -688,11 +803,13 @@ class HipAllegroModel(torch.nn.Module):
         self._hip_graph = bool(on)
         self._out = None
 
-    def debug_tap(self, name: str, graph: PreparedGraph) -> torch.Tensor:
+    def debug_tap(self, name: str, graph: PreparedGraph, with_forces: bool = False) -> torch.Tensor:
+        """Copy of a per-edge intermediate of the LAST step out of the workspace ("dvec" / "vec" need the layout of a
+        step that computed forces: `with_forces=True`)."""
         lib = self._get_lib()
         ptr, ld = C.c_void_p(), C.c_int64()
-        rc = lib.lib.aa_model_debug_tap(self._plan_handle, name.encode(), graph.num_atoms, graph.num_edges,
-                                        self._workspace.data_ptr(), C.byref(ptr), C.byref(ld))
+        rc = lib.lib.aa_model_debug_tap(self._plan_handle, (name + ("+f" if with_forces else "")).encode(), graph.num_atoms,
+                                        graph.num_edges, self._workspace.data_ptr(), C.byref(ptr), C.byref(ld))
         if rc < 0:
             lib.check(rc, "aa_model_debug_tap")
         off = (ptr.value - self._workspace.data_ptr()) // self._workspace.element_size()
@@ -700,37 +817,68 @@ class HipAllegroModel(torch.nn.Module):
         flat = self._workspace[off: off + graph.num_edges * ld.value * esz].view(self.dtype)
         return flat.view(graph.num_edges, ld.value).clone()
 
+    def _graph_for(self, data: Dict[str, torch.Tensor]) -> PreparedGraph:
+        """Center-sorted CSR view of `data`'s edge list.  The STRUCTURE (sort permutation, rowptr, transposed CSR,
+        types) is cached, keyed on the identity + in-place version of `edge_index` and `atom_types`; the keyed
+        tensors are kept alive by the cache entry so their addresses cannot be recycled.  Everything that depends
+        on values that change while the edge list stays put -- the periodic shift vectors `edge_cell_shift @ cell`
+        -- is recomputed on every call (NPT / strain scans change `cell` with a fixed edge list)."""
+        pos, ei, at = data["pos"], data["edge_index"], data["atom_types"]
+        key = (ei.data_ptr(), tuple(ei.shape), int(ei._version), at.data_ptr(), int(at._version), int(pos.shape[0]),
+               str(ei.device))
+        if self._graph_cache is None or self._graph_cache[0] != key:
+            self._graph_cache = (key, (ei, at), PreparedGraph(ei, at, pos.shape[0], None))
+        graph = self._graph_cache[2]
+        shift_vec = None
+        if "edge_cell_shift" in data and "cell" in data:
+            ecs = data["edge_cell_shift"].to(self.dtype)
+            cell = data["cell"].to(self.dtype).reshape(-1, 3, 3)
+            if cell.shape[0] == 1:
+                shift_vec = ecs @ cell[0]
+            else:  # batched frames: the cell of each edge's frame (nequip with_edge_vectors_: cell[batch[center]])
+                if "batch" not in data:
+                    raise ValueError("a [B,3,3] cell needs the `batch` vector")
+                shift_vec = torch.einsum("ei,eij->ej", ecs, cell[data["batch"][ei[0]]])
+            if graph.perm is not None:
+                shift_vec = shift_vec[graph.perm]
+            shift_vec = shift_vec.contiguous()
+        graph.shift_vec = shift_vec
+        return graph
+
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """AtomicDataDict in, AtomicDataDict out (keys: pos, edge_index, atom_types [, cell, edge_cell_shift, batch])."""
         pos = data["pos"]
-        ei = data["edge_index"]
-        key = (ei.data_ptr(), tuple(ei.shape), int(ei._version), pos.shape[0])
-        if self._graph_cache[0] != key:
-            shift_vec = None
-            if "edge_cell_shift" in data and "cell" in data:
-                shift_vec = (data["edge_cell_shift"].to(self.dtype) @ data["cell"].view(3, 3).to(self.dtype))
-            self._graph_cache = (key, PreparedGraph(ei, data["atom_types"], pos.shape[0], shift_vec))
-        graph = self._graph_cache[1]
+        graph = self._graph_for(data)
         e_atom, forces = self.energy_forces(pos.to(self.dtype), graph, with_forces=True)
         out = dict(data)
         out["atomic_energy"] = e_atom.unsqueeze(-1)
+        nf = 1
         if "batch" in data:
-            nf = int(data["batch"].max()) + 1
+            nf = int(data["cell"].reshape(-1, 3, 3).shape[0]) if "cell" in data else int(data["batch"].max()) + 1
             out["total_energy"] = torch.zeros(nf, 1, dtype=self.dtype, device=pos.device).index_add_(0, data["batch"], e_atom.unsqueeze(-1))
         else:
             out["total_energy"] = e_atom.sum().reshape(1, 1)
         out["forces"] = forces
-        if "cell" in data and "batch" not in data:
+        if "cell" in data:
             # nequip ForceStressOutput (EXT) conventions: stress = dE/d(strain) / volume, virial = -dE/d(strain)
-            w = self.virial(graph)
-            vol = torch.linalg.det(data["cell"].view(3, 3).to(self.dtype)).abs()
-            out["stress"] = (w / vol).unsqueeze(0)
-            out["virial"] = (-w).unsqueeze(0)
+            cell = data["cell"].to(self.dtype).reshape(-1, 3, 3)
+            if nf == 1:
+                w = self.virial(graph).unsqueeze(0)
+            else:
+                # per-frame strain derivative from the per-edge dE/dr_e and r_e the step left in the workspace
+                d = self.debug_tap("dvec", graph, with_forces=True)[:, :3]
+                v = self.debug_tap("vec", graph, with_forces=True)
+                r = v[:, :3] * v[:, 3:4]
+                frame = data["batch"][graph.center.long()]
+                w = torch.zeros(nf, 3, 3, dtype=self.dtype, device=pos.device).index_add_(
+                    0, frame, d.unsqueeze(2) * r.unsqueeze(1))
+            vol = torch.linalg.det(cell).abs().reshape(-1, 1, 1)
+            out["stress"] = w / vol
+            out["virial"] = -w
         return out
 
     def __del__(self):
         try:
-            if self._plan_handle is not None:
-                self._get_lib().model_plan_destroy(self._plan_handle)
+            self._drop_device_state()
         except Exception:
             pass

@@ -9,8 +9,13 @@ The reference registers its accelerated contraction as a functional library op w
     torch.ops.allegro_amd.tp_backward(gout, x1, x2s, weights, rowptr, eids?, num_atoms, scatter_factor, plan, lib_id)
         -> (gx1 [E,u,d1], gx2 [E,u,d2])
 
-Both are functional (fresh outputs, nothing mutated); all non-tensor arguments are int/float; the backward returns
-`None` for the weights, like the reference's op (`_flashallegro.py:641-666`: input gradients only).  `plan` is the
+    torch.ops.allegro_amd.tp_backward_weights(gout, x1, x2s, weights, rowptr, eids?, num_atoms, plan, lib_id)
+        -> gweights (shape of weights)
+
+All are functional (fresh outputs, nothing mutated); all non-tensor arguments are int/float.  Unlike the reference's
+Triton op, which returns `None` for the weights (`_flashallegro.py:641-666`) and therefore has to fall back to the
+eager contraction in training mode (`:725-755`), the backward here also returns the path-weight gradient whenever the
+weights require grad -- the coverage of the reference's eager / cuEquivariance contracters (`_contract.py:172-177`).  `plan` is the
 `aa_tp_plan*` handle as an integer, `lib_id` selects the loaded library (0 = the gfx950 build; tests register the
 emulation build under another id).  There is no CPU implementation: the ops raise on CPU tensors.
 """
@@ -88,6 +93,28 @@ def _(gout, x1, x2s, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib
     return torch.empty_like(x1), x1.new_empty((x1.shape[0], x1.shape[1], x2s.shape[2]))
 
 
+@torch.library.custom_op("allegro_amd::tp_backward_weights", mutates_args=())
+def tp_backward_weights(gout: torch.Tensor, x1: torch.Tensor, x2s: torch.Tensor, weights: torch.Tensor,
+                        rowptr: torch.Tensor, eids: Optional[torch.Tensor], num_atoms: int, plan: int,
+                        lib_id: int) -> torch.Tensor:
+    lib = _resolve(lib_id)
+    _check_device(lib, x1, "allegro_amd::tp_backward_weights")
+    goutc, x1c, x2sc = gout.contiguous(), x1.contiguous(), x2s.contiguous()
+    E = x1c.shape[0]
+    gw = torch.empty(weights.shape, dtype=x1.dtype, device=x1.device)
+    nbytes = lib.lib.aa_tp_weights_workspace_bytes(plan, num_atoms)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x1.device)
+    lib.tp_backward_weights(plan, E, num_atoms, x1c.data_ptr(), x2sc.data_ptr(), rowptr.data_ptr(),
+                            eids.data_ptr() if eids is not None else None, goutc.data_ptr(), ws.data_ptr(), nbytes,
+                            gw.data_ptr(), _stream_ptr(x1))
+    return gw
+
+
+@tp_backward_weights.register_fake
+def _(gout, x1, x2s, weights, rowptr, eids, num_atoms, plan, lib_id):
+    return x1.new_empty(weights.shape)
+
+
 def _setup_context(ctx, inputs, output):
     x1, _x2, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id, _d2, _dout = inputs
     _out, x2s = output
@@ -99,8 +126,12 @@ def _backward(ctx, gout, _gx2s):
     x1, x2s, weights, rowptr, eids = ctx.saved_tensors
     gx1, gx2 = torch.ops.allegro_amd.tp_backward(gout, x1, x2s, weights.detach(), rowptr, eids, ctx.num_atoms,
                                                  ctx.scatter_factor, ctx.plan, ctx.lib_id)
-    # no weight gradient: inference/force path only (allegro/nn/_strided/_flashallegro.py:660)
-    return gx1, gx2, None, None, None, None, None, None, None, None, None
+    gw = None
+    if ctx.needs_input_grad[2]:  # training: path-weight gradient (first order; the x1/x2 gradients above are what
+        # forces need, and a force-matching loss differentiates THEM again -- not supported through this op)
+        gw = torch.ops.allegro_amd.tp_backward_weights(gout, x1, x2s, weights.detach(), rowptr, eids, ctx.num_atoms,
+                                                       ctx.plan, ctx.lib_id)
+    return gx1, gx2, gw, None, None, None, None, None, None, None, None
 
 
 tp_forward.register_autograd(_backward, setup_context=_setup_context)

@@ -70,11 +70,20 @@ int aa_tp_forward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, 
                   const void* weights, const int32_t* rowptr, const int32_t* eids,
                   double scatter_factor, void* x2s, void* out, aa_stream stream);
 
-/* input gradients of the above (the reference's accelerated path also returns no weight grad,
- * _flashallegro.py:660): gx1:[E,u,d1], gx2:[E,u,d2]. */
+/* input gradients of the above: gx1:[E,u,d1], gx2:[E,u,d2]. */
 int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,
                    const void* weights, const int32_t* rowptr, const int32_t* eids,
                    double scatter_factor, const void* gout, void* gx1, void* gx2, aa_stream stream);
+
+/* path-weight gradient of the above (training): gweights has the shape of `weights` ([u,p] or [p]).  The
+ * reference's eager Contracter and its cuEquivariance variant get it from autograd through the `weights`
+ * Parameter (_contract.py:172-177,219; docs/guide/accelerations.rst:15-17); its Triton path omits it
+ * (_flashallegro.py:660).  Deterministic (fixed summation order, no atomics).  `workspace`: caller scratch of
+ * aa_tp_weights_workspace_bytes(plan, N) bytes. */
+size_t aa_tp_weights_workspace_bytes(const aa_tp_plan* plan, int64_t N);
+int aa_tp_backward_weights(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,
+                           const int32_t* rowptr, const int32_t* eids, const void* gout, void* workspace,
+                           size_t workspace_bytes, void* gweights, aa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Whole hot path: forward + forces  (seam B3 + ForceStressOutput)
@@ -189,7 +198,8 @@ int aa_model_virial(const aa_model_plan* plan, const aa_graph* graph, void* work
                     void* virial9, aa_stream stream);
 
 /* debug/parity taps: copy an intermediate of the LAST call out of the workspace layout.
- * name in {"edge_attrs","edge_embedding","edge_features"}; returns elements per edge or <0 */
+ * name in {"edge_attrs","edge_embedding","edge_features","emb0","vec"}; a "+f" suffix selects the workspace layout of
+ * a step that computed forces (required for "dvec": dE/dr_e [E,4]); returns elements per edge or <0 */
 int aa_model_debug_tap(const aa_model_plan* plan, const char* name, int64_t num_atoms, int64_t num_edges,
                        const void* workspace, const void** ptr, int64_t* ld);
 

@@ -9,7 +9,7 @@ state_dict (fp64, "func." prefix stripped), and reference outputs in fp64 and fp
 (atomic_energy, total_energy, forces).
 Op fixtures (`contract_cases.npz`): the shapes of the reference's own kernel test
 (tests/nn/test_contract_kernels.py:37-40,93-97): 17 edges, 5 atoms, random scatter idxs, mul 3/8,
-both weight modes; forward and both input gradients from the reference's eager `Contracter`.
+both weight modes; forward, both input gradients and the path-weight gradient from the reference's eager `Contracter`.
 """
 import json
 import os
@@ -134,7 +134,9 @@ def dump_contract_cases():
                     idxs = torch.randint(0, N, (E,), generator=gen)
                     y = c(x1, x2, idxs, N)
                     gy = torch.randn(y.shape, generator=gen)
-                    g1, g2 = torch.autograd.grad(y, [x1, x2], gy)
+                    # input gradients and the path-weight gradient of the reference's eager Contracter (autograd through
+                    # its `weights` Parameter, _contract.py:172-177,219)
+                    g1, g2, gw = torch.autograd.grad(y, [x1, x2, c.weights], gy)
                     tag = f"case{idx}"
                     names.append(tag)
                     meta = dict(irreps_in1=in1, irreps_in2="0e + 0o + 1e + 1o", irreps_out=out, mul=mul,
@@ -142,7 +144,7 @@ def dump_contract_cases():
                                 ij_diagonal=bool(c.w3j_is_ij_diagonal), num_paths=c.num_paths)
                     arrays[f"{tag}/meta"] = np.array(json.dumps(meta))
                     for k, v in dict(x1=x1, x2=x2, idxs=idxs, weights=c.weights, w3j=c.w3j, out=y, gout=gy, gx1=g1,
-                                     gx2=g2).items():
+                                     gx2=g2, gw=gw).items():
                         arrays[f"{tag}/{k}"] = v.detach().numpy()
                     idx += 1
     arrays["names"] = np.array(names)

@@ -125,9 +125,11 @@ def contracter_forward(x1, x2, idxs, num_atoms, weights, w3j, coupling, scatter_
 
 # ----------------------------------------------------------------------------- full path
 def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom_types, shift_vec=None,
-                   return_intermediates: bool = False):
+                   return_intermediates: bool = False, contracters=None):
     """Forward of AllegroEnergyModel (module order: allegro/model/allegro_models.py:222-228,262-268,297).
-    `sd` keys are the reference state_dict keys with the leading "func." stripped."""
+    `sd` keys are the reference state_dict keys with the leading "func." stripped.
+    `contracters` (tests of the operator seam): one callable per layer with the signature of
+    `Contracter.forward(x1, x2, idxs, scatter_dim_size)` (_contract.py:185) used instead of `contracter_forward`."""
     S, u, L, l_max = cfg["num_scalar_features"], cfg["num_tensor_features"], cfg["num_layers"], cfg["l_max"]
     coupling = cfg.get("tp_path_channel_coupling", True)
     fwi = cfg.get("forward_normalize", True)
@@ -185,8 +187,11 @@ def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom
         w3j = sd[f"allegro.tps.{layer}.w3j"]
         d1 = tf.shape[-1]
         # later layers use only the irreps that survived pruning; with parity=True, L<=2 they equal SH irreps
-        tf = contracter_forward(tf.reshape(-1, u, d1), env, center, N, sd[f"allegro.tps.{layer}.weights"], w3j,
-                                coupling, 1.0 / math.sqrt(avg_nn))  # :268, _contract.py:185-211
+        if contracters is not None:
+            tf = contracters[layer](tf.reshape(-1, u, d1), env, center, N)  # :268
+        else:
+            tf = contracter_forward(tf.reshape(-1, u, d1), env, center, N, sd[f"allegro.tps.{layer}.weights"], w3j,
+                                    coupling, 1.0 / math.sqrt(avg_nn))  # :268, _contract.py:185-211
         inter[f"tf{layer + 1}"] = tf
         scalars = tf[:, :, :1].reshape(tf.shape[0], u)  # :272-275
         lat = scalar_mlp(torch.cat(acc + [scalars], dim=-1), _mlp_weights(sd, f"allegro.latents.{layer}.mlp"), fwi, act_c)

@@ -56,9 +56,14 @@ def test_contracter_matches_reference_cases(dtype, tol):
             x1 = torch.tensor(c["x1"]).to(dtype).requires_grad_(True)
             x2 = torch.tensor(c["x2"]).to(dtype).requires_grad_(True)
             y = mod(x1, x2, torch.tensor(c["idxs"]), torch.tensor([m["num_atoms"]]))
-            g1, g2 = torch.autograd.grad(y, [x1, x2], torch.tensor(c["gout"]).to(dtype))
+            g1, g2, gw = torch.autograd.grad(y, [x1, x2, mod.weights], torch.tensor(c["gout"]).to(dtype))
+            assert gw.shape == mod.weights.shape
             for got, want in ((y, c["out"]), (g1, c["gx1"]), (g2, c["gx2"])):
                 assert (got.double() - torch.tensor(want)).abs().max().item() < tol
+            # path-weight gradient (training; the reference's eager autograd, _contract.py:172-177): a sum over all
+            # edges (and, uncoupled, channels), hence relative to its own scale
+            want = torch.tensor(c["gw"])
+            assert (gw.double() - want).abs().max().item() < tol * max(1.0, float(want.abs().max()))
     finally:
         torch.set_default_dtype(old)
 

@@ -31,7 +31,7 @@ def test_native_op_is_registered_and_exportable():
     outs = [n for n in ep.graph.nodes if n.op == "output"][0].args[0]
     shapes = [tuple(o.meta["val"].shape) for o in outs]
     N = data["pos"].shape[0]
-    assert shapes == [(N, 1), (1, 1), (N, 3)]
+    assert shapes == [(N, 1), (1, 1), (N, 3), (1, 3, 3)]  # LMP_OUTPUTS: per-atom energy, total energy, forces, virial
     # the program round-trips through the serialized form with its constants (config words, weight blob)
     buf = io.BytesIO()
     torch.export.save(ep, buf)
@@ -55,7 +55,14 @@ def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol):
     ref = fx["out"]
     perm = torch.randperm(data["edge_index"].shape[1], generator=torch.Generator().manual_seed(1)).to(dev)
     for ei, s in ((data["edge_index"], sv), (data["edge_index"][:, perm], None if sv is None else sv[perm])):
-        e_atom, e_tot, f = ex(data["pos"], ei, data["atom_types"], s)
+        e_atom, e_tot, f, vir = ex(data["pos"], ei, data["atom_types"], s)
+        # virial = -dE/d(strain), checked against the model's own strain derivative (itself pinned to the oracle's
+        # autograd-through-strain in test_hip_model.py / test_emu_kernels.py)
+        g = m.prepare_graph(ei, data["atom_types"], data["pos"].shape[0], s)
+        m.energy_forces(data["pos"], g)
+        w = m.virial(g)
+        assert vir.shape == (1, 3, 3)
+        assert (vir[0] + w).abs().max().item() <= tol * max(1.0, float(w.abs().max()))
         for got, want in ((e_atom.cpu().reshape(-1), ref["atomic_energy"].reshape(-1)), (f.cpu(), ref["forces"])):
             assert (got - want).abs().max().item() <= tol * max(1.0, float(want.abs().max()))
         assert abs(float(e_tot) - float(ref["atomic_energy"].sum())) <= 10 * tol * max(1.0, abs(float(ref["atomic_energy"].sum())))
@@ -64,5 +71,5 @@ def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol):
     buf = io.BytesIO()
     torch.export.save(ep, buf)
     buf.seek(0)
-    e2, _, f2 = torch.export.load(buf).module()(data["pos"], data["edge_index"], data["atom_types"], sv)
+    e2, _, f2, _v2 = torch.export.load(buf).module()(data["pos"], data["edge_index"], data["atom_types"], sv)
     assert (f2.cpu() - ref["forces"]).abs().max().item() <= tol * max(1.0, float(ref["forces"].abs().max()))

@@ -1,6 +1,6 @@
 """GPU: HipContracter vs the reference's eager Contracter at the shapes and tolerances of the reference's
 own kernel test (tests/nn/test_contract_kernels.py:93-134): 17 edges, 5 atoms, random idxs, mul 3/8,
-both weight modes, fp32 1e-5 / fp64 1e-10, forward and both input gradients."""
+both weight modes, fp32 1e-5 / fp64 1e-10, forward, both input gradients and the path-weight gradient."""
 import pytest
 import torch
 
@@ -25,9 +25,12 @@ def test_contracter_forward_and_input_grads(dtype, tol):
             x1 = torch.tensor(c["x1"]).to(dtype).to(dev).requires_grad_(True)
             x2 = torch.tensor(c["x2"]).to(dtype).to(dev).requires_grad_(True)
             y = mod(x1, x2, torch.tensor(c["idxs"]).to(dev), torch.tensor([m["num_atoms"]]))
-            g1, g2 = torch.autograd.grad(y, [x1, x2], torch.tensor(c["gout"]).to(dtype).to(dev))
+            g1, g2, gw = torch.autograd.grad(y, [x1, x2, mod.weights], torch.tensor(c["gout"]).to(dtype).to(dev))
             for got, want in ((y, c["out"]), (g1, c["gx1"]), (g2, c["gx2"])):
                 assert (got.double().cpu() - torch.tensor(want)).abs().max().item() < tol
+            want = torch.tensor(c["gw"])  # path-weight gradient vs the reference's eager autograd
+            assert gw.shape == mod.weights.shape
+            assert (gw.double().cpu() - want).abs().max().item() < tol * max(1.0, float(want.abs().max()))
     finally:
         torch.set_default_dtype(old)
 

@@ -88,6 +88,103 @@ def test_modifier_on_reference_model_matches_unmodified_reference():
         assert (got[k] - want[k]).abs().max().item() <= 1e-9 * max(1.0, float(want[k].abs().max())), k
 
 
+def _check_modifier_on_module_model(dtype, tol, dev, lib):
+    """`enable_HipContracter` on a module-structured model built from the t_coupled fixture's reference state_dict:
+    every Contracter swapped, state_dict keys unchanged (_contract.py:277), energies / autograd forces equal to the
+    reference's golden vectors at the reference's model tolerances (tests/model/test_allegro.py:72-74); in training
+    mode the swapped model yields the path-weight gradients of the eager one."""
+    from tests.golden_utils import load_model_fixture
+    from tests.module_model import EagerContracter, ModuleAllegro
+    from allegro_amd.nn import HipContracter
+
+    fx = load_model_fixture("t_coupled", dtype)
+    model = ModuleAllegro(fx["cfg"], fx["sd"], dtype).to(dev).eval()
+    data = {"pos": fx["pos"].to(dev), "edge_index": fx["edge_index"].to(dev), "atom_types": fx["types"].to(dev)}
+    sv = fx["shift_vec"].to(dev)
+    ref = fx["out"]
+
+    def check(out):
+        for k in ("atomic_energy", "forces"):
+            want = ref[k]
+            assert (out[k].detach().cpu() - want).abs().max().item() <= tol * max(1.0, float(want.abs().max())), k
+
+    check(model(data, sv))  # the stand-in itself reproduces the reference
+    keys = list(model.state_dict().keys())
+    n_before = sum(isinstance(mm, EagerContracter) for mm in model.modules())
+    # energy-only training signal of the eager model (what the swapped one must reproduce)
+    model.train()
+    e = model(data, sv)["atomic_energy"]
+    want_gw = torch.autograd.grad((e * e).sum(), [c.weights for c in model.func.allegro.tps])
+    model.eval()
+    model = enable_HipContracter(model)
+    swapped = [mm for mm in model.modules() if isinstance(mm, HipContracter)]
+    assert len(swapped) == n_before == fx["cfg"]["num_layers"]
+    assert not any(isinstance(mm, EagerContracter) for mm in model.modules())
+    assert list(model.state_dict().keys()) == keys
+    if lib is not None:
+        for mm in swapped:
+            mm._bind_library(lib)
+    check(model(data, sv))
+    model.train()  # training mode: same kernels, plus the path-weight gradient
+    e = model(data, sv)["atomic_energy"]
+    got_gw = torch.autograd.grad((e * e).sum(), [c.weights for c in model.func.allegro.tps])
+    for a, b in zip(got_gw, want_gw):
+        assert (a - b).abs().max().item() <= 20 * tol * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 5e-5)])
+def test_modifier_on_module_model_matches_golden_emulated(dtype, tol):
+    _check_modifier_on_module_model(dtype, tol, torch.device("cpu"), emu_lib())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 5e-5)])
+def test_modifier_on_module_model_matches_golden_on_gpu(dtype, tol):
+    _check_modifier_on_module_model(dtype, tol, torch.device("cuda:0"), None)
+
+
+def test_nequip_extension_registers_the_modifier_on_the_reference_contracter():
+    """With nequip + allegro importable (here: the reference's files behind the leaf shim) the entry-point hook
+    attaches `enable_HipContracter` to the reference's Contracter as a model modifier (_contract.py:253-255)."""
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference sources are only mounted in the build container")
+    ref_loader.import_reference()
+    import allegro_amd._nequip_ext as ext
+    from allegro.nn._strided import Contracter
+    from allegro_amd.nn import HipContracter
+
+    ext._STATUS = None
+    status = ext.register()
+    assert "Contracter.enable_HipContracter" in status, status
+    torch.manual_seed(0)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        from e3nn import o3 as e3o3  # (the leaf shim)
+
+        ir = e3o3.Irreps("0e + 1o")
+        net = torch.nn.Sequential(Contracter(irreps_in1=ir, irreps_in2=ir, irreps_out=ir, mul=2))
+    finally:
+        torch.set_default_dtype(old)
+    net = Contracter.enable_HipContracter(net)
+    assert isinstance(net[0], HipContracter)
+
+
+def test_double_backward_through_the_op_fails_loudly():
+    """Force-matching training differentiates the x1/x2 gradients again; the op registers no second-order formula and
+    must say so instead of returning silently wrong (zero) gradients."""
+    c = _contracter()
+    g = torch.Generator().manual_seed(4)
+    x1 = torch.randn(5, 4, 9, dtype=torch.float64, generator=g, requires_grad=True)
+    x2 = torch.randn(5, 4, 9, dtype=torch.float64, generator=g, requires_grad=True)
+    y = c(x1, x2, torch.tensor([0, 0, 1, 1, 1]), 2)
+    (g1,) = torch.autograd.grad(y.sum(), x1, create_graph=True)
+    with pytest.raises(RuntimeError):
+        g1.square().sum().backward()
+
+
 def test_op_traces_under_torch_compile_fullgraph():
     """The op is traceable (fake kernel + functional schema + registered autograd): dynamo/AOTAutograd capture the
     forward and the backward in one graph with no graph break -- what `nequip-compile` needs of an accelerated
