@@ -86,6 +86,8 @@ class AllegroLib:
         L.aa_tp_weights_workspace_bytes.restype = C.c_size_t
         L.aa_tp_backward_weights.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.aa_debug_gemm_f32.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_debug_gemm_f32.restype = C.c_int
         L.aa_model_plan_create.argtypes = [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]
         L.aa_model_plan_destroy.argtypes = [C.c_void_p]
         L.aa_model_plan_destroy.restype = None

@@ -139,6 +139,7 @@ struct GemmArgs {
   int act_a;       // apply silu to A on load
   int has_add;     // result += add (before the dsilu(z) factor); split like c
   SegList add;
+  int force_kernel;  // 0: automatic; 1: native fp32-input MFMA kernel; 3: VALU kernel (aa_debug_gemm_f32 / A-B tests)
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);

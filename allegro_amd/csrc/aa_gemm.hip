@@ -1533,7 +1533,7 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     const char* e = getenv("AA_GEMM_V1");
     v1_only = (e && e[0] == '1') ? 1 : 0;
   }
-  if (force_valu()) {
+  if (force_valu() || g.force_kernel == 3) {
     dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
     size_t smem = sizeof(float) * (GV_BK * GV_LDA + GV_BK * GV_BN);
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
@@ -1559,7 +1559,7 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     }
     bool seg32 = true;
     for (int q = 0; q < g.a.count; ++q) seg32 = seg32 && (g.a.s[q].n % 32 == 0);
-    if (g.Bq && !no_split && seg32) {
+    if (g.Bq && !no_split && g.force_kernel != 1 && seg32) {
       const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
       const bool lds = vec_ok && !direct_epi;
       const size_t smem = lds ? sizeof(float) * 4 * 32 * EP_LD : 0;
@@ -1620,3 +1620,66 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
 }
 
 }  // namespace aa
+
+// ---------------------------------------------------------------------------------------------
+// test hook (include/allegro_amd.h, "debug entry points"): one plain linear layer C = A @ W through a chosen fp32
+// GEMM kernel, so that the split-precision arithmetic can be bounded directly against an fp64 product
+// ---------------------------------------------------------------------------------------------
+extern "C" int aa_debug_gemm_f32(int kernel, int64_t M, int K, int N, const float* A_dev, const float* W_host,
+                                 float* C_dev, aa_stream stream) {
+  using namespace aa;
+  AA_REQUIRE(A_dev && W_host && C_dev && M >= 0 && K > 0 && N > 0, "aa_debug_gemm_f32: bad argument");
+  AA_REQUIRE(kernel >= 0 && kernel <= 3, "aa_debug_gemm_f32: kernel must be 0 (bf16x3), 1 (fp32 MFMA), 2 (fused chain), 3 (VALU)");
+  AA_REQUIRE((K % 32) == 0 && (N % 32) == 0, "aa_debug_gemm_f32: K and N must be multiples of 32");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t nw = size_t(K) * N, np = gemm_packed_elems(K, N), nq = gemm_bf16x3_words(K, N);
+  std::vector<double> wd(W_host, W_host + nw), wpd(np);
+  gemm_pack_b(wd.data(), K, N, wpd.data());
+  std::vector<float> wp(wpd.begin(), wpd.end());
+  std::vector<unsigned> wq(nq);
+  gemm_pack_bf16x3(W_host, K, N, wq.data());
+  void *dW = nullptr, *dWp = nullptr, *dWq = nullptr;
+  AA_CHECK_HIP(hipMalloc(&dW, nw * 4));
+  AA_CHECK_HIP(hipMalloc(&dWp, np * 4));
+  AA_CHECK_HIP(hipMalloc(&dWq, nq * 4));
+  auto cleanup = [&]() {
+    (void)hipFree(dW);
+    (void)hipFree(dWp);
+    (void)hipFree(dWq);
+  };
+  int rc = AA_OK;
+  if (hipMemcpy(dW, W_host, nw * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dWp, wp.data(), np * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(dWq, wq.data(), nq * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    cleanup();
+    return fail(AA_ERR_HIP, "aa_debug_gemm_f32: upload failed");
+  }
+  SegList a{1, {Seg{const_cast<float*>(A_dev), K, K}}}, c{1, {Seg{C_dev, N, N}}};
+  if (kernel == 2) {
+    ChainArgs ca{};
+    ca.M = M;
+    ca.nlayers = 1;
+    ca.L[0].g.M = M;
+    ca.L[0].g.K = K;
+    ca.L[0].g.N = N;
+    ca.L[0].g.a = a;
+    ca.L[0].g.Bq = dWq;
+    ca.L[0].g.c = c;
+    ca.L[0].keep_tile = -1;
+    rc = launch_gemm_chain(ca, s);
+  } else {
+    GemmArgs g{};
+    g.M = M;
+    g.K = K;
+    g.N = N;
+    g.a = a;
+    g.B = dW;
+    g.Bp = dWp;
+    g.Bq = dWq;
+    g.c = c;
+    g.force_kernel = kernel;
+    rc = launch_gemm<float>(g, s);
+  }
+  if (rc == AA_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(AA_ERR_HIP, "aa_debug_gemm_f32: kernel failed");
+  cleanup();
+  return rc;
+}

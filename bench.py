@@ -56,8 +56,10 @@ WORKLOADS = {
     "c2": dict(kind="si", cells=2, dtype="float32", desc="Si 2^3 cells (64 atoms), l_max=2, L=2, u=64"),
     "c3": dict(kind="si", cells=11, dtype="float32", desc="bulk Si 11^3 cells (10 648 atoms), r_cut 5 A, l_max=2, L=2, u=64"),
     "c4": dict(kind="si", cells=23, dtype="float32", desc="bulk Si 23^3 cells (97 336 atoms), r_cut 5 A, l_max=2, L=2, u=64"),
+    # 22^3 molecules at the density of BASELINE's "3x10^4-atom" box: 31 944 atoms, ~1.72e6 edges (the exact counts
+    # of the generated graph are in config.atoms / config.edges of the line)
     "c5": dict(kind="water", side=22, box=66.9 * 22 / 21.544, dtype="float64",
-               desc="water box (~3x10^4 atoms, 2 species), r_cut 5 A, l_max=3, L=3, u=128, fp64"),
+               desc="water box 22^3 molecules (31 944 atoms, ~1.72e6 edges, 2 species), r_cut 5 A, l_max=3, L=3, u=128, fp64"),
 }
 
 
@@ -137,6 +139,7 @@ def profile_stages(model, pos, graph):
 
 # kernel symbol behind each stage-name prefix
 _SYMBOLS = (("gc_", "gemm_chain_bf16x3_kernel"), ("gemm_", "gemm_bf16x3_kernel"))
+_SYMBOLS_F64 = (("gemm_", "gemm_mfma_f64_pipe_kernel"),)
 
 
 def roofline_from_stages(stages, dtype, workload="c4"):
@@ -148,7 +151,7 @@ def roofline_from_stages(stages, dtype, workload="c4"):
     report their fp32-equivalent TFLOP/s."""
     by_sym = {}
     for name, ms, nbytes, flops in stages:
-        sym = next((s for pre, s in _SYMBOLS if name.startswith(pre)), name)
+        sym = next((s for pre, s in (_SYMBOLS if dtype == "float32" else _SYMBOLS_F64) if name.startswith(pre)), name)
         d = by_sym.setdefault(sym, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
         d["ms"] += ms
         d["launches"] += 1
@@ -161,18 +164,33 @@ def roofline_from_stages(stages, dtype, workload="c4"):
     roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
                 kernel=sym, avg_launch_ms=d["ms"] / n, launches_per_step=d["launches"],
                 algorithmic_bytes_per_launch=d["bytes"] / n)
+    if dtype == "float64" and sym.startswith("gemm_") and d["flops"] > 0:
+        # the fp64 linear layers (K, N >= 128) run at >= 64 flop/B: bound by the fp64 matrix pipe, not by HBM
+        tf = d["flops"] / n / t / 1e12
+        roof.update(bound="mfma", achieved=tf, peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F64_TFLOPS,
+                    algorithmic_flops_per_launch=d["flops"] / n, hbm_GBps=ach)
     # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (tools/profile_gpu.sh ->
     # tools/pmc_to_json.py, committed under profiles/): rocprofv3 cannot wrap the process from inside, so the last
     # committed measurement of this workload is attached with its provenance
+    # (attached only when the measurement was taken on THESE kernel sources: the JSON carries allegro_amd.build.source_hash())
     try:
+        from allegro_amd.build import source_hash
+
         pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{workload}.json")))
         key = next((k for k in pj["per_launch"] if k in sym or sym.startswith(k)), None)
-        if key is not None:
+        have, want = pj.get("source_hash"), source_hash()
+        if key is None:
+            roof["traffic_source"] = f"traffic: null -- {pj['source']} has no entry for {sym}"
+        elif have != want:
+            roof["traffic_source"] = (f"traffic: null -- committed PMC measurement {pj['source']} was taken on kernel sources "
+                                      f"{have}, this build is {want}")
+        else:
             e = pj["per_launch"][key]
             roof["traffic"] = e.get("fetch_bytes", 0.0) + e.get("write_bytes", 0.0)
-            roof["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, mean per launch, {pj['source']}"
-    except (OSError, ValueError, KeyError):
-        pass
+            roof["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, mean per launch, {pj['source']} "
+                                      f"(kernel sources {want})")
+    except (OSError, ValueError, KeyError) as ex:
+        roof["traffic_source"] = f"traffic: null -- no committed PMC measurement for this workload ({type(ex).__name__})"
     if d["flops"] > 0:
         roof["fp32_equiv_TFLOPs"] = d["flops"] / n / t / 1e12
         roof["mfma_bf16_TFLOPs"] = (6.0 if dtype == "float32" else 1.0) * d["flops"] / n / t / 1e12
@@ -204,16 +222,31 @@ def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3):
     ocfg = dict(cfg)
     R.allegro_energy_forces_chunked(ocfg, sd, pos, ei[:, :min(e1, 12000)], types, None if sv is None else sv[:min(e1, 12000)], 12000)
     ts = []
+    out = None
     for _ in range(reps):
         t0 = time.perf_counter()
-        R.allegro_energy_forces_chunked(ocfg, sd, pos, ei, types, sv, 12000)
+        out = R.allegro_energy_forces_chunked(ocfg, sd, pos, ei, types, sv, 12000)
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
     L = cfg["num_layers"]
-    return dict(value=e1 * L / t, unit="edge-TP/s", cores=threads, kind="port",
+    base = dict(value=e1 * L / t, unit="edge-TP/s", cores=threads, kind="port",
                 sample=f"first {a1} center atoms / {e1} edges of the same box in chunks of <=12k edges, "
                        f"oracle/restatement.py eager PyTorch CPU {cfg['model_dtype']}, {threads} threads of {cores} cores, "
                        f"median of {reps}, {t:.2f} s per pass")
+    # parity of the timed HIP path against this oracle pass (same edge subset: the first a1 center atoms' edges)
+    dev = next(model.parameters()).device
+    gsub = PreparedGraph(ei.to(dev), types.to(dev), g.num_atoms, None if sv is None else sv.to(dev))
+    e_h, f_h = model.energy_forces(pos.to(dev), gsub)
+    e_o, f_o = out["atomic_energy"].reshape(-1)[:a1], out["forces"]
+    d_e = float((e_h[:a1].cpu() - e_o).abs().max())
+    d_f = float((f_h.cpu() - f_o).abs().max())
+    tol_f = 1e-4 if dtype == torch.float32 else 1e-9 * max(1.0, float(f_o.abs().max()))
+    tol_e = (5e-5 if dtype == torch.float32 else 1e-9) * max(1.0, float(e_o.abs().max()))
+    parity = dict(atoms=a1, edges=e1, max_dE=d_e, max_dF=d_f, tol_dE=tol_e, tol_dF=tol_f, ok=bool(d_e <= tol_e and d_f <= tol_f),
+                  against="oracle/restatement.py (CPU, same dtype) on the same edge subset; tolerances: forces 1e-4 eV/A "
+                          "(north star) in fp32, 1e-9 x scale in fp64; energies 5e-5 / 1e-9 x scale "
+                          "(tests/model/test_allegro.py:72-74 of the reference)")
+    return base, parity
 
 
 def gpu_reference_baseline(g: G.Graph, cfg, model, dev, target_edges=60000, reps=3):
@@ -250,8 +283,11 @@ def gpu_reference_baseline(g: G.Graph, cfg, model, dev, target_edges=60000, reps
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
-    return dict(value=e1 * cfg["num_layers"] / t, unit="edge-TP/s", kind="port on PyTorch-ROCm eager (GPU)",
-                sample=f"{e1} edges in chunks of <=20k, median of {reps}, {t * 1e3:.1f} ms per pass")
+    return dict(value=e1 * cfg["num_layers"] / t, unit="edge-TP/s", kind="port",
+                what="oracle/restatement.py (a port that already avoids the reference's [E,u,9,9,9] intermediate) as eager "
+                     "PyTorch-ROCm on this GPU -- the denominator of north_star's '>= 5x the reference PyTorch-ROCm forward'",
+                sample=f"first {a1} center atoms / {e1} edges of the same box in chunks of <=20k edges, median of {reps}, "
+                       f"{t * 1e3:.1f} ms per pass")
 
 
 def main():
@@ -262,7 +298,11 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--gpu-reference", action="store_true", help="also time the eager PyTorch-ROCm oracle path on the GPU")
+    ap.add_argument("--no-gpu-reference", action="store_true", help="skip the eager PyTorch-ROCm oracle path on the GPU")
+    ap.add_argument("--gpu-reference", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--sustain", type=float, default=8.0,
+                    help="seconds of additional back-to-back steps AFTER the timed region (reported as config.sustained): "
+                         "long enough for an external sampler (rocm-smi every few seconds) to witness the GPU busy; 0 = off")
     ap.add_argument("--stages", action="store_true", help="also print every launch of one step with its HIP-event time")
     ap.add_argument("--emulate-shard", default=None, metavar="R/W",
                     help="analysis only: run rank R's atom block of a W-way partition on this one GPU (no collective)")
@@ -325,6 +365,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    # sustained run (outside the timed region, same step): the K-step region of the contract is ~0.2 s at C4, too short
+    # for an independent utilisation sampler; all ranks take part so the collective pattern is the same
+    sustained = None
+    if args.sustain > 0 and not args.emulate_shard:
+        n_sus = max(args.steps, int(args.sustain / max(dt / args.steps, 1e-6)))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        ds = time.perf_counter() - t1
+        sustained = {"steps": n_sus, "seconds": ds, "ms_per_step": ds / n_sus * 1e3}
 
     if rank == 0:
         t_step = ms_per_step * 1e-3
@@ -346,6 +398,8 @@ def main():
                        "parallelism": f"atom-block x{world}" if world > 1 else "single GPU",
                        "weights": "random init (reference initialisers), seed 456"},
         }
+        if sustained is not None:
+            line["config"]["sustained"] = sustained
         if not args.no_profile:
             stages = profile_stages(model, pos, graph)
             roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload)
@@ -379,13 +433,21 @@ def main():
             torch.cuda.synchronize()
             line["config"]["neighbor_list_device_ms"]["list"] = (time.perf_counter() - t1) * 1e3
             del nl_graph
+        parity_failed = False
         if world == 1 and not args.no_cpu_baseline:
             # ~20 s of CPU work for the headline model; the l_max=3 fp64 stack is ~10x heavier per edge
-            line["cpu_baseline"] = cpu_baseline(g, cfg, model, target_edges=180000 if cfg["l_max"] <= 2 else 24000)
-        if world == 1 and args.gpu_reference:
-            line["gpu_reference_baseline"] = gpu_reference_baseline(g, cfg, model, dev)
+            line["cpu_baseline"], line["parity_sample"] = cpu_baseline(g, cfg, model,
+                                                                       target_edges=180000 if cfg["l_max"] <= 2 else 24000)
+            parity_failed = not line["parity_sample"]["ok"]
+        if world == 1 and not args.no_gpu_reference and not args.emulate_shard:
+            line["gpu_reference_baseline"] = gpu_reference_baseline(g, cfg, model, dev,
+                                                                    target_edges=60000 if cfg["l_max"] <= 2 else 12000)
             line["speedup_vs_gpu_reference"] = line["value"] / line["gpu_reference_baseline"]["value"]
         print(json.dumps(line), flush=True)
+        if parity_failed:
+            print("bench.py: parity_sample outside the north-star tolerance -- the measured number is INVALID", file=sys.stderr)
+            if dist is None:
+                sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -229,6 +229,16 @@ int aa_nl_count(const aa_nl_input* in, void* workspace, size_t workspace_bytes, 
 int aa_nl_fill(const aa_nl_input* in, void* workspace, size_t workspace_bytes, const int32_t* rowptr, int32_t* center,
                int32_t* nbr, int32_t* cell_shift, void* shift_vec, aa_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 4. Debug entry points (parity tests; not part of the drop-in surface).
+ *    aa_debug_gemm_f32: C[M,N] = A[M,K] @ W[K,N] (A, C device fp32 row-major; W HOST fp32 row-major) through one of
+ *    the fp32 linear-layer kernels of the scalar MLPs: 0 = bf16x3 split-precision MFMA, 1 = native fp32-input MFMA,
+ *    2 = the fused-chain kernel (one layer), 3 = VALU.  K and N multiples of 32.  Allocates temporaries and
+ *    synchronises the stream: test use only.
+ * ------------------------------------------------------------------------------------------ */
+int aa_debug_gemm_f32(int kernel, int64_t M, int K, int N, const float* A_dev, const float* W_host, float* C_dev,
+                      aa_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

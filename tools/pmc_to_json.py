@@ -28,4 +28,12 @@ for line in open(path):
             k = out.setdefault(m.group(1).strip(), {})
             k["launches"] = int(m.group(2))
             k["fetch_bytes" if sec == "FETCH_SIZE" else "write_bytes"] = float(m.group(3)) * 1e3 * (2.0 if sec == "FETCH_SIZE" else 1.0)
-print(json.dumps({"workload": workload, "source": path, "per_launch": out}, indent=1))
+import os  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from allegro_amd.build import source_hash  # noqa: E402
+
+# source_hash: the kernel sources the measurement was taken on (run this right after profiling, before editing csrc/);
+# bench.py attaches `traffic` only when it matches the sources it runs
+print(json.dumps({"workload": workload, "source": path, "source_hash": sys.argv[3] if len(sys.argv) > 3 else source_hash(),
+                  "per_launch": out}, indent=1))
