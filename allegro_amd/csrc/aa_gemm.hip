@@ -10,10 +10,10 @@
 // f32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF peak) -- the only place MFMA is used,
 // because only the scalar MLPs are true GEMMs.  f64 (and the A/B check path): LDS-tiled VALU kernel.
 #include "aa_common.h"
+#include "aa_mfma.h"
 
 namespace aa {
 
-typedef float v16f __attribute__((ext_vector_type(16)));
 
 template <typename T>
 __device__ __forceinline__ T seg_load(const SegList& sl, int64_t row, int col) {
@@ -384,7 +384,6 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) 
   }  // column tiles
 }
 
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 // destination of one output column, resolved once per 32-column tile (not per element)
 struct ColDst {
@@ -755,43 +754,6 @@ __device__ __forceinline__ void load_a_frag_acc(const GemmArgs& g, int64_t gm, i
 // Same data flow as v3: activation fragments straight from global (64 contiguous bytes per lane and
 // chunk), weights pre-split and pre-permuted on the host, swapped operands, 16-B epilogue accesses.
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
-__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
-
-// 16 floats -> three levels of 8 packed bf16 pairs (element 2q in the low half, 2q+1 in the high half)
-__device__ __forceinline__ void split3_pack(const v4f* a, u32x4* lv1, u32x4* lv2, u32x4* lv3) {
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    u32x4 o1, o2, o3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned h1[2], h2[2], h3[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int idx = half * 8 + q * 2 + e;
-        const float x = a[idx >> 2][idx & 3];
-        h1[e] = f2u(x) & 0xFFFF0000u;
-        const float r = x - u2f(h1[e]);
-        h2[e] = f2u(r) & 0xFFFF0000u;
-        const float r2 = r - u2f(h2[e]);
-        h3[e] = f2u(r2) & 0xFFFF0000u;
-      }
-      o1[q] = (h1[0] >> 16) | h1[1];
-      o2[q] = (h2[0] >> 16) | h2[1];
-      o3[q] = (h3[0] >> 16) | h3[1];
-    }
-    lv1[half] = o1;
-    lv2[half] = o2;
-    lv3[half] = o3;
-  }
-}
-
-__device__ __forceinline__ v16f mma_bf16(const u32x4& w, const u32x4& x, v16f acc) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-}
 
 // one 32-deep chunk of a tile pair: 2 k-halves x 6 cross products per tile; the two tiles' accumulator
 // chains are interleaved so consecutive MFMAs are independent
@@ -923,15 +885,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
 // two k chunks of the next layer -- the hidden activations of the reference's ScalarMLPFunction chains never
 // travel through HBM except for the one store of the pre-activation that the reverse pass needs.
 // ---------------------------------------------------------------------------------------------
-struct XSplit {
-  u32x4 l1[2], l2[2], l3[2];
-};
-__device__ __forceinline__ void xsplit_from_acc(const v16f& acc, XSplit& x) {
-  v4f a[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) a[q] = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-  split3_pack(a, x.l1, x.l2, x.l3);
-}
 
 // epilogue of one tile in accumulator layout, in place: acc <- (acc + add) * silu'(z), then stored (=|+=) unless
 // the destination segment is a "computed only" (null) segment
@@ -1006,7 +959,6 @@ struct ChainDev {
 // MFMAs issue (double buffer, one barrier per step), and the MFMA operands are read just in time with
 // conflict-free ds_read_b128.  Operand rows are loaded one step ahead, also across tile-pair and layer
 // boundaries; rows beyond M are clamped for loads and masked for stores.
-constexpr int kWStep = 2 * 6 * 64;  // u32x4 per staged step
 constexpr int kEpLd = 36;          // row stride (floats) of the store-transpose patch: 32 + 4 keeps b128 accesses conflict-light
 
 // PRE: layers with at most two k chunks and more than two output tiles (a chained 64-wide operand feeding a wide

@@ -12,7 +12,7 @@
 // it builds the center-sorted CSR view with ATen ops, takes the workspace from the caching allocator and
 // launches on the current stream.  There is no CPU kernel: only a Meta (shape) kernel besides the GPU one.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -129,7 +129,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tenso
                   weights.get_device() == pos.get_device(),
               "allegro_amd::energy_forces: all tensors must live on the same device");
   // plan tables, workspace and launches all belong to the device of `pos`, whatever the caller's current device is
-  const c10::hip::HIPGuard device_guard(pos.device());
+  const c10::DeviceGuard device_guard(pos.device());
   const PlanEntry& pe = plan_for(config, int(pos.get_device()));
   TORCH_CHECK(pos.dim() == 2 && pos.size(1) == 3 && edge_index.dim() == 2 && edge_index.size(0) == 2, "bad shapes");
   const int64_t N = pos.size(0), E = edge_index.size(1);
