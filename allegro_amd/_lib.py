@@ -46,7 +46,8 @@ class RawWeights(C.Structure):
 class Graph(C.Structure):
     _fields_ = [("num_atoms", C.c_int64), ("num_edges", C.c_int64), ("center", C.c_void_p), ("nbr", C.c_void_p),
                 ("rowptr", C.c_void_p), ("types", C.c_void_p), ("shift_vec", C.c_void_p),
-                ("t_rowptr", C.c_void_p), ("t_perm", C.c_void_p), ("atom_begin", C.c_int64), ("atom_end", C.c_int64)]
+                ("t_rowptr", C.c_void_p), ("t_perm", C.c_void_p), ("atom_begin", C.c_int64), ("atom_end", C.c_int64),
+                ("max_degree", C.c_int64)]
 
 
 class AllegroError(RuntimeError):
@@ -93,6 +94,8 @@ class AllegroLib:
         L.aa_model_plan_destroy.restype = None
         L.aa_model_plan_enable_graph.argtypes = [C.c_void_p, C.c_int]
         L.aa_model_plan_enable_graph.restype = C.c_int
+        L.aa_model_plan_enable_taps.argtypes = [C.c_void_p, C.c_int]
+        L.aa_model_plan_enable_taps.restype = C.c_int
         L.aa_model_virial.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.aa_model_virial.restype = C.c_int
         L.aa_nl_workspace_bytes.argtypes = [C.c_int64]

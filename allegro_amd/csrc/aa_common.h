@@ -436,6 +436,47 @@ template <typename T>
 int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------
+// fused per-atom-tile kernels (aa_fused.hip): the whole forward of the standard 2-layer, 64-wide stack in ONE launch
+// ----------------------------------------------------------------------------------------------
+struct FusedLayerDev {
+  const void* Wq;  // bf16x3 fragments of the layer (gemm_pack_bf16x3), first tile of the layer
+  int KC;          // k chunks of the packed matrix (tile stride)
+};
+struct FusedFwdArgs {
+  int64_t N, atom0, atom_end;  // atoms [atom0, atom_end) are evaluated (one wave each); every one has <= 32 edges
+  const int32_t *rowptr, *nbr, *types;
+  const float* pos;
+  const float* shift_vec;  // [E,3] or nullptr
+  int num_types, embed_kind, spline_span;
+  float poly_p;
+  const float *rmax_recip, *bessel_w;
+  const float* emb_tab;    // [T*T][8][64]
+  // linear layers in execution order: embed0, embed1, [two-body | w0], latent0 hidden, latent0 out, w0 (again),
+  // latent1 hidden, latent1 out, readout hidden
+  FusedLayerDev L[9];
+  const float *wk0, *wk1;    // Wenv of layer 0 / 1 as [k][R][64]
+  const float *tpw0, *tpw1;  // path weights
+  int coupling;
+  float sf;                  // 1/sqrt(avg_num_neighbors)
+  const float* ro_w;         // [64] last readout layer
+  float ro_factor;
+  const float *scales, *shifts;
+  // outputs (what the reverse pass reads again)
+  float* vec;      // [E,4]
+  float* sh;       // [E,D] or nullptr
+  float* se_h;     // [E,64] pre-activation of scalar_embed_mlp's hidden layer
+  float* emb;      // [E,64] EDGE_EMBEDDING
+  float* w0;       // [E,R*64] or nullptr (the staged reverse kernels read it; the fused reverse recomputes it)
+  float* lat_h0;   // [E,64]
+  float* lat_h1;   // [E,64]
+  float* ro_h;     // [E,64]
+  float* fcat;     // [E,192] EDGE_FEATURES or nullptr
+  float *x2s0, *x2s1;  // [N][D][64]
+  float* atom_energy;  // [N]
+};
+int launch_fused_fwd(int pair, const FusedFwdArgs& a, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------
 // edge prologue / epilogue / readout reduce
 // ----------------------------------------------------------------------------------------------
 struct EdgeGeomArgs {

@@ -144,6 +144,8 @@ struct aa_model_plan {
   bool env_mom;                      // env weights through per-atom moments: no [E,R*u] env tensors (TpMomArgs / TpOpArgs)
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
+  bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
+  mutable bool taps = false;         // aa_model_plan_enable_taps: staged pipeline so that every tap is materialised
   bool embed_fused;                  // reverse pass: d(two-body embedding) [E,S0] never materialised, the last reverse chain
                                      // contracts it back to the 8 basis functions in its epilogue (embrev_out in aa_common.h)
   size_t o_embtab;                   // [T*T][8][64] type_embed(c | pair) * basis_linear[n][c]
@@ -321,6 +323,12 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_scales = take(T);
   p->o_shifts = take(T);
   p->n_elems = o;
+  {
+    // fused per-atom-tile forward: the standard 2-layer 64-wide fp32 stack with the two-body table in LDS
+    const char* nf = getenv("AA_NOFUSE");
+    p->fused_fwd = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
+                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 && !(nf && nf[0] == '1');
+  }
   *out = p;
   return AA_OK;
 }
@@ -334,6 +342,12 @@ extern "C" int aa_model_plan_enable_graph(aa_model_plan* plan, int on) {
   g.graph = nullptr;
   g.enabled = on != 0;
   if (g.enabled && !g.cap_stream) AA_CHECK_HIP(hipStreamCreateWithFlags(&g.cap_stream, hipStreamNonBlocking));
+  return AA_OK;
+}
+
+extern "C" int aa_model_plan_enable_taps(aa_model_plan* plan, int on) {
+  AA_REQUIRE(plan, "aa_model_plan_enable_taps: null plan");
+  plan->taps = on != 0;
   return AA_OK;
 }
 
@@ -952,9 +966,77 @@ struct Runner {
     return o;
   }
 
+  // the whole forward in one launch (aa_fused.hip): every center atom's edge segment fits one 32-row MFMA tile
+  bool use_fused_fwd(const aa_graph* g) const {
+    return sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= 32;
+  }
+  int forward_fused(const aa_graph* g, const void* pos, void* atom_energy) {
+    const aa_model_config& c = p->cfg;
+    const int S = c.num_scalar, u = c.num_tensor;
+    FusedFwdArgs a{};
+    a.N = N;
+    a.atom0 = atom_begin(g);
+    a.atom_end = atom_end(g);
+    a.rowptr = g->rowptr;
+    a.nbr = g->nbr;
+    a.types = g->types;
+    a.pos = static_cast<const float*>(pos);
+    a.shift_vec = static_cast<const float*>(g->shift_vec);
+    a.num_types = c.num_types;
+    a.embed_kind = c.embed_kind;
+    a.spline_span = c.spline_span;
+    a.poly_p = float(c.poly_p);
+    auto wf = [&](size_t off) { return reinterpret_cast<const float*>(wt(off)); };
+    auto bf = [&](size_t off) { return reinterpret_cast<float*>(buf(off)); };
+    a.rmax_recip = wf(p->o_rmax);
+    a.bessel_w = wf(p->o_bessel);
+    a.emb_tab = wf(p->o_embtab);
+    const size_t tile_words = size_t(2) * 64 * 24;  // one output tile of a K = 64 matrix (2 chunks), 32-bit words
+    a.L[0] = FusedLayerDev{wf(p->embed.wq[0]), 2};
+    a.L[1] = FusedLayerDev{wf(p->embed.wq[1]), 2};
+    a.L[2] = FusedLayerDev{wf(p->o_g0q), 2};
+    a.L[3] = FusedLayerDev{wf(p->latent[0].wq[0]), 4};
+    a.L[4] = FusedLayerDev{wf(p->latent[0].wq[1]), 2};
+    a.L[5] = FusedLayerDev{wf(p->o_g0q) + 2 * tile_words, 2};  // the w0 columns of the same matrix
+    a.L[6] = FusedLayerDev{wf(p->latent[1].wq[0]), 6};
+    a.L[7] = FusedLayerDev{wf(p->latent[1].wq[1]), 2};
+    a.L[8] = FusedLayerDev{wf(p->readout.wq[0]), 6};
+    a.wk0 = wf(p->o_wk[0]);
+    a.wk1 = wf(p->o_wk[1]);
+    a.tpw0 = wf(p->o_tpw[0]);
+    a.tpw1 = wf(p->o_tpw[1]);
+    a.coupling = c.tps[0].coupling;
+    a.sf = float(1.0 / std::sqrt(c.avg_num_neighbors));
+    a.ro_w = wf(p->o_ro_last);
+    a.ro_factor = float(1.0 / std::sqrt(2.0 * c.avg_num_neighbors));
+    a.scales = c.has_scales ? wf(p->o_scales) : nullptr;
+    a.shifts = c.has_shifts ? wf(p->o_shifts) : nullptr;
+    a.vec = bf(w.vec);
+    a.sh = bf(w.sh);
+    a.se_h = bf(w.se_h[0]);
+    a.emb = bf(w.emb);
+    a.w0 = bf(w.w0);
+    a.lat_h0 = bf(w.lat_h[0][0]);
+    a.lat_h1 = bf(w.lat_h[1][0]);
+    a.ro_h = bf(w.ro_h[0]);
+    a.fcat = nullptr;
+    a.x2s0 = bf(w.x2s[0]);
+    a.x2s1 = bf(w.x2s[1]);
+    a.atom_energy = static_cast<float*>(atom_energy);
+    if (int rc = mark("begin")) return rc;
+    if (int rc = launch_fused_fwd(p->chain_pair, a, stream)) return rc;
+    // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;
+    // position, two x2s blocks, energy, row pointer per atom.  Flops: the linear layers of the forward (w0 counted once).
+    const double per_edge = 1 + (g->shift_vec ? 3 : 0) + 3 + 4 + p->D + 5 * 64 + p->W;
+    const double per_atom = 3 + 2.0 * p->D * u + 1 + 1;
+    const double fl = 2.0 * double(E) * (2.0 * 64 * 64 + 64.0 * p->ng0 + double(S + u) * 64 + 64.0 * S + double(2 * S + u) * 64 + 64.0 * S + 3.0 * S * 64);
+    return mark("fused_fwd", per_edge, per_atom, fl);
+  }
+
   int forward(const aa_graph* g, const void* pos, void* atom_energy) {
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
+    if (use_fused_fwd(g)) return forward_fused(g, pos, atom_energy);
     // 1-2: geometry, SH, radial-chemical embedding
     if (int rc = mark("begin")) return rc;
     const double idx2 = 8.0 / sizeof(T);  // center + nbr ids, in elements

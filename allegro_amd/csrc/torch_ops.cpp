@@ -165,6 +165,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tenso
   g.shift_vec = svc.defined() ? svc.data_ptr() : nullptr;
   g.t_rowptr = trow.data_ptr<int32_t>();
   g.t_perm = tperm.data_ptr<int32_t>();
+  // (one more host read next to the sortedness check above: selects the fused per-atom-tile kernels)
+  g.max_degree = E > 0 ? (rowptr.slice(0, 1) - rowptr.slice(0, 0, N)).max().item<int64_t>() : 0;
   const size_t wsb = aa_model_workspace_bytes(pe.plan, N, E, 1);
   at::Tensor ws = at::empty({int64_t(wsb)}, pos.options().dtype(at::kByte));
   at::Tensor e_atom = at::empty({N}, pos.options()), forces = at::empty({N, 3}, pos.options());

@@ -390,9 +390,11 @@ class PreparedGraph:
         self.shift_vec = None if shift_vec is None else shift_vec.contiguous()
         # block of center atoms that have edges (the owned block of an atom-block partition, allegro_amd/dist.py):
         # the per-atom kernels only visit it.  One host read at graph-preparation time, none per step.
-        self.atom_begin = self.atom_end = 0
+        self.atom_begin = self.atom_end = self.max_degree = 0
         if self.num_edges > 0:
             self.atom_begin, self.atom_end = int(self.center[0]), int(self.center[-1]) + 1
+            # largest edge segment: <= 32 selects the fused per-atom-tile kernels (one wave = one atom's MFMA tile)
+            self.max_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max())
         # transposed CSR (edges grouped by neighbor): lets the library gather forces per atom in a fixed order
         # (bit-reproducible); without it neighbor contributions are accumulated with floating-point atomics
         self.t_perm = self.t_rowptr = None
@@ -407,7 +409,7 @@ class PreparedGraph:
                           self.shift_vec.data_ptr() if self.shift_vec is not None else None,
                           self.t_rowptr.data_ptr() if self.t_rowptr is not None else None,
                           self.t_perm.data_ptr() if self.t_perm is not None else None,
-                          self.atom_begin, self.atom_end)
+                          self.atom_begin, self.atom_end, self.max_degree)
 
 
 class DeviceNeighborList:
@@ -802,6 +804,13 @@ class HipAllegroModel(torch.nn.Module):
         lib.check(lib.lib.aa_model_plan_enable_graph(self._plan_handle, int(on)), "aa_model_plan_enable_graph")
         self._hip_graph = bool(on)
         self._out = None
+
+    def enable_debug_taps(self, on: bool = True) -> None:
+        """Make the following steps materialise the per-edge intermediates `debug_tap` reads (staged pipeline instead
+        of the fused kernels, which keep them on chip).  Parity tests only."""
+        lib = self._get_lib()
+        self._ensure_plan()
+        lib.check(lib.lib.aa_model_plan_enable_taps(self._plan_handle, int(on)), "aa_model_plan_enable_taps")
 
     def debug_tap(self, name: str, graph: PreparedGraph, with_forces: bool = False) -> torch.Tensor:
         """Copy of a per-edge intermediate of the LAST step out of the workspace ("dvec" / "vec" need the layout of a

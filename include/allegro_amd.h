@@ -153,6 +153,10 @@ typedef struct {
    * atom-block partition.  Per-atom kernels are then launched over that range only.  0,0 = all atoms.
    * The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
   int64_t atom_begin, atom_end;
+  /* optional hint: no center atom has more than max_degree edges (0 = unknown).  With max_degree <= 32 the standard
+   * 2-layer 64-wide fp32 stack runs the fused per-atom-tile forward (one wave = one atom's edge tile);
+   * otherwise the staged pipeline.  The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
+  int64_t max_degree;
 } aa_graph;
 
 typedef struct aa_model_plan aa_model_plan;
@@ -163,6 +167,9 @@ void aa_model_plan_destroy(aa_model_plan* plan);
  * arguments (all pointers and sizes) and replays it with one hipGraphLaunch afterwards -- for launch-bound (small)
  * systems in MD loops whose buffers stay put.  The plan then carries mutable state: one caller thread per plan. */
 int aa_model_plan_enable_graph(aa_model_plan* plan, int on);
+/* on != 0: every step materialises the per-edge intermediates that aa_model_debug_tap exposes (the staged pipeline is
+ * used; the fused kernels keep them on chip).  Parity tests only. */
+int aa_model_plan_enable_taps(aa_model_plan* plan, int on);
 
 /* size of the packed device weight blob, and packing (host fp64 -> device model dtype, with the
  * ScalarMLPFunction normalisation constants folded and the two linear maps of the first stage

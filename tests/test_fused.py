@@ -1,0 +1,167 @@
+"""Fused per-atom-tile kernels (allegro_amd/csrc/aa_fused.hip): the whole forward of the standard 2-layer, 64-wide fp32
+stack in one launch, one wave per center atom's edge tile.
+
+CPU: the unmodified kernel source in the test-only emulation build, against the reference's golden vectors, against
+the fp64 oracle on ragged graphs (partial tiles, an atom without edges, two species, per-type scale/shift), and on
+atom-block sub-ranges (the multi-GPU partition).  GPU: the same checks on hardware plus the staged pipeline as A/B.
+The fused path is selected by `aa_graph.max_degree <= 32`; larger segments must fall back to the staged pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from allegro_amd import graph as G
+from allegro_amd.nn import HipAllegroModel
+from tests.golden_utils import load_model_fixture
+from tests.hip_utils import emu_lib, fixture_data, model_from_fixture
+
+
+def _cfg(embed="bessel", coupling=True, l_max=2, seed=11, avg=9.0, scale_shift=True):
+    rce = ({"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8} if embed == "bessel" else
+           {"_target_": "allegro.nn.TwoBodySplineScalarEmbed", "num_splines": 8, "spline_span": 6})
+    c = dict(type_names=["A", "B"], r_max=3.4, l_max=l_max, num_layers=2, num_scalar_features=64, num_tensor_features=64,
+             radial_chemical_embed=rce, radial_chemical_embed_dim=64, scalar_embed_mlp_hidden_layers_width=64,
+             allegro_mlp_hidden_layers_width=64, readout_mlp_hidden_layers_width=64, avg_num_neighbors=avg, seed=seed,
+             tp_path_channel_coupling=coupling, model_dtype="float32")
+    if scale_shift:
+        c.update(per_type_energy_scales=[1.3, 0.6], per_type_energy_shifts=[-2.0, 0.25])
+    return c
+
+
+def _ragged(dims=(4, 4, 4), keep=0.88, a=1.8, seed=5, r_cut=3.4):
+    """A ragged open cluster: jittered lattice (spacing a) with vacancies -- degrees from a few (corners) up to ~30
+    (interior), no unphysically short contacts that would make the fp32 sums ill-conditioned -- plus one isolated
+    atom without any edge."""
+    rng = np.random.default_rng(seed)
+    grid = np.stack(np.meshgrid(*[np.arange(d) for d in dims], indexing="ij"), -1).reshape(-1, 3)
+    sel = np.sort(rng.permutation(len(grid))[:int(round(keep * len(grid)))])
+    pos = grid[sel] * a + rng.uniform(-0.2, 0.2, size=(len(sel), 3)) + 10.0
+    pos = np.concatenate([pos, [[70.0, 70.0, 70.0]]])  # isolated: no edges
+    cell = np.eye(3) * 120.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, r_cut)
+    types = rng.integers(0, 2, size=len(pos))
+    return pos, cell, ei, shift, types
+
+
+def _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev, blocks=None):
+    """HIP fp32 (fused) may not be further from the fp64 oracle on the same (upcast) weights than the fp32 CPU oracle
+    is (x2 + a small floor) -- the criterion of tests/test_hip_model.py for ill-conditioned fp32 sums."""
+    from oracle import restatement as R
+
+    n = pos.shape[0]
+    m = HipAllegroModel(**cfg).to(dev)
+    if lib is not None:
+        m._bind_library(lib)
+    sv = torch.tensor(shift @ cell, dtype=torch.float32)
+    tt = torch.tensor(types)
+    g = m.prepare_graph(torch.tensor(ei).to(dev), tt.to(dev), n, sv.to(dev))
+    assert 0 < g.max_degree <= 32
+    e, f = m.energy_forces(torch.tensor(pos, dtype=torch.float32, device=dev), g)
+    e, f = e.cpu(), f.cpu()
+    sd = {k[len("func."):]: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref32 = R.allegro_energy_forces(cfg, sd, torch.tensor(pos, dtype=torch.float32), torch.tensor(ei), tt, sv)
+    cfg64 = dict(cfg, model_dtype="float64")
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    ref64 = R.allegro_energy_forces(cfg64, sd64, torch.tensor(pos), torch.tensor(ei), tt, sv.double())
+    for got, w32, w64 in ((e, ref32["atomic_energy"].reshape(-1), ref64["atomic_energy"].reshape(-1)),
+                          (f, ref32["forces"], ref64["forces"])):
+        assert torch.isfinite(got).all()
+        scale = max(1.0, float(w64.abs().max()))
+        err_hip = (got.double() - w64).abs().max().item()
+        err_cpu32 = (w32.double() - w64).abs().max().item()
+        assert err_hip <= 2.0 * err_cpu32 + 1e-5 * scale, (err_hip, err_cpu32, scale)
+    if blocks:
+        # atom-block decomposition (allegro_amd/dist.py): the sum over blocks reproduces the full evaluation
+        rowptr = G.csr_from_sorted_centers(ei[0], n)
+        cuts = [0] + [int(np.searchsorted(rowptr, rowptr[-1] * k / blocks, side="left")) for k in range(1, blocks)] + [n]
+        fa, ea = torch.zeros_like(f), torch.zeros_like(e)
+        for a0, a1 in zip(cuts[:-1], cuts[1:]):
+            lo, hi = int(rowptr[a0]), int(rowptr[a1])
+            if hi == lo:
+                continue
+            gb = m.prepare_graph(torch.tensor(ei[:, lo:hi]).to(dev), tt.to(dev), n, sv[lo:hi].to(dev))
+            eb, fb = m.energy_forces(torch.tensor(pos, dtype=torch.float32, device=dev), gb)
+            fa += fb.cpu()
+            ea[a0:a1] = eb.cpu()[a0:a1]
+            # atoms outside the block carry no edges: E_i = shift of their type
+            shifts = torch.tensor(cfg.get("per_type_energy_shifts", [0.0, 0.0]), dtype=torch.float32)[tt]
+            outside = torch.ones(n, dtype=torch.bool)
+            outside[a0:a1] = False
+            assert (eb.cpu()[outside] - shifts[outside]).abs().max() < 1e-6
+        assert (fa - f).abs().max().item() < 2e-5 * max(1.0, float(f.abs().max()))
+        iso = np.bincount(ei[0], minlength=n) == 0
+        assert (ea - e)[~torch.tensor(iso)].abs().max().item() < 1e-5 * max(1.0, float(e.abs().max()))
+    return m, g
+
+
+@pytest.mark.parametrize("name", ["c2", "c2_spline", "c2_l1", "c2_uncoupled"])
+def test_fused_forward_matches_reference_golden_emulated(name):
+    fx = load_model_fixture(name, torch.float32)
+    m = model_from_fixture(fx, torch.float32, emu_lib())
+    data, sv = fixture_data(fx, torch.float32)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    assert 0 < g.max_degree <= 32
+    e, f = m.energy_forces(data["pos"], g)
+    for got, want in ((e, fx["out"]["atomic_energy"].reshape(-1)), (f, fx["out"]["forces"])):
+        assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("embed,coupling", [("bessel", True), ("spline", False)])
+def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(embed, coupling):
+    pos, cell, ei, shift, types = _ragged()
+    deg = np.bincount(ei[0], minlength=pos.shape[0])
+    assert 20 <= deg.max() <= 32 and deg.min() == 0 and len(set(deg.tolist())) > 6, deg
+    _check_vs_oracle64(_cfg(embed, coupling, avg=float(deg.mean())), pos, cell, ei, shift, types, emu_lib(), torch.device("cpu"),
+                       blocks=3)
+
+
+def test_degree_above_32_falls_back_to_the_staged_pipeline_emulated():
+    rng = np.random.default_rng(9)
+    grid = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(3), indexing="ij"), -1).reshape(-1, 3)[:40]
+    pos = grid * 0.7 + rng.uniform(-0.05, 0.05, size=(40, 3)) + 20.0
+    cell = np.eye(3) * 60.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
+    deg = np.bincount(ei[0], minlength=40)
+    assert deg.max() > 32
+    from oracle import restatement as R
+
+    cfg = _cfg(avg=float(deg.mean()), scale_shift=False)
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    tt = torch.tensor(rng.integers(0, 2, size=40))
+    sv = torch.tensor(shift @ cell, dtype=torch.float32)
+    g = m.prepare_graph(torch.tensor(ei), tt, 40, sv)
+    assert g.max_degree > 32
+    e, f = m.energy_forces(torch.tensor(pos, dtype=torch.float32), g)
+    sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
+    cfg64 = dict(cfg, model_dtype="float64")
+    ref = R.allegro_energy_forces(cfg64, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()},
+                                  torch.tensor(pos), torch.tensor(ei), tt, sv.double())
+    assert (f.double() - ref["forces"]).abs().max().item() < 2e-4 * max(1.0, float(ref["forces"].abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("embed,coupling,l_max", [("bessel", True, 2), ("spline", False, 2), ("bessel", True, 1)])
+def test_fused_forward_ragged_graph_vs_fp64_oracle_on_gpu(embed, coupling, l_max):
+    pos, cell, ei, shift, types = _ragged(dims=(9, 9, 8), keep=0.93, seed=8)
+    deg = np.bincount(ei[0], minlength=pos.shape[0])
+    assert 24 <= deg.max() <= 32 and deg.min() == 0, (deg.max(), deg.min())
+    _check_vs_oracle64(_cfg(embed, coupling, l_max=l_max, avg=float(deg.mean())), pos, cell, ei, shift, types, None,
+                       torch.device("cuda:0"), blocks=4)
+
+
+@pytest.mark.gpu
+def test_fused_and_staged_forward_agree_on_gpu(monkeypatch):
+    """A/B on hardware: the same model and graph through the fused kernel and through the staged pipeline
+    (AA_NOFUSE=1 at plan creation)."""
+    dev = torch.device("cuda:0")
+    fx = load_model_fixture("c2", torch.float32)
+    data, sv = fixture_data(fx, torch.float32, dev)
+    m = model_from_fixture(fx, torch.float32, device=dev)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    e, f = m.energy_forces(data["pos"], g)
+    monkeypatch.setenv("AA_NOFUSE", "1")
+    m2 = model_from_fixture(fx, torch.float32, device=dev)
+    e2, f2 = m2.energy_forces(data["pos"], g)
+    assert (e - e2).abs().max().item() < 5e-6 and (f - f2).abs().max().item() < 2e-5
+    for got, want in ((e.cpu(), fx["out"]["atomic_energy"].reshape(-1)), (f.cpu(), fx["out"]["forces"])):
+        assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))

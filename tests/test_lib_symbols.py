@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_match_header_sizes():
     # layout sanity of the ctypes mirrors (pointer-heavy structs: check field counts against the header)
     assert ctypes.sizeof(_lib.TpDesc) == 7 * 4 + 4 + 5 * 8  # 7 int32 + pad + 5 pointers
-    assert ctypes.sizeof(_lib.Graph) == 11 * 8  # 2 int64 + 7 pointers (incl. the optional transposed CSR) + owned range
+    assert ctypes.sizeof(_lib.Graph) == 12 * 8  # 2 int64 + 7 pointers (incl. the optional transposed CSR) + owned range + max_degree
     assert _lib.ModelConfig.tps.size == _lib.AA_MAX_LAYERS * ctypes.sizeof(_lib.TpDesc)
 
 
