@@ -156,7 +156,9 @@ LIB_NAME = "liballegro_amd.so"
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    """In-tree library next to this file; ALLEGRO_AMD_LIBRARY points at another build of the same sources
+    (instrumented variants of tools/)."""
+    return os.environ.get("ALLEGRO_AMD_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 def load(build_if_stale: bool = True) -> AllegroLib:
@@ -164,7 +166,7 @@ def load(build_if_stale: bool = True) -> AllegroLib:
     global _LIB
     if _LIB is not None:
         return _LIB
-    if build_if_stale and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+    if build_if_stale and not os.environ.get("ALLEGRO_AMD_LIBRARY") and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         from .build import build_library
 
         build_library(verbose=False)

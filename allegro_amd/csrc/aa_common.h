@@ -438,10 +438,7 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream);
 // ----------------------------------------------------------------------------------------------
 // fused per-atom-tile kernels (aa_fused.hip): the whole forward of the standard 2-layer, 64-wide stack in ONE launch
 // ----------------------------------------------------------------------------------------------
-struct FusedLayerDev {
-  const void* Wq;  // bf16x3 fragments of the layer (gemm_pack_bf16x3), first tile of the layer
-  int KC;          // k chunks of the packed matrix (tile stride)
-};
+constexpr int kFusedMaxSteps = 56;
 struct FusedFwdArgs {
   int64_t N, atom0, atom_end;  // atoms [atom0, atom_end) are evaluated (one wave each); every one has <= 32 edges
   const int32_t *rowptr, *nbr, *types;
@@ -451,10 +448,9 @@ struct FusedFwdArgs {
   float poly_p;
   const float *rmax_recip, *bessel_w;
   const float* emb_tab;    // [T*T][8][64]
-  // linear layers in execution order: embed0, embed1, [two-body | w0], latent0 hidden, latent0 out, w0 (again),
-  // latent1 hidden, latent1 out, readout hidden
-  FusedLayerDev L[9];
-  const float *wk0, *wk1;    // Wenv of layer 0 / 1 as [k][R][64]
+  // the kernel's weight program: one 12-KB block per step, as two 6-KB halves (a tile pair x 32-deep chunk of a linear
+  // layer's bf16x3 fragments, or 16 rows of an env-weight matrix [k][R][64]) -- built by fused_fwd_program()
+  const void* wstep[kFusedMaxSteps][2];
   const float *tpw0, *tpw1;  // path weights
   int coupling;
   float sf;                  // 1/sqrt(avg_num_neighbors)
@@ -474,7 +470,8 @@ struct FusedFwdArgs {
   float *x2s0, *x2s1;  // [N][D][64]
   float* atom_energy;  // [N]
 };
-int launch_fused_fwd(int pair, const FusedFwdArgs& a, hipStream_t stream);
+int fused_fwd_num_steps(int R, bool hold_w0);
+int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
 
 // ----------------------------------------------------------------------------------------------
 // edge prologue / epilogue / readout reduce

@@ -57,27 +57,65 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-struct FusedCtx {
-  int tid, lane, hh, el;
+// ---- weight pipeline --------------------------------------------------------------------------------------------
+// The kernel's program is a fixed sequence of NS "steps"; step S consumes one 12-KB block of weights (a tile pair x
+// 32-deep chunk of a linear layer in bf16x3 fragments, or 16 rows of an env-weight matrix) from LDS buffer S & 1.
+// Block S + 2 is requested from L2 at the START of step S into one of two register sets and lands in LDS at the END
+// of step S + 1, i.e. every load has two full steps to arrive (the kernel runs one wave per SIMD: nothing else hides
+// L2 latency).  Barriers are raw s_barrier with LDS-only fences, so that they do not drain the loads in flight
+// (__syncthreads() carries a vmcnt(0)).  All indices are compile-time: the whole program is unrolled.
+struct FusedPipe {
+  u32x4 ra[3], rb[3];
   u32x4* wbuf;  // [2][kWStep]
-  int step;
+  int tid, lane;
 };
 
-// block-cooperative staging of one weight step (tile pair nt, nt+1; chunk kc) -- see gemm_chain_bf16x3_kernel
-__device__ __forceinline__ void fused_stage_load(const FusedLayerDev& L, int nt, int kc, int tid, u32x4* r) {
-  const size_t chunk_stride = 64 * 6, tile_stride = size_t(L.KC) * chunk_stride;
-  const u32x4* W = static_cast<const u32x4*>(L.Wq);
-  const u32x4* s0 = W + size_t(nt) * tile_stride + size_t(kc) * chunk_stride;
-  const u32x4* s1 = W + size_t(nt + 1) * tile_stride + size_t(kc) * chunk_stride;
-  r[0] = s0[tid];
-  r[1] = tid < 128 ? s0[256 + tid] : s1[tid - 128];
-  r[2] = s1[128 + tid];
+__device__ __forceinline__ void lds_barrier() {
+#ifdef AA_EXP_SYNC
+  __syncthreads();
+  return;
+#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-__device__ __forceinline__ void fused_stage_write(u32x4* wbuf, int b, int tid, const u32x4* r) {
+
+// (every load is wave-uniform base + lane offset: the bases stay in SGPRs and all loads of the program share ONE
+//  offset register -- with per-lane base selects the compiler hoists ~140 loop-invariant 64-bit address pairs out of
+//  the persistent loop and spills them)
+//  What remains hoisted -- the block addresses of the ~46 steps -- costs two or three scratch reloads per step.)
+__device__ __forceinline__ void pipe_load(const FusedFwdArgs& A, int tid, int t, u32x4* r) {
+  const u32x4* s0 = static_cast<const u32x4*>(A.wstep[t][0]);
+  const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t][1]);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const u32x4* mid = wv < 2 ? s0 + 256 : s1 - 128;  // elements 256..383 of the first half | 0..127 of the second
+  r[0] = s0[tid];
+  r[1] = mid[tid];
+  r[2] = (s1 + 128)[tid];
+}
+__device__ __forceinline__ void pipe_store(u32x4* wbuf, int b, int tid, const u32x4* r) {
   u32x4* d = wbuf + b * kWStep;
   d[tid] = r[0];
   d[256 + tid] = r[1];
   d[512 + tid] = r[2];
+}
+template <int S, int NS>
+__device__ __forceinline__ void pipe_issue(const FusedFwdArgs& A, FusedPipe& p) {
+  if constexpr ((S & 1) == 0)
+    pipe_load(A, p.tid, (S + 2) % NS, p.ra);
+  else
+    pipe_load(A, p.tid, (S + 2) % NS, p.rb);
+}
+template <int S>
+__device__ __forceinline__ void pipe_commit(FusedPipe& p) {
+  if constexpr (((S + 1) & 1) == 0)
+    pipe_store(p.wbuf, 0, p.tid, p.ra);
+  else
+    pipe_store(p.wbuf, 1, p.tid, p.rb);
+  lds_barrier();
+  // one scheduling region per step: without it the fully unrolled program is treated as one region and later steps'
+  // operand splits / LDS reads are hoisted far ahead (hundreds of spilled registers)
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // 24 MFMAs of one step (6 cross products x 2 k halves x 2 tiles); weight levels read from LDS just in time
@@ -120,21 +158,30 @@ __device__ __forceinline__ void fused_mma_step(const u32x4* wb, int lane, const 
 #undef AA_W
 }
 
-// One linear layer on the wave's tile: KC 32-deep operand chunks (op(kc) -> the v16f tile that is chunk kc), NT output
-// tiles in pairs (epi(pair, acc0, acc1) after each pair).  Every step stages the NEXT step's weights (next chunk /
-// next pair / first step of layer Ln) while its own MFMAs issue; one block barrier per step.
-template <int KC, int NT, class OpF, class EpiF>
-__device__ __forceinline__ void fused_layer(FusedCtx& c, const FusedLayerDev& L, const FusedLayerDev& Ln, bool kernel_last,
-                                            OpF&& op, EpiF&& epi) {
+// One linear layer on the wave's tile, steps S0 .. S0 + KC * NT / 2 - 1 of the program: KC 32-deep operand chunks
+// (op(kc) -> the v16f tile that is chunk kc), NT output tiles in pairs (epi(pair, acc0, acc1) after each pair).
+// Operand splits are software-pipelined: chunk kc + 1 is split while the MFMAs of chunk kc execute (layers with few
+// chunks and several pairs split all chunks once up front).
+template <int S0, int NS, int KC, int NT, class OpF, class EpiF>
+__device__ __forceinline__ void fused_layer(const FusedFwdArgs& A, FusedPipe& p, OpF&& op, EpiF&& epi) {
   static_assert(NT % 2 == 0, "output tiles come in pairs");
-  constexpr bool PRE = KC <= 2 && NT > 2;  // few chunks, many pairs: split the operand once
-  XSplit ps[PRE ? KC : 1];
+  constexpr bool PRE = NT > 2;
+#ifdef AA_EXP_NOPIPE
+  constexpr bool PIPE = false;
+#else
+  constexpr bool PIPE = true;
+#endif
+  XSplit xs[PRE ? KC : 2];
   if constexpr (PRE) {
-    static_for<0, KC>([&](auto kc) { const v16f t = op(kc); xsplit_from_acc(t, ps[kc]); });
+    static_for<0, KC>([&](auto kc) {
+      const v16f t = op(kc);
+      xsplit_from_acc(t, xs[kc]);
+    });
+  } else if constexpr (PIPE) {
+    const v16f t = op(std::integral_constant<int, 0>{});
+    xsplit_from_acc(t, xs[0]);
   }
   static_for<0, NT / 2>([&](auto ntp) {
-    constexpr int nt = 2 * decltype(ntp)::value;
-    constexpr bool last_pair = nt + 2 >= NT;
     v16f acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -143,32 +190,18 @@ __device__ __forceinline__ void fused_layer(FusedCtx& c, const FusedLayerDev& L,
     }
     static_for<0, KC>([&](auto kcc) {
       constexpr int kc = decltype(kcc)::value;
-      constexpr bool lastc = kc + 1 >= KC;
-      u32x4 r[3];
-      if constexpr (!lastc) {
-        fused_stage_load(L, nt, kc + 1, c.tid, r);
-      } else if constexpr (!last_pair) {
-        fused_stage_load(L, nt + 2, 0, c.tid, r);
-      } else {
-        if (kernel_last)
-          fused_stage_load(L, nt, kc, c.tid, r);  // (nothing follows: re-stage own step, uniform instruction stream)
-        else
-          fused_stage_load(Ln, 0, 0, c.tid, r);
+      constexpr int S = S0 + decltype(ntp)::value * KC + kc;
+      pipe_issue<S, NS>(A, p);
+      if constexpr (!PRE && !PIPE) {
+        const v16f t = op(kcc);
+        xsplit_from_acc(t, xs[kc & 1]);
       }
-      if constexpr (PRE) {
-        fused_mma_step(c.wbuf + (c.step & 1) * kWStep, c.lane, ps[kc], acc0, acc1);
-      } else {
-        XSplit x;
-        {
-          const v16f t = op(kcc);
-          xsplit_from_acc(t, x);
-        }
-        fused_mma_step(c.wbuf + (c.step & 1) * kWStep, c.lane, x, acc0, acc1);
+      fused_mma_step(p.wbuf + (S & 1) * kWStep, p.lane, xs[PRE ? kc : (kc & 1)], acc0, acc1);
+      if constexpr (!PRE && PIPE && kc + 1 < KC) {
+        const v16f t = op(std::integral_constant<int, kc + 1>{});
+        xsplit_from_acc(t, xs[(kc + 1) & 1]);
       }
-      fused_stage_write(c.wbuf, (c.step + 1) & 1, c.tid, r);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);  // keep later steps' operand splits / loads from being hoisted over this one
-      ++c.step;
+      pipe_commit<S>(p);
     });
     epi(ntp, acc0, acc1);
   });
@@ -197,6 +230,11 @@ __device__ __forceinline__ void fused_store_tile(float* sT, const v16f& acc, flo
 // A tile pair parked in LDS in accumulator layout ([q][lane] 16-B cells: conflict-free b128 accesses).  The two-body
 // scalars and lat0 are operands of three / two later layers; parking them frees 64 registers per lane for the whole
 // second half of the kernel (the kernel runs one wave per SIMD, LDS is plentiful).
+#ifdef AA_EXP_OCC2
+constexpr int kFusedOcc = 2;
+#else
+constexpr int kFusedOcc = 1;
+#endif
 __device__ __forceinline__ void park_tile(float* slot, const v16f& t, int lane) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(slot + (q * 64 + lane) * 4) = v4f{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
@@ -249,10 +287,11 @@ __device__ __forceinline__ void tile_moments(float* sA, const float* sY, const v
   __builtin_amdgcn_wave_barrier();
 }
 
-// x2s[j] (lane = channel) = f * sum_k M[j][k] * Wk[k][r(j)][ch]  with M handed over through sM [k][D]
-template <int D, int R>
-__device__ __forceinline__ void project_moments(float* sM, const float* M, const float* __restrict__ Wk, float sf, int lane, float* x2s) {
-  constexpr int KB = 8;
+// x2s[j] (lane = channel) = f * sum_k M[j][k] * Wk[k][r(j)][ch].  M is handed over through sM [k][D]; the env-weight
+// matrix Wk [64][R][64] arrives through the weight pipeline as 4 blocks of 16 rows (steps S0 .. S0 + 3).
+template <int S0, int NS, int D, int R>
+__device__ __forceinline__ void project_moments(const FusedFwdArgs& A, FusedPipe& p, float* sM, const float* M, float sf, float* x2s) {
+  const int lane = p.lane;
 #pragma unroll
   for (int q = 0; q < (D + 3) / 4; ++q) {
     v4f mm;
@@ -263,38 +302,30 @@ __device__ __forceinline__ void project_moments(float* sM, const float* M, const
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int j = 0; j < D; ++j) x2s[j] = 0.f;
-  float wc[KB][R], wn[KB][R];
-  auto loadw = [&](int k0, float(*w)[R]) {
+  static_for<0, 4>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    constexpr int S = S0 + c;
+    pipe_issue<S, NS>(A, p);
+    const float* wf = reinterpret_cast<const float*>(p.wbuf + (S & 1) * kWStep) + lane;
 #pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      const int k = k0 + i < 64 ? k0 + i : 63;
+    for (int kk = 0; kk < 16; ++kk) {
+      float w[R], m[16];
 #pragma unroll
-      for (int r = 0; r < R; ++r) w[i][r] = Wk[(int64_t(k) * R + r) * 64 + lane];
-    }
-  };
-  loadw(0, wc);
-  for (int k0 = 0; k0 < 64; k0 += KB) {
-    loadw(k0 + KB, wn);
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      float m[16];
+      for (int r = 0; r < R; ++r) w[r] = wf[(kk * R + r) * 64];
 #pragma unroll
       for (int q = 0; q < (D + 3) / 4; ++q) {
-        const v4f mm = *reinterpret_cast<const v4f*>(sM + (k0 + i) * kLdY + 4 * q);
+        const v4f mm = *reinterpret_cast<const v4f*>(sM + (16 * c + kk) * kLdY + 4 * q);
 #pragma unroll
         for (int t = 0; t < 4; ++t) m[4 * q + t] = mm[t];
       }
 #pragma unroll
-      for (int j = 0; j < D; ++j) x2s[j] += m[j] * wc[i][r_of<0>(j)];
+      for (int j = 0; j < D; ++j) x2s[j] += m[j] * w[r_of<0>(j)];
+      if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 rows' LDS operands in flight
     }
-#pragma unroll
-    for (int i = 0; i < KB; ++i)
-#pragma unroll
-      for (int r = 0; r < R; ++r) wc[i][r] = wn[i][r];
-  }
+    pipe_commit<S>(p);
+  });
 #pragma unroll
   for (int j = 0; j < D; ++j) x2s[j] *= sf;
-  __builtin_amdgcn_wave_barrier();
 }
 
 // scal[e][ch] += w[e][r][ch] * sum_{a in irrep r} Y[e][a] * B[a][ch]  for the tile pair (w0a: channels 0..31,
@@ -329,291 +360,389 @@ __device__ __forceinline__ void scal_accumulate(const float* sB, const float* Y,
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <class Sig0, class Sig1>
-__global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdArgs A) {
+// Optional phase timing (tools/fused_timing.sh builds with -DAA_FUSED_TIMING): wave 0 of the middle workgroup stamps the
+// shader clock at every phase boundary into a small global buffer that the launcher prints.
+#ifdef AA_FUSED_TIMING
+__device__ unsigned long long g_fused_ticks[32];
+#define AA_TICK(i)                                                                   \
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_fused_ticks[i] = __builtin_readcyclecounter();
+#else
+#define AA_TICK(i)
+#endif
+
+// per-lane geometry inputs of one tile, fetched one iteration ahead of their use
+struct TileIn {
+  int beg, cnt;   // edge segment of the wave's atom (cnt = 0: nothing to do)
+  int j;          // neighbor of the lane's edge
+  float pi[3], pj[3], sv[3];
+  int ti, tj;
+};
+
+template <class Sig0, class Sig1, bool HOLD>
+__global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs A) {
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   static_assert(Sig0::D1 == D && Sig0::DOUT == D && Sig1::D1 == D && Sig1::DOUT == 1, "standard 2-layer stack");
   static_assert(D <= 16, "l_max <= 3");
+  // the program: L0 L1 | Wenv0 | L2 | L3 | Wenv1 | L4 | (L5: w0 again, unless held) | L6 L7 L8
+  constexpr int S_L0 = 0, S_L1 = 2, S_P0 = 4, S_L2 = 8, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L4 = S_P1 + 4,
+                S_L5 = S_L4 + 2, S_L6 = S_L5 + (HOLD ? 0 : 2 * R), S_L7 = S_L6 + 6, S_L8 = S_L7 + 2, NS = S_L8 + 6;
+  static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps, "the two LDS buffers alternate consistently across iterations");
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);            // [64] last readout weights
-  float* sTab = sRo + 64;                                              // [T*T][8][64] two-body table
+  float* sRm = sRo + 64;                                               // [T*T] 1 / r_max per type pair, [8] Bessel roots
+  float* sTab = sRm + 16;                                              // [T*T][8][64] two-body table
   const int ntab = A.num_types * A.num_types * 512;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, el = lane & 31;
   float* sW = sTab + ntab + wv * (kWaveRegion + 32 * kLdY);            // wave region: patch / per-atom vectors ...
   float* sY = sW + kWaveRegion;                                        // ... and the harmonics of the tile [32][kLdY]
   float* sBv = sW + kOffB;
   // parked tiles of this wave: two-body scalars (2 tiles) and lat0 (2 tiles)
+#ifdef AA_EXP_OCC2
+  v16f pk[4];  // (occupancy-2 experiment: "parked" tiles stay in registers / compiler-managed scratch)
+#define AA_PARK(i, t) pk[i] = t
+#define AA_FETCH(i) pk[i]
+#else
   float* sPark = sTab + ntab + 4 * (kWaveRegion + 32 * kLdY) + wv * 4 * kTileFloats;
+#define AA_PARK(i, t) park_tile(sPark + (i) * kTileFloats, t, lane)
+#define AA_FETCH(i) fetch_tile(sPark + (i) * kTileFloats, lane)
+#endif
   for (int i = tid; i < 64; i += 256) sRo[i] = A.ro_w[i];
+  if (tid < A.num_types * A.num_types) sRm[tid] = A.rmax_recip[tid];
+  if (tid >= 8 && tid < 16) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 8] : 0.f;
   for (int i = tid; i < ntab; i += 256) sTab[i] = A.emb_tab[i];
-  FusedCtx c{tid, lane, hh, el, wbuf, 0};
+  FusedPipe p;
+  p.wbuf = wbuf;
+  p.tid = tid;
+  p.lane = lane;
   {
     u32x4 r[3];
-    fused_stage_load(A.L[0], 0, 0, tid, r);
-    fused_stage_write(wbuf, 0, tid, r);
+    pipe_load(A, tid, 0, r);
+    pipe_store(wbuf, 0, tid, r);
+    pipe_load(A, tid, 1, p.rb);  // (step 1 lands in LDS at the end of step 0)
   }
-  // ---- the wave's atom and edge tile
-  const int64_t atom = A.atom0 + int64_t(blockIdx.x) * 4 + wv;
-  const bool atom_ok = atom < A.atom_end;
-  int beg = 0, cnt = 0;
-  if (atom_ok) {
-    beg = A.rowptr[atom];
-    cnt = A.rowptr[atom + 1] - beg;
-  }
-  beg = __builtin_amdgcn_readfirstlane(beg);
-  cnt = __builtin_amdgcn_readfirstlane(cnt);
-  const bool row_ok = el < cnt;
-  // ---- geometry of the lane's edge (rows beyond the segment: a harmless dummy that is masked everywhere)
-  float Y[D], basis[8];
-  int pair = 0;
-  {
-    float vx = 1.f, vy = 0.f, vz = 0.f;
-    float x = 0.5f;
-    if (row_ok) {
-      const int64_t e = int64_t(beg) + el;
-      const int j = A.nbr[e];
+  // ---- persistent loop over groups of 4 atoms; the inputs of the next tile are fetched during the current one
+  const int64_t ngroups = (A.atom_end - A.atom0 + 3) / 4;
+  auto atom_of = [&](int64_t it) { return A.atom0 + (int64_t(blockIdx.x) + it * gridDim.x) * 4 + wv; };
+  auto load_rows = [&](int64_t atom, int& beg, int& cnt) {
+    beg = 0;
+    cnt = 0;
+    if (atom < A.atom_end) {
+      beg = A.rowptr[atom];
+      cnt = A.rowptr[atom + 1] - beg;
+    }
+  };
+  auto load_nbr = [&](int beg, int cnt) { return el < cnt ? A.nbr[int64_t(beg) + el] : 0; };
+  auto load_geo = [&](int64_t atom, TileIn& t) {
+    if (el < t.cnt) {
+      const int64_t e = int64_t(t.beg) + el;
       const float* pi = A.pos + 3 * atom;
-      const float* pj = A.pos + 3 * int64_t(j);
-      vx = pj[0] - pi[0];
-      vy = pj[1] - pi[1];
-      vz = pj[2] - pi[2];
-      if (A.shift_vec) {
-        const float* sv = A.shift_vec + 3 * e;
-        vx += sv[0];
-        vy += sv[1];
-        vz += sv[2];
+      const float* pj = A.pos + 3 * int64_t(t.j);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        t.pi[q] = pi[q];
+        t.pj[q] = pj[q];
+        t.sv[q] = A.shift_vec ? A.shift_vec[3 * e + q] : 0.f;
       }
-      pair = A.types[atom] * A.num_types + A.types[j];
+      t.ti = A.types[atom];
+      t.tj = A.types[t.j];
     }
-    const float rr = aa_sqrt(vx * vx + vy * vy + vz * vz);
-    const float inv = 1.f / rr;
-    const float nx = vx * inv, ny = vy * inv, nz = vz * inv;
-    if (row_ok) x = rr * A.rmax_recip[pair];
-    float Yf[16];
-    sh_eval<float>(Sig0::LMAX, nx, ny, nz, Yf);
+  };
+  TileIn cur, nxt;
+  int beg2 = 0, cnt2 = 0;
+  load_rows(atom_of(0), cur.beg, cur.cnt);
+  load_rows(atom_of(1), nxt.beg, nxt.cnt);
+  cur.j = load_nbr(cur.beg, cur.cnt);
+  load_geo(atom_of(0), cur);
+  float wp0[Sig0::P], wp1[Sig1::P];
 #pragma unroll
-    for (int m = 0; m < D; ++m) Y[m] = row_ok ? Yf[m] : 0.f;
-    if (row_ok && hh == 0) {
-      const int64_t e = int64_t(beg) + el;
-      *reinterpret_cast<v4f*>(A.vec + 4 * e) = v4f{nx, ny, nz, rr};
-      if (A.sh) {
+  for (int q = 0; q < Sig0::P; ++q) wp0[q] = A.coupling ? A.tpw0[lane * Sig0::P + q] : A.tpw0[q];
 #pragma unroll
-        for (int m = 0; m < D; ++m) A.sh[e * D + m] = Yf[m];
+  for (int q = 0; q < Sig1::P; ++q) wp1[q] = A.coupling ? A.tpw1[lane * Sig1::P + q] : A.tpw1[q];
+  lds_barrier();  // tables + first weight step staged
+  for (int64_t it = 0; blockIdx.x + it * gridDim.x < ngroups; ++it) {
+    AA_TICK(0)
+    const int64_t atom = atom_of(it);
+    const bool atom_ok = atom < A.atom_end;
+    const int beg = __builtin_amdgcn_readfirstlane(cur.beg), cnt = __builtin_amdgcn_readfirstlane(cur.cnt);
+    const bool row_ok = el < cnt;
+    const int64_t row0 = beg;
+    // prefetch: neighbor ids of the next tile, row pointers of the one after
+    nxt.j = load_nbr(nxt.beg, nxt.cnt);
+    load_rows(atom_of(it + 2), beg2, cnt2);
+    // ---- geometry of the lane's edge (rows beyond the segment: a harmless dummy that is masked everywhere)
+    float Y[D], basis[8];
+    int pair = 0;
+    {
+      float vx = 1.f, vy = 0.f, vz = 0.f;
+      float x = 0.5f;
+      if (row_ok) {
+        vx = cur.pj[0] - cur.pi[0] + cur.sv[0];
+        vy = cur.pj[1] - cur.pi[1] + cur.sv[1];
+        vz = cur.pj[2] - cur.pi[2] + cur.sv[2];
+        pair = cur.ti * A.num_types + cur.tj;
+      }
+      const float rr = aa_sqrt(vx * vx + vy * vy + vz * vz);
+      const float inv = 1.f / rr;
+      const float nx = vx * inv, ny = vy * inv, nz = vz * inv;
+      if (row_ok) x = rr * sRm[pair];
+      float Yf[16];
+      sh_eval<float>(Sig0::LMAX, nx, ny, nz, Yf);
+#pragma unroll
+      for (int m = 0; m < D; ++m) Y[m] = row_ok ? Yf[m] : 0.f;
+      if (row_ok && hh == 0) {
+        const int64_t e = row0 + el;
+        *reinterpret_cast<v4f*>(A.vec + 4 * e) = v4f{nx, ny, nz, rr};
+        if (A.sh) {
+#pragma unroll
+          for (int m = 0; m < D; ++m) A.sh[e * D + m] = Yf[m];
+        }
+      }
+      if (hh == 0) {
+#pragma unroll
+        for (int m = 0; m < kLdY; ++m) sY[el * kLdY + m] = m < D ? Y[m] : 0.f;
+      }
+      if (A.embed_kind == 1) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          float dbv;
+          spline_basis_and_grad<float>(x, n, 8, A.spline_span, basis[n], dbv);
+        }
+      } else {
+        float f, df;
+        cutoff_and_grad<float>(x, A.poly_p, f, df);
+        const float fx = f / x;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) basis[n] = aa_sin(sRm[8 + n] * x) * fx;
       }
     }
-    if (hh == 0) {
+    AA_TICK(1)
+    // ---- two-body embedding of the lane's 32 features: emb0[c] = sum_n basis[n] * tab[pair][n][c]
+    v16f em0, em1;
+    {
+      const float* tb = sTab + pair * 512 + 4 * hh;
 #pragma unroll
-      for (int m = 0; m < kLdY; ++m) sY[el * kLdY + m] = m < D ? Y[m] : 0.f;
-    }
-    if (A.embed_kind == 1) {
+      for (int r = 0; r < 16; ++r) {
+        em0[r] = 0.f;
+        em1[r] = 0.f;
+      }
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
-        float dbv;
-        spline_basis_and_grad<float>(x, n, 8, A.spline_span, basis[n], dbv);
-      }
-    } else {
-      float f, df;
-      cutoff_and_grad<float>(x, A.poly_p, f, df);
-      const float fx = f / x;
 #pragma unroll
-      for (int n = 0; n < 8; ++n) basis[n] = aa_sin(A.bessel_w[n] * x) * fx;
-    }
-  }
-  __syncthreads();  // tables + first weight step staged
-  // ---- two-body embedding of the lane's 32 features: emb0[c] = sum_n basis[n] * tab[pair][n][c]
-  v16f em0, em1;
-  {
-    const float* tb = sTab + pair * 512 + 4 * hh;
+        for (int q = 0; q < 4; ++q) {
+          const v4f t0 = *reinterpret_cast<const v4f*>(tb + n * 64 + 8 * q);
+          const v4f t1 = *reinterpret_cast<const v4f*>(tb + n * 64 + 32 + 8 * q);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      em0[r] = 0.f;
-      em1[r] = 0.f;
-    }
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const v4f t0 = *reinterpret_cast<const v4f*>(tb + n * 64 + 8 * q);
-        const v4f t1 = *reinterpret_cast<const v4f*>(tb + n * 64 + 32 + 8 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          em0[4 * q + i] += basis[n] * t0[i];
-          em1[4 * q + i] += basis[n] * t1[i];
+          for (int i = 0; i < 4; ++i) {
+            em0[4 * q + i] += basis[n] * t0[i];
+            em1[4 * q + i] += basis[n] * t1[i];
+          }
         }
       }
     }
-  }
-  const int64_t row0 = beg;
-  v16f k0, k1, sc0, sc1;
-  // ---- L0: scalar_embed_mlp layer 0 (pre-activation kept for the reverse pass)
-  fused_layer<2, 2>(c, A.L[0], A.L[1], false,
-                    [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
-                    [&](auto, const v16f& a0, const v16f& a1) {
-                      fused_store_tile(sW, a0, A.se_h, row0, cnt, 64, lane);
-                      fused_store_tile(sW, a1, A.se_h + 32, row0, cnt, 64, lane);
-                      keep_tile<true>(a0, k0);
-                      keep_tile<true>(a1, k1);
-                    });
-  // ---- L1: scalar_embed_mlp layer 1 -> EDGE_EMBEDDING
-  fused_layer<2, 2>(c, A.L[1], A.L[2], false,
-                    [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-                    [&](auto, const v16f& a0, const v16f& a1) {
-                      fused_store_tile(sW, a0, A.emb, row0, cnt, 64, lane);
-                      fused_store_tile(sW, a1, A.emb + 32, row0, cnt, 64, lane);
-                      em0 = a0;
-                      em1 = a1;
-                    });
-  // ---- per-atom part of layer 0: moments of the embedding -> x2s0 -> B0 = Sig0^T_x1(e_0, x2s0)
-  float wp0[Sig0::P], wp1[Sig1::P];
+    v16f k0, k1, sc0, sc1;
+    v16f w0t[HOLD ? 2 * R : 1];
+    AA_TICK(2)
+    // ---- L0: scalar_embed_mlp layer 0 (pre-activation kept for the reverse pass)
+    fused_layer<S_L0, NS, 2, 2>(A, p,
+                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
+                                [&](auto, const v16f& a0, const v16f& a1) {
+                                  fused_store_tile(sW, a0, A.se_h, row0, cnt, 64, lane);
+                                  fused_store_tile(sW, a1, A.se_h + 32, row0, cnt, 64, lane);
+                                  keep_tile<true>(a0, k0);
+                                  keep_tile<true>(a1, k1);
+                                });
+    AA_TICK(3)
+    // ---- L1: scalar_embed_mlp layer 1 -> EDGE_EMBEDDING
+    fused_layer<S_L1, NS, 2, 2>(A, p,
+                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+                                [&](auto, const v16f& a0, const v16f& a1) {
+                                  fused_store_tile(sW, a0, A.emb, row0, cnt, 64, lane);
+                                  fused_store_tile(sW, a1, A.emb + 32, row0, cnt, 64, lane);
+                                  em0 = a0;
+                                  em1 = a1;
+                                });
+    AA_TICK(4)
+    // ---- per-atom part of layer 0: moments of the embedding -> x2s0 -> B0 = Sig0^T_x1(e_0, x2s0)
+    float x2s0[D];
+    {
+      float M[D];
+      tile_moments<D>(sW, sY, em0, em1, lane, M);
+      project_moments<S_P0, NS, D, R>(A, p, sW, M, A.sf, x2s0);
+      if (atom_ok) {
 #pragma unroll
-  for (int p = 0; p < Sig0::P; ++p) wp0[p] = A.coupling ? A.tpw0[lane * Sig0::P + p] : A.tpw0[p];
+        for (int j = 0; j < D; ++j) A.x2s0[(atom * D + j) * 64 + lane] = x2s0[j];
+      }
+      float e0[D], B0[D];
 #pragma unroll
-  for (int p = 0; p < Sig1::P; ++p) wp1[p] = A.coupling ? A.tpw1[lane * Sig1::P + p] : A.tpw1[p];
-  float x2s0[D];
-  {
-    float M[D];
-    tile_moments<D>(sW, sY, em0, em1, lane, M);
-    project_moments<D, R>(sW, M, A.wk0, A.sf, lane, x2s0);
-    if (atom_ok) {
+      for (int k = 0; k < D; ++k) e0[k] = k == 0 ? 1.f : 0.f;
+      Sig0::template bx1<float>(e0, x2s0, wp0, B0);
 #pragma unroll
-      for (int j = 0; j < D; ++j) A.x2s0[(atom * D + j) * 64 + lane] = x2s0[j];
+      for (int a = 0; a < D; ++a) sBv[a * 64 + lane] = B0[a];
+      __builtin_amdgcn_wave_barrier();
     }
-    float e0[D], B0[D];
+    AA_TICK(5)
+    // ---- L2: [two-body scalars | w0 irrep 0 | irrep 1 | ...] = emb @ [first_proj[:, :S] | env_embed_linear]; the
+    //          layer-0 tensor-track scalars are accumulated as each irrep's tile pair comes out
 #pragma unroll
-    for (int k = 0; k < D; ++k) e0[k] = k == 0 ? 1.f : 0.f;
-    Sig0::template bx1<float>(e0, x2s0, wp0, B0);
-#pragma unroll
-    for (int a = 0; a < D; ++a) sBv[a * 64 + lane] = B0[a];
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- L2: [two-body scalars | w0 irrep 0 | irrep 1 | ...] = emb @ [first_proj[:, :S] | env_embed_linear]; the
-  //          layer-0 tensor-track scalars are accumulated as each irrep's tile pair comes out
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    sc0[r] = 0.f;
-    sc1[r] = 0.f;
-  }
-  fused_layer<2, 2 + 2 * R>(c, A.L[2], A.L[3], false,
-                            [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
-                            [&](auto ntp, const v16f& a0, const v16f& a1) {
-                              constexpr int p = decltype(ntp)::value;
-                              if constexpr (p == 0) {
-                                park_tile(sPark, a0, lane);
-                                park_tile(sPark + kTileFloats, a1, lane);
-                                if (A.fcat) {
-                                  fused_store_tile(sW, a0, A.fcat, row0, cnt, 192, lane);
-                                  fused_store_tile(sW, a1, A.fcat + 32, row0, cnt, 192, lane);
-                                }
-                              } else {
-                                if (A.w0) {
-                                  fused_store_tile(sW, a0, A.w0 + (p - 1) * 64, row0, cnt, 64 * R, lane);
-                                  fused_store_tile(sW, a1, A.w0 + (p - 1) * 64 + 32, row0, cnt, 64 * R, lane);
-                                }
-                                scal_accumulate<p - 1>(sBv, Y, a0, a1, hh, sc0, sc1);
-                              }
-                            });
-  // ---- L3: latent 0, hidden layer: [two-body | scal0] -> h (pre-activation stored), a1 = silu(h)
-  fused_layer<4, 2>(c, A.L[3], A.L[4], false,
-                    [&](auto kc) -> v16f {
-                      constexpr int k = decltype(kc)::value;
-                      if constexpr (k < 2) return fetch_tile(sPark + k * kTileFloats, lane); else if constexpr (k == 2) return sc0; else return sc1;
-                    },
-                    [&](auto, const v16f& a0, const v16f& a1) {
-                      fused_store_tile(sW, a0, A.lat_h0, row0, cnt, 64, lane);
-                      fused_store_tile(sW, a1, A.lat_h0 + 32, row0, cnt, 64, lane);
-                      keep_tile<true>(a0, k0);
-                      keep_tile<true>(a1, k1);
-                    });
-  // ---- per-atom part of layer 1: moments of a1 -> x2s1 -> v = dSig1/dtf1 (x2s1) -> B1 = Sig0^T_x1(v, x2s0)
-  {
-    float M[D], x2s1[D];
-    tile_moments<D>(sW, sY, k0, k1, lane, M);
-    project_moments<D, R>(sW, M, A.wk1, A.sf, lane, x2s1);
-    if (atom_ok) {
-#pragma unroll
-      for (int j = 0; j < D; ++j) A.x2s1[(atom * D + j) * 64 + lane] = x2s1[j];
+    for (int r = 0; r < 16; ++r) {
+      sc0[r] = 0.f;
+      sc1[r] = 0.f;
     }
-    float one[1] = {1.f}, v[D], B1[D];
-    Sig1::template bx1<float>(one, x2s1, wp1, v);
-    Sig0::template bx1<float>(v, x2s0, wp0, B1);
+    fused_layer<S_L2, NS, 2, 2 + 2 * R>(A, p,
+                                        [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
+                                        [&](auto ntp, const v16f& a0, const v16f& a1) {
+                                          constexpr int q = decltype(ntp)::value;
+                                          if constexpr (q == 0) {
+                                            AA_PARK(0, a0);
+                                            AA_PARK(1, a1);
+                                            if (A.fcat) {
+                                              fused_store_tile(sW, a0, A.fcat, row0, cnt, 192, lane);
+                                              fused_store_tile(sW, a1, A.fcat + 32, row0, cnt, 192, lane);
+                                            }
+                                          } else {
+                                            if (A.w0) {
+                                              fused_store_tile(sW, a0, A.w0 + (q - 1) * 64, row0, cnt, 64 * R, lane);
+                                              fused_store_tile(sW, a1, A.w0 + (q - 1) * 64 + 32, row0, cnt, 64 * R, lane);
+                                            }
+                                            scal_accumulate<q - 1>(sBv, Y, a0, a1, hh, sc0, sc1);
+                                            if constexpr (HOLD) {
+                                              w0t[2 * (q - 1)] = a0;
+                                              w0t[2 * (q - 1) + 1] = a1;
+                                            }
+                                          }
+                                        });
+    AA_TICK(6)
+    // ---- L3: latent 0, hidden layer: [two-body | scal0] -> h (pre-activation stored), a1 = silu(h)
+    fused_layer<S_L3, NS, 4, 2>(A, p,
+                                [&](auto kc) -> v16f {
+                                  constexpr int k = decltype(kc)::value;
+                                  if constexpr (k < 2) return AA_FETCH(k); else if constexpr (k == 2) return sc0; else return sc1;
+                                },
+                                [&](auto, const v16f& a0, const v16f& a1) {
+                                  fused_store_tile(sW, a0, A.lat_h0, row0, cnt, 64, lane);
+                                  fused_store_tile(sW, a1, A.lat_h0 + 32, row0, cnt, 64, lane);
+                                  keep_tile<true>(a0, k0);
+                                  keep_tile<true>(a1, k1);
+                                });
+    AA_TICK(7)
+    // ---- per-atom part of layer 1: moments of a1 -> x2s1 -> v = dSig1/dtf1 (x2s1) -> B1 = Sig0^T_x1(v, x2s0)
+    {
+      float M[D], x2s1[D];
+      tile_moments<D>(sW, sY, k0, k1, lane, M);
+      project_moments<S_P1, NS, D, R>(A, p, sW, M, A.sf, x2s1);
+      if (atom_ok) {
 #pragma unroll
-    for (int a = 0; a < D; ++a) sBv[a * 64 + lane] = B1[a];
-    __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < D; ++j) A.x2s1[(atom * D + j) * 64 + lane] = x2s1[j];
+      }
+      float one[1] = {1.f}, v[D], B1[D];
+      Sig1::template bx1<float>(one, x2s1, wp1, v);
+      Sig0::template bx1<float>(v, x2s0, wp0, B1);
+#pragma unroll
+      for (int a = 0; a < D; ++a) sBv[a * 64 + lane] = B1[a];
+      __builtin_amdgcn_wave_barrier();
+    }
+    AA_TICK(8)
+    // ---- L4: latent 0, output layer -> lat0
+    fused_layer<S_L4, NS, 2, 2>(A, p,
+                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+                                [&](auto, const v16f& a0, const v16f& a1) {
+                                  AA_PARK(2, a0);
+                                  AA_PARK(3, a1);
+                                  if (A.fcat) {
+                                    fused_store_tile(sW, a0, A.fcat + 64, row0, cnt, 192, lane);
+                                    fused_store_tile(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
+                                  }
+                                });
+#ifndef AA_EXP_NOGEO
+    // inputs of the next tile (its neighbor ids arrived long ago): positions, shifts, types
+    load_geo(atom_of(it + 1), nxt);
+#endif
+    AA_TICK(9)
+    // ---- L5: layer-1 scalars with B1 -- from the held w0 tiles, or from w0 recomputed out of the embedding
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc0[r] = 0.f;
+      sc1[r] = 0.f;
+    }
+    if constexpr (HOLD) {
+      static_for<0, R>([&](auto rr) {
+        scal_accumulate<decltype(rr)::value>(sBv, Y, w0t[2 * decltype(rr)::value], w0t[2 * decltype(rr)::value + 1], hh, sc0, sc1);
+      });
+    } else {
+      fused_layer<S_L5, NS, 2, 2 * R>(A, p,
+                                      [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
+                                      [&](auto ntp, const v16f& a0, const v16f& a1) {
+                                        scal_accumulate<decltype(ntp)::value>(sBv, Y, a0, a1, hh, sc0, sc1);
+                                      });
+    }
+    AA_TICK(10)
+    // ---- L6: latent 1, hidden layer: [two-body | lat0 | scal1]
+    fused_layer<S_L6, NS, 6, 2>(A, p,
+                                [&](auto kc) -> v16f {
+                                  constexpr int k = decltype(kc)::value;
+                                  if constexpr (k < 4) return AA_FETCH(k); else if constexpr (k == 4) return sc0; else return sc1;
+                                },
+                                [&](auto, const v16f& a0, const v16f& a1) {
+                                  fused_store_tile(sW, a0, A.lat_h1, row0, cnt, 64, lane);
+                                  fused_store_tile(sW, a1, A.lat_h1 + 32, row0, cnt, 64, lane);
+                                  keep_tile<true>(a0, k0);
+                                  keep_tile<true>(a1, k1);
+                                });
+    AA_TICK(11)
+    // ---- L7: latent 1, output layer -> lat1
+    fused_layer<S_L7, NS, 2, 2>(A, p,
+                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+                                [&](auto, const v16f& a0, const v16f& a1) {
+                                  k0 = a0;
+                                  k1 = a1;
+                                  if (A.fcat) {
+                                    fused_store_tile(sW, a0, A.fcat + 128, row0, cnt, 192, lane);
+                                    fused_store_tile(sW, a1, A.fcat + 160, row0, cnt, 192, lane);
+                                  }
+                                });
+    AA_TICK(12)
+    // ---- L8: edge readout hidden layer on [two-body | lat0 | lat1]; last linear layer + edge sum in the epilogue
+    fused_layer<S_L8, NS, 6, 2>(A, p,
+                                [&](auto kc) -> v16f {
+                                  constexpr int k = decltype(kc)::value;
+                                  if constexpr (k < 4) return AA_FETCH(k); else if constexpr (k == 4) return k0; else return k1;
+                                },
+                                [&](auto, const v16f& a0, const v16f& a1) {
+                                  fused_store_tile(sW, a0, A.ro_h, row0, cnt, 64, lane);
+                                  fused_store_tile(sW, a1, A.ro_h + 32, row0, cnt, 64, lane);
+                                  float part = 0.f;
+#pragma unroll
+                                  for (int q = 0; q < 4; ++q) {
+                                    const v4f w0v = *reinterpret_cast<const v4f*>(sRo + 8 * q + 4 * hh);
+                                    const v4f w1v = *reinterpret_cast<const v4f*>(sRo + 32 + 8 * q + 4 * hh);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) part += silu(a0[4 * q + i]) * w0v[i] + silu(a1[4 * q + i]) * w1v[i];
+                                  }
+                                  // E_i = scale_t * factor * sum over the rows of the segment (each lane half holds half a row) + shift_t
+                                  float tot = row_ok ? part : 0.f;
+#pragma unroll
+                                  for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
+                                  if (atom_ok && lane == 0) {
+                                    float en = tot * A.ro_factor;
+                                    const int t = A.types[atom];
+                                    if (A.scales) en *= A.scales[t];
+                                    if (A.shifts) en += A.shifts[t];
+                                    A.atom_energy[atom] = en;
+                                  }
+                                });
+    AA_TICK(13)
+    // rotate the prefetched inputs
+#ifdef AA_EXP_NOGEO
+    cur.beg = nxt.beg;
+    cur.cnt = nxt.cnt;
+    cur.j = nxt.j;
+    load_geo(atom_of(it + 1), cur);
+#else
+    cur = nxt;
+#endif
+    nxt.beg = beg2;
+    nxt.cnt = cnt2;
   }
-  // ---- L4: latent 0, output layer -> lat0
-  fused_layer<2, 2>(c, A.L[4], A.L[5], false,
-                    [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-                    [&](auto, const v16f& a0, const v16f& a1) {
-                      park_tile(sPark + 2 * kTileFloats, a0, lane);
-                      park_tile(sPark + 3 * kTileFloats, a1, lane);
-                      if (A.fcat) {
-                        fused_store_tile(sW, a0, A.fcat + 64, row0, cnt, 192, lane);
-                        fused_store_tile(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
-                      }
-                    });
-  // ---- L5: w0 again (recomputed from the embedding still held in registers) -> layer-1 scalars with B1
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    sc0[r] = 0.f;
-    sc1[r] = 0.f;
-  }
-  fused_layer<2, 2 * R>(c, A.L[5], A.L[6], false,
-                        [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
-                        [&](auto ntp, const v16f& a0, const v16f& a1) {
-                          scal_accumulate<decltype(ntp)::value>(sBv, Y, a0, a1, hh, sc0, sc1);
-                        });
-  // ---- L6: latent 1, hidden layer: [two-body | lat0 | scal1]
-  fused_layer<6, 2>(c, A.L[6], A.L[7], false,
-                    [&](auto kc) -> v16f {
-                      constexpr int k = decltype(kc)::value;
-                      if constexpr (k < 4) return fetch_tile(sPark + k * kTileFloats, lane); else if constexpr (k == 4) return sc0; else return sc1;
-                    },
-                    [&](auto, const v16f& a0, const v16f& a1) {
-                      fused_store_tile(sW, a0, A.lat_h1, row0, cnt, 64, lane);
-                      fused_store_tile(sW, a1, A.lat_h1 + 32, row0, cnt, 64, lane);
-                      keep_tile<true>(a0, k0);
-                      keep_tile<true>(a1, k1);
-                    });
-  // ---- L7: latent 1, output layer -> lat1
-  fused_layer<2, 2>(c, A.L[7], A.L[8], false,
-                    [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-                    [&](auto, const v16f& a0, const v16f& a1) {
-                      k0 = a0;
-                      k1 = a1;
-                      if (A.fcat) {
-                        fused_store_tile(sW, a0, A.fcat + 128, row0, cnt, 192, lane);
-                        fused_store_tile(sW, a1, A.fcat + 160, row0, cnt, 192, lane);
-                      }
-                    });
-  // ---- L8: edge readout hidden layer on [two-body | lat0 | lat1]; last linear layer + edge sum in the epilogue
-  fused_layer<6, 2>(c, A.L[8], A.L[8], true,
-                    [&](auto kc) -> v16f {
-                      constexpr int k = decltype(kc)::value;
-                      if constexpr (k < 4) return fetch_tile(sPark + k * kTileFloats, lane); else if constexpr (k == 4) return k0; else return k1;
-                    },
-                    [&](auto, const v16f& a0, const v16f& a1) {
-                      fused_store_tile(sW, a0, A.ro_h, row0, cnt, 64, lane);
-                      fused_store_tile(sW, a1, A.ro_h + 32, row0, cnt, 64, lane);
-                      float part = 0.f;
-#pragma unroll
-                      for (int q = 0; q < 4; ++q) {
-                        const v4f w0v = *reinterpret_cast<const v4f*>(sRo + 8 * q + 4 * hh);
-                        const v4f w1v = *reinterpret_cast<const v4f*>(sRo + 32 + 8 * q + 4 * hh);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) part += silu(a0[4 * q + i]) * w0v[i] + silu(a1[4 * q + i]) * w1v[i];
-                      }
-                      // E_i = scale_t * factor * sum_{rows of the segment} (both lane halves of a row hold half of it) + shift_t
-                      float tot = row_ok ? part : 0.f;
-#pragma unroll
-                      for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
-                      if (atom_ok && lane == 0) {
-                        float en = tot * A.ro_factor;
-                        const int t = A.types[atom];
-                        if (A.scales) en *= A.scales[t];
-                        if (A.shifts) en += A.shifts[t];
-                        A.atom_energy[atom] = en;
-                      }
-                    });
 }
 
 // atoms outside the block the fused kernel covers (other ranks' blocks of an atom partition): E_i = shift_t
@@ -625,10 +754,13 @@ __global__ __launch_bounds__(256) void fused_fill_energy_kernel(int64_t N, int64
 
 size_t fused_fwd_lds_bytes(int num_types) {
   return sizeof(u32x4) * 2 * kWStep +
-         sizeof(float) * (64 + size_t(num_types) * num_types * 512 + 4 * (kWaveRegion + 32 * kLdY) + 4 * 4 * kTileFloats);
+         sizeof(float) * (64 + 16 + size_t(num_types) * num_types * 512 + 4 * (kWaveRegion + 32 * kLdY) + (kFusedOcc == 1 ? 4 * 4 * kTileFloats : 0));
 }
 
-int launch_fused_fwd(int pair, const FusedFwdArgs& a, hipStream_t stream) {
+// number of weight-pipeline steps of the program for R irreps (see the kernel)
+int fused_fwd_num_steps(int R, bool hold) { return 8 + (2 + 2 * R) + 4 + 4 + 2 + (hold ? 0 : 2 * R) + 6 + 2 + 6; }
+
+int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;
   const size_t smem = fused_fwd_lds_bytes(a.num_types);
   if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "fused forward: LDS budget exceeded");
@@ -636,24 +768,55 @@ int launch_fused_fwd(int pair, const FusedFwdArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(fused_fill_energy_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, stream, a.N, a.atom0, a.atom_end,
                        a.types, a.shifts, a.atom_energy);
   }
-  dim3 grid((unsigned)((a.atom_end - a.atom0 + 3) / 4));
-  switch (pair) {
-    case 0: {
-      const void* fn = (const void*)fused_fwd_kernel<cg::Sig1, cg::Sig0>;
-      AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-      hipLaunchKernelGGL((fused_fwd_kernel<cg::Sig1, cg::Sig0>), grid, dim3(256), smem, stream, a);
-      break;
-    }
-    case 1: {
-      const void* fn = (const void*)fused_fwd_kernel<cg::Sig5, cg::Sig4>;
-      AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-      hipLaunchKernelGGL((fused_fwd_kernel<cg::Sig5, cg::Sig4>), grid, dim3(256), smem, stream, a);
-      break;
-    }
-    default:
-      return fail(AA_ERR_INVALID, "fused forward: unsupported signature pair");
+  // persistent: one workgroup per CU (the kernel needs the whole register file and most of the LDS of a CU)
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0, n = 0;
+    AA_CHECK_HIP(hipGetDevice(&dev));
+    AA_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    num_cu = n > 0 ? n : 256;
   }
+  const int64_t ngroups = (a.atom_end - a.atom0 + 3) / 4;
+  dim3 grid((unsigned)std::min<int64_t>(ngroups, int64_t(num_cu) * kFusedOcc));
+#define AA_FUSED_LAUNCH(S0_, S1_, H_)                                                                          \
+  {                                                                                                            \
+    const void* fn = (const void*)fused_fwd_kernel<cg::S0_, cg::S1_, H_>;                                      \
+    AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));              \
+    hipLaunchKernelGGL((fused_fwd_kernel<cg::S0_, cg::S1_, H_>), grid, dim3(256), smem, stream, a);            \
+  }
+#ifdef AA_EXP_ONE
+  if (pair == 1 && !hold_w0) {
+    AA_FUSED_LAUNCH(Sig5, Sig4, false)
+  } else if (pair == 1) {
+    AA_FUSED_LAUNCH(Sig5, Sig4, true)
+  } else {
+    return fail(AA_ERR_INVALID, "experiment build");
+  }
+  if (false) {
+#else
+  if (pair == 0) {
+    if (hold_w0) AA_FUSED_LAUNCH(Sig1, Sig0, true) else AA_FUSED_LAUNCH(Sig1, Sig0, false)
+  } else if (pair == 1) {
+    if (hold_w0) AA_FUSED_LAUNCH(Sig5, Sig4, true) else AA_FUSED_LAUNCH(Sig5, Sig4, false)
+#endif
+  } else {
+    return fail(AA_ERR_INVALID, "fused forward: unsupported signature pair");
+  }
+#undef AA_FUSED_LAUNCH
   AA_CHECK_HIP(hipGetLastError());
+#ifdef AA_FUSED_TIMING
+  {
+    static int calls = 0;
+    if (++calls == 8) {  // a warm call
+      unsigned long long t[32];
+      AA_CHECK_HIP(hipStreamSynchronize(stream));
+      AA_CHECK_HIP(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_fused_ticks), sizeof(t)));
+      static const char* nm[13] = {"geometry", "emb0", "L0", "L1", "TPA0", "L2", "L3", "TPA1", "L4", "L5", "L6", "L7", "L8"};
+      for (int i = 0; i < 13; ++i) fprintf(stderr, "[fused timing] %-16s %8llu cycles\n", nm[i], t[i + 1] - t[i]);
+      fprintf(stderr, "[fused timing] %-16s %8llu cycles\n", "total", t[13] - t[0]);
+    }
+  }
+#endif
   return AA_OK;
 }
 

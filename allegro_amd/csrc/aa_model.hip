@@ -145,6 +145,7 @@ struct aa_model_plan {
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
+  bool fused_hold_w0;                // ... holding the w0 tiles in registers between the two layers (else: recomputed)
   mutable bool taps = false;         // aa_model_plan_enable_taps: staged pipeline so that every tap is materialised
   bool embed_fused;                  // reverse pass: d(two-body embedding) [E,S0] never materialised, the last reverse chain
                                      // contracts it back to the 8 basis functions in its epilogue (embrev_out in aa_common.h)
@@ -324,10 +325,15 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_shifts = take(T);
   p->n_elems = o;
   {
-    // fused per-atom-tile forward: the standard 2-layer 64-wide fp32 stack with the two-body table in LDS
-    const char* nf = getenv("AA_NOFUSE");
+    // fused per-atom-tile forward (aa_fused.hip): the standard 2-layer 64-wide fp32 stack with the two-body table in
+    // LDS.  OPT-IN (AA_FUSED=1): correct (same parity tests as the staged pipeline) but measured SLOWER than the staged
+    // forward on MI355X -- 6.3-8.7 ms vs 5.5 ms at C4 -- because its register / LDS footprint allows one wave per
+    // SIMD only and a single wave cannot hide its own LDS / MFMA / L2 latencies (profiles/r02_v5_*)
+    const char* fu = getenv("AA_FUSED");
     p->fused_fwd = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 && !(nf && nf[0] == '1');
+                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 && (fu && fu[0] == '1');
+    const char* rc = getenv("AA_FUSED_RECOMPUTE");  // A/B: recompute w0 for the second layer instead of holding it
+    p->fused_hold_w0 = !(rc && rc[0] == '1');
   }
   *out = p;
   return AA_OK;
@@ -991,18 +997,36 @@ struct Runner {
     a.rmax_recip = wf(p->o_rmax);
     a.bessel_w = wf(p->o_bessel);
     a.emb_tab = wf(p->o_embtab);
-    const size_t tile_words = size_t(2) * 64 * 24;  // one output tile of a K = 64 matrix (2 chunks), 32-bit words
-    a.L[0] = FusedLayerDev{wf(p->embed.wq[0]), 2};
-    a.L[1] = FusedLayerDev{wf(p->embed.wq[1]), 2};
-    a.L[2] = FusedLayerDev{wf(p->o_g0q), 2};
-    a.L[3] = FusedLayerDev{wf(p->latent[0].wq[0]), 4};
-    a.L[4] = FusedLayerDev{wf(p->latent[0].wq[1]), 2};
-    a.L[5] = FusedLayerDev{wf(p->o_g0q) + 2 * tile_words, 2};  // the w0 columns of the same matrix
-    a.L[6] = FusedLayerDev{wf(p->latent[1].wq[0]), 6};
-    a.L[7] = FusedLayerDev{wf(p->latent[1].wq[1]), 2};
-    a.L[8] = FusedLayerDev{wf(p->readout.wq[0]), 6};
-    a.wk0 = wf(p->o_wk[0]);
-    a.wk1 = wf(p->o_wk[1]);
+    // the weight program of the kernel (see fused_fwd_kernel): 12-KB blocks in execution order
+    int ns = 0;
+    auto add_layer = [&](const float* Wq, int KC, int tile0, int ntiles) {
+      for (int t = tile0; t < tile0 + ntiles; t += 2)
+        for (int kc = 0; kc < KC; ++kc) {
+          a.wstep[ns][0] = Wq + (size_t(t) * KC + kc) * 64 * 24;
+          a.wstep[ns][1] = Wq + (size_t(t + 1) * KC + kc) * 64 * 24;
+          ++ns;
+        }
+    };
+    auto add_env = [&](const float* Wk) {
+      for (int cblk = 0; cblk < 4; ++cblk) {
+        a.wstep[ns][0] = Wk + size_t(cblk) * 16 * p->R * 64;
+        a.wstep[ns][1] = Wk + size_t(cblk) * 16 * p->R * 64 + 1536;  // (blocks are loaded as 2 x 6 KB; 16 R 256 B are used)
+        ++ns;
+      }
+    };
+    const bool hold = p->fused_hold_w0;
+    add_layer(wf(p->embed.wq[0]), 2, 0, 2);
+    add_layer(wf(p->embed.wq[1]), 2, 0, 2);
+    add_env(wf(p->o_wk[0]));
+    add_layer(wf(p->o_g0q), 2, 0, 2 + 2 * p->R);
+    add_layer(wf(p->latent[0].wq[0]), 4, 0, 2);
+    add_env(wf(p->o_wk[1]));
+    add_layer(wf(p->latent[0].wq[1]), 2, 0, 2);
+    if (!hold) add_layer(wf(p->o_g0q), 2, 2, 2 * p->R);  // the w0 columns of the first-stage matrix again
+    add_layer(wf(p->latent[1].wq[0]), 6, 0, 2);
+    add_layer(wf(p->latent[1].wq[1]), 2, 0, 2);
+    add_layer(wf(p->readout.wq[0]), 6, 0, 2);
+    if (ns != fused_fwd_num_steps(p->R, hold) || ns > kFusedMaxSteps) return fail(AA_ERR_INVALID, "fused forward: program length mismatch");
     a.tpw0 = wf(p->o_tpw[0]);
     a.tpw1 = wf(p->o_tpw[1]);
     a.coupling = c.tps[0].coupling;
@@ -1024,7 +1048,7 @@ struct Runner {
     a.x2s1 = bf(w.x2s[1]);
     a.atom_energy = static_cast<float*>(atom_energy);
     if (int rc = mark("begin")) return rc;
-    if (int rc = launch_fused_fwd(p->chain_pair, a, stream)) return rc;
+    if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
     // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;
     // position, two x2s blocks, energy, row pointer per atom.  Flops: the linear layers of the forward (w0 counted once).
     const double per_edge = 1 + (g->shift_vec ? 3 : 0) + 3 + 4 + p->D + 5 * 64 + p->W;

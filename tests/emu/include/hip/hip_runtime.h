@@ -73,6 +73,9 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+constexpr int hipDeviceAttributeMultiprocessorCount = 0;
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 3; return 0; }  // a few "CUs": persistent kernels loop
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 
 namespace emu {
@@ -233,6 +236,8 @@ inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_barrier() { emu::yield_block_barrier(); }
+#define __builtin_amdgcn_fence(...) ((void)0)  // (address-space scoped fences around a raw s_barrier)
 inline void __builtin_amdgcn_wave_barrier() { emu::wave_rendezvous(); }  // fibers of a wave run one after another here
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on wave-uniform values
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }

@@ -4,7 +4,8 @@ stack in one launch, one wave per center atom's edge tile.
 CPU: the unmodified kernel source in the test-only emulation build, against the reference's golden vectors, against
 the fp64 oracle on ragged graphs (partial tiles, an atom without edges, two species, per-type scale/shift), and on
 atom-block sub-ranges (the multi-GPU partition).  GPU: the same checks on hardware plus the staged pipeline as A/B.
-The fused path is selected by `aa_graph.max_degree <= 32`; larger segments must fall back to the staged pipeline."""
+The fused path needs `aa_graph.max_degree <= 32` (larger segments fall back to the staged pipeline) and is opt-in
+(AA_FUSED=1): on MI355X it is correct but slower than the staged forward -- see DESIGN.md section 9 for the measurements."""
 import numpy as np
 import pytest
 import torch
@@ -13,6 +14,13 @@ from allegro_amd import graph as G
 from allegro_amd.nn import HipAllegroModel
 from tests.golden_utils import load_model_fixture
 from tests.hip_utils import emu_lib, fixture_data, model_from_fixture
+
+
+@pytest.fixture(autouse=True)
+def _opt_in(monkeypatch):
+    """The fused path is opt-in (measured slower than the staged forward on MI355X): read when the plan
+    is created, i.e. at the first step of a model."""
+    monkeypatch.setenv("AA_FUSED", "1")
 
 
 def _cfg(embed="bessel", coupling=True, l_max=2, seed=11, avg=9.0, scale_shift=True):
@@ -151,15 +159,15 @@ def test_fused_forward_ragged_graph_vs_fp64_oracle_on_gpu(embed, coupling, l_max
 
 @pytest.mark.gpu
 def test_fused_and_staged_forward_agree_on_gpu(monkeypatch):
-    """A/B on hardware: the same model and graph through the fused kernel and through the staged pipeline
-    (AA_NOFUSE=1 at plan creation)."""
+    """A/B on hardware: the same model and graph through the fused kernel (AA_FUSED=1 at plan creation) and through
+    the staged pipeline."""
     dev = torch.device("cuda:0")
     fx = load_model_fixture("c2", torch.float32)
     data, sv = fixture_data(fx, torch.float32, dev)
     m = model_from_fixture(fx, torch.float32, device=dev)
     g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
     e, f = m.energy_forces(data["pos"], g)
-    monkeypatch.setenv("AA_NOFUSE", "1")
+    monkeypatch.delenv("AA_FUSED")
     m2 = model_from_fixture(fx, torch.float32, device=dev)
     e2, f2 = m2.energy_forces(data["pos"], g)
     assert (e - e2).abs().max().item() < 5e-6 and (f - f2).abs().max().item() < 2e-5
