@@ -32,7 +32,8 @@ class ModelConfig(C.Structure):
                 ("readout_mlp_depth", C.c_int32), ("readout_mlp_width", C.c_int32),
                 ("forward_weight_init", C.c_int32), ("avg_num_neighbors", C.c_double), ("act_const", C.c_double),
                 ("has_scales", C.c_int32), ("has_shifts", C.c_int32), ("tps", TpDesc * AA_MAX_LAYERS),
-                ("embed_kind", C.c_int32), ("spline_span", C.c_int32)]
+                ("embed_kind", C.c_int32), ("spline_span", C.c_int32), ("env_shared_weights", C.c_int32),
+                ("act_kind", C.c_int32 * 3), ("act_consts", C.c_double * 3)]
 
 
 class RawWeights(C.Structure):

@@ -97,6 +97,34 @@ __device__ __forceinline__ T dsilu(T x) {
   T s = sigmoid_(x);
   return s * (T(1) + x * (T(1) - s));
 }
+// Activation by kind (aa_model_config.act_kind): 0 silu, 1 mish, 2 gelu (erf), 3 identity.  Only the general (VALU)
+// linear-layer kernels and the readout kernels take a kind; every fused fast path is SiLU-only and the plan falls
+// back to the general kernels for the other nonlinearities of the reference (allegro_models.py:49-60).
+enum { AA_ACT_SILU = 0, AA_ACT_MISH = 1, AA_ACT_GELU = 2, AA_ACT_NONE = 3 };
+template <typename T>
+__device__ __forceinline__ T act_apply(int kind, T x) {
+  if (kind == AA_ACT_SILU) return silu(x);
+  if (kind == AA_ACT_NONE) return x;
+  const double xd = double(x);
+  if (kind == AA_ACT_MISH) {
+    const double sp = xd > 30.0 ? xd : log1p(exp(xd));  // softplus
+    return T(xd * tanh(sp));
+  }
+  return T(0.5 * xd * (1.0 + erf(xd * 0.70710678118654752440)));
+}
+template <typename T>
+__device__ __forceinline__ T act_grad(int kind, T x) {
+  if (kind == AA_ACT_SILU) return dsilu(x);
+  if (kind == AA_ACT_NONE) return T(1);
+  const double xd = double(x);
+  if (kind == AA_ACT_MISH) {
+    const double sp = xd > 30.0 ? xd : log1p(exp(xd));
+    const double t = tanh(sp), sg = 1.0 / (1.0 + exp(-xd));
+    return T(t + xd * (1.0 - t * t) * sg);
+  }
+  const double cdf = 0.5 * (1.0 + erf(xd * 0.70710678118654752440));
+  return T(cdf + xd * 0.39894228040143267794 * exp(-0.5 * xd * xd));
+}
 __device__ __forceinline__ float aa_sin(float x) { return sinf(x); }
 __device__ __forceinline__ double aa_sin(double x) { return sin(x); }
 __device__ __forceinline__ float aa_cos(float x) { return cosf(x); }
@@ -140,6 +168,7 @@ struct GemmArgs {
   int has_add;     // result += add (before the dsilu(z) factor); split like c
   SegList add;
   int force_kernel;  // 0: automatic; 1: native fp32-input MFMA kernel; 3: VALU kernel (aa_debug_gemm_f32 / A-B tests)
+  int act_kind;      // activation behind act_a / has_z (AA_ACT_*); anything but SiLU runs the general VALU kernel
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -542,6 +571,7 @@ struct ReadoutArgs {
   void* atom_energy;   // [N]
   void* g_h;           // bwd: [E,H] written
   const void* edge_sum;  // [E] or nullptr: per-edge values already contracted with w (then h/w/act are unused)
+  int act_kind;          // AA_ACT_* of the readout MLP (used when act != 0)
 };
 template <typename T>
 int launch_readout_reduce(const ReadoutArgs& a, hipStream_t stream);

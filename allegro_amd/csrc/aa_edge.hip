@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void readout_reduce_kernel(ReadoutArgs a) {
       T wc = w[c];
       for (int s = beg; s < end; ++s) {
         T h = static_cast<const T*>(a.h)[int64_t(s) * a.ld + c];
-        acc += (a.act ? silu(h) : h) * wc;
+        acc += (a.act ? act_apply(a.act_kind, h) : h) * wc;
       }
     }
   }
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void readout_backward_kernel(ReadoutArgs a) {
     int c = int(idx % a.H);
     T g = T(a.factor) * static_cast<const T*>(a.w)[c];
     if (a.scales) g *= static_cast<const T*>(a.scales)[a.types[a.center[e]]];
-    if (a.act) g *= dsilu(static_cast<const T*>(a.h)[e * a.ld + c]);
+    if (a.act) g *= act_grad(a.act_kind, static_cast<const T*>(a.h)[e * a.ld + c]);
     static_cast<T*>(a.g_h)[e * a.H + c] = g;
   }
 }

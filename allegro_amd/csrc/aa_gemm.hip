@@ -38,7 +38,7 @@ __device__ __forceinline__ void seg_store(const GemmArgs& g, int64_t row, int co
         if (g.has_add) v += static_cast<const T*>(g.add.s[s].p)[row * g.add.s[s].ld + c];
         if (g.has_z) {
           T z = static_cast<const T*>(g.z.s[s].p)[row * g.z.s[s].ld + c];
-          v *= dsilu(z);
+          v *= act_grad(g.act_kind, z);
         }
         T* p = static_cast<T*>(g.c.s[s].p) + row * g.c.s[s].ld + c;
         if (g.c_accum[s]) v += *p;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
       T v = T(0);
       if (gm < g.M && gk < g.K) {
         v = seg_load<T>(g.a, gm, gk);
-        if (g.act_a) v = silu(v);
+        if (g.act_a) v = act_apply(g.act_kind, v);
       }
       As[k * GV_LDA + m] = v;
     }
@@ -1485,7 +1485,7 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     const char* e = getenv("AA_GEMM_V1");
     v1_only = (e && e[0] == '1') ? 1 : 0;
   }
-  if (force_valu() || g.force_kernel == 3) {
+  if (force_valu() || g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
     size_t smem = sizeof(float) * (GV_BK * GV_LDA + GV_BK * GV_BN);
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
@@ -1553,7 +1553,7 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   for (int s2 = 0; s2 < g.a.count; ++s2)
     pipe_ok = pipe_ok && (g.a.s[s2].n % 16) == 0 && (g.a.s[s2].ld % 2) == 0 && (reinterpret_cast<uintptr_t>(g.a.s[s2].p) & 15) == 0;
   for (int s2 = 0; s2 < g.c.count; ++s2) pipe_ok = pipe_ok && (g.c.s[s2].n % 16) == 0;
-  if (force_valu()) {
+  if (force_valu() || g.act_kind != AA_ACT_SILU) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok) {
     dim3 grid6((unsigned)((g.M + G6_BM - 1) / G6_BM), (unsigned)((g.N + G6_BN - 1) / G6_BN));

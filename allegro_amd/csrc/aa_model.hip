@@ -181,6 +181,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   AA_REQUIRE(cfg && out, "aa_model_plan_create: null argument");
   AA_REQUIRE(cfg->dtype == AA_F32 || cfg->dtype == AA_F64, "model: bad dtype");
   AA_REQUIRE(cfg->l_max >= 1 && cfg->l_max <= 3, "model: l_max must be 1..3");
+  for (int i = 0; i < 3; ++i) AA_REQUIRE(cfg->act_kind[i] >= AA_ACT_SILU && cfg->act_kind[i] <= AA_ACT_NONE, "model: unknown nonlinearity");
   AA_REQUIRE(cfg->num_layers >= 1 && cfg->num_layers <= AA_MAX_LAYERS, "model: num_layers out of range");
   AA_REQUIRE(cfg->embed_mlp_depth + 1 <= AA_MAX_MLP_LAYERS && cfg->latent_mlp_depth + 1 <= AA_MAX_MLP_LAYERS &&
                  cfg->readout_mlp_depth + 1 <= AA_MAX_MLP_LAYERS,
@@ -224,7 +225,9 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     if (p->use_spec && L == 2 && !(nc && nc[0] == '1')) p->chain_pair = find_chain_pair(p->spec_sig[0], p->spec_sig[1]);
     const char* nm = getenv("AA_TP_NOMOM");
     const int Dsh = (cfg->l_max + 1) * (cfg->l_max + 1);
-    p->env_mom = p->chain_pair >= 0 && u == 64 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
+    // every fused fast path below has SiLU built in; the other nonlinearities run the general kernels
+    const bool all_silu = cfg->act_kind[0] == AA_ACT_SILU && cfg->act_kind[1] == AA_ACT_SILU && cfg->act_kind[2] == AA_ACT_SILU;
+    p->env_mom = all_silu && p->chain_pair >= 0 && u == 64 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
                  (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) &&
                  (cfg->dtype == AA_F32 ? 4 : 8) * 4 * Dsh * (std::max(S, cfg->latent_mlp_width) + 64 + 64) <= 160 * 1024 &&
                  !(nm && nm[0] == '1');
@@ -236,7 +239,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     const char* force_op = getenv("AA_TP_OP");
     bool sigs_ok = !(e && e[0] == '1');
     for (int l = 0; l < L; ++l) sigs_ok = sigs_ok && p->spec_sig[l] >= 0;
-    if (sigs_ok && L >= 2 && L <= 3 && (u % 64) == 0 && u <= 256 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
+    if (all_silu && sigs_ok && L >= 2 && L <= 3 && (u % 64) == 0 && u <= 256 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
         (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) && !(nm && nm[0] == '1') && !(no_op && no_op[0] == '1') &&
         (!p->env_mom || (force_op && force_op[0] == '1'))) {
       const int chain = find_op_chain(p->spec_sig, L);
@@ -369,8 +372,14 @@ extern "C" void aa_model_plan_destroy(aa_model_plan* plan) {
 extern "C" size_t aa_model_weights_bytes(const aa_model_plan* plan) { return plan ? plan->n_elems * plan->esize() : 0; }
 
 // alpha_i of nequip ScalarMLPFunction: c_prev / sqrt(fan_in | fan_out)
-static double mlp_alpha(const aa_model_config& c, int layer, int din, int dout) {
-  double norm = layer == 0 ? 1.0 : c.act_const;
+// `which`: 0 scalar_embed_mlp, 1 latent MLPs, 2 edge_readout (their nonlinearities may differ); linear maps pass -1
+static double act_const_of(const aa_model_config& c, int which) {
+  if (which < 0) return 1.0;
+  if (c.act_kind[which] == AA_ACT_NONE) return 1.0;
+  return c.act_consts[which] > 0 ? c.act_consts[which] : c.act_const;
+}
+static double mlp_alpha(const aa_model_config& c, int layer, int din, int dout, int which = -1) {
+  double norm = layer == 0 ? 1.0 : act_const_of(c, which);
   return norm / std::sqrt(double(c.forward_weight_init ? din : dout));
 }
 
@@ -402,18 +411,28 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     copy(p->o_nemb, raw->neighbor_embed, size_t(T) * S0 / 2, 1.0);
     copy(p->o_basis, raw->basis_linear, size_t(B) * S0, mlp_alpha(c, 0, B, S0));
   }
-  // env-weight columns: reference layout [u][R] (_channels.py:46-51); the specialised kernels want [R][u]
+  // env-weight columns: reference layout [u][R] (_channels.py:46-51); the specialised kernels want [R][u].
+  // With weight_individual_irreps=False the Allegro layers' env weights are [u] in the reference (_channels.py:29-31,
+  // 60-63: one weight per channel for all irreps): the packed matrices replicate that column for every irrep, which
+  // is the same linear map, so every kernel runs unchanged.  (The tensor-embedding weights w0 are always individual,
+  // tensorembed.py:76-81.)
   const int Rr = p->R;
-  auto env_col = [&](int q) { return p->use_spec ? (q % u) * Rr + q / u : q; };  // packed col q <- reference col
+  const bool shared = c.env_shared_weights != 0;
+  const int We = shared ? u : W;  // env-weight columns of first_proj / latent outputs in the state_dict
+  auto w0_col = [&](int q) { return p->use_spec ? (q % u) * Rr + q / u : q; };  // packed col q <- reference col
+  auto env_col = [&](int q) {
+    const int ch = p->use_spec ? q % u : q / Rr, r = p->use_spec ? q / u : q % Rr;
+    return shared ? ch : ch * Rr + r;
+  };
   // pack an MLP; if env_off >= 0 the LAST layer's columns [env_off, env_off+W) are env weights
   // raw_last_width: true column count of the LAST layer in the state_dict (>= packed width when the env columns
   // are split off for the moments path); alpha always follows the reference's full layer shape
-  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off, int raw_last_width = -1) -> bool {
+  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off, int which, int raw_last_width = -1) -> bool {
     for (int i = 0; i < nlayers; ++i) {
       if (!ws[i]) return false;
       int din = m.dims[i], dout = m.dims[i + 1];
       int raw_w = (i == nlayers - 1 && raw_last_width > 0) ? raw_last_width : dout;
-      double al = mlp_alpha(c, i, din, raw_w);
+      double al = mlp_alpha(c, i, din, raw_w, which);
       for (int r = 0; r < din; ++r)
         for (int q = 0; q < dout; ++q) {
           int src = q;
@@ -427,21 +446,21 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     }
     return true;
   };
-  AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1, -1), "pack: missing scalar_embed_mlp weights");
+  AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1, -1, 0), "pack: missing scalar_embed_mlp weights");
   {
     // fused first stage: [ two_body (first_proj[:, :S]) | w0 (env_embed_linear) | env_w0 (first_proj[:, S:]) ]
     // (moments path: the env_w0 columns are not part of the GEMM; they become Wenv of layer 0 below)
     const int NG = p->ng0;
-    double a_env = mlp_alpha(c, 0, S, W), a_proj = mlp_alpha(c, 0, S, S + W);
+    double a_env = mlp_alpha(c, 0, S, W), a_proj = mlp_alpha(c, 0, S, S + We);
     for (int r = 0; r < S; ++r)
       for (int q = 0; q < NG; ++q) {
         double v;
         if (q < S)
-          v = raw->first_proj[size_t(r) * (S + W) + q] * a_proj;
+          v = raw->first_proj[size_t(r) * (S + We) + q] * a_proj;
         else if (q < S + W)
-          v = raw->env_embed_linear[size_t(r) * W + env_col(q - S)] * a_env;
+          v = raw->env_embed_linear[size_t(r) * W + w0_col(q - S)] * a_env;
         else
-          v = raw->first_proj[size_t(r) * (S + W) + S + env_col(q - S - W)] * a_proj;
+          v = raw->first_proj[size_t(r) * (S + We) + S + env_col(q - S - W)] * a_proj;
         h[p->o_g0 + size_t(r) * NG + q] = v;
         h[p->o_g0t + size_t(q) * S + r] = v;
       }
@@ -449,8 +468,8 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     gemm_pack_b(&h[p->o_g0t], NG, S, &h[p->o_g0tp]);
   }
   for (int l = 0; l < L; ++l) {
-    AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, (l < L - 1 && !p->env_mom) ? S : -1,
-                        S + (l < L - 1 ? W : 0)),
+    AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, (l < L - 1 && !p->env_mom) ? S : -1, 1,
+                        S + (l < L - 1 ? We : 0)),
                "pack: missing latent weights");
     AA_REQUIRE(raw->tp_weights[l], "pack: missing tp weights");
     copy(p->o_tpw[l], raw->tp_weights[l], size_t(c.tps[l].coupling ? u : 1) * c.tps[l].num_paths, 1.0);
@@ -461,21 +480,21 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       for (int k = 0; k < ka; ++k)
         for (int r = 0; r < Rr; ++r)
           for (int ch = 0; ch < u; ++ch) {
-            double v = rawm[size_t(k) * raw_w + S + ch * Rr + r] * al;
+            double v = rawm[size_t(k) * raw_w + S + (shared ? ch : ch * Rr + r)] * al;
             h[p->o_wk[l] + (size_t(k) * Rr + r) * u + ch] = v;
             h[p->o_wt[l] + (size_t(r) * u + ch) * ka + k] = v;
           }
     };
-    fill(0, raw->first_proj, S, S + W, mlp_alpha(c, 0, S, S + W));
+    fill(0, raw->first_proj, S, S + We, mlp_alpha(c, 0, S, S + We));
     const int dl = c.latent_mlp_depth;  // index of a latent's last layer
     for (int l = 1; l < L; ++l)
-      fill(l, raw->latent[l - 1][dl], c.latent_mlp_width, S + W, mlp_alpha(c, dl, c.latent_mlp_width, S + W));
+      fill(l, raw->latent[l - 1][dl], c.latent_mlp_width, S + We, mlp_alpha(c, dl, c.latent_mlp_width, S + We, 1));
   }
-  AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1), "pack: missing readout weights");
+  AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1, 2), "pack: missing readout weights");
   {
     const double* wl = raw->readout[c.readout_mlp_depth];
     AA_REQUIRE(wl, "pack: missing readout weights");
-    copy(p->o_ro_last, wl, p->ro_last_dim, mlp_alpha(c, c.readout_mlp_depth, p->ro_last_dim, 1));
+    copy(p->o_ro_last, wl, p->ro_last_dim, mlp_alpha(c, c.readout_mlp_depth, p->ro_last_dim, 1, 2));
   }
   if (c.has_scales) {
     AA_REQUIRE(raw->scales, "pack: missing scales");
@@ -716,6 +735,7 @@ struct Runner {
     g.has_z = z ? 1 : 0;
     if (z) g.z = *z;
     g.act_a = act_a;
+    g.act_kind = act_now;
     g.has_add = add ? 1 : 0;
     if (add) g.add = *add;
     if (int rc = launch_gemm<T>(g, stream)) return rc;
@@ -725,8 +745,11 @@ struct Runner {
     return mark(nm, gemm_row_elems(g, true), 0, 2.0 * double(E) * K * Nn);
   }
 
+  int act_now = AA_ACT_SILU;  // nonlinearity of the MLP whose layers are being launched (gemm() reads it)
   // forward of a ScalarMLPFunction: hidden pre-activations to h[i]; final linear output to `out`
-  int mlp_fwd(const MlpLayout& m, int nlayers, const SegList& in, const size_t* h, const SegList& out) {
+  // which: 0 scalar_embed_mlp, 1 latent, 2 readout (selects the nonlinearity)
+  int mlp_fwd(const MlpLayout& m, int nlayers, const SegList& in, const size_t* h, const SegList& out, int which) {
+    act_now = p->cfg.act_kind[which];
     SegList a = in;
     for (int i = 0; i < nlayers; ++i) {
       SegList c;
@@ -745,7 +768,8 @@ struct Runner {
   // reverse: g_out (grad of final output) -> g_in (with per-segment accumulate flags)
   // add_last: optional extra gradient wrt the ACTIVATED last hidden layer (moments path), added before silu'
   int mlp_bwd(const MlpLayout& m, int nlayers, const SegList& g_out, const size_t* h, const size_t* g_h,
-              const SegList& g_in, const int* g_in_accum, const SegList* add_last = nullptr) {
+              const SegList& g_in, const int* g_in_accum, int which, const SegList* add_last = nullptr) {
+    act_now = p->cfg.act_kind[which];
     SegList a = g_out;
     for (int i = nlayers - 1; i >= 0; --i) {
       SegList c, z;
@@ -817,6 +841,7 @@ struct Runner {
       r.act = 0;
     }
     r.w = wt(p->o_ro_last);
+    r.act_kind = c.act_kind[2];
     r.factor = 1.0 / std::sqrt(2.0 * c.avg_num_neighbors);
     r.scales = c.has_scales ? wt(p->o_scales) : nullptr;
     r.shifts = c.has_shifts ? wt(p->o_shifts) : nullptr;
@@ -1084,13 +1109,14 @@ struct Runner {
     {
       SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
       SegList out{1, {seg(buf(w.emb), S, S)}};
-      if (int rc = mlp_fwd(p->embed, c.embed_mlp_depth + 1, in, w.se_h, out)) return rc;
+      if (int rc = mlp_fwd(p->embed, c.embed_mlp_depth + 1, in, w.se_h, out, 0)) return rc;
     }
     // 4+5a: env_embed_linear and first_layer_env_embed_projection as ONE GEMM (tensorembed.py:89, _allegro.py:251)
     {
       SegList in{1, {seg(buf(w.emb), S, S)}};
       SegList out{3, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W), seg(buf(w.envw[0]), W, W)}};
       if (p->env_mom) out.count = 2;
+      act_now = AA_ACT_SILU;  // (a plain linear map: no activation involved)
       if (int rc = gemm(in, 0, wt(p->o_g0), wt(p->o_g0p), wt(p->o_g0q), S, p->ng0, out, nullptr, nullptr)) return rc;
     }
     }
@@ -1186,10 +1212,11 @@ struct Runner {
       out.count = (l < L - 1 && !p->env_mom) ? 2 : 1;
       out.s[0] = seg(buf(w.fcat) + S * (l + 1), SL1, S);
       if (l < L - 1 && !p->env_mom) out.s[1] = seg(buf(w.envw[l + 1]), W, W);
-      if (int rc = mlp_fwd(p->latent[l], c.latent_mlp_depth + 1, in, w.lat_h[l], out)) return rc;
+      if (int rc = mlp_fwd(p->latent[l], c.latent_mlp_depth + 1, in, w.lat_h[l], out, 1)) return rc;
     }
     // 6: edge readout GEMM layers, 7-8: last linear + edge sum + per-type scale/shift
     if (c.readout_mlp_depth > 0 && !p->chain_gemm) {
+      act_now = c.act_kind[2];
       SegList a{1, {seg(buf(w.fcat), SL1, SL1)}};
       for (int i = 0; i < c.readout_mlp_depth; ++i) {
         SegList cs{1, {seg(buf(w.ro_h[i]), c.readout_mlp_width, c.readout_mlp_width)}};
@@ -1246,6 +1273,7 @@ struct Runner {
       ReadoutArgs r = readout_args(g, nullptr);
       if (c.readout_mlp_depth > 0) {
         r.g_h = buf(w.g_ro_h[c.readout_mlp_depth - 1]);
+        act_now = c.act_kind[2];
         if (int rc = launch_readout_backward<T>(r, stream)) return rc;
         if (int rc = mark("readout_backward", 2.0 * (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1))) return rc;
         SegList a{1, {seg(r.g_h, c.readout_mlp_width, c.readout_mlp_width)}};
@@ -1296,7 +1324,7 @@ struct Runner {
       const SegList* addp = (p->env_mom && l < L - 1) ? &aenv : nullptr;
       SegList gi{2, {seg(buf(w.g_fcat), SL1, S * (l + 1)), seg(buf(w.g_scal[l]), u, u)}};
       int acc[3] = {1, 0, 0};
-      if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc, addp)) return rc;
+      if (int rc = mlp_bwd(p->latent[l], c.latent_mlp_depth + 1, go, w.lat_h[l], w.g_lat_h, gi, acc, 1, addp)) return rc;
       }
       // tensor-product layer reverse
       if (p->tp_op >= 0) {
@@ -1444,6 +1472,7 @@ struct Runner {
       if (p->env_mom) go.count = 2;
       SegList gi{1, {seg(buf(w.g_emb), S, S)}};
       SegList aenv{1, {seg(p->env_mom ? buf(w.g_aenv) : nullptr, S, S)}};
+      act_now = AA_ACT_SILU;
       if (int rc = gemm(go, 0, wt(p->o_g0t), wt(p->o_g0tp), wt(p->o_g0tq), p->ng0, S, gi, nullptr, nullptr,
                         p->env_mom ? &aenv : nullptr))
         return rc;
@@ -1452,7 +1481,7 @@ struct Runner {
     {
       SegList go{1, {seg(buf(w.g_emb), S, S)}};
       SegList gi{1, {seg(buf(w.g_emb0), c.embed_dim, c.embed_dim)}};
-      if (int rc = mlp_bwd(p->embed, c.embed_mlp_depth + 1, go, w.se_h, w.g_se_h, gi, nullptr)) return rc;
+      if (int rc = mlp_bwd(p->embed, c.embed_mlp_depth + 1, go, w.se_h, w.g_se_h, gi, nullptr, 0)) return rc;
     }
     }
     EdgeBwdArgs eb{};

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int64_t kMagic = 0x414c4c4547524f31;  // "ALLEGRO1"
-constexpr int kHeader = 26;
+constexpr int kHeader = 30;
 
 struct PlanEntry {
   aa_model_plan* plan = nullptr;
@@ -51,7 +51,8 @@ double as_double(int64_t bits) {
 // config layout (int64 words): [magic, dtype, num_types, num_bessels, l_max, num_layers, num_scalar, num_tensor,
 //   embed_dim, embed_mlp_depth, embed_mlp_width, latent_mlp_depth, latent_mlp_width, readout_mlp_depth,
 //   readout_mlp_width, forward_weight_init, has_scales, has_shifts, embed_kind, spline_span,
-//   bits(poly_p), bits(avg_num_neighbors), bits(act_const), 0, 0, 0]  then per layer
+//   bits(poly_p), bits(avg_num_neighbors), bits(act_const), env_shared_weights, act_kind[0..2] (one byte each),
+//   bits(act_consts[0..2]), 0, 0]  then per layer
 //   [mul, d1, d2, dout, num_paths, coupling, nnz, i[nnz], j[nnz], k[nnz], path[nnz], bits(val)[nnz]]
 // (a plan owns Clebsch-Gordan tables in the memory of the device that was current when it was created: the cache
 //  key carries the device index and the caller holds a device guard)
@@ -88,6 +89,11 @@ const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
   c.poly_p = as_double(w[20]);
   c.avg_num_neighbors = as_double(w[21]);
   c.act_const = as_double(w[22]);
+  c.env_shared_weights = int32_t(w[23]);
+  for (int i = 0; i < 3; ++i) {
+    c.act_kind[i] = int32_t((w[24] >> (8 * i)) & 0xff);
+    c.act_consts[i] = as_double(w[25 + i]);
+  }
   TORCH_CHECK(c.num_layers >= 1 && c.num_layers <= AA_MAX_LAYERS, "allegro_amd: bad layer count in config");
   int64_t o = kHeader;
   for (int l = 0; l < c.num_layers; ++l) {

@@ -40,7 +40,9 @@ def serialize_config(model) -> list:
     w = [_MAGIC, cfg.dtype, cfg.num_types, cfg.num_bessels, cfg.l_max, cfg.num_layers, cfg.num_scalar, cfg.num_tensor,
          cfg.embed_dim, cfg.embed_mlp_depth, cfg.embed_mlp_width, cfg.latent_mlp_depth, cfg.latent_mlp_width,
          cfg.readout_mlp_depth, cfg.readout_mlp_width, cfg.forward_weight_init, cfg.has_scales, cfg.has_shifts,
-         cfg.embed_kind, cfg.spline_span, _bits(cfg.poly_p), _bits(cfg.avg_num_neighbors), _bits(cfg.act_const), 0, 0, 0]
+         cfg.embed_kind, cfg.spline_span, _bits(cfg.poly_p), _bits(cfg.avg_num_neighbors), _bits(cfg.act_const),
+         cfg.env_shared_weights, cfg.act_kind[0] | (cfg.act_kind[1] << 8) | (cfg.act_kind[2] << 16),
+         _bits(cfg.act_consts[0]), _bits(cfg.act_consts[1]), _bits(cfg.act_consts[2]), 0, 0]
     for l in range(cfg.num_layers):
         d = cfg.tps[l]
         w += [d.mul, d.d1, d.d2, d.dout, d.num_paths, d.coupling, d.nnz]

@@ -25,12 +25,32 @@ from . import _lib, ops, o3
 _TORCH2AA = {torch.float32: _lib.AA_F32, torch.float64: _lib.AA_F64}
 
 
-def silu_second_moment_const() -> float:
-    """normalize2mom constant of SiLU, 1/sqrt(E_{z~N(0,1)}[silu(z)^2]), by quadrature."""
+ACT_KINDS = {"silu": 0, "mish": 1, "gelu": 2, None: 3}
+
+
+def second_moment_const(nonlinearity: Optional[str] = "silu") -> float:
+    """normalize2mom constant of an activation, 1/sqrt(E_{z~N(0,1)}[act(z)^2]), by quadrature (the constant nequip's
+    ScalarMLPFunction folds into the layer after an activation); 1 for `None`."""
+    if nonlinearity is None:
+        return 1.0
     z = np.linspace(-12.0, 12.0, 240001)
     w = np.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
-    f = (z / (1.0 + np.exp(-z))) ** 2 * w
+    if nonlinearity == "silu":
+        a = z / (1.0 + np.exp(-z))
+    elif nonlinearity == "mish":
+        a = z * np.tanh(np.logaddexp(0.0, z))
+    elif nonlinearity == "gelu":
+        from math import erf
+
+        a = 0.5 * z * (1.0 + np.vectorize(erf)(z / math.sqrt(2.0)))
+    else:
+        raise NotImplementedError(f"nonlinearity {nonlinearity!r}: the reference offers silu, mish, gelu, None")
+    f = a * a * w
     return 1.0 / math.sqrt(float(np.sum((f[1:] + f[:-1]) * 0.5 * (z[1] - z[0]))))
+
+
+def silu_second_moment_const() -> float:
+    return second_moment_const("silu")
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -487,14 +507,12 @@ class HipAllegroModel(torch.nn.Module):
         super().__init__()
         assert avg_num_neighbors is not None, "`avg_num_neighbors` must be set for Allegro models"
         if pair_potential is not None:
-            raise NotImplementedError("pair potentials are outside the hot path (DESIGN.md, out of scope)")
-        if not weight_individual_irreps:
-            raise NotImplementedError("weight_individual_irreps=False is not supported by the HIP path")
-        for nl, depth in ((scalar_embed_mlp_nonlinearity, scalar_embed_mlp_hidden_layers_depth),
-                          (allegro_mlp_nonlinearity, allegro_mlp_hidden_layers_depth),
-                          (readout_mlp_nonlinearity, readout_mlp_hidden_layers_depth)):
-            if depth > 0 and nl != "silu":
-                raise NotImplementedError("only SiLU MLPs are implemented in the HIP path")
+            raise NotImplementedError("pair potentials (nequip's ZBL module, EXT) are outside the hot path (DESIGN.md section 8)")
+        self.nonlinearities = (scalar_embed_mlp_nonlinearity, allegro_mlp_nonlinearity, readout_mlp_nonlinearity)
+        for nl in self.nonlinearities:
+            if nl not in ACT_KINDS:
+                raise NotImplementedError(f"nonlinearity {nl!r}: the reference offers silu, mish, gelu, None")
+        self.weight_individual_irreps = bool(weight_individual_irreps)
         rce = dict(radial_chemical_embed or {})
         tgt = rce.pop("_target_", "allegro.nn.TwoBodyBesselScalarEmbed")
         self.embed_kind = {"TwoBodyBesselScalarEmbed": 0, "TwoBodySplineScalarEmbed": 1}.get(tgt.rsplit(".", 1)[-1])
@@ -568,16 +586,20 @@ class HipAllegroModel(torch.nn.Module):
 
         R = l_max + 1
         W = R * u
+        We = W if weight_individual_irreps else u  # env-weight columns of the Allegro layers (_channels.py:29-35)
         self._embed_dims = [S0] + [scalar_embed_mlp_hidden_layers_width] * scalar_embed_mlp_hidden_layers_depth + [S]
         add_mlp("scalar_embed_mlp.mlp.mlp", self._embed_dims)
         add_mlp("tensor_embed.env_embed_linear.mlp", [S, W])
-        add_mlp("allegro.first_layer_env_embed_projection.mlp", [S, S + W])
+        if not weight_individual_irreps:
+            # the reference registers an empty, persistent `_rtoi` in this mode (_channels.py:29-31): keep the key
+            add("allegro._env_weighter._rtoi", torch.empty(0, dtype=dt), "buffer")
+        add_mlp("allegro.first_layer_env_embed_projection.mlp", [S, S + We])
         self.tps_irreps = allegro_layer_irreps(l_max, parity, L)
         env = o3.Irreps.spherical_harmonics(l_max, p=-1)
         self._tp_meta = []
         for l in range(L):
             lat_dims = [S * (l + 1) + u] + [allegro_mlp_hidden_layers_width] * allegro_mlp_hidden_layers_depth + \
-                       [S + (W if l < L - 1 else 0)]
+                       [S + (We if l < L - 1 else 0)]
             add_mlp(f"allegro.latents.{l}.mlp", lat_dims)
         for l in range(L):
             w3j, instr, diag, dims = build_w3j(self.tps_irreps[l], env, self.tps_irreps[l + 1])
@@ -679,6 +701,10 @@ class HipAllegroModel(torch.nn.Module):
         cfg.forward_weight_init = int(hp["forward_normalize"])
         cfg.avg_num_neighbors = hp["avg_num_neighbors"]
         cfg.act_const = silu_second_moment_const()
+        cfg.env_shared_weights = int(not self.weight_individual_irreps)
+        for i, nl in enumerate(self.nonlinearities):
+            cfg.act_kind[i] = ACT_KINDS[nl]
+            cfg.act_consts[i] = second_moment_const(nl)
         cfg.has_scales, cfg.has_shifts = int(self.has_scales), int(self.has_shifts)
         cfg.embed_kind, cfg.spline_span = self.embed_kind, hp["spline_span"]
         keep = []

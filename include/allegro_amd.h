@@ -114,6 +114,14 @@ typedef struct {
    * 1 = TwoBodySplineScalarEmbed (scalarembed.py:84-175; spline.py): `num_bessels` is then num_splines */
   int32_t embed_kind;
   int32_t spline_span;     /* spline.py:27                                                     */
+  /* MakeWeightedChannels of the Allegro layers (_allegro.py:83-86, _channels.py:29-31,60-63): 0 = one env weight per
+   * (channel, irrep) [default, weight_individual_irreps=True], 1 = one per channel shared by all irreps */
+  int32_t env_shared_weights;
+  /* nonlinearity of scalar_embed_mlp / the latent MLPs / edge_readout (allegro_models.py:49-60,126-138):
+   * 0 silu, 1 mish, 2 gelu (erf form), 3 none (no activation between the layers); act_consts[i] is the matching
+   * normalize2mom constant of nequip's ScalarMLPFunction (1 for "none"; 0 = use act_const) */
+  int32_t act_kind[3];
+  double act_consts[3];
 } aa_model_config;
 
 /* Raw parameters in the reference's own state_dict layout, HOST memory, float64.

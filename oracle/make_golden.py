@@ -181,6 +181,14 @@ def main(only=None):
     dump_model("c2_L3", si_cfg(2, 3, 64), si)                      # 3 layers: per-atom operator path + chains
     dump_model("c2_u128", si_cfg(2, 2, 128, S=128, H=128), si)     # 128 features: operator path, single-layer GEMMs
     dump_model("c2_uncoupled", dict(si_cfg(2, 2, 64), tp_path_channel_coupling=False), si)  # p-mode weights
+    # constructor options of the reference beyond the defaults (allegro_models.py:49-60,126-142): the other MLP
+    # nonlinearities (incl. None = linear MLPs) and one env weight per channel shared by all irreps
+    dump_model("t_acts", dict(test_cfg(True, False), scalar_embed_mlp_nonlinearity="gelu", allegro_mlp_nonlinearity="mish",
+                              readout_mlp_nonlinearity=None), mol)
+    dump_model("t_mish", dict(test_cfg(False, True), scalar_embed_mlp_nonlinearity="mish", allegro_mlp_nonlinearity="gelu",
+                              readout_mlp_nonlinearity="mish"), mol)
+    dump_model("t_shared", dict(test_cfg(True, False), weight_individual_irreps=False), mol)
+    dump_model("c2_shared", dict(si_cfg(2, 2, 64), weight_individual_irreps=False), si)  # ... on the moments / chain fast path
     for seed in range(100):  # pick a seed without unphysically close intermolecular contacts
         w = G.make_water_graph(3, 9.9, r_cut=4.0, seed=seed)
         r = w.pos[w.edge_index[1]] - w.pos[w.edge_index[0]] + w.shift_vec()

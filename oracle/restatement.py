@@ -59,18 +59,34 @@ def polynomial_cutoff(x: torch.Tensor, p: float) -> torch.Tensor:
     return out * (x < 1.0)
 
 
-def scalar_mlp(x: torch.Tensor, weights, forward_weight_init: bool = True, act_const: Optional[float] = None):
-    """nequip ScalarMLPFunction: y = x @ (W_i*alpha_i), SiLU between layers (Appendix A).
+_ACTS = {"silu": torch.nn.functional.silu, "mish": torch.nn.functional.mish, "gelu": torch.nn.functional.gelu}
+_ACT_CONSTS: Dict[str, float] = {}
+
+
+def second_moment_const(nonlinearity: Optional[str]) -> float:
+    """normalize2mom constant of the MLP nonlinearity (1 for None)."""
+    if nonlinearity is None:
+        return 1.0
+    if nonlinearity not in _ACT_CONSTS:
+        z = torch.linspace(-12.0, 12.0, 240001, dtype=torch.float64)
+        w = torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+        _ACT_CONSTS[nonlinearity] = 1.0 / math.sqrt(torch.trapezoid(_ACTS[nonlinearity](z) ** 2 * w, z).item())
+    return _ACT_CONSTS[nonlinearity]
+
+
+def scalar_mlp(x: torch.Tensor, weights, forward_weight_init: bool = True, act_const: Optional[float] = None,
+               nonlinearity: Optional[str] = "silu"):
+    """nequip ScalarMLPFunction: y = x @ (W_i*alpha_i), the nonlinearity (silu / mish / gelu / None,
+    allegro_models.py:49-60) between layers (Appendix A).
     Call sites: _allegro.py:90-94,193-213,251,278; tensorembed.py:76-81,89; allegro_models.py:173,231."""
-    if act_const is None:
-        act_const = silu_second_moment_const()
+    act_const = second_moment_const(nonlinearity)
     norm_from_last = 1.0
     n = len(weights)
     for i, w in enumerate(weights):
         alpha = norm_from_last / math.sqrt(float(w.shape[0] if forward_weight_init else w.shape[1]))
         x = x @ (w * alpha)
-        if i < n - 1:
-            x = torch.nn.functional.silu(x)
+        if i < n - 1 and nonlinearity is not None:
+            x = _ACTS[nonlinearity](x)
             norm_from_last = act_const
     return x
 
@@ -86,7 +102,10 @@ def _mlp_weights(sd: Dict[str, torch.Tensor], prefix: str):
 
 # ----------------------------------------------------------------------------- strided ops
 def make_weighted_channels(sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int) -> torch.Tensor:
-    """out[z,u,i] = sh[z,i] * w[z,u,irrep(i)]  (allegro/nn/_strided/_channels.py:44-57; layout [z,u,r])."""
+    """out[z,u,i] = sh[z,i] * w[z,u,irrep(i)]  (allegro/nn/_strided/_channels.py:44-57; layout [z,u,r]); with
+    weight_individual_irreps=False the weights are [z,u] and shared by all irreps (:60-63)."""
+    if w.shape[1] == u:
+        return w.unsqueeze(-1) * sh.unsqueeze(-2)
     r_of_i = torch.tensor([l for l in range(l_max + 1) for _ in range(2 * l + 1)], device=sh.device)
     wz = w.reshape(sh.shape[0], u, l_max + 1)
     return sh.unsqueeze(1) * wz[:, :, r_of_i]
@@ -170,7 +189,8 @@ def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom
         emb = type_embed * basis
     inter["emb0"] = emb
     # 3 scalar_embed_mlp (allegro_models.py:173-183)
-    emb = scalar_mlp(emb, _mlp_weights(sd, "scalar_embed_mlp.mlp.mlp"), fwi, act_c)
+    emb = scalar_mlp(emb, _mlp_weights(sd, "scalar_embed_mlp.mlp.mlp"), fwi, act_c,
+                     cfg.get("scalar_embed_mlp_nonlinearity", "silu"))
     inter["edge_embedding"] = emb
     # 4 tensor_embed (tensorembed.py:85-96)
     w0 = scalar_mlp(emb, _mlp_weights(sd, "tensor_embed.env_embed_linear.mlp"), fwi, act_c)
@@ -178,7 +198,7 @@ def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom
     inter["edge_attrs"] = sh
     tf = make_weighted_channels(sh, w0, u, l_max)
     # 5 allegro (_allegro.py:237-301)
-    W = (l_max + 1) * u
+    W = (l_max + 1) * u if cfg.get("weight_individual_irreps", True) else u  # env-weight columns (_channels.py:29-35)
     proj = scalar_mlp(emb, _mlp_weights(sd, "allegro.first_layer_env_embed_projection.mlp"), fwi, act_c)
     acc = [proj[:, :S]]
     env_w = proj[:, S:S + W]
@@ -194,14 +214,16 @@ def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom
                                     coupling, 1.0 / math.sqrt(avg_nn))  # :268, _contract.py:185-211
         inter[f"tf{layer + 1}"] = tf
         scalars = tf[:, :, :1].reshape(tf.shape[0], u)  # :272-275
-        lat = scalar_mlp(torch.cat(acc + [scalars], dim=-1), _mlp_weights(sd, f"allegro.latents.{layer}.mlp"), fwi, act_c)
+        lat = scalar_mlp(torch.cat(acc + [scalars], dim=-1), _mlp_weights(sd, f"allegro.latents.{layer}.mlp"), fwi, act_c,
+                         cfg.get("allegro_mlp_nonlinearity", "silu"))
         acc.append(lat[:, :S])  # :284-286
         if layer < L - 1:
             env_w = lat[:, S:S + W]  # :289-294
     feats = torch.cat(acc, dim=-1)  # :300
     inter["edge_features"] = feats
     # 6 edge_readout (allegro_models.py:231-241), 7 edge_eng_sum (edgewise.py:40-60; factor allegro_models.py:245)
-    e_edge = scalar_mlp(feats, _mlp_weights(sd, "edge_readout.mlp.mlp"), fwi, act_c)
+    e_edge = scalar_mlp(feats, _mlp_weights(sd, "edge_readout.mlp.mlp"), fwi, act_c,
+                        cfg.get("readout_mlp_nonlinearity", "silu"))
     e_edge = e_edge * (1.0 / math.sqrt(2 * avg_nn))
     e_atom = torch.zeros((N, 1), dtype=e_edge.dtype, device=e_edge.device).index_add_(0, center, e_edge)
     # 8 per_type_energy_scale_shift (allegro_models.py:251-260)

@@ -7,7 +7,8 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MODEL_FIXTURES = ["c1_L1", "c1_L2", "c2", "t_coupled", "t_uncoupled", "t_peredge", "c5_small", "t_spline",
-                  "t_spline_peredge", "c2_spline", "c2_l3", "c2_l1", "c2_L3", "c2_u128", "c2_uncoupled"]
+                  "t_spline_peredge", "c2_spline", "c2_l3", "c2_l1", "c2_L3", "c2_u128", "c2_uncoupled", "t_acts", "t_mish", "t_shared",
+                  "c2_shared"]
 
 
 def load_model_fixture(name, dtype=torch.float64):

@@ -14,7 +14,10 @@ from allegro_amd.nn import HipContracter
     ("t_coupled", torch.float64, 1e-9), ("t_coupled", torch.float32, 5e-5), ("t_uncoupled", torch.float64, 1e-9),
     ("t_peredge", torch.float64, 1e-9), ("c5_small", torch.float64, 1e-9), ("c1_L1", torch.float32, 5e-5),
     ("t_spline", torch.float64, 1e-9), ("t_spline_peredge", torch.float32, 5e-5),
-    ("c2_spline", torch.float32, 5e-5)])
+    ("c2_spline", torch.float32, 5e-5),
+    # constructor options beyond the defaults: gelu / mish / None MLPs (general kernels), one env weight per channel
+    ("t_acts", torch.float64, 1e-9), ("t_mish", torch.float32, 5e-5), ("t_shared", torch.float64, 1e-9),
+    ("c2_shared", torch.float32, 5e-5)])
 def test_model_matches_reference_golden(name, dtype, tol):
     fx = load_model_fixture(name, dtype)
     m = model_from_fixture(fx, dtype, emu_lib())
