@@ -406,10 +406,18 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   } else {
     AA_REQUIRE(raw->bessel_weights && raw->center_embed && raw->neighbor_embed && raw->basis_linear,
                "pack: missing embedding weights");
-    copy(p->o_bessel, raw->bessel_weights, B, 1.0);
+    // Two published conventions of nequip's BesselEdgeLengthEncoding (EXT; which one a given nequip release uses
+    // cannot be checked in this container -- DESIGN.md section 6): (a) bessel_weights = n pi, basis sin(w x) / x;
+    // (b) bessel_weights = n (linspace(1, B, B)), basis sinc(x w) w = sin(pi w x) / (pi x).  Both are served by the
+    // same kernels, sin(w' x) / x: (b) is recognised by its integer roots and packed as w' = pi w with the 1/pi
+    // prefactor folded into the basis_linear rows.
+    bool sinc_form = true;
+    for (int n = 0; n < B; ++n) sinc_form = sinc_form && std::fabs(raw->bessel_weights[n] - double(n + 1)) < 1e-6;
+    const double kPi = 3.14159265358979323846;
+    copy(p->o_bessel, raw->bessel_weights, B, sinc_form ? kPi : 1.0);
     copy(p->o_cemb, raw->center_embed, size_t(T) * S0 / 2, 1.0);
     copy(p->o_nemb, raw->neighbor_embed, size_t(T) * S0 / 2, 1.0);
-    copy(p->o_basis, raw->basis_linear, size_t(B) * S0, mlp_alpha(c, 0, B, S0));
+    copy(p->o_basis, raw->basis_linear, size_t(B) * S0, mlp_alpha(c, 0, B, S0) * (sinc_form ? 1.0 / kPi : 1.0));
   }
   // env-weight columns: reference layout [u][R] (_channels.py:46-51); the specialised kernels want [R][u].
   // With weight_individual_irreps=False the Allegro layers' env weights are [u] in the reference (_channels.py:29-31,

@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from allegro_amd import graph as G  # noqa: E402
-from allegro_amd.dist import partition_atoms  # noqa: E402
+from allegro_amd.dist import LocalShard  # noqa: E402
 from allegro_amd.nn import HipAllegroModel, PreparedGraph  # noqa: E402
 
 BESSEL = {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8, "polynomial_cutoff_p": 6}
@@ -306,6 +306,9 @@ def main():
     ap.add_argument("--stages", action="store_true", help="also print every launch of one step with its HIP-event time")
     ap.add_argument("--emulate-shard", default=None, metavar="R/W",
                     help="analysis only: run rank R's atom block of a W-way partition on this one GPU (no collective)")
+    ap.add_argument("--shard-sweep", type=int, default=0, metavar="W",
+                    help="analysis only: time every rank's compact shard of a W-way partition on this one GPU, one after "
+                         "the other (load balance: max / mean shard time; no collective), print one JSON line and exit")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -328,25 +331,51 @@ def main():
     model = HipAllegroModel(**cfg).to(dev)
     N, E, L = g.num_atoms, g.num_edges, cfg["num_layers"]
     rowptr = G.csr_from_sorted_centers(g.edge_index[0], N)
-    cuts = partition_atoms(rowptr, world)
-    a0, a1 = cuts[rank], cuts[rank + 1]
-    if args.emulate_shard:
-        er, ew = (int(x) for x in args.emulate_shard.split("/"))
-        cuts = partition_atoms(rowptr, ew)
-        a0, a1 = cuts[er], cuts[er + 1]
-    e0, e1 = int(rowptr[a0]), int(rowptr[a1])
-    ei_local = torch.tensor(g.edge_index[:, e0:e1], device=dev)
     sv = g.shift_vec()
-    sv_local = torch.tensor(sv[e0:e1], dtype=dtype, device=dev) if sv is not None else None
     pos = torch.tensor(g.pos, dtype=dtype, device=dev)
     types = torch.tensor(g.types, device=dev)
-    graph = PreparedGraph(ei_local, types, N, sv_local)
+    if args.shard_sweep:
+        # every rank's compact shard (owned block + ghost atoms, allegro_amd/dist.py) timed on this GPU, one at a time
+        W = args.shard_sweep
+        rows = []
+        for r in range(W):
+            sh = LocalShard(g.edge_index, g.types, N, sv, r, W, dev, dtype, rowptr)
+            for _ in range(args.warmup):
+                sh.step(model, pos)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sh.step(model, pos)
+            torch.cuda.synchronize()
+            rows.append(dict(rank=r, owned=sh.n_own, ghosts=sh.n_ghost, edges=sh.graph.num_edges,
+                             ms=(time.perf_counter() - t0) / args.steps * 1e3))
+            del sh
+        ms = [x["ms"] for x in rows]
+        print(json.dumps({"shard_sweep": W, "workload": args.workload, "atoms": N, "edges": E, "shards": rows,
+                          "max_ms": max(ms), "mean_ms": sum(ms) / W, "imbalance_max_over_mean": max(ms) / (sum(ms) / W),
+                          "note": "one GPU, shards run one after the other, no collective: an upper bound of the per-rank "
+                                  "compute time of a W-GPU run, NOT a multi-GPU measurement"}), flush=True)
+        return
+    shard = None
+    a0, a1 = 0, N
+    if world > 1 or args.emulate_shard:
+        er, ew = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
+        # this rank's compact share: owned atom block + ghost atoms in local numbering (O(local) graph / workspace)
+        shard = LocalShard(g.edge_index, g.types, N, sv, er, ew, dev, dtype, rowptr)
+        a0, a1 = shard.a0, shard.a1
+        graph = shard.graph
+    else:
+        graph = PreparedGraph(torch.tensor(g.edge_index, device=dev), types, N,
+                              torch.tensor(sv, dtype=dtype, device=dev) if sv is not None else None)
+    e0, e1 = int(rowptr[a0]), int(rowptr[a1])
 
     def step():
-        e_atom, forces = model.energy_forces(pos, graph)
+        if shard is None:
+            return model.energy_forces(pos, graph)
+        e_own, forces = shard.step(model, pos)
         if dist is not None:
             dist.all_reduce(forces)  # ghost-atom force contributions: one RCCL all-reduce over xGMI
-        return e_atom, forces
+        return e_own, forces
 
     for _ in range(args.warmup):
         step()
@@ -395,13 +424,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "atoms": N, "edges": E,
                        "edges_per_s": E / t_step, "ns_per_day_at_1fs": 0.0864 / t_step,
-                       "parallelism": f"atom-block x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"atom-block x{world}: compact shards (owned block + ghost atoms), one all-reduce of F[N,3]"
+                                       if world > 1 else "single GPU"),
                        "weights": "random init (reference initialisers), seed 456"},
         }
         if sustained is not None:
             line["config"]["sustained"] = sustained
         if not args.no_profile:
-            stages = profile_stages(model, pos, graph)
+            stages = profile_stages(model, pos if shard is None else pos.index_select(0, shard.local_ids), graph)
             roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload)
             line["roofline"] = roof
             line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])

@@ -182,7 +182,13 @@ def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom
     else:
         # 2 radial_chemical_embed: Bessel x cutoff -> ProductTypeEmbedding (scalarembed.py:60-81; _edgeembed.py:68-84)
         bw = sd["radial_chemical_embed.bessel_encode.bessel_weights"]
-        bessel = torch.sin(bw * x) / x * polynomial_cutoff(x, float(cfg.get("polynomial_cutoff_p", 6)))
+        # nequip BesselEdgeLengthEncoding (EXT), two published forms, told apart by the stored roots: n*pi with
+        # sin(w x)/x (what the shim that generated the golden vectors uses), or n with sinc(x w) w = sin(pi w x)/(pi x)
+        if torch.allclose(bw.reshape(-1).double(), torch.arange(1, bw.numel() + 1, dtype=torch.float64)):
+            bessel = torch.sinc(x * bw) * bw
+        else:
+            bessel = torch.sin(bw * x) / x
+        bessel = bessel * polynomial_cutoff(x, float(cfg.get("polynomial_cutoff_p", 6)))
         type_embed = torch.cat((sd["radial_chemical_embed.type_embed.center_embed.weight"][et[0]],
                                 sd["radial_chemical_embed.type_embed.neighbor_embed.weight"][et[1]]), dim=-1)
         basis = scalar_mlp(bessel, _mlp_weights(sd, "radial_chemical_embed.type_embed.basis_linear.mlp"), fwi, act_c)

@@ -32,6 +32,48 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_local(rank, world, port, q):
+    """Compact shards (LocalShard: owned block + ghosts in local numbering) + all-reduce."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from allegro_amd.dist import LocalShard, energy_forces_local
+    from tests.golden_utils import load_model_fixture
+    from tests.hip_utils import emu_lib, model_from_fixture
+
+    fx = load_model_fixture("t_coupled", torch.float64)
+    m = model_from_fixture(fx, torch.float64, emu_lib())
+    n = fx["pos"].shape[0]
+    sh = LocalShard(fx["edge_index"].numpy(), fx["types"].numpy(), n, fx["shift_vec"].numpy(), rank, world, "cpu", torch.float64)
+    e, f = energy_forces_local(m, fx["pos"], sh)
+    stats = torch.tensor([sh.n_own, sh.n_ghost, sh.graph.num_edges], dtype=torch.int64)
+    allstats = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allstats, stats)
+    if rank == 0:
+        q.put(((e - fx["out"]["atomic_energy"].reshape(-1)).abs().max().item(),
+               (f - fx["out"]["forces"]).abs().max().item(), [t.tolist() for t in allstats], n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_compact_shards_match_reference():
+    """world_size 4, gloo: every rank holds only its owned block + ghost atoms (local numbering), one all-reduce of the
+    force array; the result equals the reference's golden vectors."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_local, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    de, df, stats, n = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert de < 1e-8 and df < 1e-8
+    assert sum(s[0] for s in stats) == n and sum(s[2] for s in stats) == 192  # blocks partition atoms and edges
+    assert all(s[0] > 0 and s[0] + s[1] <= n for s in stats)
+
+
 def test_two_rank_sharding_matches_reference():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -309,3 +309,27 @@ def test_tiny_graphs_on_the_fast_paths_vs_oracle(n, box, L, l_max, dt):
     ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos, dtype=dtype), torch.tensor(ei), types, sv)
     for got, want in ((e, ref["atomic_energy"].reshape(-1)), (f, ref["forces"])):
         assert (got - want).abs().max().item() <= tol * max(1.0, float(want.abs().max()))
+
+
+def test_bessel_sinc_convention_is_recognised_from_the_stored_roots():
+    """nequip's BesselEdgeLengthEncoding exists in two published forms (roots n*pi with sin(w x)/x, or roots n with
+    sinc(x w) w): a checkpoint of either kind must evaluate correctly.  The packed weights switch on the stored
+    `bessel_weights`; checked against the oracle, which applies the same rule with torch.sinc."""
+    from oracle import restatement as R
+
+    fx = load_model_fixture("t_coupled", torch.float64)
+    sd = dict(fx["sd"])
+    key = "radial_chemical_embed.bessel_encode.bessel_weights"
+    n = sd[key].numel()
+    sd[key] = torch.arange(1, n + 1, dtype=torch.float64).reshape(sd[key].shape)
+    fx2 = dict(fx, sd=sd)
+    m = model_from_fixture(fx2, torch.float64, emu_lib())
+    data, sv = fixture_data(fx2, torch.float64)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    e, f = m.energy_forces(data["pos"], g)
+    cfg = dict(fx["cfg"], model_dtype="float64")
+    ref = R.allegro_energy_forces(cfg, sd, fx["pos"], fx["edge_index"], fx["types"], fx["shift_vec"])
+    assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9
+    assert (f - ref["forces"]).abs().max() < 1e-9
+    # and it IS a different function of the same weights than the n*pi form (1/pi prefactor)
+    assert (f - fx["out"]["forces"]).abs().max() > 1e-3
