@@ -84,7 +84,43 @@ __device__ __forceinline__ float dpp_move(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 
-__device__ __forceinline__ double sigmoid_(double x) { return 1.0 / (1.0 + exp(-x)); }
+// fp64 exp for the activations: argument reduction by ln 2 (two-part constant) + a degree-13 Taylor polynomial on
+// |r| <= ln2/2 (remainder < 4e-18) + ldexp -- ~20 fp64 instructions instead of the ~150 of the generic libm exp with
+// its special-case handling, < 1.5 ulp (tests/test_host_logic.py).  fp64 models evaluate SiLU / SiLU' for every
+// element of every hidden layer in the GEMM operand staging, the epilogues and the moment kernels: with the libm
+// sequence those were 5 VALU instructions per MFMA in the fp64 linear layers (profiles/r02_v7_rocprofv3_c5_summary.txt).
+__device__ __forceinline__ double aa_exp_f64(double x) {
+  x = x > 709.0 ? 709.0 : (x < -745.0 ? -745.0 : x);
+  const double k = rint(x * 1.44269504088896338700e+00);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821614599e-10;  // 1/13!
+  p = fma(p, r, 2.0876756987868098979e-09);
+  p = fma(p, r, 2.5052108385441718775e-08);
+  p = fma(p, r, 2.7557319223985890653e-07);
+  p = fma(p, r, 2.7557319223985892510e-06);
+  p = fma(p, r, 2.4801587301587301566e-05);
+  p = fma(p, r, 1.9841269841269841253e-04);
+  p = fma(p, r, 1.3888888888888889419e-03);
+  p = fma(p, r, 8.3333333333333332177e-03);
+  p = fma(p, r, 4.1666666666666664354e-02);
+  p = fma(p, r, 1.6666666666666665741e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, int(k));
+}
+__device__ __forceinline__ double sigmoid_(double x) {
+  const double d = 1.0 + aa_exp_f64(-x);
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(d);  // v_rcp_f64 + two Newton steps: full double accuracy without the IEEE division sequence
+  y = fma(fma(-d, y, 1.0), y, y);
+  y = fma(fma(-d, y, 1.0), y, y);
+  return y;
+#else
+  return 1.0 / d;
+#endif
+}
 __device__ __forceinline__ float sigmoid_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
@@ -501,6 +537,11 @@ struct FusedFwdArgs {
 };
 int fused_fwd_num_steps(int R, bool hold_w0);
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
+// 16-edge-tile form (aa_fused16.hip; two waves per atom, two waves per SIMD): same arguments, its own weight packing
+int launch_fused16_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
+// bf16x3 fragments for v_mfma_f32_16x16x32_bf16: [N/64 groups][K/32 chunks][4 tiles x 3 levels][64 lanes][4 words];
+// same word count as gemm_bf16x3_words(K, N); K multiple of 32, N multiple of 64
+void gemm_pack_bf16x3_16(const float* B, int K, int N, unsigned* out);
 
 // ----------------------------------------------------------------------------------------------
 // edge prologue / epilogue / readout reduce

@@ -1429,6 +1429,41 @@ void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out) {
       }
 }
 
+void gemm_pack_bf16x3_16(const float* B, int K, int N, unsigned* out) {
+  const int NQ = N / 64, KC = K / 32;
+  auto trunc = [](float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    return u & 0xFFFF0000u;
+  };
+  auto tof = [](unsigned u) {
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+  };
+  for (int q = 0; q < NQ; ++q)
+    for (int kc = 0; kc < KC; ++kc)
+      for (int t = 0; t < 4; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = 64 * q + 16 * t + (lane & 15), g = lane >> 4;
+          unsigned lv[3][8];
+          for (int e = 0; e < 8; ++e) {
+            // operand slot (g, e) of a chunk <-> accumulator register of the producing layer (aa_fused16.hip)
+            const int k = 32 * kc + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+            const float x = B[size_t(k) * N + n];
+            lv[0][e] = trunc(x);
+            const float r = x - tof(lv[0][e]);
+            lv[1][e] = trunc(r);
+            const float r2 = r - tof(lv[1][e]);
+            lv[2][e] = trunc(r2);
+          }
+          for (int l = 0; l < 3; ++l) {
+            unsigned* o = out + ((((size_t(q) * KC + kc) * 12 + (t * 3 + l)) * 64 + lane) * 4);
+            for (int w = 0; w < 4; ++w) o[w] = (lv[l][2 * w] >> 16) | lv[l][2 * w + 1];
+          }
+        }
+}
+
 size_t gemm_packed_elems(int K, int N) { return size_t((N + 31) / 32) * size_t((K + 31) / 32) * 64 * 16; }
 
 // out[nt][kc][lane][s] = B[kc*32 + (lane>>5)*16 + s][nt*32 + (lane&31)]   (zero padded)

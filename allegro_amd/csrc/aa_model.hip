@@ -123,6 +123,7 @@ struct MlpLayout {
   std::vector<size_t> w, wt;    // blob offsets (elements) of W_i [d_i,d_{i+1}] and its transpose
   std::vector<size_t> wp, wtp;  // the same two matrices in MFMA fragment order (aa_gemm.hip v3)
   std::vector<size_t> wq, wtq;  // ... and split into 3 bf16 levels (bf16x3 path; fp32 plans only)
+  std::vector<size_t> wq16;     // W_i in the 16x16x32 fragment order of the 16-edge-tile fused forward (fused_mode 2)
 };
 
 struct aa_model_plan {
@@ -145,6 +146,8 @@ struct aa_model_plan {
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
+  int fused_mode;                    // 1: 32-edge tiles, one wave per atom; 2: 16-edge tiles, two waves per atom (aa_fused16.hip)
+  size_t o_g0q16;
   bool fused_hold_w0;                // ... holding the w0 tiles in registers between the two layers (else: recomputed)
   mutable bool taps = false;         // aa_model_plan_enable_taps: staged pipeline so that every tap is materialised
   bool embed_fused;                  // reverse pass: d(two-body embedding) [E,S0] never materialised, the last reverse chain
@@ -265,6 +268,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_basis = take(size_t(B) * S0);
   AA_REQUIRE(cfg->embed_kind == 0 || (cfg->embed_kind == 1 && cfg->spline_span >= 0 && cfg->spline_span <= B),
              "model: embed_kind must be 0 (Bessel) or 1 (spline, 0 <= span <= num_splines)");
+  const bool fused16 = getenv("AA_FUSED") && getenv("AA_FUSED")[0] == '2';
   auto lay = [&](MlpLayout& m, const std::vector<int>& dims, int nlayers) {
     m.dims = dims;
     for (int i = 0; i < nlayers; ++i) {
@@ -274,6 +278,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
       m.wtp.push_back(take(gemm_packed_elems(dims[i + 1], dims[i])));
       m.wq.push_back(take(gemm_bf16x3_words(dims[i], dims[i + 1])));
       m.wtq.push_back(take(gemm_bf16x3_words(dims[i + 1], dims[i])));
+      m.wq16.push_back(fused16 && dims[i] % 32 == 0 && dims[i + 1] % 64 == 0 ? take(gemm_bf16x3_words(dims[i], dims[i + 1])) : 0);
     }
   };
   lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
@@ -293,6 +298,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_g0tp = take(gemm_packed_elems(p->ng0, S));
   p->o_g0q = take(gemm_bf16x3_words(S, p->ng0));
   p->o_g0tq = take(gemm_bf16x3_words(p->ng0, S));
+  p->o_g0q16 = (fused16 && S % 32 == 0 && p->ng0 % 64 == 0) ? take(gemm_bf16x3_words(S, p->ng0)) : 0;
   if (p->env_mom) {
     for (int l = 0; l < L; ++l) {
       const size_t ka = l == 0 ? S : cfg->latent_mlp_width;
@@ -334,7 +340,8 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     // SIMD only and a single wave cannot hide its own LDS / MFMA / L2 latencies (profiles/r02_v5_*)
     const char* fu = getenv("AA_FUSED");
     p->fused_fwd = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 && (fu && fu[0] == '1');
+                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 && (fu && (fu[0] == '1' || fu[0] == '2'));
+    p->fused_mode = (fu && fu[0] == '2') ? 2 : 1;
     const char* rc = getenv("AA_FUSED_RECOMPUTE");  // A/B: recompute w0 for the second layer instead of holding it
     p->fused_hold_w0 = !(rc && rc[0] == '1');
   }
@@ -538,6 +545,18 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       }
     };
     split_mlp(p->embed, c.embed_mlp_depth + 1);
+    {
+      auto split16 = [&](size_t w_off, int K, int N, size_t q_off) {
+        if (q_off) gemm_pack_bf16x3_16(&hf[w_off], K, N, reinterpret_cast<unsigned*>(&hf[q_off]));
+      };
+      auto split16_mlp = [&](const MlpLayout& m, int nlayers) {
+        for (int i = 0; i < nlayers; ++i) split16(m.w[i], m.dims[i], m.dims[i + 1], m.wq16[i]);
+      };
+      split16_mlp(p->embed, c.embed_mlp_depth + 1);
+      split16(p->o_g0, S, p->ng0, p->o_g0q16);
+      for (int l = 0; l < L; ++l) split16_mlp(p->latent[l], c.latent_mlp_depth + 1);
+      split16_mlp(p->readout, c.readout_mlp_depth);
+    }
     splitw(p->o_g0, S, p->ng0, p->o_g0q);
     splitw(p->o_g0t, p->ng0, S, p->o_g0tq);
     for (int l = 0; l < L; ++l) split_mlp(p->latent[l], c.latent_mlp_depth + 1);
@@ -1048,6 +1067,28 @@ struct Runner {
       }
     };
     const bool hold = p->fused_hold_w0;
+    if (p->fused_mode == 2) {
+      // 16-edge-tile kernel: one contiguous 12-KB block per (64-feature group, chunk) of the 16x16x32-ordered copies
+      auto add16 = [&](const float* Wq, int KC, int q0, int nq) {
+        for (int q = q0; q < q0 + nq; ++q)
+          for (int kc = 0; kc < KC; ++kc) {
+            a.wstep[ns][0] = Wq + (size_t(q) * KC + kc) * 3072;
+            a.wstep[ns][1] = Wq + (size_t(q) * KC + kc) * 3072 + 1536;
+            ++ns;
+          }
+      };
+      add16(wf(p->embed.wq16[0]), 2, 0, 1);
+      add16(wf(p->embed.wq16[1]), 2, 0, 1);
+      add_env(wf(p->o_wk[0]));
+      add16(wf(p->o_g0q16), 2, 0, 1 + p->R);
+      add16(wf(p->latent[0].wq16[0]), 4, 0, 1);
+      add_env(wf(p->o_wk[1]));
+      add16(wf(p->latent[0].wq16[1]), 2, 0, 1);
+      if (!hold) add16(wf(p->o_g0q16), 2, 1, p->R);
+      add16(wf(p->latent[1].wq16[0]), 6, 0, 1);
+      add16(wf(p->latent[1].wq16[1]), 2, 0, 1);
+      add16(wf(p->readout.wq16[0]), 6, 0, 1);
+    } else {
     add_layer(wf(p->embed.wq[0]), 2, 0, 2);
     add_layer(wf(p->embed.wq[1]), 2, 0, 2);
     add_env(wf(p->o_wk[0]));
@@ -1059,6 +1100,7 @@ struct Runner {
     add_layer(wf(p->latent[1].wq[0]), 6, 0, 2);
     add_layer(wf(p->latent[1].wq[1]), 2, 0, 2);
     add_layer(wf(p->readout.wq[0]), 6, 0, 2);
+    }
     if (ns != fused_fwd_num_steps(p->R, hold) || ns > kFusedMaxSteps) return fail(AA_ERR_INVALID, "fused forward: program length mismatch");
     a.tpw0 = wf(p->o_tpw[0]);
     a.tpw1 = wf(p->o_tpw[1]);
@@ -1081,7 +1123,8 @@ struct Runner {
     a.x2s1 = bf(w.x2s[1]);
     a.atom_energy = static_cast<float*>(atom_energy);
     if (int rc = mark("begin")) return rc;
-    if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
+    if (p->fused_mode == 2 && p->cfg.l_max > 2) return fail(AA_ERR_INVALID, "fused forward (16-edge tiles): l_max <= 2");
+    if (int rc = p->fused_mode == 2 ? launch_fused16_fwd(p->chain_pair, hold, a, stream) : launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
     // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;
     // position, two x2s blocks, energy, row pointer per atom.  Flops: the linear layers of the forward (w0 counted once).
     const double per_edge = 1 + (g->shift_vec ? 3 : 0) + 3 + 4 + p->D + 5 * 64 + p->W;

@@ -342,13 +342,15 @@ def main():
             sh = LocalShard(g.edge_index, g.types, N, sv, r, W, dev, dtype, rowptr)
             for _ in range(args.warmup):
                 sh.step(model, pos)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                sh.step(model, pos)
-            torch.cuda.synchronize()
-            rows.append(dict(rank=r, owned=sh.n_own, ghosts=sh.n_ghost, edges=sh.graph.num_edges,
-                             ms=(time.perf_counter() - t0) / args.steps * 1e3))
+            reps = []
+            for _ in range(3):  # median of 3 timed batches: one-off hiccups (allocator, clocks) are not load imbalance
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    sh.step(model, pos)
+                torch.cuda.synchronize()
+                reps.append((time.perf_counter() - t0) / args.steps * 1e3)
+            rows.append(dict(rank=r, owned=sh.n_own, ghosts=sh.n_ghost, edges=sh.graph.num_edges, ms=sorted(reps)[1]))
             del sh
         ms = [x["ms"] for x in rows]
         print(json.dumps({"shard_sweep": W, "workload": args.workload, "atoms": N, "edges": E, "shards": rows,

@@ -184,7 +184,7 @@ def allegro_energy(cfg: dict, sd: Dict[str, torch.Tensor], pos, edge_index, atom
         bw = sd["radial_chemical_embed.bessel_encode.bessel_weights"]
         # nequip BesselEdgeLengthEncoding (EXT), two published forms, told apart by the stored roots: n*pi with
         # sin(w x)/x (what the shim that generated the golden vectors uses), or n with sinc(x w) w = sin(pi w x)/(pi x)
-        if torch.allclose(bw.reshape(-1).double(), torch.arange(1, bw.numel() + 1, dtype=torch.float64)):
+        if torch.allclose(bw.reshape(-1).double(), torch.arange(1, bw.numel() + 1, dtype=torch.float64, device=bw.device)):
             bessel = torch.sinc(x * bw) * bw
         else:
             bessel = torch.sin(bw * x) / x

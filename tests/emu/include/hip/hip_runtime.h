@@ -233,6 +233,31 @@ inline emu_v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8
   emu::wave_rendezvous();
   return d;
 }
+// v_mfma_f32_16x16x32_bf16: lane l holds A[i=l&15][k=8*(l>>4)+e] and B[k=8*(l>>4)+e][j=l&15], e=0..7;
+// D[i = 4*(l>>4) + r][j = l&15], r = 0..3
+typedef float emu_v4f_mfma __attribute__((ext_vector_type(4)));
+inline emu_v4f_mfma __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_v4f_mfma c, int, int, int) {
+  int l = emu::lane(), w = emu::wave();
+  memcpy(emu::slot(w, l), &a, 16);
+  memcpy(reinterpret_cast<char*>(emu::slot(w, l)) + 16, &b, 16);
+  emu::wave_rendezvous();
+  emu_v4f_mfma d = c;
+  const int j = l & 15;
+  auto bf = [](unsigned short h) { unsigned u = unsigned(h) << 16; float f; memcpy(&f, &u, 4); return f; };
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g) {
+      unsigned short av[8], bv[8];
+      memcpy(av, emu::slot(w, i + 16 * g), 16);                                      // lane holding A[i][8g..8g+7]
+      memcpy(bv, reinterpret_cast<char*>(emu::slot(w, j + 16 * g)) + 16, 16);        // lane holding B[8g..8g+7][j]
+      for (int e = 0; e < 8; ++e) acc += bf(av[e]) * bf(bv[e]);
+    }
+    d[r] = acc;
+  }
+  emu::wave_rendezvous();
+  return d;
+}
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
 inline void __builtin_amdgcn_sched_barrier(int) {}

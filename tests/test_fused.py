@@ -16,11 +16,11 @@ from tests.golden_utils import load_model_fixture
 from tests.hip_utils import emu_lib, fixture_data, model_from_fixture
 
 
-@pytest.fixture(autouse=True)
-def _opt_in(monkeypatch):
-    """The fused path is opt-in (measured slower than the staged forward on MI355X): read when the plan
-    is created, i.e. at the first step of a model."""
-    monkeypatch.setenv("AA_FUSED", "1")
+@pytest.fixture(autouse=True, params=["1", "2"], ids=["tile32", "tile16"])
+def _opt_in(request, monkeypatch):
+    """AA_FUSED selects the fused forward when the plan is created (the first step of a model): 1 = one wave per atom
+    (32-edge tile, aa_fused.hip), 2 = two waves per atom (16-edge tiles, aa_fused16.hip)."""
+    monkeypatch.setenv("AA_FUSED", request.param)
 
 
 def _cfg(embed="bessel", coupling=True, l_max=2, seed=11, avg=9.0, scale_shift=True):
