@@ -256,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
   float* sB = sX + 2 * 9 * 64;            // [D][64] per-atom Clebsch-Gordan vectors
   float* sE = sB + 9 * 64;                // [4] energy partial of the second tile
   float* sP = sA + 16 * h * kLdP;         // the wave's store patch
+  float* sX0 = sTab + ntab + 4 * kSlotFloats + wv * 9 * 64;  // [D][64] the wave's copy of x2s0
   for (int i = tid; i < 64; i += 512) sRo[i] = A.ro_w[i];
   if (tid < A.num_types * A.num_types) sRm[tid] = A.rmax_recip[tid];
   if (tid >= 8 && tid < 16) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 8] : 0.f;
@@ -270,11 +271,14 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
     pipe16_store(wbuf, 0, tid, r);
     pipe16_load(A, 1, tid, p.rb);
   }
-  float wp0[Sig0::P], wp1[Sig1::P];
+  // (path weights of the lane's channel are re-read from L2 where the per-atom vectors are formed: 14 registers that
+  //  would otherwise be live through the whole kernel)
+  auto load_wp = [&](float* wp0, float* wp1) {
 #pragma unroll
-  for (int q = 0; q < Sig0::P; ++q) wp0[q] = A.coupling ? A.tpw0[lane * Sig0::P + q] : A.tpw0[q];
+    for (int q = 0; q < Sig0::P; ++q) wp0[q] = A.coupling ? A.tpw0[lane * Sig0::P + q] : A.tpw0[q];
 #pragma unroll
-  for (int q = 0; q < Sig1::P; ++q) wp1[q] = A.coupling ? A.tpw1[lane * Sig1::P + q] : A.tpw1[q];
+    for (int q = 0; q < Sig1::P; ++q) wp1[q] = A.coupling ? A.tpw1[lane * Sig1::P + q] : A.tpw1[q];
+  };
   // ---- the wave's atom and 16-edge tile
   const int64_t atom = A.atom0 + int64_t(blockIdx.x) * 4 + slot;
   const bool atom_ok = atom < A.atom_end;
@@ -378,7 +382,6 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
                           });
   AA_TICK16(4)
   // ---- per-atom part of a layer: partial moments of this tile -> (exchange) -> x2s -> per-atom vector B -> sB
-  float x2s0[D];
   auto per_atom = [&](auto s0c, const Act& a, float* x2s) {
     constexpr int SP = decltype(s0c)::value;
     // the wave's 16 rows to its half of the atom patch, then lane = k walks them
@@ -450,15 +453,20 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
     for (int j = 0; j < D; ++j) x2s[j] = A.sf * (sX[j * 64 + lane] + sX[(9 + j) * 64 + lane]);
   };
   {
+    float x2s0[D];
     per_atom(std::integral_constant<int, S_P0>{}, em, x2s0);
     if (atom_ok && h == 0) {
 #pragma unroll
       for (int j = 0; j < D; ++j) A.x2s0[(atom * D + j) * 64 + lane] = x2s0[j];
     }
-    float e0[D], B0[D];
+    float e0[D], B0[D], wp0[Sig0::P], wp1[Sig1::P];
+    load_wp(wp0, wp1);
 #pragma unroll
     for (int q = 0; q < D; ++q) e0[q] = q == 0 ? 1.f : 0.f;
     Sig0::template bx1<float>(e0, x2s0, wp0, B0);
+    // x2s0 is needed again for the second layer's per-atom vector: parked in the wave's LDS slot until then
+#pragma unroll
+    for (int j = 0; j < D; ++j) sX0[j * 64 + lane] = x2s0[j];
     if (h == 0) {
 #pragma unroll
       for (int a = 0; a < D; ++a) sB[a * 64 + lane] = B0[a];
@@ -498,7 +506,10 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
 #pragma unroll
       for (int j = 0; j < D; ++j) A.x2s1[(atom * D + j) * 64 + lane] = x2s1[j];
     }
-    float one[1] = {1.f}, v[D], B1[D];
+    float one[1] = {1.f}, v[D], B1[D], x2s0[D], wp0[Sig0::P], wp1[Sig1::P];
+    load_wp(wp0, wp1);
+#pragma unroll
+    for (int j = 0; j < D; ++j) x2s0[j] = sX0[j * 64 + lane];
     Sig1::template bx1<float>(one, x2s1, wp1, v);
     Sig0::template bx1<float>(v, x2s0, wp0, B1);
     if (h == 0) {
@@ -577,7 +588,7 @@ __global__ __launch_bounds__(256) void fused16_fill_energy_kernel(int64_t N, int
 }
 
 size_t fused16_lds_bytes(int num_types) {
-  return sizeof(u32x4) * 2 * kWStep + sizeof(float) * (64 + 16 + size_t(num_types) * num_types * 512 + 4 * kSlotFloats);
+  return sizeof(u32x4) * 2 * kWStep + sizeof(float) * (64 + 16 + size_t(num_types) * num_types * 512 + 4 * kSlotFloats + 8 * 9 * 64);
 }
 
 int launch_fused16_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {

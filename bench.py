@@ -68,6 +68,8 @@ def make_workload(name):
     if w["kind"] == "si":
         g = G.make_si_graph(w["cells"])
         cfg = si_model_cfg(g.num_edges / g.num_atoms)
+        if os.environ.get("AA_BENCH_LMAX"):  # experiments only: the same box and widths at another l_max
+            cfg["l_max"] = int(os.environ["AA_BENCH_LMAX"])
     else:
         g = G.make_water_graph(w["side"], w["box"])
         cfg = water_model_cfg(g.num_edges / g.num_atoms)
