@@ -36,6 +36,33 @@ class ModelConfig(C.Structure):
                 ("act_kind", C.c_int32 * 3), ("act_consts", C.c_double * 3)]
 
 
+class PlanOptions(C.Structure):
+    """`aa_plan_options`: kernel-selection switches for A/B measurements and tests (all zero = defaults)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "tp_generic", "tp_no_chain", "tp_no_moments", "tp_no_operator", "tp_force_operator", "tp_operator_fused",
+        "gemm_no_chain", "gemm_fp32_mfma", "gemm_valu", "gemm_v1", "gemm_lds_epilogue", "f64_column_loop",
+        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block")]
+
+
+def options_from_env() -> PlanOptions:
+    """The library itself never reads the environment; this host-side mapping keeps the AA_* variables of the
+    measurement scripts and tests working (read when a model's plan is created)."""
+    env = os.environ
+    flag = lambda k: int(env.get(k, "0")[:1] == "1")  # noqa: E731
+    o = PlanOptions()
+    o.tp_generic, o.tp_no_chain, o.tp_no_moments = flag("AA_TP_GENERIC"), flag("AA_TP_NOCHAIN"), flag("AA_TP_NOMOM")
+    o.tp_no_operator, o.tp_force_operator, o.tp_operator_fused = flag("AA_TP_NOOP"), flag("AA_TP_OP"), flag("AA_OP_NOSPLIT")
+    o.gemm_no_chain, o.gemm_fp32_mfma, o.gemm_valu, o.gemm_v1 = (flag("AA_GEMM_NOCHAIN"), flag("AA_GEMM_FP32_MFMA"),
+                                                                 flag("AA_GEMM_VALU"), flag("AA_GEMM_V1"))
+    o.gemm_lds_epilogue = int(env.get("AA_GEMM_DIRECT_EPILOGUE", "1")[:1] == "0")
+    o.f64_column_loop = {"0": 1, "2": 2}.get(env.get("AA_F64_NLOOP", "1")[:1], 0)
+    o.embed_no_fuse = flag("AA_EMBED_NOFUSE")
+    o.fused_forward = {"1": 1, "2": 2}.get(env.get("AA_FUSED", "0")[:1], 0)
+    o.fused_recompute_w0 = flag("AA_FUSED_RECOMPUTE")
+    o.moments_waves_per_block = int(env.get("AA_MOM_WPB", "0") or 0)
+    return o
+
+
 class RawWeights(C.Structure):
     _fields_ = [("rmax_recip", _dp), ("bessel_weights", _dp), ("center_embed", _dp), ("neighbor_embed", _dp),
                 ("basis_linear", _dp), ("embed_mlp", _dp * AA_MAX_MLP_LAYERS), ("env_embed_linear", _dp),
@@ -91,6 +118,7 @@ class AllegroLib:
         L.aa_debug_gemm_f32.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_debug_gemm_f32.restype = C.c_int
         L.aa_model_plan_create.argtypes = [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]
+        L.aa_model_plan_create_with_options.argtypes = [C.POINTER(ModelConfig), C.POINTER(PlanOptions), C.POINTER(C.c_void_p)]
         L.aa_model_plan_destroy.argtypes = [C.c_void_p]
         L.aa_model_plan_destroy.restype = None
         L.aa_model_plan_enable_graph.argtypes = [C.c_void_p, C.c_int]
@@ -142,9 +170,10 @@ class AllegroLib:
                    "aa_tp_backward_weights")
 
     # -- model
-    def model_plan_create(self, cfg: ModelConfig) -> int:
+    def model_plan_create(self, cfg: ModelConfig, options: Optional[PlanOptions] = None) -> int:
         h = C.c_void_p()
-        self.check(self.lib.aa_model_plan_create(C.byref(cfg), C.byref(h)), "aa_model_plan_create")
+        opt = options if options is not None else options_from_env()
+        self.check(self.lib.aa_model_plan_create_with_options(C.byref(cfg), C.byref(opt), C.byref(h)), "aa_model_plan_create")
         return h.value
 
     def model_plan_destroy(self, h):

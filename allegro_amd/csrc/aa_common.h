@@ -45,27 +45,15 @@ constexpr int kThreads = 256;
 // ---- cross-lane exchange primitives of gfx950 used by the wave reductions (VALU only, no LDS traffic).
 // v_permlane32_swap / v_permlane16_swap exchange the upper half (odd 16-lane rows) of `a` with the lower half
 // (even rows) of `b`.  They are issued as inline ISA: the compiler builtin of ROCm 7.2 returns the first result
-// for both outputs.  (The CPU emulator that tests/ compile these sources with supplies its own versions.)
-#ifdef AA_EMU_LANE_OPS
-__device__ __forceinline__ void permlane32_swap(float& a, float& b) { aa_emu_permlane_swap(a, b, 32); }
-__device__ __forceinline__ void permlane16_swap(float& a, float& b) { aa_emu_permlane_swap(a, b, 16); }
-#else
+// for both outputs.
+#ifndef AA_HAVE_LANE_OPS  // (a build may pre-define these four primitives itself: the test-only CPU emulation does)
 __device__ __forceinline__ void permlane32_swap(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void permlane16_swap(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
-#endif
 // four independent swaps in one block (one pair of hazard nops for all of them)
-#ifdef AA_EMU_LANE_OPS
-__device__ __forceinline__ void permlane32_swap4(float* a, float* b) {
-  for (int i = 0; i < 4; ++i) aa_emu_permlane_swap(a[i], b[i], 32);
-}
-__device__ __forceinline__ void permlane16_swap4(float* a, float* b) {
-  for (int i = 0; i < 4; ++i) aa_emu_permlane_swap(a[i], b[i], 16);
-}
-#else
 __device__ __forceinline__ void permlane32_swap4(float* a, float* b) {
   asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
       "v_permlane32_swap_b32 %3, %7\n\ts_nop 1"
@@ -205,6 +193,7 @@ struct GemmArgs {
   SegList add;
   int force_kernel;  // 0: automatic; 1: native fp32-input MFMA kernel; 3: VALU kernel (aa_debug_gemm_f32 / A-B tests)
   int act_kind;      // activation behind act_a / has_z (AA_ACT_*); anything but SiLU runs the general VALU kernel
+  int opt_v1, opt_lds_epilogue, opt_f64_column_loop;  // aa_plan_options pass-throughs (A/B switches)
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -436,6 +425,7 @@ struct TpMomArgs {
   void* g_a;            // reverse kernels: grad wrt the env input of the layer being reversed [E, ld_ga]
   int ld_ga;
   int ka_lds;           // row stride of the wave-private moment patch in LDS (set by the launcher: max(ka0, ka1))
+  int waves_per_block;  // 0 = 1 (aa_plan_options.moments_waves_per_block)
 };
 // Per-atom operator form of the tensor-product track for L <= 3 layers, u = 64*m (aa_tp_op.hip)
 struct TpOpArgs {

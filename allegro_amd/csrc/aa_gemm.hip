@@ -1502,25 +1502,12 @@ static int check_args(const GemmArgs& g) {
   return AA_OK;
 }
 
-static bool force_valu() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("AA_GEMM_VALU");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-
 template <>
 int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
   if (g.M == 0) return AA_OK;
   if (int rc = check_args(g)) return rc;
-  static int v1_only = -1;
-  if (v1_only < 0) {
-    const char* e = getenv("AA_GEMM_V1");
-    v1_only = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (force_valu() || g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
+  const bool v1_only = g.opt_v1 != 0;
+  if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
     size_t smem = sizeof(float) * (GV_BK * GV_LDA + GV_BK * GV_BN);
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
@@ -1534,19 +1521,10 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
       if (g.has_add && ((g.add.s[s].ld & 3) || (reinterpret_cast<uintptr_t>(g.add.s[s].p) & 15))) vec_ok = 0;
     }
     const int KC = (g.K + 31) / 32;
-    static int no_split = -1;
-    if (no_split < 0) {
-      const char* e = getenv("AA_GEMM_FP32_MFMA");
-      no_split = (e && e[0] == '1') ? 1 : 0;
-    }
-    static int direct_epi = -1;
-    if (direct_epi < 0) {
-      const char* e = getenv("AA_GEMM_DIRECT_EPILOGUE");  // A/B switch: 16-B per-lane epilogue without the LDS transpose
-      direct_epi = (e && e[0] == '0') ? 0 : 1;  // default: direct (the LDS-transposed variant measured slower)
-    }
+    const bool direct_epi = g.opt_lds_epilogue == 0;  // default: direct (the LDS-transposed variant measured slower)
     bool seg32 = true;
     for (int q = 0; q < g.a.count; ++q) seg32 = seg32 && (g.a.s[q].n % 32 == 0);
-    if (g.Bq && !no_split && g.force_kernel != 1 && seg32) {
+    if (g.Bq && g.force_kernel != 1 && seg32) {
       const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
       const bool lds = vec_ok && !direct_epi;
       const size_t smem = lds ? sizeof(float) * 4 * 32 * EP_LD : 0;
@@ -1588,15 +1566,13 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   for (int s2 = 0; s2 < g.a.count; ++s2)
     pipe_ok = pipe_ok && (g.a.s[s2].n % 16) == 0 && (g.a.s[s2].ld % 2) == 0 && (reinterpret_cast<uintptr_t>(g.a.s[s2].p) & 15) == 0;
   for (int s2 = 0; s2 < g.c.count; ++s2) pipe_ok = pipe_ok && (g.c.s[s2].n % 16) == 0;
-  if (force_valu() || g.act_kind != AA_ACT_SILU) {
+  if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok) {
     dim3 grid6((unsigned)((g.M + G6_BM - 1) / G6_BM), (unsigned)((g.N + G6_BN - 1) / G6_BN));
     // enough row tiles to fill the chip on their own: one workgroup per row tile looping over the column tiles
-    // (AA_F64_NLOOP=0: never, 2: always -- tests)
-    const char* ev = getenv("AA_F64_NLOOP");
-    const int f64_loop = ev ? atoi(ev) : 1;
-    if (f64_loop == 2 || (f64_loop == 1 && grid6.x >= 2048)) grid6.y = 1;
+    // (aa_plan_options.f64_column_loop: 1 never, 2 always -- tests)
+    if (g.opt_f64_column_loop == 2 || (g.opt_f64_column_loop == 0 && grid6.x >= 2048)) grid6.y = 1;
     const size_t smem6 = sizeof(double) * 2 * (G6_BK * G6_LDA + G6_BK * G6_BN);
     hipLaunchKernelGGL(gemm_mfma_f64_pipe_kernel, grid6, dim3(256), smem6, stream, g);
   } else {

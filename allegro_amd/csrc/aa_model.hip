@@ -128,6 +128,7 @@ struct MlpLayout {
 
 struct aa_model_plan {
   aa_model_config cfg;
+  aa_plan_options opt{};
   int D, R, W, SL1;  // SH dim, irreps, env weight numel, S*(L+1)
   std::vector<std::vector<int32_t>> keep_i32;
   std::vector<std::vector<double>> keep_f64;
@@ -181,7 +182,12 @@ static std::vector<int> mlp_dims(int in, int depth, int width, int out) {
 }
 
 extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out) {
+  return aa_model_plan_create_with_options(cfg, nullptr, out);
+}
+
+extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, const aa_plan_options* options, aa_model_plan** out) {
   AA_REQUIRE(cfg && out, "aa_model_plan_create: null argument");
+  const aa_plan_options opt = options ? *options : aa_plan_options{};
   AA_REQUIRE(cfg->dtype == AA_F32 || cfg->dtype == AA_F64, "model: bad dtype");
   AA_REQUIRE(cfg->l_max >= 1 && cfg->l_max <= 3, "model: l_max must be 1..3");
   for (int i = 0; i < 3; ++i) AA_REQUIRE(cfg->act_kind[i] >= AA_ACT_SILU && cfg->act_kind[i] <= AA_ACT_NONE, "model: unknown nonlinearity");
@@ -193,6 +199,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
              "model: bad embedding sizes");
   aa_model_plan* p = new aa_model_plan();
   p->cfg = *cfg;
+  p->opt = opt;
   const int L = cfg->num_layers, S = cfg->num_scalar, u = cfg->num_tensor;
   p->R = cfg->l_max + 1;
   p->D = p->R * p->R;
@@ -217,34 +224,29 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
     p->cfg.tps[l].nz_val = nullptr;
   }
   {
-    const char* e = getenv("AA_TP_GENERIC");
-    p->use_spec = !(e && e[0] == '1');
+    p->use_spec = !opt.tp_generic;
     for (int l = 0; l < L; ++l) p->use_spec = p->use_spec && p->spec_sig[l] >= 0;
     // fp64 at l_max=3 does not fit the register file (256 VGPR + 256 AGPR + 1.9 KB scratch per lane, and
     // wrong results on hardware in round 1): keep it on the general LDS-table kernels for now
     if (cfg->dtype == AA_F64 && cfg->l_max >= 3) p->use_spec = false;
     p->chain_pair = -1;
-    const char* nc = getenv("AA_TP_NOCHAIN");
-    if (p->use_spec && L == 2 && !(nc && nc[0] == '1')) p->chain_pair = find_chain_pair(p->spec_sig[0], p->spec_sig[1]);
-    const char* nm = getenv("AA_TP_NOMOM");
+    if (p->use_spec && L == 2 && !opt.tp_no_chain) p->chain_pair = find_chain_pair(p->spec_sig[0], p->spec_sig[1]);
     const int Dsh = (cfg->l_max + 1) * (cfg->l_max + 1);
     // every fused fast path below has SiLU built in; the other nonlinearities run the general kernels
     const bool all_silu = cfg->act_kind[0] == AA_ACT_SILU && cfg->act_kind[1] == AA_ACT_SILU && cfg->act_kind[2] == AA_ACT_SILU;
     p->env_mom = all_silu && p->chain_pair >= 0 && u == 64 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
                  (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) &&
                  (cfg->dtype == AA_F32 ? 4 : 8) * 4 * Dsh * (std::max(S, cfg->latent_mlp_width) + 64 + 64) <= 160 * 1024 &&
-                 !(nm && nm[0] == '1');
+                 !opt.tp_no_moments;
     // per-atom operator kernels: every standard stack the tuned 2-layer/u=64 kernels above do not cover (and, with
     // AA_TP_OP=1, those too); they need the channel-minor layouts of the specialised path but none of its kernels,
     // so fp64 at l_max = 3 is fine here
     p->tp_op = -1;
-    const char* no_op = getenv("AA_TP_NOOP");
-    const char* force_op = getenv("AA_TP_OP");
-    bool sigs_ok = !(e && e[0] == '1');
+    bool sigs_ok = !opt.tp_generic;
     for (int l = 0; l < L; ++l) sigs_ok = sigs_ok && p->spec_sig[l] >= 0;
     if (all_silu && sigs_ok && L >= 2 && L <= 3 && (u % 64) == 0 && u <= 256 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
-        (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) && !(nm && nm[0] == '1') && !(no_op && no_op[0] == '1') &&
-        (!p->env_mom || (force_op && force_op[0] == '1'))) {
+        (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) && !opt.tp_no_moments && !opt.tp_no_operator &&
+        (!p->env_mom || opt.tp_force_operator)) {
       const int chain = find_op_chain(p->spec_sig, L);
       if (chain >= 0) {
         p->tp_op = chain;
@@ -268,7 +270,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->o_basis = take(size_t(B) * S0);
   AA_REQUIRE(cfg->embed_kind == 0 || (cfg->embed_kind == 1 && cfg->spline_span >= 0 && cfg->spline_span <= B),
              "model: embed_kind must be 0 (Bessel) or 1 (spline, 0 <= span <= num_splines)");
-  const bool fused16 = getenv("AA_FUSED") && getenv("AA_FUSED")[0] == '2';
+  const bool fused16 = opt.fused_forward == 2;
   auto lay = [&](MlpLayout& m, const std::vector<int>& dims, int nlayers) {
     m.dims = dims;
     for (int i = 0; i < nlayers; ++i) {
@@ -283,13 +285,10 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   };
   lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
   {
-    const char* ncg = getenv("AA_GEMM_NOCHAIN");
-    const char* f32 = getenv("AA_GEMM_FP32_MFMA");
-    const char* vl = getenv("AA_GEMM_VALU");
     p->chain_gemm = p->env_mom && (p->tp_op < 0 || u == 64) && cfg->dtype == AA_F32 && S == 64 && cfg->embed_mlp_depth == 1 &&
                     cfg->embed_mlp_width == 64 && cfg->latent_mlp_depth == 1 && cfg->latent_mlp_width == 64 &&
                     cfg->readout_mlp_depth == 1 && cfg->readout_mlp_width == 64 && cfg->embed_dim % 32 == 0 &&
-                    !(ncg && ncg[0] == '1') && !(f32 && f32[0] == '1') && !(vl && vl[0] == '1');
+                    !opt.gemm_no_chain && !opt.gemm_fp32_mfma && !opt.gemm_valu;
   }
   p->ng0 = p->env_mom ? S + p->W : S + 2 * p->W;
   p->o_g0 = take(size_t(S) * p->ng0);
@@ -319,8 +318,7 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   }
   p->o_b3a_q = p->o_b3b_q = p->o_b3c_q = 0;
   {
-    const char* nf = getenv("AA_EMBED_NOFUSE");
-    p->embed_fused = p->chain_gemm && T <= 2 && B == 8 && S0 == 64 && !(nf && nf[0] == '1');
+    p->embed_fused = p->chain_gemm && T <= 2 && B == 8 && S0 == 64 && !opt.embed_no_fuse;
     p->o_embtab = (p->embed_fused || cfg->embed_kind == 1) ? take(size_t(T) * T * B * S0) : 0;
   }
   if (p->chain_gemm) {
@@ -335,15 +333,14 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   p->n_elems = o;
   {
     // fused per-atom-tile forward (aa_fused.hip): the standard 2-layer 64-wide fp32 stack with the two-body table in
-    // LDS.  OPT-IN (AA_FUSED=1): correct (same parity tests as the staged pipeline) but measured SLOWER than the staged
+    // LDS.  OPT-IN (aa_plan_options.fused_forward): correct (same parity tests as the staged pipeline) but measured SLOWER than the staged
     // forward on MI355X -- 6.3-8.7 ms vs 5.5 ms at C4 -- because its register / LDS footprint allows one wave per
     // SIMD only and a single wave cannot hide its own LDS / MFMA / L2 latencies (profiles/r02_v5_*)
-    const char* fu = getenv("AA_FUSED");
     p->fused_fwd = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 && (fu && (fu[0] == '1' || fu[0] == '2'));
-    p->fused_mode = (fu && fu[0] == '2') ? 2 : 1;
-    const char* rc = getenv("AA_FUSED_RECOMPUTE");  // A/B: recompute w0 for the second layer instead of holding it
-    p->fused_hold_w0 = !(rc && rc[0] == '1');
+                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 &&
+                   (opt.fused_forward == 1 || opt.fused_forward == 2);
+    p->fused_mode = opt.fused_forward == 2 ? 2 : 1;
+    p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
   }
   *out = p;
   return AA_OK;
@@ -763,6 +760,10 @@ struct Runner {
     if (z) g.z = *z;
     g.act_a = act_a;
     g.act_kind = act_now;
+    g.force_kernel = p->opt.gemm_valu ? 3 : (p->opt.gemm_fp32_mfma ? 1 : 0);
+    g.opt_v1 = p->opt.gemm_v1;
+    g.opt_lds_epilogue = p->opt.gemm_lds_epilogue;
+    g.opt_f64_column_loop = p->opt.f64_column_loop;
     g.has_add = add ? 1 : 0;
     if (add) g.add = *add;
     if (int rc = launch_gemm<T>(g, stream)) return rc;
@@ -966,6 +967,7 @@ struct Runner {
     m.wt0 = wt(p->o_wt[0]);
     m.wk1 = wt(p->o_wk[1]);
     m.wt1 = wt(p->o_wt[1]);
+    m.waves_per_block = p->opt.moments_waves_per_block;
     return m;
   }
 
@@ -1003,8 +1005,8 @@ struct Runner {
     o.q = buf(w.q_op);
     o.num_layers = c.num_layers;
     {
-      // split form (default): per-atom vectors through HBM, edge loops in lean kernels (AA_OP_NOSPLIT=1: fused form)
-      static const bool nosplit = getenv("AA_OP_NOSPLIT") && getenv("AA_OP_NOSPLIT")[0] == '1';
+      // split form (default): per-atom vectors through HBM, edge loops in lean kernels (tp_operator_fused: fused form)
+      const bool nosplit = p->opt.tp_operator_fused != 0;
       o.bvec = (!nosplit && w.bvec_op) ? buf(w.bvec_op) : nullptr;
       o.gmbuf = (!nosplit && w.bvec_op && w.gm_op) ? buf(w.gm_op) : nullptr;
       o.mbuf = (!nosplit && w.mom_op) ? buf(w.mom_op) : nullptr;

@@ -1346,7 +1346,7 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream) {
       return fail(AA_ERR_INVALID, #NAME ": needs u == 64 and env-input widths of 64 or 128");            \
     /* one wave per atom and no inter-wave cooperation: single-wave workgroups give the dispatcher the finest    \
        granularity (shorter tail on small boxes / per-rank shards) */                                            \
-    static const int wpb = getenv("AA_MOM_WPB") ? std::max(1, std::min(4, atoi(getenv("AA_MOM_WPB")))) : 1;     \
+    const int wpb = std::max(1, std::min(4, a.waves_per_block));                                                 \
     if (a.c.N <= a.c.atom0) return AA_OK;                                                                \
     dim3 grid((unsigned)((a.c.N - a.c.atom0 + wpb - 1) / wpb));                                          \
     const int dpair = pair == 0 ? 4 : (pair == 1 ? 9 : 16);                                              \

@@ -53,6 +53,8 @@ def water_model_cfg(avg_nn):
 
 
 WORKLOADS = {
+    # BASELINE config 0 (configs/tutorial.yaml hyper-parameters on the 64-atom Si cell: l_max=1, 2 layers, 32 tensor features)
+    "c1": dict(kind="si", cells=2, dtype="float32", l_max=1, u=32, desc="Si 2^3 cells (64 atoms), l_max=1, L=2, u=32 (tutorial.yaml)"),
     "c2": dict(kind="si", cells=2, dtype="float32", desc="Si 2^3 cells (64 atoms), l_max=2, L=2, u=64"),
     "c3": dict(kind="si", cells=11, dtype="float32", desc="bulk Si 11^3 cells (10 648 atoms), r_cut 5 A, l_max=2, L=2, u=64"),
     "c4": dict(kind="si", cells=23, dtype="float32", desc="bulk Si 23^3 cells (97 336 atoms), r_cut 5 A, l_max=2, L=2, u=64"),
@@ -68,6 +70,8 @@ def make_workload(name):
     if w["kind"] == "si":
         g = G.make_si_graph(w["cells"])
         cfg = si_model_cfg(g.num_edges / g.num_atoms)
+        cfg["l_max"] = w.get("l_max", cfg["l_max"])
+        cfg["num_tensor_features"] = w.get("u", cfg["num_tensor_features"])
         if os.environ.get("AA_BENCH_LMAX"):  # experiments only: the same box and widths at another l_max
             cfg["l_max"] = int(os.environ["AA_BENCH_LMAX"])
     else:

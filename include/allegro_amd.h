@@ -169,7 +169,30 @@ typedef struct {
 
 typedef struct aa_model_plan aa_model_plan;
 
+/* Kernel-selection switches for A/B measurements and tests.  The library never reads the environment: a host that
+ * wants switches passes them here (allegro_amd/_lib.py maps the AA_* environment variables of the Python host onto
+ * this struct).  All zero = the defaults the plan would choose itself. */
+typedef struct {
+  int32_t tp_generic;      /* table-driven tensor-product kernels instead of the compile-time-CG ones          */
+  int32_t tp_no_chain;     /* no 2-layer chain kernels                                                          */
+  int32_t tp_no_moments;   /* no moments / per-atom operator kernels                                            */
+  int32_t tp_no_operator;  /* no per-atom operator kernels (aa_tp_op.hip)                                       */
+  int32_t tp_force_operator; /* operator kernels also where the 2-layer u = 64 kernels apply                   */
+  int32_t tp_operator_fused; /* operator kernels in fused (not split) form                                      */
+  int32_t gemm_no_chain;   /* single-layer linear kernels instead of the fused chains                           */
+  int32_t gemm_fp32_mfma;  /* native fp32-input MFMA instead of bf16x3                                          */
+  int32_t gemm_valu;       /* VALU linear layers                                                                */
+  int32_t gemm_v1;         /* first-generation fp32 MFMA kernel                                                 */
+  int32_t gemm_lds_epilogue; /* LDS-transposed epilogue in the single-layer bf16x3 kernel                       */
+  int32_t f64_column_loop; /* fp64 linear layers: 0 automatic, 1 never, 2 always walk all column tiles per workgroup */
+  int32_t embed_no_fuse;   /* reverse pass: materialise d(two-body embedding)                                   */
+  int32_t fused_forward;   /* 0 staged pipeline; 1 fused forward, 32-edge tiles; 2 fused forward, 16-edge tiles */
+  int32_t fused_recompute_w0; /* fused forward: recompute w0 for the second layer instead of holding it         */
+  int32_t moments_waves_per_block; /* 0 = 1                                                                      */
+} aa_plan_options;
+
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);
+int aa_model_plan_create_with_options(const aa_model_config* cfg, const aa_plan_options* options, aa_model_plan** out);
 void aa_model_plan_destroy(aa_model_plan* plan);
 /* on != 0: aa_model_energy_forces captures its launch sequence into a hipGraph the first time it sees a set of
  * arguments (all pointers and sizes) and replays it with one hipGraphLaunch afterwards -- for launch-bound (small)
