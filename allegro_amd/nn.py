@@ -272,9 +272,17 @@ class HipContracter(torch.nn.Module):
             scatter_dim_size = int(scatter_dim_size.reshape(-1)[0])
         x1 = x1.reshape(-1, self.mul, self.base_dim1)
         x2 = x2.reshape(-1, self.mul, self.base_dim2)
+        sf = 1.0 if self.scatter_factor is None else float(self.scatter_factor)
+        if self.training and torch.is_grad_enabled():
+            # training: scale + scatter + gather as differentiable torch ops around the arbitrarily differentiable
+            # contraction (ops.contract_differentiable) -- a force-matching loss differentiates the forces again.
+            # (The reference's accelerated contracters make the same split: fused kernel in eval mode, the general
+            # formulation when training, _flashallegro.py:725-755.)
+            x2s = torch.zeros((int(scatter_dim_size),) + tuple(x2.shape[1:]), dtype=x2.dtype, device=x2.device)
+            x2s = x2s.index_add(0, idxs.reshape(-1), sf * x2)
+            return self._contract(x1, x2s.index_select(0, idxs.reshape(-1)))
         # per-call host sync / bincount / cumsum only on the first layer of the first forward with this index tensor
         rowptr, eids = _SEGMENTS.get(idxs, scatter_dim_size, self.assume_sorted_idxs)
-        sf = 1.0 if self.scatter_factor is None else float(self.scatter_factor)
         return self._op(x1, x2, rowptr, eids, int(scatter_dim_size), sf)
 
     def _op(self, x1, x2, rowptr, eids, num_atoms: int, scatter_factor: float):
@@ -289,10 +297,12 @@ class HipContracter(torch.nn.Module):
         return out
 
     def _contract(self, x1, x2):
-        """Contraction only (seam B1, _contract.py:213): every edge is its own segment."""
-        E = x1.shape[0]
-        rowptr = torch.arange(E + 1, dtype=torch.int32, device=x1.device)
-        return self._op(x1, x2, rowptr, None, E, 1.0)
+        """Contraction only (seam B1, _contract.py:213): every edge is its own segment.  Differentiable to any order
+        (x1, x2 and the path weights)."""
+        _require_gpu(self._get_lib(), x1, "HipContracter")
+        with _device_ctx(x1.device):
+            return ops.contract_differentiable(x1, x2, self.weights, self._plan(x1.dtype, x1.device), self._lib_id,
+                                               self.base_dim1, self.base_dim2, self.base_dim_out)
 
     @classmethod
     def from_contracter(cls, old: torch.nn.Module) -> "HipContracter":

@@ -135,3 +135,119 @@ def _backward(ctx, gout, _gx2s):
 
 
 tp_forward.register_autograd(_backward, setup_context=_setup_context)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Training path: arbitrarily differentiable contraction
+# ------------------------------------------------------------------------------------------------------------------
+# The contraction is one trilinear form  T(a, b, c; w) = sum_p w[ch,p] sum_nz C_nz a_i b_j c_k  per (edge, channel)
+# (a = x1, b = x2 gathered per edge, c = the cotangent of the output).  The forward, both input gradients and the
+# path-weight gradient are its four partial contractions, and the derivative of any of them with respect to any
+# operand is again one of the four with operands substituted -- so a family of four mutually recursive
+# autograd Functions, each one launch of a kernel that already exists (`aa_tp_forward` / `aa_tp_backward` /
+# `aa_tp_backward_weights` with every edge as its own segment), is differentiable to any order.  That is what a
+# force-matching loss needs (forces are first derivatives; the loss differentiates them again with respect to the
+# weights), i.e. what the reference gets from autograd through its eager Contracter in training mode
+# (allegro/nn/_strided/_contract.py:213-251; its Triton op has no second-order formula and falls back to eager,
+# _flashallegro.py:725-755).  The scale + scatter + gather around the contraction (_contract.py:195-205) are plain
+# differentiable torch ops in this path.
+class _TriCtx:
+    """Static description shared by the four functions: plan handle, library id, dims."""
+
+    def __init__(self, plan: int, lib_id: int, d1: int, d2: int, dout: int):
+        self.plan, self.lib_id, self.d1, self.d2, self.dout = plan, lib_id, d1, d2, dout
+
+
+def _edge_rowptr(E: int, device) -> torch.Tensor:
+    return torch.arange(E + 1, dtype=torch.int32, device=device)
+
+
+def _raw_out(t: _TriCtx, a, b, w):  # [E,u,dout]
+    E = a.shape[0]
+    out, _ = torch.ops.allegro_amd.tp_forward(a.detach(), b.detach(), w.detach(), _edge_rowptr(E, a.device), None, E, 1.0,
+                                              t.plan, t.lib_id, t.d2, t.dout)
+    return out
+
+
+def _raw_in_grads(t: _TriCtx, c, a, b, w):  # (d/d a [E,u,d1], d/d b [E,u,d2])
+    E = a.shape[0]
+    return torch.ops.allegro_amd.tp_backward(c.detach(), a.detach(), b.detach(), w.detach(), _edge_rowptr(E, a.device), None, E,
+                                             1.0, t.plan, t.lib_id)
+
+
+def _raw_wgrad(t: _TriCtx, c, a, b, w_like):  # [shape of w]
+    E = a.shape[0]
+    return torch.ops.allegro_amd.tp_backward_weights(c.detach(), a.detach(), b.detach(), w_like.detach(),
+                                                     _edge_rowptr(E, a.device), None, E, t.plan, t.lib_id)
+
+
+class _TriK(torch.autograd.Function):
+    """out[k] = T with (a, b) filled."""
+
+    @staticmethod
+    def forward(ctx, a, b, w, t):
+        ctx.t = t
+        ctx.save_for_backward(a, b, w)
+        return _raw_out(t, a, b, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, w = ctx.saved_tensors
+        t = ctx.t
+        return _TriI.apply(g, b, w, t), _TriJ.apply(g, a, w, t), _TriW.apply(g, a, b, w, t), None
+
+
+class _TriI(torch.autograd.Function):
+    """[i]: T with (c, b) filled (the x1 gradient)."""
+
+    @staticmethod
+    def forward(ctx, c, b, w, t):
+        ctx.t = t
+        ctx.save_for_backward(c, b, w)
+        a0 = torch.zeros((c.shape[0], c.shape[1], t.d1), dtype=c.dtype, device=c.device)
+        return _raw_in_grads(t, c, a0, b, w)[0]
+
+    @staticmethod
+    def backward(ctx, h):
+        c, b, w = ctx.saved_tensors
+        t = ctx.t
+        return _TriK.apply(h, b, w, t), _TriJ.apply(c, h, w, t), _TriW.apply(c, h, b, w, t), None
+
+
+class _TriJ(torch.autograd.Function):
+    """[j]: T with (c, a) filled (the gradient of the gathered x2)."""
+
+    @staticmethod
+    def forward(ctx, c, a, w, t):
+        ctx.t = t
+        ctx.save_for_backward(c, a, w)
+        b0 = torch.zeros((c.shape[0], c.shape[1], t.d2), dtype=c.dtype, device=c.device)
+        return _raw_in_grads(t, c, a, b0, w)[1]
+
+    @staticmethod
+    def backward(ctx, h):
+        c, a, w = ctx.saved_tensors
+        t = ctx.t
+        return _TriK.apply(a, h, w, t), _TriI.apply(c, h, w, t), _TriW.apply(c, a, h, w, t), None
+
+
+class _TriW(torch.autograd.Function):
+    """[u,P] / [P]: T with (c, a, b) filled, summed over edges (and channels when uncoupled)."""
+
+    @staticmethod
+    def forward(ctx, c, a, b, w_like, t):
+        ctx.t = t
+        ctx.save_for_backward(c, a, b)
+        return _raw_wgrad(t, c, a, b, w_like)
+
+    @staticmethod
+    def backward(ctx, hw):
+        c, a, b = ctx.saved_tensors
+        t = ctx.t
+        return _TriK.apply(a, b, hw, t), _TriI.apply(c, b, hw, t), _TriJ.apply(c, a, hw, t), None, None
+
+
+def contract_differentiable(x1: torch.Tensor, x2_gathered: torch.Tensor, weights: torch.Tensor, plan: int, lib_id: int,
+                            d1: int, d2: int, dout: int) -> torch.Tensor:
+    """`Contracter._contract(x1, x2)` (allegro/nn/_strided/_contract.py:213-251) with derivatives of every order."""
+    return _TriK.apply(x1.contiguous(), x2_gathered.contiguous(), weights, _TriCtx(plan, lib_id, d1, d2, dout))

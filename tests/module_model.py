@@ -64,5 +64,5 @@ class ModuleAllegro(torch.nn.Module):
             sd[f"allegro.tps.{l}.w3j"], sd[f"allegro.tps.{l}.weights"] = c.w3j, c.weights
         e_atom = R.allegro_energy(self.cfg, sd, pos, data["edge_index"], data["atom_types"], shift_vec,
                                   contracters=list(self.func.allegro.tps))
-        (g,) = torch.autograd.grad(e_atom.sum(), pos, create_graph=False, retain_graph=self.training)
+        (g,) = torch.autograd.grad(e_atom.sum(), pos, create_graph=self.training)  # training: forces stay differentiable
         return {"atomic_energy": e_atom, "total_energy": e_atom.sum().reshape(1, 1), "forces": -g}

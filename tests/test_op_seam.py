@@ -111,10 +111,14 @@ def _check_modifier_on_module_model(dtype, tol, dev, lib):
     check(model(data, sv))  # the stand-in itself reproduces the reference
     keys = list(model.state_dict().keys())
     n_before = sum(isinstance(mm, EagerContracter) for mm in model.modules())
-    # energy-only training signal of the eager model (what the swapped one must reproduce)
+    # training signal of the eager model (what the swapped one must reproduce): an energy + force-matching loss, i.e.
+    # second-order derivatives through every Contracter
+    def train_loss(m):
+        out = m(data, sv)
+        return (out["atomic_energy"] ** 2).sum() + (out["forces"] ** 2).sum()
+
     model.train()
-    e = model(data, sv)["atomic_energy"]
-    want_gw = torch.autograd.grad((e * e).sum(), [c.weights for c in model.func.allegro.tps])
+    want_gw = torch.autograd.grad(train_loss(model), [c.weights for c in model.func.allegro.tps])
     model.eval()
     model = enable_HipContracter(model)
     swapped = [mm for mm in model.modules() if isinstance(mm, HipContracter)]
@@ -125,9 +129,8 @@ def _check_modifier_on_module_model(dtype, tol, dev, lib):
         for mm in swapped:
             mm._bind_library(lib)
     check(model(data, sv))
-    model.train()  # training mode: same kernels, plus the path-weight gradient
-    e = model(data, sv)["atomic_energy"]
-    got_gw = torch.autograd.grad((e * e).sum(), [c.weights for c in model.func.allegro.tps])
+    model.train()  # training mode: the arbitrarily differentiable contraction, path-weight gradients included
+    got_gw = torch.autograd.grad(train_loss(model), [c.weights for c in model.func.allegro.tps])
     for a, b in zip(got_gw, want_gw):
         assert (a - b).abs().max().item() <= 20 * tol * max(1.0, float(b.abs().max()))
 
@@ -172,10 +175,48 @@ def test_nequip_extension_registers_the_modifier_on_the_reference_contracter():
     assert isinstance(net[0], HipContracter)
 
 
-def test_double_backward_through_the_op_fails_loudly():
-    """Force-matching training differentiates the x1/x2 gradients again; the op registers no second-order formula and
-    must say so instead of returning silently wrong (zero) gradients."""
+@pytest.mark.parametrize("coupling", [True, False])
+def test_training_mode_is_differentiable_to_second_order(coupling):
+    """Training mode (`.train()`): a force-matching style loss -- a function of the first derivatives wrt x1, differentiated
+    again wrt the path weights and both inputs -- equals the eager oracle (autograd through the reference's formulation,
+    _contract.py:185-251) in value and in all gradients; plus gradcheck / gradgradcheck of the contraction itself."""
+    from oracle import restatement as R
+
+    torch.manual_seed(0)
+    c = HipContracter("0e + 1o + 2e", "0e + 1o + 2e", "0e + 1o + 2e", mul=3, path_channel_coupling=coupling,
+                      scatter_factor=0.3).double()
+    c._bind_library(emu_lib())
+    c.train()
+    E, N = 9, 4
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(E, 3, 9, dtype=torch.float64, generator=g, requires_grad=True)
+    x2 = torch.randn(E, 3, 9, dtype=torch.float64, generator=g, requires_grad=True)
+    idx = torch.randint(0, N, (E,), generator=g)
+
+    def loss(fwd, w):
+        y = fwd(x1, x2, w)
+        (g1,) = torch.autograd.grad(y.square().sum(), x1, create_graph=True)  # "forces"
+        return (g1 ** 2).sum() + y.sum()
+
+    l_hip = loss(lambda a, b, w: c(a, b, idx, N), c.weights)
+    got = torch.autograd.grad(l_hip, [c.weights, x1, x2])
+    w_ref = c.weights.detach().clone().requires_grad_(True)
+    l_ref = loss(lambda a, b, w: R.contracter_forward(a, b, idx, N, w, c.w3j, coupling, 0.3), w_ref)
+    want = torch.autograd.grad(l_ref, [w_ref, x1, x2])
+    assert abs(float(l_hip.detach() - l_ref.detach())) < 1e-10 * max(1.0, abs(float(l_ref.detach())))
+    for a, b in zip(got, want):
+        assert (a - b).abs().max().item() < 1e-9 * max(1.0, float(b.abs().max()))
+    xs = (x1[:4].detach().requires_grad_(True), x2[:4].detach().requires_grad_(True))
+    assert torch.autograd.gradcheck(lambda a, b: c._contract(a, b), xs, eps=1e-6, atol=1e-7, rtol=1e-6)
+    assert torch.autograd.gradgradcheck(lambda a, b: c._contract(a, b), xs, eps=1e-6, atol=1e-6, rtol=1e-5)
+
+
+def test_double_backward_through_the_inference_op_fails_loudly():
+    """Eval mode runs the fused inference op (scale + scatter + gather + contraction in one kernel, first-order autograd
+    for forces).  It registers no second-order formula and must say so instead of returning silently wrong gradients;
+    second order is what training mode is for (test above)."""
     c = _contracter()
+    c.eval()
     g = torch.Generator().manual_seed(4)
     x1 = torch.randn(5, 4, 9, dtype=torch.float64, generator=g, requires_grad=True)
     x2 = torch.randn(5, 4, 9, dtype=torch.float64, generator=g, requires_grad=True)
