@@ -8,6 +8,6 @@ algorithms (real-basis Wigner 3j from su(2) Clebsch-Gordan + real<->complex
 change of basis; component-normalised real spherical harmonics with y as the
 polar axis) -- PARITY UNPINNED against e3nn itself: no e3nn golden vectors
 exist in /root/reference; the leaves are pinned by identities in
-tests/test_oracle_leaves.py.
+tests/test_conventions.py.
 """
 from . import o3  # noqa: F401

@@ -11,7 +11,7 @@ pyproject.toml:15-17; source NOT under /root/reference):
 su(2) Clebsch-Gordan coefficients come from sympy (exact rationals/surds), which
 is an independent source from the product's float Racah implementation
 (allegro_amd/o3.py).  PARITY UNPINNED vs e3nn (absent); pinned by identities in
-tests/test_oracle_leaves.py (norm 1, w3j(l,l,0)=delta/sqrt(2l+1), nnz counts of
+tests/test_conventions.py (norm 1, w3j(l,l,0)=delta/sqrt(2l+1), nnz counts of
 SURVEY.md §8c, joint SH/CG equivariance).
 """
 import functools

@@ -1,5 +1,5 @@
 """Export path: the whole step as one C++-registered dispatcher op behind the pair_allegro tensor
-contract `[pos, edge_index, atom_types] -> (atomic_energy, total_energy, forces)` (allegro/_compile.py:10-14).
+contract `[pos, edge_index, atom_types] -> (atomic_energy, total_energy, forces, virial)` (allegro/_compile.py:10-14).
 CPU: the extension builds and loads, `torch.export` captures the op through its Meta kernel, and there is no CPU
 kernel to fall back to.  GPU: the op reproduces `HipAllegroModel.energy_forces` (also for an unsorted edge list and
 from a re-loaded exported program)."""
@@ -24,7 +24,7 @@ def _exportable(name, dtype, device, lib=None):
 def test_native_op_is_registered_and_exportable():
     fx, m, data, sv, ex = _exportable("t_coupled", torch.float64, "cpu", emu_lib())
     schema = str(torch.ops.allegro_amd_native.energy_forces.default._schema)
-    assert "Tensor? shift_vec" in schema and "int[] config" in schema and "-> (Tensor, Tensor)" in schema
+    assert "Tensor? shift_vec" in schema and "int[] config" in schema and "-> (Tensor, Tensor, Tensor)" in schema
     ep = torch.export.export(ex, (data["pos"], data["edge_index"], data["atom_types"], sv))
     targets = [str(n.target) for n in ep.graph.nodes if n.op == "call_function"]
     assert any("allegro_amd_native.energy_forces" in t for t in targets), targets

@@ -16,11 +16,12 @@ from tests.golden_utils import load_model_fixture
 from tests.hip_utils import emu_lib, fixture_data, model_from_fixture
 
 
-@pytest.fixture(autouse=True, params=["1", "2"], ids=["tile32", "tile16"])
-def _opt_in(request, monkeypatch):
-    """AA_FUSED selects the fused forward when the plan is created (the first step of a model): 1 = one wave per atom
-    (32-edge tile, aa_fused.hip), 2 = two waves per atom (16-edge tiles, aa_fused16.hip)."""
-    monkeypatch.setenv("AA_FUSED", request.param)
+MODES = {"tile32": "1", "tile16": "2"}  # AA_FUSED: one wave per atom (aa_fused.hip) / two waves per atom (aa_fused16.hip)
+
+
+def _opt_in(monkeypatch, mode):
+    """AA_FUSED selects the fused forward when the plan is created (the first step of a model)."""
+    monkeypatch.setenv("AA_FUSED", MODES[mode])
 
 
 def _cfg(embed="bessel", coupling=True, l_max=2, seed=11, avg=9.0, scale_shift=True):
@@ -101,8 +102,11 @@ def _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev, blocks=None):
     return m, g
 
 
-@pytest.mark.parametrize("name", ["c2", "c2_spline", "c2_l1", "c2_uncoupled"])
-def test_fused_forward_matches_reference_golden_emulated(name):
+# (the CPU suite runs a cross-section of (tile form, fixture) pairs -- the emulated 64-wide model takes ~18 s per case;
+#  the GPU tests below run every combination)
+@pytest.mark.parametrize("mode,name", [("tile32", "c2_uncoupled"), ("tile16", "c2_spline"), ("tile16", "c2_l1")])
+def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch):
+    _opt_in(monkeypatch, mode)
     fx = load_model_fixture(name, torch.float32)
     m = model_from_fixture(fx, torch.float32, emu_lib())
     data, sv = fixture_data(fx, torch.float32)
@@ -113,8 +117,9 @@ def test_fused_forward_matches_reference_golden_emulated(name):
         assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("embed,coupling", [("bessel", True), ("spline", False)])
-def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(embed, coupling):
+@pytest.mark.parametrize("mode,embed,coupling", [("tile32", "bessel", True), ("tile16", "spline", False)])
+def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(mode, embed, coupling, monkeypatch):
+    _opt_in(monkeypatch, mode)
     pos, cell, ei, shift, types = _ragged()
     deg = np.bincount(ei[0], minlength=pos.shape[0])
     assert 20 <= deg.max() <= 32 and deg.min() == 0 and len(set(deg.tolist())) > 6, deg
@@ -122,7 +127,8 @@ def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(embed, coupling):
                        blocks=3)
 
 
-def test_degree_above_32_falls_back_to_the_staged_pipeline_emulated():
+def test_degree_above_32_falls_back_to_the_staged_pipeline_emulated(monkeypatch):
+    _opt_in(monkeypatch, "tile16")
     rng = np.random.default_rng(9)
     grid = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(3), indexing="ij"), -1).reshape(-1, 3)[:40]
     pos = grid * 0.7 + rng.uniform(-0.05, 0.05, size=(40, 3)) + 20.0
@@ -148,8 +154,10 @@ def test_degree_above_32_falls_back_to_the_staged_pipeline_emulated():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["tile32", "tile16"])
 @pytest.mark.parametrize("embed,coupling,l_max", [("bessel", True, 2), ("spline", False, 2), ("bessel", True, 1)])
-def test_fused_forward_ragged_graph_vs_fp64_oracle_on_gpu(embed, coupling, l_max):
+def test_fused_forward_ragged_graph_vs_fp64_oracle_on_gpu(mode, embed, coupling, l_max, monkeypatch):
+    _opt_in(monkeypatch, mode)
     pos, cell, ei, shift, types = _ragged(dims=(9, 9, 8), keep=0.93, seed=8)
     deg = np.bincount(ei[0], minlength=pos.shape[0])
     assert 24 <= deg.max() <= 32 and deg.min() == 0, (deg.max(), deg.min())
@@ -158,11 +166,14 @@ def test_fused_forward_ragged_graph_vs_fp64_oracle_on_gpu(embed, coupling, l_max
 
 
 @pytest.mark.gpu
-def test_fused_and_staged_forward_agree_on_gpu(monkeypatch):
-    """A/B on hardware: the same model and graph through the fused kernel (AA_FUSED=1 at plan creation) and through
-    the staged pipeline."""
+@pytest.mark.parametrize("mode", ["tile32", "tile16"])
+@pytest.mark.parametrize("name", ["c2", "c2_spline", "c2_l1", "c2_uncoupled"])
+def test_fused_and_staged_forward_agree_on_gpu(mode, name, monkeypatch):
+    """A/B on hardware: the same model and graph through the fused kernel (AA_FUSED at plan creation) and through
+    the staged pipeline, and both against the reference's golden vectors."""
+    _opt_in(monkeypatch, mode)
     dev = torch.device("cuda:0")
-    fx = load_model_fixture("c2", torch.float32)
+    fx = load_model_fixture(name, torch.float32)
     data, sv = fixture_data(fx, torch.float32, dev)
     m = model_from_fixture(fx, torch.float32, device=dev)
     g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)

@@ -52,12 +52,12 @@ def test_si_box_and_ghost_layout():
 
 
 def test_partition_covers_all_edges():
-    import bench
+    from allegro_amd.dist import partition_atoms
 
     g = G.make_si_graph(3)
     rowptr = G.csr_from_sorted_centers(g.edge_index[0], g.num_atoms)
     for parts in (1, 2, 4, 8):
-        cuts = bench.partition_atoms(rowptr, parts)
+        cuts = partition_atoms(rowptr, parts)
         assert cuts[0] == 0 and cuts[-1] == g.num_atoms and all(a <= b for a, b in zip(cuts, cuts[1:]))
         sizes = [rowptr[b] - rowptr[a] for a, b in zip(cuts, cuts[1:])]
         assert sum(sizes) == g.num_edges and max(sizes) - min(sizes) <= 2 * 28
