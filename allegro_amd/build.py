@@ -10,7 +10,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused16.hip", "aa_model.hip", "aa_nl.hip"]
+SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused16.hip", "aa_tp_mfma.hip", "aa_model.hip", "aa_nl.hip"]
 LIB_PATH = os.path.join(HERE, "liballegro_amd.so")
 TORCH_LIB_PATH = os.path.join(HERE, "liballegro_amd_torch.so")  # dispatcher op for torch.export / AOTI / C++ hosts
 

@@ -64,6 +64,12 @@ __device__ __forceinline__ void permlane16_swap4(float* a, float* b) {
       "v_permlane16_swap_b32 %3, %7\n\ts_nop 1"
       : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
 }
+// scheduling anchor: the value (a scalar or a register tuple) is final at this program point -- orders the arithmetic
+// that produced it against the neighbouring anchors and memory operations (emits no instruction)
+template <class V>
+__device__ __forceinline__ void anchor(V& v) {
+  asm volatile("" : "+v"(v)::"memory");
+}
 #endif
 // DPP lane pattern applied to v (fused by the compiler into the consuming VALU op)
 constexpr int kDppRowRor8 = 0x128, kDppRowRor4 = 0x124, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
@@ -427,6 +433,26 @@ struct TpMomArgs {
   int ka_lds;           // row stride of the wave-private moment patch in LDS (set by the launcher: max(ka0, ka1))
   int waves_per_block;  // 0 = 1 (aa_plan_options.moments_waves_per_block)
 };
+// Moments kernels with the first-layer x1 weights w0 = EDGE_EMBEDDING @ Wg recomputed on the matrix cores instead of
+// re-read from HBM (aa_tp_mfma.hip; fp32, u = S = latent width = 64, l_max <= 2)
+struct TpMfmaArgs {
+  int64_t N, atom0;      // atoms [atom0, N) are processed
+  const int32_t* rowptr;
+  const float* sh;       // [E, ld_sh]
+  int ld_sh;
+  const float* emb;      // [E,64] EDGE_EMBEDDING
+  const float* a;        // [E,64] env input of the layer (first: the embedding; last: pre-activation of latent 0's hidden layer, silu applied)
+  const float* wk;       // Wenv of the layer as [64][R][64] (alpha folded)
+  const void* wq;        // bf16x3 fragments of Wg's w0 columns: [2R tiles][2 chunks][64 lanes][24 words]
+  const float *tpw0, *tpw1;  // path weights
+  int coupling;
+  float sf;              // 1/sqrt(avg_num_neighbors)
+  float* x2s0;           // [N][D][64]: written by the first layer, read by the last
+  float* x2s1;           // written by the last layer
+  float* scal;           // [E,64] the layer's tensor-track scalars
+};
+int launch_tp_mfma_fwd(int pair, bool last, const TpMfmaArgs& a, hipStream_t stream);
+
 // Per-atom operator form of the tensor-product track for L <= 3 layers, u = 64*m (aa_tp_op.hip)
 struct TpOpArgs {
   int64_t N, E;          // atoms [atom0, N) are processed

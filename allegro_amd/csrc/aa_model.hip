@@ -146,6 +146,7 @@ struct aa_model_plan {
   bool env_mom;                      // env weights through per-atom moments: no [E,R*u] env tensors (TpMomArgs / TpOpArgs)
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
+  bool tp_mfma;                      // moments kernels recompute w0 on the matrix cores (aa_tp_mfma.hip)
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
   int fused_mode;                    // 1: 32-edge tiles, one wave per atom; 2: 16-edge tiles, two waves per atom (aa_fused16.hip)
   size_t o_g0q16;
@@ -341,6 +342,9 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, con
                    (opt.fused_forward == 1 || opt.fused_forward == 2);
     p->fused_mode = opt.fused_forward == 2 ? 2 : 1;
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
+    // moments kernels with w0 recomputed on the matrix cores (aa_tp_mfma.hip): same stack, no table requirement
+    p->tp_mfma = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
+                 u == 64 && S == 64 && cfg->latent_mlp_width == 64 && opt.tp_mfma == 1;
   }
   *out = p;
   return AA_OK;
@@ -1181,6 +1185,27 @@ struct Runner {
         o.scal = buf(w.scal[l]);
         if (int rc = launch_tp_op<T>(p->tp_op, l, false, o, stream)) return rc;
         if (int rc = mark("tp_op_fwd", p->D + o.ka + W + u, double(l + 1) * p->D * u)) return rc;
+      } else if (p->env_mom && p->tp_mfma) {
+        TpMomArgs m = mom_args(g);
+        TpMfmaArgs a{};
+        a.N = m.c.N;
+        a.atom0 = m.c.atom0;
+        a.rowptr = g->rowptr;
+        a.sh = reinterpret_cast<const float*>(buf(w.sh));
+        a.ld_sh = p->D;
+        a.emb = reinterpret_cast<const float*>(buf(w.emb));
+        a.a = reinterpret_cast<const float*>(l == 0 ? m.a0 : m.a1);
+        a.wk = reinterpret_cast<const float*>(l == 0 ? m.wk0 : m.wk1);
+        a.wq = reinterpret_cast<const float*>(wt(p->o_g0q)) + size_t(2) * 2 * 1536;  // tiles 2..: the w0 columns of [two-body | w0]
+        a.tpw0 = reinterpret_cast<const float*>(wt(p->o_tpw[0]));
+        a.tpw1 = reinterpret_cast<const float*>(wt(p->o_tpw[1]));
+        a.coupling = c.tps[0].coupling;
+        a.sf = float(sfac);
+        a.x2s0 = reinterpret_cast<float*>(buf(w.x2s[0]));
+        a.x2s1 = reinterpret_cast<float*>(buf(w.x2s[1]));
+        a.scal = reinterpret_cast<float*>(buf(w.scal[l]));
+        if (int rc = launch_tp_mfma_fwd(p->chain_pair, l == 1, a, stream)) return rc;
+        if (int rc = mark(l == 0 ? "tp_mfma_fwd_first" : "tp_mfma_fwd_last", p->D + (l == 0 ? 64 : 128) + u, double(l + 1) * p->D * u)) return rc;
       } else if (p->env_mom) {
         TpMomArgs m = mom_args(g);
         if (l == 0) {

@@ -132,10 +132,11 @@ def profile_stages(model, pos, graph):
                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     acc = {}
     reps = 5
+    stream = torch.cuda.current_stream(pos.device).cuda_stream if pos.is_cuda else 0  # (CPU: the tests' emulation build)
     for _ in range(reps):
         rc = fn(model._plan_handle, model._blob.data_ptr(), C.byref(g), pos.data_ptr(), model._workspace.data_ptr(),
                 model._workspace.numel(), e_atom.data_ptr(), forces.data_ptr(),
-                torch.cuda.current_stream(pos.device).cuda_stream, max_stages, ms, names, C.byref(n), by, fl)
+                stream, max_stages, ms, names, C.byref(n), by, fl)
         lib.check(rc, "aa_model_energy_forces_profiled")
         for i in range(n.value):
             nm = names.raw[32 * i: 32 * i + 32].split(b"\0")[0].decode()

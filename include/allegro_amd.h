@@ -189,6 +189,8 @@ typedef struct {
   int32_t fused_forward;   /* 0 staged pipeline; 1 fused forward, 32-edge tiles; 2 fused forward, 16-edge tiles */
   int32_t fused_recompute_w0; /* fused forward: recompute w0 for the second layer instead of holding it         */
   int32_t moments_waves_per_block; /* 0 = 1                                                                      */
+  int32_t tp_mfma;         /* tensor-product kernels that recompute the first-layer x1 weights on the matrix cores
+                            * (aa_tp_mfma.hip) instead of re-reading them: 0 automatic, 1 on where supported, 2 off  */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

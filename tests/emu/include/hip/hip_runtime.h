@@ -142,7 +142,7 @@ inline T __shfl_up(T v, int delta, int width = 64) {
 }
 
 // gfx950 lane-exchange primitives (aa_common.h issues them as inline ISA on the device)
-#define AA_HAVE_LANE_OPS 1  // the four permlane-swap primitives of aa_common.h are supplied below (namespace aa)
+#define AA_HAVE_LANE_OPS 1  // the permlane-swap primitives and the scheduling anchor of aa_common.h are supplied below (namespace aa)
 // swap the upper half (odd `width`-lane rows) of a with the lower half (even rows) of b
 inline void aa_emu_permlane_swap(float& a, float& b, int width) {
   const int l = emu::lane();
@@ -160,6 +160,8 @@ inline void permlane32_swap4(float* a, float* b) {
 inline void permlane16_swap4(float* a, float* b) {
   for (int i = 0; i < 4; ++i) aa_emu_permlane_swap(a[i], b[i], 16);
 }
+template <class V>
+inline void anchor(V&) {}  // (a scheduling anchor on the device: no semantics)
 }  // namespace aa
 inline int __builtin_amdgcn_update_dpp(int, int v, int ctrl, int, int, bool) {
   const int l = emu::lane();
