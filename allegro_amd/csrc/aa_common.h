@@ -199,7 +199,7 @@ struct GemmArgs {
   SegList add;
   int force_kernel;  // 0: automatic; 1: native fp32-input MFMA kernel; 3: VALU kernel (aa_debug_gemm_f32 / A-B tests)
   int act_kind;      // activation behind act_a / has_z (AA_ACT_*); anything but SiLU runs the general VALU kernel
-  int opt_v1, opt_lds_epilogue, opt_f64_column_loop;  // aa_plan_options pass-throughs (A/B switches)
+  int opt_v1, opt_lds_epilogue, opt_f64_column_loop, opt_f64_rows;  // aa_plan_options pass-throughs (A/B switches)
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);

@@ -11,12 +11,16 @@
 
 namespace aa {
 
+__host__ __device__ inline int prologue_ldb(int B) { return B == 8 ? 12 : B + 1; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
   const int B = a.num_bessels, S0 = a.S0, D = (a.l_max + 1) * (a.l_max + 1), Tn = a.num_types;
-  T* sB = reinterpret_cast<T*>(aa_smem);           // [256][B+1]
-  T* sWb = sB + 256 * (B + 1);                     // [B][S0]
-  int* sTy = reinterpret_cast<int*>(sWb + B * S0);  // [256][2]
+  const int ldb = prologue_ldb(B);                 // row stride of sB (B = 8: 12, so that a row is two aligned 16-B reads)
+  T* sB = reinterpret_cast<T*>(aa_smem);           // [256][ldb]
+  T* sWb = sB + 256 * ldb;                         // [B][S0]
+  T* sSh = sWb + B * S0;                           // [256][D]: the block's harmonics, written out as one contiguous run
+  int* sTy = reinterpret_cast<int*>(sSh + 256 * D);  // [256][2]
   const int tid = threadIdx.x;
   const int64_t e0 = int64_t(blockIdx.x) * 256;
   const T* pos = static_cast<const T*>(a.pos);
@@ -37,15 +41,11 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
       T r = aa_sqrt(vx * vx + vy * vy + vz * vz);
       T inv = T(1) / r;
       T nx = vx * inv, ny = vy * inv, nz = vz * inv;
-      T* vec = static_cast<T*>(a.vec) + 4 * e;
-      vec[0] = nx;
-      vec[1] = ny;
-      vec[2] = nz;
-      vec[3] = r;
+      typedef T V4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<V4*>(static_cast<T*>(a.vec) + 4 * e) = V4{nx, ny, nz, r};
       T Y[16];
       sh_eval<T>(a.l_max, nx, ny, nz, Y);
-      T* sh = static_cast<T*>(a.sh) + e * D;
-      for (int m = 0; m < D; ++m) sh[m] = Y[m];
+      for (int m = 0; m < D; ++m) sSh[tid * D + m] = Y[m];
       int ti = a.types[i], tj = a.types[j];
       sTy[2 * tid] = ti;
       sTy[2 * tid + 1] = tj;
@@ -54,19 +54,26 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
         for (int nb = 0; nb < B; ++nb) {
           T bv, dbv;
           spline_basis_and_grad<T>(x, nb, B, a.spline_span, bv, dbv);
-          sB[tid * (B + 1) + nb] = bv;
+          sB[tid * ldb + nb] = bv;
         }
       } else {
         T f, df;
         cutoff_and_grad<T>(x, T(a.poly_p), f, df);
+        const T fx = f / x;
         for (int nb = 0; nb < B; ++nb) {
           T w = static_cast<const T*>(a.bessel_w)[nb];
-          sB[tid * (B + 1) + nb] = aa_sin(w * x) / x * f;
+          sB[tid * ldb + nb] = aa_sin(w * x) * fx;
         }
       }
     }
   }
   __syncthreads();
+  {
+    // harmonics of the block's edges: rows [e0, e0 + 256) of sh are one contiguous run
+    const int64_t n = (a.E - e0 < 256 ? a.E - e0 : 256) * D;
+    T* sh = static_cast<T*>(a.sh) + e0 * D;
+    for (int idx = tid; idx < n; idx += 256) sh[idx] = sSh[idx];
+  }
   if (a.embed_kind == 1) {
     // emb0[e][c] = sum_s W[class(e)][c][s] b_s(x)  (spline.py:69-79), class = t_center * T + t_neighbor
     // (scalarembed.py:170); table is basis-major [class][s][c] so a wave reads contiguous rows
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
       if (e >= a.E) break;
       const T* tc = tab + size_t(sTy[2 * le] * Tn + sTy[2 * le + 1]) * B * S0 + c;
       T acc = T(0);
-      for (int nb = 0; nb < B; ++nb) acc += sB[le * (B + 1) + nb] * tc[size_t(nb) * S0];
+      for (int nb = 0; nb < B; ++nb) acc += sB[le * ldb + nb] * tc[size_t(nb) * S0];
       static_cast<T*>(a.emb0)[e * S0 + c] = acc;
     }
     return;
@@ -98,9 +105,16 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
       const int64_t e = e0 + le;
       if (e >= a.E) break;
       T basis = T(0);
+      if (B == 8) {  // (the usual basis size: the row is two aligned vector reads, broadcast to the wave)
+        typedef T V4 __attribute__((ext_vector_type(4)));
+        const V4 b0 = *reinterpret_cast<const V4*>(sB + le * ldb), b1 = *reinterpret_cast<const V4*>(sB + le * ldb + 4);
 #pragma unroll
-      for (int nb = 0; nb < kMaxBessel; ++nb)
-        if (nb < B) basis += sB[le * (B + 1) + nb] * wreg[nb];
+        for (int nb = 0; nb < 4; ++nb) basis += b0[nb] * wreg[nb] + b1[nb] * wreg[4 + nb];
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < kMaxBessel; ++nb)
+          if (nb < B) basis += sB[le * ldb + nb] * wreg[nb];
+      }
       const T te = tab[sTy[2 * le + tsel] * half];
       static_cast<T*>(a.emb0)[e * S0 + c] = te * basis;
     }
@@ -111,7 +125,7 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
     int64_t e = e0 + le;
     if (e >= a.E) break;
     T basis = T(0);
-    for (int nb = 0; nb < B; ++nb) basis += sB[le * (B + 1) + nb] * sWb[nb * S0 + c];
+    for (int nb = 0; nb < B; ++nb) basis += sB[le * ldb + nb] * sWb[nb * S0 + c];
     T te = c < half ? cemb[sTy[2 * le] * half + c] : nemb[sTy[2 * le + 1] * half + (c - half)];
     static_cast<T*>(a.emb0)[e * S0 + c] = te * basis;
   }
@@ -218,9 +232,20 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
   T* sWb = sT + 256 * (B + 1);                    // [B][S0] (general path only)
   T* sEmb = sWb + size_t(S0) * kMaxBessel;        // [2][Tn][S0/2] center / neighbor type embeddings
   int* sTy = reinterpret_cast<int*>(sEmb + size_t(Tn) * S0);  // [256] ti | tj << 16
+  T* sG = reinterpret_cast<T*>(sTy + 256);        // [256][D]: summed dE/dY slots of the block's edges
   const int tid = threadIdx.x;
   const int64_t e0 = int64_t(blockIdx.x) * 256;
   const int half = S0 / 2;
+  {
+    // the block's rows of every g_sh slot are one contiguous run: coalesced reads, summed on the way in
+    const int64_t n = (a.E - e0 < 256 ? a.E - e0 : 256) * D;
+    const T* gsh = static_cast<const T*>(b.g_sh) + e0 * D;
+    for (int idx = tid; idx < n; idx += 256) {
+      T v = gsh[idx];
+      for (int sl = 1; sl < b.num_gsh; ++sl) v += gsh[int64_t(sl) * a.E * D + idx];
+      sG[idx] = v;
+    }
+  }
   const T* cemb = static_cast<const T*>(a.center_embed);
   const T* nemb = static_cast<const T*>(a.neighbor_embed);
   const bool spline = a.embed_kind == 1;
@@ -293,7 +318,8 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
   T fx = T(0), fy = T(0), fz = T(0);
   if (e < a.E) {
     const int j = cj;
-    const T* vec = static_cast<const T*>(a.vec) + 4 * e;
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    const V4 vec = *reinterpret_cast<const V4*>(static_cast<const T*>(a.vec) + 4 * e);
     T nx = vec[0], ny = vec[1], nz = vec[2], r = vec[3];
     T recip = static_cast<const T*>(a.rmax_recip)[ti * Tn + tj];
     T x = r * recip;
@@ -317,12 +343,7 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
     }
     T dEdr = dEdx * recip;
     T gY[16];
-    const T* gsh = static_cast<const T*>(b.g_sh) + e * D;
-    for (int m = 0; m < D; ++m) gY[m] = gsh[m];
-    for (int sl = 1; sl < b.num_gsh; ++sl) {
-      const T* g2 = gsh + int64_t(sl) * a.E * D;
-      for (int m = 0; m < D; ++m) gY[m] += g2[m];
-    }
+    for (int m = 0; m < D; ++m) gY[m] = sG[tid * D + m];
     T gx, gy, gz;
     sh_grad<T>(a.l_max, nx, ny, nz, gY, gx, gy, gz);
     T dot = gx * nx + gy * ny + gz * nz;
@@ -335,11 +356,7 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
     fy = dy;
     fz = dz;
     if (b.dvec) {
-      T* dv = static_cast<T*>(b.dvec) + 4 * e;
-      dv[0] = dx;
-      dv[1] = dy;
-      dv[2] = dz;
-      dv[3] = T(0);
+      *reinterpret_cast<V4*>(static_cast<T*>(b.dvec) + 4 * e) = V4{dx, dy, dz, T(0)};
     }
     if (!b.gather) {
       T* F = static_cast<T*>(b.forces);
@@ -455,7 +472,11 @@ template <typename T>
 int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream) {
   if (a.E == 0) return AA_OK;
   AA_REQUIRE(a.num_bessels <= kMaxBessel && a.l_max >= 1 && a.l_max <= 3 && a.S0 % 2 == 0, "prologue: unsupported sizes");
-  size_t smem = sizeof(T) * (256 * size_t(a.num_bessels + 1) + size_t(a.num_bessels) * a.S0) + sizeof(int) * 512;
+  const int D = (a.l_max + 1) * (a.l_max + 1);
+  size_t smem = sizeof(T) * (256 * size_t(prologue_ldb(a.num_bessels)) + size_t(a.num_bessels) * a.S0 + 256 * size_t(D)) + sizeof(int) * 512;
+  if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "prologue: LDS tables too large");
+  if (smem > 64 * 1024)
+    AA_CHECK_HIP(hipFuncSetAttribute((const void*)edge_prologue_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   hipLaunchKernelGGL(edge_prologue_kernel<T>, dim3((unsigned)((a.E + 255) / 256)), dim3(256), smem, stream, a);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
@@ -464,8 +485,11 @@ int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_edge_backward(const EdgeBwdArgs& b, hipStream_t stream) {
   if (b.g.E == 0) return AA_OK;
-  size_t smem = sizeof(T) * (256 * size_t(b.g.num_bessels + 1) + size_t(kMaxBessel) * b.g.S0 + size_t(b.g.num_types) * b.g.S0) + sizeof(int) * 256;
-  if (smem > 64 * 1024) return fail(AA_ERR_INVALID, "edge_backward: too many types / embedding columns for the LDS tables");
+  const int D = (b.g.l_max + 1) * (b.g.l_max + 1);
+  size_t smem = sizeof(T) * (256 * size_t(b.g.num_bessels + 1) + size_t(kMaxBessel) * b.g.S0 + size_t(b.g.num_types) * b.g.S0 + 256 * size_t(D)) + sizeof(int) * 256;
+  if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "edge_backward: too many types / embedding columns for the LDS tables");
+  if (smem > 64 * 1024)
+    AA_CHECK_HIP(hipFuncSetAttribute((const void*)edge_backward_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
   hipLaunchKernelGGL(edge_backward_kernel<T>, dim3((unsigned)((b.g.E + 255) / 256)), dim3(256), smem, stream, b);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;

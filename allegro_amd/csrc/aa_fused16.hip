@@ -221,6 +221,7 @@ __device__ __forceinline__ void scal_acc16(const float* sB, const float* Y, cons
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) sc.t[t][i] += w.t[t][i] * T4[i];
+    anchor(sc.t[t]);  // (otherwise the arithmetic is sunk below the following MFMA steps and every w tile stays live)
   }
 }
 

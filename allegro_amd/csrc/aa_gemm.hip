@@ -384,6 +384,188 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) 
   }  // column tiles
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp64 linear layers, row-resident form: every wave owns 32 rows and the OPERAND ROWS NEVER TOUCH LDS.
+// v_mfma_f64_16x16x4 takes A[i = lane & 15][k = lane >> 4]; with the k index permuted inside each 16-deep chunk (lane
+// group g supplies k = 4 g + s at MFMA step s, the weights are read from LDS with the same mapping) lane (i, g) needs
+// A[row i][16 c + 4 g .. + 3]: 32 contiguous bytes of its own row, fetched straight into VGPRs.  Each A element is read
+// from HBM exactly once per layer:
+//   CSTAT (N <= 128, any K): the wave holds its whole 32 x N output in accumulators (128 VGPRs) and streams A by chunks;
+//   ASTAT (K <= 128, any N): the wave holds its 32 x K operand rows in registers (128 VGPRs) and walks the column
+//                            tiles of 64.
+// (the staged kernel above re-reads the 128-row A tile once per 64-column tile -- at N = 512 that is 8 reads, which no
+// longer come from L2 once ~770 workgroups are resident: rocprofv3 FETCH_SIZE showed 2.5x the algorithmic read bytes)
+// Only the weights go through LDS: a [16][NB] block per chunk, staged by the four waves together, double-buffered,
+// one barrier per 32-64 MFMAs of 64 cycles each.
+template <bool ASTAT>
+__global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
+  constexpr int NB = ASTAT ? 64 : 128;  // columns per pass
+  constexpr int JT = NB / 16;           // MFMA column tiles per pass
+  constexpr int LDB = NB + 4;           // (rows 4 g + s of the four lane groups land in different banks)
+  constexpr int SPT = NB / 16;          // doubles per thread of a staged [16][NB] block
+  constexpr int KCMAX = ASTAT ? 8 : 1;  // resident operand chunks
+  double* smem = reinterpret_cast<double*>(aa_smem);  // [2][16][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t m_base = (int64_t(blockIdx.x) * 4 + wv) * 32;
+  const double* B = static_cast<const double*>(g.B);
+  const int KC = g.K / 16;
+  int64_t arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t r = m_base + 16 * i + li;
+    arow[i] = r < g.M ? r : g.M - 1;
+  }
+  const int sr = tid >> 4, sc = (tid & 15) * SPT;
+  v2d rb[SPT / 2];
+  auto stage_load = [&](int c, int n0) {
+    const double* src = B + int64_t(16 * c + sr) * g.N + n0 + sc;
+#pragma unroll
+    for (int q = 0; q < SPT / 2; ++q) rb[q] = n0 + sc + 2 * q + 1 < g.N ? *reinterpret_cast<const v2d*>(src + 2 * q) : v2d{0.0, 0.0};
+  };
+  auto stage_write = [&](int b) {
+    double* d = smem + b * 16 * LDB + sr * LDB + sc;
+#pragma unroll
+    for (int q = 0; q < SPT / 2; ++q) *reinterpret_cast<v2d*>(d + 2 * q) = rb[q];
+  };
+  // operand chunk c of the lane's two rows: A[row][16 c + 4 lg .. + 3]
+  auto a_load = [&](int c, v2d (*a)[2]) {
+    int kk = 16 * c;
+    const double* base = nullptr;
+    int ld = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      if (s2 < g.a.count && base == nullptr) {
+        if (kk < g.a.s[s2].n) {
+          base = static_cast<const double*>(g.a.s[s2].p) + kk;
+          ld = g.a.s[s2].ld;
+        } else {
+          kk -= g.a.s[s2].n;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double* ap = base + arow[i] * ld + 4 * lg;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v2d v = *reinterpret_cast<const v2d*>(ap + 2 * h);
+        if (g.act_a) v = v2d{silu(v[0]), silu(v[1])};
+        a[i][h] = v;
+      }
+    }
+  };
+  // 2 x JT x 4 MFMAs of one chunk against the staged weight block
+  auto mma_chunk = [&](const double* bs, const v2d (*a)[2], v4d (*acc)[JT]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      double b[JT];
+#pragma unroll
+      for (int j = 0; j < JT; ++j) b[j] = bs[(4 * lg + s) * LDB + 16 * j + li];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][s >> 1][s & 1], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // epilogue of one pass: a 16-column tile never straddles a C segment (widths are multiples of 16, checked by the
+  // launcher), so the destination / z / add rows are resolved once per tile, wave-uniformly
+  auto epilogue = [&](int n0, v4d (*acc)[JT]) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const int t0 = n0 + j * 16;
+      if (t0 >= g.N) continue;
+      int cc = t0, si = -1;
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        if (s2 < g.c.count && si < 0) {
+          if (cc < g.c.s[s2].n)
+            si = s2;
+          else
+            cc -= g.c.s[s2].n;
+        }
+      }
+      if (si < 0) continue;
+      double* cp = static_cast<double*>(g.c.s[si].p);
+      if (!cp) continue;
+      const int ldc = g.c.s[si].ld, col = cc + li;
+      const double* zp = g.has_z ? static_cast<const double*>(g.z.s[si].p) : nullptr;
+      const double* ap = g.has_add ? static_cast<const double*>(g.add.s[si].p) : nullptr;
+      const int ldz = g.has_z ? g.z.s[si].ld : 0, lda2 = g.has_add ? g.add.s[si].ld : 0;
+      const bool accum = g.c_accum[si] != 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t gm = m_base + i * 16 + 4 * r + lg;
+          if (gm >= g.M) continue;
+          double v = acc[i][j][r];
+          if (ap) v += ap[gm * lda2 + col];
+          if (zp) v *= dsilu(zp[gm * ldz + col]);
+          if (accum) v += cp[gm * ldc + col];
+          cp[gm * ldc + col] = v;
+        }
+    }
+  };
+  v4d acc[2][JT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < JT; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  };
+  if constexpr (ASTAT) {
+    v2d areg[KCMAX][2][2];
+#pragma unroll
+    for (int c = 0; c < KCMAX; ++c)
+      if (c < KC) a_load(c, areg[c]);
+    stage_load(0, 0);
+    stage_write(0);
+    __syncthreads();
+    int buf = 0;
+    for (int n0 = 0; n0 < g.N; n0 += NB) {
+      zero_acc();
+#pragma unroll
+      for (int c = 0; c < KCMAX; ++c) {
+        if (c < KC) {  // (wave-uniform)
+          const bool last_c = c + 1 >= KC;
+          const bool more = !last_c || n0 + NB < g.N;
+          if (more) stage_load(last_c ? 0 : c + 1, last_c ? n0 + NB : n0);
+          mma_chunk(smem + buf * 16 * LDB, areg[c], acc);
+          if (more) stage_write(buf ^ 1);
+          __syncthreads();
+          buf ^= 1;
+        }
+      }
+      epilogue(n0, acc);
+    }
+  } else {
+    v2d acur[2][2], anext[2][2];
+    zero_acc();
+    stage_load(0, 0);
+    a_load(0, acur);
+    stage_write(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c = 0; c < KC; ++c) {
+      const bool more = c + 1 < KC;
+      if (more) {
+        stage_load(c + 1, 0);
+        a_load(c + 1, anext);
+      }
+      mma_chunk(smem + buf * 16 * LDB, acur, acc);
+      if (more) stage_write(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acur[i][h] = anext[i][h];
+    }
+    epilogue(0, acc);
+  }
+}
+
 
 // destination of one output column, resolved once per 32-column tile (not per element)
 struct ColDst {
@@ -1568,6 +1750,22 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   for (int s2 = 0; s2 < g.c.count; ++s2) pipe_ok = pipe_ok && (g.c.s[s2].n % 16) == 0;
   if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
+  } else if (pipe_ok && g.opt_f64_column_loop == 0 && g.opt_f64_rows != 2 && (g.K % 16) == 0 &&
+             (g.opt_f64_rows == 1 ? (g.N <= 128 || g.K <= 128) : (g.N <= 128 && (g.K > 128 || !(g.has_z || g.has_add))))) {
+    // row-resident kernels: every operand row is read from HBM once.  Measured at C5 (1.7 M rows, profiles/
+    // r02_v12_f64rows_*): the accumulator-resident form wins 4-9 % for K > 128 and for plain 128 x 128 layers, loses
+    // 10-20 % where the epilogue carries z / add operands (two waves per SIMD hide their latency worse than three);
+    // the operand-resident form (N > 128) is 5-30 % slower than the staged kernel although it reads A once instead
+    // of N / 64 times -- those re-reads are served by the infinity cache, not HBM -- so it only runs when forced
+    // (aa_plan_options.f64_rows = 1).
+    dim3 gridr((unsigned)((g.M + 127) / 128));
+    if (g.N <= 128) {
+      const size_t smemr = sizeof(double) * 2 * 16 * (128 + 4);
+      hipLaunchKernelGGL(gemm_f64_rows_kernel<false>, gridr, dim3(256), smemr, stream, g);
+    } else {
+      const size_t smemr = sizeof(double) * 2 * 16 * (64 + 4);
+      hipLaunchKernelGGL(gemm_f64_rows_kernel<true>, gridr, dim3(256), smemr, stream, g);
+    }
   } else if (pipe_ok) {
     dim3 grid6((unsigned)((g.M + G6_BM - 1) / G6_BM), (unsigned)((g.N + G6_BN - 1) / G6_BN));
     // enough row tiles to fill the chip on their own: one workgroup per row tile looping over the column tiles

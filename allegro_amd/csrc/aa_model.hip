@@ -768,6 +768,7 @@ struct Runner {
     g.opt_v1 = p->opt.gemm_v1;
     g.opt_lds_epilogue = p->opt.gemm_lds_epilogue;
     g.opt_f64_column_loop = p->opt.f64_column_loop;
+    g.opt_f64_rows = p->opt.f64_rows;
     g.has_add = add ? 1 : 0;
     if (add) g.add = *add;
     if (int rc = launch_gemm<T>(g, stream)) return rc;

@@ -628,6 +628,25 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_first_kernel(TpChainArgs a) 
 // math reads them as 2-vectors.
 // =============================================================================================
 namespace {
+// streamed-once operands of the moments kernels carry the non-temporal hint: each row is read by exactly one wave and
+// written rows are not read again before they have left the caches (C4: 2-4 % per kernel, profiles/r02_v12_nt_stages_*;
+// tools/ubench/hbm_stream.hip: +5-10 % for this one-row-per-instruction pattern; -DAA_NO_NT builds without)
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#ifndef AA_NO_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+#ifndef AA_NO_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 constexpr int kMaxKa = 128;
 constexpr int kSegCap = 64;  // edges of a segment staged per pass (longer segments are walked in chunks of this size)
 constexpr int kPB = 8;       // edge pairs per load batch in the moment loops
@@ -658,7 +677,7 @@ __device__ __forceinline__ void load_a_batch(const T* a, int ld_a, int kb, bool 
   for (int i = 0; i < kPB; ++i) {
     const int e0 = s0 + 2 * i, e1 = e0 + 1;
     const int c0 = e0 < ce ? e0 : ce - 1, c1 = e1 < ce ? e1 : ce - 1;
-    T x0 = a[int64_t(c0) * ld_a + kb + lane], x1 = a[int64_t(c1) * ld_a + kb + lane];
+    T x0 = ld_stream(a + int64_t(c0) * ld_a + kb + lane), x1 = ld_stream(a + int64_t(c1) * ld_a + kb + lane);
     if (act) {
       x0 = silu(x0);
       x1 = silu(x1);
@@ -785,7 +804,7 @@ __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const
     for (int i = 0; i < B; ++i) {
       const int e0 = s0 + 2 * i, e1 = e0 + 1;
       const int c0 = e0 < ce ? e0 : ce - 1, c1 = e1 < ce ? e1 : ce - 1;
-      T x0 = a[int64_t(c0) * ld_a + lane], x1 = a[int64_t(c1) * ld_a + lane];
+      T x0 = ld_stream(a + int64_t(c0) * ld_a + lane), x1 = ld_stream(a + int64_t(c1) * ld_a + lane);
       if (act) {
         x0 = silu(x0);
         x1 = silu(x1);
@@ -834,10 +853,10 @@ __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const
             ga[j] = gy[j][0];
             gb[j] = gy[j][1];
           }
-          g_a[int64_t(s) * ld_ga + lane] = d0[0];
+          st_stream(g_a + int64_t(s) * ld_ga + lane, d0[0]);
           if (two) g_a[int64_t(s) * ld_ga + 64 + lane] = d1[0];
           if (vb) {
-            g_a[int64_t(s + 1) * ld_ga + lane] = d0[1];
+            st_stream(g_a + int64_t(s + 1) * ld_ga + lane, d0[1]);
             if (two) g_a[int64_t(s + 1) * ld_ga + 64 + lane] = d1[1];
           }
           wave_sum_store2<T, D>(ga, gb, gsh + int64_t(s) * ld_gsh, gsh + int64_t(s + (vb ? 1 : 0)) * ld_gsh, true, vb);
@@ -866,7 +885,7 @@ __device__ __forceinline__ void mom_x2s(const T* sh, int ld_sh, const T* a, int 
     for (int j = 0; j < D; ++j) m[j] = T(0);
 #pragma unroll 4
     for (int s = beg; s < end; ++s) {
-      T av = a[int64_t(s) * ld_a + kb + lane];
+      T av = ld_stream(a + int64_t(s) * ld_a + kb + lane);
       if (act) av = silu(av);
       const T* y = sh + int64_t(s) * ld_sh;
 #pragma unroll
@@ -1003,7 +1022,7 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
 #pragma unroll
-    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{ld_stream(wa + r * 64), ld_stream(wb + r * 64)};
   };
   if (beg < end) {
     EdgeIn2<T, D, R> cur, nxt;
@@ -1015,8 +1034,8 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
 #pragma unroll
       for (int i = 0; i < Sig0::D1; ++i) x1[i] = cur.y[i] * cur.wa[r_of<0>(i)];
       Sig0::template fwd4<T2, T2, T, T>(x1, x2s0, wp0, tf1);
-      sc[int64_t(s) * a.ld_scal] = tf1[0][0];
-      if (s + 1 < end) sc[int64_t(s + 1) * a.ld_scal] = tf1[0][1];
+      st_stream(sc + int64_t(s) * a.ld_scal, tf1[0][0]);
+      if (s + 1 < end) st_stream(sc + int64_t(s + 1) * a.ld_scal, tf1[0][1]);
       cur = nxt;
     }
   }
@@ -1067,7 +1086,7 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int j = 0; j < D; ++j) in.y[j] = T2{ya[j], yb[j]};
 #pragma unroll
-    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{ld_stream(wa + r * 64), ld_stream(wb + r * 64)};
   };
   if (beg < end) {
     EdgeIn2<T, D, R> cur, nxt;
@@ -1080,8 +1099,8 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
       out[0] = T2{T(0), T(0)};
 #pragma unroll
       for (int i = 0; i < Sig0::D1; ++i) out[0] += (cur.y[i] * cur.wa[r_of<0>(i)]) * B1[i];
-      sc[int64_t(s) * a.ld_scal] = out[0][0];
-      if (s + 1 < end) sc[int64_t(s + 1) * a.ld_scal] = out[0][1];
+      st_stream(sc + int64_t(s) * a.ld_scal, out[0][0]);
+      if (s + 1 < end) st_stream(sc + int64_t(s + 1) * a.ld_scal, out[0][1]);
       cur = nxt;
     }
   }
@@ -1121,8 +1140,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? (KA2 ? 3
     const T* wa = w0g + int64_t(sa) * a.ld_w0;
     const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
-    const T ga = gs1[int64_t(sa) * a.ld_gscal], gb = gs1[int64_t(sb) * a.ld_gscal];
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{ld_stream(wa + r * 64), ld_stream(wb + r * 64)};
+    const T ga = ld_stream(gs1 + int64_t(sa) * a.ld_gscal), gb = ld_stream(gs1 + int64_t(sb) * a.ld_gscal);
     in.g1 = T2{ga, s + 1 < ce ? gb : T(0)};  // a padded second edge contributes nothing
   };
   mom_pair_loop<T, D, R, 2>(sh, a.ld_sh, beg, end, lane, sY, staged_cb, fetch, [&](int s, bool vb, const T2* y, const PairIn<T, R>& cur) {
@@ -1195,10 +1214,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
     const T* wa = w0g + int64_t(sa) * a.ld_w0;
     const T* wb = w0g + int64_t(sb) * a.ld_w0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) in.wa[r] = T2{wa[r * 64], wb[r * 64]};
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{ld_stream(wa + r * 64), ld_stream(wb + r * 64)};
     const bool vb2 = s + 1 < ce;
-    const T g0a = gs0[int64_t(sa) * a.ld_gscal], g0b = gs0[int64_t(sb) * a.ld_gscal];
-    const T g1a = gs1[int64_t(sa) * a.ld_gscal], g1b = gs1[int64_t(sb) * a.ld_gscal];
+    const T g0a = ld_stream(gs0 + int64_t(sa) * a.ld_gscal), g0b = ld_stream(gs0 + int64_t(sb) * a.ld_gscal);
+    const T g1a = ld_stream(gs1 + int64_t(sa) * a.ld_gscal), g1b = ld_stream(gs1 + int64_t(sb) * a.ld_gscal);
     in.g0 = T2{g0a, vb2 ? g0b : T(0)};
     in.g1 = T2{g1a, vb2 ? g1b : T(0)};
   };
@@ -1223,10 +1242,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
       gyb[i] = t[1];
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * 64] = gw[r][0];
+    for (int r = 0; r < R; ++r) st_stream(gw0 + int64_t(s) * a.ld_gw0 + r * 64, gw[r][0]);
     if (vb) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) gw0[int64_t(s + 1) * a.ld_gw0 + r * 64] = gw[r][1];
+      for (int r = 0; r < R; ++r) st_stream(gw0 + int64_t(s + 1) * a.ld_gw0 + r * 64, gw[r][1]);
     }
     wave_sum_store2<T, D1>(gya, gyb, gsx + int64_t(s) * a.ld_gsh, gsx + int64_t(s + (vb ? 1 : 0)) * a.ld_gsh, true, vb);
   });
