@@ -13,14 +13,16 @@ namespace aa {
 
 __host__ __device__ inline int prologue_ldb(int B) { return B == 8 ? 12 : B + 1; }
 
-template <typename T>
+// STAGE_SH: the block's harmonics go through LDS and leave as one contiguous run (fp32 stacks: +9-16 KB of LDS);
+// without it every lane stores its own D values (large fp64 stacks, where the extra LDS would halve the occupancy)
+template <typename T, bool STAGE_SH>
 __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
   const int B = a.num_bessels, S0 = a.S0, D = (a.l_max + 1) * (a.l_max + 1), Tn = a.num_types;
   const int ldb = prologue_ldb(B);                 // row stride of sB (B = 8: 12, so that a row is two aligned 16-B reads)
   T* sB = reinterpret_cast<T*>(aa_smem);           // [256][ldb]
   T* sWb = sB + 256 * ldb;                         // [B][S0]
   T* sSh = sWb + B * S0;                           // [256][D]: the block's harmonics, written out as one contiguous run
-  int* sTy = reinterpret_cast<int*>(sSh + 256 * D);  // [256][2]
+  int* sTy = reinterpret_cast<int*>(sSh + (STAGE_SH ? 256 * D : 0));  // [256][2]
   const int tid = threadIdx.x;
   const int64_t e0 = int64_t(blockIdx.x) * 256;
   const T* pos = static_cast<const T*>(a.pos);
@@ -45,7 +47,12 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
       *reinterpret_cast<V4*>(static_cast<T*>(a.vec) + 4 * e) = V4{nx, ny, nz, r};
       T Y[16];
       sh_eval<T>(a.l_max, nx, ny, nz, Y);
-      for (int m = 0; m < D; ++m) sSh[tid * D + m] = Y[m];
+      if (STAGE_SH) {
+        for (int m = 0; m < D; ++m) sSh[tid * D + m] = Y[m];
+      } else {
+        T* sh = static_cast<T*>(a.sh) + e * D;
+        for (int m = 0; m < D; ++m) sh[m] = Y[m];
+      }
       int ti = a.types[i], tj = a.types[j];
       sTy[2 * tid] = ti;
       sTy[2 * tid + 1] = tj;
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256) void edge_prologue_kernel(EdgeGeomArgs a) {
     }
   }
   __syncthreads();
-  {
+  if (STAGE_SH) {
     // harmonics of the block's edges: rows [e0, e0 + 256) of sh are one contiguous run
     const int64_t n = (a.E - e0 < 256 ? a.E - e0 : 256) * D;
     T* sh = static_cast<T*>(a.sh) + e0 * D;
@@ -232,20 +239,9 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
   T* sWb = sT + 256 * (B + 1);                    // [B][S0] (general path only)
   T* sEmb = sWb + size_t(S0) * kMaxBessel;        // [2][Tn][S0/2] center / neighbor type embeddings
   int* sTy = reinterpret_cast<int*>(sEmb + size_t(Tn) * S0);  // [256] ti | tj << 16
-  T* sG = reinterpret_cast<T*>(sTy + 256);        // [256][D]: summed dE/dY slots of the block's edges
   const int tid = threadIdx.x;
   const int64_t e0 = int64_t(blockIdx.x) * 256;
   const int half = S0 / 2;
-  {
-    // the block's rows of every g_sh slot are one contiguous run: coalesced reads, summed on the way in
-    const int64_t n = (a.E - e0 < 256 ? a.E - e0 : 256) * D;
-    const T* gsh = static_cast<const T*>(b.g_sh) + e0 * D;
-    for (int idx = tid; idx < n; idx += 256) {
-      T v = gsh[idx];
-      for (int sl = 1; sl < b.num_gsh; ++sl) v += gsh[int64_t(sl) * a.E * D + idx];
-      sG[idx] = v;
-    }
-  }
   const T* cemb = static_cast<const T*>(a.center_embed);
   const T* nemb = static_cast<const T*>(a.neighbor_embed);
   const bool spline = a.embed_kind == 1;
@@ -342,8 +338,15 @@ __global__ __launch_bounds__(256) void edge_backward_kernel(EdgeBwdArgs b) {
       }
     }
     T dEdr = dEdx * recip;
+    // (staging the block's dE/dY rows through LDS for coalesced reads measured slower here: 191 vs 169 us at C4 --
+    //  the per-lane strided loads overlap with phase 1, the staged copy does not)
     T gY[16];
-    for (int m = 0; m < D; ++m) gY[m] = sG[tid * D + m];
+    const T* gsh = static_cast<const T*>(b.g_sh) + e * D;
+    for (int m = 0; m < D; ++m) gY[m] = gsh[m];
+    for (int sl = 1; sl < b.num_gsh; ++sl) {
+      const T* g2 = gsh + int64_t(sl) * a.E * D;
+      for (int m = 0; m < D; ++m) gY[m] += g2[m];
+    }
     T gx, gy, gz;
     sh_grad<T>(a.l_max, nx, ny, nz, gY, gx, gy, gz);
     T dot = gx * nx + gy * ny + gz * nz;
@@ -473,11 +476,15 @@ int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream) {
   if (a.E == 0) return AA_OK;
   AA_REQUIRE(a.num_bessels <= kMaxBessel && a.l_max >= 1 && a.l_max <= 3 && a.S0 % 2 == 0, "prologue: unsupported sizes");
   const int D = (a.l_max + 1) * (a.l_max + 1);
-  size_t smem = sizeof(T) * (256 * size_t(prologue_ldb(a.num_bessels)) + size_t(a.num_bessels) * a.S0 + 256 * size_t(D)) + sizeof(int) * 512;
-  if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "prologue: LDS tables too large");
-  if (smem > 64 * 1024)
-    AA_CHECK_HIP(hipFuncSetAttribute((const void*)edge_prologue_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
-  hipLaunchKernelGGL(edge_prologue_kernel<T>, dim3((unsigned)((a.E + 255) / 256)), dim3(256), smem, stream, a);
+  const size_t base = sizeof(T) * (256 * size_t(prologue_ldb(a.num_bessels)) + size_t(a.num_bessels) * a.S0) + sizeof(int) * 512;
+  const size_t staged = base + sizeof(T) * 256 * size_t(D);
+  const bool stage = staged <= 40 * 1024;  // (four workgroups per CU stay resident)
+  const size_t smem = stage ? staged : base;
+  if (smem > 64 * 1024) return fail(AA_ERR_INVALID, "prologue: LDS tables too large");
+  if (stage)
+    hipLaunchKernelGGL((edge_prologue_kernel<T, true>), dim3((unsigned)((a.E + 255) / 256)), dim3(256), smem, stream, a);
+  else
+    hipLaunchKernelGGL((edge_prologue_kernel<T, false>), dim3((unsigned)((a.E + 255) / 256)), dim3(256), smem, stream, a);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
@@ -485,8 +492,7 @@ int launch_edge_prologue(const EdgeGeomArgs& a, hipStream_t stream) {
 template <typename T>
 int launch_edge_backward(const EdgeBwdArgs& b, hipStream_t stream) {
   if (b.g.E == 0) return AA_OK;
-  const int D = (b.g.l_max + 1) * (b.g.l_max + 1);
-  size_t smem = sizeof(T) * (256 * size_t(b.g.num_bessels + 1) + size_t(kMaxBessel) * b.g.S0 + size_t(b.g.num_types) * b.g.S0 + 256 * size_t(D)) + sizeof(int) * 256;
+  size_t smem = sizeof(T) * (256 * size_t(b.g.num_bessels + 1) + size_t(kMaxBessel) * b.g.S0 + size_t(b.g.num_types) * b.g.S0) + sizeof(int) * 256;
   if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "edge_backward: too many types / embedding columns for the LDS tables");
   if (smem > 64 * 1024)
     AA_CHECK_HIP(hipFuncSetAttribute((const void*)edge_backward_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));
