@@ -218,6 +218,11 @@ struct ChainLayer {
                        // reverse of the two-body basis expansion folded into the epilogue (C itself need not be stored)
   void* edge_sum_out;  // [M] or nullptr: out[e] = sum_c silu(C[e,c]) * ro_w[c] of this (64-wide) layer -- the last linear
                        // readout layer folded into the epilogue, so the edge sum reads 4 B/edge instead of a row
+  // tensor-track scalars evaluated where w0 is produced (ChainArgs.tp_*): output tiles from index tp_from1 - 1 on are the
+  // irreps of w0[e][r][64] in pairs; after each pair  sc[e][ch] += w0[e][r][ch] * sum_{a in r} Y[e][a] B[center(e)][a][ch]
+  // is accumulated into a second kept tile pair (zero at kernel start).  Encoded as first tile index + 1; 0 = no such tiles.
+  int tp_from1;
+  int use_sc;          // append that pair as the last two k chunks (after the use_prev chunks)
 };
 struct ChainArgs {
   int64_t M;
@@ -231,6 +236,11 @@ struct ChainArgs {
   const int32_t* nbr;       // embrev_out extras
   const void* emb_table;    // [T*T][8][64]: type_embed(c | pair) * basis_linear[n][c]  (_edgeembed.py:70-84)
   int num_types;
+  // tensor-track scalars (ChainLayer.tp_from1): harmonics [M, tp_ld_sh] and the per-atom Clebsch-Gordan vectors
+  // B [N][tp_D][64] of the layer (tp_mom_fwd_* with TpMomArgs.bvec_out), gathered by center[e]; tp_D <= 9
+  const void* tp_sh;
+  int tp_ld_sh, tp_D;
+  const void* tp_bvec;
 };
 int launch_gemm_chain(const ChainArgs& c, hipStream_t stream);  // fp32 only
 // element count of the fragment-ordered copy of a [K,N] matrix, and the host-side packer
@@ -430,6 +440,8 @@ struct TpMomArgs {
   const void* wt1;
   void* g_a;            // reverse kernels: grad wrt the env input of the layer being reversed [E, ld_ga]
   int ld_ga;
+  void* bvec_out;       // forward kernels: when set, write the layer's per-atom vector B [N][D][64] (scal[e] = <x1[e], B>) and
+                        // SKIP the per-edge scalars -- the linear-layer chain that produces w0 evaluates them (ChainArgs.tp_*)
   int ka_lds;           // row stride of the wave-private moment patch in LDS (set by the launcher: max(ka0, ka1))
   int waves_per_block;  // 0 = 1 (aa_plan_options.moments_waves_per_block)
 };

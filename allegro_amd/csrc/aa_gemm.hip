@@ -1114,6 +1114,7 @@ struct ChainLayerDev {
   const u32x4* Wq;
   int KCg, KC, NT;  // k chunks from global memory, total k chunks (+2 chained), output tiles
   int keep_tile, keep_act, a_mode, pad_;
+  int tp_from1, use_prev, use_sc, pad2_;
   float* edge_sum_out;
   float* embrev_out;
   const float* a[kChainMaxBlocks];
@@ -1132,8 +1133,48 @@ struct ChainDev {
   const int32_t* nbr;
   const float* emb_table;  // [T*T][8][64] or nullptr
   int num_types;
+  const float* tp_sh;      // tensor-track scalars (TPX): harmonics [M, tp_ld_sh], per-atom vectors [N][tp_D][64]
+  const float* tp_bvec;
+  int tp_ld_sh, tp_D;
   ChainLayerDev L[4];
 };
+
+// sc[e][ch] += w[e][r][ch] * sum_{a in irrep RR} Y[e][a] * B[center(e)][a][ch] for the tile pair (w0a: channels 0..31,
+// w0b: 32..63) of irrep RR; bb = the lane's view of its center atom's vector block (+ 4 hh): 16-B cells gathered from
+// L1 / L2 (the lanes of one atom read the same addresses).  Groups of four channels are evaluated one after the other
+// with the next group's cells in flight; the anchors keep that order (see aa::anchor).
+template <int RR>
+__device__ __forceinline__ void chain_tp_accumulate(const float* bb, const float* Y, const v16f& w0a, const v16f& w0b, v16f& s0, v16f& s1) {
+  constexpr int a0 = RR * RR, na = 2 * RR + 1;
+  v4f b[2][na];
+  auto request = [&](int g, v4f* d) {
+#pragma unroll
+    for (int a = 0; a < na; ++a) d[a] = *reinterpret_cast<const v4f*>(bb + (a0 + a) * 64 + 32 * (g >> 2) + 8 * (g & 3));
+  };
+  request(0, b[0]);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g + 1 < 8) request(g + 1, b[(g + 1) & 1]);
+    v4f T4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < na; ++a) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) T4[i] += Y[a0 + a] * b[g & 1][a][i];
+    }
+    const int q = g & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (g < 4)
+        s0[4 * q + i] += w0a[4 * q + i] * T4[i];
+      else
+        s1[4 * q + i] += w0b[4 * q + i] * T4[i];
+    }
+    if (g < 4)
+      anchor(s0);
+    else
+      anchor(s1);
+  }
+}
 
 // Weights of one step (tile pair x 32-deep chunk: 2 x 6 x 64 fragments of 16 B = 12 KB) are staged through LDS
 // by the whole block (the four waves run the same layer/tile/chunk sequence on different rows): one L2 fetch
@@ -1148,7 +1189,9 @@ constexpr int kEpLd = 36;          // row stride (floats) of the store-transpose
 // such layers runs at 3 waves/SIMD and the one with them at 2.
 // EMB: the embrev_out epilogue (reverse of the two-body basis expansion) is compiled in; only the last reverse chain
 // of a step uses it, and it costs registers the other chains should not pay for.
-template <bool PRE, bool EMB>
+// TPX: the tensor-track scalars are evaluated behind the tile pairs that produce w0 (chain_tp_accumulate) into a second
+// kept tile pair that later layers consume like the first (ChainLayer.tp_from1 / use_sc); implies PRE.
+template <bool PRE, bool EMB, bool TPX>
 __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(ChainDev c) {
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);  // [2][kWStep]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1162,6 +1205,19 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
   for (int r = 0; r < 16; ++r) {
     kept0[r] = 0.f;
     kept1[r] = 0.f;
+  }
+  v16f sc0, sc1;  // (TPX) the tensor-track scalars of the row
+  float Yh[TPX ? 9 : 1];
+  const float* tp_bb = nullptr;
+  if constexpr (TPX) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sc0[r] = 0.f;
+      sc1[r] = 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) Yh[m] = (m < c.tp_D && row_ok) ? c.tp_sh[gmc * c.tp_ld_sh + m] : 0.f;
+    tp_bb = c.tp_bvec + int64_t(c.center[gmc]) * c.tp_D * 64 + 4 * hh;
   }
   float rofac = c.ro_factor;  // readout-reverse transform factor of this row
   if (c.ro_scales) rofac *= c.ro_scales[c.types[c.center[gmc]]];
@@ -1209,11 +1265,20 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
       }
     }
   };
-  auto kept_a = [&](bool first, v4f* a) {
+  // chained chunk j of a layer: the kept pair (use_prev) first, then the tensor-track scalars (use_sc)
+  auto kept_a = [&](const ChainLayerDev& L, int j, v4f* a) {
+    const bool from_sc = TPX && L.use_sc && (!L.use_prev || j >= 2);
+    const bool first = (j & 1) == 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a[q][e] = first ? kept0[4 * q + e] : kept1[4 * q + e];
+      for (int e = 0; e < 4; ++e) {
+        float v = first ? kept0[4 * q + e] : kept1[4 * q + e];
+        if constexpr (TPX) {
+          if (from_sc) v = first ? sc0[4 * q + e] : sc1[4 * q + e];
+        }
+        a[q][e] = v;
+      }
   };
   // 24 MFMAs of one step; weight levels are read from LDS just in time (level l is reused by 3-l products)
   auto mma_step = [&](int b, const u32x4* x1, const u32x4* x2, const u32x4* x3, v16f& acc0, v16f& acc1) {
@@ -1351,7 +1416,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
           if (kc < KC) {
             v4f a[4];
             if (kc >= KCg) {
-              kept_a(kc == KCg, a);
+              kept_a(L, kc - KCg, a);
             } else {
               load_a(L, kc, a);
               finish_a(L, kc, a);
@@ -1383,7 +1448,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
         if (!pre) {
           if (kc >= KCg) {
             v4f a[4];
-            kept_a(kc == KCg, a);
+            kept_a(L, kc - KCg, a);
             split3_pack(a, x1, x2, x3);
           } else {
             finish_a(L, kc, a0);
@@ -1424,6 +1489,17 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
       }
       epilogue(L.t[nt], acc0);
       if (two) epilogue(L.t[nt + 1], acc1);
+      if constexpr (TPX) {
+        if (L.tp_from1 > 0 && nt >= L.tp_from1 - 1) {  // (wave-uniform) this pair is irrep r of w0
+          const int r = (nt - (L.tp_from1 - 1)) >> 1;
+          if (r == 0)
+            chain_tp_accumulate<0>(tp_bb, Yh, acc0, acc1, sc0, sc1);
+          else if (r == 1)
+            chain_tp_accumulate<1>(tp_bb, Yh, acc0, acc1, sc0, sc1);
+          else
+            chain_tp_accumulate<2>(tp_bb, Yh, acc0, acc1, sc0, sc1);
+        }
+      }
       if (EMB && L.embrev_out) {  // (64-wide layer: this is its only tile pair)
         float part[8];
 #pragma unroll
@@ -1489,8 +1565,12 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
   if (c.emb_table && (c.num_types < 1 || c.num_types > 2 || !c.types || !c.center || !c.nbr))
     return fail(AA_ERR_INVALID, "gemm chain: the embedding table needs 1..2 types and the edge / type arrays");
   if (c.nlayers < 1 || c.nlayers > 4) return fail(AA_ERR_INVALID, "gemm chain: 1..4 layers");
-  bool have_kept = false;
+  bool have_kept = false, any_tp = false;
   static_assert(sizeof(ChainDev) <= 4096, "kernel argument block too large");
+  d.tp_sh = static_cast<const float*>(c.tp_sh);
+  d.tp_bvec = static_cast<const float*>(c.tp_bvec);
+  d.tp_ld_sh = c.tp_ld_sh;
+  d.tp_D = c.tp_D;
   for (int li = 0; li < c.nlayers; ++li) {
     const ChainLayer& L = c.L[li];
     const GemmArgs& g = L.g;
@@ -1533,14 +1613,25 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
       }
       nc += sg.n;
     }
-    if (ka + (L.use_prev ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
-    if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 != g.N))
-      return fail(AA_ERR_INVALID, "gemm chain: the kept 64 features must be the last tile pair of the layer");
+    if (ka + (L.use_prev ? 64 : 0) + (L.use_sc ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
+    // (a layer that chains from the kept pair may only replace it behind its last tile pair; one that does not may keep any pair)
+    if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 > g.N || (L.use_prev && L.keep_tile * 32 + 64 != g.N)))
+      return fail(AA_ERR_INVALID, "gemm chain: the kept 64 features must be a tile pair (the last one of a layer that chains)");
+    if (L.tp_from1 != 0 || L.use_sc) {
+      any_tp = true;
+      const int t0 = L.tp_from1 - 1;
+      if (L.tp_from1 < 0 || (L.tp_from1 > 0 && ((t0 & 1) || (g.N - 32 * t0) % 64 != 0 || (g.N - 32 * t0) / 64 > 3 || g.N - 32 * t0 <= 0)))
+        return fail(AA_ERR_INVALID, "gemm chain: tensor-track tiles must be whole 64-channel irreps (l_max <= 2) behind an even tile index");
+      if (!c.tp_sh || !c.tp_bvec || !c.center || c.tp_D < 1 || c.tp_D > 9) return fail(AA_ERR_INVALID, "gemm chain: tensor-track scalars need sh, bvec, center, D <= 9");
+    }
     if (L.use_prev && !have_kept) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
     have_kept = have_kept || L.keep_tile >= 0;  // (kept features stay available until a later layer replaces them)
     D.Wq = static_cast<const u32x4*>(g.Bq);
     D.KCg = nchunk;
-    D.KC = nchunk + (L.use_prev ? 2 : 0);
+    D.KC = nchunk + (L.use_prev ? 2 : 0) + (L.use_sc ? 2 : 0);
+    D.tp_from1 = L.tp_from1;
+    D.use_prev = L.use_prev;
+    D.use_sc = L.use_sc;
     D.NT = ntile;
     D.keep_tile = L.keep_tile;
     D.keep_act = L.keep_act;
@@ -1564,8 +1655,11 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
                       (c.emb_table ? sizeof(float) * 512 * c.num_types * c.num_types : 0);
   bool emb = false;
   for (int li = 0; li < d.nlayers; ++li) emb = emb || d.L[li].embrev_out != nullptr;
-#define AA_CHAIN_LAUNCH(P_, E_) hipLaunchKernelGGL((gemm_chain_bf16x3_kernel<P_, E_>), grid, dim3(256), smem, stream, d)
-  if (any_pre) {
+#define AA_CHAIN_LAUNCH(P_, E_) hipLaunchKernelGGL((gemm_chain_bf16x3_kernel<P_, E_, false>), grid, dim3(256), smem, stream, d)
+  if (any_tp) {
+    if (emb) return fail(AA_ERR_INVALID, "gemm chain: tensor-track scalars and embrev_out do not combine");
+    hipLaunchKernelGGL((gemm_chain_bf16x3_kernel<true, false, true>), grid, dim3(256), smem, stream, d);
+  } else if (any_pre) {
     if (emb) AA_CHAIN_LAUNCH(true, true); else AA_CHAIN_LAUNCH(true, false);
   } else {
     if (emb) AA_CHAIN_LAUNCH(false, true); else AA_CHAIN_LAUNCH(false, false);

@@ -147,6 +147,8 @@ struct aa_model_plan {
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
   bool tp_mfma;                      // moments kernels recompute w0 on the matrix cores (aa_tp_mfma.hip)
+  bool chain_tp;                     // forward: the tensor-track scalars are evaluated inside the linear-layer chains that produce
+                                     // w0 (gemm_chain TPX); the moments kernels only form the per-atom vectors
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
   int fused_mode;                    // 1: 32-edge tiles, one wave per atom; 2: 16-edge tiles, two waves per atom (aa_fused16.hip)
   size_t o_g0q16;
@@ -343,6 +345,9 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, con
     p->fused_mode = opt.fused_forward == 2 ? 2 : 1;
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
     // moments kernels with w0 recomputed on the matrix cores (aa_tp_mfma.hip): same stack, no table requirement
+    p->chain_tp = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
+                  u == 64 && S == 64 && cfg->latent_mlp_width == 64 && cfg->embed_mlp_width == 64 && cfg->readout_mlp_width == 64 &&
+                  opt.chain_tp == 1;
     p->tp_mfma = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
                  u == 64 && S == 64 && cfg->latent_mlp_width == 64 && opt.tp_mfma == 1;
   }
@@ -598,6 +603,7 @@ struct Workspace {
   size_t lat_h[AA_MAX_LAYERS][AA_MAX_MLP_LAYERS], g_lat_h[AA_MAX_MLP_LAYERS];
   size_t ro_h[AA_MAX_MLP_LAYERS], g_ro_h[AA_MAX_MLP_LAYERS];
   size_t g_tf[2];
+  size_t bvec[2];  // chain_tp: per-atom Clebsch-Gordan vectors of the two layers [N][D][u]
   size_t total;
 };
 
@@ -645,6 +651,10 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   }
   for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
   if (p->chain_gemm) w.e_edge = take(Ez);
+  if (p->chain_tp) {
+    w.bvec[0] = take(Nz * u * p->D);
+    w.bvec[1] = take(Nz * u * p->D);
+  }
   if (p->embed_fused) w.trev = take(Ez * 8);
   if (with_forces) {
     w.dvec = take(Ez * 4);
@@ -1140,10 +1150,86 @@ struct Runner {
     return mark("fused_fwd", per_edge, per_atom, fl);
   }
 
+  // forward with the tensor-track scalars evaluated inside the chains (plan->chain_tp):
+  //   prologue | emb0 -> h_e -> emb | moments 0 -> B0 | emb -> [two-body | w0 -> scal0] -> latent 0 | moments 1 -> B1 |
+  //   emb -> [w0 -> scal1] -> latent 1 -> readout hidden layer + edge sum | reduce
+  // w0 is still stored once (the reverse pass reads it); scal0 / scal1 never exist in HBM.
+  int forward_chain_tp(const aa_graph* g, const void* pos, void* atom_energy) {
+    const aa_model_config& c = p->cfg;
+    const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
+    if (int rc = mark("begin")) return rc;
+    const double idx2 = 8.0 / sizeof(T);
+    if (int rc = launch_edge_prologue<T>(geom(g, pos), stream)) return rc;
+    if (int rc = mark("edge_prologue", idx2 + 6 + (g->shift_vec ? 3 : 0) + 4 + p->D + c.embed_dim)) return rc;
+    const SegList none{0, {}};
+    {
+      ChainArgs ca{};
+      ca.nlayers = 2;
+      SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
+      SegList c0{1, {seg(buf(w.se_h[0]), 64, 64)}};
+      SegList c1{1, {seg(buf(w.emb), S, S)}};
+      ca.L[0] = chain_layer(E, in, 0, wt(p->embed.wq[0]), c.embed_dim, 64, c0, nullptr, nullptr, nullptr, 0, 0, 1);
+      ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wq[1]), 64, S, c1, nullptr, nullptr, nullptr, 1, -1, 0);
+      if (int rc = run_chain(ca, "F1a")) return rc;
+    }
+    auto tp_chain_args = [&](ChainArgs& ca, int l) {
+      ca.center = g->center;
+      ca.tp_sh = buf(w.sh);
+      ca.tp_ld_sh = p->D;
+      ca.tp_D = p->D;
+      ca.tp_bvec = buf(w.bvec[l]);
+    };
+    for (int l = 0; l < L; ++l) {
+      TpMomArgs m = mom_args(g);
+      m.bvec_out = buf(w.bvec[l]);
+      if (l == 0) {
+        if (int rc = launch_tp_mom_fwd_first<T>(p->chain_pair, m, stream)) return rc;
+        if (int rc = mark("tp_mom_vec_first", p->D + m.ka0, 2.0 * p->D * u)) return rc;
+      } else {
+        if (int rc = launch_tp_mom_fwd_last<T>(p->chain_pair, m, stream)) return rc;
+        if (int rc = mark("tp_mom_vec_last", p->D + m.ka1, 3.0 * p->D * u)) return rc;
+      }
+      ChainArgs ca{};
+      tp_chain_args(ca, l);
+      SegList in{1, {seg(buf(w.emb), S, S)}};
+      SegList ch{1, {seg(buf(w.lat_h[l][0]), 64, 64)}};
+      SegList cl{1, {seg(buf(w.fcat) + S * (l + 1), SL1, S)}};
+      if (l == 0) {
+        // emb -> [two-body (stored, kept) | w0 (stored; scal0 accumulated behind every irrep)] -> [two-body | scal0] -> h -> lat0
+        ca.nlayers = 3;
+        SegList c2{2, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W)}};
+        ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0q), 64, p->ng0, c2, nullptr, nullptr, nullptr, 0, 0, 0);
+        ca.L[0].tp_from1 = 3;  // tiles 2.. are the irreps of w0
+        ca.L[1] = chain_layer(E, none, 0, wt(p->latent[0].wq[0]), S + u, 64, ch, nullptr, nullptr, nullptr, 1, 0, 1);
+        ca.L[1].use_sc = 1;
+        ca.L[2] = chain_layer(E, none, 0, wt(p->latent[0].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, -1, 0);
+      } else {
+        // emb -> w0 again (not stored; scal1) -> [two-body | lat0 | scal1] -> h -> lat1 -> readout hidden layer + edge sum
+        ca.nlayers = 4;
+        SegList cw{1, {seg(nullptr, W, W)}};
+        SegList in2{1, {seg(buf(w.fcat), SL1, S * 2)}};
+        SegList fin{1, {seg(buf(w.fcat), SL1, S * L)}};
+        SegList cr{1, {seg(buf(w.ro_h[0]), 64, 64)}};
+        ca.L[0] = chain_layer(E, in, 0, reinterpret_cast<const float*>(wt(p->o_g0q)) + size_t(2) * 2 * 1536, 64, W, cw, nullptr, nullptr, nullptr, 0, -1, 0);
+        ca.L[0].tp_from1 = 1;  // every tile is an irrep of w0
+        ca.L[1] = chain_layer(E, in2, 0, wt(p->latent[1].wq[0]), S * 2 + u, 64, ch, nullptr, nullptr, nullptr, 0, 0, 1);
+        ca.L[1].use_sc = 1;
+        ca.L[2] = chain_layer(E, none, 0, wt(p->latent[1].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, 0, 0);
+        ca.L[3] = chain_layer(E, fin, 0, wt(p->readout.wq[0]), S * L + 64, 64, cr, nullptr, nullptr, nullptr, 1, -1, 0);
+        ca.L[3].edge_sum_out = buf(w.e_edge);
+        ca.ro_w = wt(p->o_ro_last);
+      }
+      if (int rc = run_chain(ca, l == 0 ? "F1b" : "F2b")) return rc;
+    }
+    if (int rc = launch_readout_reduce<T>(readout_args(g, atom_energy), stream)) return rc;
+    return mark("readout_reduce", 1, 1);
+  }
+
   int forward(const aa_graph* g, const void* pos, void* atom_energy) {
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
     if (use_fused_fwd(g)) return forward_fused(g, pos, atom_energy);
+    if (sizeof(T) == 4 && p->chain_tp && !p->taps) return forward_chain_tp(g, pos, atom_energy);
     // 1-2: geometry, SH, radial-chemical embedding
     if (int rc = mark("begin")) return rc;
     const double idx2 = 8.0 / sizeof(T);  // center + nbr ids, in elements

@@ -113,7 +113,7 @@ def step_roofline(cfg, E, t_step, stages, dtype):
                 frac_of_hbm_roof_this_design=t_hbm / t_step)
 
 
-def profile_stages(model, pos, graph):
+def profile_stages(model, pos, graph, reps=5):
     """[(kernel-launch name, ms, algorithmic bytes, flops)] of one forward+force pass, averaged over 5 passes:
     HIP events recorded by the library on the launch stream around every kernel (aa_model_energy_forces_profiled)."""
     lib = model._get_lib()
@@ -131,7 +131,6 @@ def profile_stages(model, pos, graph):
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     acc = {}
-    reps = 5
     stream = torch.cuda.current_stream(pos.device).cuda_stream if pos.is_cuda else 0  # (CPU: the tests' emulation build)
     for _ in range(reps):
         rc = fn(model._plan_handle, model._blob.data_ptr(), C.byref(g), pos.data_ptr(), model._workspace.data_ptr(),

@@ -192,6 +192,8 @@ typedef struct {
   int32_t tp_mfma;         /* tensor-product kernels that recompute the first-layer x1 weights on the matrix cores
                             * (aa_tp_mfma.hip) instead of re-reading them: 0 automatic, 1 on where supported, 2 off  */
   int32_t f64_rows;        /* fp64 linear layers, row-resident kernels (operand rows read once): 0 where measured faster, 1 wherever applicable, 2 off */
+  int32_t chain_tp;        /* 1: forward with the tensor-track scalars evaluated inside the linear-layer chains that produce w0
+                            * (scal0 / scal1 never reach HBM; the moments kernels only form the per-atom vectors)         */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

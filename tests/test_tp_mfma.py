@@ -2,9 +2,9 @@
 w0 = EDGE_EMBEDDING @ Wg is rebuilt per 32-edge tile from LDS-resident bf16x3 fragments instead of being re-read from
 HBM by every tensor-product kernel.
 
-CPU: the unmodified kernel source in the test-only emulation build against the reference's golden vectors and against the
-fp64 oracle on a ragged graph whose segments span several tiles (degree > 32, partial tiles, an atom without edges).
-GPU: the same on hardware plus an A/B against the kernels that read w0 (AA_TP_MFMA=0)."""
+CPU: the unmodified kernel source in the test-only emulation build against the fp64 oracle on a graph whose segments
+span several tiles (degree > 32, partial tiles, an atom without edges), with the launch list checked.
+GPU: the same on hardware, the reference's golden vectors, and an A/B against the kernels that read w0 (AA_TP_MFMA=0)."""
 import numpy as np
 import pytest
 import torch
@@ -61,21 +61,13 @@ def _vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev):
 
 
 
-@pytest.mark.parametrize("name", ["c2", "c2_l1"])
-def test_matches_reference_golden_emulated(name, monkeypatch):
-    _on(monkeypatch)
-    fx = load_model_fixture(name, torch.float32)
-    m = model_from_fixture(fx, torch.float32, emu_lib())
-    data, sv = fixture_data(fx, torch.float32)
-    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
-    e, f = m.energy_forces(data["pos"], g)
-    for got, want in ((e, fx["out"]["atomic_energy"].reshape(-1)), (f, fx["out"]["forces"])):
-        assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
-    if name == "c2_l1":  # the launch list of a step names the kernels that ran
-        import bench
+def _assert_launched(m, pos, cell, ei, shift, types, present, absent):
+    """The launch list of a step names the kernels that ran."""
+    import bench
 
-        names = [s[0] for s in bench.profile_stages(m, data["pos"], g)]
-        assert "tp_mfma_fwd_first" in names and "tp_mfma_fwd_last" in names and "tp_mom_fwd_first" not in names
+    g = m.prepare_graph(torch.tensor(ei), torch.tensor(types), pos.shape[0], torch.tensor(shift @ cell, dtype=torch.float32))
+    names = [s[0] for s in bench.profile_stages(m, torch.tensor(pos, dtype=torch.float32), g, reps=1)]
+    assert all(n in names for n in present) and not any(n in names for n in absent), names
 
 
 def test_segments_longer_than_one_tile_vs_fp64_oracle_emulated(monkeypatch):
@@ -83,8 +75,9 @@ def test_segments_longer_than_one_tile_vs_fp64_oracle_emulated(monkeypatch):
     pos, cell, ei, shift, types = _dense_cluster()
     deg = np.bincount(ei[0], minlength=pos.shape[0])
     assert deg.max() > 32 and deg.min() == 0 and (deg % 32 != 0).any()
-    _vs_oracle64(_cfg("bessel", True, avg=float(deg.mean()), scale_shift=False), pos, cell, ei, shift, types, emu_lib(),
-                 torch.device("cpu"))
+    m = _vs_oracle64(_cfg("bessel", True, avg=float(deg.mean()), scale_shift=False), pos, cell, ei, shift, types, emu_lib(),
+                     torch.device("cpu"))
+    _assert_launched(m, pos, cell, ei, shift, types, ("tp_mfma_fwd_first", "tp_mfma_fwd_last"), ("tp_mom_fwd_first",))
 
 
 @pytest.mark.gpu
