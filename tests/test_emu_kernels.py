@@ -103,8 +103,8 @@ def test_moments_packed_path_ragged_degrees_vs_oracle():
 
 
 def test_moments_path_long_segments_vs_oracle():
-    """Degrees above the 64-edge staging chunk of the moments kernels (and odd): every atom of a dense cluster sees
-    all 68 others, so each segment is walked in two staged chunks (64 + 5 edges, padded last pair)."""
+    """Degrees above the 64-edge staging chunk of the moments kernels (and odd): every center atom of a dense cluster sees
+    all 69 others, so each segment is walked in two staged chunks (64 + 5 edges, padded last pair)."""
     import numpy as np
 
     from oracle import restatement as R
@@ -116,8 +116,10 @@ def test_moments_path_long_segments_vs_oracle():
     pos = grid * 0.52 + rng.uniform(-0.05, 0.05, size=(70, 3)) + 20.0
     cell = np.eye(3) * 60.0
     ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
+    keep = ei[0] < 12  # (only the first 12 atoms keep their segments: the emulated 64-wide model costs ~15 ms per edge;
+    ei, shift = ei[:, keep], shift[keep]  # the rest are neighbors only -- empty segments behind long ones)
     deg = np.bincount(ei[0], minlength=70)
-    assert deg.min() == 69 and deg.max() == 69
+    assert deg[:12].min() == 69 and deg.max() == 69 and deg[12:].max() == 0
     cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=2, num_layers=2, num_scalar_features=64, num_tensor_features=64,
                radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
                radial_chemical_embed_dim=32, scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=64,

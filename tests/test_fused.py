@@ -104,7 +104,7 @@ def _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev, blocks=None):
 
 # (the CPU suite runs a cross-section of (tile form, fixture) pairs -- the emulated 64-wide model takes ~18 s per case;
 #  the GPU tests below run every combination)
-@pytest.mark.parametrize("mode,name", [("tile32", "c2_uncoupled"), ("tile16", "c2_spline"), ("tile16", "c2_l1")])
+@pytest.mark.parametrize("mode,name", [("tile32", "c2_uncoupled"), ("tile16", "c2_spline")])
 def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch):
     _opt_in(monkeypatch, mode)
     fx = load_model_fixture(name, torch.float32)
@@ -117,7 +117,7 @@ def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch
         assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("mode,embed,coupling", [("tile32", "bessel", True), ("tile16", "spline", False)])
+@pytest.mark.parametrize("mode,embed,coupling", [("tile16", "spline", False)])
 def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(mode, embed, coupling, monkeypatch):
     _opt_in(monkeypatch, mode)
     pos, cell, ei, shift, types = _ragged()

@@ -29,7 +29,8 @@ def _dense_cluster(n=40, seed=9):
     pos = np.concatenate([pos, [[50.0, 50.0, 50.0]]])  # isolated: no edges
     cell = np.eye(3) * 60.0
     ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
-    return pos, cell, ei, shift, rng.integers(0, 2, size=n + 1)
+    keep = ei[0] < 14  # (14 center atoms keep their segments, the rest are neighbors only: emulation time)
+    return pos, cell, ei[:, keep], shift[keep], rng.integers(0, 2, size=n + 1)
 
 
 def _vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev):
