@@ -151,6 +151,8 @@ struct aa_model_plan {
                                      // w0 (gemm_chain TPX); the moments kernels only form the per-atom vectors
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
   int fused_mode;                    // 1: 32-edge tiles, one wave per atom; 2: 16-edge tiles, two waves per atom (aa_fused16.hip)
+  bool fused_auto;                   // the fused forward only runs where it is the faster one: at most fused_auto_atoms owned atoms
+  int64_t fused_auto_atoms;          // 4 atoms per workgroup x number of CUs
   size_t o_g0q16;
   bool fused_hold_w0;                // ... holding the w0 tiles in registers between the two layers (else: recomputed)
   mutable bool taps = false;         // aa_model_plan_enable_taps: staged pipeline so that every tap is materialised
@@ -273,7 +275,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, con
   p->o_basis = take(size_t(B) * S0);
   AA_REQUIRE(cfg->embed_kind == 0 || (cfg->embed_kind == 1 && cfg->spline_span >= 0 && cfg->spline_span <= B),
              "model: embed_kind must be 0 (Bessel) or 1 (spline, 0 <= span <= num_splines)");
-  const bool fused16 = opt.fused_forward == 2;
+  const bool fused16 = opt.fused_forward == 2 || opt.fused_forward == 0;  // (0: automatic -- small graphs run the 16-edge-tile form)
   auto lay = [&](MlpLayout& m, const std::vector<int>& dims, int nlayers) {
     m.dims = dims;
     for (int i = 0; i < nlayers; ++i) {
@@ -335,14 +337,24 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, con
   p->o_shifts = take(T);
   p->n_elems = o;
   {
-    // fused per-atom-tile forward (aa_fused.hip): the standard 2-layer 64-wide fp32 stack with the two-body table in
-    // LDS.  OPT-IN (aa_plan_options.fused_forward): correct (same parity tests as the staged pipeline) but measured SLOWER than the staged
-    // forward on MI355X -- 6.3-8.7 ms vs 5.5 ms at C4 -- because its register / LDS footprint allows one wave per
-    // SIMD only and a single wave cannot hide its own LDS / MFMA / L2 latencies (profiles/r02_v5_*)
-    p->fused_fwd = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                   u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0 &&
-                   (opt.fused_forward == 1 || opt.fused_forward == 2);
-    p->fused_mode = opt.fused_forward == 2 ? 2 : 1;
+    // fused per-atom-tile forward (aa_fused.hip / aa_fused16.hip): the standard 2-layer 64-wide fp32 stack with the
+    // two-body table in LDS.  Same parity tests as the staged pipeline.  On MI355X it is SLOWER than the staged forward
+    // once the chip is full (6.3-10 ms vs 5.5 ms at C4: one or two waves per SIMD cannot hide their own LDS / MFMA / L2
+    // latencies) and FASTER in the launch-latency regime: up to one workgroup per CU (4 atoms
+    // each) the 16-edge-tile form replaces seven dependent launches by one (64-1000 atoms: 13-17 % of the step,
+    // profiles/r02_v15_small_sweep.log).  aa_plan_options.fused_forward: 0 = automatic (that regime), 1 / 2 = always
+    // (32- / 16-edge tiles), 3 = never.
+    const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
+                          u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0;
+    p->fused_fwd = eligible && (opt.fused_forward == 1 || opt.fused_forward == 2 || (opt.fused_forward == 0 && cfg->l_max <= 2));
+    p->fused_auto = opt.fused_forward == 0;
+    p->fused_mode = opt.fused_forward == 1 ? 1 : 2;
+    p->fused_auto_atoms = 0;
+    if (p->fused_fwd && p->fused_auto) {
+      int dev = 0, ncu = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
+        p->fused_auto_atoms = 4 * int64_t(ncu);
+    }
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
     // moments kernels with w0 recomputed on the matrix cores (aa_tp_mfma.hip): same stack, no table requirement
     p->chain_tp = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
@@ -1043,7 +1055,8 @@ struct Runner {
 
   // the whole forward in one launch (aa_fused.hip): every center atom's edge segment fits one 32-row MFMA tile
   bool use_fused_fwd(const aa_graph* g) const {
-    return sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= 32;
+    if (!(sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= 32)) return false;
+    return !p->fused_auto || atom_end(g) - atom_begin(g) <= p->fused_auto_atoms;
   }
   int forward_fused(const aa_graph* g, const void* pos, void* atom_energy) {
     const aa_model_config& c = p->cfg;

@@ -68,7 +68,7 @@ WORKLOADS = {
 def make_workload(name):
     w = WORKLOADS[name]
     if w["kind"] == "si":
-        g = G.make_si_graph(w["cells"])
+        g = G.make_si_graph(int(os.environ.get("AA_BENCH_CELLS", w["cells"])))  # (AA_BENCH_CELLS: size sweeps, experiments only)
         cfg = si_model_cfg(g.num_edges / g.num_atoms)
         cfg["l_max"] = w.get("l_max", cfg["l_max"])
         cfg["num_tensor_features"] = w.get("u", cfg["num_tensor_features"])

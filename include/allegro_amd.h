@@ -162,8 +162,10 @@ typedef struct {
    * The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
   int64_t atom_begin, atom_end;
   /* optional hint: no center atom has more than max_degree edges (0 = unknown).  With max_degree <= 32 the standard
-   * 2-layer 64-wide fp32 stack runs the fused per-atom-tile forward (one wave = one atom's edge tile);
-   * otherwise the staged pipeline.  The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
+   * 2-layer 64-wide fp32 stack may run the fused per-atom-tile forward (one launch instead of seven; chosen automatically
+   * for small blocks -- at most 4 owned atoms per CU -- where the step is launch-latency-bound, see
+   * aa_plan_options.fused_forward and DESIGN.md section 9.1); otherwise the staged pipeline.  The caller guarantees it
+   * (allegro_amd.nn.PreparedGraph derives it from rowptr). */
   int64_t max_degree;
 } aa_graph;
 
@@ -186,7 +188,8 @@ typedef struct {
   int32_t gemm_lds_epilogue; /* LDS-transposed epilogue in the single-layer bf16x3 kernel                       */
   int32_t f64_column_loop; /* fp64 linear layers: 0 automatic, 1 never, 2 always walk all column tiles per workgroup */
   int32_t embed_no_fuse;   /* reverse pass: materialise d(two-body embedding)                                   */
-  int32_t fused_forward;   /* 0 staged pipeline; 1 fused forward, 32-edge tiles; 2 fused forward, 16-edge tiles */
+  int32_t fused_forward;   /* fused per-atom-tile forward: 0 automatic (small graphs: at most 4 atoms per CU, 16-edge tiles),
+                            * 1 always, 32-edge tiles; 2 always, 16-edge tiles; 3 never (staged pipeline)          */
   int32_t fused_recompute_w0; /* fused forward: recompute w0 for the second layer instead of holding it         */
   int32_t moments_waves_per_block; /* 0 = 1                                                                      */
   int32_t tp_mfma;         /* tensor-product kernels that recompute the first-layer x1 weights on the matrix cores

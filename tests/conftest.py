@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# Kernel selection is explicit in the tests: the staged pipeline unless a test opts into another path (monkeypatch of the
+# AA_* variables that allegro_amd/_lib.py maps onto aa_plan_options).  Unset, AA_FUSED means "automatic" -- small graphs
+# run the fused forward -- which tests/test_fused.py covers on its own.
+os.environ.setdefault("AA_FUSED", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
