@@ -275,7 +275,8 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, con
   p->o_basis = take(size_t(B) * S0);
   AA_REQUIRE(cfg->embed_kind == 0 || (cfg->embed_kind == 1 && cfg->spline_span >= 0 && cfg->spline_span <= B),
              "model: embed_kind must be 0 (Bessel) or 1 (spline, 0 <= span <= num_splines)");
-  const bool fused16 = opt.fused_forward == 2 || opt.fused_forward == 0;  // (0: automatic -- small graphs run the 16-edge-tile form)
+  const bool fused16 = true;  // (the 16-edge-tile copies are always part of the blob: its layout must not depend on fused_forward,
+                              //  a blob packed by one plan is consumed by plans created with other options -- the exported op)
   auto lay = [&](MlpLayout& m, const std::vector<int>& dims, int nlayers) {
     m.dims = dims;
     for (int i = 0; i < nlayers; ++i) {
