@@ -41,7 +41,7 @@ class PlanOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "tp_generic", "tp_no_chain", "tp_no_moments", "tp_no_operator", "tp_force_operator", "tp_operator_fused",
         "gemm_no_chain", "gemm_fp32_mfma", "gemm_valu", "gemm_v1", "gemm_lds_epilogue", "f64_column_loop",
-        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "tp_mfma", "f64_rows", "chain_tp")]
+        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "tp_mfma", "f64_rows", "chain_tp", "no_channel_padding")]
 
 
 def options_from_env() -> PlanOptions:
@@ -62,6 +62,7 @@ def options_from_env() -> PlanOptions:
     o.moments_waves_per_block = int(env.get("AA_MOM_WPB", "0") or 0)
     o.tp_mfma = {"1": 1, "0": 2}.get(env.get("AA_TP_MFMA", "")[:1], 0)
     o.chain_tp = flag("AA_CHAIN_TP")
+    o.no_channel_padding = flag("AA_NO_PAD")
     o.f64_rows = {"0": 2, "2": 1}.get(env.get("AA_F64_ROWS", "")[:1], 0)  # 0: off, 2: wherever applicable
     return o
 

@@ -142,6 +142,7 @@ struct aa_model_plan {
   int ro_last_dim;                   // input dim of the final readout linear
   int spec_sig[AA_MAX_LAYERS];       // generated-signature id per layer, or -1
   bool use_spec;                     // all layers specialised -> channel-minor internal layouts
+  int u_raw;                         // num_tensor_features of the model; cfg.num_tensor is 64 when the channels were padded (see plan_create)
   int chain_pair;                    // >= 0: 2-layer stack on the chain kernels (no [E,u,D] tensors in HBM)
   bool env_mom;                      // env weights through per-atom moments: no [E,R*u] env tensors (TpMomArgs / TpOpArgs)
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
@@ -190,9 +191,29 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
   return aa_model_plan_create_with_options(cfg, nullptr, out);
 }
 
-extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, const aa_plan_options* options, aa_model_plan** out) {
-  AA_REQUIRE(cfg && out, "aa_model_plan_create: null argument");
+extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, const aa_plan_options* options, aa_model_plan** out) {
+  AA_REQUIRE(cfg_in && out, "aa_model_plan_create: null argument");
   const aa_plan_options opt = options ? *options : aa_plan_options{};
+  // Channel padding.  A stack with 16 or 32 tensor channels is evaluated as the 64-channel stack whose extra channels
+  // have zero weights: env_embed_linear / the env columns of first_proj and of the latent outputs / the scalar rows of
+  // the latent inputs are zero-padded at pack time (aa_model_pack_weights), so the padded channels carry exact zeros
+  // through every layer and the results are those of the narrow model -- which thereby runs the tuned 64-channel
+  // kernels (moments, fused chains, fused forward) instead of the per-edge ones (BASELINE config 0, u = 32: 26 launches
+  // and 0.40 ms per step on 64 atoms without, 15 launches with).  Only where the 64-channel stack takes that path.
+  aa_model_config cfg_local = *cfg_in;
+  const int u_raw = cfg_in->num_tensor;
+  {
+    const aa_model_config& q = *cfg_in;
+    const bool silu = q.act_kind[0] == AA_ACT_SILU && q.act_kind[1] == AA_ACT_SILU && q.act_kind[2] == AA_ACT_SILU;
+    const bool pad = !opt.no_channel_padding && (u_raw == 16 || u_raw == 32) && silu && q.num_layers == 2 && q.l_max <= 2 &&
+                     (q.num_scalar == 64 || q.num_scalar == 128) && q.latent_mlp_depth >= 1 &&
+                     (q.latent_mlp_width == 64 || q.latent_mlp_width == 128) && !opt.tp_generic && !opt.tp_no_chain && !opt.tp_no_moments;
+    if (pad) {
+      cfg_local.num_tensor = 64;
+      for (int l = 0; l < q.num_layers && l < AA_MAX_LAYERS; ++l) cfg_local.tps[l].mul = 64;
+    }
+  }
+  const aa_model_config* cfg = &cfg_local;
   AA_REQUIRE(cfg->dtype == AA_F32 || cfg->dtype == AA_F64, "model: bad dtype");
   AA_REQUIRE(cfg->l_max >= 1 && cfg->l_max <= 3, "model: l_max must be 1..3");
   for (int i = 0; i < 3; ++i) AA_REQUIRE(cfg->act_kind[i] >= AA_ACT_SILU && cfg->act_kind[i] <= AA_ACT_NONE, "model: unknown nonlinearity");
@@ -204,6 +225,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg, con
              "model: bad embedding sizes");
   aa_model_plan* p = new aa_model_plan();
   p->cfg = *cfg;
+  p->u_raw = u_raw;
   p->opt = opt;
   const int L = cfg->num_layers, S = cfg->num_scalar, u = cfg->num_tensor;
   p->R = cfg->l_max + 1;
@@ -409,13 +431,52 @@ static double mlp_alpha(const aa_model_config& c, int layer, int din, int dout, 
   return norm / std::sqrt(double(c.forward_weight_init ? din : dout));
 }
 
-extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_weights* raw, void* dev_blob,
+extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_weights* raw_in, void* dev_blob,
                                      size_t blob_bytes, aa_stream stream) {
-  AA_REQUIRE(p && raw && dev_blob, "aa_model_pack_weights: null argument");
+  AA_REQUIRE(p && raw_in && dev_blob, "aa_model_pack_weights: null argument");
   AA_REQUIRE(blob_bytes >= aa_model_weights_bytes(p), "aa_model_pack_weights: blob too small");
   const aa_model_config& c = p->cfg;
   const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, T = c.num_types, B = c.num_bessels, S0 = c.embed_dim;
   const int W = p->W;
+  // Channel-padded plan (aa_model_plan_create): the state_dict tensors carry u_raw channels; build zero-padded copies in
+  // the reference's own layouts so that everything below indexes a u-channel model.  The ScalarMLPFunction constants
+  // (alpha = c / sqrt(fan_in | fan_out)) keep following the TRUE layer shapes (the *_raw widths).
+  const int u_raw = p->u_raw, Rp = p->R, dlat = c.latent_mlp_depth;
+  const bool padded = u_raw != u;
+  const int We_in = (c.env_shared_weights != 0) ? u_raw : Rp * u_raw;   // env columns in the state_dict
+  const int We_pad = (c.env_shared_weights != 0) ? u : W;
+  const int dW = W - Rp * u_raw, dWe = We_pad - We_in, du = u - u_raw;  // how much wider the padded shapes are
+  aa_model_raw_weights raw_local = *raw_in;
+  std::vector<std::vector<double>> pad_store;
+  if (padded) {
+    AA_REQUIRE(raw_in->env_embed_linear && raw_in->first_proj, "pack: missing embedding weights");
+    // columns: [prefix | blocks of `blk_raw` per ... ] -- both env layouts are channel-major ([u][R] or [u]), so padding
+    // appends zero columns at the end of the env block
+    auto pad_cols = [&](const double* src, int rows, int prefix, int env_raw, int env_pad) {
+      pad_store.emplace_back(size_t(rows) * (prefix + env_pad), 0.0);
+      std::vector<double>& d = pad_store.back();
+      for (int r = 0; r < rows; ++r) {
+        for (int q = 0; q < prefix + env_raw; ++q) d[size_t(r) * (prefix + env_pad) + q] = src[size_t(r) * (prefix + env_raw) + q];
+      }
+      return d.data();
+    };
+    auto pad_rows = [&](const double* src, int rows_raw, int rows_pad, int cols) {
+      pad_store.emplace_back(size_t(rows_pad) * cols, 0.0);
+      std::vector<double>& d = pad_store.back();
+      for (size_t i = 0; i < size_t(rows_raw) * cols; ++i) d[i] = src[i];
+      return d.data();
+    };
+    raw_local.env_embed_linear = pad_cols(raw_in->env_embed_linear, S, 0, Rp * u_raw, W);
+    raw_local.first_proj = pad_cols(raw_in->first_proj, S, S, We_in, We_pad);
+    for (int l = 0; l < L; ++l) {
+      AA_REQUIRE(raw_in->latent[l][0] && raw_in->latent[l][dlat] && raw_in->tp_weights[l], "pack: missing latent / tp weights");
+      // first layer: input rows [S (l + 1) | u scalars]
+      raw_local.latent[l][0] = pad_rows(raw_in->latent[l][0], S * (l + 1) + u_raw, S * (l + 1) + u, dlat > 0 ? c.latent_mlp_width : S + (l < L - 1 ? We_in : 0));
+      if (l < L - 1) raw_local.latent[l][dlat] = pad_cols(dlat > 0 ? raw_in->latent[l][dlat] : raw_local.latent[l][0], dlat > 0 ? c.latent_mlp_width : S * (l + 1) + u, S, We_in, We_pad);
+      if (c.tps[l].coupling) raw_local.tp_weights[l] = pad_rows(raw_in->tp_weights[l], u_raw, u, c.tps[l].num_paths);
+    }
+  }
+  const aa_model_raw_weights* raw = &raw_local;
   std::vector<double> h(p->n_elems, 0.0);
   auto copy = [&](size_t off, const double* src, size_t n, double scale) {
     for (size_t i = 0; i < n; ++i) h[off + i] = src[i] * scale;
@@ -461,12 +522,15 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   // pack an MLP; if env_off >= 0 the LAST layer's columns [env_off, env_off+W) are env weights
   // raw_last_width: true column count of the LAST layer in the state_dict (>= packed width when the env columns
   // are split off for the moments path); alpha always follows the reference's full layer shape
-  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off, int which, int raw_last_width = -1) -> bool {
+  // true_din_less / true_dout_less: how much narrower the reference's first-layer input / last-layer output is than the
+  // (channel-padded) shapes packed here -- alpha follows the reference
+  auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off, int which, int raw_last_width = -1,
+                      int true_din_less = 0, int true_dout_less = 0) -> bool {
     for (int i = 0; i < nlayers; ++i) {
       if (!ws[i]) return false;
       int din = m.dims[i], dout = m.dims[i + 1];
       int raw_w = (i == nlayers - 1 && raw_last_width > 0) ? raw_last_width : dout;
-      double al = mlp_alpha(c, i, din, raw_w, which);
+      double al = mlp_alpha(c, i, din - (i == 0 ? true_din_less : 0), raw_w - (i == nlayers - 1 ? true_dout_less : 0), which);
       for (int r = 0; r < din; ++r)
         for (int q = 0; q < dout; ++q) {
           int src = q;
@@ -485,7 +549,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     // fused first stage: [ two_body (first_proj[:, :S]) | w0 (env_embed_linear) | env_w0 (first_proj[:, S:]) ]
     // (moments path: the env_w0 columns are not part of the GEMM; they become Wenv of layer 0 below)
     const int NG = p->ng0;
-    double a_env = mlp_alpha(c, 0, S, W), a_proj = mlp_alpha(c, 0, S, S + We);
+    double a_env = mlp_alpha(c, 0, S, W - dW), a_proj = mlp_alpha(c, 0, S, S + We - dWe);
     for (int r = 0; r < S; ++r)
       for (int q = 0; q < NG; ++q) {
         double v;
@@ -503,7 +567,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   }
   for (int l = 0; l < L; ++l) {
     AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, (l < L - 1 && !p->env_mom) ? S : -1, 1,
-                        S + (l < L - 1 ? We : 0)),
+                        S + (l < L - 1 ? We : 0), du, l < L - 1 ? dWe : 0),
                "pack: missing latent weights");
     AA_REQUIRE(raw->tp_weights[l], "pack: missing tp weights");
     copy(p->o_tpw[l], raw->tp_weights[l], size_t(c.tps[l].coupling ? u : 1) * c.tps[l].num_paths, 1.0);
@@ -519,10 +583,10 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
             h[p->o_wt[l] + (size_t(r) * u + ch) * ka + k] = v;
           }
     };
-    fill(0, raw->first_proj, S, S + We, mlp_alpha(c, 0, S, S + We));
+    fill(0, raw->first_proj, S, S + We, mlp_alpha(c, 0, S, S + We - dWe));
     const int dl = c.latent_mlp_depth;  // index of a latent's last layer
     for (int l = 1; l < L; ++l)
-      fill(l, raw->latent[l - 1][dl], c.latent_mlp_width, S + We, mlp_alpha(c, dl, c.latent_mlp_width, S + We, 1));
+      fill(l, raw->latent[l - 1][dl], c.latent_mlp_width, S + We, mlp_alpha(c, dl, c.latent_mlp_width, S + We - dWe, 1));
   }
   AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1, 2), "pack: missing readout weights");
   {
