@@ -47,7 +47,7 @@ def test_native_op_has_no_cpu_kernel():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,dtype,tol", [("c2", torch.float32, 5e-5), ("t_peredge", torch.float64, 1e-9),
+@pytest.mark.parametrize("name,dtype,tol", [("c2", torch.float32, 5e-5), ("c1_L2", torch.float32, 5e-5), ("t_peredge", torch.float64, 1e-9),
                                             ("c2_spline", torch.float32, 5e-5)])
 def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol):
     dev = torch.device("cuda:0")
