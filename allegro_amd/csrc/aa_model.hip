@@ -198,14 +198,14 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   // have zero weights: env_embed_linear / the env columns of first_proj and of the latent outputs / the scalar rows of
   // the latent inputs are zero-padded at pack time (aa_model_pack_weights), so the padded channels carry exact zeros
   // through every layer and the results are those of the narrow model -- which thereby runs the tuned 64-channel
-  // kernels (moments, fused chains, fused forward) instead of the per-edge ones (BASELINE config 0, u = 32: 26 launches
+  // kernels (moments or per-atom operator kernels, fused chains, fused forward) instead of the per-edge ones (BASELINE config 0, u = 32: 26 launches
   // and 0.40 ms per step on 64 atoms without, 15 launches with).  Only where the 64-channel stack takes that path.
   aa_model_config cfg_local = *cfg_in;
   const int u_raw = cfg_in->num_tensor;
   {
     const aa_model_config& q = *cfg_in;
     const bool silu = q.act_kind[0] == AA_ACT_SILU && q.act_kind[1] == AA_ACT_SILU && q.act_kind[2] == AA_ACT_SILU;
-    const bool pad = !opt.no_channel_padding && (u_raw == 16 || u_raw == 32) && silu && q.num_layers == 2 && q.l_max <= 2 &&
+    const bool pad = !opt.no_channel_padding && (u_raw == 16 || u_raw == 32) && silu && (q.num_layers == 2 || q.num_layers == 3) &&
                      (q.num_scalar == 64 || q.num_scalar == 128) && q.latent_mlp_depth >= 1 &&
                      (q.latent_mlp_width == 64 || q.latent_mlp_width == 128) && !opt.tp_generic && !opt.tp_no_chain && !opt.tp_no_moments;
     if (pad) {

@@ -74,6 +74,8 @@ def make_workload(name):
         cfg["num_tensor_features"] = w.get("u", cfg["num_tensor_features"])
         if os.environ.get("AA_BENCH_LMAX"):  # experiments only: the same box and widths at another l_max
             cfg["l_max"] = int(os.environ["AA_BENCH_LMAX"])
+        if os.environ.get("AA_BENCH_LAYERS"):  # experiments only
+            cfg["num_layers"] = int(os.environ["AA_BENCH_LAYERS"])
     else:
         g = G.make_water_graph(w["side"], w["box"])
         cfg = water_model_cfg(g.num_edges / g.num_atoms)

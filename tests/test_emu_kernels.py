@@ -337,8 +337,8 @@ def test_bessel_sinc_convention_is_recognised_from_the_stored_roots():
     assert (f - fx["out"]["forces"]).abs().max() > 1e-3
 
 
-@pytest.mark.parametrize("u,coupling,individual", [(16, False, True), (32, True, False)])
-def test_narrow_stacks_run_zero_padded_on_the_64_channel_kernels(u, coupling, individual, monkeypatch):
+@pytest.mark.parametrize("u,coupling,individual,layers", [(16, False, True, 2), (32, True, False, 2), (32, True, True, 3)])
+def test_narrow_stacks_run_zero_padded_on_the_64_channel_kernels(u, coupling, individual, layers, monkeypatch):
     """Channel padding (aa_model_plan_create): a stack with 16 / 32 tensor channels is evaluated as the 64-channel stack
     whose extra channels have zero weights -- same energies and forces as the narrow model (fp64 oracle criterion), on
     the moments / chain kernels (launch list); AA_NO_PAD=1 keeps the narrow kernels and agrees."""
@@ -351,7 +351,8 @@ def test_narrow_stacks_run_zero_padded_on_the_64_channel_kernels(u, coupling, in
     pos, cell, ei, shift, types = _ragged(dims=(3, 3, 3), keep=0.9, seed=4)
     deg = np.bincount(ei[0], minlength=pos.shape[0])
     cfg = _cfg("bessel", coupling, avg=float(deg.mean()))
-    cfg.update(num_tensor_features=u, weight_individual_irreps=individual)
+    cfg.update(num_tensor_features=u, weight_individual_irreps=individual, num_layers=layers)
+    fast = "tp_mom_fwd_first" if layers == 2 else "tp_op_fwd"  # 3 layers: the per-atom operator kernels
     out = {}
     for no_pad in ("0", "1"):
         monkeypatch.setenv("AA_NO_PAD", no_pad)
@@ -359,6 +360,6 @@ def test_narrow_stacks_run_zero_padded_on_the_64_channel_kernels(u, coupling, in
         g = m.prepare_graph(torch.tensor(ei), torch.tensor(types), pos.shape[0], torch.tensor(shift @ cell, dtype=torch.float32))
         p32 = torch.tensor(pos, dtype=torch.float32)
         names = [s[0] for s in bench.profile_stages(m, p32, g, reps=1)]
-        assert ("tp_mom_fwd_first" in names) == (no_pad == "0"), names
+        assert (fast in names) == (no_pad == "0"), names
         out[no_pad] = m.energy_forces(p32, g)
     assert (out["0"][1] - out["1"][1]).abs().max().item() < 2e-5 * max(1.0, float(out["1"][1].abs().max()))
