@@ -194,8 +194,8 @@ extern "C" int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** 
 extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, const aa_plan_options* options, aa_model_plan** out) {
   AA_REQUIRE(cfg_in && out, "aa_model_plan_create: null argument");
   const aa_plan_options opt = options ? *options : aa_plan_options{};
-  // Channel padding.  A stack with 16 or 32 tensor channels is evaluated as the 64-channel stack whose extra channels
-  // have zero weights: env_embed_linear / the env columns of first_proj and of the latent outputs / the scalar rows of
+  // Channel padding.  A stack whose tensor-channel count is not a multiple of 64 (16 <= u < 256) is evaluated as the
+  // next multiple-of-64 stack whose extra channels have zero weights: env_embed_linear / the env columns of first_proj and of the latent outputs / the scalar rows of
   // the latent inputs are zero-padded at pack time (aa_model_pack_weights), so the padded channels carry exact zeros
   // through every layer and the results are those of the narrow model -- which thereby runs the tuned 64-channel
   // kernels (moments or per-atom operator kernels, fused chains, fused forward) instead of the per-edge ones (BASELINE config 0, u = 32: 26 launches
@@ -205,12 +205,13 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   {
     const aa_model_config& q = *cfg_in;
     const bool silu = q.act_kind[0] == AA_ACT_SILU && q.act_kind[1] == AA_ACT_SILU && q.act_kind[2] == AA_ACT_SILU;
-    const bool pad = !opt.no_channel_padding && (u_raw == 16 || u_raw == 32) && silu && (q.num_layers == 2 || q.num_layers == 3) &&
+    const int u_pad = (u_raw + 63) / 64 * 64;  // 16..63 -> 64 (moments / operator kernels), 65..127 -> 128, ... (operator kernels)
+    const bool pad = !opt.no_channel_padding && u_raw >= 16 && u_raw != u_pad && u_pad <= 256 && silu && (q.num_layers == 2 || q.num_layers == 3) &&
                      (q.num_scalar == 64 || q.num_scalar == 128) && q.latent_mlp_depth >= 1 &&
                      (q.latent_mlp_width == 64 || q.latent_mlp_width == 128) && !opt.tp_generic && !opt.tp_no_chain && !opt.tp_no_moments;
     if (pad) {
-      cfg_local.num_tensor = 64;
-      for (int l = 0; l < q.num_layers && l < AA_MAX_LAYERS; ++l) cfg_local.tps[l].mul = 64;
+      cfg_local.num_tensor = u_pad;
+      for (int l = 0; l < q.num_layers && l < AA_MAX_LAYERS; ++l) cfg_local.tps[l].mul = u_pad;
     }
   }
   const aa_model_config* cfg = &cfg_local;

@@ -100,8 +100,8 @@ typedef struct {
   int32_t l_max;           /* 1..3                                                            */
   int32_t num_layers;      /* L, _allegro.py:24                                               */
   int32_t num_scalar;      /* S, _allegro.py:25                                               */
-  int32_t num_tensor;      /* u, _allegro.py:26 (16 / 32: evaluated as a zero-padded 64-channel stack where that is
-                            * the faster path -- same results; aa_plan_options.no_channel_padding)           */
+  int32_t num_tensor;      /* u, _allegro.py:26 (not a multiple of 64: evaluated as the zero-padded next multiple where
+                            * that is the faster path -- same results; aa_plan_options.no_channel_padding)  */
   int32_t embed_dim;       /* S0 = radial_chemical_embed_dim, allegro_models.py:160-164        */
   int32_t embed_mlp_depth, embed_mlp_width;     /* allegro_models.py:175-176                  */
   int32_t latent_mlp_depth, latent_mlp_width;   /* allegro_models.py:205-206                  */
@@ -198,8 +198,8 @@ typedef struct {
   int32_t f64_rows;        /* fp64 linear layers, row-resident kernels (operand rows read once): 0 where measured faster, 1 wherever applicable, 2 off */
   int32_t chain_tp;        /* 1: forward with the tensor-track scalars evaluated inside the linear-layer chains that produce w0
                             * (scal0 / scal1 never reach HBM; the moments kernels only form the per-atom vectors)         */
-  int32_t no_channel_padding; /* stacks with 16 / 32 tensor channels are normally evaluated as zero-padded 64-channel stacks
-                               * (same results, tuned kernels); 1: keep the narrow kernels                              */
+  int32_t no_channel_padding; /* stacks whose channel count is not a multiple of 64 are normally evaluated zero-padded to the
+                               * next multiple (same results, tuned kernels); 1: keep the narrow kernels                */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

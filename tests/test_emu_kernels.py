@@ -337,22 +337,23 @@ def test_bessel_sinc_convention_is_recognised_from_the_stored_roots():
     assert (f - fx["out"]["forces"]).abs().max() > 1e-3
 
 
-@pytest.mark.parametrize("u,coupling,individual,layers", [(16, False, True, 2), (32, True, False, 2), (32, True, True, 3)])
-def test_narrow_stacks_run_zero_padded_on_the_64_channel_kernels(u, coupling, individual, layers, monkeypatch):
-    """Channel padding (aa_model_plan_create): a stack with 16 / 32 tensor channels is evaluated as the 64-channel stack
-    whose extra channels have zero weights -- same energies and forces as the narrow model (fp64 oracle criterion), on
-    the moments / chain kernels (launch list); AA_NO_PAD=1 keeps the narrow kernels and agrees."""
+@pytest.mark.parametrize("u,coupling,individual,layers", [(16, False, True, 2), (32, True, True, 3), (48, True, False, 2), (96, True, True, 2)])
+def test_channel_counts_off_the_multiples_of_64_run_zero_padded(u, coupling, individual, layers, monkeypatch):
+    """Channel padding (aa_model_plan_create): a stack whose tensor-channel count is not a multiple of 64 is evaluated as
+    the next multiple-of-64 stack whose extra channels have zero weights -- same energies and forces as the narrow model
+    (fp64 oracle criterion), on the moments / operator / chain kernels (launch list); AA_NO_PAD=1 keeps the narrow
+    kernels and agrees."""
     import numpy as np
 
     import bench
     from tests.test_fused import _cfg, _ragged
     from tests.test_tp_mfma import _vs_oracle64
 
-    pos, cell, ei, shift, types = _ragged(dims=(3, 3, 3), keep=0.9, seed=4)
+    pos, cell, ei, shift, types = _ragged(dims=(3, 3, 2), keep=0.9, seed=4)
     deg = np.bincount(ei[0], minlength=pos.shape[0])
     cfg = _cfg("bessel", coupling, avg=float(deg.mean()))
     cfg.update(num_tensor_features=u, weight_individual_irreps=individual, num_layers=layers)
-    fast = "tp_mom_fwd_first" if layers == 2 else "tp_op_fwd"  # 3 layers: the per-atom operator kernels
+    fast = "tp_mom_fwd_first" if layers == 2 and u < 64 else "tp_op_fwd"  # 3 layers / 128 channels: the per-atom operator kernels
     out = {}
     for no_pad in ("0", "1"):
         monkeypatch.setenv("AA_NO_PAD", no_pad)
