@@ -142,7 +142,8 @@ struct aa_model_plan {
   int ro_last_dim;                   // input dim of the final readout linear
   int spec_sig[AA_MAX_LAYERS];       // generated-signature id per layer, or -1
   bool use_spec;                     // all layers specialised -> channel-minor internal layouts
-  int u_raw;                         // num_tensor_features of the model; cfg.num_tensor is 64 when the channels were padded (see plan_create)
+  int u_raw;                         // num_tensor_features of the model; cfg.num_tensor is the next multiple of 64 when the channels were padded
+  int hid_raw[3];                    // hidden widths of scalar_embed_mlp / latent MLPs / edge_readout in the model (cfg holds the padded ones)
   int chain_pair;                    // >= 0: 2-layer stack on the chain kernels (no [E,u,D] tensors in HBM)
   bool env_mom;                      // env weights through per-atom moments: no [E,R*u] env tensors (TpMomArgs / TpOpArgs)
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
@@ -208,11 +209,20 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     const int u_pad = (u_raw + 63) / 64 * 64;  // 16..63 -> 64 (moments / operator kernels), 65..127 -> 128, ... (operator kernels)
     const bool pad = !opt.no_channel_padding && u_raw >= 16 && u_raw != u_pad && u_pad <= 256 && silu && (q.num_layers == 2 || q.num_layers == 3) &&
                      (q.num_scalar == 64 || q.num_scalar == 128) && q.latent_mlp_depth >= 1 &&
-                     (q.latent_mlp_width == 64 || q.latent_mlp_width == 128) && !opt.tp_generic && !opt.tp_no_chain && !opt.tp_no_moments;
+                     (q.latent_mlp_width == 64 || q.latent_mlp_width == 128 || (q.latent_mlp_depth == 1 && q.latent_mlp_width >= 8 && q.latent_mlp_width < 64)) &&
+                     !opt.tp_generic && !opt.tp_no_chain && !opt.tp_no_moments;
     if (pad) {
       cfg_local.num_tensor = u_pad;
       for (int l = 0; l < q.num_layers && l < AA_MAX_LAYERS; ++l) cfg_local.tps[l].mul = u_pad;
     }
+    // Hidden-width padding, same idea: a single hidden layer narrower than 64 (the reference's constructor default for
+    // edge_readout is 32, allegro_models.py:137) is zero-padded to 64 -- silu(0) = 0 and there are no biases, so the
+    // extra units stay exactly zero -- which is what lets the stack run the fused linear-layer chains.
+    const bool hid = !opt.no_channel_padding && silu && (q.num_layers == 2 || q.num_layers == 3) && (q.num_scalar == 64 || q.num_scalar == 128) &&
+                     !opt.tp_generic && !opt.tp_no_chain && !opt.tp_no_moments;
+    if (hid && q.embed_mlp_depth == 1 && q.embed_mlp_width >= 8 && q.embed_mlp_width < 64) cfg_local.embed_mlp_width = 64;
+    if (hid && q.latent_mlp_depth == 1 && q.latent_mlp_width >= 8 && q.latent_mlp_width < 64) cfg_local.latent_mlp_width = 64;
+    if (hid && q.readout_mlp_depth == 1 && q.readout_mlp_width >= 8 && q.readout_mlp_width < 64) cfg_local.readout_mlp_width = 64;
   }
   const aa_model_config* cfg = &cfg_local;
   AA_REQUIRE(cfg->dtype == AA_F32 || cfg->dtype == AA_F64, "model: bad dtype");
@@ -227,6 +237,9 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   aa_model_plan* p = new aa_model_plan();
   p->cfg = *cfg;
   p->u_raw = u_raw;
+  p->hid_raw[0] = cfg_in->embed_mlp_width;
+  p->hid_raw[1] = cfg_in->latent_mlp_width;
+  p->hid_raw[2] = cfg_in->readout_mlp_width;
   p->opt = opt;
   const int L = cfg->num_layers, S = cfg->num_scalar, u = cfg->num_tensor;
   p->R = cfg->l_max + 1;
@@ -443,38 +456,48 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   // the reference's own layouts so that everything below indexes a u-channel model.  The ScalarMLPFunction constants
   // (alpha = c / sqrt(fan_in | fan_out)) keep following the TRUE layer shapes (the *_raw widths).
   const int u_raw = p->u_raw, Rp = p->R, dlat = c.latent_mlp_depth;
-  const bool padded = u_raw != u;
   const int We_in = (c.env_shared_weights != 0) ? u_raw : Rp * u_raw;   // env columns in the state_dict
   const int We_pad = (c.env_shared_weights != 0) ? u : W;
   const int dW = W - Rp * u_raw, dWe = We_pad - We_in, du = u - u_raw;  // how much wider the padded shapes are
+  const int dHe = c.embed_mlp_width - p->hid_raw[0], dHl = c.latent_mlp_width - p->hid_raw[1], dHr = c.readout_mlp_width - p->hid_raw[2];
   aa_model_raw_weights raw_local = *raw_in;
   std::vector<std::vector<double>> pad_store;
-  if (padded) {
+  // zero-extend a row-major [r_raw][c_raw] matrix to [r_pad][c_pad] (every padded block is a suffix: both env layouts are
+  // channel-major -- [u][R] or [u] -- and hidden units / scalar rows are appended at the end)
+  auto pad2d = [&](const double* src, int r_raw, int c_raw, int r_pad, int c_pad) -> const double* {
+    if (r_raw == r_pad && c_raw == c_pad) return src;
+    pad_store.emplace_back(size_t(r_pad) * c_pad, 0.0);
+    std::vector<double>& d = pad_store.back();
+    for (int r = 0; r < r_raw; ++r)
+      for (int q = 0; q < c_raw; ++q) d[size_t(r) * c_pad + q] = src[size_t(r) * c_raw + q];
+    return d.data();
+  };
+  if (du || dHe || dHl || dHr) {
     AA_REQUIRE(raw_in->env_embed_linear && raw_in->first_proj, "pack: missing embedding weights");
-    // columns: [prefix | blocks of `blk_raw` per ... ] -- both env layouts are channel-major ([u][R] or [u]), so padding
-    // appends zero columns at the end of the env block
-    auto pad_cols = [&](const double* src, int rows, int prefix, int env_raw, int env_pad) {
-      pad_store.emplace_back(size_t(rows) * (prefix + env_pad), 0.0);
-      std::vector<double>& d = pad_store.back();
-      for (int r = 0; r < rows; ++r) {
-        for (int q = 0; q < prefix + env_raw; ++q) d[size_t(r) * (prefix + env_pad) + q] = src[size_t(r) * (prefix + env_raw) + q];
-      }
-      return d.data();
-    };
-    auto pad_rows = [&](const double* src, int rows_raw, int rows_pad, int cols) {
-      pad_store.emplace_back(size_t(rows_pad) * cols, 0.0);
-      std::vector<double>& d = pad_store.back();
-      for (size_t i = 0; i < size_t(rows_raw) * cols; ++i) d[i] = src[i];
-      return d.data();
-    };
-    raw_local.env_embed_linear = pad_cols(raw_in->env_embed_linear, S, 0, Rp * u_raw, W);
-    raw_local.first_proj = pad_cols(raw_in->first_proj, S, S, We_in, We_pad);
+    raw_local.env_embed_linear = pad2d(raw_in->env_embed_linear, S, Rp * u_raw, S, W);
+    raw_local.first_proj = pad2d(raw_in->first_proj, S, S + We_in, S, S + We_pad);
+    if (dHe) {  // (only single-hidden-layer MLPs are padded)
+      AA_REQUIRE(raw_in->embed_mlp[0] && raw_in->embed_mlp[1], "pack: missing scalar_embed_mlp weights");
+      raw_local.embed_mlp[0] = pad2d(raw_in->embed_mlp[0], S0, p->hid_raw[0], S0, c.embed_mlp_width);
+      raw_local.embed_mlp[1] = pad2d(raw_in->embed_mlp[1], p->hid_raw[0], S, c.embed_mlp_width, S);
+    }
     for (int l = 0; l < L; ++l) {
       AA_REQUIRE(raw_in->latent[l][0] && raw_in->latent[l][dlat] && raw_in->tp_weights[l], "pack: missing latent / tp weights");
-      // first layer: input rows [S (l + 1) | u scalars]
-      raw_local.latent[l][0] = pad_rows(raw_in->latent[l][0], S * (l + 1) + u_raw, S * (l + 1) + u, dlat > 0 ? c.latent_mlp_width : S + (l < L - 1 ? We_in : 0));
-      if (l < L - 1) raw_local.latent[l][dlat] = pad_cols(dlat > 0 ? raw_in->latent[l][dlat] : raw_local.latent[l][0], dlat > 0 ? c.latent_mlp_width : S * (l + 1) + u, S, We_in, We_pad);
-      if (c.tps[l].coupling) raw_local.tp_weights[l] = pad_rows(raw_in->tp_weights[l], u_raw, u, c.tps[l].num_paths);
+      const int out_raw = S + (l < L - 1 ? We_in : 0), out_pad = S + (l < L - 1 ? We_pad : 0);
+      if (dlat == 0) {
+        raw_local.latent[l][0] = pad2d(raw_in->latent[l][0], S * (l + 1) + u_raw, out_raw, S * (l + 1) + u, out_pad);
+      } else {
+        // first layer: input rows [S (l + 1) | u scalars], output = hidden units; last layer: [hidden][S | env columns]
+        raw_local.latent[l][0] = pad2d(raw_in->latent[l][0], S * (l + 1) + u_raw, dlat == 1 ? p->hid_raw[1] : c.latent_mlp_width,
+                                       S * (l + 1) + u, c.latent_mlp_width);
+        raw_local.latent[l][dlat] = pad2d(raw_in->latent[l][dlat], dlat == 1 ? p->hid_raw[1] : c.latent_mlp_width, out_raw, c.latent_mlp_width, out_pad);
+      }
+      if (c.tps[l].coupling) raw_local.tp_weights[l] = pad2d(raw_in->tp_weights[l], u_raw, c.tps[l].num_paths, u, c.tps[l].num_paths);
+    }
+    if (dHr) {
+      AA_REQUIRE(raw_in->readout[0] && raw_in->readout[1], "pack: missing readout weights");
+      raw_local.readout[0] = pad2d(raw_in->readout[0], p->SL1, p->hid_raw[2], p->SL1, c.readout_mlp_width);
+      raw_local.readout[1] = pad2d(raw_in->readout[1], p->hid_raw[2], 1, c.readout_mlp_width, 1);
     }
   }
   const aa_model_raw_weights* raw = &raw_local;
@@ -525,13 +548,17 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   // are split off for the moments path); alpha always follows the reference's full layer shape
   // true_din_less / true_dout_less: how much narrower the reference's first-layer input / last-layer output is than the
   // (channel-padded) shapes packed here -- alpha follows the reference
+  // hidden_less: by how much the (single) hidden layer was widened -- layer 0's fan_out and layer 1's fan_in are narrower
+  // in the reference.  `total_layers`: layers of the whole MLP (the readout packs only its first ones here).
   auto pack_mlp = [&](const MlpLayout& m, const double* const* ws, int nlayers, int env_off, int which, int raw_last_width = -1,
-                      int true_din_less = 0, int true_dout_less = 0) -> bool {
+                      int true_din_less = 0, int true_dout_less = 0, int hidden_less = 0, int total_layers = -1) -> bool {
+    if (total_layers < 0) total_layers = nlayers;
     for (int i = 0; i < nlayers; ++i) {
       if (!ws[i]) return false;
       int din = m.dims[i], dout = m.dims[i + 1];
       int raw_w = (i == nlayers - 1 && raw_last_width > 0) ? raw_last_width : dout;
-      double al = mlp_alpha(c, i, din - (i == 0 ? true_din_less : 0), raw_w - (i == nlayers - 1 ? true_dout_less : 0), which);
+      double al = mlp_alpha(c, i, din - (i == 0 ? true_din_less : hidden_less),
+                            raw_w - (i == total_layers - 1 ? true_dout_less : hidden_less), which);
       for (int r = 0; r < din; ++r)
         for (int q = 0; q < dout; ++q) {
           int src = q;
@@ -545,7 +572,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     }
     return true;
   };
-  AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1, -1, 0), "pack: missing scalar_embed_mlp weights");
+  AA_REQUIRE(pack_mlp(p->embed, raw->embed_mlp, c.embed_mlp_depth + 1, -1, 0, -1, 0, 0, dHe), "pack: missing scalar_embed_mlp weights");
   {
     // fused first stage: [ two_body (first_proj[:, :S]) | w0 (env_embed_linear) | env_w0 (first_proj[:, S:]) ]
     // (moments path: the env_w0 columns are not part of the GEMM; they become Wenv of layer 0 below)
@@ -568,7 +595,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
   }
   for (int l = 0; l < L; ++l) {
     AA_REQUIRE(pack_mlp(p->latent[l], raw->latent[l], c.latent_mlp_depth + 1, (l < L - 1 && !p->env_mom) ? S : -1, 1,
-                        S + (l < L - 1 ? We : 0), du, l < L - 1 ? dWe : 0),
+                        S + (l < L - 1 ? We : 0), du, l < L - 1 ? dWe : 0, dHl),
                "pack: missing latent weights");
     AA_REQUIRE(raw->tp_weights[l], "pack: missing tp weights");
     copy(p->o_tpw[l], raw->tp_weights[l], size_t(c.tps[l].coupling ? u : 1) * c.tps[l].num_paths, 1.0);
@@ -587,13 +614,13 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     fill(0, raw->first_proj, S, S + We, mlp_alpha(c, 0, S, S + We - dWe));
     const int dl = c.latent_mlp_depth;  // index of a latent's last layer
     for (int l = 1; l < L; ++l)
-      fill(l, raw->latent[l - 1][dl], c.latent_mlp_width, S + We, mlp_alpha(c, dl, c.latent_mlp_width, S + We - dWe, 1));
+      fill(l, raw->latent[l - 1][dl], c.latent_mlp_width, S + We, mlp_alpha(c, dl, c.latent_mlp_width - dHl, S + We - dWe, 1));
   }
-  AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1, 2), "pack: missing readout weights");
+  AA_REQUIRE(pack_mlp(p->readout, raw->readout, c.readout_mlp_depth, -1, 2, -1, 0, 0, dHr, c.readout_mlp_depth + 1), "pack: missing readout weights");
   {
     const double* wl = raw->readout[c.readout_mlp_depth];
     AA_REQUIRE(wl, "pack: missing readout weights");
-    copy(p->o_ro_last, wl, p->ro_last_dim, mlp_alpha(c, c.readout_mlp_depth, p->ro_last_dim, 1, 2));
+    copy(p->o_ro_last, wl, p->ro_last_dim, mlp_alpha(c, c.readout_mlp_depth, p->ro_last_dim - (c.readout_mlp_depth > 0 ? dHr : 0), 1, 2));
   }
   if (c.has_scales) {
     AA_REQUIRE(raw->scales, "pack: missing scales");

@@ -74,6 +74,8 @@ def make_workload(name):
         cfg["num_tensor_features"] = w.get("u", cfg["num_tensor_features"])
         if os.environ.get("AA_BENCH_LMAX"):  # experiments only: the same box and widths at another l_max
             cfg["l_max"] = int(os.environ["AA_BENCH_LMAX"])
+        if os.environ.get("AA_BENCH_CFG"):  # experiments only: JSON overrides of the model constructor arguments
+            cfg.update(json.loads(os.environ["AA_BENCH_CFG"]))
         if os.environ.get("AA_BENCH_U"):  # experiments only
             cfg["num_tensor_features"] = int(os.environ["AA_BENCH_U"])
         if os.environ.get("AA_BENCH_LAYERS"):  # experiments only

@@ -198,8 +198,8 @@ typedef struct {
   int32_t f64_rows;        /* fp64 linear layers, row-resident kernels (operand rows read once): 0 where measured faster, 1 wherever applicable, 2 off */
   int32_t chain_tp;        /* 1: forward with the tensor-track scalars evaluated inside the linear-layer chains that produce w0
                             * (scal0 / scal1 never reach HBM; the moments kernels only form the per-atom vectors)         */
-  int32_t no_channel_padding; /* stacks whose channel count is not a multiple of 64 are normally evaluated zero-padded to the
-                               * next multiple (same results, tuned kernels); 1: keep the narrow kernels                */
+  int32_t no_channel_padding; /* stacks whose channel count is not a multiple of 64, or with single hidden layers narrower than
+                               * 64, are normally evaluated zero-padded (same results, tuned kernels); 1: keep them narrow */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

@@ -364,3 +364,31 @@ def test_channel_counts_off_the_multiples_of_64_run_zero_padded(u, coupling, ind
         assert (fast in names) == (no_pad == "0"), names
         out[no_pad] = m.energy_forces(p32, g)
     assert (out["0"][1] - out["1"][1]).abs().max().item() < 2e-5 * max(1.0, float(out["1"][1].abs().max()))
+
+
+@pytest.mark.parametrize("widths", [dict(readout_mlp_hidden_layers_width=32, num_tensor_features=16),  # the reference's constructor defaults
+                                    dict(scalar_embed_mlp_hidden_layers_width=32, allegro_mlp_hidden_layers_width=48, readout_mlp_hidden_layers_width=8)])
+def test_narrow_hidden_layers_run_zero_padded_on_the_fused_chains(widths, monkeypatch):
+    """Hidden-width padding (aa_model_plan_create): single hidden layers narrower than 64 -- e.g. the constructor default
+    readout width 32 (allegro_models.py:137) -- are zero-padded to 64 (silu(0) = 0, no biases), which puts the stack on the
+    fused linear-layer chains; results are those of the narrow model (fp64 oracle criterion; AA_NO_PAD=1 agrees)."""
+    import numpy as np
+
+    import bench
+    from tests.test_fused import _cfg, _ragged
+    from tests.test_tp_mfma import _vs_oracle64
+
+    pos, cell, ei, shift, types = _ragged(dims=(3, 3, 2), keep=0.9, seed=4)
+    deg = np.bincount(ei[0], minlength=pos.shape[0])
+    cfg = _cfg("bessel", True, avg=float(deg.mean()))
+    cfg.update(widths)
+    out = {}
+    for no_pad in ("0", "1"):
+        monkeypatch.setenv("AA_NO_PAD", no_pad)
+        m = _vs_oracle64(cfg, pos, cell, ei, shift, types, emu_lib(), torch.device("cpu"))
+        g = m.prepare_graph(torch.tensor(ei), torch.tensor(types), pos.shape[0], torch.tensor(shift @ cell, dtype=torch.float32))
+        p32 = torch.tensor(pos, dtype=torch.float32)
+        names = [s[0] for s in bench.profile_stages(m, p32, g, reps=1)]
+        assert any(n.startswith("gc_") for n in names) == (no_pad == "0"), names
+        out[no_pad] = m.energy_forces(p32, g)
+    assert (out["0"][1] - out["1"][1]).abs().max().item() < 2e-5 * max(1.0, float(out["1"][1].abs().max()))
