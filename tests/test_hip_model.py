@@ -455,3 +455,29 @@ def test_fast_path_species_and_embedding_variants_vs_oracle(species, embed, dtyp
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     wref = R.allegro_virial(cfg64, sd64, torch.tensor(pos), torch.tensor(ei), types, sv.double())
     assert (w.double() - wref).abs().max().item() <= 4 * tol * max(1.0, float(wref.abs().max()))
+
+
+@pytest.mark.parametrize("over", [dict(num_tensor_features=96), dict(num_tensor_features=16, readout_mlp_hidden_layers_width=32),
+                                  dict(num_tensor_features=32, num_layers=3, allegro_mlp_hidden_layers_width=48)])
+def test_zero_padded_stacks_match_the_oracle_and_their_narrow_kernels(over, dev, monkeypatch):
+    """Channel / hidden-width padding on hardware (aa_model_plan_create): the padded evaluation meets the fp64-oracle
+    criterion of the narrow model and agrees with the narrow kernels (AA_NO_PAD=1)."""
+    import numpy as np
+
+    from allegro_amd.nn import HipAllegroModel
+    from tests.test_fused import _cfg, _ragged
+    from tests.test_tp_mfma import _vs_oracle64
+
+    pos, cell, ei, shift, types = _ragged(dims=(6, 6, 5), keep=0.93, seed=8)
+    deg = np.bincount(ei[0], minlength=pos.shape[0])
+    cfg = _cfg("bessel", True, avg=float(deg.mean()))
+    cfg.update(over)
+    m = _vs_oracle64(cfg, pos, cell, ei, shift, types, None, dev)
+    monkeypatch.setenv("AA_NO_PAD", "1")
+    m2 = HipAllegroModel(**cfg).to(dev)
+    m2.load_state_dict(m.state_dict())
+    args = (torch.tensor(ei).to(dev), torch.tensor(types).to(dev), pos.shape[0], torch.tensor(shift @ cell, dtype=torch.float32, device=dev))
+    p32 = torch.tensor(pos, dtype=torch.float32, device=dev)
+    f1 = m.energy_forces(p32, m.prepare_graph(*args))[1]
+    f2 = m2.energy_forces(p32, m2.prepare_graph(*args))[1]
+    assert (f1 - f2).abs().max().item() < 2e-5 * max(1.0, float(f2.abs().max()))
