@@ -43,19 +43,11 @@ namespace aa {
 namespace {
 
 constexpr int kLdA = 68;   // row stride (floats) of the [32 edges][64 features] patch: 16-B aligned rows, conflict-light
-constexpr int kLdT = 36;   // row stride of the [32][32] store-transpose patch (as in the chain kernel)
+constexpr int kLdT = kTileLdT;  // row stride of the [32][32] store-transpose patch (as in the chain kernel)
 constexpr int kLdY = 16;   // row stride of sY [32 edges][D <= 16] and sM [64 k][D]
 constexpr int kOffB = 32 * kLdT;          // sB [D][64] sits behind the store patch inside the wave region
 constexpr int kWaveRegion = 32 * kLdA;    // floats: max(sA, sT + sB, sM + sB)
 static_assert(kOffB + 16 * 64 <= kWaveRegion, "per-atom vectors must fit behind the store patch");
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // ---- weight pipeline --------------------------------------------------------------------------------------------
 // The kernel's program is a fixed sequence of NS "steps"; step S consumes one 12-KB block of weights (a tile pair x
@@ -207,26 +199,6 @@ __device__ __forceinline__ void fused_layer(const FusedFwdArgs& A, FusedPipe& p,
   });
 }
 
-// store one 32-feature tile (accumulator layout) to rows [row0, row0 + cnt) of a row-major [E, ld] array through the
-// wave-private transpose patch, so that every store instruction writes whole 128-B lines
-__device__ __forceinline__ void fused_store_tile(float* sT, const v16f& acc, float* dst, int64_t row0, int cnt, int ld, int lane) {
-  const int el = lane & 31, hh = lane >> 5;
-  float* st = sT + el * kLdT + 4 * hh;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(st + 8 * q) = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-  __builtin_amdgcn_wave_barrier();
-  const int pr = lane >> 3, pc = 4 * (lane & 7);
-  v4f v[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const v4f*>(sT + (8 * q + pr) * kLdT + pc);
-  __builtin_amdgcn_wave_barrier();
-  float* p = dst + (row0 + pr) * ld + pc;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (pr + 8 * q < cnt) *reinterpret_cast<v4f*>(p + int64_t(8 * q) * ld) = v[q];
-}
-
 // A tile pair parked in LDS in accumulator layout ([q][lane] 16-B cells: conflict-free b128 accesses).  The two-body
 // scalars and lat0 are operands of three / two later layers; parking them frees 64 registers per lane for the whole
 // second half of the kernel (the kernel runs one wave per SIMD, LDS is plentiful).
@@ -326,33 +298,6 @@ __device__ __forceinline__ void project_moments(const FusedFwdArgs& A, FusedPipe
   });
 #pragma unroll
   for (int j = 0; j < D; ++j) x2s[j] *= sf;
-}
-
-// scal[e][ch] += w[e][r][ch] * sum_{a in irrep r} Y[e][a] * B[a][ch]  for the tile pair (w0a: channels 0..31,
-// w0b: 32..63) of irrep r; B[a][ch] from LDS (the lanes of a half read the same address: broadcast)
-template <int RR>
-__device__ __forceinline__ void scal_accumulate(const float* sB, const float* Y, const v16f& w0a, const v16f& w0b, int hh, v16f& s0, v16f& s1) {
-  constexpr int a0 = RR * RR, na = 2 * RR + 1;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v4f T4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int a = 0; a < na; ++a) {
-        const v4f b4 = *reinterpret_cast<const v4f*>(sB + (a0 + a) * 64 + 32 * t + 8 * q + 4 * hh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) T4[i] += Y[a0 + a] * b4[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (t == 0)
-          s0[4 * q + i] += w0a[4 * q + i] * T4[i];
-        else
-          s1[4 * q + i] += w0b[4 * q + i] * T4[i];
-      }
-    }
-  }
 }
 
 }  // namespace
@@ -546,8 +491,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     fused_layer<S_L0, NS, 2, 2>(A, p,
                                 [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
                                 [&](auto, const v16f& a0, const v16f& a1) {
-                                  fused_store_tile(sW, a0, A.se_h, row0, cnt, 64, lane);
-                                  fused_store_tile(sW, a1, A.se_h + 32, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a0, A.se_h, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a1, A.se_h + 32, row0, cnt, 64, lane);
                                   keep_tile<true>(a0, k0);
                                   keep_tile<true>(a1, k1);
                                 });
@@ -556,8 +501,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     fused_layer<S_L1, NS, 2, 2>(A, p,
                                 [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
                                 [&](auto, const v16f& a0, const v16f& a1) {
-                                  fused_store_tile(sW, a0, A.emb, row0, cnt, 64, lane);
-                                  fused_store_tile(sW, a1, A.emb + 32, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a0, A.emb, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a1, A.emb + 32, row0, cnt, 64, lane);
                                   em0 = a0;
                                   em1 = a1;
                                 });
@@ -596,15 +541,15 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                             AA_PARK(0, a0);
                                             AA_PARK(1, a1);
                                             if (A.fcat) {
-                                              fused_store_tile(sW, a0, A.fcat, row0, cnt, 192, lane);
-                                              fused_store_tile(sW, a1, A.fcat + 32, row0, cnt, 192, lane);
+                                              tile_store_rows(sW, a0, A.fcat, row0, cnt, 192, lane);
+                                              tile_store_rows(sW, a1, A.fcat + 32, row0, cnt, 192, lane);
                                             }
                                           } else {
                                             if (A.w0) {
-                                              fused_store_tile(sW, a0, A.w0 + (q - 1) * 64, row0, cnt, 64 * R, lane);
-                                              fused_store_tile(sW, a1, A.w0 + (q - 1) * 64 + 32, row0, cnt, 64 * R, lane);
+                                              tile_store_rows(sW, a0, A.w0 + (q - 1) * 64, row0, cnt, 64 * R, lane);
+                                              tile_store_rows(sW, a1, A.w0 + (q - 1) * 64 + 32, row0, cnt, 64 * R, lane);
                                             }
-                                            scal_accumulate<q - 1>(sBv, Y, a0, a1, hh, sc0, sc1);
+                                            tile_scal_accumulate<q - 1>(sBv + 4 * hh, Y, a0, a1, sc0, sc1);
                                             if constexpr (HOLD) {
                                               w0t[2 * (q - 1)] = a0;
                                               w0t[2 * (q - 1) + 1] = a1;
@@ -619,8 +564,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   if constexpr (k < 2) return AA_FETCH(k); else if constexpr (k == 2) return sc0; else return sc1;
                                 },
                                 [&](auto, const v16f& a0, const v16f& a1) {
-                                  fused_store_tile(sW, a0, A.lat_h0, row0, cnt, 64, lane);
-                                  fused_store_tile(sW, a1, A.lat_h0 + 32, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a0, A.lat_h0, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a1, A.lat_h0 + 32, row0, cnt, 64, lane);
                                   keep_tile<true>(a0, k0);
                                   keep_tile<true>(a1, k1);
                                 });
@@ -649,8 +594,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   AA_PARK(2, a0);
                                   AA_PARK(3, a1);
                                   if (A.fcat) {
-                                    fused_store_tile(sW, a0, A.fcat + 64, row0, cnt, 192, lane);
-                                    fused_store_tile(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
+                                    tile_store_rows(sW, a0, A.fcat + 64, row0, cnt, 192, lane);
+                                    tile_store_rows(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
                                   }
                                 });
 #ifndef AA_EXP_NOGEO
@@ -666,13 +611,13 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     }
     if constexpr (HOLD) {
       static_for<0, R>([&](auto rr) {
-        scal_accumulate<decltype(rr)::value>(sBv, Y, w0t[2 * decltype(rr)::value], w0t[2 * decltype(rr)::value + 1], hh, sc0, sc1);
+        tile_scal_accumulate<decltype(rr)::value>(sBv + 4 * hh, Y, w0t[2 * decltype(rr)::value], w0t[2 * decltype(rr)::value + 1], sc0, sc1);
       });
     } else {
       fused_layer<S_L5, NS, 2, 2 * R>(A, p,
                                       [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
                                       [&](auto ntp, const v16f& a0, const v16f& a1) {
-                                        scal_accumulate<decltype(ntp)::value>(sBv, Y, a0, a1, hh, sc0, sc1);
+                                        tile_scal_accumulate<decltype(ntp)::value>(sBv + 4 * hh, Y, a0, a1, sc0, sc1);
                                       });
     }
     AA_TICK(10)
@@ -683,8 +628,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   if constexpr (k < 4) return AA_FETCH(k); else if constexpr (k == 4) return sc0; else return sc1;
                                 },
                                 [&](auto, const v16f& a0, const v16f& a1) {
-                                  fused_store_tile(sW, a0, A.lat_h1, row0, cnt, 64, lane);
-                                  fused_store_tile(sW, a1, A.lat_h1 + 32, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a0, A.lat_h1, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a1, A.lat_h1 + 32, row0, cnt, 64, lane);
                                   keep_tile<true>(a0, k0);
                                   keep_tile<true>(a1, k1);
                                 });
@@ -696,8 +641,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   k0 = a0;
                                   k1 = a1;
                                   if (A.fcat) {
-                                    fused_store_tile(sW, a0, A.fcat + 128, row0, cnt, 192, lane);
-                                    fused_store_tile(sW, a1, A.fcat + 160, row0, cnt, 192, lane);
+                                    tile_store_rows(sW, a0, A.fcat + 128, row0, cnt, 192, lane);
+                                    tile_store_rows(sW, a1, A.fcat + 160, row0, cnt, 192, lane);
                                   }
                                 });
     AA_TICK(12)
@@ -708,8 +653,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   if constexpr (k < 4) return AA_FETCH(k); else if constexpr (k == 4) return k0; else return k1;
                                 },
                                 [&](auto, const v16f& a0, const v16f& a1) {
-                                  fused_store_tile(sW, a0, A.ro_h, row0, cnt, 64, lane);
-                                  fused_store_tile(sW, a1, A.ro_h + 32, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a0, A.ro_h, row0, cnt, 64, lane);
+                                  tile_store_rows(sW, a1, A.ro_h + 32, row0, cnt, 64, lane);
                                   float part = 0.f;
 #pragma unroll
                                   for (int q = 0; q < 4; ++q) {

@@ -1139,43 +1139,6 @@ struct ChainDev {
   ChainLayerDev L[4];
 };
 
-// sc[e][ch] += w[e][r][ch] * sum_{a in irrep RR} Y[e][a] * B[center(e)][a][ch] for the tile pair (w0a: channels 0..31,
-// w0b: 32..63) of irrep RR; bb = the lane's view of its center atom's vector block (+ 4 hh): 16-B cells gathered from
-// L1 / L2 (the lanes of one atom read the same addresses).  Groups of four channels are evaluated one after the other
-// with the next group's cells in flight; the anchors keep that order (see aa::anchor).
-template <int RR>
-__device__ __forceinline__ void chain_tp_accumulate(const float* bb, const float* Y, const v16f& w0a, const v16f& w0b, v16f& s0, v16f& s1) {
-  constexpr int a0 = RR * RR, na = 2 * RR + 1;
-  v4f b[2][na];
-  auto request = [&](int g, v4f* d) {
-#pragma unroll
-    for (int a = 0; a < na; ++a) d[a] = *reinterpret_cast<const v4f*>(bb + (a0 + a) * 64 + 32 * (g >> 2) + 8 * (g & 3));
-  };
-  request(0, b[0]);
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    if (g + 1 < 8) request(g + 1, b[(g + 1) & 1]);
-    v4f T4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < na; ++a) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) T4[i] += Y[a0 + a] * b[g & 1][a][i];
-    }
-    const int q = g & 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (g < 4)
-        s0[4 * q + i] += w0a[4 * q + i] * T4[i];
-      else
-        s1[4 * q + i] += w0b[4 * q + i] * T4[i];
-    }
-    if (g < 4)
-      anchor(s0);
-    else
-      anchor(s1);
-  }
-}
-
 // Weights of one step (tile pair x 32-deep chunk: 2 x 6 x 64 fragments of 16 B = 12 KB) are staged through LDS
 // by the whole block (the four waves run the same layer/tile/chunk sequence on different rows): one L2 fetch
 // instead of four, the next step's weights -- also across layer boundaries -- are in flight while this step's
@@ -1493,11 +1456,11 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
         if (L.tp_from1 > 0 && nt >= L.tp_from1 - 1) {  // (wave-uniform) this pair is irrep r of w0
           const int r = (nt - (L.tp_from1 - 1)) >> 1;
           if (r == 0)
-            chain_tp_accumulate<0>(tp_bb, Yh, acc0, acc1, sc0, sc1);
+            tile_scal_accumulate<0>(tp_bb, Yh, acc0, acc1, sc0, sc1);
           else if (r == 1)
-            chain_tp_accumulate<1>(tp_bb, Yh, acc0, acc1, sc0, sc1);
+            tile_scal_accumulate<1>(tp_bb, Yh, acc0, acc1, sc0, sc1);
           else
-            chain_tp_accumulate<2>(tp_bb, Yh, acc0, acc1, sc0, sc1);
+            tile_scal_accumulate<2>(tp_bb, Yh, acc0, acc1, sc0, sc1);
         }
       }
       if (EMB && L.embrev_out) {  // (64-wide layer: this is its only tile pair)

@@ -2,6 +2,8 @@
 // per-atom-tile kernels (aa_fused.hip).  See aa_gemm.hip for the arithmetic ("fp32 GEMM on the bf16 matrix cores by
 // exact 3-way splitting") and the fragment layouts.
 #pragma once
+#include <type_traits>
+
 #include "aa_common.h"
 
 namespace aa {
@@ -59,5 +61,77 @@ __device__ __forceinline__ void xsplit_from_acc(const v16f& acc, XSplit& x) {
 }
 
 constexpr int kWStep = 2 * 6 * 64;  // u32x4 per staged weight step (tile pair x 32-deep chunk x 3 levels)
+
+// ---- helpers shared by the kernels that work on 32-edge tiles in the accumulator layout (aa_fused.hip, aa_tp_mfma.hip,
+//      the tensor-track epilogue of gemm_chain_bf16x3_kernel)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int kTileLdT = 36;  // row stride (floats) of the wave-private [32][32] store-transpose patch: 32 + 4 keeps b128 accesses conflict-light
+
+// store one 32-feature tile (accumulator layout) to rows [row0, row0 + cnt) of a row-major [E, ld] array through the
+// wave-private transpose patch sT [32][kTileLdT], so that every store instruction writes whole 128-B lines
+__device__ __forceinline__ void tile_store_rows(float* sT, const v16f& acc, float* dst, int64_t row0, int cnt, int ld, int lane) {
+  const int el = lane & 31, hh = lane >> 5;
+  float* st = sT + el * kTileLdT + 4 * hh;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(st + 8 * q) = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+  __builtin_amdgcn_wave_barrier();
+  const int pr = lane >> 3, pc = 4 * (lane & 7);
+  v4f v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const v4f*>(sT + (8 * q + pr) * kTileLdT + pc);
+  __builtin_amdgcn_wave_barrier();
+  float* p = dst + (row0 + pr) * ld + pc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (pr + 8 * q < cnt) *reinterpret_cast<v4f*>(p + int64_t(8 * q) * ld) = v[q];
+}
+
+// Tensor-track scalars of a tile:  s[e][ch] += w[e][r][ch] * sum_{a in irrep RR} Y[e][a] * B[a][ch]  for the tile pair
+// (w0a: channels 0..31, w0b: 32..63) of irrep RR.  bb: the lane's view of the per-atom vector block B [D][64], already
+// offset by 4 * (lane >> 5) -- in LDS (broadcast reads) or in global memory (gathered by center atom: the lanes of one
+// atom read the same 16-B cells).  Groups of four channels are evaluated one after the other with the next group's
+// cells in flight; the anchors pin that order (unconstrained, the optimizer gathers all cells at the front and sinks
+// the arithmetic below the following MFMA phases -- see aa::anchor).
+template <int RR>
+__device__ __forceinline__ void tile_scal_accumulate(const float* bb, const float* Y, const v16f& w0a, const v16f& w0b, v16f& s0, v16f& s1) {
+  constexpr int a0 = RR * RR, na = 2 * RR + 1;
+  v4f b[2][na];
+  auto request = [&](int g, v4f* d) {
+#pragma unroll
+    for (int a = 0; a < na; ++a) d[a] = *reinterpret_cast<const v4f*>(bb + (a0 + a) * 64 + 32 * (g >> 2) + 8 * (g & 3));
+  };
+  request(0, b[0]);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (g + 1 < 8) request(g + 1, b[(g + 1) & 1]);
+    v4f T4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < na; ++a) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) T4[i] += Y[a0 + a] * b[g & 1][a][i];
+    }
+    const int q = g & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (g < 4)
+        s0[4 * q + i] += w0a[4 * q + i] * T4[i];
+      else
+        s1[4 * q + i] += w0b[4 * q + i] * T4[i];
+    }
+    if (g < 4)
+      anchor(s0);
+    else
+      anchor(s1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 }  // namespace aa

@@ -28,21 +28,13 @@ namespace aa {
 namespace {
 
 constexpr int kLdA = 68;   // row stride (floats) of the [32 edges][64 k] patch
-constexpr int kLdT = 36;   // row stride of the [32][32] store-transpose patch
+constexpr int kLdT = kTileLdT;  // row stride of the [32][32] store-transpose patch
 constexpr int kLdY = 16;   // row stride of sY [32 edges][<=16] and sM [64 k][<=16]
 constexpr int kOffB = 32 * kLdT;                     // sB [D][64] sits behind the store patch inside the wave region
 constexpr int kWaveFloats = 32 * kLdA + 32 * kLdY;   // wave region: max(sA, sM | sT + sB) then sY
 constexpr int kWBlock = 6 * 64;                      // u32x4 per (tile, chunk) block of bf16x3 fragments (6 KB)
 constexpr int kWaves = 8;                            // waves per workgroup (two per SIMD)
 static_assert(kOffB + 16 * 64 <= 32 * kLdA, "per-atom vectors must fit behind the store patch");
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 // pointer with a wave-uniform value -> SGPR pair (global loads then use the scalar-base + lane-offset form)
 template <class P>
@@ -190,66 +182,6 @@ __device__ __forceinline__ void project_moments(float* sM, const float* M, const
   __builtin_amdgcn_wave_barrier();
 }
 
-// scal[e][ch] += w[e][r][ch] * sum_{a in irrep r} Y[e][a] * B[a][ch]  for the tile pair (w0a: channels 0..31, w0b:
-// 32..63) of irrep r; B[a][ch] from LDS (the lanes of a half read the same address: broadcast)
-template <int RR>
-__device__ __forceinline__ void scal_accumulate(const float* sB, const float* Y, const v16f& w0a, const v16f& w0b, int hh, v16f& s0, v16f& s1) {
-  constexpr int a0 = RR * RR, na = 2 * RR + 1;
-  // 8 groups (tile t, quad q) of 4 channels; the B cells of group g + 1 are requested before group g is evaluated and a
-  // scheduling barrier closes every group (unconstrained, the compiler requests all 8 na cells up front: 160 registers)
-  v4f b[2][na];
-  auto request = [&](int g, v4f* d) {
-#pragma unroll
-    for (int a = 0; a < na; ++a) d[a] = *reinterpret_cast<const v4f*>(sB + (a0 + a) * 64 + 32 * (g >> 2) + 8 * (g & 3) + 4 * hh);
-  };
-  request(0, b[0]);
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    if (g + 1 < 8) request(g + 1, b[(g + 1) & 1]);
-    v4f T4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < na; ++a) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) T4[i] += Y[a0 + a] * b[g & 1][a][i];
-    }
-    const int q = g & 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (g < 4)
-        s0[4 * q + i] += w0a[4 * q + i] * T4[i];
-      else
-        s1[4 * q + i] += w0b[4 * q + i] * T4[i];
-    }
-    // (anchors: without them the optimizer gathers the LDS reads of all groups at the front and sinks the arithmetic
-    //  below the following irreps' MFMAs -- every B cell and accumulator tile then lives across the whole phase)
-    if (g < 4)
-      anchor(s0);
-    else
-      anchor(s1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// store one 32-feature tile (accumulator layout) to rows [row0, row0 + cnt) of a row-major [E, ld] array through the
-// wave-private transpose patch, so that every store instruction writes whole 128-B lines
-__device__ __forceinline__ void store_tile(float* sT, const v16f& acc, float* dst, int64_t row0, int cnt, int ld, int lane) {
-  const int el = lane & 31, hh = lane >> 5;
-  float* st = sT + el * kLdT + 4 * hh;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(st + 8 * q) = v4f{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-  __builtin_amdgcn_wave_barrier();
-  const int pr = lane >> 3, pc = 4 * (lane & 7);
-  v4f v[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const v4f*>(sT + (8 * q + pr) * kLdT + pc);
-  __builtin_amdgcn_wave_barrier();
-  float* p = dst + (row0 + pr) * ld + pc;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (pr + 8 * q < cnt) *reinterpret_cast<v4f*>(p + int64_t(8 * q) * ld) = v[q];
-}
-
 // the lane's harmonics (lane = edge el of the tile; zero beyond the segment), also left in sY [32][kLdY] for phase 1
 template <int D>
 __device__ __forceinline__ void load_harmonics(const float* sh, int ld_sh, int64_t row0, int cnt, int lane, float* Y, float* sY) {
@@ -364,11 +296,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void tp_mfma_fwd_kernel(TpMfmaArgs 
         __builtin_amdgcn_sched_barrier(0);
         mma_pair(wa + kWBlock, wb + kWBlock, xs[1], acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
-        scal_accumulate<r>(sBv, Y, acc0, acc1, hh, sc0, sc1);
+        tile_scal_accumulate<r>(sBv + 4 * hh, Y, acc0, acc1, sc0, sc1);
       });
       __builtin_amdgcn_sched_barrier(0);
-      store_tile(sW, sc0, A.scal, t0, cnt, 64, lane);
-      store_tile(sW, sc1, A.scal + 32, t0, cnt, 64, lane);
+      tile_store_rows(sW, sc0, A.scal, t0, cnt, 64, lane);
+      tile_store_rows(sW, sc1, A.scal + 32, t0, cnt, 64, lane);
     }
     __builtin_amdgcn_wave_barrier();  // (the next atom's patches alias this one's)
   }
