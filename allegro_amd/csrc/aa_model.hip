@@ -153,8 +153,6 @@ struct aa_model_plan {
                                      // w0 (gemm_chain TPX); the moments kernels only form the per-atom vectors
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
   int fused_mode;                    // 1: 32-edge tiles, one wave per atom; 2: 16-edge tiles, two waves per atom (aa_fused16.hip)
-  bool fused_auto;                   // the fused forward only runs where it is the faster one: at most fused_auto_atoms owned atoms
-  int64_t fused_auto_atoms;          // 4 atoms per workgroup x number of CUs
   size_t o_g0q16;
   bool fused_hold_w0;                // ... holding the w0 tiles in registers between the two layers (else: recomputed)
   mutable bool taps = false;         // aa_model_plan_enable_taps: staged pipeline so that every tap is materialised
@@ -375,23 +373,16 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   p->n_elems = o;
   {
     // fused per-atom-tile forward (aa_fused.hip / aa_fused16.hip): the standard 2-layer 64-wide fp32 stack with the
-    // two-body table in LDS.  Same parity tests as the staged pipeline.  On MI355X it is SLOWER than the staged forward
-    // once the chip is full (6.3-10 ms vs 5.5 ms at C4: one or two waves per SIMD cannot hide their own LDS / MFMA / L2
-    // latencies) and FASTER in the launch-latency regime: up to one workgroup per CU (4 atoms
-    // each) the 16-edge-tile form replaces seven dependent launches by one (64-1000 atoms: 13-17 % of the step,
-    // profiles/r02_v15_small_sweep.log).  aa_plan_options.fused_forward: 0 = automatic (that regime), 1 / 2 = always
-    // (32- / 16-edge tiles), 3 = never.
+    // two-body table in LDS; same parity tests as the staged pipeline.  With the tensor-track scalars accumulated in
+    // anchored program order (aa::anchor -- the kernel used to carry 70-350 spilled VGPRs) the 32-edge-tile form beats the
+    // staged forward at every size on MI355X: 22-24 % of the step on 64-1000 atoms (one launch instead of seven), 9 % at
+    // 4096, 4.5 % at 10 648, 0.5 % at 97 336 atoms, and it moves 2.1 instead of 7.3 KB/edge (profiles/r02_v23_fused_sweep.log).
+    // aa_plan_options.fused_forward: 0 = automatic (32-edge tiles whenever the graph allows: max_degree <= 32), 1 / 2 = the
+    // 32- / 16-edge-tile form explicitly, 3 = never (staged pipeline).
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
                           u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0;
-    p->fused_fwd = eligible && (opt.fused_forward == 1 || opt.fused_forward == 2 || (opt.fused_forward == 0 && cfg->l_max <= 2));
-    p->fused_auto = opt.fused_forward == 0;
-    p->fused_mode = opt.fused_forward == 1 ? 1 : 2;
-    p->fused_auto_atoms = 0;
-    if (p->fused_fwd && p->fused_auto) {
-      int dev = 0, ncu = 0;
-      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
-        p->fused_auto_atoms = 4 * int64_t(ncu);
-    }
+    p->fused_fwd = eligible && opt.fused_forward != 3;
+    p->fused_mode = opt.fused_forward == 2 ? 2 : 1;
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
     // moments kernels with w0 recomputed on the matrix cores (aa_tp_mfma.hip): same stack, no table requirement
     p->chain_tp = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
@@ -1148,8 +1139,7 @@ struct Runner {
 
   // the whole forward in one launch (aa_fused.hip): every center atom's edge segment fits one 32-row MFMA tile
   bool use_fused_fwd(const aa_graph* g) const {
-    if (!(sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= 32)) return false;
-    return !p->fused_auto || atom_end(g) - atom_begin(g) <= p->fused_auto_atoms;
+    return sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= 32;
   }
   int forward_fused(const aa_graph* g, const void* pos, void* atom_energy) {
     const aa_model_config& c = p->cfg;

@@ -162,9 +162,9 @@ typedef struct {
    * atom-block partition.  Per-atom kernels are then launched over that range only.  0,0 = all atoms.
    * The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
   int64_t atom_begin, atom_end;
-  /* optional hint: no center atom has more than max_degree edges (0 = unknown).  With max_degree <= 32 the standard
-   * 2-layer 64-wide fp32 stack may run the fused per-atom-tile forward (one launch instead of seven; chosen automatically
-   * for small blocks -- at most 4 owned atoms per CU -- where the step is launch-latency-bound, see
+  /* optional hint: no center atom has more than max_degree edges (0 = unknown).  With 0 < max_degree <= 32 the standard
+   * 2-layer 64-wide fp32 stack runs the fused per-atom-tile forward (one launch instead of seven, 2.1 instead of 7.3 KB
+   * of HBM traffic per edge; faster at every size, most where the step is launch-latency-bound -- see
    * aa_plan_options.fused_forward and DESIGN.md section 9.1); otherwise the staged pipeline.  The caller guarantees it
    * (allegro_amd.nn.PreparedGraph derives it from rowptr). */
   int64_t max_degree;
@@ -189,8 +189,8 @@ typedef struct {
   int32_t gemm_lds_epilogue; /* LDS-transposed epilogue in the single-layer bf16x3 kernel                       */
   int32_t f64_column_loop; /* fp64 linear layers: 0 automatic, 1 never, 2 always walk all column tiles per workgroup */
   int32_t embed_no_fuse;   /* reverse pass: materialise d(two-body embedding)                                   */
-  int32_t fused_forward;   /* fused per-atom-tile forward: 0 automatic (small graphs: at most 4 atoms per CU, 16-edge tiles),
-                            * 1 always, 32-edge tiles; 2 always, 16-edge tiles; 3 never (staged pipeline)          */
+  int32_t fused_forward;   /* fused per-atom-tile forward: 0 automatic (32-edge tiles whenever aa_graph.max_degree allows),
+                            * 1 32-edge tiles; 2 16-edge tiles; 3 never (staged pipeline)                           */
   int32_t fused_recompute_w0; /* fused forward: recompute w0 for the second layer instead of holding it         */
   int32_t moments_waves_per_block; /* 0 = 1                                                                      */
   int32_t tp_mfma;         /* tensor-product kernels that recompute the first-layer x1 weights on the matrix cores

@@ -10,8 +10,9 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 # Kernel selection is explicit in the tests: the staged pipeline unless a test opts into another path (monkeypatch of the
-# AA_* variables that allegro_amd/_lib.py maps onto aa_plan_options).  Unset, AA_FUSED means "automatic" -- small graphs
-# run the fused forward -- which tests/test_fused.py covers on its own.
+# AA_* variables that allegro_amd/_lib.py maps onto aa_plan_options).  Unset, AA_FUSED means "automatic" -- the fused
+# forward whenever the graph allows it -- which tests/test_fused.py, the full-size block tests, bench.py's parity_sample and
+# smoke() cover; pinning the staged pipeline here keeps its own kernels under test.
 os.environ.setdefault("AA_FUSED", "0")
 
 

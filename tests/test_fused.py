@@ -104,7 +104,7 @@ def _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev, blocks=None):
 
 # (the CPU suite runs a cross-section of (tile form, fixture) pairs -- the emulated 64-wide model takes ~18 s per case;
 #  the GPU tests below run every combination)
-@pytest.mark.parametrize("mode,name", [("tile32", "c2_uncoupled")])  # (16-edge tiles: the automatic-selection test below)
+@pytest.mark.parametrize("mode,name", [("tile16", "c2_uncoupled")])  # (32-edge tiles: the automatic-selection test below)
 def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch):
     _opt_in(monkeypatch, mode)
     fx = load_model_fixture(name, torch.float32)
@@ -159,18 +159,15 @@ def _launches(m, data, g):
     return [s[0] for s in bench.profile_stages(m, data["pos"], g, reps=1)]
 
 
-def test_automatic_selection_runs_the_fused_forward_on_small_graphs_only_emulated(monkeypatch):
-    """AA_FUSED unset = aa_plan_options.fused_forward 0: blocks of at most 4 atoms per CU (the emulation reports 3 CUs) take
-    the one-launch forward, larger ones the staged pipeline; both match the reference's golden vectors."""
+def test_automatic_selection_emulated(monkeypatch):
+    """AA_FUSED unset = aa_plan_options.fused_forward 0: the 32-edge-tile fused forward whenever the graph allows it
+    (max_degree <= 32), the staged pipeline otherwise and under AA_FUSED=0; an atom block (what a rank of a partition
+    owns) too.  All match the reference's golden vectors."""
     monkeypatch.delenv("AA_FUSED", raising=False)
     fx = load_model_fixture("c2_spline", torch.float32)
     m = model_from_fixture(fx, torch.float32, emu_lib())
     data, sv = fixture_data(fx, torch.float32)
     n = data["pos"].shape[0]
-    g = m.prepare_graph(data["edge_index"], data["atom_types"], n, sv)
-    assert "fused_fwd" not in _launches(m, data, g)  # 64 atoms > 12
-    e, f = m.energy_forces(data["pos"], g)
-    # the first 12 center atoms as an atom block (what a rank of a partition owns): small enough for the fused forward
     ei = data["edge_index"]
     keep = ei[0] < 12
     gb = m.prepare_graph(ei[:, keep], data["atom_types"], n, None if sv is None else sv[keep])
@@ -178,19 +175,22 @@ def test_automatic_selection_runs_the_fused_forward_on_small_graphs_only_emulate
     eb, fb = m.energy_forces(data["pos"], gb)
     want = fx["out"]["atomic_energy"].reshape(-1)
     assert (eb[:12] - want[:12]).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
-    assert (e - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
+    monkeypatch.setenv("AA_FUSED", "0")
+    m0 = model_from_fixture(fx, torch.float32, emu_lib())
+    assert "fused_fwd" not in _launches(m0, data, gb)
+    e0, f0 = m0.energy_forces(data["pos"], gb)
+    assert (e0[:12] - eb[:12]).abs().max().item() < 5e-6 and (f0 - fb).abs().max().item() < 2e-5
 
 
 @pytest.mark.gpu
 def test_automatic_selection_on_gpu(monkeypatch):
-    """On hardware: the 64-atom fixture runs the fused forward by default, a 12^3-cell box the staged pipeline, AA_FUSED=0
-    always the staged pipeline; results agree with the golden vectors either way."""
+    """On hardware: the fused forward runs by default at any size (64 atoms and a 1728-atom box), AA_FUSED=0 selects the
+    staged pipeline; results agree with the golden vectors either way."""
     from allegro_amd import graph as G
 
     dev = torch.device("cuda:0")
     fx = load_model_fixture("c2", torch.float32)
     data, sv = fixture_data(fx, torch.float32, dev)
-    out = {}
     for mode in ("auto", "0"):
         if mode == "auto":
             monkeypatch.delenv("AA_FUSED", raising=False)
@@ -199,15 +199,15 @@ def test_automatic_selection_on_gpu(monkeypatch):
         m = model_from_fixture(fx, torch.float32, device=dev)
         g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
         assert ("fused_fwd" in _launches(m, data, g)) == (mode == "auto")
-        out[mode] = m.energy_forces(data["pos"], g)
-        for got, want in ((out[mode][0].cpu(), fx["out"]["atomic_energy"].reshape(-1)), (out[mode][1].cpu(), fx["out"]["forces"])):
+        e, f = m.energy_forces(data["pos"], g)
+        for got, want in ((e.cpu(), fx["out"]["atomic_energy"].reshape(-1)), (f.cpu(), fx["out"]["forces"])):
             assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
     monkeypatch.delenv("AA_FUSED", raising=False)
-    big = G.make_si_graph(6)  # 1728 atoms > 4 per CU
+    big = G.make_si_graph(6)
     m = model_from_fixture(fx, torch.float32, device=dev)
     gb = m.prepare_graph(torch.tensor(big.edge_index).to(dev), torch.zeros(big.num_atoms, dtype=torch.int64, device=dev), big.num_atoms,
                          torch.tensor(big.shift_vec(), dtype=torch.float32, device=dev))
-    assert "fused_fwd" not in _launches(m, {"pos": torch.tensor(big.pos, dtype=torch.float32, device=dev)}, gb)
+    assert "fused_fwd" in _launches(m, {"pos": torch.tensor(big.pos, dtype=torch.float32, device=dev)}, gb)
 
 
 @pytest.mark.gpu

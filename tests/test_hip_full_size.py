@@ -63,7 +63,13 @@ def _block_check(workload, block_atoms, chunk_edges):
     return worst
 
 
-def test_c4_full_step_vs_oracle_on_three_atom_blocks():
+@pytest.mark.parametrize("forward", ["staged", "automatic"])
+def test_c4_full_step_vs_oracle_on_three_atom_blocks(forward, monkeypatch):
+    # "automatic" is what bench.py and a host without switches run: the fused per-atom-tile forward (28 edges per atom)
+    if forward == "automatic":
+        monkeypatch.delenv("AA_FUSED", raising=False)
+    else:
+        monkeypatch.setenv("AA_FUSED", "0")
     _block_check("c4", block_atoms=96, chunk_edges=12000)
 
 
