@@ -176,6 +176,14 @@ def roofline_from_stages(stages, dtype, workload="c4"):
     roof = dict(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None,
                 kernel=sym, avg_launch_ms=d["ms"] / n, launches_per_step=d["launches"],
                 algorithmic_bytes_per_launch=d["bytes"] / n)
+    if dtype == "float32" and sym.startswith("fused_fwd") and d["flops"] > 0:
+        # the fused per-atom-tile forward does the work of seven launches with 2.1 KB/edge of traffic: ~80 flop/B against a
+        # ridge of ~20 (fp32 matrix peak / HBM peak) -- bound by the matrix pipe.  Priced as SURVEY 8(d) prescribes for the
+        # fused design: algorithmic fp32 flops of its linear layers against the fp32 MFMA peak (the arithmetic itself runs
+        # as 6 bf16 MFMAs per product: mfma_bf16_TFLOPs below, against the 2.5 PFLOP/s bf16 peak)
+        tf = d["flops"] / n / t / 1e12
+        roof.update(bound="mfma", achieved=tf, peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_TFLOPS,
+                    algorithmic_flops_per_launch=d["flops"] / n, hbm_GBps=ach)
     if dtype == "float64" and sym.startswith("gemm_") and d["flops"] > 0:
         # the fp64 linear layers (K, N >= 128) run at >= 64 flop/B: bound by the fp64 matrix pipe, not by HBM
         tf = d["flops"] / n / t / 1e12

@@ -78,3 +78,14 @@ def test_bench_roofline_accounting_on_synthetic_stages():
     sr = bench.step_roofline(cfg, 1000, 1e-3, stages, "float32")
     assert abs(sr["flop_per_edge"] - 423898.0) < 1.0                     # ~424 kflop/edge
     assert abs(sr["algorithmic_bytes_per_edge"] - 10.5e9 / 1000) < 1e-3
+
+
+def test_bench_prices_the_fused_forward_against_the_matrix_roofline():
+    """The fused forward (one launch, ~80 flop/B) is matrix-bound: fp32-equivalent flops of its linear layers against the
+    fp32 MFMA peak, with the HBM rate kept as a secondary figure."""
+    import bench
+
+    stages = [("fused_fwd", 5.0, 6.0e9, 3.0e11), ("gc_64x64_64x64_128x128_64x64", 1.4, 4.2e9, 1.5e11), ("tp_mom_bwd_first", 2.0, 7.7e9, 0.0)]
+    roof, _ = bench.roofline_from_stages(stages, "float32", workload="none")
+    assert roof["kernel"] == "fused_fwd" and roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == bench.PEAK_F32_TFLOPS
+    assert abs(roof["achieved"] - 60.0) < 1e-9 and abs(roof["frac"] - 60.0 / 157.3) < 1e-9 and abs(roof["hbm_GBps"] - 1200.0) < 1e-6
