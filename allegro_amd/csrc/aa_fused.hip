@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps, "the two LDS buffers alternate consistently across iterations");
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);            // [64] last readout weights
-  float* sRm = sRo + 64;                                               // [T*T] 1 / r_max per type pair, [8] Bessel roots
-  float* sTab = sRm + 16;                                              // [T*T][8][64] two-body table
+  float* sRm = sRo + 64;                                               // [16: T*T <= 9 used] 1 / r_max per type pair, then [8] Bessel roots at 16
+  float* sTab = sRm + 32;                                              // [T*T][8][64] two-body table
   const int ntab = A.num_types * A.num_types * 512;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, hh = lane >> 5, el = lane & 31;
   float* sW = sTab + ntab + wv * (kWaveRegion + 32 * kLdY);            // wave region: patch / per-atom vectors ...
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
 #endif
   for (int i = tid; i < 64; i += 256) sRo[i] = A.ro_w[i];
   if (tid < A.num_types * A.num_types) sRm[tid] = A.rmax_recip[tid];
-  if (tid >= 8 && tid < 16) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 8] : 0.f;
+  if (tid >= 16 && tid < 24) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 16] : 0.f;
   for (int i = tid; i < ntab; i += 256) sTab[i] = A.emb_tab[i];
   FusedPipe p;
   p.wbuf = wbuf;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
         cutoff_and_grad<float>(x, A.poly_p, f, df);
         const float fx = f / x;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) basis[n] = aa_sin(sRm[8 + n] * x) * fx;
+        for (int n = 0; n < 8; ++n) basis[n] = aa_sin(sRm[16 + n] * x) * fx;
       }
     }
     AA_TICK(1)
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void fused_fill_energy_kernel(int64_t N, int64
 
 size_t fused_fwd_lds_bytes(int num_types) {
   return sizeof(u32x4) * 2 * kWStep +
-         sizeof(float) * (64 + 16 + size_t(num_types) * num_types * 512 + 4 * (kWaveRegion + 32 * kLdY) + (kFusedOcc == 1 ? 4 * 4 * kTileFloats : 0));
+         sizeof(float) * (64 + 32 + size_t(num_types) * num_types * 512 + 4 * (kWaveRegion + 32 * kLdY) + (kFusedOcc == 1 ? 4 * 4 * kTileFloats : 0));
 }
 
 // number of weight-pipeline steps of the program for R irreps (see the kernel)

@@ -245,8 +245,8 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
   // ---- LDS carve
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);  // [64]
-  float* sRm = sRo + 64;                                      // [T*T] 1/r_max, [8] Bessel roots
-  float* sTab = sRm + 16;                                     // [T*T][8][64]
+  float* sRm = sRo + 64;                                      // [16: T*T <= 9 used] 1/r_max per type pair, then [8] Bessel roots at 16
+  float* sTab = sRm + 32;                                     // [T*T][8][64]
   const int ntab = A.num_types * A.num_types * 512;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, slot = wv >> 1, h = wv & 1, el = lane & 15, g = lane >> 4;
   float* sSlot = sTab + ntab + slot * kSlotFloats;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
   float* sX0 = sTab + ntab + 4 * kSlotFloats + wv * 9 * 64;  // [D][64] the wave's copy of x2s0
   for (int i = tid; i < 64; i += 512) sRo[i] = A.ro_w[i];
   if (tid < A.num_types * A.num_types) sRm[tid] = A.rmax_recip[tid];
-  if (tid >= 8 && tid < 16) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 8] : 0.f;
+  if (tid >= 16 && tid < 24) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 16] : 0.f;
   for (int i = tid; i < ntab; i += 512) sTab[i] = A.emb_tab[i];
   FusedPipe16 p;
   p.wbuf = wbuf;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void fused16_fwd_kernel(FusedFwdArgs A) {
       cutoff_and_grad<float>(x, A.poly_p, f, df);
       const float fx = f / x;
 #pragma unroll
-      for (int n = 0; n < 8; ++n) basis[n] = aa_sin(sRm[8 + n] * x) * fx;
+      for (int n = 0; n < 8; ++n) basis[n] = aa_sin(sRm[16 + n] * x) * fx;
     }
   }
   AA_TICK16(1)
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void fused16_fill_energy_kernel(int64_t N, int
 }
 
 size_t fused16_lds_bytes(int num_types) {
-  return sizeof(u32x4) * 2 * kWStep + sizeof(float) * (64 + 16 + size_t(num_types) * num_types * 512 + 4 * kSlotFloats + 8 * 9 * 64);
+  return sizeof(u32x4) * 2 * kWStep + sizeof(float) * (64 + 32 + size_t(num_types) * num_types * 512 + 4 * kSlotFloats + 8 * 9 * 64);
 }
 
 int launch_fused16_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {

@@ -358,8 +358,12 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   }
   p->o_b3a_q = p->o_b3b_q = p->o_b3c_q = 0;
   {
-    p->embed_fused = p->chain_gemm && T <= 2 && B == 8 && S0 == 64 && !opt.embed_no_fuse;
-    p->o_embtab = (p->embed_fused || cfg->embed_kind == 1) ? take(size_t(T) * T * B * S0) : 0;
+    // two-body table [T*T][B][S0] (type embedding x basis weights): the last reverse chain contracts against it (<= 2
+    // species: its LDS copy must leave room for three workgroups per CU) and the fused forward evaluates the embedding
+    // from it (<= 3 species: 18 KB of its LDS).  Part of the blob whenever the shapes allow -- not a function of the options.
+    const bool tab_ok = p->chain_gemm && T <= 3 && B == 8 && S0 == 64;
+    p->embed_fused = tab_ok && T <= 2 && !opt.embed_no_fuse;
+    p->o_embtab = (tab_ok || cfg->embed_kind == 1) ? take(size_t(T) * T * B * S0) : 0;
   }
   if (p->chain_gemm) {
     // merged reverse chain "readout' o latent_{L-1}'" (see Runner::backward): the readout-reverse columns that feed
@@ -380,7 +384,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     // aa_plan_options.fused_forward: 0 = automatic (32-edge tiles whenever the graph allows: max_degree <= 32), 1 / 2 = the
     // 32- / 16-edge-tile form explicitly, 3 = never (staged pipeline).
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                          u == 64 && S == 64 && T <= 2 && B == 8 && S0 == 64 && p->o_embtab != 0;
+                          u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0;
     p->fused_fwd = eligible && opt.fused_forward != 3;
     p->fused_mode = opt.fused_forward == 2 ? 2 : 1;
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
@@ -621,7 +625,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     AA_REQUIRE(raw->shifts, "pack: missing shifts");
     copy(p->o_shifts, raw->shifts, T, 1.0);
   }
-  if (p->embed_fused && c.embed_kind == 0) {
+  if (p->o_embtab && c.embed_kind == 0) {
     const int half = S0 / 2;
     for (int ti = 0; ti < T; ++ti)
       for (int tj = 0; tj < T; ++tj)

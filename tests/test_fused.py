@@ -127,6 +127,28 @@ def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(mode, embed, couplin
                        blocks=3)
 
 
+def _three_species(dims, seed, embed, lib, dev, monkeypatch):
+    monkeypatch.delenv("AA_FUSED", raising=False)  # automatic: the 32-edge-tile fused forward
+    pos, cell, ei, shift, _ = _ragged(dims=dims, keep=0.9, seed=seed)
+    types = np.random.default_rng(seed).integers(0, 3, size=pos.shape[0])
+    deg = np.bincount(ei[0], minlength=pos.shape[0])
+    cfg = _cfg(embed, True, avg=float(deg.mean()), scale_shift=False)
+    cfg.update(type_names=["A", "B", "C"], per_type_energy_scales=[1.3, 0.6, 0.9], per_type_energy_shifts=[-2.0, 0.25, 1.0])
+    m, g = _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev)
+    assert "fused_fwd" in _launches(m, {"pos": torch.tensor(pos, dtype=torch.float32, device=dev)}, g)
+
+
+def test_three_species_run_the_fused_forward_emulated(monkeypatch):
+    """Three species (the 3 x 3 two-body table is 18 KB of the kernel's LDS; more fall back to the staged forward)."""
+    _three_species((3, 3, 2), 4, "bessel", emu_lib(), torch.device("cpu"), monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("embed", ["bessel", "spline"])
+def test_three_species_run_the_fused_forward_on_gpu(embed, monkeypatch):
+    _three_species((8, 8, 7), 6, embed, None, torch.device("cuda:0"), monkeypatch)
+
+
 def test_degree_above_32_falls_back_to_the_staged_pipeline_emulated(monkeypatch):
     _opt_in(monkeypatch, "tile16")
     rng = np.random.default_rng(9)
