@@ -33,7 +33,7 @@ class ModelConfig(C.Structure):
                 ("forward_weight_init", C.c_int32), ("avg_num_neighbors", C.c_double), ("act_const", C.c_double),
                 ("has_scales", C.c_int32), ("has_shifts", C.c_int32), ("tps", TpDesc * AA_MAX_LAYERS),
                 ("embed_kind", C.c_int32), ("spline_span", C.c_int32), ("env_shared_weights", C.c_int32),
-                ("act_kind", C.c_int32 * 3), ("act_consts", C.c_double * 3)]
+                ("act_kind", C.c_int32 * 3), ("act_consts", C.c_double * 3), ("bessel_convention", C.c_int32)]
 
 
 class PlanOptions(C.Structure):
@@ -41,7 +41,7 @@ class PlanOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "tp_generic", "tp_no_chain", "tp_no_moments", "tp_no_operator", "tp_force_operator", "tp_operator_fused",
         "gemm_no_chain", "gemm_fp32_mfma", "gemm_valu", "gemm_v1", "gemm_lds_epilogue", "f64_column_loop",
-        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "tp_mfma", "f64_rows", "chain_tp", "no_channel_padding")]
+        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "tp_mfma", "f64_rows", "chain_tp", "no_channel_padding", "poison_workspace")]
 
 
 def options_from_env() -> PlanOptions:
@@ -63,6 +63,7 @@ def options_from_env() -> PlanOptions:
     o.tp_mfma = {"1": 1, "0": 2}.get(env.get("AA_TP_MFMA", "")[:1], 0)
     o.chain_tp = flag("AA_CHAIN_TP")
     o.no_channel_padding = flag("AA_NO_PAD")
+    o.poison_workspace = flag("AA_POISON")  # debugging: NaN-filled workspace before every step
     o.f64_rows = {"0": 2, "2": 1}.get(env.get("AA_F64_ROWS", "")[:1], 0)  # 0: off, 2: wherever applicable
     return o
 
@@ -140,6 +141,8 @@ class AllegroLib:
         L.aa_nl_fill.restype = C.c_int
         L.aa_model_weights_bytes.argtypes = [C.c_void_p]
         L.aa_model_weights_bytes.restype = C.c_size_t
+        L.aa_model_plan_layout_hash.argtypes = [C.c_void_p]
+        L.aa_model_plan_layout_hash.restype = C.c_uint64
         L.aa_model_pack_weights.argtypes = [C.c_void_p, C.POINTER(RawWeights), C.c_void_p, C.c_size_t, C.c_void_p]
         L.aa_model_workspace_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
         L.aa_model_workspace_bytes.restype = C.c_size_t

@@ -11,11 +11,29 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused16.hip", "aa_tp_mfma.hip", "aa_model.hip", "aa_nl.hip"]
+# public C ABI header: the package ships its own copy (package data, so that an installed package can rebuild itself);
+# in the source tree it is the same file as <repo>/include/allegro_amd.h (tests/test_lib_symbols.py checks identity)
+INCLUDE_DIR = os.path.join(HERE, "include")
 LIB_PATH = os.path.join(HERE, "liballegro_amd.so")
 TORCH_LIB_PATH = os.path.join(HERE, "liballegro_amd_torch.so")  # dispatcher op for torch.export / AOTI / C++ hosts
 
 
+def _sync_public_header() -> None:
+    """Source tree only: <repo>/include/allegro_amd.h is the canonical C ABI header; the package's copy follows it."""
+    src = os.path.join(ROOT, "include", "allegro_amd.h")
+    dst = os.path.join(INCLUDE_DIR, "allegro_amd.h")
+    if os.path.exists(src):
+        with open(src, "rb") as f:
+            want = f.read()
+        have = open(dst, "rb").read() if os.path.exists(dst) else None
+        if have != want:
+            os.makedirs(INCLUDE_DIR, exist_ok=True)
+            with open(dst, "wb") as f:
+                f.write(want)
+
+
 def _stale() -> bool:
+    _sync_public_header()
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
@@ -25,7 +43,7 @@ def _stale() -> bool:
 def _source_deps():
     """Files the device library is compiled from (not __pycache__, generators or the host-only torch_ops.cpp)."""
     deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
-    return deps + [os.path.join(ROOT, "include", "allegro_amd.h")]
+    return deps + [os.path.join(INCLUDE_DIR, "allegro_amd.h")]
 
 
 def source_hash() -> str:
@@ -67,16 +85,58 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         return _build_library_locked(verbose)
 
 
+OBJ_DIR = os.path.join(HERE, ".objcache")  # per-source objects keyed by content hash (git-ignored, rebuilt on demand)
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _object_for(src: str, header_hash: str) -> str:
+    import hashlib
+
+    h = hashlib.sha256(header_hash.encode())
+    h.update(" ".join(CFLAGS + EXTRA_DEFINES).encode())
+    with open(os.path.join(CSRC, src), "rb") as f:
+        h.update(f.read())
+    return os.path.join(OBJ_DIR, f"{os.path.splitext(src)[0]}-{h.hexdigest()[:16]}.o")
+
+
+EXTRA_DEFINES = [d for d in os.environ.get("AA_BUILD_DEFINES", "").split() if d]  # e.g. "-DAA_FUSED_TIMING" (experiments)
+
+
 def _build_library_locked(verbose: bool) -> str:
+    """One `hipcc -c` per translation unit, in parallel, cached by content hash (a source-only edit recompiles one
+    file; a header edit all of them), then one link."""
+    _sync_public_header()
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    tmp = LIB_PATH + f".tmp{os.getpid()}"
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hh = hashlib.sha256()
+    for d in _source_deps():
+        if d.endswith(".h"):
+            with open(d, "rb") as f:
+                hh.update(os.path.basename(d).encode() + f.read())
+    objs = {s: _object_for(s, hh.hexdigest()) for s in SOURCES}
     t0 = time.time()
-    if verbose:
-        print("[allegro_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+
+    def compile_one(s):
+        if os.path.exists(objs[s]):
+            return
+        tmp = objs[s] + f".tmp{os.getpid()}"
+        cmd = [hipcc] + CFLAGS + EXTRA_DEFINES + ["-I", INCLUDE_DIR, "-I", CSRC, "-c", os.path.join(CSRC, s), "-o", tmp]
+        if verbose:
+            print("[allegro_amd.build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, objs[s])
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        list(ex.map(compile_one, SOURCES))
+    keep = set(objs.values())
+    for f in os.listdir(OBJ_DIR):  # objects of earlier source states
+        if os.path.join(OBJ_DIR, f) not in keep and f.endswith(".o"):
+            os.remove(os.path.join(OBJ_DIR, f))
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [objs[s] for s in SOURCES] + ["-o", tmp], check=True)
     os.replace(tmp, LIB_PATH)  # atomic: a concurrently starting process never maps a half-written library
     if verbose:
         print(f"[allegro_amd.build] built {LIB_PATH} in {time.time() - t0:.1f}s", flush=True)
@@ -109,7 +169,7 @@ def _build_torch_ops_locked(src: str, verbose: bool) -> str:
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
            f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-I", os.path.join(tdir, "include"),
            "-I", os.path.join(tdir, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
-           "-I", os.path.join(ROOT, "include"), src, "-o", TORCH_LIB_PATH + f".tmp{os.getpid()}", "-L", HERE, "-lallegro_amd",
+           "-I", INCLUDE_DIR, src, "-o", TORCH_LIB_PATH + f".tmp{os.getpid()}", "-L", HERE, "-lallegro_amd",
            "-Wl,-rpath,$ORIGIN", "-L", os.path.join(tdir, "lib"), "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip",
            "-ltorch_hip", "-Wl,-rpath," + os.path.join(tdir, "lib")]
     t0 = time.time()

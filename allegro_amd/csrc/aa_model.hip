@@ -173,6 +173,8 @@ struct aa_model_plan {
       const void *weights, *pos, *ws, *e, *f, *center, *nbr, *rowptr, *types, *shift, *trow, *tperm;
       int64_t N, E, a0, a1;
       size_t wsb;
+      int64_t max_degree;  // selects the fused forward: part of what was captured
+      int64_t taps;        // aa_model_plan_enable_taps switches pipelines
       bool operator==(const Key& o) const { return std::memcmp(this, &o, sizeof(Key)) == 0; }
     } key{};
   };
@@ -414,6 +416,12 @@ extern "C" int aa_model_plan_enable_graph(aa_model_plan* plan, int on) {
 extern "C" int aa_model_plan_enable_taps(aa_model_plan* plan, int on) {
   AA_REQUIRE(plan, "aa_model_plan_enable_taps: null plan");
   plan->taps = on != 0;
+  // a captured step belongs to the pipeline that was selected when it was captured
+  aa_model_plan::StepGraph& g = plan->sg;
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr;
+  g.graph = nullptr;
   return AA_OK;
 }
 
@@ -427,6 +435,45 @@ extern "C" void aa_model_plan_destroy(aa_model_plan* plan) {
 }
 
 extern "C" size_t aa_model_weights_bytes(const aa_model_plan* plan) { return plan ? plan->n_elems * plan->esize() : 0; }
+
+extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
+  if (!p) return 0;
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over every quantity aa_model_pack_weights lays the blob out by
+  auto mix = [&](uint64_t v) {
+    for (int i = 0; i < 8; ++i) {
+      h ^= (v >> (8 * i)) & 0xff;
+      h *= 1099511628211ull;
+    }
+  };
+  auto mixv = [&](const std::vector<size_t>& v) {
+    mix(v.size());
+    for (size_t x : v) mix(x);
+  };
+  auto mixm = [&](const MlpLayout& m) {
+    mix(m.dims.size());
+    for (int d : m.dims) mix(uint64_t(d));
+    mixv(m.w); mixv(m.wt); mixv(m.wp); mixv(m.wtp); mixv(m.wq); mixv(m.wtq); mixv(m.wq16);
+  };
+  const aa_model_config& c = p->cfg;
+  for (uint64_t v : {uint64_t(c.dtype), uint64_t(c.num_types), uint64_t(c.num_bessels), uint64_t(c.l_max), uint64_t(c.num_layers),
+                     uint64_t(c.num_scalar), uint64_t(c.num_tensor), uint64_t(c.embed_dim), uint64_t(c.embed_mlp_width),
+                     uint64_t(c.latent_mlp_width), uint64_t(c.readout_mlp_width), uint64_t(p->u_raw), uint64_t(p->use_spec),
+                     uint64_t(p->env_mom), uint64_t(p->chain_gemm), uint64_t(p->chain_pair + 1), uint64_t(p->tp_op + 1), uint64_t(p->ng0),
+                     uint64_t(p->n_elems)})
+    mix(v);
+  for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
+                   p->o_g0q16, p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab})
+    mix(v);
+  for (int l = 0; l < c.num_layers; ++l) {
+    mix(p->o_tpw[l]);
+    mix(p->env_mom ? p->o_wk[l] : 0);
+    mix(p->env_mom ? p->o_wt[l] : 0);
+    mixm(p->latent[l]);
+  }
+  mixm(p->embed);
+  mixm(p->readout);
+  return h ? h : 1;
+}
 
 // alpha_i of nequip ScalarMLPFunction: c_prev / sqrt(fan_in | fan_out)
 // `which`: 0 scalar_embed_mlp, 1 latent MLPs, 2 edge_readout (their nonlinearities may differ); linear maps pass -1
@@ -517,9 +564,21 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     // (b) bessel_weights = n (linspace(1, B, B)), basis sinc(x w) w = sin(pi w x) / (pi x).  Both are served by the
     // same kernels, sin(w' x) / x: (b) is recognised by its integer roots and packed as w' = pi w with the 1/pi
     // prefactor folded into the basis_linear rows.
-    bool sinc_form = true;
-    for (int n = 0; n < B; ++n) sinc_form = sinc_form && std::fabs(raw->bessel_weights[n] - double(n + 1)) < 1e-6;
     const double kPi = 3.14159265358979323846;
+    bool sinc_form = c.bessel_convention == 2;
+    if (c.bessel_convention == 0) {
+      bool is_n = true, is_npi = true;
+      for (int n = 0; n < B; ++n) {
+        // (relative 1e-5: the roots of an fp32 state_dict are n*pi rounded to fp32)
+        is_n = is_n && std::fabs(raw->bessel_weights[n] - double(n + 1)) < 1e-5 * double(n + 1);
+        is_npi = is_npi && std::fabs(raw->bessel_weights[n] - double(n + 1) * kPi) < 1e-5 * double(n + 1) * kPi;
+      }
+      if (!is_n && !is_npi)
+        return fail(AA_ERR_INVALID, "pack: bessel_weights are neither n nor n*pi (trained roots?): state aa_model_config.bessel_convention (1: sin(w x)/x, 2: sinc)");
+      sinc_form = is_n;
+    } else if (c.bessel_convention != 1 && c.bessel_convention != 2) {
+      return fail(AA_ERR_INVALID, "pack: bessel_convention must be 0 (recognise), 1 (roots n*pi) or 2 (sinc form)");
+    }
     copy(p->o_bessel, raw->bessel_weights, B, sinc_form ? kPi : 1.0);
     copy(p->o_cemb, raw->center_embed, size_t(T) * S0 / 2, 1.0);
     copy(p->o_nemb, raw->neighbor_embed, size_t(T) * S0 / 2, 1.0);
@@ -1784,6 +1843,7 @@ int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g
   r.stream = stream;
   r.w = layout_workspace(p, r.N, r.E, forces != nullptr);
   if (r.w.total > ws_bytes) return fail(AA_ERR_WORKSPACE, "aa_model_energy_forces: workspace too small");
+  if (p->opt.poison_workspace) AA_CHECK_HIP(hipMemsetAsync(workspace, 0xFF, r.w.total, stream));  // debugging: NaN everywhere
   if (int rc = r.forward(g, pos, atom_energy)) return rc;
   if (forces) return r.backward(g, pos, forces);
   return AA_OK;
@@ -1813,7 +1873,7 @@ extern "C" int aa_model_energy_forces(const aa_model_plan* plan, const void* dev
   const aa_model_plan::StepGraph::Key key{dev_weights,    pos,           workspace,     atom_energy,      forces,          graph->center,
                                           graph->nbr,     graph->rowptr, graph->types,  graph->shift_vec, graph->t_rowptr, graph->t_perm,
                                           graph->num_atoms, graph->num_edges, graph->atom_begin, graph->atom_end,
-                                          workspace_bytes};
+                                          workspace_bytes, graph->max_degree, plan->taps ? 1 : 0};
   if (!sg.exec || !(sg.key == key)) {
     if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
     if (sg.graph) (void)hipGraphDestroy(sg.graph);

@@ -52,7 +52,8 @@ double as_double(int64_t bits) {
 //   embed_dim, embed_mlp_depth, embed_mlp_width, latent_mlp_depth, latent_mlp_width, readout_mlp_depth,
 //   readout_mlp_width, forward_weight_init, has_scales, has_shifts, embed_kind, spline_span,
 //   bits(poly_p), bits(avg_num_neighbors), bits(act_const), env_shared_weights, act_kind[0..2] (one byte each),
-//   bits(act_consts[0..2]), 0, 0]  then per layer
+//   bits(act_consts[0..2]), bessel_convention, layout digest of the blob (aa_model_plan_layout_hash; 0 = unchecked)]
+//   then per layer
 //   [mul, d1, d2, dout, num_paths, coupling, nnz, i[nnz], j[nnz], k[nnz], path[nnz], bits(val)[nnz]]
 // (a plan owns Clebsch-Gordan tables in the memory of the device that was current when it was created: the cache
 //  key carries the device index and the caller holds a device guard)
@@ -94,6 +95,7 @@ const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
     c.act_kind[i] = int32_t((w[24] >> (8 * i)) & 0xff);
     c.act_consts[i] = as_double(w[25 + i]);
   }
+  c.bessel_convention = int32_t(w[28]);
   TORCH_CHECK(c.num_layers >= 1 && c.num_layers <= AA_MAX_LAYERS, "allegro_amd: bad layer count in config");
   int64_t o = kHeader;
   for (int l = 0; l < c.num_layers; ++l) {
@@ -122,7 +124,63 @@ const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
   }
   const int rc = aa_model_plan_create(&c, &e->plan);
   TORCH_CHECK(rc == 0, "aa_model_plan_create failed (", rc, "): ", aa_last_error());
+  // the weight blob travels with the config: it must have been packed for THIS plan's layout (default options)
+  TORCH_CHECK(w[29] == 0 || uint64_t(w[29]) == aa_model_plan_layout_hash(e->plan),
+              "allegro_amd: the weight blob was packed for another plan layout (kernel-selection options differ); "
+              "re-export the model (allegro_amd.export.ExportableAllegro packs for the default options)");
   return *(g_plans[key] = std::move(e));
+}
+
+// Center-sorted CSR view of an edge list + the step's workspace, kept between calls.  An MD driver that holds its
+// neighbour list for several steps hands the op the SAME `edge_index` / `atom_types` tensors each time: the sortedness
+// check, the sort, both CSR builds, the degree reduction (two host syncs) and the workspace allocation are then paid
+// once per list instead of once per step.  Keyed on identity + in-place version of the two tensors, which the entry
+// keeps alive so that their addresses cannot be recycled (the scheme of HipAllegroModel._graph_for).  One entry per
+// device: a driver that rebuilds its list every step simply replaces it.
+struct GraphEntry {
+  at::Tensor key_ei, key_types;  // kept alive
+  uint32_t ver_ei = 0, ver_types = 0;
+  int64_t N = -1;
+  bool permuted = false;
+  at::Tensor perm, center, nbr, rowptr, trow, tperm, types, ws;
+  int64_t max_degree = 0;
+};
+std::map<int, GraphEntry> g_graphs;  // device index -> most recent graph (guarded by g_mu)
+
+bool tensor_version(const at::Tensor& t, uint32_t* v) {
+  try {
+    *v = t._version();
+    return true;
+  } catch (...) {  // inference tensors carry no version counter: never cached
+    return false;
+  }
+}
+
+GraphEntry build_graph(const at::Tensor& edge_index, const at::Tensor& atom_types, int64_t N, const at::TensorOptions& popt) {
+  GraphEntry ge;
+  ge.N = N;
+  const int64_t E = edge_index.size(1);
+  at::Tensor ei = edge_index.to(at::kLong);
+  if (E > 1) {  // edges must be grouped by center (LAMMPS' i-major lists are); sort stably otherwise
+    const bool sorted = at::all(ei[0].slice(0, 1) >= ei[0].slice(0, 0, E - 1)).item<bool>();
+    if (!sorted) {
+      ge.perm = at::argsort(ei[0], /*stable=*/true, 0, false);
+      ge.permuted = true;
+      ei = ei.index_select(1, ge.perm);
+    }
+  }
+  auto i32 = popt.dtype(at::kInt);
+  ge.center = ei[0].to(at::kInt).contiguous();
+  ge.nbr = ei[1].to(at::kInt).contiguous();
+  ge.rowptr = at::zeros({N + 1}, i32);
+  ge.trow = at::zeros({N + 1}, i32);
+  ge.rowptr.slice(0, 1).copy_(at::cumsum(at::bincount(ei[0], {}, N), 0));
+  ge.trow.slice(0, 1).copy_(at::cumsum(at::bincount(ei[1], {}, N), 0));
+  ge.tperm = at::argsort(ei[1], /*stable=*/true, 0, false).to(at::kInt).contiguous();
+  ge.types = atom_types.reshape({-1}).to(at::kInt).contiguous();
+  // (one more host read next to the sortedness check above: selects the fused per-atom-tile kernels)
+  ge.max_degree = E > 0 ? (ge.rowptr.slice(0, 1) - ge.rowptr.slice(0, 0, N)).max().item<int64_t>() : 0;
+  return ge;
 }
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tensor& pos, const at::Tensor& edge_index,
@@ -142,39 +200,56 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tenso
   const int64_t dt = config[1];
   TORCH_CHECK(pos.scalar_type() == (dt == AA_F32 ? at::kFloat : at::kDouble), "positions must be in the model dtype");
   at::Tensor p = pos.contiguous();
-  at::Tensor ei = edge_index.to(at::kLong);
-  std::optional<at::Tensor> sv = shift_vec;
-  if (E > 1) {  // edges must be grouped by center (LAMMPS' i-major lists are); sort stably otherwise
-    const bool sorted = at::all(ei[0].slice(0, 1) >= ei[0].slice(0, 0, E - 1)).item<bool>();
-    if (!sorted) {
-      at::Tensor perm = at::argsort(ei[0], /*stable=*/true, 0, false);
-      ei = ei.index_select(1, perm);
-      if (sv.has_value()) sv = sv->index_select(0, perm);
+  // graph structure: from the cache when the caller hands the same (unmodified) tensors again
+  GraphEntry ge;
+  {
+    uint32_t ve = 0, vt = 0;
+    const bool keyed = tensor_version(edge_index, &ve) && tensor_version(atom_types, &vt);
+    bool hit = false;
+    if (keyed) {
+      std::lock_guard<std::mutex> lock(g_mu);
+      auto it = g_graphs.find(int(pos.get_device()));
+      if (it != g_graphs.end() && it->second.key_ei.is_same(edge_index) && it->second.key_types.is_same(atom_types) &&
+          it->second.ver_ei == ve && it->second.ver_types == vt && it->second.N == N) {
+        ge = it->second;
+        hit = true;
+      }
+    }
+    if (!hit) {
+      ge = build_graph(edge_index, atom_types, N, pos.options());
+      const size_t wsb0 = aa_model_workspace_bytes(pe.plan, N, E, 1);
+      ge.ws = at::empty({int64_t(wsb0)}, pos.options().dtype(at::kByte));
+      if (keyed) {
+        ge.key_ei = edge_index;
+        ge.key_types = atom_types;
+        ge.ver_ei = ve;
+        ge.ver_types = vt;
+        std::lock_guard<std::mutex> lock(g_mu);
+        g_graphs[int(pos.get_device())] = ge;
+      }
     }
   }
-  auto i32 = pos.options().dtype(at::kInt);
-  at::Tensor center = ei[0].to(at::kInt).contiguous(), nbr = ei[1].to(at::kInt).contiguous();
-  at::Tensor rowptr = at::zeros({N + 1}, i32), trow = at::zeros({N + 1}, i32);
-  rowptr.slice(0, 1).copy_(at::cumsum(at::bincount(ei[0], {}, N), 0));
-  trow.slice(0, 1).copy_(at::cumsum(at::bincount(ei[1], {}, N), 0));
-  at::Tensor tperm = at::argsort(ei[1], /*stable=*/true, 0, false).to(at::kInt).contiguous();
-  at::Tensor types = atom_types.reshape({-1}).to(at::kInt).contiguous();
+  const size_t wsb = aa_model_workspace_bytes(pe.plan, N, E, 1);
+  if (size_t(ge.ws.numel()) < wsb) ge.ws = at::empty({int64_t(wsb)}, pos.options().dtype(at::kByte));  // (another model on the same list)
+  // what depends on VALUES that change while the list stays put is rebuilt every call: the periodic shift vectors
   at::Tensor svc;
-  if (sv.has_value()) svc = sv->to(pos.scalar_type()).contiguous();
+  if (shift_vec.has_value()) {
+    svc = shift_vec->to(pos.scalar_type());
+    if (ge.permuted) svc = svc.index_select(0, ge.perm);
+    svc = svc.contiguous();
+  }
   aa_graph g{};
   g.num_atoms = N;
   g.num_edges = E;
-  g.center = center.data_ptr<int32_t>();
-  g.nbr = nbr.data_ptr<int32_t>();
-  g.rowptr = rowptr.data_ptr<int32_t>();
-  g.types = types.data_ptr<int32_t>();
+  g.center = ge.center.data_ptr<int32_t>();
+  g.nbr = ge.nbr.data_ptr<int32_t>();
+  g.rowptr = ge.rowptr.data_ptr<int32_t>();
+  g.types = ge.types.data_ptr<int32_t>();
   g.shift_vec = svc.defined() ? svc.data_ptr() : nullptr;
-  g.t_rowptr = trow.data_ptr<int32_t>();
-  g.t_perm = tperm.data_ptr<int32_t>();
-  // (one more host read next to the sortedness check above: selects the fused per-atom-tile kernels)
-  g.max_degree = E > 0 ? (rowptr.slice(0, 1) - rowptr.slice(0, 0, N)).max().item<int64_t>() : 0;
-  const size_t wsb = aa_model_workspace_bytes(pe.plan, N, E, 1);
-  at::Tensor ws = at::empty({int64_t(wsb)}, pos.options().dtype(at::kByte));
+  g.t_rowptr = ge.trow.data_ptr<int32_t>();
+  g.t_perm = ge.tperm.data_ptr<int32_t>();
+  g.max_degree = ge.max_degree;
+  at::Tensor& ws = ge.ws;
   at::Tensor e_atom = at::empty({N}, pos.options()), forces = at::empty({N, 3}, pos.options());
   TORCH_CHECK(size_t(weights.numel()) * weights.element_size() >= aa_model_weights_bytes(pe.plan),
               "allegro_amd::energy_forces: weight blob too small for this config");

@@ -54,10 +54,11 @@ class LocalShard:
                      of the reference's `pair_allegro` layout (allegro/_compile.py:28-63) and of LAMMPS itself;
       local edges  = the CSR range of the owned centers with both endpoints renumbered; periodic shift vectors kept.
 
-    `step()` gathers the local positions from the caller's position array, runs the whole hot path on the local
-    arrays (graph, workspace and kernels see n_own + n_ghost atoms), and returns this rank's contribution to the
-    GLOBAL force array (`[N,3]`, non-zero on the local atoms only) plus the energies of the owned atoms;
-    `energy_forces_local()` below adds the one collective (all-reduce of that array: 12 N bytes, 1.2 MB at C4)."""
+    `step()` gathers the local positions from the caller's position array into a persistent buffer, runs the whole hot
+    path on the local arrays (graph, workspace and kernels see n_own + n_ghost atoms), and deposits this rank's
+    contribution to the GLOBAL force array (`[N,3]`, non-zero on the local atoms only) and the energies of the owned
+    atoms in ONE persistent buffer; `energy_forces_local()` below adds the one collective of the step (all-reduce of
+    that buffer: 16 N bytes, 1.56 MB at C4).  Nothing is allocated per step."""
 
     def __init__(self, edge_index: np.ndarray, types: np.ndarray, num_atoms: int, shift_vec: Optional[np.ndarray],
                  rank: int, world: int, device, dtype, rowptr: Optional[np.ndarray] = None):
@@ -79,30 +80,49 @@ class LocalShard:
         ei_local = torch.tensor(np.stack([center - self.a0, lookup[nbr]]), device=device)
         sv = None if shift_vec is None else torch.tensor(shift_vec[e0:e1], dtype=dtype, device=device)
         self.graph = PreparedGraph(ei_local, torch.tensor(types[local_ids], device=device), int(local_ids.size), sv)
+        self._reduce = self._pos_local = None  # persistent step buffers (see _buffers)
 
     @property
     def num_local_atoms(self) -> int:
         return self.n_own + self.n_ghost
 
+    def _buffers(self, pos: torch.Tensor):
+        """Persistent per-shard buffers (allocated on the first step, reused afterwards -- no allocation in the MD loop):
+        the gathered local positions and the ONE array the ranks all-reduce, `[N + ceil(N/3), 3]`: rows 0..N-1 are this
+        rank's contribution to the global forces, the tail rows carry the per-atom energies (flattened: element
+        3N + i = E_i), so energies ride in the same collective as the forces."""
+        N = self.num_atoms_global
+        if self._reduce is None or self._reduce.dtype != pos.dtype or self._reduce.device != pos.device:
+            self._reduce = torch.zeros((N + (N + 2) // 3, 3), dtype=pos.dtype, device=pos.device)
+            self._pos_local = torch.empty((self.num_local_atoms, 3), dtype=pos.dtype, device=pos.device)
+        return self._reduce, self._pos_local
+
     def step(self, model, pos: torch.Tensor):
-        """(energies of the owned atoms [n_own], contribution to the global forces [N,3])."""
-        e_loc, f_loc = model.energy_forces(pos.index_select(0, self.local_ids), self.graph)
-        f_glob = torch.zeros((self.num_atoms_global, 3), dtype=f_loc.dtype, device=f_loc.device)
-        f_glob.index_copy_(0, self.local_ids, f_loc)  # local ids are unique: a plain scatter, deterministic
-        return e_loc[: self.n_own], f_glob
+        """Runs the hot path on the local arrays and deposits the result in the shard's reduce buffer.  Returns
+        (E_i [N] view: this rank's owned block filled in, zero elsewhere; forces [N,3] view: this rank's contribution,
+        non-zero on its local atoms only).  Both are views of ONE buffer: `energy_forces_local` all-reduces it once."""
+        buf, pos_local = self._buffers(pos)
+        N = self.num_atoms_global
+        torch.index_select(pos, 0, self.local_ids, out=pos_local)
+        e_loc, f_loc = model.energy_forces(pos_local, self.graph)
+        buf.zero_()  # (the previous step's all-reduce left every rank's rows in it)
+        buf.index_copy_(0, self.local_ids, f_loc)  # local ids are unique: a plain scatter, deterministic
+        e_all = buf.view(-1)[3 * N: 4 * N]
+        e_all[self.a0: self.a1] = e_loc[: self.n_own]
+        return e_all, buf[:N]
 
 
 def energy_forces_local(model, pos: torch.Tensor, shard: LocalShard, group=None):
-    """One step on this rank's compact shard + the force all-reduce.  Returns (E_i [N] with the owned block filled
-    in and summed over ranks, forces [N,3] summed over ranks)."""
+    """One step on this rank's compact shard + THE collective of the step: one all-reduce (sum) of the shard's reduce
+    buffer -- ghost-atom force contributions and the owned-atom energies in one message of 16 N bytes (fp32: 1.56 MB at
+    C4; RCCL over xGMI with backend "nccl").  Returns (E_i [N], forces [N,3]) summed over ranks, as views of the
+    shard's persistent buffer (valid until its next step).  This is the function `bench.py --gpus N` times and the
+    world-size-2/4/8 gloo tests drive (tests/test_dist_gloo.py)."""
     import torch.distributed as dist
 
-    e_own, f = shard.step(model, pos)
-    e = torch.zeros(shard.num_atoms_global, dtype=e_own.dtype, device=e_own.device)
-    e[shard.a0:shard.a1] = e_own
+    e, f = shard.step(model, pos)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(f, group=group)  # ghost-atom force contributions: RCCL over xGMI with backend "nccl"
-        dist.all_reduce(e, group=group)
+        dist.all_reduce(shard._reduce, group=group)
     return e, f
 
 

@@ -33,8 +33,9 @@ def _bits(x: float) -> int:
     return struct.unpack("<q", struct.pack("<d", float(x)))[0]
 
 
-def serialize_config(model) -> list:
-    """`aa_model_config` of a HipAllegroModel as the int64 word list torch_ops.cpp parses."""
+def serialize_config(model, layout_hash: int = 0) -> list:
+    """`aa_model_config` of a HipAllegroModel as the int64 word list torch_ops.cpp parses; `layout_hash` is the digest of
+    the blob layout the weights were packed for (aa_model_plan_layout_hash; 0 = unchecked)."""
     model._ensure_plan()
     cfg, _keep = model._plan_keep
     w = [_MAGIC, cfg.dtype, cfg.num_types, cfg.num_bessels, cfg.l_max, cfg.num_layers, cfg.num_scalar, cfg.num_tensor,
@@ -42,7 +43,8 @@ def serialize_config(model) -> list:
          cfg.readout_mlp_depth, cfg.readout_mlp_width, cfg.forward_weight_init, cfg.has_scales, cfg.has_shifts,
          cfg.embed_kind, cfg.spline_span, _bits(cfg.poly_p), _bits(cfg.avg_num_neighbors), _bits(cfg.act_const),
          cfg.env_shared_weights, cfg.act_kind[0] | (cfg.act_kind[1] << 8) | (cfg.act_kind[2] << 16),
-         _bits(cfg.act_consts[0]), _bits(cfg.act_consts[1]), _bits(cfg.act_consts[2]), 0, 0]
+         _bits(cfg.act_consts[0]), _bits(cfg.act_consts[1]), _bits(cfg.act_consts[2]), cfg.bessel_convention,
+         layout_hash - (1 << 64) if layout_hash >= (1 << 63) else layout_hash]
     for l in range(cfg.num_layers):
         d = cfg.tps[l]
         w += [d.mul, d.d1, d.d2, d.dout, d.num_paths, d.coupling, d.nnz]
@@ -64,10 +66,22 @@ class ExportableAllegro(torch.nn.Module):
         super().__init__()
         load_native_ops()
         device = torch.device(device)
+        model._select_device(device)
         model._ensure_plan()
-        model._ensure_weights(device)
-        self.config = serialize_config(model)  # int list (a constant of the exported program)
-        self.register_buffer("weights", model._blob.clone())
+        # The op creates its plan with DEFAULT aa_plan_options, whatever AA_* switches the Python host of this process
+        # maps onto the model's own plan, and several of those switches change the blob layout (column order, padding,
+        # moments split): pack the blob for a default-options plan, and store that layout's digest in the config so that
+        # the op can refuse a blob packed for another layout instead of computing garbage from it.
+        lib = model._get_lib()
+        cfg, _keep = model._plan_keep
+        plan = lib.model_plan_create(cfg, _lib.PlanOptions())
+        try:
+            blob = model._pack_blob(plan, device)
+            layout = int(lib.lib.aa_model_plan_layout_hash(plan))
+        finally:
+            lib.model_plan_destroy(plan)
+        self.config = serialize_config(model, layout)  # int list (a constant of the exported program)
+        self.register_buffer("weights", blob)
 
     def forward(self, pos: torch.Tensor, edge_index: torch.Tensor, atom_types: torch.Tensor,
                 shift_vec: Optional[torch.Tensor] = None):

@@ -210,6 +210,12 @@ class _SegmentCache:
 _SEGMENTS = _SegmentCache()
 
 
+def _is_tracing() -> bool:
+    """True under torch.compile / torch.export tracing (FakeTensors: no addresses, no values)."""
+    c = torch.compiler
+    return bool(c.is_compiling() or (hasattr(c, "is_exporting") and c.is_exporting()))
+
+
 # ------------------------------------------------------------------------------------------------
 # Contracter (seam B1/B2)
 # ------------------------------------------------------------------------------------------------
@@ -281,6 +287,12 @@ class HipContracter(torch.nn.Module):
             x2s = torch.zeros((int(scatter_dim_size),) + tuple(x2.shape[1:]), dtype=x2.dtype, device=x2.device)
             x2s = x2s.index_add(0, idxs.reshape(-1), sf * x2)
             return self._contract(x1, x2s.index_select(0, idxs.reshape(-1)))
+        if _is_tracing():
+            # torch.export / torch.compile: no data pointers, no data-dependent Python -- the bookkeeping is one opaque
+            # op with a fake kernel (ops.segments); plan handles are process-local, so a traced program is valid in
+            # THIS process (a Python-free host loads the whole-step op of allegro_amd/export.py instead)
+            rowptr, eids = torch.ops.allegro_amd.segments(idxs, scatter_dim_size, self.assume_sorted_idxs)
+            return self._op(x1, x2, rowptr, None if self.assume_sorted_idxs else eids, scatter_dim_size, sf)
         # per-call host sync / bincount / cumsum only on the first layer of the first forward with this index tensor
         rowptr, eids = _SEGMENTS.get(idxs, scatter_dim_size, self.assume_sorted_idxs)
         return self._op(x1, x2, rowptr, eids, int(scatter_dim_size), sf)
@@ -392,6 +404,9 @@ def _ensure_path(root: torch.nn.Module, dotted: str) -> Tuple[torch.nn.Module, s
             node.add_module(name, _Node())
         node = getattr(node, name)
     return node, parts[-1]
+
+
+_BESSEL_CONVENTIONS = {"auto": 0, "npi": 1, "sinc": 2}
 
 
 class PreparedGraph:
@@ -513,9 +528,16 @@ class HipAllegroModel(torch.nn.Module):
                  weight_individual_irreps: bool = True, per_type_energy_scales=None, per_type_energy_shifts=None,
                  per_type_energy_scales_trainable: bool = False, per_type_energy_shifts_trainable: bool = False,
                  pair_potential=None, forward_normalize: bool = True, seed: Optional[int] = None,
-                 model_dtype: str = "float32", compile_mode: Optional[str] = None):
+                 model_dtype: str = "float32", compile_mode: Optional[str] = None,
+                 bessel_convention: str = "auto"):
         super().__init__()
         assert avg_num_neighbors is not None, "`avg_num_neighbors` must be set for Allegro models"
+        # which published form of nequip's BesselEdgeLengthEncoding (EXT) the state_dict follows: "npi" (roots n*pi,
+        # sin(w x)/x), "sinc" (roots n, sinc(x w) w), or "auto" = told apart by the stored values -- which is only
+        # possible for untrained roots (aa_model_config.bessel_convention)
+        if bessel_convention not in _BESSEL_CONVENTIONS:
+            raise ValueError(f"bessel_convention {bessel_convention!r}: one of {sorted(_BESSEL_CONVENTIONS)}")
+        self.bessel_convention = bessel_convention
         if pair_potential is not None:
             raise NotImplementedError("pair potentials (nequip's ZBL module, EXT) are outside the hot path (DESIGN.md section 8)")
         self.nonlinearities = (scalar_embed_mlp_nonlinearity, allegro_mlp_nonlinearity, readout_mlp_nonlinearity)
@@ -529,8 +551,9 @@ class HipAllegroModel(torch.nn.Module):
         if self.embed_kind is None:
             raise NotImplementedError(f"radial_chemical_embed {tgt}: only allegro.nn.TwoBodyBesselScalarEmbed and "
                                       "allegro.nn.TwoBodySplineScalarEmbed exist in the reference (scalarembed.py)")
-        if rce.get("bessel_trainable", False):
-            raise NotImplementedError("trainable Bessel roots are a training feature (out of scope)")
+        if rce.get("bessel_trainable", False) and bessel_convention == "auto":
+            raise NotImplementedError("trained Bessel roots cannot be told apart by their values: pass bessel_convention='sinc' "
+                                      "or 'npi' (this model evaluates them; it does not train them)")
         self.dtype = {"float32": torch.float32, "float64": torch.float64}[model_dtype]
         self.type_names = list(type_names)
         T = len(self.type_names)
@@ -717,6 +740,7 @@ class HipAllegroModel(torch.nn.Module):
             cfg.act_consts[i] = second_moment_const(nl)
         cfg.has_scales, cfg.has_shifts = int(self.has_scales), int(self.has_shifts)
         cfg.embed_kind, cfg.spline_span = self.embed_kind, hp["spline_span"]
+        cfg.bessel_convention = _BESSEL_CONVENTIONS[self.bessel_convention]
         keep = []
         sd = self._sd()
         for l in range(hp["num_layers"]):
@@ -732,6 +756,11 @@ class HipAllegroModel(torch.nn.Module):
         key = (str(device), tuple(int(p._version) for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
         if self._blob is not None and self._blob_key == key:
             return
+        self._blob, self._blob_key = self._pack_blob(self._plan_handle, device), key
+
+    def _pack_blob(self, plan_handle, device) -> torch.Tensor:
+        """The model's state_dict packed for `plan_handle` (aa_model_pack_weights): the blob's layout belongs to that plan
+        (aa_model_plan_layout_hash)."""
         lib = self._get_lib()
         hp = self.hparams
         sd = {k: v.detach().to("cpu", torch.float64).contiguous() for k, v in self._sd().items()}
@@ -767,12 +796,12 @@ class HipAllegroModel(torch.nn.Module):
             raw.scales = ptr(sd["per_type_energy_scale_shift.scales"])
         if self.has_shifts:
             raw.shifts = ptr(sd["per_type_energy_scale_shift.shifts"])
-        nbytes = lib.lib.aa_model_weights_bytes(self._plan_handle)
+        nbytes = lib.lib.aa_model_weights_bytes(plan_handle)
         blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
-        lib.check(lib.lib.aa_model_pack_weights(self._plan_handle, C.byref(raw), blob.data_ptr(), nbytes, stream),
+        lib.check(lib.lib.aa_model_pack_weights(plan_handle, C.byref(raw), blob.data_ptr(), nbytes, stream),
                   "aa_model_pack_weights")
-        self._blob, self._blob_key = blob, key
+        return blob
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)

@@ -115,6 +115,27 @@ def _(gout, x1, x2s, weights, rowptr, eids, num_atoms, plan, lib_id):
     return x1.new_empty(weights.shape)
 
 
+@torch.library.custom_op("allegro_amd::segments", mutates_args=())
+def segments(idxs: torch.Tensor, num_segments: int, assume_sorted: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Segment bookkeeping of `Contracter.forward`'s scatter index (allegro/nn/_strided/_contract.py:195-205) as an OPAQUE
+    op, so that `torch.export` / `torch.compile(fullgraph=True)` can trace through HipContracter.forward: the bincount /
+    cumsum / sort below are data dependent, but their results have static shapes -- rowptr int32 [num_segments + 1] and
+    the stable sort permutation eids int32 [E] (the identity when `assume_sorted`, which the kernels accept)."""
+    flat = idxs.reshape(-1)
+    rowptr = torch.zeros(num_segments + 1, dtype=torch.int32, device=flat.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(flat, minlength=num_segments), 0).to(torch.int32)
+    if assume_sorted:
+        eids = torch.arange(flat.numel(), dtype=torch.int32, device=flat.device)
+    else:
+        eids = torch.argsort(flat, stable=True).to(torch.int32)
+    return rowptr, eids
+
+
+@segments.register_fake
+def _(idxs, num_segments, assume_sorted):
+    return (idxs.new_empty((num_segments + 1,), dtype=torch.int32), idxs.new_empty((idxs.numel(),), dtype=torch.int32))
+
+
 def _setup_context(ctx, inputs, output):
     x1, _x2, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id, _d2, _dout = inputs
     _out, x2s = output

@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from allegro_amd import graph as G  # noqa: E402
-from allegro_amd.dist import LocalShard  # noqa: E402
+from allegro_amd.dist import LocalShard, energy_forces_local  # noqa: E402
 from allegro_amd.nn import HipAllegroModel, PreparedGraph  # noqa: E402
 
 BESSEL = {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8, "polynomial_cutoff_p": 6}
@@ -394,10 +394,9 @@ def main():
     def step():
         if shard is None:
             return model.energy_forces(pos, graph)
-        e_own, forces = shard.step(model, pos)
-        if dist is not None:
-            dist.all_reduce(forces)  # ghost-atom force contributions: one RCCL all-reduce over xGMI
-        return e_own, forces
+        # compact shard + THE collective of the step (one RCCL all-reduce over xGMI carrying ghost-atom force
+        # contributions and owned-atom energies; allegro_amd/dist.py) -- the function the gloo tests drive
+        return energy_forces_local(model, pos, shard)
 
     for _ in range(args.warmup):
         step()

@@ -112,6 +112,50 @@ def dump_model(name, cfg, g):
           f"-> {os.path.getsize(path) / 1024:.0f} KB")
 
 
+def dump_ghost(name, base, cfg, g):
+    """`pair_allegro` tensor contract from the reference's OWN data transform: `allegro_data_settings`
+    (allegro/_compile.py:17-65) turns the periodic frame into the ghost-atom layout LAMMPS hands over -- ghosts
+    appended, no cell, edges in ITS order (inside-cell edges first, then the outside-cell ones, i.e. NOT sorted by
+    center, :47-58) -- and the reference model runs on the result.  Stored: the transformed inputs exactly as emitted
+    and the reference's outputs on them (ghost rows carry the force contributions LAMMPS reverse-communicates).
+    The weights are those of fixture `base` (same cfg and seed; asserted)."""
+    from allegro._compile import PAIR_ALLEGRO_INPUTS, allegro_data_settings
+    from allegro.model import AllegroModel
+    from nequip.data import AtomicDataDict as ADD
+
+    arrays = {"cfg_json": np.array(json.dumps(cfg)), "weights_of": np.array(base), "n_local": np.array(g.num_atoms)}
+    zb = np.load(os.path.join(GOLD, f"model_{base}.npz"))
+    for dtype, tag in ((torch.float64, "64"), (torch.float32, "32")):
+        model = AllegroModel(model_dtype="float64", **cfg).eval()
+        for k, v in model.state_dict().items():
+            assert np.array_equal(zb["sd/" + k[len("func."):]], v.detach().to(torch.float64).numpy()), k
+        if dtype == torch.float32:
+            m32 = AllegroModel(model_dtype="float32", **cfg).eval()
+            m32.load_state_dict({k: v.to(torch.float32) for k, v in model.state_dict().items()})
+            model = m32
+        data = {ADD.POSITIONS_KEY: torch.tensor(g.pos, dtype=dtype), ADD.EDGE_INDEX_KEY: torch.tensor(g.edge_index),
+                ADD.ATOM_TYPE_KEY: torch.tensor(g.types), ADD.CELL_KEY: torch.tensor(g.cell, dtype=dtype),
+                ADD.EDGE_CELL_SHIFT_KEY: torch.tensor(g.cell_shift, dtype=dtype)}
+        data = allegro_data_settings(data)  # the reference's transform, verbatim
+        assert ADD.CELL_KEY not in data and ADD.EDGE_CELL_SHIFT_KEY not in data
+        if tag == "64":
+            assert PAIR_ALLEGRO_INPUTS == [ADD.POSITIONS_KEY, ADD.EDGE_INDEX_KEY, ADD.ATOM_TYPE_KEY]
+            arrays["pos"] = data[ADD.POSITIONS_KEY].numpy()
+            arrays["edge_index"] = data[ADD.EDGE_INDEX_KEY].numpy()
+            arrays["types"] = data[ADD.ATOM_TYPE_KEY].numpy()
+            c = arrays["edge_index"][0]
+            assert (np.diff(c) < 0).any(), "the reference emits inside-cell edges first: not center-sorted"
+        out = model({k: v for k, v in data.items()})
+        for k in ("atomic_energy", "total_energy", "forces"):
+            arrays[f"out{tag}/{k}"] = out[k].detach().numpy()
+    n = g.num_atoms
+    path = os.path.join(GOLD, f"model_{name}.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {n} local + {arrays['pos'].shape[0] - n} ghost atoms, E={arrays['edge_index'].shape[1]} "
+          f"E_local={float(arrays['out64/atomic_energy'][:n].sum()):.10f} |F|max={np.abs(arrays['out64/forces']).max():.6f} "
+          f"-> {os.path.getsize(path) / 1024:.0f} KB")
+
+
 def dump_contract_cases():
     from allegro.nn._strided import Contracter
     from e3nn import o3
@@ -196,6 +240,8 @@ def main(only=None):
         if d[2 * 2 * 27] > 1.45:  # skip the 2*27 intramolecular O-H bonds (directed: x2); H-H intra is 1.51
             break
     dump_model("c5_small", water_cfg(), w)
+    if not only or "c2_ghost" in only:
+        dump_ghost("c2_ghost", "c2", si_cfg(2, 2, 64), si)  # the reference's own pair_allegro data transform on C2
     if not only or "contract_cases" in only:
         dump_contract_cases()
 

@@ -9,11 +9,22 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
-# Kernel selection is explicit in the tests: the staged pipeline unless a test opts into another path (monkeypatch of the
-# AA_* variables that allegro_amd/_lib.py maps onto aa_plan_options).  Unset, AA_FUSED means "automatic" -- the fused
-# forward whenever the graph allows it -- which tests/test_fused.py, the full-size block tests, bench.py's parity_sample and
-# smoke() cover; pinning the staged pipeline here keeps its own kernels under test.
-os.environ.setdefault("AA_FUSED", "0")
+# Kernel selection: nothing is pinned here.  With AA_FUSED unset the plan is created with aa_plan_options.fused_forward = 0
+# ("automatic": the fused per-atom-tile forward whenever the graph allows it) -- the product's DEFAULT path, which is
+# therefore what every test runs unless it opts into another one.  The model-level GPU modules additionally run every
+# test twice through the `forward_mode` fixture below ("auto" and "staged"), so both pipelines stay certified against
+# the golden vectors, the oracle, finite differences, the ghost layout and the virial.
+os.environ.pop("AA_FUSED", None)
+
+
+@pytest.fixture(params=["auto", "staged"])
+def forward_mode(request, monkeypatch):
+    """AA_FUSED unset (automatic selection, the default) / AA_FUSED=0 (staged pipeline) for the plans a test creates."""
+    if request.param == "auto":
+        monkeypatch.delenv("AA_FUSED", raising=False)
+    else:
+        monkeypatch.setenv("AA_FUSED", "0")
+    return request.param
 
 
 def pytest_configure(config):

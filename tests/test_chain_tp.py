@@ -18,6 +18,7 @@ from tests.test_tp_mfma import _assert_launched, _dense_cluster, _vs_oracle64
 def _on(monkeypatch, on=True):
     """AA_CHAIN_TP is read when the plan is created (the first step of a model)."""
     monkeypatch.setenv("AA_CHAIN_TP", "1" if on else "0")
+    monkeypatch.setenv("AA_FUSED", "0")  # (the fused forward takes precedence over this staged variant)
 
 
 def test_ragged_graph_vs_fp64_oracle_emulated(monkeypatch):

@@ -1,5 +1,5 @@
-"""CPU, world_size 2, gloo: the N>1 path (atom-block sharding + force all-reduce) reproduces the
-single-process result.  Kernels run through the test-only emulation build (no GPU here)."""
+"""CPU, world_size 2 / 4 / 8, gloo: the N>1 path (atom-block sharding + ONE all-reduce of forces and energies per step)
+reproduces the single-process result.  Kernels run through the test-only emulation build (no GPU here)."""
 import os
 import sys
 
@@ -46,6 +46,19 @@ def _worker_local(rank, world, port, q):
     n = fx["pos"].shape[0]
     sh = LocalShard(fx["edge_index"].numpy(), fx["types"].numpy(), n, fx["shift_vec"].numpy(), rank, world, "cpu", torch.float64)
     e, f = energy_forces_local(m, fx["pos"], sh)
+    buf_ptr = sh._reduce.data_ptr()
+    # a second step with other positions and back: the persistent reduce buffer is re-zeroed, nothing is re-allocated,
+    # and exactly ONE collective was issued per step (counted on the process group's all_reduce)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        energy_forces_local(m, fx["pos"] + 0.01, sh)
+        e, f = energy_forces_local(m, fx["pos"], sh)
+    finally:
+        dist.all_reduce = orig
+    assert len(calls) == 2 and sh._reduce.data_ptr() == buf_ptr
+    e, f = e.clone(), f.clone()
     stats = torch.tensor([sh.n_own, sh.n_ghost, sh.graph.num_edges], dtype=torch.int64)
     allstats = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(allstats, stats)
@@ -56,13 +69,15 @@ def _worker_local(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_four_rank_compact_shards_match_reference():
-    """world_size 4, gloo: every rank holds only its owned block + ghost atoms (local numbering), one all-reduce of the
-    force array; the result equals the reference's golden vectors."""
+@pytest.mark.parametrize("world", [4, 8])
+def test_compact_shards_with_one_collective_match_reference(world):
+    """world_size 4 and 8, gloo: every rank holds only its owned block + ghost atoms (local numbering) and runs
+    `allegro_amd.dist.energy_forces_local` -- the very function `bench.py --gpus N` times: one all-reduce per step of one
+    persistent buffer carrying forces and energies; the result equals the reference's golden vectors."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker_local, args=(r, 4, port, q)) for r in range(4)]
+    port = 31500 + (os.getpid() + 37 * world) % 2000
+    procs = [ctx.Process(target=_worker_local, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     de, df, stats, n = q.get(timeout=300)
@@ -71,7 +86,7 @@ def test_four_rank_compact_shards_match_reference():
         assert p.exitcode == 0
     assert de < 1e-8 and df < 1e-8
     assert sum(s[0] for s in stats) == n and sum(s[2] for s in stats) == 192  # blocks partition atoms and edges
-    assert all(s[0] > 0 and s[0] + s[1] <= n for s in stats)
+    assert all(s[0] > 0 and s[0] + s[1] <= n for s in stats) and len(stats) == world
 
 
 def test_two_rank_sharding_matches_reference():

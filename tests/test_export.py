@@ -49,11 +49,18 @@ def test_native_op_has_no_cpu_kernel():
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,dtype,tol", [("c2", torch.float32, 5e-5), ("c1_L2", torch.float32, 5e-5), ("t_peredge", torch.float64, 1e-9),
                                             ("c2_spline", torch.float32, 5e-5)])
-def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol):
+def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol, forward_mode):
     dev = torch.device("cuda:0")
     fx, m, data, sv, ex = _exportable(name, dtype, dev)
     ref = fx["out"]
     perm = torch.randperm(data["edge_index"].shape[1], generator=torch.Generator().manual_seed(1)).to(dev)
+    # the op's virial directly against the ORACLE's strain derivative (autograd through strained positions + shifts)
+    from oracle import restatement as R
+
+    cfg64 = dict(fx["cfg"], model_dtype="float64")
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in fx["sd"].items()}
+    wref = R.allegro_virial(cfg64, sd64, fx["pos"].double(), fx["edge_index"], fx["types"],
+                            None if fx["shift_vec"] is None else fx["shift_vec"].double())
     for ei, s in ((data["edge_index"], sv), (data["edge_index"][:, perm], None if sv is None else sv[perm])):
         e_atom, e_tot, f, vir = ex(data["pos"], ei, data["atom_types"], s)
         # virial = -dE/d(strain), checked against the model's own strain derivative (itself pinned to the oracle's
@@ -62,6 +69,8 @@ def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol):
         m.energy_forces(data["pos"], g)
         w = m.virial(g)
         assert vir.shape == (1, 3, 3)
+        do = (vir[0].double().cpu() + wref).abs().max().item()
+        assert do <= tol * max(1.0, float(wref.abs().max())), f"virial: native op {vir[0].tolist()} vs oracle {(-wref).tolist()} (max diff {do:.3e})"
         dv = (vir[0] + w).abs().max().item()
         assert dv <= tol * max(1.0, float(w.abs().max())), f"virial: native op {vir[0].tolist()} vs model {(-w).tolist()} (max diff {dv:.3e})"
         for what, got, want in (("energies", e_atom.cpu().reshape(-1), ref["atomic_energy"].reshape(-1)), ("forces", f.cpu(), ref["forces"])):

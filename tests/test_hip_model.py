@@ -21,13 +21,18 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run(fx, dtype, dev):
-    m = model_from_fixture(fx, dtype, device=dev)
-    data, sv = fixture_data(fx, dtype, dev)
-    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
-    e, f = m.energy_forces(data["pos"], g)
-    torch.cuda.synchronize()
-    return m, g, e.cpu(), f.cpu()
+@pytest.fixture(autouse=True)
+def _both_forwards(forward_mode):
+    """Every test of this module runs through the default (automatic: fused per-atom-tile forward wherever the graph
+    allows) AND through the staged pipeline (tests/conftest.py: forward_mode)."""
+    return forward_mode
+
+
+def _launches(m, g, pos):
+    """Kernel symbols of one step (aa_model_energy_forces_profiled)."""
+    import bench
+
+    return [st[0] for st in bench.profile_stages(m, pos, g, reps=1)]
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
@@ -392,16 +397,24 @@ def test_graph_without_edges_gives_shifts_and_zero_forces(dtype, dev):
 
 
 @pytest.mark.parametrize("name,dtype,tol", [("t_coupled", torch.float64, 1e-9), ("c5_small", torch.float64, 1e-9),
-                                            ("c2", torch.float32, 5e-5)])
-def test_virial_matches_oracle_strain_derivative(name, dtype, tol, dev):
+                                            ("c2", torch.float32, 5e-5), ("c1_L2", torch.float32, 5e-5),
+                                            ("c2_spline", torch.float32, 5e-5)])
+def test_virial_matches_oracle_strain_derivative(name, dtype, tol, dev, forward_mode):
     """aa_model_virial (strain derivative, stress * volume) vs autograd through the oracle with strained positions and
-    shifts; also identical for the gather and the atomic force layouts, and symmetric."""
+    shifts; also identical for the gather and the atomic force layouts, and symmetric.  `c2`, `c1_L2` (channel-padded)
+    and `c2_spline` take the fused forward in "auto" mode (asserted on the launch list): the virial reads the unit
+    vectors that kernel leaves in the workspace."""
     from oracle import restatement as R
     from allegro_amd.nn import PreparedGraph
 
     fx = load_model_fixture(name, dtype)
     m, g, _, _ = _run(fx, dtype, dev)
     w = m.virial(g).cpu()
+    if dtype == torch.float32:
+        names = _launches(m, g, fixture_data(fx, dtype, dev)[0]["pos"])
+        assert ("fused_fwd" in names) == (forward_mode == "auto"), names
+        m.energy_forces(fixture_data(fx, dtype, dev)[0]["pos"], g)
+        assert torch.equal(m.virial(g).cpu(), w)  # bit-reproducible (fixed summation order)
     cfg = dict(fx["cfg"])
     cfg["model_dtype"] = "float64"
     sd = {k: (v.double() if v.is_floating_point() else v) for k, v in fx["sd"].items()}

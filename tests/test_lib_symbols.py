@@ -26,6 +26,15 @@ def test_library_exports_every_declared_symbol():
     assert lib.aa_version() >= 1
 
 
+def test_package_ships_the_public_header():
+    # pyproject package-data: an installed copy rebuilds itself from allegro_amd/csrc + allegro_amd/include alone
+    from allegro_amd.build import INCLUDE_DIR
+
+    pub = open(os.path.join(ROOT, "include", "allegro_amd.h"), "rb").read()
+    assert open(os.path.join(INCLUDE_DIR, "allegro_amd.h"), "rb").read() == pub
+    assert '"include/*.h"' in open(os.path.join(ROOT, "pyproject.toml")).read()
+
+
 def test_ctypes_structs_match_header_sizes():
     # layout sanity of the ctypes mirrors (pointer-heavy structs: check field counts against the header)
     assert ctypes.sizeof(_lib.TpDesc) == 7 * 4 + 4 + 5 * 8  # 7 int32 + pad + 5 pointers

@@ -249,3 +249,43 @@ def test_op_traces_under_torch_compile_fullgraph():
     got = torch.autograd.grad(y2, [x1, x2])
     assert torch.equal(y.detach(), y2.detach())
     assert all(torch.equal(a, b) for a, b in zip(want, got))
+
+
+@pytest.mark.parametrize("assume_sorted", [False, True])
+def test_contracter_forward_itself_traces_under_export_and_compile(assume_sorted):
+    """`HipContracter.forward` -- not just the op behind it -- must be traceable: the segment bookkeeping
+    (bincount / cumsum / sort of the scatter index, the address-keyed cache) is one opaque op with a fake kernel under
+    tracing (allegro_amd::segments), so torch.export and torch.compile(fullgraph=True) capture the module as the
+    reference's accelerated contracters are captured by `nequip-compile` (_flashallegro.py:725-755).  Random
+    (unsorted) and sorted scatter indices, as in tests/nn/test_contract_kernels.py:95-97."""
+    c = _contracter().eval()
+    c.assume_sorted_idxs = assume_sorted
+    E, N = 13, 4
+    g = torch.Generator().manual_seed(4)
+    x1 = torch.randn(E, 4, 9, dtype=torch.float64, generator=g)
+    x2 = torch.randn(E, 4, 9, dtype=torch.float64, generator=g)
+    idxs = torch.randint(0, N, (E,), generator=g)
+    if assume_sorted:
+        idxs = torch.sort(idxs)[0]
+    want = c(x1, x2, idxs, N)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = c
+
+        def forward(self, a, b, i):
+            return self.c(a, b, i, N)
+
+    ep = torch.export.export(Wrap(), (x1, x2, idxs))
+    targets = [str(n.target) for n in ep.graph.nodes if n.op == "call_function"]
+    assert any("allegro_amd.segments" in t for t in targets) and any("allegro_amd.tp_forward" in t for t in targets), targets
+    assert torch.equal(ep.module()(x1, x2, idxs), want)
+    # other index values through the SAME program (nothing about the traced indices was baked in)
+    idxs2 = torch.randint(0, N, (E,), generator=g)
+    if assume_sorted:
+        idxs2 = torch.sort(idxs2)[0]
+    assert torch.equal(ep.module()(x1, x2, idxs2), c(x1, x2, idxs2, N))
+    fc = torch.compile(Wrap(), backend="aot_eager", fullgraph=True)
+    assert torch.equal(fc(x1, x2, idxs), want)
+    torch.library.opcheck(torch.ops.allegro_amd.segments, (idxs, N, assume_sorted), test_utils=("test_schema", "test_faketensor"))
