@@ -41,7 +41,7 @@ class PlanOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "tp_generic", "tp_no_chain", "tp_no_moments", "tp_no_operator", "tp_force_operator", "tp_operator_fused",
         "gemm_no_chain", "gemm_fp32_mfma", "gemm_valu", "gemm_v1", "gemm_lds_epilogue", "f64_column_loop",
-        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "tp_mfma", "f64_rows", "chain_tp", "no_channel_padding", "poison_workspace")]
+        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "f64_rows", "no_channel_padding", "poison_workspace")]
 
 
 def options_from_env() -> PlanOptions:
@@ -57,11 +57,9 @@ def options_from_env() -> PlanOptions:
     o.gemm_lds_epilogue = int(env.get("AA_GEMM_DIRECT_EPILOGUE", "1")[:1] == "0")
     o.f64_column_loop = {"0": 1, "2": 2}.get(env.get("AA_F64_NLOOP", "1")[:1], 0)
     o.embed_no_fuse = flag("AA_EMBED_NOFUSE")
-    o.fused_forward = {"0": 3, "1": 1, "2": 2}.get(env.get("AA_FUSED", "")[:1], 0)  # unset: automatic (small graphs)
+    o.fused_forward = {"0": 3, "1": 1}.get(env.get("AA_FUSED", "")[:1], 0)  # unset: whenever the graph allows
     o.fused_recompute_w0 = flag("AA_FUSED_RECOMPUTE")
     o.moments_waves_per_block = int(env.get("AA_MOM_WPB", "0") or 0)
-    o.tp_mfma = {"1": 1, "0": 2}.get(env.get("AA_TP_MFMA", "")[:1], 0)
-    o.chain_tp = flag("AA_CHAIN_TP")
     o.no_channel_padding = flag("AA_NO_PAD")
     o.poison_workspace = flag("AA_POISON")  # debugging: NaN-filled workspace before every step
     o.f64_rows = {"0": 2, "2": 1}.get(env.get("AA_F64_ROWS", "")[:1], 0)  # 0: off, 2: wherever applicable

@@ -218,11 +218,6 @@ struct ChainLayer {
                        // reverse of the two-body basis expansion folded into the epilogue (C itself need not be stored)
   void* edge_sum_out;  // [M] or nullptr: out[e] = sum_c silu(C[e,c]) * ro_w[c] of this (64-wide) layer -- the last linear
                        // readout layer folded into the epilogue, so the edge sum reads 4 B/edge instead of a row
-  // tensor-track scalars evaluated where w0 is produced (ChainArgs.tp_*): output tiles from index tp_from1 - 1 on are the
-  // irreps of w0[e][r][64] in pairs; after each pair  sc[e][ch] += w0[e][r][ch] * sum_{a in r} Y[e][a] B[center(e)][a][ch]
-  // is accumulated into a second kept tile pair (zero at kernel start).  Encoded as first tile index + 1; 0 = no such tiles.
-  int tp_from1;
-  int use_sc;          // append that pair as the last two k chunks (after the use_prev chunks)
 };
 struct ChainArgs {
   int64_t M;
@@ -236,11 +231,6 @@ struct ChainArgs {
   const int32_t* nbr;       // embrev_out extras
   const void* emb_table;    // [T*T][8][64]: type_embed(c | pair) * basis_linear[n][c]  (_edgeembed.py:70-84)
   int num_types;
-  // tensor-track scalars (ChainLayer.tp_from1): harmonics [M, tp_ld_sh] and the per-atom Clebsch-Gordan vectors
-  // B [N][tp_D][64] of the layer (tp_mom_fwd_* with TpMomArgs.bvec_out), gathered by center[e]; tp_D <= 9
-  const void* tp_sh;
-  int tp_ld_sh, tp_D;
-  const void* tp_bvec;
 };
 int launch_gemm_chain(const ChainArgs& c, hipStream_t stream);  // fp32 only
 // element count of the fragment-ordered copy of a [K,N] matrix, and the host-side packer
@@ -440,31 +430,9 @@ struct TpMomArgs {
   const void* wt1;
   void* g_a;            // reverse kernels: grad wrt the env input of the layer being reversed [E, ld_ga]
   int ld_ga;
-  void* bvec_out;       // forward kernels: when set, write the layer's per-atom vector B [N][D][64] (scal[e] = <x1[e], B>) and
-                        // SKIP the per-edge scalars -- the linear-layer chain that produces w0 evaluates them (ChainArgs.tp_*)
   int ka_lds;           // row stride of the wave-private moment patch in LDS (set by the launcher: max(ka0, ka1))
   int waves_per_block;  // 0 = 1 (aa_plan_options.moments_waves_per_block)
 };
-// Moments kernels with the first-layer x1 weights w0 = EDGE_EMBEDDING @ Wg recomputed on the matrix cores instead of
-// re-read from HBM (aa_tp_mfma.hip; fp32, u = S = latent width = 64, l_max <= 2)
-struct TpMfmaArgs {
-  int64_t N, atom0;      // atoms [atom0, N) are processed
-  const int32_t* rowptr;
-  const float* sh;       // [E, ld_sh]
-  int ld_sh;
-  const float* emb;      // [E,64] EDGE_EMBEDDING
-  const float* a;        // [E,64] env input of the layer (first: the embedding; last: pre-activation of latent 0's hidden layer, silu applied)
-  const float* wk;       // Wenv of the layer as [64][R][64] (alpha folded)
-  const void* wq;        // bf16x3 fragments of Wg's w0 columns: [2R tiles][2 chunks][64 lanes][24 words]
-  const float *tpw0, *tpw1;  // path weights
-  int coupling;
-  float sf;              // 1/sqrt(avg_num_neighbors)
-  float* x2s0;           // [N][D][64]: written by the first layer, read by the last
-  float* x2s1;           // written by the last layer
-  float* scal;           // [E,64] the layer's tensor-track scalars
-};
-int launch_tp_mfma_fwd(int pair, bool last, const TpMfmaArgs& a, hipStream_t stream);
-
 // Per-atom operator form of the tensor-product track for L <= 3 layers, u = 64*m (aa_tp_op.hip)
 struct TpOpArgs {
   int64_t N, E;          // atoms [atom0, N) are processed
@@ -565,11 +533,7 @@ struct FusedFwdArgs {
 };
 int fused_fwd_num_steps(int R, bool hold_w0);
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
-// 16-edge-tile form (aa_fused16.hip; two waves per atom, two waves per SIMD): same arguments, its own weight packing
-int launch_fused16_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
-// bf16x3 fragments for v_mfma_f32_16x16x32_bf16: [N/64 groups][K/32 chunks][4 tiles x 3 levels][64 lanes][4 words];
-// same word count as gemm_bf16x3_words(K, N); K multiple of 32, N multiple of 64
-void gemm_pack_bf16x3_16(const float* B, int K, int N, unsigned* out);
+
 
 // ----------------------------------------------------------------------------------------------
 // edge prologue / epilogue / readout reduce

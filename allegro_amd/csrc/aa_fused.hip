@@ -63,10 +63,6 @@ struct FusedPipe {
 };
 
 __device__ __forceinline__ void lds_barrier() {
-#ifdef AA_EXP_SYNC
-  __syncthreads();
-  return;
-#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
@@ -158,11 +154,7 @@ template <int S0, int NS, int KC, int NT, class OpF, class EpiF>
 __device__ __forceinline__ void fused_layer(const FusedFwdArgs& A, FusedPipe& p, OpF&& op, EpiF&& epi) {
   static_assert(NT % 2 == 0, "output tiles come in pairs");
   constexpr bool PRE = NT > 2;
-#ifdef AA_EXP_NOPIPE
-  constexpr bool PIPE = false;
-#else
   constexpr bool PIPE = true;
-#endif
   XSplit xs[PRE ? KC : 2];
   if constexpr (PRE) {
     static_for<0, KC>([&](auto kc) {
@@ -202,11 +194,7 @@ __device__ __forceinline__ void fused_layer(const FusedFwdArgs& A, FusedPipe& p,
 // A tile pair parked in LDS in accumulator layout ([q][lane] 16-B cells: conflict-free b128 accesses).  The two-body
 // scalars and lat0 are operands of three / two later layers; parking them frees 64 registers per lane for the whole
 // second half of the kernel (the kernel runs one wave per SIMD, LDS is plentiful).
-#ifdef AA_EXP_OCC2
-constexpr int kFusedOcc = 2;
-#else
-constexpr int kFusedOcc = 1;
-#endif
+constexpr int kFusedOcc = 1;  // one workgroup per CU: the kernel needs the whole register file and most of the LDS
 __device__ __forceinline__ void park_tile(float* slot, const v16f& t, int lane) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(slot + (q * 64 + lane) * 4) = v4f{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
@@ -342,15 +330,9 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   float* sY = sW + kWaveRegion;                                        // ... and the harmonics of the tile [32][kLdY]
   float* sBv = sW + kOffB;
   // parked tiles of this wave: two-body scalars (2 tiles) and lat0 (2 tiles)
-#ifdef AA_EXP_OCC2
-  v16f pk[4];  // (occupancy-2 experiment: "parked" tiles stay in registers / compiler-managed scratch)
-#define AA_PARK(i, t) pk[i] = t
-#define AA_FETCH(i) pk[i]
-#else
   float* sPark = sTab + ntab + 4 * (kWaveRegion + 32 * kLdY) + wv * 4 * kTileFloats;
 #define AA_PARK(i, t) park_tile(sPark + (i) * kTileFloats, t, lane)
 #define AA_FETCH(i) fetch_tile(sPark + (i) * kTileFloats, lane)
-#endif
   for (int i = tid; i < 64; i += 256) sRo[i] = A.ro_w[i];
   if (tid < A.num_types * A.num_types) sRm[tid] = A.rmax_recip[tid];
   if (tid >= 16 && tid < 24) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 16] : 0.f;
@@ -598,10 +580,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                     tile_store_rows(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
                                   }
                                 });
-#ifndef AA_EXP_NOGEO
     // inputs of the next tile (its neighbor ids arrived long ago): positions, shifts, types
     load_geo(atom_of(it + 1), nxt);
-#endif
     AA_TICK(9)
     // ---- L5: layer-1 scalars with B1 -- from the held w0 tiles, or from w0 recomputed out of the embedding
 #pragma unroll
@@ -677,14 +657,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                 });
     AA_TICK(13)
     // rotate the prefetched inputs
-#ifdef AA_EXP_NOGEO
-    cur.beg = nxt.beg;
-    cur.cnt = nxt.cnt;
-    cur.j = nxt.j;
-    load_geo(atom_of(it + 1), cur);
-#else
     cur = nxt;
-#endif
     nxt.beg = beg2;
     nxt.cnt = cnt2;
   }
@@ -729,21 +702,10 @@ int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t 
     AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));              \
     hipLaunchKernelGGL((fused_fwd_kernel<cg::S0_, cg::S1_, H_>), grid, dim3(256), smem, stream, a);            \
   }
-#ifdef AA_EXP_ONE
-  if (pair == 1 && !hold_w0) {
-    AA_FUSED_LAUNCH(Sig5, Sig4, false)
-  } else if (pair == 1) {
-    AA_FUSED_LAUNCH(Sig5, Sig4, true)
-  } else {
-    return fail(AA_ERR_INVALID, "experiment build");
-  }
-  if (false) {
-#else
   if (pair == 0) {
     if (hold_w0) AA_FUSED_LAUNCH(Sig1, Sig0, true) else AA_FUSED_LAUNCH(Sig1, Sig0, false)
   } else if (pair == 1) {
     if (hold_w0) AA_FUSED_LAUNCH(Sig5, Sig4, true) else AA_FUSED_LAUNCH(Sig5, Sig4, false)
-#endif
   } else {
     return fail(AA_ERR_INVALID, "fused forward: unsupported signature pair");
   }

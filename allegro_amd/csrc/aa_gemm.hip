@@ -1114,7 +1114,7 @@ struct ChainLayerDev {
   const u32x4* Wq;
   int KCg, KC, NT;  // k chunks from global memory, total k chunks (+2 chained), output tiles
   int keep_tile, keep_act, a_mode, pad_;
-  int tp_from1, use_prev, use_sc, pad2_;
+  int use_prev, pad2_;
   float* edge_sum_out;
   float* embrev_out;
   const float* a[kChainMaxBlocks];
@@ -1133,9 +1133,6 @@ struct ChainDev {
   const int32_t* nbr;
   const float* emb_table;  // [T*T][8][64] or nullptr
   int num_types;
-  const float* tp_sh;      // tensor-track scalars (TPX): harmonics [M, tp_ld_sh], per-atom vectors [N][tp_D][64]
-  const float* tp_bvec;
-  int tp_ld_sh, tp_D;
   ChainLayerDev L[4];
 };
 
@@ -1152,9 +1149,7 @@ constexpr int kEpLd = 36;          // row stride (floats) of the store-transpose
 // such layers runs at 3 waves/SIMD and the one with them at 2.
 // EMB: the embrev_out epilogue (reverse of the two-body basis expansion) is compiled in; only the last reverse chain
 // of a step uses it, and it costs registers the other chains should not pay for.
-// TPX: the tensor-track scalars are evaluated behind the tile pairs that produce w0 (chain_tp_accumulate) into a second
-// kept tile pair that later layers consume like the first (ChainLayer.tp_from1 / use_sc); implies PRE.
-template <bool PRE, bool EMB, bool TPX>
+template <bool PRE, bool EMB>
 __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(ChainDev c) {
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);  // [2][kWStep]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1168,19 +1163,6 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
   for (int r = 0; r < 16; ++r) {
     kept0[r] = 0.f;
     kept1[r] = 0.f;
-  }
-  v16f sc0, sc1;  // (TPX) the tensor-track scalars of the row
-  float Yh[TPX ? 9 : 1];
-  const float* tp_bb = nullptr;
-  if constexpr (TPX) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sc0[r] = 0.f;
-      sc1[r] = 0.f;
-    }
-#pragma unroll
-    for (int m = 0; m < 9; ++m) Yh[m] = (m < c.tp_D && row_ok) ? c.tp_sh[gmc * c.tp_ld_sh + m] : 0.f;
-    tp_bb = c.tp_bvec + int64_t(c.center[gmc]) * c.tp_D * 64 + 4 * hh;
   }
   float rofac = c.ro_factor;  // readout-reverse transform factor of this row
   if (c.ro_scales) rofac *= c.ro_scales[c.types[c.center[gmc]]];
@@ -1228,20 +1210,13 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
       }
     }
   };
-  // chained chunk j of a layer: the kept pair (use_prev) first, then the tensor-track scalars (use_sc)
+  // chained chunk j of a layer: the kept pair (use_prev)
   auto kept_a = [&](const ChainLayerDev& L, int j, v4f* a) {
-    const bool from_sc = TPX && L.use_sc && (!L.use_prev || j >= 2);
     const bool first = (j & 1) == 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = first ? kept0[4 * q + e] : kept1[4 * q + e];
-        if constexpr (TPX) {
-          if (from_sc) v = first ? sc0[4 * q + e] : sc1[4 * q + e];
-        }
-        a[q][e] = v;
-      }
+      for (int e = 0; e < 4; ++e) a[q][e] = first ? kept0[4 * q + e] : kept1[4 * q + e];
   };
   // 24 MFMAs of one step; weight levels are read from LDS just in time (level l is reused by 3-l products)
   auto mma_step = [&](int b, const u32x4* x1, const u32x4* x2, const u32x4* x3, v16f& acc0, v16f& acc1) {
@@ -1452,17 +1427,6 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
       }
       epilogue(L.t[nt], acc0);
       if (two) epilogue(L.t[nt + 1], acc1);
-      if constexpr (TPX) {
-        if (L.tp_from1 > 0 && nt >= L.tp_from1 - 1) {  // (wave-uniform) this pair is irrep r of w0
-          const int r = (nt - (L.tp_from1 - 1)) >> 1;
-          if (r == 0)
-            tile_scal_accumulate<0>(tp_bb, Yh, acc0, acc1, sc0, sc1);
-          else if (r == 1)
-            tile_scal_accumulate<1>(tp_bb, Yh, acc0, acc1, sc0, sc1);
-          else
-            tile_scal_accumulate<2>(tp_bb, Yh, acc0, acc1, sc0, sc1);
-        }
-      }
       if (EMB && L.embrev_out) {  // (64-wide layer: this is its only tile pair)
         float part[8];
 #pragma unroll
@@ -1528,12 +1492,8 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
   if (c.emb_table && (c.num_types < 1 || c.num_types > 2 || !c.types || !c.center || !c.nbr))
     return fail(AA_ERR_INVALID, "gemm chain: the embedding table needs 1..2 types and the edge / type arrays");
   if (c.nlayers < 1 || c.nlayers > 4) return fail(AA_ERR_INVALID, "gemm chain: 1..4 layers");
-  bool have_kept = false, any_tp = false;
+  bool have_kept = false;
   static_assert(sizeof(ChainDev) <= 4096, "kernel argument block too large");
-  d.tp_sh = static_cast<const float*>(c.tp_sh);
-  d.tp_bvec = static_cast<const float*>(c.tp_bvec);
-  d.tp_ld_sh = c.tp_ld_sh;
-  d.tp_D = c.tp_D;
   for (int li = 0; li < c.nlayers; ++li) {
     const ChainLayer& L = c.L[li];
     const GemmArgs& g = L.g;
@@ -1576,25 +1536,16 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
       }
       nc += sg.n;
     }
-    if (ka + (L.use_prev ? 64 : 0) + (L.use_sc ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
+    if (ka + (L.use_prev ? 64 : 0) != g.K || nc != g.N || !g.Bq) return fail(AA_ERR_INVALID, "gemm chain: bad layer shape");
     // (a layer that chains from the kept pair may only replace it behind its last tile pair; one that does not may keep any pair)
     if (L.keep_tile >= 0 && ((L.keep_tile & 1) || L.keep_tile * 32 + 64 > g.N || (L.use_prev && L.keep_tile * 32 + 64 != g.N)))
       return fail(AA_ERR_INVALID, "gemm chain: the kept 64 features must be a tile pair (the last one of a layer that chains)");
-    if (L.tp_from1 != 0 || L.use_sc) {
-      any_tp = true;
-      const int t0 = L.tp_from1 - 1;
-      if (L.tp_from1 < 0 || (L.tp_from1 > 0 && ((t0 & 1) || (g.N - 32 * t0) % 64 != 0 || (g.N - 32 * t0) / 64 > 3 || g.N - 32 * t0 <= 0)))
-        return fail(AA_ERR_INVALID, "gemm chain: tensor-track tiles must be whole 64-channel irreps (l_max <= 2) behind an even tile index");
-      if (!c.tp_sh || !c.tp_bvec || !c.center || c.tp_D < 1 || c.tp_D > 9) return fail(AA_ERR_INVALID, "gemm chain: tensor-track scalars need sh, bvec, center, D <= 9");
-    }
     if (L.use_prev && !have_kept) return fail(AA_ERR_INVALID, "gemm chain: nothing to chain from");
     have_kept = have_kept || L.keep_tile >= 0;  // (kept features stay available until a later layer replaces them)
     D.Wq = static_cast<const u32x4*>(g.Bq);
     D.KCg = nchunk;
-    D.KC = nchunk + (L.use_prev ? 2 : 0) + (L.use_sc ? 2 : 0);
-    D.tp_from1 = L.tp_from1;
+    D.KC = nchunk + (L.use_prev ? 2 : 0);
     D.use_prev = L.use_prev;
-    D.use_sc = L.use_sc;
     D.NT = ntile;
     D.keep_tile = L.keep_tile;
     D.keep_act = L.keep_act;
@@ -1618,11 +1569,8 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
                       (c.emb_table ? sizeof(float) * 512 * c.num_types * c.num_types : 0);
   bool emb = false;
   for (int li = 0; li < d.nlayers; ++li) emb = emb || d.L[li].embrev_out != nullptr;
-#define AA_CHAIN_LAUNCH(P_, E_) hipLaunchKernelGGL((gemm_chain_bf16x3_kernel<P_, E_, false>), grid, dim3(256), smem, stream, d)
-  if (any_tp) {
-    if (emb) return fail(AA_ERR_INVALID, "gemm chain: tensor-track scalars and embrev_out do not combine");
-    hipLaunchKernelGGL((gemm_chain_bf16x3_kernel<true, false, true>), grid, dim3(256), smem, stream, d);
-  } else if (any_pre) {
+#define AA_CHAIN_LAUNCH(P_, E_) hipLaunchKernelGGL((gemm_chain_bf16x3_kernel<P_, E_>), grid, dim3(256), smem, stream, d)
+  if (any_pre) {
     if (emb) AA_CHAIN_LAUNCH(true, true); else AA_CHAIN_LAUNCH(true, false);
   } else {
     if (emb) AA_CHAIN_LAUNCH(false, true); else AA_CHAIN_LAUNCH(false, false);
@@ -1666,41 +1614,6 @@ void gemm_pack_bf16x3(const float* B, int K, int N, unsigned* out) {
             for (int lv = 0; lv < 3; ++lv) o[size_t(lv * 2 + half) * 64 * 4 + q] = (h[lv][0] >> 16) | h[lv][1];
           }
       }
-}
-
-void gemm_pack_bf16x3_16(const float* B, int K, int N, unsigned* out) {
-  const int NQ = N / 64, KC = K / 32;
-  auto trunc = [](float x) {
-    unsigned u;
-    memcpy(&u, &x, 4);
-    return u & 0xFFFF0000u;
-  };
-  auto tof = [](unsigned u) {
-    float x;
-    memcpy(&x, &u, 4);
-    return x;
-  };
-  for (int q = 0; q < NQ; ++q)
-    for (int kc = 0; kc < KC; ++kc)
-      for (int t = 0; t < 4; ++t)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int n = 64 * q + 16 * t + (lane & 15), g = lane >> 4;
-          unsigned lv[3][8];
-          for (int e = 0; e < 8; ++e) {
-            // operand slot (g, e) of a chunk <-> accumulator register of the producing layer (aa_fused16.hip)
-            const int k = 32 * kc + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
-            const float x = B[size_t(k) * N + n];
-            lv[0][e] = trunc(x);
-            const float r = x - tof(lv[0][e]);
-            lv[1][e] = trunc(r);
-            const float r2 = r - tof(lv[1][e]);
-            lv[2][e] = trunc(r2);
-          }
-          for (int l = 0; l < 3; ++l) {
-            unsigned* o = out + ((((size_t(q) * KC + kc) * 12 + (t * 3 + l)) * 64 + lane) * 4);
-            for (int w = 0; w < 4; ++w) o[w] = (lv[l][2 * w] >> 16) | lv[l][2 * w + 1];
-          }
-        }
 }
 
 size_t gemm_packed_elems(int K, int N) { return size_t((N + 31) / 32) * size_t((K + 31) / 32) * 64 * 16; }

@@ -123,7 +123,6 @@ struct MlpLayout {
   std::vector<size_t> w, wt;    // blob offsets (elements) of W_i [d_i,d_{i+1}] and its transpose
   std::vector<size_t> wp, wtp;  // the same two matrices in MFMA fragment order (aa_gemm.hip v3)
   std::vector<size_t> wq, wtq;  // ... and split into 3 bf16 levels (bf16x3 path; fp32 plans only)
-  std::vector<size_t> wq16;     // W_i in the 16x16x32 fragment order of the 16-edge-tile fused forward (fused_mode 2)
 };
 
 struct aa_model_plan {
@@ -148,12 +147,7 @@ struct aa_model_plan {
   bool env_mom;                      // env weights through per-atom moments: no [E,R*u] env tensors (TpMomArgs / TpOpArgs)
   int tp_op;                         // >= 0: signature chain of the per-atom operator kernels (aa_tp_op.hip; any L <= 3, u = 64 m)
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
-  bool tp_mfma;                      // moments kernels recompute w0 on the matrix cores (aa_tp_mfma.hip)
-  bool chain_tp;                     // forward: the tensor-track scalars are evaluated inside the linear-layer chains that produce
-                                     // w0 (gemm_chain TPX); the moments kernels only form the per-atom vectors
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
-  int fused_mode;                    // 1: 32-edge tiles, one wave per atom; 2: 16-edge tiles, two waves per atom (aa_fused16.hip)
-  size_t o_g0q16;
   bool fused_hold_w0;                // ... holding the w0 tiles in registers between the two layers (else: recomputed)
   mutable bool taps = false;         // aa_model_plan_enable_taps: staged pipeline so that every tap is materialised
   bool embed_fused;                  // reverse pass: d(two-body embedding) [E,S0] never materialised, the last reverse chain
@@ -311,8 +305,6 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   p->o_basis = take(size_t(B) * S0);
   AA_REQUIRE(cfg->embed_kind == 0 || (cfg->embed_kind == 1 && cfg->spline_span >= 0 && cfg->spline_span <= B),
              "model: embed_kind must be 0 (Bessel) or 1 (spline, 0 <= span <= num_splines)");
-  const bool fused16 = true;  // (the 16-edge-tile copies are always part of the blob: its layout must not depend on fused_forward,
-                              //  a blob packed by one plan is consumed by plans created with other options -- the exported op)
   auto lay = [&](MlpLayout& m, const std::vector<int>& dims, int nlayers) {
     m.dims = dims;
     for (int i = 0; i < nlayers; ++i) {
@@ -322,7 +314,6 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
       m.wtp.push_back(take(gemm_packed_elems(dims[i + 1], dims[i])));
       m.wq.push_back(take(gemm_bf16x3_words(dims[i], dims[i + 1])));
       m.wtq.push_back(take(gemm_bf16x3_words(dims[i + 1], dims[i])));
-      m.wq16.push_back(fused16 && dims[i] % 32 == 0 && dims[i + 1] % 64 == 0 ? take(gemm_bf16x3_words(dims[i], dims[i + 1])) : 0);
     }
   };
   lay(p->embed, mlp_dims(S0, cfg->embed_mlp_depth, cfg->embed_mlp_width, S), cfg->embed_mlp_depth + 1);
@@ -339,7 +330,6 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   p->o_g0tp = take(gemm_packed_elems(p->ng0, S));
   p->o_g0q = take(gemm_bf16x3_words(S, p->ng0));
   p->o_g0tq = take(gemm_bf16x3_words(p->ng0, S));
-  p->o_g0q16 = (fused16 && S % 32 == 0 && p->ng0 % 64 == 0) ? take(gemm_bf16x3_words(S, p->ng0)) : 0;
   if (p->env_mom) {
     for (int l = 0; l < L; ++l) {
       const size_t ka = l == 0 ? S : cfg->latent_mlp_width;
@@ -378,24 +368,16 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   p->o_shifts = take(T);
   p->n_elems = o;
   {
-    // fused per-atom-tile forward (aa_fused.hip / aa_fused16.hip): the standard 2-layer 64-wide fp32 stack with the
+    // fused per-atom-tile forward (aa_fused.hip): the standard 2-layer 64-wide fp32 stack with the
     // two-body table in LDS; same parity tests as the staged pipeline.  With the tensor-track scalars accumulated in
     // anchored program order (aa::anchor -- the kernel used to carry 70-350 spilled VGPRs) the 32-edge-tile form beats the
     // staged forward at every size on MI355X: 22-24 % of the step on 64-1000 atoms (one launch instead of seven), 9 % at
     // 4096, 4.5 % at 10 648, 0.5 % at 97 336 atoms, and it moves 2.1 instead of 7.3 KB/edge (profiles/r02_v23_fused_sweep.log).
-    // aa_plan_options.fused_forward: 0 = automatic (32-edge tiles whenever the graph allows: max_degree <= 32), 1 / 2 = the
-    // 32- / 16-edge-tile form explicitly, 3 = never (staged pipeline).
+    // aa_plan_options.fused_forward: 0 / 1 = whenever the graph allows (max_degree <= 32), 3 = never (staged pipeline).
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
                           u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0;
     p->fused_fwd = eligible && opt.fused_forward != 3;
-    p->fused_mode = opt.fused_forward == 2 ? 2 : 1;
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
-    // moments kernels with w0 recomputed on the matrix cores (aa_tp_mfma.hip): same stack, no table requirement
-    p->chain_tp = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                  u == 64 && S == 64 && cfg->latent_mlp_width == 64 && cfg->embed_mlp_width == 64 && cfg->readout_mlp_width == 64 &&
-                  opt.chain_tp == 1;
-    p->tp_mfma = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                 u == 64 && S == 64 && cfg->latent_mlp_width == 64 && opt.tp_mfma == 1;
   }
   *out = p;
   return AA_OK;
@@ -452,7 +434,7 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
   auto mixm = [&](const MlpLayout& m) {
     mix(m.dims.size());
     for (int d : m.dims) mix(uint64_t(d));
-    mixv(m.w); mixv(m.wt); mixv(m.wp); mixv(m.wtp); mixv(m.wq); mixv(m.wtq); mixv(m.wq16);
+    mixv(m.w); mixv(m.wt); mixv(m.wp); mixv(m.wtp); mixv(m.wq); mixv(m.wtq);
   };
   const aa_model_config& c = p->cfg;
   for (uint64_t v : {uint64_t(c.dtype), uint64_t(c.num_types), uint64_t(c.num_bessels), uint64_t(c.l_max), uint64_t(c.num_layers),
@@ -462,7 +444,7 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
                      uint64_t(p->n_elems)})
     mix(v);
   for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
-                   p->o_g0q16, p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab})
+                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab})
     mix(v);
   for (int l = 0; l < c.num_layers; ++l) {
     mix(p->o_tpw[l]);
@@ -710,18 +692,6 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       }
     };
     split_mlp(p->embed, c.embed_mlp_depth + 1);
-    {
-      auto split16 = [&](size_t w_off, int K, int N, size_t q_off) {
-        if (q_off) gemm_pack_bf16x3_16(&hf[w_off], K, N, reinterpret_cast<unsigned*>(&hf[q_off]));
-      };
-      auto split16_mlp = [&](const MlpLayout& m, int nlayers) {
-        for (int i = 0; i < nlayers; ++i) split16(m.w[i], m.dims[i], m.dims[i + 1], m.wq16[i]);
-      };
-      split16_mlp(p->embed, c.embed_mlp_depth + 1);
-      split16(p->o_g0, S, p->ng0, p->o_g0q16);
-      for (int l = 0; l < L; ++l) split16_mlp(p->latent[l], c.latent_mlp_depth + 1);
-      split16_mlp(p->readout, c.readout_mlp_depth);
-    }
     splitw(p->o_g0, S, p->ng0, p->o_g0q);
     splitw(p->o_g0t, p->ng0, S, p->o_g0tq);
     for (int l = 0; l < L; ++l) split_mlp(p->latent[l], c.latent_mlp_depth + 1);
@@ -762,7 +732,6 @@ struct Workspace {
   size_t lat_h[AA_MAX_LAYERS][AA_MAX_MLP_LAYERS], g_lat_h[AA_MAX_MLP_LAYERS];
   size_t ro_h[AA_MAX_MLP_LAYERS], g_ro_h[AA_MAX_MLP_LAYERS];
   size_t g_tf[2];
-  size_t bvec[2];  // chain_tp: per-atom Clebsch-Gordan vectors of the two layers [N][D][u]
   size_t total;
 };
 
@@ -810,10 +779,6 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   }
   for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
   if (p->chain_gemm) w.e_edge = take(Ez);
-  if (p->chain_tp) {
-    w.bvec[0] = take(Nz * u * p->D);
-    w.bvec[1] = take(Nz * u * p->D);
-  }
   if (p->embed_fused) w.trev = take(Ez * 8);
   if (with_forces) {
     w.dvec = take(Ez * 4);
@@ -1243,28 +1208,6 @@ struct Runner {
       }
     };
     const bool hold = p->fused_hold_w0;
-    if (p->fused_mode == 2) {
-      // 16-edge-tile kernel: one contiguous 12-KB block per (64-feature group, chunk) of the 16x16x32-ordered copies
-      auto add16 = [&](const float* Wq, int KC, int q0, int nq) {
-        for (int q = q0; q < q0 + nq; ++q)
-          for (int kc = 0; kc < KC; ++kc) {
-            a.wstep[ns][0] = Wq + (size_t(q) * KC + kc) * 3072;
-            a.wstep[ns][1] = Wq + (size_t(q) * KC + kc) * 3072 + 1536;
-            ++ns;
-          }
-      };
-      add16(wf(p->embed.wq16[0]), 2, 0, 1);
-      add16(wf(p->embed.wq16[1]), 2, 0, 1);
-      add_env(wf(p->o_wk[0]));
-      add16(wf(p->o_g0q16), 2, 0, 1 + p->R);
-      add16(wf(p->latent[0].wq16[0]), 4, 0, 1);
-      add_env(wf(p->o_wk[1]));
-      add16(wf(p->latent[0].wq16[1]), 2, 0, 1);
-      if (!hold) add16(wf(p->o_g0q16), 2, 1, p->R);
-      add16(wf(p->latent[1].wq16[0]), 6, 0, 1);
-      add16(wf(p->latent[1].wq16[1]), 2, 0, 1);
-      add16(wf(p->readout.wq16[0]), 6, 0, 1);
-    } else {
     add_layer(wf(p->embed.wq[0]), 2, 0, 2);
     add_layer(wf(p->embed.wq[1]), 2, 0, 2);
     add_env(wf(p->o_wk[0]));
@@ -1276,7 +1219,6 @@ struct Runner {
     add_layer(wf(p->latent[1].wq[0]), 6, 0, 2);
     add_layer(wf(p->latent[1].wq[1]), 2, 0, 2);
     add_layer(wf(p->readout.wq[0]), 6, 0, 2);
-    }
     if (ns != fused_fwd_num_steps(p->R, hold) || ns > kFusedMaxSteps) return fail(AA_ERR_INVALID, "fused forward: program length mismatch");
     a.tpw0 = wf(p->o_tpw[0]);
     a.tpw1 = wf(p->o_tpw[1]);
@@ -1299,8 +1241,7 @@ struct Runner {
     a.x2s1 = bf(w.x2s[1]);
     a.atom_energy = static_cast<float*>(atom_energy);
     if (int rc = mark("begin")) return rc;
-    if (p->fused_mode == 2 && p->cfg.l_max > 2) return fail(AA_ERR_INVALID, "fused forward (16-edge tiles): l_max <= 2");
-    if (int rc = p->fused_mode == 2 ? launch_fused16_fwd(p->chain_pair, hold, a, stream) : launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
+    if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
     // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;
     // position, two x2s blocks, energy, row pointer per atom.  Flops: the linear layers of the forward (w0 counted once).
     const double per_edge = 1 + (g->shift_vec ? 3 : 0) + 3 + 4 + p->D + 5 * 64 + p->W;
@@ -1309,86 +1250,10 @@ struct Runner {
     return mark("fused_fwd", per_edge, per_atom, fl);
   }
 
-  // forward with the tensor-track scalars evaluated inside the chains (plan->chain_tp):
-  //   prologue | emb0 -> h_e -> emb | moments 0 -> B0 | emb -> [two-body | w0 -> scal0] -> latent 0 | moments 1 -> B1 |
-  //   emb -> [w0 -> scal1] -> latent 1 -> readout hidden layer + edge sum | reduce
-  // w0 is still stored once (the reverse pass reads it); scal0 / scal1 never exist in HBM.
-  int forward_chain_tp(const aa_graph* g, const void* pos, void* atom_energy) {
-    const aa_model_config& c = p->cfg;
-    const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
-    if (int rc = mark("begin")) return rc;
-    const double idx2 = 8.0 / sizeof(T);
-    if (int rc = launch_edge_prologue<T>(geom(g, pos), stream)) return rc;
-    if (int rc = mark("edge_prologue", idx2 + 6 + (g->shift_vec ? 3 : 0) + 4 + p->D + c.embed_dim)) return rc;
-    const SegList none{0, {}};
-    {
-      ChainArgs ca{};
-      ca.nlayers = 2;
-      SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
-      SegList c0{1, {seg(buf(w.se_h[0]), 64, 64)}};
-      SegList c1{1, {seg(buf(w.emb), S, S)}};
-      ca.L[0] = chain_layer(E, in, 0, wt(p->embed.wq[0]), c.embed_dim, 64, c0, nullptr, nullptr, nullptr, 0, 0, 1);
-      ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wq[1]), 64, S, c1, nullptr, nullptr, nullptr, 1, -1, 0);
-      if (int rc = run_chain(ca, "F1a")) return rc;
-    }
-    auto tp_chain_args = [&](ChainArgs& ca, int l) {
-      ca.center = g->center;
-      ca.tp_sh = buf(w.sh);
-      ca.tp_ld_sh = p->D;
-      ca.tp_D = p->D;
-      ca.tp_bvec = buf(w.bvec[l]);
-    };
-    for (int l = 0; l < L; ++l) {
-      TpMomArgs m = mom_args(g);
-      m.bvec_out = buf(w.bvec[l]);
-      if (l == 0) {
-        if (int rc = launch_tp_mom_fwd_first<T>(p->chain_pair, m, stream)) return rc;
-        if (int rc = mark("tp_mom_vec_first", p->D + m.ka0, 2.0 * p->D * u)) return rc;
-      } else {
-        if (int rc = launch_tp_mom_fwd_last<T>(p->chain_pair, m, stream)) return rc;
-        if (int rc = mark("tp_mom_vec_last", p->D + m.ka1, 3.0 * p->D * u)) return rc;
-      }
-      ChainArgs ca{};
-      tp_chain_args(ca, l);
-      SegList in{1, {seg(buf(w.emb), S, S)}};
-      SegList ch{1, {seg(buf(w.lat_h[l][0]), 64, 64)}};
-      SegList cl{1, {seg(buf(w.fcat) + S * (l + 1), SL1, S)}};
-      if (l == 0) {
-        // emb -> [two-body (stored, kept) | w0 (stored; scal0 accumulated behind every irrep)] -> [two-body | scal0] -> h -> lat0
-        ca.nlayers = 3;
-        SegList c2{2, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W)}};
-        ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0q), 64, p->ng0, c2, nullptr, nullptr, nullptr, 0, 0, 0);
-        ca.L[0].tp_from1 = 3;  // tiles 2.. are the irreps of w0
-        ca.L[1] = chain_layer(E, none, 0, wt(p->latent[0].wq[0]), S + u, 64, ch, nullptr, nullptr, nullptr, 1, 0, 1);
-        ca.L[1].use_sc = 1;
-        ca.L[2] = chain_layer(E, none, 0, wt(p->latent[0].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, -1, 0);
-      } else {
-        // emb -> w0 again (not stored; scal1) -> [two-body | lat0 | scal1] -> h -> lat1 -> readout hidden layer + edge sum
-        ca.nlayers = 4;
-        SegList cw{1, {seg(nullptr, W, W)}};
-        SegList in2{1, {seg(buf(w.fcat), SL1, S * 2)}};
-        SegList fin{1, {seg(buf(w.fcat), SL1, S * L)}};
-        SegList cr{1, {seg(buf(w.ro_h[0]), 64, 64)}};
-        ca.L[0] = chain_layer(E, in, 0, reinterpret_cast<const float*>(wt(p->o_g0q)) + size_t(2) * 2 * 1536, 64, W, cw, nullptr, nullptr, nullptr, 0, -1, 0);
-        ca.L[0].tp_from1 = 1;  // every tile is an irrep of w0
-        ca.L[1] = chain_layer(E, in2, 0, wt(p->latent[1].wq[0]), S * 2 + u, 64, ch, nullptr, nullptr, nullptr, 0, 0, 1);
-        ca.L[1].use_sc = 1;
-        ca.L[2] = chain_layer(E, none, 0, wt(p->latent[1].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, 0, 0);
-        ca.L[3] = chain_layer(E, fin, 0, wt(p->readout.wq[0]), S * L + 64, 64, cr, nullptr, nullptr, nullptr, 1, -1, 0);
-        ca.L[3].edge_sum_out = buf(w.e_edge);
-        ca.ro_w = wt(p->o_ro_last);
-      }
-      if (int rc = run_chain(ca, l == 0 ? "F1b" : "F2b")) return rc;
-    }
-    if (int rc = launch_readout_reduce<T>(readout_args(g, atom_energy), stream)) return rc;
-    return mark("readout_reduce", 1, 1);
-  }
-
   int forward(const aa_graph* g, const void* pos, void* atom_energy) {
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
     if (use_fused_fwd(g)) return forward_fused(g, pos, atom_energy);
-    if (sizeof(T) == 4 && p->chain_tp && !p->taps) return forward_chain_tp(g, pos, atom_energy);
     // 1-2: geometry, SH, radial-chemical embedding
     if (int rc = mark("begin")) return rc;
     const double idx2 = 8.0 / sizeof(T);  // center + nbr ids, in elements
@@ -1431,27 +1296,6 @@ struct Runner {
         o.scal = buf(w.scal[l]);
         if (int rc = launch_tp_op<T>(p->tp_op, l, false, o, stream)) return rc;
         if (int rc = mark("tp_op_fwd", p->D + o.ka + W + u, double(l + 1) * p->D * u)) return rc;
-      } else if (p->env_mom && p->tp_mfma) {
-        TpMomArgs m = mom_args(g);
-        TpMfmaArgs a{};
-        a.N = m.c.N;
-        a.atom0 = m.c.atom0;
-        a.rowptr = g->rowptr;
-        a.sh = reinterpret_cast<const float*>(buf(w.sh));
-        a.ld_sh = p->D;
-        a.emb = reinterpret_cast<const float*>(buf(w.emb));
-        a.a = reinterpret_cast<const float*>(l == 0 ? m.a0 : m.a1);
-        a.wk = reinterpret_cast<const float*>(l == 0 ? m.wk0 : m.wk1);
-        a.wq = reinterpret_cast<const float*>(wt(p->o_g0q)) + size_t(2) * 2 * 1536;  // tiles 2..: the w0 columns of [two-body | w0]
-        a.tpw0 = reinterpret_cast<const float*>(wt(p->o_tpw[0]));
-        a.tpw1 = reinterpret_cast<const float*>(wt(p->o_tpw[1]));
-        a.coupling = c.tps[0].coupling;
-        a.sf = float(sfac);
-        a.x2s0 = reinterpret_cast<float*>(buf(w.x2s[0]));
-        a.x2s1 = reinterpret_cast<float*>(buf(w.x2s[1]));
-        a.scal = reinterpret_cast<float*>(buf(w.scal[l]));
-        if (int rc = launch_tp_mfma_fwd(p->chain_pair, l == 1, a, stream)) return rc;
-        if (int rc = mark(l == 0 ? "tp_mfma_fwd_first" : "tp_mfma_fwd_last", p->D + (l == 0 ? 64 : 128) + u, double(l + 1) * p->D * u)) return rc;
       } else if (p->env_mom) {
         TpMomArgs m = mom_args(g);
         if (l == 0) {

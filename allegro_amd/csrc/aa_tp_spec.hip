@@ -1013,17 +1013,6 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_first_kernel(TpMomArgs ma) {
 #pragma unroll
     for (int p = 0; p < Sig0::P; ++p) wp0[p] = a.coupling ? W0[lane * Sig0::P + p] : W0[p];
   }
-  if (ma.bvec_out) {
-    // the chain that produces w0 evaluates scal0[e] = <x1[e], B0> itself (ChainArgs.tp_*): hand it B0 = Sig0^T_x1(e_0, x2s0)
-    T e0[Sig0::DOUT], B0[Sig0::D1];
-#pragma unroll
-    for (int k = 0; k < Sig0::DOUT; ++k) e0[k] = k == 0 ? T(1) : T(0);
-    Sig0::template bx1<T>(e0, x2s0, wp0, B0);
-    T* bo = static_cast<T*>(ma.bvec_out) + atom * D * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < Sig0::D1; ++i) bo[int64_t(i) * 64] = B0[i];
-    return;
-  }
   auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
     const int sb = s + 1 < end ? s + 1 : s;
     const T* ya = sh + int64_t(s) * a.ld_sh;
@@ -1087,12 +1076,6 @@ __global__ __launch_bounds__(256) void tp_mom_fwd_last_kernel(TpMomArgs ma) {
     T one[1] = {T(1)}, v[Sig1::D1];
     Sig1::template bx1<T>(one, x2s1, wp1, v);
     Sig0::template bx1<T>(v, x2s0, wp0, B1);
-  }
-  if (ma.bvec_out) {  // (see tp_mom_fwd_first_kernel)
-    T* bo = static_cast<T*>(ma.bvec_out) + atom * D * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < Sig0::D1; ++i) bo[int64_t(i) * 64] = B1[i];
-    return;
   }
   auto fetch = [&](int s, EdgeIn2<T, D, R>& in) {
     const int sb = s + 1 < end ? s + 1 : s;

@@ -195,15 +195,10 @@ typedef struct {
   int32_t gemm_lds_epilogue; /* LDS-transposed epilogue in the single-layer bf16x3 kernel                       */
   int32_t f64_column_loop; /* fp64 linear layers: 0 automatic, 1 never, 2 always walk all column tiles per workgroup */
   int32_t embed_no_fuse;   /* reverse pass: materialise d(two-body embedding)                                   */
-  int32_t fused_forward;   /* fused per-atom-tile forward: 0 automatic (32-edge tiles whenever aa_graph.max_degree allows),
-                            * 1 32-edge tiles; 2 16-edge tiles; 3 never (staged pipeline)                           */
+  int32_t fused_forward;   /* fused per-atom-tile forward: 0 / 1 whenever aa_graph.max_degree allows; 3 never (staged pipeline) */
   int32_t fused_recompute_w0; /* fused forward: recompute w0 for the second layer instead of holding it         */
   int32_t moments_waves_per_block; /* 0 = 1                                                                      */
-  int32_t tp_mfma;         /* tensor-product kernels that recompute the first-layer x1 weights on the matrix cores
-                            * (aa_tp_mfma.hip) instead of re-reading them: 0 automatic, 1 on where supported, 2 off  */
   int32_t f64_rows;        /* fp64 linear layers, row-resident kernels (operand rows read once): 0 where measured faster, 1 wherever applicable, 2 off */
-  int32_t chain_tp;        /* 1: forward with the tensor-track scalars evaluated inside the linear-layer chains that produce w0
-                            * (scal0 / scal1 never reach HBM; the moments kernels only form the per-atom vectors)         */
   int32_t no_channel_padding; /* stacks whose channel count is not a multiple of 64, or with single hidden layers narrower than
                                * 64, are normally evaluated zero-padded (same results, tuned kernels); 1: keep them narrow */
   int32_t poison_workspace; /* debugging: every step first fills the whole workspace with 0xFF bytes (NaN in fp32 and fp64), so

@@ -346,8 +346,8 @@ def test_channel_counts_off_the_multiples_of_64_run_zero_padded(u, coupling, ind
     import numpy as np
 
     import bench
-    from tests.test_fused import _cfg, _ragged
-    from tests.test_tp_mfma import _vs_oracle64
+    from tests.fastpath_utils import _cfg, _ragged
+    from tests.fastpath_utils import _vs_oracle64
 
     pos, cell, ei, shift, types = _ragged(dims=(3, 3, 2), keep=0.9, seed=4)
     deg = np.bincount(ei[0], minlength=pos.shape[0])
@@ -384,8 +384,8 @@ def test_narrow_hidden_layers_run_zero_padded_on_the_fused_chains(widths, monkey
     import numpy as np
 
     import bench
-    from tests.test_fused import _cfg, _ragged
-    from tests.test_tp_mfma import _vs_oracle64
+    from tests.fastpath_utils import _cfg, _ragged
+    from tests.fastpath_utils import _vs_oracle64
 
     pos, cell, ei, shift, types = _ragged(dims=(3, 3, 2), keep=0.9, seed=4)
     deg = np.bincount(ei[0], minlength=pos.shape[0])

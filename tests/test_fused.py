@@ -4,8 +4,8 @@ stack in one launch, one wave per center atom's edge tile.
 CPU: the unmodified kernel source in the test-only emulation build, against the reference's golden vectors, against
 the fp64 oracle on ragged graphs (partial tiles, an atom without edges, two species, per-type scale/shift), and on
 atom-block sub-ranges (the multi-GPU partition).  GPU: the same checks on hardware plus the staged pipeline as A/B.
-The fused path needs `aa_graph.max_degree <= 32` (larger segments fall back to the staged pipeline) and is opt-in
-(AA_FUSED=1): on MI355X it is correct but slower than the staged forward -- see DESIGN.md section 9 for the measurements."""
+The fused path needs `aa_graph.max_degree <= 32` (larger segments fall back to the staged pipeline) and is the DEFAULT
+forward wherever the graph allows it; AA_FUSED=0 selects the staged pipeline."""
 import numpy as np
 import pytest
 import torch
@@ -16,39 +16,12 @@ from tests.golden_utils import load_model_fixture
 from tests.hip_utils import emu_lib, fixture_data, model_from_fixture
 
 
-MODES = {"tile32": "1", "tile16": "2"}  # AA_FUSED: one wave per atom (aa_fused.hip) / two waves per atom (aa_fused16.hip)
+def _opt_in(monkeypatch, mode="tile32"):
+    """The fused forward is the default wherever the graph allows it (AA_FUSED unset); AA_FUSED=1 states it."""
+    monkeypatch.setenv("AA_FUSED", "1")
 
 
-def _opt_in(monkeypatch, mode):
-    """AA_FUSED selects the fused forward when the plan is created (the first step of a model)."""
-    monkeypatch.setenv("AA_FUSED", MODES[mode])
-
-
-def _cfg(embed="bessel", coupling=True, l_max=2, seed=11, avg=9.0, scale_shift=True):
-    rce = ({"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8} if embed == "bessel" else
-           {"_target_": "allegro.nn.TwoBodySplineScalarEmbed", "num_splines": 8, "spline_span": 6})
-    c = dict(type_names=["A", "B"], r_max=3.4, l_max=l_max, num_layers=2, num_scalar_features=64, num_tensor_features=64,
-             radial_chemical_embed=rce, radial_chemical_embed_dim=64, scalar_embed_mlp_hidden_layers_width=64,
-             allegro_mlp_hidden_layers_width=64, readout_mlp_hidden_layers_width=64, avg_num_neighbors=avg, seed=seed,
-             tp_path_channel_coupling=coupling, model_dtype="float32")
-    if scale_shift:
-        c.update(per_type_energy_scales=[1.3, 0.6], per_type_energy_shifts=[-2.0, 0.25])
-    return c
-
-
-def _ragged(dims=(4, 4, 4), keep=0.88, a=1.8, seed=5, r_cut=3.4):
-    """A ragged open cluster: jittered lattice (spacing a) with vacancies -- degrees from a few (corners) up to ~30
-    (interior), no unphysically short contacts that would make the fp32 sums ill-conditioned -- plus one isolated
-    atom without any edge."""
-    rng = np.random.default_rng(seed)
-    grid = np.stack(np.meshgrid(*[np.arange(d) for d in dims], indexing="ij"), -1).reshape(-1, 3)
-    sel = np.sort(rng.permutation(len(grid))[:int(round(keep * len(grid)))])
-    pos = grid[sel] * a + rng.uniform(-0.2, 0.2, size=(len(sel), 3)) + 10.0
-    pos = np.concatenate([pos, [[70.0, 70.0, 70.0]]])  # isolated: no edges
-    cell = np.eye(3) * 120.0
-    ei, shift = G.neighbor_list_pbc(pos, cell, r_cut)
-    types = rng.integers(0, 2, size=len(pos))
-    return pos, cell, ei, shift, types
+from tests.fastpath_utils import _cfg, _ragged  # noqa: E402,F401
 
 
 def _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev, blocks=None):
@@ -102,9 +75,8 @@ def _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev, blocks=None):
     return m, g
 
 
-# (the CPU suite runs a cross-section of (tile form, fixture) pairs -- the emulated 64-wide model takes ~18 s per case;
-#  the GPU tests below run every combination)
-@pytest.mark.parametrize("mode,name", [("tile16", "c2_uncoupled")])  # (32-edge tiles: the automatic-selection test below)
+# (the emulated 64-wide model takes ~18 s per case: one fixture here, the GPU tests below run every combination)
+@pytest.mark.parametrize("mode,name", [("tile32", "c2_uncoupled")])
 def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch):
     _opt_in(monkeypatch, mode)
     fx = load_model_fixture(name, torch.float32)
@@ -117,7 +89,7 @@ def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch
         assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("mode,embed,coupling", [("tile16", "spline", False)])
+@pytest.mark.parametrize("mode,embed,coupling", [("tile32", "spline", False)])
 def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(mode, embed, coupling, monkeypatch):
     _opt_in(monkeypatch, mode)
     pos, cell, ei, shift, types = _ragged()
@@ -150,7 +122,7 @@ def test_three_species_run_the_fused_forward_on_gpu(embed, monkeypatch):
 
 
 def test_degree_above_32_falls_back_to_the_staged_pipeline_emulated(monkeypatch):
-    _opt_in(monkeypatch, "tile16")
+    _opt_in(monkeypatch)
     rng = np.random.default_rng(9)
     grid = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(3), indexing="ij"), -1).reshape(-1, 3)[:40]
     pos = grid * 0.7 + rng.uniform(-0.05, 0.05, size=(40, 3)) + 20.0
@@ -233,7 +205,7 @@ def test_automatic_selection_on_gpu(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["tile32", "tile16"])
+@pytest.mark.parametrize("mode", ["tile32"])
 @pytest.mark.parametrize("embed,coupling,l_max", [("bessel", True, 2), ("spline", False, 2), ("bessel", True, 1)])
 def test_fused_forward_ragged_graph_vs_fp64_oracle_on_gpu(mode, embed, coupling, l_max, monkeypatch):
     _opt_in(monkeypatch, mode)
@@ -245,7 +217,7 @@ def test_fused_forward_ragged_graph_vs_fp64_oracle_on_gpu(mode, embed, coupling,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["tile32", "tile16"])
+@pytest.mark.parametrize("mode", ["tile32"])
 @pytest.mark.parametrize("name", ["c2", "c2_spline", "c2_l1", "c2_uncoupled"])
 def test_fused_and_staged_forward_agree_on_gpu(mode, name, monkeypatch):
     """A/B on hardware: the same model and graph through the fused kernel (AA_FUSED at plan creation) and through

@@ -28,6 +28,15 @@ def _both_forwards(forward_mode):
     return forward_mode
 
 
+def _run(fx, dtype, dev):
+    m = model_from_fixture(fx, dtype, device=dev)
+    data, sv = fixture_data(fx, dtype, dev)
+    g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+    e, f = m.energy_forces(data["pos"], g)
+    torch.cuda.synchronize()
+    return m, g, e.cpu(), f.cpu()
+
+
 def _launches(m, g, pos):
     """Kernel symbols of one step (aa_model_energy_forces_profiled)."""
     import bench
@@ -478,8 +487,8 @@ def test_zero_padded_stacks_match_the_oracle_and_their_narrow_kernels(over, dev,
     import numpy as np
 
     from allegro_amd.nn import HipAllegroModel
-    from tests.test_fused import _cfg, _ragged
-    from tests.test_tp_mfma import _vs_oracle64
+    from tests.fastpath_utils import _cfg, _ragged
+    from tests.fastpath_utils import _vs_oracle64
 
     pos, cell, ei, shift, types = _ragged(dims=(6, 6, 5), keep=0.93, seed=8)
     deg = np.bincount(ei[0], minlength=pos.shape[0])
