@@ -531,6 +531,35 @@ struct FusedFwdArgs {
   float *x2s0, *x2s1;  // [N][D][64]
   float* atom_energy;  // [N]
 };
+// reverse tail (aa_fused_bwd.hip): layer-0 tensor product reverse + first-stage / scalar_embed_mlp reverse + edge reverse
+struct FusedTailArgs {
+  int64_t N, atom0, atom_end;  // atoms [atom0, atom_end), one wave each; every one has <= 32 edges
+  const int32_t *rowptr, *nbr, *types;
+  int num_types, embed_kind, spline_span;
+  float poly_p;
+  const float *rmax_recip, *bessel_w;
+  const float* emb_tab;      // [T*T][8][64]
+  const void* wstep[kFusedMaxSteps][2];  // weight program, 12-KB blocks (see fused_bwd_tail_kernel)
+  const float *tpw0, *tpw1;  // path weights
+  int coupling;
+  float sf;                  // 1/sqrt(avg_num_neighbors)
+  // inputs
+  const float* vec;          // [E,4] unit vector, length (forward)
+  const float* w0;           // [E,R*64] (forward)
+  const float* emb;          // [E,64] EDGE_EMBEDDING (forward)
+  const float* se_h;         // [E,64] pre-activation of scalar_embed_mlp's hidden layer (forward)
+  const float *x2s0, *x2s1;  // [N][D][64] (forward)
+  const float *gscal0, *gscal1;  // [E,64] gradients of the tensor-track scalars of the two layers
+  const float* g_tb;         // [E, ld_gtb] gradient of the two-body scalars (first 64 columns of d EDGE_FEATURES)
+  int ld_gtb;
+  const float* gsh_env1;     // [E,D] dE/dY of the layer-1 env path (tp_mom_bwd_last) or nullptr
+  // outputs: dvec [E,4] = dE/dr_e (edge reverse fused), or -- dvec == nullptr -- the inputs of edge_backward
+  float* dvec;
+  float* trev;               // [E,8]
+  float* gsh_out;            // [E,D]
+};
+int fused_bwd_tail_num_steps(int R);
+int launch_fused_bwd_tail(int pair, const FusedTailArgs& a, hipStream_t stream);
 int fused_fwd_num_steps(int R, bool hold_w0);
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
 

@@ -30,265 +30,9 @@
 // Limits of this first version: every center atom of the block has <= 32 edges (aa_graph.max_degree; larger
 // segments run the staged pipeline), u = S = all MLP widths = 64, embedding table path (<= 2 species, 8 basis
 // functions), fp32.
-#include <type_traits>
-
-#include "aa_cg_gen.h"
-#include "aa_wave.h"
-#include "aa_common.h"
-#include "aa_geom.h"
-#include "aa_mfma.h"
+#include "aa_fused_tile.h"
 
 namespace aa {
-
-namespace {
-
-constexpr int kLdA = 68;   // row stride (floats) of the [32 edges][64 features] patch: 16-B aligned rows, conflict-light
-constexpr int kLdT = kTileLdT;  // row stride of the [32][32] store-transpose patch (as in the chain kernel)
-constexpr int kLdY = 16;   // row stride of sY [32 edges][D <= 16] and sM [64 k][D]
-constexpr int kOffB = 32 * kLdT;          // sB [D][64] sits behind the store patch inside the wave region
-constexpr int kWaveRegion = 32 * kLdA;    // floats: max(sA, sT + sB, sM + sB)
-static_assert(kOffB + 16 * 64 <= kWaveRegion, "per-atom vectors must fit behind the store patch");
-
-// ---- weight pipeline --------------------------------------------------------------------------------------------
-// The kernel's program is a fixed sequence of NS "steps"; step S consumes one 12-KB block of weights (a tile pair x
-// 32-deep chunk of a linear layer in bf16x3 fragments, or 16 rows of an env-weight matrix) from LDS buffer S & 1.
-// Block S + 2 is requested from L2 at the START of step S into one of two register sets and lands in LDS at the END
-// of step S + 1, i.e. every load has two full steps to arrive (the kernel runs one wave per SIMD: nothing else hides
-// L2 latency).  Barriers are raw s_barrier with LDS-only fences, so that they do not drain the loads in flight
-// (__syncthreads() carries a vmcnt(0)).  All indices are compile-time: the whole program is unrolled.
-struct FusedPipe {
-  u32x4 ra[3], rb[3];
-  u32x4* wbuf;  // [2][kWStep]
-  int tid, lane;
-};
-
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// (every load is wave-uniform base + lane offset: the bases stay in SGPRs and all loads of the program share ONE
-//  offset register -- with per-lane base selects the compiler hoists ~140 loop-invariant 64-bit address pairs out of
-//  the persistent loop and spills them)
-//  What remains hoisted -- the block addresses of the ~46 steps -- costs two or three scratch reloads per step.)
-__device__ __forceinline__ void pipe_load(const FusedFwdArgs& A, int tid, int t, u32x4* r) {
-  const u32x4* s0 = static_cast<const u32x4*>(A.wstep[t][0]);
-  const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t][1]);
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const u32x4* mid = wv < 2 ? s0 + 256 : s1 - 128;  // elements 256..383 of the first half | 0..127 of the second
-  r[0] = s0[tid];
-  r[1] = mid[tid];
-  r[2] = (s1 + 128)[tid];
-}
-__device__ __forceinline__ void pipe_store(u32x4* wbuf, int b, int tid, const u32x4* r) {
-  u32x4* d = wbuf + b * kWStep;
-  d[tid] = r[0];
-  d[256 + tid] = r[1];
-  d[512 + tid] = r[2];
-}
-template <int S, int NS>
-__device__ __forceinline__ void pipe_issue(const FusedFwdArgs& A, FusedPipe& p) {
-  if constexpr ((S & 1) == 0)
-    pipe_load(A, p.tid, (S + 2) % NS, p.ra);
-  else
-    pipe_load(A, p.tid, (S + 2) % NS, p.rb);
-}
-template <int S>
-__device__ __forceinline__ void pipe_commit(FusedPipe& p) {
-  if constexpr (((S + 1) & 1) == 0)
-    pipe_store(p.wbuf, 0, p.tid, p.ra);
-  else
-    pipe_store(p.wbuf, 1, p.tid, p.rb);
-  lds_barrier();
-  // one scheduling region per step: without it the fully unrolled program is treated as one region and later steps'
-  // operand splits / LDS reads are hoisted far ahead (hundreds of spilled registers)
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// 24 MFMAs of one step (6 cross products x 2 k halves x 2 tiles); weight levels read from LDS just in time
-__device__ __forceinline__ void fused_mma_step(const u32x4* wb, int lane, const XSplit& x, v16f& acc0, v16f& acc1) {
-  const u32x4* w = wb + lane;
-#define AA_W(T_, Q_) w[((T_)*6 + (Q_)) * 64]
-  {
-    const u32x4 a0 = AA_W(0, 4), b0 = AA_W(1, 4), a1 = AA_W(0, 5), b1 = AA_W(1, 5);  // level 3
-    acc0 = mma_bf16(a0, x.l1[0], acc0);
-    acc1 = mma_bf16(b0, x.l1[0], acc1);
-    acc0 = mma_bf16(a1, x.l1[1], acc0);
-    acc1 = mma_bf16(b1, x.l1[1], acc1);
-  }
-  {
-    const u32x4 a0 = AA_W(0, 2), b0 = AA_W(1, 2), a1 = AA_W(0, 3), b1 = AA_W(1, 3);  // level 2
-    acc0 = mma_bf16(a0, x.l2[0], acc0);
-    acc1 = mma_bf16(b0, x.l2[0], acc1);
-    acc0 = mma_bf16(a1, x.l2[1], acc0);
-    acc1 = mma_bf16(b1, x.l2[1], acc1);
-    acc0 = mma_bf16(a0, x.l1[0], acc0);
-    acc1 = mma_bf16(b0, x.l1[0], acc1);
-    acc0 = mma_bf16(a1, x.l1[1], acc0);
-    acc1 = mma_bf16(b1, x.l1[1], acc1);
-  }
-  {
-    const u32x4 a0 = AA_W(0, 0), b0 = AA_W(1, 0), a1 = AA_W(0, 1), b1 = AA_W(1, 1);  // level 1
-    acc0 = mma_bf16(a0, x.l3[0], acc0);
-    acc1 = mma_bf16(b0, x.l3[0], acc1);
-    acc0 = mma_bf16(a1, x.l3[1], acc0);
-    acc1 = mma_bf16(b1, x.l3[1], acc1);
-    acc0 = mma_bf16(a0, x.l2[0], acc0);
-    acc1 = mma_bf16(b0, x.l2[0], acc1);
-    acc0 = mma_bf16(a1, x.l2[1], acc0);
-    acc1 = mma_bf16(b1, x.l2[1], acc1);
-    acc0 = mma_bf16(a0, x.l1[0], acc0);
-    acc1 = mma_bf16(b0, x.l1[0], acc1);
-    acc0 = mma_bf16(a1, x.l1[1], acc0);
-    acc1 = mma_bf16(b1, x.l1[1], acc1);
-  }
-#undef AA_W
-}
-
-// One linear layer on the wave's tile, steps S0 .. S0 + KC * NT / 2 - 1 of the program: KC 32-deep operand chunks
-// (op(kc) -> the v16f tile that is chunk kc), NT output tiles in pairs (epi(pair, acc0, acc1) after each pair).
-// Operand splits are software-pipelined: chunk kc + 1 is split while the MFMAs of chunk kc execute (layers with few
-// chunks and several pairs split all chunks once up front).
-template <int S0, int NS, int KC, int NT, class OpF, class EpiF>
-__device__ __forceinline__ void fused_layer(const FusedFwdArgs& A, FusedPipe& p, OpF&& op, EpiF&& epi) {
-  static_assert(NT % 2 == 0, "output tiles come in pairs");
-  constexpr bool PRE = NT > 2;
-  constexpr bool PIPE = true;
-  XSplit xs[PRE ? KC : 2];
-  if constexpr (PRE) {
-    static_for<0, KC>([&](auto kc) {
-      const v16f t = op(kc);
-      xsplit_from_acc(t, xs[kc]);
-    });
-  } else if constexpr (PIPE) {
-    const v16f t = op(std::integral_constant<int, 0>{});
-    xsplit_from_acc(t, xs[0]);
-  }
-  static_for<0, NT / 2>([&](auto ntp) {
-    v16f acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc0[r] = 0.f;
-      acc1[r] = 0.f;
-    }
-    static_for<0, KC>([&](auto kcc) {
-      constexpr int kc = decltype(kcc)::value;
-      constexpr int S = S0 + decltype(ntp)::value * KC + kc;
-      pipe_issue<S, NS>(A, p);
-      if constexpr (!PRE && !PIPE) {
-        const v16f t = op(kcc);
-        xsplit_from_acc(t, xs[kc & 1]);
-      }
-      fused_mma_step(p.wbuf + (S & 1) * kWStep, p.lane, xs[PRE ? kc : (kc & 1)], acc0, acc1);
-      if constexpr (!PRE && PIPE && kc + 1 < KC) {
-        const v16f t = op(std::integral_constant<int, kc + 1>{});
-        xsplit_from_acc(t, xs[(kc + 1) & 1]);
-      }
-      pipe_commit<S>(p);
-    });
-    epi(ntp, acc0, acc1);
-  });
-}
-
-// A tile pair parked in LDS in accumulator layout ([q][lane] 16-B cells: conflict-free b128 accesses).  The two-body
-// scalars and lat0 are operands of three / two later layers; parking them frees 64 registers per lane for the whole
-// second half of the kernel (the kernel runs one wave per SIMD, LDS is plentiful).
-constexpr int kFusedOcc = 1;  // one workgroup per CU: the kernel needs the whole register file and most of the LDS
-__device__ __forceinline__ void park_tile(float* slot, const v16f& t, int lane) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f*>(slot + (q * 64 + lane) * 4) = v4f{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
-}
-__device__ __forceinline__ v16f fetch_tile(const float* slot, int lane) {
-  v16f t;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const v4f v = *reinterpret_cast<const v4f*>(slot + (q * 64 + lane) * 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[4 * q + i] = v[i];
-  }
-  return t;
-}
-constexpr int kTileFloats = 64 * 16;  // one parked 32-feature tile
-
-template <bool ACT>
-__device__ __forceinline__ void keep_tile(const v16f& acc, v16f& k) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) k[r] = ACT ? silu(acc[r]) : acc[r];
-}
-
-// M[j] (lane = k) = sum over the tile's rows of Y[e][j] * a[e][k]: the two tiles go to the LDS patch in [e][k] order,
-// every lane then walks its column.  Rows beyond the segment carry Y = 0 (sY), so they drop out.
-template <int D>
-__device__ __forceinline__ void tile_moments(float* sA, const float* sY, const v16f& t0, const v16f& t1, int lane, float* M) {
-  const int el = lane & 31, hh = lane >> 5;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    *reinterpret_cast<v4f*>(sA + el * kLdA + 8 * q + 4 * hh) = v4f{t0[4 * q], t0[4 * q + 1], t0[4 * q + 2], t0[4 * q + 3]};
-    *reinterpret_cast<v4f*>(sA + el * kLdA + 32 + 8 * q + 4 * hh) = v4f{t1[4 * q], t1[4 * q + 1], t1[4 * q + 2], t1[4 * q + 3]};
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < D; ++j) M[j] = 0.f;
-#pragma unroll 4
-  for (int e = 0; e < 32; ++e) {
-    const float a = sA[e * kLdA + lane];
-    float y[16];
-#pragma unroll
-    for (int q = 0; q < (D + 3) / 4; ++q) {
-      const v4f yy = *reinterpret_cast<const v4f*>(sY + e * kLdY + 4 * q);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) y[4 * q + i] = yy[i];
-    }
-#pragma unroll
-    for (int j = 0; j < D; ++j) M[j] += y[j] * a;
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-// x2s[j] (lane = channel) = f * sum_k M[j][k] * Wk[k][r(j)][ch].  M is handed over through sM [k][D]; the env-weight
-// matrix Wk [64][R][64] arrives through the weight pipeline as 4 blocks of 16 rows (steps S0 .. S0 + 3).
-template <int S0, int NS, int D, int R>
-__device__ __forceinline__ void project_moments(const FusedFwdArgs& A, FusedPipe& p, float* sM, const float* M, float sf, float* x2s) {
-  const int lane = p.lane;
-#pragma unroll
-  for (int q = 0; q < (D + 3) / 4; ++q) {
-    v4f mm;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mm[i] = 4 * q + i < D ? M[4 * q + i] : 0.f;
-    *reinterpret_cast<v4f*>(sM + lane * kLdY + 4 * q) = mm;
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < D; ++j) x2s[j] = 0.f;
-  static_for<0, 4>([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    constexpr int S = S0 + c;
-    pipe_issue<S, NS>(A, p);
-    const float* wf = reinterpret_cast<const float*>(p.wbuf + (S & 1) * kWStep) + lane;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float w[R], m[16];
-#pragma unroll
-      for (int r = 0; r < R; ++r) w[r] = wf[(kk * R + r) * 64];
-#pragma unroll
-      for (int q = 0; q < (D + 3) / 4; ++q) {
-        const v4f mm = *reinterpret_cast<const v4f*>(sM + (16 * c + kk) * kLdY + 4 * q);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) m[4 * q + t] = mm[t];
-      }
-#pragma unroll
-      for (int j = 0; j < D; ++j) x2s[j] += m[j] * w[r_of<0>(j)];
-      if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 rows' LDS operands in flight
-    }
-    pipe_commit<S>(p);
-  });
-#pragma unroll
-  for (int j = 0; j < D; ++j) x2s[j] *= sf;
-}
-
-}  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
@@ -341,6 +85,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   p.wbuf = wbuf;
   p.tid = tid;
   p.lane = lane;
+  p.stager = true;
   {
     u32x4 r[3];
     pipe_load(A, tid, 0, r);

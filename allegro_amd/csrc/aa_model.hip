@@ -155,6 +155,9 @@ struct aa_model_plan {
   size_t o_embtab;                   // [T*T][8][64] type_embed(c | pair) * basis_linear[n][c]
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
+  size_t o_wtk[AA_MAX_LAYERS];                      // ... and [u][R][ka] (the fused reverse tail streams it in 16-channel blocks)
+  bool fused_tail;                   // reverse: layer-0 tensor product reverse + first-stage / embed-MLP reverse + edge reverse as ONE
+                                     // per-atom-tile kernel whenever the fused forward runs (aa_fused_bwd.hip)
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
   // optional hipGraph replay of the whole step (aa_model_plan_enable_graph): the launch sequence is captured once per
   // distinct argument set and replayed with one hipGraphLaunch -- for launch-bound (small) systems
@@ -335,6 +338,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
       const size_t ka = l == 0 ? S : cfg->latent_mlp_width;
       p->o_wk[l] = take(ka * p->W);
       p->o_wt[l] = take(ka * p->W);
+      p->o_wtk[l] = take(ka * p->W);
     }
   }
   for (int l = 0; l < L; ++l) {
@@ -377,6 +381,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
                           u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0;
     p->fused_fwd = eligible && opt.fused_forward != 3;
+    p->fused_tail = p->fused_fwd && p->embed_fused && !opt.no_fused_tail;
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
   }
   *out = p;
@@ -450,6 +455,7 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
     mix(p->o_tpw[l]);
     mix(p->env_mom ? p->o_wk[l] : 0);
     mix(p->env_mom ? p->o_wt[l] : 0);
+    mix(p->env_mom ? p->o_wtk[l] : 0);
     mixm(p->latent[l]);
   }
   mixm(p->embed);
@@ -645,6 +651,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
             double v = rawm[size_t(k) * raw_w + S + (shared ? ch : ch * Rr + r)] * al;
             h[p->o_wk[l] + (size_t(k) * Rr + r) * u + ch] = v;
             h[p->o_wt[l] + (size_t(r) * u + ch) * ka + k] = v;
+            h[p->o_wtk[l] + (size_t(ch) * Rr + r) * ka + k] = v;
           }
     };
     fill(0, raw->first_proj, S, S + We, mlp_alpha(c, 0, S, S + We - dWe));
@@ -1169,6 +1176,97 @@ struct Runner {
   bool use_fused_fwd(const aa_graph* g) const {
     return sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= 32;
   }
+  // the reverse tail in one launch (aa_fused_bwd.hip): same eligibility as the fused forward + the two-body table of the reverse
+  bool use_fused_tail(const aa_graph* g) const { return use_fused_fwd(g) && p->fused_tail; }
+  int backward_fused_tail(const aa_graph* g, void* forces) {
+    const aa_model_config& c = p->cfg;
+    const int u = c.num_tensor;
+    FusedTailArgs a{};
+    a.N = N;
+    a.atom0 = atom_begin(g);
+    a.atom_end = atom_end(g);
+    a.rowptr = g->rowptr;
+    a.nbr = g->nbr;
+    a.types = g->types;
+    a.num_types = c.num_types;
+    a.embed_kind = c.embed_kind;
+    a.spline_span = c.spline_span;
+    a.poly_p = float(c.poly_p);
+    auto wf = [&](size_t off) { return reinterpret_cast<const float*>(wt(off)); };
+    auto bf = [&](size_t off) { return reinterpret_cast<float*>(buf(off)); };
+    a.rmax_recip = wf(p->o_rmax);
+    a.bessel_w = wf(p->o_bessel);
+    a.emb_tab = wf(p->o_embtab);
+    int ns = 0;
+    {
+      const float* Wk = wf(p->o_wtk[0]);  // GM: 4 blocks of 16 channels x R x 64
+      for (int cblk = 0; cblk < 4; ++cblk) {
+        a.wstep[ns][0] = Wk + size_t(cblk) * 16 * p->R * 64;
+        a.wstep[ns][1] = Wk + size_t(cblk) * 16 * p->R * 64 + 1536;
+        ++ns;
+      }
+    }
+    auto add_layer = [&](const float* Wq, int KC) {  // one tile pair (64 outputs), KC 32-deep chunks
+      for (int kc = 0; kc < KC; ++kc) {
+        a.wstep[ns][0] = Wq + size_t(kc) * 64 * 24;
+        a.wstep[ns][1] = Wq + (size_t(KC) + kc) * 64 * 24;
+        ++ns;
+      }
+    };
+    add_layer(wf(p->o_g0tq), 2 + 2 * p->R);
+    add_layer(wf(p->embed.wtq[1]), 2);
+    add_layer(wf(p->embed.wtq[0]), 2);
+    if (ns != fused_bwd_tail_num_steps(p->R) || ns > kFusedMaxSteps) return fail(AA_ERR_INVALID, "fused reverse tail: program length mismatch");
+    a.tpw0 = wf(p->o_tpw[0]);
+    a.tpw1 = wf(p->o_tpw[1]);
+    a.coupling = c.tps[0].coupling;
+    a.sf = float(1.0 / std::sqrt(c.avg_num_neighbors));
+    a.vec = bf(w.vec);
+    a.w0 = bf(w.w0);
+    a.emb = bf(w.emb);
+    a.se_h = bf(w.se_h[0]);
+    a.x2s0 = bf(w.x2s[0]);
+    a.x2s1 = bf(w.x2s[1]);
+    a.gscal0 = bf(w.g_scal[0]);
+    a.gscal1 = bf(w.g_scal[1]);
+    a.g_tb = bf(w.g_fcat);
+    a.ld_gtb = p->SL1;
+    a.gsh_env1 = bf(w.g_sh) + size_t(2) * size_t(E) * p->D;  // slot of the layer-1 env path (tp_mom_bwd_last)
+    const bool gather = g->t_rowptr && g->t_perm;
+    const bool fuse_edge = gather && !p->opt.tail_keep_edge_backward;
+    if (fuse_edge) {
+      a.dvec = bf(w.dvec);
+    } else {
+      a.trev = bf(w.trev);
+      a.gsh_out = bf(w.g_sh);  // slot 0 carries the complete dE/dY
+    }
+    if (int rc = launch_fused_bwd_tail(p->chain_pair, a, stream)) return rc;
+    // algorithmic traffic per edge: neighbor id, unit vector, w0, embedding, one pre-activation, three gradient rows, the
+    // layer-1 dE/dY slot in; dE/dr_e (or the 8 basis sums + dE/dY) out.  Per atom: two x2s blocks, row pointer.
+    const double per_edge = 1 + 4 + p->W + 64 + 64 + 2.0 * u + 64 + p->D + (fuse_edge ? 4 : 8 + p->D);
+    const double fl = 2.0 * double(E) * (double(p->ng0) * 64 + 64.0 * 64 + 64.0 * c.embed_dim);
+    if (int rc = mark("fused_bwd_tail", per_edge, 2.0 * p->D * u + 1, fl)) return rc;
+    if (!fuse_edge) {
+      EdgeBwdArgs eb{};
+      eb.g = geom(g, nullptr);
+      eb.g_emb0 = nullptr;
+      eb.g_sh = buf(w.g_sh);
+      eb.num_gsh = 1;
+      eb.forces = forces;
+      eb.t_in = buf(w.trev);
+      eb.dvec = buf(w.dvec);
+      eb.gather = gather ? 1 : 0;
+      if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
+      if (int rc = mark("edge_backward", 8.0 / sizeof(T) + 4 + c.num_bessels + double(p->D) + (gather ? 4 : 6))) return rc;
+    }
+    if (gather) {
+      ForceGatherArgs fg{N, g->rowptr, g->t_rowptr, g->t_perm, buf(w.dvec), forces};
+      if (int rc = launch_force_gather<T>(fg, stream)) return rc;
+      return mark("force_gather", 8.0 + 4.0 / sizeof(T), 3 + 8.0 / sizeof(T));
+    }
+    return AA_OK;
+  }
+
   int forward_fused(const aa_graph* g, const void* pos, void* atom_energy) {
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor;
@@ -1521,6 +1619,8 @@ struct Runner {
           m.ld_ga = c.latent_mlp_width;
           if (int rc = launch_tp_mom_bwd_last<T>(p->chain_pair, m, stream)) return rc;
           if (int rc = mark("tp_mom_bwd_last", p->D + W + u + 2 * m.ka1 + p->D, double(p->D) * u)) return rc;
+        } else if (use_fused_tail(g)) {
+          // (the fused reverse tail below takes it from here: layer-0 tensor product reverse + first-stage / embed-MLP reverse + edge reverse)
         } else {
           m.ld_ga = S;
           if (int rc = launch_tp_mom_bwd_first<T>(p->chain_pair, m, stream)) return rc;
@@ -1610,6 +1710,7 @@ struct Runner {
       if (int rc = launch_tp_layer_bwd<T>(p->layers[l], a, stream)) return rc;
       if (int rc = mark("tp_layer_bwd", 4 * W + 2 * p->D + 2 * u * p->D + u, 2.0 * p->D * u)) return rc;
     }
+    if (use_fused_tail(g)) return backward_fused_tail(g, forces);
     if (p->chain_gemm) {
       // first-stage reverse + scalar_embed_mlp reverse in ONE kernel
       ChainArgs ca{};
