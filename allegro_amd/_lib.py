@@ -41,7 +41,7 @@ class PlanOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "tp_generic", "tp_no_chain", "tp_no_moments", "tp_no_operator", "tp_force_operator", "tp_operator_fused",
         "gemm_no_chain", "gemm_fp32_mfma", "gemm_valu", "gemm_v1", "gemm_lds_epilogue", "f64_column_loop",
-        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "f64_rows", "no_channel_padding", "no_fused_tail", "tail_keep_edge_backward", "poison_workspace")]
+        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "f64_rows", "no_channel_padding", "fused_tail", "poison_workspace")]
 
 
 def options_from_env() -> PlanOptions:
@@ -61,8 +61,7 @@ def options_from_env() -> PlanOptions:
     o.fused_recompute_w0 = flag("AA_FUSED_RECOMPUTE")
     o.moments_waves_per_block = int(env.get("AA_MOM_WPB", "0") or 0)
     o.no_channel_padding = flag("AA_NO_PAD")
-    o.no_fused_tail = int(env.get("AA_FUSED_TAIL", "1")[:1] == "0")
-    o.tail_keep_edge_backward = flag("AA_TAIL_KEEP_EDGE")
+    o.fused_tail = {"1": 1, "2": 2}.get(env.get("AA_FUSED_TAIL", "")[:1], 0)  # experimental builds only (AA_BUILD_EXPERIMENTAL=1)
     o.poison_workspace = flag("AA_POISON")  # debugging: NaN-filled workspace before every step
     o.f64_rows = {"0": 2, "2": 1}.get(env.get("AA_F64_ROWS", "")[:1], 0)  # 0: off, 2: wherever applicable
     return o
@@ -195,7 +194,9 @@ LIB_NAME = "liballegro_amd.so"
 def lib_path() -> str:
     """In-tree library next to this file; ALLEGRO_AMD_LIBRARY points at another build of the same sources
     (instrumented variants of tools/)."""
-    return os.environ.get("ALLEGRO_AMD_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    from .build import LIB_PATH  # (liballegro_amd_experimental.so under AA_BUILD_EXPERIMENTAL=1)
+
+    return os.environ.get("ALLEGRO_AMD_LIBRARY") or LIB_PATH
 
 
 def load(build_if_stale: bool = True) -> AllegroLib:

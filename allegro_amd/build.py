@@ -10,11 +10,18 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused_bwd.hip", "aa_model.hip", "aa_nl.hip"]
+SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_fused.hip", "aa_model.hip", "aa_nl.hip"]
 # public C ABI header: the package ships its own copy (package data, so that an installed package can rebuild itself);
 # in the source tree it is the same file as <repo>/include/allegro_amd.h (tests/test_lib_symbols.py checks identity)
 INCLUDE_DIR = os.path.join(HERE, "include")
 LIB_PATH = os.path.join(HERE, "liballegro_amd.so")
+# Measured-and-rejected kernels stay out of the product library; AA_BUILD_EXPERIMENTAL=1 adds them (their own opt-in
+# switches, their own tests) so that the measurements recorded in DESIGN.md section 9 stay reproducible:
+#   aa_fused_bwd.hip  fused per-atom-tile reverse tail (aa_plan_options.fused_tail / AA_FUSED_TAIL=1), section 9.4
+EXPERIMENTAL = os.environ.get("AA_BUILD_EXPERIMENTAL", "0")[:1] == "1"
+if EXPERIMENTAL:
+    SOURCES = SOURCES[:SOURCES.index("aa_model.hip")] + ["aa_fused_bwd.hip"] + SOURCES[SOURCES.index("aa_model.hip"):]
+    LIB_PATH = os.path.join(HERE, "liballegro_amd_experimental.so")  # (never overwrites the product library)
 TORCH_LIB_PATH = os.path.join(HERE, "liballegro_amd_torch.so")  # dispatcher op for torch.export / AOTI / C++ hosts
 
 
@@ -42,7 +49,7 @@ def _stale() -> bool:
 
 def _source_deps():
     """Files the device library is compiled from (not __pycache__, generators or the host-only torch_ops.cpp)."""
-    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h") or f in SOURCES]
     return deps + [os.path.join(INCLUDE_DIR, "allegro_amd.h")]
 
 
@@ -99,7 +106,7 @@ def _object_for(src: str, header_hash: str) -> str:
     return os.path.join(OBJ_DIR, f"{os.path.splitext(src)[0]}-{h.hexdigest()[:16]}.o")
 
 
-EXTRA_DEFINES = [d for d in os.environ.get("AA_BUILD_DEFINES", "").split() if d]  # e.g. "-DAA_FUSED_TIMING" (experiments)
+EXTRA_DEFINES = [d for d in os.environ.get("AA_BUILD_DEFINES", "").split() if d] + (["-DAA_EXPERIMENTAL_TAIL"] if EXPERIMENTAL else [])  # e.g. "-DAA_FUSED_TIMING" (experiments)
 
 
 def _build_library_locked(verbose: bool) -> str:

@@ -33,23 +33,27 @@ namespace aa {
 
 namespace {
 
-constexpr int kTailWaves = 8;  // waves (= atoms) per workgroup: two per SIMD share one 24-KB weight double buffer
+#ifndef AA_TAIL_WAVES
+#define AA_TAIL_WAVES 8
+#endif
+constexpr int kTailWaves = AA_TAIL_WAVES;  // waves (= atoms) per workgroup: 8 = two per SIMD share one 24-KB weight double buffer
 constexpr int kTailD = 9;      // l_max <= 2
 // wave-private LDS region (floats): sY [32][kLdY] | patch [32][kLdA] (later: sG [64][kLdY] at 0, sGM [D][64] behind it) | sB0 [D][64] | sB1 [D][64]
 constexpr int kTailOffP = 32 * kLdY, kTailOffGM = kTailOffP + 64 * kLdY, kTailOffB0 = kTailOffP + 32 * kLdA,
               kTailOffB1 = kTailOffB0 + kTailD * 64, kTailWaveFloats = kTailOffB1 + kTailD * 64;
 static_assert(64 * kLdY + kTailD * 64 <= 32 * kLdA, "sG and sGM live inside the patch region");
 
-// rows [row0, row0 + 32) x 32 features of a row-major [E, ld] array -> one tile in accumulator layout (zero beyond the segment)
-__device__ __forceinline__ v16f ld_tile(const float* col0, int64_t row, int ld, int hh, bool ok) {
+// rows [beg, beg + 32) x 32 features of a row-major array -> one tile in accumulator layout (zero beyond the segment).
+// `tile0` = the array's column block at row `beg` (wave-uniform: it stays in scalar registers), `off` = the lane's
+// el * ld + 4 * hh (one 32-bit register per leading dimension, shared by every array with that row stride)
+__device__ __forceinline__ v16f ld_tile(const float* tile0, int off, bool ok) {
   v16f t;
 #pragma unroll
   for (int r = 0; r < 16; ++r) t[r] = 0.f;
   if (ok) {
-    const float* p = col0 + row * ld + 4 * hh;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const v4f v = *reinterpret_cast<const v4f*>(p + 8 * q);
+      const v4f v = *reinterpret_cast<const v4f*>(tile0 + off + 8 * q);
 #pragma unroll
       for (int i = 0; i < 4; ++i) t[4 * q + i] = v[i];
     }
@@ -77,7 +81,11 @@ __device__ __forceinline__ void tile_gy_x1(const float* b1, const float* b0, con
         gy[a0 + a] += x1 * c1[i] + x0 * c0[i];
       }
     }
-    if ((g & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // at most two groups' cells in flight
+    // gy is consumed at the very end of the tile's program: unanchored, the optimizer sinks these sums below the MFMA
+    // phases and keeps every product tile alive until then (aa::anchor)
+#pragma unroll
+    for (int a = 0; a < na; ++a) anchor(gy[a0 + a]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -137,7 +145,126 @@ __device__ __forceinline__ void tile_q_accumulate(float* sP, const float* sY, co
   __builtin_amdgcn_wave_barrier();
 }
 
+// ---- weight pipeline of this kernel: the forward's (aa_fused_tile.h) with distance 1 and all eight waves staging -- block
+// S + 1 is requested from L2 at the START of step S (two / one 16-B loads per lane) and lands in LDS buffer (S + 1) & 1 at
+// its END, one raw barrier per step.  8 instead of 24 registers: two waves per SIMD hide the L2 latency that the forward,
+// at one wave per SIMD, covers with a distance-2 pipeline.
+struct TailPipe {
+  u32x4 r0, r1, r2;
+  u32x4* wbuf;  // [2][kWStep]
+  int tid, lane, wv;
+};
+template <class Args>
+__device__ __forceinline__ void tail_pipe_load(const Args& A, TailPipe& p, int t) {
+  const u32x4* s0 = static_cast<const u32x4*>(A.wstep[t][0]);  // elements 0..383 of the 768-element step
+  const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t][1]);  // elements 384..767
+  if constexpr (kTailWaves == 8) {
+    const u32x4* b0 = p.wv < 6 ? s0 : s1 - 384;                // (wave-uniform bases: the lane offset is shared)
+    p.r0 = b0[p.tid];
+    if (p.wv < 4) p.r1 = (s1 + 128)[p.tid];
+  } else {
+    const u32x4* mid = p.wv < 2 ? s0 + 256 : s1 - 128;
+    p.r0 = s0[p.tid];
+    p.r1 = mid[p.tid];
+    p.r2 = (s1 + 128)[p.tid];
+  }
+}
+__device__ __forceinline__ void tail_pipe_store(TailPipe& p, int b) {
+  u32x4* d = p.wbuf + b * kWStep;
+  d[p.tid] = p.r0;
+  if constexpr (kTailWaves == 8) {
+    if (p.wv < 4) d[512 + p.tid] = p.r1;
+  } else {
+    d[256 + p.tid] = p.r1;
+    d[512 + p.tid] = p.r2;
+  }
+}
+template <int S, int NS, class Args>
+__device__ __forceinline__ void tail_issue(const Args& A, TailPipe& p) {
+  tail_pipe_load(A, p, (S + 1) % NS);
+}
+template <int S>
+__device__ __forceinline__ void tail_commit(TailPipe& p) {
+  tail_pipe_store(p, (S + 1) & 1);
+  lds_barrier();
+  __builtin_amdgcn_sched_barrier(0);  // one scheduling region per step
+}
+// one 64-output linear layer on the wave's tile: KC 32-deep operand chunks op(kc), steps S0 .. S0 + KC - 1; epi(acc0, acc1)
+// pre(kc) runs at the start of step kc, before the step's operand is built: the place to REQUEST global operands of later
+// steps (this kernel is bound by exposed memory latency, not by issue: every operand is requested at least a step ahead)
+template <int S0, int NS, int KC, class Args, class PreF, class OpF, class EpiF>
+__device__ __forceinline__ void tail_layer(const Args& A, TailPipe& p, PreF&& pre, OpF&& op, EpiF&& epi) {
+  v16f acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    acc0[r] = 0.f;
+    acc1[r] = 0.f;
+  }
+  static_for<0, KC>([&](auto kcc) {
+    constexpr int S = S0 + decltype(kcc)::value;
+    tail_issue<S, NS>(A, p);
+    pre(kcc);
+    XSplit xs;
+    {
+      const v16f t = op(kcc);
+      xsplit_from_acc(t, xs);
+    }
+    fused_mma_step(p.wbuf + (S & 1) * kWStep, p.lane, xs, acc0, acc1);
+    tail_commit<S>(p);
+  });
+  epi(acc0, acc1);
+}
+
+// GM[j] (lane = k) = sum_ch g[j][ch] * W[ch][r(j)][k]: the forward's project_moments with the roles of the two indices
+// exchanged (g is handed over through sG [ch][kLdY]; the matrix [64 ch][R][64 k] arrives as 4 blocks of 16 channels through
+// the weight pipeline, steps S0 .. S0 + 3).  Rolled loops: this kernel runs two waves per SIMD on half the register file.
+template <int S0, int NS, int D, int R, class Args>
+__device__ __forceinline__ void project_gm(const Args& A, TailPipe& p, float* sG, const float* g, float* gm) {
+  const int lane = p.lane;
+#pragma unroll
+  for (int q = 0; q < (D + 3) / 4; ++q) {
+    v4f mm;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mm[i] = 4 * q + i < D ? g[4 * q + i] : 0.f;
+    *reinterpret_cast<v4f*>(sG + lane * kLdY + 4 * q) = mm;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < D; ++j) gm[j] = 0.f;
+  static_for<0, 4>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    constexpr int S = S0 + c;
+    tail_issue<S, NS>(A, p);
+    const float* wf = reinterpret_cast<const float*>(p.wbuf + (S & 1) * kWStep) + lane;
+#pragma unroll 2
+    for (int kk = 0; kk < 16; ++kk) {
+      float w[R], m[12];
+#pragma unroll
+      for (int r = 0; r < R; ++r) w[r] = wf[(kk * R + r) * 64];
+#pragma unroll
+      for (int q = 0; q < (D + 3) / 4; ++q) {
+        const v4f mm = *reinterpret_cast<const v4f*>(sG + (16 * c + kk) * kLdY + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m[4 * q + t] = mm[t];
+      }
+#pragma unroll
+      for (int j = 0; j < D; ++j) gm[j] += m[j] * w[r_of<0>(j)];
+    }
+    tail_commit<S>(p);
+  });
+}
+
 }  // namespace
+
+// Optional phase timing (build with AA_BUILD_DEFINES=-DAA_TAIL_TIMING): wave 0 of the middle workgroup stamps the shader
+// clock at every phase boundary of its first tile into a small global buffer that the launcher prints.
+#ifdef AA_TAIL_TIMING
+__device__ unsigned long long g_tail_ticks[32];
+#define AA_TTICK(i)                                                                   \
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0 && it == 1) g_tail_ticks[i] = __builtin_readcyclecounter();
+#else
+#define AA_TTICK(i)
+#endif
 
 template <class Sig0, class Sig1>
 __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(FusedTailArgs A) {
@@ -160,25 +287,27 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
   if (tid < A.num_types * A.num_types) sRm[tid] = A.rmax_recip[tid];
   if (tid >= 16 && tid < 24) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 16] : 0.f;
   for (int i = tid; i < ntab; i += 64 * kTailWaves) sTab[i] = A.emb_tab[i];
-  FusedPipe p;
+  TailPipe p;
   p.wbuf = wbuf;
   p.tid = tid;
   p.lane = lane;
-  p.stager = wv < 4;
-  if (p.stager) {
-    u32x4 r[3];
-    pipe_load(A, tid, 0, r);
-    pipe_store(wbuf, 0, tid, r);
-    pipe_load(A, tid, 1, p.rb);  // (step 1 lands in LDS at the end of step 0)
-  }
-  float wp0[Sig0::P], wp1[Sig1::P];
+  p.wv = __builtin_amdgcn_readfirstlane(wv);
+  tail_pipe_load(A, p, 0);
+  tail_pipe_store(p, 0);
+  // (the path weights are re-read per tile -- L1 / L2 hits -- instead of living in 14 registers across the MFMA phases)
+  auto load_wp = [&](float* wp0, float* wp1) {
 #pragma unroll
-  for (int q = 0; q < Sig0::P; ++q) wp0[q] = A.coupling ? A.tpw0[lane * Sig0::P + q] : A.tpw0[q];
+    for (int q = 0; q < Sig0::P; ++q) wp0[q] = A.coupling ? A.tpw0[lane * Sig0::P + q] : A.tpw0[q];
 #pragma unroll
-  for (int q = 0; q < Sig1::P; ++q) wp1[q] = A.coupling ? A.tpw1[lane * Sig1::P + q] : A.tpw1[q];
+    for (int q = 0; q < Sig1::P; ++q) wp1[q] = A.coupling ? A.tpw1[lane * Sig1::P + q] : A.tpw1[q];
+  };
   lds_barrier();  // tables + first weight step staged
   const int64_t ngroups = (A.atom_end - A.atom0 + kTailWaves - 1) / kTailWaves;
   for (int64_t it = 0; blockIdx.x + it * gridDim.x < ngroups; ++it) {
+    // (the staging loads' lane offset is made opaque per iteration: otherwise the 64-bit addresses of all 16 weight blocks are
+    //  hoisted out of this loop as loop invariants and live in -- spilled -- registers across the whole tile program)
+    asm volatile("" : "+v"(p.tid));
+    AA_TTICK(0)
     const int64_t atom = A.atom0 + (int64_t(blockIdx.x) + it * gridDim.x) * kTailWaves + wv;
     const bool atom_ok = atom < A.atom_end;
     int beg = 0, cnt = 0;
@@ -189,19 +318,37 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
     beg = __builtin_amdgcn_readfirstlane(beg);
     cnt = __builtin_amdgcn_readfirstlane(cnt);
     const bool row_ok = el < cnt;
-    const int64_t e = int64_t(beg) + el;
-    // ---- geometry of the lane's edge: unit vector + length as the forward left them; harmonics re-evaluated from it
-    float Y[D], nx = 1.f, ny = 0.f, nz = 0.f, rr = 1.f;
-    int pair = 0, nbr = 0;
+    const int64_t row0 = beg;                 // (wave-uniform: array bases at this row stay in scalar registers)
+    const int64_t e = row0 + el;
+    const int off64 = el * 64 + 4 * hh, offw = el * (64 * R) + 4 * hh, offg = el * A.ld_gtb + 4 * hh;
+    // ---- REQUEST everything the first phases read, then compute: unit vector + length and the neighbor (forward), the
+    //      atom's x2s blocks, the two scalar-gradient rows, the first irrep of w0
+    v4f vv4 = {1.f, 0.f, 0.f, 1.f};
+    int nbr = 0;
     if (row_ok) {
-      const v4f vv4 = *reinterpret_cast<const v4f*>(A.vec + 4 * e);
-      nx = vv4[0];
-      ny = vv4[1];
-      nz = vv4[2];
-      rr = vv4[3];
+      vv4 = *reinterpret_cast<const v4f*>(A.vec + 4 * e);
       nbr = A.nbr[e];
-      pair = A.types[atom] * A.num_types + A.types[nbr];
     }
+    float x2s0[D], x2s1[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      x2s0[j] = atom_ok ? A.x2s0[(atom * D + j) * 64 + lane] : 0.f;
+      x2s1[j] = atom_ok ? A.x2s1[(atom * D + j) * 64 + lane] : 0.f;
+    }
+    const float* gs0 = A.gscal0 + row0 * 64;
+    const float* gs1 = A.gscal1 + row0 * 64;
+    const float* w0t = A.w0 + row0 * (64 * R);
+    const v16f g0a = ld_tile(gs0, off64, row_ok), g0b = ld_tile(gs0 + 32, off64, row_ok);
+    const v16f g1a = ld_tile(gs1, off64, row_ok), g1b = ld_tile(gs1 + 32, off64, row_ok);
+    v16f wq[2][2];  // w0 tiles of the current / the next irrep
+    wq[0][0] = ld_tile(w0t, offw, row_ok);
+    wq[0][1] = ld_tile(w0t + 32, offw, row_ok);
+    AA_TTICK(1)
+    // ---- geometry of the lane's edge; harmonics re-evaluated from the stored unit vector
+    float Y[D];
+    const float nx = vv4[0], ny = vv4[1], nz = vv4[2], rr = vv4[3];
+    int pair = 0;
+    if (row_ok) pair = A.types[atom] * A.num_types + A.types[nbr];
     {
       float Yf[16];
       sh_eval<float>(Sig0::LMAX, nx, ny, nz, Yf);
@@ -213,15 +360,12 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
       }
     }
     // ---- per-atom vectors (lane = channel): v = dSig1/dtf1 (x2s1), B1 = Sig0^T_x1(v, x2s0), B0 = Sig0^T_x1(e_0, x2s0)
-    float vv[D];
     {
-      float x2s0[D], x2s1[D], B0[D], B1[D], e0[D], one[1] = {1.f};
+      float wp0[Sig0::P], wp1[Sig1::P], vv[D];
+      load_wp(wp0, wp1);
+      float B0[D], B1[D], e0[D], one[1] = {1.f};
 #pragma unroll
-      for (int j = 0; j < D; ++j) {
-        x2s0[j] = atom_ok ? A.x2s0[(atom * D + j) * 64 + lane] : 0.f;
-        x2s1[j] = atom_ok ? A.x2s1[(atom * D + j) * 64 + lane] : 0.f;
-        e0[j] = j == 0 ? 1.f : 0.f;
-      }
+      for (int j = 0; j < D; ++j) e0[j] = j == 0 ? 1.f : 0.f;
       Sig1::template bx1<float>(one, x2s1, wp1, vv);
       Sig0::template bx1<float>(vv, x2s0, wp0, B1);
       Sig0::template bx1<float>(e0, x2s0, wp0, B0);
@@ -232,10 +376,9 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
       }
       __builtin_amdgcn_wave_barrier();
     }
-    // ---- the two scalar-gradient rows of the lane's edge (operands of every later phase)
-    const v16f g0a = ld_tile(A.gscal0, e, 64, hh, row_ok), g0b = ld_tile(A.gscal0 + 32, e, 64, hh, row_ok);
-    const v16f g1a = ld_tile(A.gscal1, e, 64, hh, row_ok), g1b = ld_tile(A.gscal1 + 32, e, 64, hh, row_ok);
-    // ---- per irrep: t_l = g_l * w0_r  ->  dE/dY (x1 path, per edge)  and  Q_l (per atom)
+    AA_TTICK(2)
+    AA_TTICK(3)
+    // ---- per irrep: t_l = g_l * w0_r  ->  dE/dY (x1 path, per edge)  and  Q_l (per atom); the next irrep's w0 tiles are in flight
     float gy[D], Q1[D], Q0[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -245,7 +388,12 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
     }
     static_for<0, R>([&](auto rr_) {
       constexpr int r = decltype(rr_)::value;
-      const v16f wa = ld_tile(A.w0 + r * 64, e, 64 * R, hh, row_ok), wb = ld_tile(A.w0 + r * 64 + 32, e, 64 * R, hh, row_ok);
+      if constexpr (r + 1 < R) {
+        wq[(r + 1) & 1][0] = ld_tile(w0t + (r + 1) * 64, offw, row_ok);
+        wq[(r + 1) & 1][1] = ld_tile(w0t + (r + 1) * 64 + 32, offw, row_ok);
+      }
+      const v16f& wa = wq[r & 1][0];
+      const v16f& wb = wq[r & 1][1];
       v16f t1a, t1b, t0a, t0b;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -259,9 +407,18 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
       tile_q_accumulate<r>(sP, sY, t0a, t0b, lane, Q0);
       __builtin_amdgcn_sched_barrier(0);
     });
+    AA_TTICK(4)
+    // ---- REQUEST the two-body gradient tiles (first two operand chunks of R6): in flight during the per-atom phase
+    const float* gtb = A.g_tb + row0 * A.ld_gtb;
+    v16f tb0 = ld_tile(gtb, offg, row_ok), tb1 = ld_tile(gtb + 32, offg, row_ok);
     // ---- per atom: d x2s0 = Sig0^T_x2(v, Q1) + Sig0^T_x2(e_0, Q0), scaled; GM[j][k] = sum_ch d x2s0[j][ch] Wenv0^T[r(j)][ch][k]
     float gm[D];
     {
+      float wp0[Sig0::P], wp1[Sig1::P], vv[D], x21[D], one[1] = {1.f};
+      load_wp(wp0, wp1);
+#pragma unroll
+      for (int j = 0; j < D; ++j) x21[j] = atom_ok ? A.x2s1[(atom * D + j) * 64 + lane] : 0.f;
+      Sig1::template bx1<float>(one, x21, wp1, vv);  // (v again: 9 registers less across the edge phase)
       float ga[D], gb[D], e0[D], g2[D];
 #pragma unroll
       for (int j = 0; j < D; ++j) e0[j] = j == 0 ? 1.f : 0.f;
@@ -269,28 +426,48 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
       Sig0::template bx2<float>(e0, Q0, wp0, gb);
 #pragma unroll
       for (int j = 0; j < D; ++j) g2[j] = (ga[j] + gb[j]) * A.sf;
-      project_moments<S_GM, NS, D, R>(A, p, sP, g2, 1.f, gm);
+    AA_TTICK(5)
+      project_gm<S_GM, NS, D, R>(A, p, sP, g2, gm);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < D; ++j) sGM[j * 64 + lane] = gm[j];
       __builtin_amdgcn_wave_barrier();
     }
-    // ---- R6: g_emb = [g_two_body | g_w0] @ G0^T + g_aenv,  g_aenv[e][k] = sum_j Y[e][j] GM[j][k];  dE/dY of the env path rides along
+    AA_TTICK(6)
+    // ---- R6: g_emb = [g_two_body | g_w0] @ G0^T + g_aenv,  g_aenv[e][k] = sum_j Y[e][j] GM[j][k];  dE/dY of the env path rides
+    //      along.  Operand chunks in the order  two-body (2) | channel half 0 of every irrep | channel half 1 of every irrep
+    //      (the weight program follows, fused_bwd_tail_chunk_order): each half's two gradient tiles are read again -- L2 hits,
+    //      this wave read them a moment ago -- once, a step or more ahead of their first use, instead of being held in 64
+    //      registers across the per-atom phases.
     v16f k0, k1;
-    fused_layer<S_R6, NS, 2 + 2 * R, 2>(
+    v16f gh1[2], gh0[2], ea, eb;  // [half]: gradient tiles of the channel half being consumed
+    tail_layer<S_R6, NS, 2 + 2 * R>(
         A, p,
-        [&](auto kc) -> v16f {
+        [&](auto kc) {
           constexpr int k = decltype(kc)::value;
-          if constexpr (k < 2) {
-            return ld_tile(A.g_tb + 32 * k, e, A.ld_gtb, hh, row_ok);
-          } else {
-            constexpr int r = (k - 2) >> 1, h = (k - 2) & 1;
-            if constexpr (h == 0) return tile_gw0<r, 0>(sB1 + 4 * hh, sB0 + 4 * hh, Y, g1a, g0a);
-            return tile_gw0<r, 1>(sB1 + 4 * hh, sB0 + 4 * hh, Y, g1b, g0b);
+          if constexpr (k == 0) {
+            gh1[0] = ld_tile(gs1, off64, row_ok);
+            gh0[0] = ld_tile(gs0, off64, row_ok);
+          } else if constexpr (k == R + 1) {  // (the last half-0 chunk is step R + 1)
+            gh1[1] = ld_tile(gs1 + 32, off64, row_ok);
+            gh0[1] = ld_tile(gs0 + 32, off64, row_ok);
+          } else if constexpr (k == 2 * R + 1) {
+            ea = ld_tile(A.emb + row0 * 64, off64, row_ok);
+            eb = ld_tile(A.emb + row0 * 64 + 32, off64, row_ok);
           }
         },
-        [&](auto, const v16f& a0, const v16f& a1) {
-          const v16f ea = ld_tile(A.emb, e, 64, hh, row_ok), eb = ld_tile(A.emb + 32, e, 64, hh, row_ok);
+        [&](auto kc) -> v16f {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (k == 0) {
+            return tb0;
+          } else if constexpr (k == 1) {
+            return tb1;
+          } else {
+            constexpr int h = (k - 2) / R, r = (k - 2) % R;
+            return tile_gw0<r, h>(sB1 + 4 * hh, sB0 + 4 * hh, Y, gh1[h], gh0[h]);
+          }
+        },
+        [&](const v16f& a0, const v16f& a1) {
           k0 = a0;
           k1 = a1;
           const float* gmv = sGM + 4 * hh;
@@ -309,25 +486,32 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
               }
             }
             gy[j] += s;
-            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            anchor(gy[j]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         });
+    // ---- REQUEST the pre-activation tiles of R7's epilogue and the layer-1 dE/dY slot of the final sum
+    const v16f za = ld_tile(A.se_h + row0 * 64, off64, row_ok), zb = ld_tile(A.se_h + row0 * 64 + 32, off64, row_ok);
+    float ge1[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) ge1[j] = (A.gsh_env1 && row_ok && hh == 0) ? A.gsh_env1[e * D + j] : 0.f;
+    AA_TTICK(7)
     // ---- R7: g_h = (g_emb @ W_e1^T) * silu'(h_e)
-    fused_layer<S_R7, NS, 2, 2>(
-        A, p, [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-        [&](auto, const v16f& a0, const v16f& a1) {
-          const v16f za = ld_tile(A.se_h, e, 64, hh, row_ok), zb = ld_tile(A.se_h + 32, e, 64, hh, row_ok);
+    tail_layer<S_R7, NS, 2>(
+        A, p, [](auto) {}, [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+        [&](const v16f& a0, const v16f& a1) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             k0[i] = a0[i] * dsilu(za[i]);
             k1[i] = a1[i] * dsilu(zb[i]);
           }
         });
+    AA_TTICK(8)
     // ---- R8: g_emb0 = g_h @ W_e0^T, contracted with the two-body table of the lane's type pair to the 8 basis sums
     float tsum[8];
-    fused_layer<S_R8, NS, 2, 2>(
-        A, p, [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-        [&](auto, const v16f& a0, const v16f& a1) {
+    tail_layer<S_R8, NS, 2>(
+        A, p, [](auto) {}, [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+        [&](const v16f& a0, const v16f& a1) {
           const float* tb = sTab + pair * 512 + 4 * hh;
 #pragma unroll
           for (int n = 0; n < 8; ++n) {
@@ -342,6 +526,7 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
             tsum[n] = s;
           }
         });
+    AA_TTICK(9)
     // ---- both lane halves of a row: own + partner
     {
       float o8[8];
@@ -365,10 +550,8 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
     }
     if (row_ok && hh == 0) {
       // dE/dY of the layer-1 env path comes from tp_mom_bwd_last
-      if (A.gsh_env1) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) gy[j] += A.gsh_env1[e * D + j];
-      }
+      for (int j = 0; j < D; ++j) gy[j] += ge1[j];
       if (A.dvec) {
         // ---- edge_backward (aa_edge.hip): chain rule to the edge vector
         const float x = rr * sRm[pair];
@@ -406,6 +589,7 @@ __global__ __launch_bounds__(64 * kTailWaves, 1) void fused_bwd_tail_kernel(Fuse
         *reinterpret_cast<v4f*>(A.trev + 8 * e + 4) = v4f{tsum[4], tsum[5], tsum[6], tsum[7]};
       }
     }
+    AA_TTICK(10)
   }
 }
 
@@ -414,6 +598,9 @@ size_t fused_bwd_tail_lds_bytes(int num_types) {
 }
 
 int fused_bwd_tail_num_steps(int R) { return 4 + (2 + 2 * R) + 2 + 2; }
+
+// 32-deep operand chunk of the first linear layer (index into [two-body (2) | w0 irrep-major (2 R)]) consumed at its step i
+int fused_bwd_tail_chunk_order(int R, int i) { return i < 2 ? i : 2 + 2 * ((i - 2) % R) + (i - 2) / R; }
 
 int launch_fused_bwd_tail(int pair, const FusedTailArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;
@@ -443,6 +630,19 @@ int launch_fused_bwd_tail(int pair, const FusedTailArgs& a, hipStream_t stream) 
     return fail(AA_ERR_INVALID, "fused reverse tail: unsupported signature pair");
 #undef AA_TAIL_LAUNCH
   AA_CHECK_HIP(hipGetLastError());
+#ifdef AA_TAIL_TIMING
+  {
+    static int calls = 0;
+    if (++calls == 8) {  // a warm call
+      unsigned long long t[32];
+      AA_CHECK_HIP(hipStreamSynchronize(stream));
+      AA_CHECK_HIP(hipMemcpyFromSymbol(t, HIP_SYMBOL(g_tail_ticks), sizeof(t)));
+      static const char* nm[10] = {"geometry", "per-atom CG 1", "g tile loads", "irrep loop", "per-atom CG 2", "GM", "R6 + epilogue", "R7", "R8", "edge math"};
+      for (int i = 0; i < 10; ++i) fprintf(stderr, "[tail timing] %-16s %8llu cycles\n", nm[i], t[i + 1] - t[i]);
+      fprintf(stderr, "[tail timing] %-16s %8llu cycles\n", "total", t[10] - t[0]);
+    }
+  }
+#endif
   return AA_OK;
 }
 

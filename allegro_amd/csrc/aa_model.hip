@@ -155,9 +155,11 @@ struct aa_model_plan {
   size_t o_embtab;                   // [T*T][8][64] type_embed(c | pair) * basis_linear[n][c]
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
+#ifdef AA_EXPERIMENTAL_TAIL
   size_t o_wtk[AA_MAX_LAYERS];                      // ... and [u][R][ka] (the fused reverse tail streams it in 16-channel blocks)
-  bool fused_tail;                   // reverse: layer-0 tensor product reverse + first-stage / embed-MLP reverse + edge reverse as ONE
-                                     // per-atom-tile kernel whenever the fused forward runs (aa_fused_bwd.hip)
+#endif
+  bool fused_tail;                   // (experimental build only) reverse: layer-0 tensor product reverse + first-stage /
+                                     // embed-MLP reverse + edge reverse as ONE per-atom-tile kernel (aa_fused_bwd.hip); measured slower than the staged tail
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
   // optional hipGraph replay of the whole step (aa_model_plan_enable_graph): the launch sequence is captured once per
   // distinct argument set and replayed with one hipGraphLaunch -- for launch-bound (small) systems
@@ -338,7 +340,9 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
       const size_t ka = l == 0 ? S : cfg->latent_mlp_width;
       p->o_wk[l] = take(ka * p->W);
       p->o_wt[l] = take(ka * p->W);
+#ifdef AA_EXPERIMENTAL_TAIL
       p->o_wtk[l] = take(ka * p->W);
+#endif
     }
   }
   for (int l = 0; l < L; ++l) {
@@ -381,7 +385,11 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
                           u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0;
     p->fused_fwd = eligible && opt.fused_forward != 3;
-    p->fused_tail = p->fused_fwd && p->embed_fused && !opt.no_fused_tail;
+#ifdef AA_EXPERIMENTAL_TAIL
+    p->fused_tail = p->fused_fwd && p->embed_fused && (opt.fused_tail == 1 || opt.fused_tail == 2);
+#else
+    p->fused_tail = false;
+#endif
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
   }
   *out = p;
@@ -455,7 +463,9 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
     mix(p->o_tpw[l]);
     mix(p->env_mom ? p->o_wk[l] : 0);
     mix(p->env_mom ? p->o_wt[l] : 0);
+#ifdef AA_EXPERIMENTAL_TAIL
     mix(p->env_mom ? p->o_wtk[l] : 0);
+#endif
     mixm(p->latent[l]);
   }
   mixm(p->embed);
@@ -651,7 +661,9 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
             double v = rawm[size_t(k) * raw_w + S + (shared ? ch : ch * Rr + r)] * al;
             h[p->o_wk[l] + (size_t(k) * Rr + r) * u + ch] = v;
             h[p->o_wt[l] + (size_t(r) * u + ch) * ka + k] = v;
+#ifdef AA_EXPERIMENTAL_TAIL
             h[p->o_wtk[l] + (size_t(ch) * Rr + r) * ka + k] = v;
+#endif
           }
     };
     fill(0, raw->first_proj, S, S + We, mlp_alpha(c, 0, S, S + We - dWe));
@@ -1178,6 +1190,7 @@ struct Runner {
   }
   // the reverse tail in one launch (aa_fused_bwd.hip): same eligibility as the fused forward + the two-body table of the reverse
   bool use_fused_tail(const aa_graph* g) const { return use_fused_fwd(g) && p->fused_tail; }
+#ifdef AA_EXPERIMENTAL_TAIL
   int backward_fused_tail(const aa_graph* g, void* forces) {
     const aa_model_config& c = p->cfg;
     const int u = c.num_tensor;
@@ -1206,16 +1219,17 @@ struct Runner {
         ++ns;
       }
     }
-    auto add_layer = [&](const float* Wq, int KC) {  // one tile pair (64 outputs), KC 32-deep chunks
-      for (int kc = 0; kc < KC; ++kc) {
+    auto add_layer = [&](const float* Wq, int KC, bool tail_order) {  // one tile pair (64 outputs), KC 32-deep chunks
+      for (int i = 0; i < KC; ++i) {
+        const int kc = tail_order ? fused_bwd_tail_chunk_order(p->R, i) : i;  // (the kernel consumes the w0 chunks half-major)
         a.wstep[ns][0] = Wq + size_t(kc) * 64 * 24;
         a.wstep[ns][1] = Wq + (size_t(KC) + kc) * 64 * 24;
         ++ns;
       }
     };
-    add_layer(wf(p->o_g0tq), 2 + 2 * p->R);
-    add_layer(wf(p->embed.wtq[1]), 2);
-    add_layer(wf(p->embed.wtq[0]), 2);
+    add_layer(wf(p->o_g0tq), 2 + 2 * p->R, true);
+    add_layer(wf(p->embed.wtq[1]), 2, false);
+    add_layer(wf(p->embed.wtq[0]), 2, false);
     if (ns != fused_bwd_tail_num_steps(p->R) || ns > kFusedMaxSteps) return fail(AA_ERR_INVALID, "fused reverse tail: program length mismatch");
     a.tpw0 = wf(p->o_tpw[0]);
     a.tpw1 = wf(p->o_tpw[1]);
@@ -1233,7 +1247,7 @@ struct Runner {
     a.ld_gtb = p->SL1;
     a.gsh_env1 = bf(w.g_sh) + size_t(2) * size_t(E) * p->D;  // slot of the layer-1 env path (tp_mom_bwd_last)
     const bool gather = g->t_rowptr && g->t_perm;
-    const bool fuse_edge = gather && !p->opt.tail_keep_edge_backward;
+    const bool fuse_edge = gather && p->opt.fused_tail != 2;
     if (fuse_edge) {
       a.dvec = bf(w.dvec);
     } else {
@@ -1266,6 +1280,9 @@ struct Runner {
     }
     return AA_OK;
   }
+#else
+  int backward_fused_tail(const aa_graph*, void*) { return fail(AA_ERR_INVALID, "fused reverse tail: not part of this build"); }
+#endif
 
   int forward_fused(const aa_graph* g, const void* pos, void* atom_energy) {
     const aa_model_config& c = p->cfg;

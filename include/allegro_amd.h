@@ -201,9 +201,9 @@ typedef struct {
   int32_t f64_rows;        /* fp64 linear layers, row-resident kernels (operand rows read once): 0 where measured faster, 1 wherever applicable, 2 off */
   int32_t no_channel_padding; /* stacks whose channel count is not a multiple of 64, or with single hidden layers narrower than
                                * 64, are normally evaluated zero-padded (same results, tuned kernels); 1: keep them narrow */
-  int32_t no_fused_tail;   /* reverse pass: keep the staged tail (tp_mom_bwd_first, last chain, edge_backward) where the fused
-                            * per-atom-tile reverse tail (aa_fused_bwd.hip) would run                                  */
-  int32_t tail_keep_edge_backward; /* fused reverse tail: leave the edge reverse to edge_backward (A/B, tests)          */
+  int32_t fused_tail;      /* experimental builds only (AA_BUILD_EXPERIMENTAL=1): 1 = the fused per-atom-tile
+                            * reverse tail (aa_fused_bwd.hip) where the fused forward runs, 2 = ... leaving the edge reverse to
+                            * edge_backward; measured slower than the staged tail on MI355X, ignored by the product build      */
   int32_t poison_workspace; /* debugging: every step first fills the whole workspace with 0xFF bytes (NaN in fp32 and fp64), so
                              * that a kernel reading a cell no earlier kernel of the SAME step wrote shows up as NaN       */
 } aa_plan_options;

@@ -10,7 +10,13 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "allegro_amd", "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "liballegro_amd_emu.so")
-SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused_bwd.hip", "aa_model.hip", "aa_nl.hip"]
+SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_edge.hip", "aa_fused.hip", "aa_model.hip", "aa_nl.hip"]
+
+
+EXPERIMENTAL = os.environ.get("AA_BUILD_EXPERIMENTAL", "0")[:1] == "1"  # (see allegro_amd/build.py)
+if EXPERIMENTAL:
+    SOURCES = SOURCES[:SOURCES.index("aa_model.hip")] + ["aa_fused_bwd.hip"] + SOURCES[SOURCES.index("aa_model.hip"):]
+    LIB = os.path.join(OUT_DIR, "liballegro_amd_emu_experimental.so")
 
 
 def build_emu(force=False):
@@ -21,7 +27,7 @@ def build_emu(force=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     cxx = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-    cmd = [cxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-Wno-unused-function", "-Wno-psabi",
+    cmd = [cxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-Wno-unused-function", "-Wno-psabi"] + (["-DAA_EXPERIMENTAL_TAIL"] if EXPERIMENTAL else []) + [
            "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "emu_runtime.cpp"), "-o", LIB]
     subprocess.run(cmd, check=True)
