@@ -15,6 +15,7 @@ fallback: on a tensor that is not on a GPU these modules raise.
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -280,13 +281,20 @@ class HipContracter(torch.nn.Module):
         x2 = x2.reshape(-1, self.mul, self.base_dim2)
         sf = 1.0 if self.scatter_factor is None else float(self.scatter_factor)
         if self.training and torch.is_grad_enabled():
-            # training: scale + scatter + gather as differentiable torch ops around the arbitrarily differentiable
-            # contraction (ops.contract_differentiable) -- a force-matching loss differentiates the forces again.
-            # (The reference's accelerated contracters make the same split: fused kernel in eval mode, the general
-            # formulation when training, _flashallegro.py:725-755.)
-            x2s = torch.zeros((int(scatter_dim_size),) + tuple(x2.shape[1:]), dtype=x2.dtype, device=x2.device)
-            x2s = x2s.index_add(0, idxs.reshape(-1), sf * x2)
-            return self._contract(x1, x2s.index_select(0, idxs.reshape(-1)))
+            # training: the arbitrarily differentiable form of the WHOLE forward (scale + scatter + gather + contraction) on
+            # the segmented kernels (ops.contract_segments_differentiable) -- a force-matching loss differentiates the
+            # forces again.  (The reference's Triton contracter falls back to the eager formulation when training,
+            # _flashallegro.py:725-755; its cuEquivariance contracter keeps the fused gather, _cueq_contracter.py:84-131.)
+            if os.environ.get("AA_TRAIN_PER_EDGE", "0")[:1] == "1":  # (A/B: the first formulation, every edge its own segment)
+                x2s = torch.zeros((int(scatter_dim_size),) + tuple(x2.shape[1:]), dtype=x2.dtype, device=x2.device)
+                x2s = x2s.index_add(0, idxs.reshape(-1), sf * x2)
+                return self._contract(x1, x2s.index_select(0, idxs.reshape(-1)))
+            rowptr, eids = _SEGMENTS.get(idxs, scatter_dim_size, self.assume_sorted_idxs)
+            _require_gpu(self._get_lib(), x1, "HipContracter")
+            with _device_ctx(x1.device):
+                return ops.contract_segments_differentiable(x1, x2, self.weights, rowptr, eids, idxs, int(scatter_dim_size), sf,
+                                                            self._plan(x1.dtype, x1.device), self._lib_id, self.base_dim1,
+                                                            self.base_dim2, self.base_dim_out)
         if _is_tracing():
             # torch.export / torch.compile: no data pointers, no data-dependent Python -- the bookkeeping is one opaque
             # op with a fake kernel (ops.segments); plan handles are process-local, so a traced program is valid in

@@ -173,18 +173,36 @@ tp_forward.register_autograd(_backward, setup_context=_setup_context)
 # _flashallegro.py:725-755).  The scale + scatter + gather around the contraction (_contract.py:195-205) are plain
 # differentiable torch ops in this path.
 class _TriCtx:
-    """Static description shared by the four functions: plan handle, library id, dims."""
+    """Static description shared by the four functions: plan handle, library id, dims -- and, for the SEGMENTED form, the
+    scatter index in CSR form.  Segmented: the b operand enters through the symmetric linear map M = gather . scale .
+    scatter-sum over equal scatter index (allegro/nn/_strided/_contract.py:195-205), i.e. the form is
+    F(a, b, c; w) = T(a, M b, c; w).  Because M is linear and symmetric, F is again trilinear and the closure of its four
+    partial contractions under differentiation is the same as T's with  K(a, b) = T_k(a, M b),  I(c, b) = T_i(c, M b),
+    J(c, a) = M T_j(c, a),  W(c, a, b) = T_w(c, a, M b)  -- which are exactly what `aa_tp_forward` / `aa_tp_backward` /
+    `aa_tp_backward_weights` compute on true center segments (scale + scatter + gather fused into the kernels, one
+    workgroup per center atom instead of one per edge)."""
 
-    def __init__(self, plan: int, lib_id: int, d1: int, d2: int, dout: int):
+    def __init__(self, plan: int, lib_id: int, d1: int, d2: int, dout: int, segments=None):
         self.plan, self.lib_id, self.d1, self.d2, self.dout = plan, lib_id, d1, d2, dout
+        self.segments = segments  # None | (rowptr int32 [N+1], eids int32 [E] | None, idxs int64 [E], num_atoms, scatter_factor)
 
 
 def _edge_rowptr(E: int, device) -> torch.Tensor:
     return torch.arange(E + 1, dtype=torch.int32, device=device)
 
 
+def _segment_sum(t: _TriCtx, b):  # x2s = scale * scatter-sum of b over the scatter index  [N,u,d2]
+    _rowptr, _eids, idxs, n, sf = t.segments
+    x2s = torch.zeros((n,) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device)
+    return x2s.index_add_(0, idxs, b.detach()).mul_(sf)
+
+
 def _raw_out(t: _TriCtx, a, b, w):  # [E,u,dout]
     E = a.shape[0]
+    if t.segments is not None:
+        rowptr, eids, _idxs, n, sf = t.segments
+        out, _ = torch.ops.allegro_amd.tp_forward(a.detach(), b.detach(), w.detach(), rowptr, eids, n, sf, t.plan, t.lib_id, t.d2, t.dout)
+        return out
     out, _ = torch.ops.allegro_amd.tp_forward(a.detach(), b.detach(), w.detach(), _edge_rowptr(E, a.device), None, E, 1.0,
                                               t.plan, t.lib_id, t.d2, t.dout)
     return out
@@ -192,12 +210,18 @@ def _raw_out(t: _TriCtx, a, b, w):  # [E,u,dout]
 
 def _raw_in_grads(t: _TriCtx, c, a, b, w):  # (d/d a [E,u,d1], d/d b [E,u,d2])
     E = a.shape[0]
+    if t.segments is not None:
+        rowptr, eids, _idxs, n, sf = t.segments
+        return torch.ops.allegro_amd.tp_backward(c.detach(), a.detach(), _segment_sum(t, b), w.detach(), rowptr, eids, n, sf, t.plan, t.lib_id)
     return torch.ops.allegro_amd.tp_backward(c.detach(), a.detach(), b.detach(), w.detach(), _edge_rowptr(E, a.device), None, E,
                                              1.0, t.plan, t.lib_id)
 
 
 def _raw_wgrad(t: _TriCtx, c, a, b, w_like):  # [shape of w]
     E = a.shape[0]
+    if t.segments is not None:
+        rowptr, eids, _idxs, n, _sf = t.segments
+        return torch.ops.allegro_amd.tp_backward_weights(c.detach(), a.detach(), _segment_sum(t, b), w_like.detach(), rowptr, eids, n, t.plan, t.lib_id)
     return torch.ops.allegro_amd.tp_backward_weights(c.detach(), a.detach(), b.detach(), w_like.detach(),
                                                      _edge_rowptr(E, a.device), None, E, t.plan, t.lib_id)
 
@@ -215,7 +239,9 @@ class _TriK(torch.autograd.Function):
     def backward(ctx, g):
         a, b, w = ctx.saved_tensors
         t = ctx.t
-        return _TriI.apply(g, b, w, t), _TriJ.apply(g, a, w, t), _TriW.apply(g, a, b, w, t), None
+        n = ctx.needs_input_grad  # (only the partial contractions some gradient actually needs are launched)
+        return (_TriI.apply(g, b, w, t) if n[0] else None, _TriJ.apply(g, a, w, t) if n[1] else None,
+                _TriW.apply(g, a, b, w, t) if n[2] else None, None)
 
 
 class _TriI(torch.autograd.Function):
@@ -232,7 +258,9 @@ class _TriI(torch.autograd.Function):
     def backward(ctx, h):
         c, b, w = ctx.saved_tensors
         t = ctx.t
-        return _TriK.apply(h, b, w, t), _TriJ.apply(c, h, w, t), _TriW.apply(c, h, b, w, t), None
+        n = ctx.needs_input_grad
+        return (_TriK.apply(h, b, w, t) if n[0] else None, _TriJ.apply(c, h, w, t) if n[1] else None,
+                _TriW.apply(c, h, b, w, t) if n[2] else None, None)
 
 
 class _TriJ(torch.autograd.Function):
@@ -249,7 +277,9 @@ class _TriJ(torch.autograd.Function):
     def backward(ctx, h):
         c, a, w = ctx.saved_tensors
         t = ctx.t
-        return _TriK.apply(a, h, w, t), _TriI.apply(c, h, w, t), _TriW.apply(c, a, h, w, t), None
+        n = ctx.needs_input_grad
+        return (_TriK.apply(a, h, w, t) if n[0] else None, _TriI.apply(c, h, w, t) if n[1] else None,
+                _TriW.apply(c, a, h, w, t) if n[2] else None, None)
 
 
 class _TriW(torch.autograd.Function):
@@ -265,10 +295,21 @@ class _TriW(torch.autograd.Function):
     def backward(ctx, hw):
         c, a, b = ctx.saved_tensors
         t = ctx.t
-        return _TriK.apply(a, b, hw, t), _TriI.apply(c, b, hw, t), _TriJ.apply(c, a, hw, t), None, None
+        n = ctx.needs_input_grad
+        return (_TriK.apply(a, b, hw, t) if n[0] else None, _TriI.apply(c, b, hw, t) if n[1] else None,
+                _TriJ.apply(c, a, hw, t) if n[2] else None, None, None)
 
 
 def contract_differentiable(x1: torch.Tensor, x2_gathered: torch.Tensor, weights: torch.Tensor, plan: int, lib_id: int,
                             d1: int, d2: int, dout: int) -> torch.Tensor:
     """`Contracter._contract(x1, x2)` (allegro/nn/_strided/_contract.py:213-251) with derivatives of every order."""
     return _TriK.apply(x1.contiguous(), x2_gathered.contiguous(), weights, _TriCtx(plan, lib_id, d1, d2, dout))
+
+
+def contract_segments_differentiable(x1: torch.Tensor, x2: torch.Tensor, weights: torch.Tensor, rowptr: torch.Tensor,
+                                     eids: Optional[torch.Tensor], idxs: torch.Tensor, num_atoms: int, scatter_factor: float,
+                                     plan: int, lib_id: int, d1: int, d2: int, dout: int) -> torch.Tensor:
+    """`Contracter.forward(x1, x2, idxs, N)` (_contract.py:185-211: scale + scatter + gather + contraction) with
+    derivatives of every order, on the segmented kernels (see _TriCtx): what training mode runs."""
+    t = _TriCtx(plan, lib_id, d1, d2, dout, (rowptr, eids, idxs.reshape(-1), int(num_atoms), float(scatter_factor)))
+    return _TriK.apply(x1.contiguous(), x2.contiguous(), weights, t)

@@ -310,6 +310,78 @@ def gpu_reference_baseline(g: G.Graph, cfg, model, dev, target_edges=60000, reps
                        f"{t * 1e3:.1f} ms per pass")
 
 
+def train_op_bench(args, dev):
+    """`--mode train-op`: the training step of the OPERATOR seam (what `nequip-train` runs through a model whose
+    Contracters were swapped by `enable_HipContracter`): one `HipContracter.forward` in training mode on the workload's
+    neighbor list + a force-matching style loss (a function of the first derivatives w.r.t. x1, differentiated again
+    w.r.t. the path weights and both inputs) -- forward + double backward.  Reported for the segmented differentiable
+    form (default), the first formulation with every edge its own segment (AA_TRAIN_PER_EDGE=1) and the eager PyTorch-ROCm
+    port of the reference's Contracter (oracle, baseline only; on a bounded edge sample: its [E,u,9,9] intermediates)."""
+    from allegro_amd.nn import HipContracter
+
+    g, cfg = make_workload(args.workload)
+    u, l_max = cfg["num_tensor_features"], cfg["l_max"]
+    dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
+    irreps = " + ".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(l_max + 1))
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        c = HipContracter(irreps, irreps, irreps, mul=u, path_channel_coupling=True,
+                          scatter_factor=1.0 / float(np.sqrt(cfg["avg_num_neighbors"]))).to(dev)
+    finally:
+        torch.set_default_dtype(prev)
+    c.train()
+    c.assume_sorted_idxs = True
+    D = (l_max + 1) ** 2
+    N = g.num_atoms
+
+    def run(E, fwd, steps, warmup):
+        idxs = torch.tensor(g.edge_index[0][:E], device=dev)
+        gen = torch.Generator(device=dev).manual_seed(1)
+        x1 = torch.randn(E, u, D, dtype=dtype, device=dev, generator=gen, requires_grad=True)
+        x2 = torch.randn(E, u, D, dtype=dtype, device=dev, generator=gen, requires_grad=True)
+
+        def step():
+            y = fwd(x1, x2, idxs)
+            (g1,) = torch.autograd.grad(y.square().sum(), x1, create_graph=True)  # "forces"
+            loss = (g1 ** 2).sum() + y.sum()
+            return torch.autograd.grad(loss, [c.weights, x1, x2])
+
+        for _ in range(warmup):
+            out = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, [o.detach() for o in out]
+
+    E = g.num_edges
+    res = {}
+    os.environ.pop("AA_TRAIN_PER_EDGE", None)
+    ms_seg, out_seg = run(E, lambda a, b, i: c(a, b, i, N), args.steps, args.warmup)
+    res["segmented"] = dict(ms_per_step=ms_seg, edges=E, edges_per_s=E / ms_seg * 1e3)
+    os.environ["AA_TRAIN_PER_EDGE"] = "1"
+    ms_pe, out_pe = run(E, lambda a, b, i: c(a, b, i, N), max(2, args.steps // 4), 1)
+    os.environ.pop("AA_TRAIN_PER_EDGE", None)
+    res["per_edge_segments"] = dict(ms_per_step=ms_pe, edges=E, edges_per_s=E / ms_pe * 1e3)
+    agree = max(float((a - b).abs().max() / max(1.0, float(b.abs().max()))) for a, b in zip(out_seg, out_pe))
+    from oracle import restatement as R  # (baseline leg only)
+
+    Es = min(E, 20000)
+    ms_eager, _ = run(Es, lambda a, b, i: R.contracter_forward(a, b, i, N, c.weights, c.w3j, True, c.scatter_factor), max(2, args.steps // 4), 1)
+    res["eager_port_gpu"] = dict(ms_per_step=ms_eager, edges=Es, edges_per_s=Es / ms_eager * 1e3, kind="port")
+    line = dict(metric="Contracter training step (forward + double backward of a force-matching loss), edges/s", mode="train-op",
+                value=res["segmented"]["edges_per_s"], unit="edges/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
+                ms_per_step=ms_seg, higher_is_better=True, dtype="f32" if dtype == torch.float32 else "f64", data="synthetic",
+                config=dict(workload=f"{args.workload}: {N} atoms / {E} edges, {irreps} x {irreps} -> {irreps}, {u} channels, coupled path weights"),
+                variants=res, speedup_vs_per_edge_segments=res["segmented"]["edges_per_s"] / res["per_edge_segments"]["edges_per_s"],
+                speedup_vs_eager_port=res["segmented"]["edges_per_s"] / res["eager_port_gpu"]["edges_per_s"],
+                max_rel_diff_between_hip_variants=agree)
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,7 +401,14 @@ def main():
     ap.add_argument("--shard-sweep", type=int, default=0, metavar="W",
                     help="analysis only: time every rank's compact shard of a W-way partition on this one GPU, one after "
                          "the other (load balance: max / mean shard time; no collective), print one JSON line and exit")
+    ap.add_argument("--mode", default="step", choices=["step", "train-op"],
+                    help="step: the whole hot path (default, the driver's contract); train-op: training step of the operator seam")
     args = ap.parse_args()
+    if args.mode == "train-op":
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        return train_op_bench(args, dev)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
