@@ -35,11 +35,6 @@ struct FusedPipe {
   bool stager;  // this wave takes part in staging the weight blocks (the first four waves of the workgroup: 256 x 48 B = 12 KB)
 };
 
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 
 // (every load is wave-uniform base + lane offset: the bases stay in SGPRs and all loads of the program share ONE
 //  offset register -- with per-lane base selects the compiler hoists ~140 loop-invariant 64-bit address pairs out of

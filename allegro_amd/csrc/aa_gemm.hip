@@ -1422,7 +1422,11 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
           mma_step(step & 1, x1, x2, x3, acc0, acc1);
         }
         stage_write((step + 1) & 1, r);
+#ifdef AA_CHAIN_SYNCTHREADS
         __syncthreads();
+#else
+        lds_barrier();  // (not __syncthreads(): its vmcnt(0) would wait for the operand rows just requested for the NEXT step)
+#endif
         ++step;
       }
       epilogue(L.t[nt], acc0);

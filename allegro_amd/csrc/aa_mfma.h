@@ -60,6 +60,14 @@ __device__ __forceinline__ void xsplit_from_acc(const v16f& acc, XSplit& x) {
   split3_pack(a, x.l1, x.l2, x.l3);
 }
 
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it carries no vmcnt(0), so global loads that
+// were requested ahead of their use (operand rows, weight blocks) stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int kWStep = 2 * 6 * 64;  // u32x4 per staged weight step (tile pair x 32-deep chunk x 3 levels)
 
 // ---- helpers shared by the kernels that work on 32-edge tiles in the accumulator layout (aa_fused.hip, aa_tp_mfma.hip,
