@@ -111,6 +111,10 @@ class AllegroLib:
         L.aa_tp_plan_create.argtypes = [C.POINTER(TpDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.aa_tp_plan_destroy.argtypes = [C.c_void_p]
         L.aa_tp_plan_destroy.restype = None
+        L.aa_tp_plan_use_general_kernels.argtypes = [C.c_void_p, C.c_int]
+        L.aa_tp_plan_use_general_kernels.restype = C.c_int
+        L.aa_tp_plan_is_specialised.argtypes = [C.c_void_p]
+        L.aa_tp_plan_is_specialised.restype = C.c_int
         L.aa_tp_forward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_tp_backward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -158,6 +162,8 @@ class AllegroLib:
     def tp_plan_create(self, desc: TpDesc, dtype: int) -> int:
         h = C.c_void_p()
         self.check(self.lib.aa_tp_plan_create(C.byref(desc), dtype, C.byref(h)), "aa_tp_plan_create")
+        if os.environ.get("AA_TP_GENERIC", "0")[:1] == "1":  # A/B and tests: the table-driven kernels also for generated signatures
+            self.check(self.lib.aa_tp_plan_use_general_kernels(h, 1), "aa_tp_plan_use_general_kernels")
         return h.value
 
     def tp_plan_destroy(self, h):

@@ -535,6 +535,27 @@ template <typename T>
 int launch_tp_chain_bwd_first(int pair, const TpChainArgs& a, hipStream_t stream);
 
 int find_spec_sig(const aa_tp_desc& d);  // signature id or -1
+
+// operator seam on the generated signatures (aa_tp_dense.hip): the tensors of aa_tp_forward / aa_tp_backward in the
+// reference's strided layout [E, u, d]
+struct TpDenseArgs {
+  int64_t E, N;
+  const int32_t* rowptr;
+  const int32_t* eids;   // stable sort permutation of an unsorted scatter index, or nullptr
+  int u, coupling;
+  double sf;             // scatter factor
+  const void* x1;        // [E,u,d1]
+  const void* x2;        // [E,u,d2]   (forward)
+  const void* weights;   // [u,P] | [P]
+  void* x2s;             // [N,u,d2]   forward: written; backward: read
+  void* out;             // [E,u,dout] (forward)
+  const void* gout;      // [E,u,dout] (backward)
+  void* gx1;             // [E,u,d1]   (backward)
+  void* gx2;             // [E,u,d2]   (backward)
+};
+bool tp_dense_supported(int sig, int u, int dtype);
+template <typename T>
+int launch_tp_dense(int sig, bool backward, const TpDenseArgs& a, hipStream_t stream);
 template <typename T>
 int launch_tp_spec_fwd(int sig, const TpSpecFwdArgs& a, hipStream_t stream);
 template <typename T>

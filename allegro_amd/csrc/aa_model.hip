@@ -24,6 +24,8 @@ struct aa_tp_plan {
   aa_dtype dtype;
   TpLayerDev dev;
   std::vector<void*> owned;
+  int spec_sig = -1;           // generated signature of this layer (aa_cg_gen.h) or -1
+  bool dense_spec = false;     // forward / input gradients on the specialised dense-operand kernels (aa_tp_dense.hip)
 };
 
 extern "C" const char* aa_last_error(void) { return g_err.c_str(); }
@@ -40,9 +42,19 @@ extern "C" int aa_tp_plan_create(const aa_tp_desc* desc, aa_dtype dtype, aa_tp_p
     delete p;
     return rc;
   }
+  p->spec_sig = find_spec_sig(*desc);
+  p->dense_spec = tp_dense_supported(p->spec_sig, desc->mul, dtype);
   *out = p;
   return AA_OK;
 }
+
+extern "C" int aa_tp_plan_use_general_kernels(aa_tp_plan* plan, int on) {
+  AA_REQUIRE(plan, "aa_tp_plan_use_general_kernels: null plan");
+  plan->dense_spec = !on && tp_dense_supported(plan->spec_sig, plan->dev.mul, plan->dtype);
+  return AA_OK;
+}
+
+extern "C" int aa_tp_plan_is_specialised(const aa_tp_plan* plan) { return plan && plan->dense_spec ? 1 : 0; }
 
 extern "C" void aa_tp_plan_destroy(aa_tp_plan* plan) {
   if (!plan) return;
@@ -54,6 +66,23 @@ extern "C" int aa_tp_forward(const aa_tp_plan* plan, int64_t E, int64_t N, const
                              const void* weights, const int32_t* rowptr, const int32_t* eids, double scatter_factor,
                              void* x2s, void* out, aa_stream stream) {
   AA_REQUIRE(plan && x1 && x2 && weights && rowptr && x2s && out, "aa_tp_forward: null argument");
+  if (plan->dense_spec) {
+    TpDenseArgs d{};
+    d.E = E;
+    d.N = N;
+    d.rowptr = rowptr;
+    d.eids = eids;
+    d.u = plan->dev.mul;
+    d.coupling = plan->dev.coupling;
+    d.sf = scatter_factor;
+    d.x1 = x1;
+    d.x2 = x2;
+    d.weights = weights;
+    d.x2s = x2s;
+    d.out = out;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return plan->dtype == AA_F32 ? launch_tp_dense<float>(plan->spec_sig, false, d, st) : launch_tp_dense<double>(plan->spec_sig, false, d, st);
+  }
   TpLayerFwdArgs a{};
   a.E = E;
   a.N = N;
@@ -73,6 +102,24 @@ extern "C" int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, cons
                               const void* weights, const int32_t* rowptr, const int32_t* eids, double scatter_factor,
                               const void* gout, void* gx1, void* gx2, aa_stream stream) {
   AA_REQUIRE(plan && x1 && x2s && weights && rowptr && gout && gx1 && gx2, "aa_tp_backward: null argument");
+  if (plan->dense_spec) {
+    TpDenseArgs d{};
+    d.E = E;
+    d.N = N;
+    d.rowptr = rowptr;
+    d.eids = eids;
+    d.u = plan->dev.mul;
+    d.coupling = plan->dev.coupling;
+    d.sf = scatter_factor;
+    d.x1 = x1;
+    d.weights = weights;
+    d.x2s = const_cast<void*>(x2s);
+    d.gout = gout;
+    d.gx1 = gx1;
+    d.gx2 = gx2;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return plan->dtype == AA_F32 ? launch_tp_dense<float>(plan->spec_sig, true, d, st) : launch_tp_dense<double>(plan->spec_sig, true, d, st);
+  }
   TpLayerBwdArgs a{};
   a.E = E;
   a.N = N;

@@ -59,6 +59,11 @@ typedef struct aa_tp_plan aa_tp_plan;
 /* host arrays in `desc` are copied; tables are uploaded to the current device */
 int aa_tp_plan_create(const aa_tp_desc* desc, aa_dtype dtype, aa_tp_plan** out);
 void aa_tp_plan_destroy(aa_tp_plan* plan);
+/* A plan whose descriptor equals one of the generated signatures of standard Allegro layers (and whose channel count is
+ * 64, 128 or 256) runs aa_tp_forward / aa_tp_backward on specialised kernels with compile-time Clebsch-Gordan code
+ * (aa_tp_dense.hip); on != 0 keeps the table-driven general kernels instead (A/B measurements, tests). */
+int aa_tp_plan_use_general_kernels(aa_tp_plan* plan, int on);
+int aa_tp_plan_is_specialised(const aa_tp_plan* plan); /* 1: aa_tp_forward / aa_tp_backward run the specialised kernels */
 
 /* Contracter.forward (_contract.py:185-211) on a center-sorted segment layout:
  *   x2s[n] = scatter_factor * sum_{s in [rowptr[n],rowptr[n+1])} x2[eid(s)]   (:195-204)

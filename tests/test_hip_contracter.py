@@ -79,3 +79,4 @@ def test_library_op_opcheck_and_compile_trace_on_gpu():
     got = torch.autograd.grad(torch.compile(f, backend="aot_eager", fullgraph=True)(x1, x2), [x1, x2])
     for a, b in zip(want, got):  # (the stand-alone operator's segment sums use atomics: equal to rounding, not bitwise)
         assert (a - b).abs().max().item() <= 1e-5 * max(1.0, float(a.abs().max()))
+
