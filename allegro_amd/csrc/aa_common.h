@@ -371,6 +371,11 @@ size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N);
 template <typename T>
 int launch_tp_layer_wgrad(const TpLayerDev& L, const TpLayerWgradArgs& a, hipStream_t stream);
 
+// slots (partial slabs) of the path-weight gradient, shared by the general and the dense kernels
+int tp_wgrad_slots(int64_t N);
+template <typename T>
+int launch_tp_wgrad_reduce(const void* partial, int nslots, int u, int P, int coupling, void* gw, hipStream_t stream);
+
 int build_tp_layer(const aa_tp_desc& d, TpLayerDev* out, std::vector<void*>* owned);
 
 // ---- specialised (compile-time CG table) layer kernels, channel-minor layouts (aa_tp_spec.hip)
@@ -556,6 +561,8 @@ struct TpDenseArgs {
 bool tp_dense_supported(int sig, int u, int dtype);
 template <typename T>
 int launch_tp_dense(int sig, bool backward, const TpDenseArgs& a, hipStream_t stream);
+template <typename T>
+int launch_tp_dense_wgrad(int sig, int u, int coupling, const TpLayerWgradArgs& a, hipStream_t stream);
 template <typename T>
 int launch_tp_spec_fwd(int sig, const TpSpecFwdArgs& a, hipStream_t stream);
 template <typename T>

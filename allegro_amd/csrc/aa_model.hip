@@ -159,6 +159,9 @@ extern "C" int aa_tp_backward_weights(const aa_tp_plan* plan, int64_t E, int64_t
   a.partial = workspace;
   a.gw = gweights;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plan->dense_spec)
+    return plan->dtype == AA_F32 ? launch_tp_dense_wgrad<float>(plan->spec_sig, plan->dev.mul, plan->dev.coupling, a, s)
+                                 : launch_tp_dense_wgrad<double>(plan->spec_sig, plan->dev.mul, plan->dev.coupling, a, s);
   return plan->dtype == AA_F32 ? launch_tp_layer_wgrad<float>(plan->dev, a, s) : launch_tp_layer_wgrad<double>(plan->dev, a, s);
 }
 

@@ -354,9 +354,21 @@ __global__ __launch_bounds__(256) void tp_layer_wgrad_reduce_kernel(const T* par
   }
 }
 
-static int wgrad_blocks(int64_t N) { return int(std::min<int64_t>(std::max<int64_t>(N, 1), 1024)); }
+int tp_wgrad_slots(int64_t N) { return int(std::min<int64_t>(std::max<int64_t>(N, 1), 1024)); }
+static int wgrad_blocks(int64_t N) { return tp_wgrad_slots(N); }
 
 size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N) { return size_t(wgrad_blocks(N)) * L.mul * L.num_paths; }
+
+template <typename T>
+int launch_tp_wgrad_reduce(const void* partial, int nslots, int u, int P, int coupling, void* gw, hipStream_t stream) {
+  const int nout = (coupling ? u : 1) * P;
+  hipLaunchKernelGGL(tp_layer_wgrad_reduce_kernel<T>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<const T*>(partial), nslots, u, P, coupling, static_cast<T*>(gw));
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+template int launch_tp_wgrad_reduce<float>(const void*, int, int, int, int, void*, hipStream_t);
+template int launch_tp_wgrad_reduce<double>(const void*, int, int, int, int, void*, hipStream_t);
 
 template <typename T>
 int launch_tp_layer_wgrad(const TpLayerDev& L, const TpLayerWgradArgs& a, hipStream_t stream) {
@@ -373,11 +385,7 @@ int launch_tp_layer_wgrad(const TpLayerDev& L, const TpLayerWgradArgs& a, hipStr
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(tp_layer_wgrad_kernel<T>, dim3((unsigned)nb), dim3(kWgThreads), smem, stream, L, a, apb);
   AA_CHECK_HIP(hipGetLastError());
-  const int nout = (L.coupling ? L.mul : 1) * L.num_paths;
-  hipLaunchKernelGGL(tp_layer_wgrad_reduce_kernel<T>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<const T*>(a.partial), nb, L.mul, L.num_paths, L.coupling, static_cast<T*>(a.gw));
-  AA_CHECK_HIP(hipGetLastError());
-  return AA_OK;
+  return launch_tp_wgrad_reduce<T>(a.partial, nb, L.mul, L.num_paths, L.coupling, a.gw, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -169,6 +169,42 @@ __global__ __launch_bounds__(256) void tp_dense_bwd_kernel(TpDenseArgs a) {
   for (int s = beg; s < end; ++s) run_store<T, D2>(static_cast<T*>(a.gx2) + (edge_of(s) * u + ws.ch0) * D2, r2, lane);
 }
 
+// Path-weight gradient: wave = (slot of consecutive center atoms, 64-channel slice); lane-private accumulators over the
+// slot's edges in CSR order, one partial [u][P] slab per slot, summed in slot order by the general path's reduce kernel
+// (aa_tp.hip) -- deterministic, no atomics.  (_contract.py:205-251 differentiated w.r.t. `weights`.)
+template <class Sig, typename T>
+__global__ __launch_bounds__(256) void tp_dense_wgrad_kernel(TpLayerWgradArgs a, int u, int nslots, int atoms_per_slot) {
+  constexpr int D1 = Sig::D1, D2 = Sig::D2, DOUT = Sig::DOUT, P = Sig::P;
+  const int lane = threadIdx.x & 63, wpa = u >> 6;
+  const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int slot = gwave / wpa, ch0 = (gwave % wpa) * 64;
+  T* sS = reinterpret_cast<T*>(aa_smem) + size_t(threadIdx.x >> 6) * 64 * patch_cols<Sig>();
+  if (slot >= nslots) return;  // (whole waves)
+  const int64_t n0 = int64_t(slot) * atoms_per_slot;
+  const int64_t n1 = n0 + atoms_per_slot < a.N ? n0 + atoms_per_slot : a.N;
+  const T* X1 = static_cast<const T*>(a.x1);
+  const T* GO = static_cast<const T*>(a.gout);
+  T acc[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) acc[p] = T(0);
+  for (int64_t n = n0; n < n1; ++n) {
+    const int beg = __builtin_amdgcn_readfirstlane(a.rowptr[n]), end = __builtin_amdgcn_readfirstlane(a.rowptr[n + 1]);
+    if (beg >= end) continue;
+    T x2s[D2];
+    run_load<T, D2>(static_cast<const T*>(a.x2s) + (n * u + ch0) * D2, sS, lane, x2s);
+    for (int s = beg; s < end; ++s) {
+      const int64_t e = a.eids ? a.eids[s] : s;
+      T go[DOUT], x1[D1];
+      run_load<T, DOUT>(GO + (e * u + ch0) * DOUT, sS, lane, go);
+      run_load<T, D1>(X1 + (e * u + ch0) * D1, sS, lane, x1);
+      Sig::template bw<T>(go, x1, x2s, acc);
+    }
+  }
+  T* part = static_cast<T*>(a.partial) + (int64_t(slot) * u + ch0 + lane) * P;
+#pragma unroll
+  for (int p = 0; p < P; ++p) part[p] = acc[p];
+}
+
 bool tp_dense_supported(int sig, int u, int dtype) {
   if (sig < 0 || sig >= cg::kNumSigs || u < 64 || u > 256 || (u & 63)) return false;
   if (256 % u != 0) return false;  // 64, 128, 256: whole atoms per workgroup
@@ -206,6 +242,38 @@ int launch_tp_dense(int sig, bool backward, const TpDenseArgs& a, hipStream_t st
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
+template <typename T>
+int launch_tp_dense_wgrad(int sig, int u, int coupling, const TpLayerWgradArgs& a, hipStream_t stream) {
+  const int P = cg::kSigs[sig].num_paths;
+  if (a.N == 0 || a.E == 0) {
+    AA_CHECK_HIP(hipMemsetAsync(a.gw, 0, sizeof(T) * size_t(coupling ? u : 1) * P, stream));
+    return AA_OK;
+  }
+  const int nslots = tp_wgrad_slots(a.N);
+  const int aps = int((a.N + nslots - 1) / nslots);
+  const int waves = nslots * (u >> 6);
+  dim3 grid((unsigned)((waves + 3) / 4));
+  switch (sig) {
+#define AA_CASE(ID, SIG)                                                                                          \
+  case ID: {                                                                                                      \
+    if constexpr (sizeof(T) == 8 && cg::SIG::LMAX >= 3) {                                                         \
+      return fail(AA_ERR_INVALID, "tp dense: fp64 at l_max = 3 runs the general kernels");                        \
+    } else {                                                                                                      \
+      const size_t smem = sizeof(T) * 4 * 64 * patch_cols<cg::SIG>();                                             \
+      hipLaunchKernelGGL((tp_dense_wgrad_kernel<cg::SIG, T>), grid, dim3(256), smem, stream, a, u, nslots, aps);  \
+    }                                                                                                             \
+    break;                                                                                                        \
+  }
+    AA_FOREACH_SIG(AA_CASE)
+#undef AA_CASE
+    default:
+      return fail(AA_ERR_INVALID, "tp dense: unknown signature");
+  }
+  AA_CHECK_HIP(hipGetLastError());
+  return launch_tp_wgrad_reduce<T>(a.partial, nslots, u, P, coupling, a.gw, stream);
+}
+template int launch_tp_dense_wgrad<float>(int, int, int, const TpLayerWgradArgs&, hipStream_t);
+template int launch_tp_dense_wgrad<double>(int, int, int, const TpLayerWgradArgs&, hipStream_t);
 template int launch_tp_dense<float>(int, bool, const TpDenseArgs&, hipStream_t);
 template int launch_tp_dense<double>(int, bool, const TpDenseArgs&, hipStream_t);
 

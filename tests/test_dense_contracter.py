@@ -40,15 +40,21 @@ def _standard_layer_case(l_max, L, layer, mul, dtype, lib, dev, sorted_idxs, mon
         y = c(x1, x2, idxs.to(dev), N)
         gy = torch.randn(y.shape, dtype=dtype, generator=torch.Generator().manual_seed(3)).to(dev)
         g1, g2 = torch.autograd.grad(y, [x1, x2], gy)
-        res[generic] = (y.detach().cpu(), g1.cpu(), g2.cpu())
+        # training mode: the differentiable segmented contraction incl. the path-weight gradient (tp_dense_wgrad_kernel)
+        c.train()
+        yt = c(x1, x2, idxs.to(dev), N)
+        gw = torch.autograd.grad(yt, [c.weights], gy)[0]
+        c.eval()
+        res[generic] = (y.detach().cpu(), g1.cpu(), g2.cpu(), gw.cpu())
         assert c._get_lib().lib.aa_tp_plan_is_specialised(c._plan(dtype, dev)) == (generic == "0")
         if generic == "0":
             xr1, xr2 = x1.detach().cpu().requires_grad_(True), x2.detach().cpu().requires_grad_(True)
-            yr = R.contracter_forward(xr1, xr2, idxs, N, c.weights.detach().cpu(), c.w3j.cpu(), True, 0.37)
-            gr1, gr2 = torch.autograd.grad(yr, [xr1, xr2], gy.cpu())
-            ref = (yr.detach(), gr1, gr2)
+            wr = c.weights.detach().cpu().requires_grad_(True)
+            yr = R.contracter_forward(xr1, xr2, idxs, N, wr, c.w3j.cpu(), True, 0.37)
+            gr1, gr2, grw = torch.autograd.grad(yr, [xr1, xr2, wr], gy.cpu())
+            ref = (yr.detach(), gr1, gr2, grw)
     tol = 1e-10 if dtype == torch.float64 else 2e-5
-    for what, got, want, gen in zip(("out", "grad x1", "grad x2"), res["0"], ref, res["1"]):
+    for what, got, want, gen in zip(("out", "grad x1", "grad x2", "grad weights"), res["0"], ref, res["1"]):
         scale = max(1.0, float(want.abs().max()))
         assert (got - want).abs().max().item() <= tol * scale, f"{what}: specialised kernels vs oracle"
         assert (got - gen).abs().max().item() <= tol * scale, f"{what}: specialised vs general kernels"
