@@ -119,6 +119,8 @@ class AllegroLib:
                                     C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_tp_backward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_tp_segment_sum.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                        C.c_void_p, C.c_void_p]
         L.aa_tp_weights_workspace_bytes.argtypes = [C.c_void_p, C.c_int64]
         L.aa_tp_weights_workspace_bytes.restype = C.c_size_t
         L.aa_tp_backward_weights.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -176,6 +178,9 @@ class AllegroLib:
     def tp_backward(self, h, E, N, x1, x2s, w, rowptr, eids, sf, gout, gx1, gx2, stream):
         self.check(self.lib.aa_tp_backward(h, E, N, x1, x2s, w, rowptr, eids, sf, gout, gx1, gx2, stream),
                    "aa_tp_backward")
+
+    def tp_segment_sum(self, dtype_code, E, N, row, x, rowptr, eids, scale, out, stream):
+        self.check(self.lib.aa_tp_segment_sum(dtype_code, E, N, row, x, rowptr, eids, scale, out, stream), "aa_tp_segment_sum")
 
     def tp_backward_weights(self, h, E, N, x1, x2s, rowptr, eids, gout, ws, ws_bytes, gw, stream):
         self.check(self.lib.aa_tp_backward_weights(h, E, N, x1, x2s, rowptr, eids, gout, ws, ws_bytes, gw, stream),

@@ -101,7 +101,8 @@ extern "C" int aa_tp_forward(const aa_tp_plan* plan, int64_t E, int64_t N, const
 extern "C" int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,
                               const void* weights, const int32_t* rowptr, const int32_t* eids, double scatter_factor,
                               const void* gout, void* gx1, void* gx2, aa_stream stream) {
-  AA_REQUIRE(plan && x1 && x2s && weights && rowptr && gout && gx1 && gx2, "aa_tp_backward: null argument");
+  AA_REQUIRE(plan && weights && rowptr && gout && (gx1 || gx2), "aa_tp_backward: null argument");
+  AA_REQUIRE((!gx1 || x2s) && (!gx2 || x1), "aa_tp_backward: a requested gradient's operand is null");
   if (plan->dense_spec) {
     TpDenseArgs d{};
     d.E = E;
@@ -136,9 +137,20 @@ extern "C" int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, cons
   return plan->dtype == AA_F32 ? launch_tp_layer_bwd<float>(plan->dev, a, s) : launch_tp_layer_bwd<double>(plan->dev, a, s);
 }
 
+extern "C" int aa_tp_segment_sum(aa_dtype dtype, int64_t E, int64_t N, int64_t row_elems, const void* x, const int32_t* rowptr,
+                                 const int32_t* eids, double scale, void* out, aa_stream stream) {
+  AA_REQUIRE(rowptr && (N == 0 || row_elems == 0 || out) && (E == 0 || x), "aa_tp_segment_sum: null argument");
+  AA_REQUIRE(dtype == AA_F32 || dtype == AA_F64, "aa_tp_segment_sum: dtype");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AA_F32 ? launch_segment_sum<float>(N, row_elems, x, rowptr, eids, scale, out, s)
+                         : launch_segment_sum<double>(N, row_elems, x, rowptr, eids, scale, out, s);
+}
+
 extern "C" size_t aa_tp_weights_workspace_bytes(const aa_tp_plan* plan, int64_t N) {
   if (!plan) return 0;
-  return tp_layer_wgrad_workspace_elems(plan->dev, N) * (plan->dtype == AA_F32 ? 4 : 8);
+  const size_t elem = plan->dtype == AA_F32 ? 4 : 8;
+  if (plan->dense_spec) return size_t(tp_wgrad_slots(N, kDenseWgradSlots)) * plan->dev.mul * plan->dev.num_paths * elem;
+  return tp_layer_wgrad_workspace_elems(plan->dev, N) * elem;
 }
 
 extern "C" int aa_tp_backward_weights(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,

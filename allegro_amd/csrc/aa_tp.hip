@@ -123,9 +123,12 @@ __global__ __launch_bounds__(256) void tp_layer_bwd_kernel(TpLayerDev L, TpLayer
   const bool wave_uniform = (u % 64) == 0;
   const T* W = static_cast<const T*>(a.weights);
 
+  // a gradient the caller did not ask for is skipped together with the operand only it reads (aa_tp_backward with a
+  // null gx1 / gx2: the single partial contractions of the training path, allegro_amd/ops.py)
+  const bool need1 = a.g1.dense || a.g1.gw, need2 = a.g2.dense || a.g2.gw;
   for (int idx = tid; idx < u * d2; idx += 256) {
     int ch = idx / d2, j = idx % d2;
-    sX2[ch * d2p + j] = static_cast<const T*>(a.x2s)[(n * u + ch) * d2 + j];
+    sX2[ch * d2p + j] = need1 ? static_cast<const T*>(a.x2s)[(n * u + ch) * d2 + j] : T(0);
     sG2[ch * d2p + j] = T(0);
   }
   __syncthreads();
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void tp_layer_bwd_kernel(TpLayerDev L, TpLayer
     T* x1 = sX1 + tid * d1p;
     T* go = sGo + tid * dop;
     if (active) {
-      for (int i = 0; i < d1; ++i) x1[i] = load_operand<T>(a.x1, e, ch, i, u, d1, R1);
+      for (int i = 0; i < d1; ++i) x1[i] = (a.x1.dense || a.x1.sh) ? load_operand<T>(a.x1, e, ch, i, u, d1, R1) : T(0);  // (absent: only g1 was asked for)
       for (int k = 0; k < dout; ++k) go[k] = a.gout ? static_cast<const T*>(a.gout)[(e * u + ch) * dout + k] : T(0);
       if (a.gscal) go[0] += static_cast<const T*>(a.gscal)[e * a.ld_gscal + ch];
     } else {
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void tp_layer_bwd_kernel(TpLayerDev L, TpLayer
     }
     const T* x2 = sX2 + ch * d2p;
     // ---- grad wrt x1: g1[i] = sum W * c * gout[k] * x2s[j]
-    {
+    if (need1) {
       T cur = T(0), gw_acc = T(0);
       int r_cur = 0;
       for (int gi = 0; gi < L.bx1.num_groups; ++gi) {
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void tp_layer_bwd_kernel(TpLayerDev L, TpLayer
       if (!a.g1.dense && a.g1.gw && active) static_cast<T*>(a.g1.gw)[e * a.g1.ldgw + ch * R1 + r_cur] = gw_acc;
     }
     // ---- grad wrt x2s: g2[j] = sum W * c * gout[k] * x1[i], summed over the segment
-    {
+    if (need2) {
       T cur = T(0);
       for (int gi = 0; gi < L.bx2.num_groups; ++gi) {
         TpGroup grp = L.bx2.groups[gi];
@@ -354,8 +357,8 @@ __global__ __launch_bounds__(256) void tp_layer_wgrad_reduce_kernel(const T* par
   }
 }
 
-int tp_wgrad_slots(int64_t N) { return int(std::min<int64_t>(std::max<int64_t>(N, 1), 1024)); }
-static int wgrad_blocks(int64_t N) { return tp_wgrad_slots(N); }
+int tp_wgrad_slots(int64_t N, int cap) { return int(std::min<int64_t>(std::max<int64_t>(N, 1), cap)); }
+static int wgrad_blocks(int64_t N) { return tp_wgrad_slots(N, 1024); }
 
 size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N) { return size_t(wgrad_blocks(N)) * L.mul * L.num_paths; }
 
@@ -481,6 +484,43 @@ int launch_tp_layer_bwd(const TpLayerDev& L, const TpLayerBwdArgs& a, hipStream_
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// scale + segment sum alone (_contract.py:195-204): out[n] = scale * sum_{s in segment n} x[eid(s)], rows of `row`
+// contiguous elements.  One workgroup per segment, thread = element, edges in CSR order (deterministic, no atomics);
+// four rows in flight per thread.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const T* __restrict__ x, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ eids, int64_t row, T scale, T* __restrict__ out) {
+  const int64_t n = blockIdx.x;
+  const int beg = rowptr[n], end = rowptr[n + 1];
+  for (int64_t q = threadIdx.x; q < row; q += 256) {
+    T acc = T(0);
+    int s = beg;
+    for (; s + 4 <= end; s += 4) {
+      T v[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) v[m] = x[int64_t(eids ? eids[s + m] : s + m) * row + q];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc += v[m];
+    }
+    for (; s < end; ++s) acc += x[int64_t(eids ? eids[s] : s) * row + q];
+    out[n * row + q] = acc * scale;
+  }
+}
+
+template <typename T>
+int launch_segment_sum(int64_t N, int64_t row, const void* x, const int32_t* rowptr, const int32_t* eids, double scale, void* out,
+                       hipStream_t stream) {
+  if (N == 0 || row == 0) return AA_OK;
+  hipLaunchKernelGGL(segment_sum_kernel<T>, dim3((unsigned)N), dim3(256), 0, stream, static_cast<const T*>(x), rowptr, eids, row,
+                     T(scale), static_cast<T*>(out));
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+template int launch_segment_sum<float>(int64_t, int64_t, const void*, const int32_t*, const int32_t*, double, void*, hipStream_t);
+template int launch_segment_sum<double>(int64_t, int64_t, const void*, const int32_t*, const int32_t*, double, void*, hipStream_t);
 
 template int launch_tp_layer_fwd<float>(const TpLayerDev&, const TpLayerFwdArgs&, hipStream_t);
 template int launch_tp_layer_fwd<double>(const TpLayerDev&, const TpLayerFwdArgs&, hipStream_t);

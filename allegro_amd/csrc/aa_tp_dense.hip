@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void tp_dense_fwd_kernel(TpDenseArgs a) {
   }
 }
 
-template <class Sig, typename T>
+template <class Sig, typename T, bool G1, bool G2>
 __global__ __launch_bounds__(256) void tp_dense_bwd_kernel(TpDenseArgs a) {
   constexpr int D1 = Sig::D1, D2 = Sig::D2, DOUT = Sig::DOUT, P = Sig::P;
   const int u = a.u, lane = threadIdx.x & 63;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void tp_dense_bwd_kernel(TpDenseArgs a) {
   const T* GO = static_cast<const T*>(a.gout);
   auto edge_of = [&](int s) -> int64_t { return a.eids ? a.eids[s] : s; };
   T x2s[D2], g2acc[D2];
-  run_load<T, D2>(static_cast<const T*>(a.x2s) + (ws.atom * u + ws.ch0) * D2, sS, lane, x2s);
+  if constexpr (G1) run_load<T, D2>(static_cast<const T*>(a.x2s) + (ws.atom * u + ws.ch0) * D2, sS, lane, x2s);
 #pragma unroll
   for (int j = 0; j < D2; ++j) g2acc[j] = T(0);
   T w[P];
@@ -147,26 +147,35 @@ __global__ __launch_bounds__(256) void tp_dense_bwd_kernel(TpDenseArgs a) {
 #pragma unroll
     for (int p = 0; p < P; ++p) w[p] = a.coupling ? W[ch * P + p] : W[p];
   }
-  // ---- per edge: gradient of x1, accumulation of the gradient of the gathered sum
+  // ---- per edge: gradient of x1 (G1), accumulation of the gradient of the gathered sum (G2); a gradient the caller
+  //      did not ask for costs neither its operand stream nor its stores
   for (int s = beg; s < end; ++s) {
     const int64_t e = edge_of(s);
-    T go[DOUT], x1[D1], g1[D1], g2[D2], r[D1];
+    T go[DOUT];
     run_load<T, DOUT>(GO + (e * u + ws.ch0) * DOUT, sS, lane, go);
-    run_load<T, D1>(X1 + (e * u + ws.ch0) * D1, sS, lane, x1);
-    Sig::template bx1<T>(go, x2s, w, g1);
-    Sig::template bx2<T>(go, x1, w, g2);
+    if constexpr (G2) {
+      T x1[D1], g2[D2];
+      run_load<T, D1>(X1 + (e * u + ws.ch0) * D1, sS, lane, x1);
+      Sig::template bx2<T>(go, x1, w, g2);
 #pragma unroll
-    for (int j = 0; j < D2; ++j) g2acc[j] += g2[j];
-    run_stage<T, D1>(g1, sS, lane, r);
-    run_store<T, D1>(static_cast<T*>(a.gx1) + (e * u + ws.ch0) * D1, r, lane);
+      for (int j = 0; j < D2; ++j) g2acc[j] += g2[j];
+    }
+    if constexpr (G1) {
+      T g1[D1], r[D1];
+      Sig::template bx1<T>(go, x2s, w, g1);
+      run_stage<T, D1>(g1, sS, lane, r);
+      run_store<T, D1>(static_cast<T*>(a.gx1) + (e * u + ws.ch0) * D1, r, lane);
+    }
   }
   // ---- adjoint of scale + segment sum + gather: every edge of the segment receives the scaled accumulated gradient
-  const T sf = T(a.sf);
+  if constexpr (G2) {
+    const T sf = T(a.sf);
 #pragma unroll
-  for (int j = 0; j < D2; ++j) g2acc[j] *= sf;
-  T r2[D2];
-  run_stage<T, D2>(g2acc, sS, lane, r2);
-  for (int s = beg; s < end; ++s) run_store<T, D2>(static_cast<T*>(a.gx2) + (edge_of(s) * u + ws.ch0) * D2, r2, lane);
+    for (int j = 0; j < D2; ++j) g2acc[j] *= sf;
+    T r2[D2];
+    run_stage<T, D2>(g2acc, sS, lane, r2);
+    for (int s = beg; s < end; ++s) run_store<T, D2>(static_cast<T*>(a.gx2) + (edge_of(s) * u + ws.ch0) * D2, r2, lane);
+  }
 }
 
 // Path-weight gradient: wave = (slot of consecutive center atoms, 64-channel slice); lane-private accumulators over the
@@ -227,8 +236,12 @@ int launch_tp_dense(int sig, bool backward, const TpDenseArgs& a, hipStream_t st
       return fail(AA_ERR_INVALID, "tp dense: fp64 at l_max = 3 runs the general kernels");                     \
     } else {                                                                                                   \
       const size_t smem = sizeof(T) * 4 * 64 * patch_cols<cg::SIG>();                                          \
-      if (backward)                                                                                            \
-        hipLaunchKernelGGL((tp_dense_bwd_kernel<cg::SIG, T>), grid, dim3(256), smem, stream, a);               \
+      if (backward && a.gx1 && a.gx2)                                                                          \
+        hipLaunchKernelGGL((tp_dense_bwd_kernel<cg::SIG, T, true, true>), grid, dim3(256), smem, stream, a);   \
+      else if (backward && a.gx1)                                                                              \
+        hipLaunchKernelGGL((tp_dense_bwd_kernel<cg::SIG, T, true, false>), grid, dim3(256), smem, stream, a);  \
+      else if (backward)                                                                                       \
+        hipLaunchKernelGGL((tp_dense_bwd_kernel<cg::SIG, T, false, true>), grid, dim3(256), smem, stream, a);  \
       else                                                                                                     \
         hipLaunchKernelGGL((tp_dense_fwd_kernel<cg::SIG, T>), grid, dim3(256), smem, stream, a);               \
     }                                                                                                          \
@@ -249,7 +262,7 @@ int launch_tp_dense_wgrad(int sig, int u, int coupling, const TpLayerWgradArgs& 
     AA_CHECK_HIP(hipMemsetAsync(a.gw, 0, sizeof(T) * size_t(coupling ? u : 1) * P, stream));
     return AA_OK;
   }
-  const int nslots = tp_wgrad_slots(a.N);
+  const int nslots = tp_wgrad_slots(a.N, kDenseWgradSlots);
   const int aps = int((a.N + nslots - 1) / nslots);
   const int waves = nslots * (u >> 6);
   dim3 grid((unsigned)((waves + 3) / 4));

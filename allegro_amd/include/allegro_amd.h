@@ -75,10 +75,19 @@ int aa_tp_forward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, 
                   const void* weights, const int32_t* rowptr, const int32_t* eids,
                   double scatter_factor, void* x2s, void* out, aa_stream stream);
 
-/* input gradients of the above: gx1:[E,u,d1], gx2:[E,u,d2]. */
+/* input gradients of the above: gx1:[E,u,d1], gx2:[E,u,d2].  Either output may be NULL: that gradient is not computed and
+ * the operand only it reads may be NULL too (gx1 == NULL: x2s unused; gx2 == NULL: x1 unused) -- the single partial
+ * contractions the training path differentiates through (allegro_amd/ops.py; the reference gets them from autograd
+ * through the eager contraction, _contract.py:213-251). */
 int aa_tp_backward(const aa_tp_plan* plan, int64_t E, int64_t N, const void* x1, const void* x2s,
                    const void* weights, const int32_t* rowptr, const int32_t* eids,
                    double scatter_factor, const void* gout, void* gx1, void* gx2, aa_stream stream);
+
+/* the scale + scatter-sum of `Contracter.forward` alone (_contract.py:195-204) on the same segment layout:
+ * out[n] = scale * sum_{s in [rowptr[n],rowptr[n+1])} x[eid(s)], rows of row_elems contiguous elements (u * d2);
+ * deterministic (CSR order, no atomics).  The training path uses it to form x2s for the partial contractions. */
+int aa_tp_segment_sum(aa_dtype dtype, int64_t E, int64_t N, int64_t row_elems, const void* x, const int32_t* rowptr,
+                      const int32_t* eids, double scale, void* out, aa_stream stream);
 
 /* path-weight gradient of the above (training): gweights has the shape of `weights` ([u,p] or [p]).  The
  * reference's eager Contracter and its cuEquivariance variant get it from autograd through the `weights`

@@ -11,6 +11,9 @@ The reference registers its accelerated contraction as a functional library op w
 
     torch.ops.allegro_amd.tp_backward_weights(gout, x1, x2s, weights, rowptr, eids?, num_atoms, plan, lib_id)
         -> gweights (shape of weights)
+    torch.ops.allegro_amd.tp_backward_x1(gout, x2s, weights, ...) -> gx1      (one gradient alone: `aa_tp_backward` with
+    torch.ops.allegro_amd.tp_backward_x2(gout, x1,  weights, ...) -> gx2       the other output NULL; the training path)
+    torch.ops.allegro_amd.segment_sum(x [E,u,d], rowptr, eids?, num_atoms, scale, lib_id) -> [N,u,d]
 
 All are functional (fresh outputs, nothing mutated); all non-tensor arguments are int/float.  Unlike the reference's
 Triton op, which returns `None` for the weights (`_flashallegro.py:641-666`) and therefore has to fall back to the
@@ -91,6 +94,67 @@ def tp_backward(gout: torch.Tensor, x1: torch.Tensor, x2s: torch.Tensor, weights
 @tp_backward.register_fake
 def _(gout, x1, x2s, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id):
     return torch.empty_like(x1), x1.new_empty((x1.shape[0], x1.shape[1], x2s.shape[2]))
+
+
+@torch.library.custom_op("allegro_amd::tp_backward_x1", mutates_args=())
+def tp_backward_x1(gout: torch.Tensor, x2s: torch.Tensor, weights: torch.Tensor, rowptr: torch.Tensor, eids: Optional[torch.Tensor],
+                   num_atoms: int, scatter_factor: float, plan: int, lib_id: int, d1: int) -> torch.Tensor:
+    lib = _resolve(lib_id)
+    _check_device(lib, gout, "allegro_amd::tp_backward_x1")
+    goutc, x2sc, wc = gout.contiguous(), x2s.contiguous(), weights.contiguous()
+    E, u = goutc.shape[0], goutc.shape[1]
+    gx1 = torch.empty((E, u, d1), dtype=gout.dtype, device=gout.device)
+    lib.tp_backward(plan, E, num_atoms, None, x2sc.data_ptr(), wc.data_ptr(), rowptr.data_ptr(),
+                    eids.data_ptr() if eids is not None else None, scatter_factor, goutc.data_ptr(), gx1.data_ptr(), None,
+                    _stream_ptr(gout))
+    return gx1
+
+
+@tp_backward_x1.register_fake
+def _(gout, x2s, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id, d1):
+    return gout.new_empty((gout.shape[0], gout.shape[1], d1))
+
+
+@torch.library.custom_op("allegro_amd::tp_backward_x2", mutates_args=())
+def tp_backward_x2(gout: torch.Tensor, x1: torch.Tensor, weights: torch.Tensor, rowptr: torch.Tensor, eids: Optional[torch.Tensor],
+                   num_atoms: int, scatter_factor: float, plan: int, lib_id: int, d2: int) -> torch.Tensor:
+    lib = _resolve(lib_id)
+    _check_device(lib, gout, "allegro_amd::tp_backward_x2")
+    goutc, x1c, wc = gout.contiguous(), x1.contiguous(), weights.contiguous()
+    E, u = goutc.shape[0], goutc.shape[1]
+    gx2 = torch.empty((E, u, d2), dtype=gout.dtype, device=gout.device)
+    lib.tp_backward(plan, E, num_atoms, x1c.data_ptr(), None, wc.data_ptr(), rowptr.data_ptr(),
+                    eids.data_ptr() if eids is not None else None, scatter_factor, goutc.data_ptr(), None, gx2.data_ptr(),
+                    _stream_ptr(gout))
+    return gx2
+
+
+@tp_backward_x2.register_fake
+def _(gout, x1, weights, rowptr, eids, num_atoms, scatter_factor, plan, lib_id, d2):
+    return gout.new_empty((gout.shape[0], gout.shape[1], d2))
+
+
+@torch.library.custom_op("allegro_amd::segment_sum", mutates_args=())
+def segment_sum(x: torch.Tensor, rowptr: torch.Tensor, eids: Optional[torch.Tensor], num_atoms: int, scale: float,
+                lib_id: int) -> torch.Tensor:
+    """scale + scatter-sum of `Contracter.forward` alone (allegro/nn/_strided/_contract.py:195-204), deterministic."""
+    lib = _resolve(lib_id)
+    _check_device(lib, x, "allegro_amd::segment_sum")
+    if x.dtype not in (torch.float32, torch.float64):
+        raise _lib.AllegroError(f"allegro_amd::segment_sum: dtype {x.dtype}")
+    xc = x.contiguous()
+    E = xc.shape[0]
+    out = torch.empty((num_atoms,) + tuple(xc.shape[1:]), dtype=x.dtype, device=x.device)
+    row = xc[0].numel() if E else int(out[0].numel()) if num_atoms else 0
+    lib.tp_segment_sum(_lib.AA_F32 if x.dtype == torch.float32 else _lib.AA_F64, E, num_atoms, row, xc.data_ptr() if E else None,
+                       rowptr.data_ptr(), eids.data_ptr() if eids is not None else None, scale, out.data_ptr() if num_atoms else None,
+                       _stream_ptr(x))
+    return out
+
+
+@segment_sum.register_fake
+def _(x, rowptr, eids, num_atoms, scale, lib_id):
+    return x.new_empty((num_atoms,) + tuple(x.shape[1:]))
 
 
 @torch.library.custom_op("allegro_amd::tp_backward_weights", mutates_args=())
@@ -192,9 +256,8 @@ def _edge_rowptr(E: int, device) -> torch.Tensor:
 
 
 def _segment_sum(t: _TriCtx, b):  # x2s = scale * scatter-sum of b over the scatter index  [N,u,d2]
-    _rowptr, _eids, idxs, n, sf = t.segments
-    x2s = torch.zeros((n,) + tuple(b.shape[1:]), dtype=b.dtype, device=b.device)
-    return x2s.index_add_(0, idxs, b.detach()).mul_(sf)
+    rowptr, eids, _idxs, n, sf = t.segments
+    return torch.ops.allegro_amd.segment_sum(b.detach(), rowptr, eids, n, sf, t.lib_id)
 
 
 def _raw_out(t: _TriCtx, a, b, w):  # [E,u,dout]
@@ -208,13 +271,22 @@ def _raw_out(t: _TriCtx, a, b, w):  # [E,u,dout]
     return out
 
 
-def _raw_in_grads(t: _TriCtx, c, a, b, w):  # (d/d a [E,u,d1], d/d b [E,u,d2])
-    E = a.shape[0]
+def _raw_grad_a(t: _TriCtx, c, b, w):  # d/d a [E,u,d1]: T with (c, b) filled -- one launch, only this gradient
+    E = c.shape[0]
     if t.segments is not None:
         rowptr, eids, _idxs, n, sf = t.segments
-        return torch.ops.allegro_amd.tp_backward(c.detach(), a.detach(), _segment_sum(t, b), w.detach(), rowptr, eids, n, sf, t.plan, t.lib_id)
-    return torch.ops.allegro_amd.tp_backward(c.detach(), a.detach(), b.detach(), w.detach(), _edge_rowptr(E, a.device), None, E,
-                                             1.0, t.plan, t.lib_id)
+        return torch.ops.allegro_amd.tp_backward_x1(c.detach(), _segment_sum(t, b), w.detach(), rowptr, eids, n, sf, t.plan, t.lib_id, t.d1)
+    return torch.ops.allegro_amd.tp_backward_x1(c.detach(), b.detach(), w.detach(), _edge_rowptr(E, c.device), None, E, 1.0,
+                                                t.plan, t.lib_id, t.d1)
+
+
+def _raw_grad_b(t: _TriCtx, c, a, w):  # d/d b [E,u,d2]: T with (c, a) filled (segmented: M applied)
+    E = c.shape[0]
+    if t.segments is not None:
+        rowptr, eids, _idxs, n, sf = t.segments
+        return torch.ops.allegro_amd.tp_backward_x2(c.detach(), a.detach(), w.detach(), rowptr, eids, n, sf, t.plan, t.lib_id, t.d2)
+    return torch.ops.allegro_amd.tp_backward_x2(c.detach(), a.detach(), w.detach(), _edge_rowptr(E, c.device), None, E, 1.0,
+                                                t.plan, t.lib_id, t.d2)
 
 
 def _raw_wgrad(t: _TriCtx, c, a, b, w_like):  # [shape of w]
@@ -251,8 +323,7 @@ class _TriI(torch.autograd.Function):
     def forward(ctx, c, b, w, t):
         ctx.t = t
         ctx.save_for_backward(c, b, w)
-        a0 = torch.zeros((c.shape[0], c.shape[1], t.d1), dtype=c.dtype, device=c.device)
-        return _raw_in_grads(t, c, a0, b, w)[0]
+        return _raw_grad_a(t, c, b, w)
 
     @staticmethod
     def backward(ctx, h):
@@ -270,8 +341,7 @@ class _TriJ(torch.autograd.Function):
     def forward(ctx, c, a, w, t):
         ctx.t = t
         ctx.save_for_backward(c, a, w)
-        b0 = torch.zeros((c.shape[0], c.shape[1], t.d2), dtype=c.dtype, device=c.device)
-        return _raw_in_grads(t, c, a, b0, w)[1]
+        return _raw_grad_b(t, c, a, w)
 
     @staticmethod
     def backward(ctx, h):

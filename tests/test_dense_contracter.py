@@ -76,3 +76,56 @@ def test_standard_layers_run_the_dense_specialised_kernels_emulated(l_max, L, la
     (2, 3, 2, 128, torch.float32, True), (3, 2, 0, 64, torch.float32, False), (3, 3, 1, 64, torch.float32, True)])
 def test_standard_layers_run_the_dense_specialised_kernels_on_gpu(l_max, L, layer, mul, dtype, sorted_idxs, monkeypatch):
     _standard_layer_case(l_max, L, layer, mul, dtype, None, torch.device("cuda:0"), sorted_idxs, monkeypatch)
+
+
+def _single_gradient_case(lib, dev, dtype):
+    """`aa_tp_backward` with one output NULL returns the gradient the full call returns, and `aa_tp_segment_sum`
+    is the scale + scatter-sum of _contract.py:195-204 -- on the specialised (mul 64) and the general (mul 8) kernels."""
+    from allegro_amd import o3, ops  # noqa: F401  (registers the ops)
+    from allegro_amd.nn import HipContracter, allegro_layer_irreps, segments_from_index
+
+    irreps = allegro_layer_irreps(2, True, 2)
+    env = o3.Irreps.spherical_harmonics(2, p=-1)
+    E, N = 41, 6
+    idxs = torch.randint(0, N, (E,), generator=torch.Generator().manual_seed(4))
+    for mul, special in ((64, True), (8, False)):
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            c = HipContracter(str(irreps[0]), str(env), str(irreps[1]), mul=mul, path_channel_coupling=True, scatter_factor=0.5)
+        finally:
+            torch.set_default_dtype(prev)
+        c = c.to(dev).eval()
+        if lib is not None:
+            c._bind_library(lib)
+        plan, lib_id = c._plan(dtype, dev), c._lib_id
+        assert bool(c._get_lib().lib.aa_tp_plan_is_specialised(plan)) == special
+        g = torch.Generator().manual_seed(9)
+        x1 = torch.randn(E, mul, irreps[0].dim, dtype=dtype, generator=g).to(dev)
+        x2 = torch.randn(E, mul, env.dim, dtype=dtype, generator=g).to(dev)
+        go = torch.randn(E, mul, irreps[1].dim, dtype=dtype, generator=g).to(dev)
+        rowptr, eids = segments_from_index(idxs.to(dev), N)
+        x2s = torch.ops.allegro_amd.segment_sum(x2, rowptr, eids, N, 0.5, lib_id)
+        want = torch.zeros(N, mul, env.dim, dtype=dtype, device=dev).index_add_(0, idxs.to(dev), x2) * 0.5
+        tol = 1e-12 if dtype == torch.float64 else 1e-5
+        assert (x2s - want).abs().max().item() <= tol * float(want.abs().max())
+        w = c.weights.detach()
+        g1, g2 = torch.ops.allegro_amd.tp_backward(go, x1, x2s, w, rowptr, eids, N, 0.5, plan, lib_id)
+        o1 = torch.ops.allegro_amd.tp_backward_x1(go, x2s, w, rowptr, eids, N, 0.5, plan, lib_id, irreps[0].dim)
+        o2 = torch.ops.allegro_amd.tp_backward_x2(go, x1, w, rowptr, eids, N, 0.5, plan, lib_id, env.dim)
+        # (not bitwise: the instantiations contract their FMAs differently, the general kernel sums g2 with LDS atomics)
+        for got, ref in ((o1, g1), (o2, g2)):
+            assert (got - ref).abs().max().item() <= 10 * tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_single_gradients_and_segment_sum_emulated(dtype):
+    from tests.hip_utils import emu_lib
+
+    _single_gradient_case(emu_lib(), torch.device("cpu"), dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_single_gradients_and_segment_sum_on_gpu(dtype):
+    _single_gradient_case(None, torch.device("cuda:0"), dtype)
