@@ -374,7 +374,8 @@ int launch_tp_layer_wgrad(const TpLayerDev& L, const TpLayerWgradArgs& a, hipStr
 template <typename T>
 int launch_segment_sum(int64_t N, int64_t row, const void* x, const int32_t* rowptr, const int32_t* eids, double scale, void* out,
                        hipStream_t stream);
-// slots (partial slabs) of the path-weight gradient, shared by the general and the dense kernels
+// slots (partial slabs) of the path-weight gradient, shared by the general and the dense kernels; the workspace holds
+// nslots + 1 slabs of u * P elements (launch_tp_wgrad_reduce uses the last one)
 int tp_wgrad_slots(int64_t N, int cap);
 constexpr int kDenseWgradSlots = 8192;  // one wave per slot and 64-channel slice: enough waves to fill the chip at 10^5 atoms
 template <typename T>

@@ -149,7 +149,7 @@ extern "C" int aa_tp_segment_sum(aa_dtype dtype, int64_t E, int64_t N, int64_t r
 extern "C" size_t aa_tp_weights_workspace_bytes(const aa_tp_plan* plan, int64_t N) {
   if (!plan) return 0;
   const size_t elem = plan->dtype == AA_F32 ? 4 : 8;
-  if (plan->dense_spec) return size_t(tp_wgrad_slots(N, kDenseWgradSlots)) * plan->dev.mul * plan->dev.num_paths * elem;
+  if (plan->dense_spec) return size_t(tp_wgrad_slots(N, kDenseWgradSlots) + 1) * plan->dev.mul * plan->dev.num_paths * elem;
   return tp_layer_wgrad_workspace_elems(plan->dev, N) * elem;
 }
 

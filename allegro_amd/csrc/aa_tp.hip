@@ -340,34 +340,51 @@ __global__ __launch_bounds__(kWgThreads) void tp_layer_wgrad_kernel(TpLayerDev L
   }
 }
 
+// sum of the slot slabs, deterministic: thread (o, g) of a workgroup adds the slabs g, g + 16, g + 32, ... of output o in that
+// order, the 16 group sums are then added in group order.  64 outputs x 16 groups per workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void tp_layer_wgrad_reduce_kernel(const T* partial, int nblocks, int u, int P, int coupling, T* gw) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (coupling) {
-    if (idx >= u * P) return;
+__global__ __launch_bounds__(1024) void tp_layer_wgrad_reduce_kernel(const T* __restrict__ partial, int nslots, int nout, T* __restrict__ dst) {
+  T* sG = reinterpret_cast<T*>(aa_smem);  // [16][64]
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  T v = T(0);
+  if (o < nout)
+    for (int b = g; b < nslots; b += 16) v += partial[int64_t(b) * nout + o];
+  sG[g * 64 + (threadIdx.x & 63)] = v;
+  __syncthreads();
+  if (g == 0 && o < nout) {
+    T r = T(0);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) r += sG[m * 64 + (threadIdx.x & 63)];
+    dst[o] = r;
+  }
+}
+// uncoupled path weights: gw[p] = sum over channels (in channel order) of the per-channel sums
+template <typename T>
+__global__ __launch_bounds__(64) void tp_layer_wgrad_channels_kernel(const T* __restrict__ per_channel, int u, int P, T* __restrict__ gw) {
+  for (int p = threadIdx.x; p < P; p += 64) {
     T v = T(0);
-    for (int b = 0; b < nblocks; ++b) v += partial[int64_t(b) * u * P + idx];
-    gw[idx] = v;
-  } else {
-    if (idx >= P) return;
-    T v = T(0);
-    for (int b = 0; b < nblocks; ++b)
-      for (int ch = 0; ch < u; ++ch) v += partial[(int64_t(b) * u + ch) * P + idx];
-    gw[idx] = v;
+    for (int ch = 0; ch < u; ++ch) v += per_channel[ch * P + p];
+    gw[p] = v;
   }
 }
 
 int tp_wgrad_slots(int64_t N, int cap) { return int(std::min<int64_t>(std::max<int64_t>(N, 1), cap)); }
 static int wgrad_blocks(int64_t N) { return tp_wgrad_slots(N, 1024); }
 
-size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N) { return size_t(wgrad_blocks(N)) * L.mul * L.num_paths; }
+// (+ one slab: the per-channel sums of the uncoupled form between the two reduce kernels)
+size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N) { return size_t(wgrad_blocks(N) + 1) * L.mul * L.num_paths; }
 
 template <typename T>
 int launch_tp_wgrad_reduce(const void* partial, int nslots, int u, int P, int coupling, void* gw, hipStream_t stream) {
-  const int nout = (coupling ? u : 1) * P;
-  hipLaunchKernelGGL(tp_layer_wgrad_reduce_kernel<T>, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<const T*>(partial), nslots, u, P, coupling, static_cast<T*>(gw));
+  const int nout = u * P;
+  const T* part = static_cast<const T*>(partial);
+  T* per_channel = coupling ? static_cast<T*>(gw) : const_cast<T*>(part) + size_t(nslots) * nout;  // the extra slab
+  hipLaunchKernelGGL(tp_layer_wgrad_reduce_kernel<T>, dim3((unsigned)((nout + 63) / 64)), dim3(1024), sizeof(T) * 16 * 64, stream, part, nslots, nout, per_channel);
   AA_CHECK_HIP(hipGetLastError());
+  if (!coupling) {
+    hipLaunchKernelGGL(tp_layer_wgrad_channels_kernel<T>, dim3(1), dim3(64), 0, stream, per_channel, u, P, static_cast<T*>(gw));
+    AA_CHECK_HIP(hipGetLastError());
+  }
   return AA_OK;
 }
 template int launch_tp_wgrad_reduce<float>(const void*, int, int, int, int, void*, hipStream_t);

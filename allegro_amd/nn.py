@@ -666,8 +666,18 @@ class HipAllegroModel(torch.nn.Module):
             add("per_type_energy_scale_shift.scales", sc, "param")
         if sh is not None:
             add("per_type_energy_scale_shift.shifts", sh, "param")
+        # eval mode (the default state of a freshly built model here): the hand-written inference / force pipeline, no weight
+        # gradients (like _flashallegro.py:660).  `.train()` switches every trainable parameter on and `forward` to the
+        # differentiable evaluation of allegro_amd/training.py.
+        self._frozen_keys = set()
+        if self.has_scales and not per_type_energy_scales_trainable:
+            self._frozen_keys.add("func.per_type_energy_scale_shift.scales")
+        if self.has_shifts and not per_type_energy_shifts_trainable:
+            self._frozen_keys.add("func.per_type_energy_scale_shift.shifts")
+        self._trainer = None
+        self.training = False
         for p in self.parameters():
-            p.requires_grad_(False)  # inference/force path: no weight gradients (like _flashallegro.py:660)
+            p.requires_grad_(False)
         self._bound_lib: Optional[_lib.AllegroLib] = None
         # plans own device-resident tables and the packed weights / workspace are device buffers: one set per device,
         # `_plan_handle` / `_blob` / `_workspace` always refer to the device of the current call (`_select_device`)
@@ -680,6 +690,24 @@ class HipAllegroModel(torch.nn.Module):
         self._cur_dev = None
         self._graph_cache = None  # (key, keyed tensors kept alive, PreparedGraph structure) of forward()
 
+    # -- training ---------------------------------------------------------------------------------
+    def train(self, mode: bool = True):
+        """Training mode: every parameter the reference trains requires grad (MLPs, type embeddings, tensor-product path
+        weights; per-type scales / shifts only with `per_type_energy_*_trainable`, allegro_models.py:251-260) and `forward`
+        returns energies, forces and stress attached to the autograd graph (allegro_amd/training.py).  `.eval()` returns to
+        the inference pipeline; the packed device weights follow in-place optimizer updates (`_ensure_weights`)."""
+        super().train(mode)
+        for k, p in self.named_parameters():
+            p.requires_grad_(bool(mode) and k not in self._frozen_keys)
+        return self
+
+    def _training_evaluator(self):
+        if self._trainer is None:
+            from .training import TrainingEvaluator
+
+            self._trainer = TrainingEvaluator(self)
+        return self._trainer
+
     # -- library / plan -------------------------------------------------------------------------
     def _get_lib(self) -> _lib.AllegroLib:
         return self._bound_lib if self._bound_lib is not None else _lib.load()
@@ -688,6 +716,7 @@ class HipAllegroModel(torch.nn.Module):
         """(tests) bind an explicitly loaded library instead of the default gfx950 one."""
         self._drop_device_state()
         self._bound_lib = lib
+        self._trainer = None
 
     def _drop_device_state(self):
         self._stash_device_state()
@@ -815,6 +844,7 @@ class HipAllegroModel(torch.nn.Module):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         # w3j buffers may have changed: rebuild device tables lazily
         self._drop_device_state()
+        self._trainer = None
         return out
 
     # -- evaluation -----------------------------------------------------------------------------
@@ -931,6 +961,8 @@ class HipAllegroModel(torch.nn.Module):
         """AtomicDataDict in, AtomicDataDict out (keys: pos, edge_index, atom_types [, cell, edge_cell_shift, batch])."""
         pos = data["pos"]
         graph = self._graph_for(data)
+        if self.training and torch.is_grad_enabled():
+            return self._training_evaluator().forward(data, graph)
         e_atom, forces = self.energy_forces(pos.to(self.dtype), graph, with_forces=True)
         out = dict(data)
         out["atomic_energy"] = e_atom.unsqueeze(-1)

@@ -1,0 +1,262 @@
+"""Whole-step TRAINING evaluation of `HipAllegroModel`.
+
+The reference trains every MLP and every tensor-product path weight through autograd (weights are `Parameter`s:
+allegro/nn/_allegro.py:192-213, allegro/nn/_strided/_contract.py:172-177) and a force-matching loss differentiates
+the forces -- themselves a gradient -- again.  The inference pipeline of `aa_model_energy_forces` has hand-written
+first derivatives with respect to positions only, so training mode evaluates the same function as a differentiable
+graph instead:
+
+* the strided tensor products -- the part of the model the reference's accelerators replace -- run on the HIP
+  kernels through `ops.contract_segments_differentiable` (forward, both input gradients and the path-weight gradient
+  on true center segments, closed under differentiation of any order);
+* the per-edge linear layers are plain library GEMMs (`torch.matmul` = rocBLAS / hipBLASLt), the two-body embedding,
+  spherical harmonics, weighted channels and the edge -> atom reduction are device-side torch ops: everything autograd
+  already differentiates to any order.
+
+No CPU path: tensors must live on the GPU (`_require_gpu`), the tensor products fail loudly without the HIP library.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import o3, ops
+
+_ACT = {"silu": torch.nn.functional.silu, "mish": torch.nn.functional.mish, "gelu": torch.nn.functional.gelu, None: None}
+
+
+def _real_sh(vec: torch.Tensor, l_max: int) -> torch.Tensor:
+    """Component-normalised real spherical harmonics of the direction of `vec`, l = 0..l_max (<= 3), m = -l..l, y the polar
+    axis -- the basis of allegro/nn/tensorembed.py:55-57,92 (same polynomials as csrc/aa_geom.h)."""
+    if not 0 <= l_max <= 3:
+        raise NotImplementedError("spherical harmonics: l_max <= 3")
+    n = vec / vec.norm(dim=-1, keepdim=True)
+    x, y, z = n.unbind(-1)
+    cols = [torch.ones_like(x)]
+    if l_max >= 1:
+        c = math.sqrt(3.0)
+        cols += [c * x, c * y, c * z]
+    if l_max >= 2:
+        a, b = math.sqrt(15.0), math.sqrt(5.0)
+        xx, yy, zz = x * x, y * y, z * z
+        cols += [a * x * z, a * x * y, b * (yy - 0.5 * (xx + zz)), a * y * z, 0.5 * a * (zz - xx)]
+    if l_max >= 3:
+        xx, yy, zz = x * x, y * y, z * z
+        p, q, s, t = math.sqrt(70.0) / 4, math.sqrt(105.0), math.sqrt(42.0) / 4, math.sqrt(7.0) / 2
+        cols += [p * x * (3 * zz - xx), q * x * y * z, s * x * (5 * yy - 1), t * y * (5 * yy - 3), s * z * (5 * yy - 1),
+                 0.5 * q * y * (zz - xx), p * z * (zz - 3 * xx)]
+    return torch.stack(cols, dim=-1)
+
+
+def _mlp(x: torch.Tensor, weights: List[torch.Tensor], act: Optional[str], act_const: float, forward_init: bool) -> torch.Tensor:
+    """nequip ScalarMLPFunction (EXT; call sites _allegro.py:90-94,193-213, tensorembed.py:76-81, allegro_models.py:173,231):
+    bias-free linears scaled by 1/sqrt(fan_in) (fan_out if not forward_normalize), the activation between layers followed by
+    its second-moment constant."""
+    carry = 1.0
+    last = len(weights) - 1
+    for i, w in enumerate(weights):
+        fan = w.shape[0] if forward_init else w.shape[1]
+        x = x @ (w * (carry / math.sqrt(float(fan))))
+        if i < last and act is not None:
+            x = _ACT[act](x)
+            carry = act_const
+    return x
+
+
+def _weighted_channels(sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int) -> torch.Tensor:
+    """MakeWeightedChannels (allegro/nn/_strided/_channels.py:44-63): out[e,c,i] = sh[e,i] * w[e,c,irrep(i)] (one weight per
+    irrep) or sh[e,i] * w[e,c] (`weight_individual_irreps=False`)."""
+    if w.shape[1] == u:
+        return w.unsqueeze(-1) * sh.unsqueeze(1)
+    # (broadcast views per irrep, not an index gather: the gather's backward is a sort-based index_put)
+    wr = w.reshape(sh.shape[0], u, l_max + 1)
+    return sh.unsqueeze(1) * torch.cat([wr[:, :, l:l + 1].expand(-1, -1, 2 * l + 1) for l in range(l_max + 1)], dim=-1)
+
+
+class TrainingEvaluator:
+    """Differentiable evaluation of one `HipAllegroModel`; owns the per-layer tensor-product plans (unregistered
+    `HipContracter`s: the path weights stay the model's own parameters, state_dict keys unchanged)."""
+
+    def __init__(self, model):
+        from .nn import HipContracter, second_moment_const
+
+        self.model = model
+        hp = model.hparams
+        env = o3.Irreps.spherical_harmonics(hp["l_max"], p=-1)
+        self.sf = 1.0 / math.sqrt(hp["avg_num_neighbors"])
+        self.contracters = []
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(model.dtype)
+        try:
+            for l in range(hp["num_layers"]):
+                c = HipContracter(str(model.tps_irreps[l]), str(env), str(model.tps_irreps[l + 1]), mul=hp["num_tensor_features"],
+                                  path_channel_coupling=hp["coupling"], scatter_factor=self.sf)
+                ref = model._sd()[f"allegro.tps.{l}.w3j"]
+                if c.w3j.shape != ref.shape or not torch.allclose(c.w3j.to(ref), ref):
+                    raise RuntimeError(f"layer {l}: the model's w3j buffer is not the one its irreps generate -- cannot train it")
+                if model._bound_lib is not None:
+                    c._bind_library(model._bound_lib)
+                self.contracters.append(c)
+        finally:
+            torch.set_default_dtype(prev)
+        self.act_consts = {nl: second_moment_const(nl) for nl in set(model.nonlinearities) | {"silu"}}
+        self._bessel_conv = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _weights(self, prefix: str) -> List[torch.Tensor]:
+        node = self.model.func
+        for part in prefix.split("."):
+            node = getattr(node, part)
+        out, i = [], 0
+        while hasattr(node, str(i)):
+            out.append(getattr(node, str(i)).weight)
+            i += 1
+        return out
+
+    def _param(self, dotted: str) -> torch.Tensor:
+        node = self.model.func
+        for part in dotted.split("."):
+            node = getattr(node, part)
+        return node
+
+    def _two_body(self, x: torch.Tensor, tc: torch.Tensor, tn: torch.Tensor) -> torch.Tensor:
+        m, hp = self.model, self.model.hparams
+        T = len(m.type_names)
+        if m.embed_kind == 1:
+            # TwoBodySplineScalarEmbed (scalarembed.py:157-175) -> PerClassSpline.forward (spline.py:64-89)
+            lower, upper = self._param("radial_chemical_embed.spline.lower"), self._param("radial_chemical_embed.spline.upper")
+            k = 2 * math.pi / float(upper[0] - lower[0])
+            t = k * (torch.minimum(torch.maximum(x, lower), upper) - lower)
+            basis = 0.25 * (1 - torch.cos(t)).square()
+            w = self._param("radial_chemical_embed.spline.class_embed.weight").index_select(0, tc * T + tn).view(x.shape[0], -1, lower.numel())
+            return torch.bmm(w, basis.unsqueeze(-1)).squeeze(-1)
+        # TwoBodyBesselScalarEmbed (scalarembed.py:60-81): Bessel x polynomial cutoff -> linear, times the type-pair embedding
+        # (ProductTypeEmbedding, _edgeembed.py:68-84)
+        bw = self._param("radial_chemical_embed.bessel_encode.bessel_weights")
+        conv = m.bessel_convention if self._bessel_conv is None else self._bessel_conv
+        if conv == "auto":  # (resolved once: the roots are a buffer of this model, and the test is a host read)
+            roots = bw.reshape(-1).double()
+            n = torch.arange(1, roots.numel() + 1, dtype=torch.float64, device=roots.device)
+            if torch.allclose(roots, n, rtol=1e-5, atol=0):
+                conv = "sinc"
+            elif torch.allclose(roots, n * math.pi, rtol=1e-5, atol=0):
+                conv = "npi"
+            else:
+                raise RuntimeError("Bessel roots are neither n nor n*pi: pass bessel_convention= to the model")
+            self._bessel_conv = conv
+        bessel = torch.sinc(x * bw) * bw if conv == "sinc" else torch.sin(bw * x) / x
+        p = hp["poly_p"]
+        cut = 1.0 - ((p + 1) * (p + 2) / 2) * x ** p + p * (p + 2) * x ** (p + 1) - (p * (p + 1) / 2) * x ** (p + 2)
+        bessel = bessel * (cut * (x < 1.0))
+        basis = _mlp(bessel, self._weights("radial_chemical_embed.type_embed.basis_linear.mlp"), "silu", self.act_consts["silu"],
+                     hp["forward_normalize"])
+        # (index_select: its backward is an index_add, not the sort-based index_put of advanced indexing)
+        pair = torch.cat((self._param("radial_chemical_embed.type_embed.center_embed.weight").index_select(0, tc),
+                          self._param("radial_chemical_embed.type_embed.neighbor_embed.weight").index_select(0, tn)), dim=-1)
+        return pair * basis
+
+    def atomic_energy(self, pos: torch.Tensor, graph, shift_vec: Optional[torch.Tensor]) -> torch.Tensor:
+        """[N,1] per-atom energies of the center-sorted `graph` (nn.PreparedGraph) as a differentiable function of `pos`,
+        `shift_vec` and every parameter of the model (module order: allegro/model/allegro_models.py:222-228,262-268,297)."""
+        m, hp = self.model, self.model.hparams
+        S, u, L, l_max = hp["num_scalar_features"], hp["num_tensor_features"], hp["num_layers"], hp["l_max"]
+        fwd = hp["forward_normalize"]
+        center, nbr = graph.center.long(), graph.nbr.long()
+        N = graph.num_atoms
+        types = graph.types.long()
+        # edge vectors, normalised lengths (tensorembed.py:86; allegro_models.py:153-157)
+        vec = pos.index_select(0, nbr) - pos.index_select(0, center)
+        if shift_vec is not None:
+            vec = vec + shift_vec
+        tc, tn = types[center], types[nbr]
+        recip = self._param("edge_norm.rmax_recip")
+        x = (vec.norm(dim=-1) * (recip[tc, tn] if recip.numel() > 1 else recip.reshape(-1)[0])).unsqueeze(-1)
+        emb = self._two_body(x, tc, tn)
+        nl_embed, nl_latent, nl_readout = m.nonlinearities
+        emb = _mlp(emb, self._weights("scalar_embed_mlp.mlp.mlp"), nl_embed, self.act_consts[nl_embed], fwd)  # allegro_models.py:173-183
+        silu_c = self.act_consts["silu"]
+        # tensor embedding (tensorembed.py:85-96) and the first layer's environment weights (_allegro.py:251-258)
+        sh = _real_sh(vec, l_max)
+        tf = _weighted_channels(sh, _mlp(emb, self._weights("tensor_embed.env_embed_linear.mlp"), "silu", silu_c, fwd), u, l_max)
+        We = (l_max + 1) * u if m.weight_individual_irreps else u
+        proj = _mlp(emb, self._weights("allegro.first_layer_env_embed_projection.mlp"), "silu", silu_c, fwd)
+        scalars, env_w = [proj[:, :S]], proj[:, S:S + We]
+        for l in range(L):  # _allegro.py:262-294
+            c = self.contracters[l]
+            env = _weighted_channels(sh, env_w, u, l_max)
+            with _device_guard(pos):
+                tf = ops.contract_segments_differentiable(tf.reshape(-1, u, c.base_dim1), env, self._param(f"allegro.tps.{l}.weights"),
+                                                          graph.rowptr, None, center, N, self.sf, c._plan(pos.dtype, pos.device),
+                                                          c._lib_id, c.base_dim1, c.base_dim2, c.base_dim_out)
+            lat = _mlp(torch.cat(scalars + [tf[:, :, 0]], dim=-1), self._weights(f"allegro.latents.{l}.mlp"), nl_latent,
+                       self.act_consts[nl_latent], fwd)
+            scalars.append(lat[:, :S])
+            if l < L - 1:
+                env_w = lat[:, S:S + We]
+        # edge readout, edge -> atom sum, per-type scale / shift (allegro_models.py:231-260; edgewise.py:40-60)
+        e_edge = _mlp(torch.cat(scalars, dim=-1), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd)
+        e_edge = e_edge * (1.0 / math.sqrt(2 * hp["avg_num_neighbors"]))
+        e_atom = torch.zeros((N, 1), dtype=e_edge.dtype, device=e_edge.device).index_add(0, center, e_edge)
+        if m.has_scales:
+            e_atom = e_atom * self._param("per_type_energy_scale_shift.scales").index_select(0, types).reshape(-1, 1)
+        if m.has_shifts:
+            e_atom = e_atom + self._param("per_type_energy_scale_shift.shifts").index_select(0, types).reshape(-1, 1)
+        return e_atom
+
+    def forward(self, data: Dict[str, torch.Tensor], graph) -> Dict[str, torch.Tensor]:
+        """AtomicDataDict out with `forces` (and `stress` / `virial` when `cell` is given) that stay attached to the
+        autograd graph (`create_graph=True`): a loss on them back-propagates into every parameter -- what the reference's
+        ForceStressOutput wrapper does around its energy model (allegro_models.py:101-103)."""
+        m = self.model
+        from .nn import _require_gpu
+
+        _require_gpu(m._get_lib(), data["pos"], "HipAllegroModel (training)")
+        pos = data["pos"].to(m.dtype)
+        if not pos.requires_grad:
+            pos = pos.detach().requires_grad_(True)
+        shift = graph.shift_vec
+        wrt, eps = [pos], None
+        pos_in = pos
+        cells = None
+        if "cell" in data:
+            # strain-displacement construction (nequip ForceStressOutput, EXT): x -> x + x @ eps^T, differentiated at eps = 0
+            cells = data["cell"].to(m.dtype).reshape(-1, 3, 3)
+            nf = cells.shape[0]
+            eps = torch.zeros(nf, 3, 3, dtype=m.dtype, device=pos.device, requires_grad=True)
+            sym = 0.5 * (eps + eps.transpose(1, 2))
+            frame_of_atom = data["batch"] if nf > 1 else torch.zeros(pos.shape[0], dtype=torch.long, device=pos.device)
+            pos_in = pos + torch.einsum("ni,nji->nj", pos, sym[frame_of_atom])
+            if shift is not None:
+                shift = shift + torch.einsum("ei,eji->ej", shift, sym[frame_of_atom[graph.center.long()]])
+            wrt.append(eps)
+        e_atom = self.atomic_energy(pos_in, graph, shift)
+        out = dict(data)
+        out["atomic_energy"] = e_atom
+        if "batch" in data:
+            nf = int(cells.shape[0]) if cells is not None else int(data["batch"].max()) + 1
+            total = torch.zeros(nf, 1, dtype=m.dtype, device=pos.device).index_add(0, data["batch"], e_atom)
+        else:
+            total = e_atom.sum().reshape(1, 1)
+        out["total_energy"] = total
+        grads = torch.autograd.grad(total.sum(), wrt, create_graph=torch.is_grad_enabled() and m.training)
+        out["forces"] = -grads[0]
+        if eps is not None:
+            vol = torch.linalg.det(cells).abs().reshape(-1, 1, 1)
+            out["stress"] = grads[1] / vol
+            out["virial"] = -grads[1]
+        return out
+
+
+class _device_guard:
+    """The HIP launches go to the device of `t` (no-op for the CPU emulation library of the tests)."""
+
+    def __init__(self, t: torch.Tensor):
+        self.ctx = torch.cuda.device(t.device) if t.is_cuda else None
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)

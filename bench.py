@@ -382,6 +382,98 @@ def train_op_bench(args, dev):
     print(json.dumps(line), flush=True)
 
 
+def train_step_bench(args, dev):
+    """`--mode train-step`: one optimisation step of the WHOLE model in training mode (`HipAllegroModel.train()`,
+    allegro_amd/training.py): energies + forces attached to the graph, a force- and energy-matching loss, backward into every
+    parameter (the forces are differentiated again), Adam update.  Tensor products on the HIP kernels, linear layers on
+    library GEMMs.  Baseline: the same step through the eager PyTorch-ROCm port of the reference model (oracle, baseline
+    only) on a bounded block of center atoms (its [E,u,d,d] intermediates)."""
+    g, cfg = make_workload(args.workload)
+    dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
+    torch.manual_seed(0)
+    model = HipAllegroModel(**cfg).to(dev).train()
+    N, E = g.num_atoms, g.num_edges
+    sv = g.shift_vec()
+    pos = torch.tensor(g.pos, dtype=dtype, device=dev)
+    types = torch.tensor(g.types, device=dev)
+    graph = PreparedGraph(torch.tensor(g.edge_index, device=dev), types, N, torch.tensor(sv, dtype=dtype, device=dev) if sv is not None else None)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    f_target = 0.1 * torch.randn(N, 3, dtype=dtype, device=dev, generator=gen)
+    ev = model._training_evaluator()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = ev.forward({"pos": pos}, graph)
+        loss = (out["forces"] - f_target).square().mean() + 1e-3 * (out["total_energy"] / N).square().sum()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    peak0 = torch.cuda.max_memory_allocated(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    peak = max(peak0, torch.cuda.max_memory_allocated(dev))
+    # inference step of the same model on the same graph, for scale
+    model.eval()
+    for _ in range(3):
+        model.energy_forces(pos, graph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        model.energy_forces(pos, graph)
+    torch.cuda.synchronize()
+    ms_inf = (time.perf_counter() - t0) / 10 * 1e3
+    # baseline: eager port of the reference model, same loss, on a bounded block of centers
+    from oracle import restatement as R  # (baseline leg only)
+
+    rowptr = G.csr_from_sorted_centers(g.edge_index[0], N)
+    a1 = max(1, min(int(np.searchsorted(rowptr, 20000, side="left")), N))
+    e1 = int(rowptr[a1])
+    sd = {k[len("func."):]: v.detach().clone().to(dev) for k, v in model.state_dict().items()}
+    names = [k[len("func."):] for k, p in model.named_parameters() if k not in model._frozen_keys]
+    for k in names:
+        sd[k].requires_grad_(True)
+    opt_r = torch.optim.Adam([sd[k] for k in names], lr=1e-4)
+    ei_s = torch.tensor(g.edge_index[:, :e1], device=dev)
+    sv_s = torch.tensor(sv[:e1], dtype=dtype, device=dev) if sv is not None else None
+
+    def step_ref():
+        opt_r.zero_grad(set_to_none=True)
+        p = pos.detach().clone().requires_grad_(True)
+        e_atom = R.allegro_energy(dict(cfg), sd, p, ei_s, types, sv_s)
+        (gp,) = torch.autograd.grad(e_atom.sum(), p, create_graph=True)
+        loss = (-gp - f_target).square().mean() + 1e-3 * (e_atom.sum() / N).square()
+        loss.backward()
+        opt_r.step()
+
+    step_ref()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        step_ref()
+    torch.cuda.synchronize()
+    ms_ref = (time.perf_counter() - t0) / 3 * 1e3
+    L = cfg["num_layers"]
+    line = dict(metric="whole-model training step (forward, force+energy loss, backward into every parameter, Adam), edge tensor-products/s",
+                mode="train-step", value=E * L / ms * 1e3, unit="edge-TP/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
+                higher_is_better=True, dtype="f32" if dtype == torch.float32 else "f64", data="synthetic",
+                config=dict(workload=f"{args.workload}: {N} atoms / {E} edges, l_max {cfg['l_max']}, {L} layers, {cfg['num_tensor_features']} tensor features",
+                            parameters=int(sum(p.numel() for p in params)), optimizer="Adam"),
+                final_loss=float(loss), peak_memory_GB=peak / 1e9, inference_ms_per_step=ms_inf, train_over_inference=ms / ms_inf,
+                eager_port_gpu=dict(ms_per_step=ms_ref, edges=e1, value=e1 * L / ms_ref * 1e3, unit="edge-TP/s", kind="port",
+                                    sample=f"first {a1} center atoms / {e1} edges of the same box"),
+                speedup_vs_eager_port=(E / ms) / (e1 / ms_ref))
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -401,14 +493,20 @@ def main():
     ap.add_argument("--shard-sweep", type=int, default=0, metavar="W",
                     help="analysis only: time every rank's compact shard of a W-way partition on this one GPU, one after "
                          "the other (load balance: max / mean shard time; no collective), print one JSON line and exit")
-    ap.add_argument("--mode", default="step", choices=["step", "train-op"],
-                    help="step: the whole hot path (default, the driver's contract); train-op: training step of the operator seam")
+    ap.add_argument("--mode", default="step", choices=["step", "train-op", "train-step"],
+                    help="step: the whole hot path (default, the driver's contract); train-op: training step of the operator seam; "
+                         "train-step: optimisation step of the whole model in training mode")
     args = ap.parse_args()
     if args.mode == "train-op":
         assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(dev)
         return train_op_bench(args, dev)
+    if args.mode == "train-step":
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        return train_step_bench(args, dev)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -1,0 +1,135 @@
+"""Whole-step training mode of `HipAllegroModel` (allegro_amd/training.py): energies and forces of the
+differentiable evaluation against the REFERENCE-generated golden outputs, and the gradient of a force-matching loss
+(forces differentiated again) with respect to EVERY trainable parameter against autograd through the oracle --
+what the reference gets by training its eager model (weights are Parameters: allegro/nn/_allegro.py:192-213,
+allegro/nn/_strided/_contract.py:172-177).  CPU: the tensor-product kernels run in the emulation build of the HIP
+sources; `-m gpu`: the gfx950 library.  fp64 1e-9, fp32 2e-4 of the largest entry."""
+import pytest
+import torch
+
+from tests.golden_utils import load_model_fixture
+from tests.hip_utils import model_from_fixture
+
+
+def _loss(out, wf):
+    return (out["forces"] * wf).square().sum() + 0.3 * out["total_energy"].sum()
+
+
+def _training_case(name, dtype, lib, dev):
+    from oracle import restatement as R
+
+    fx = load_model_fixture(name, dtype)
+    m = model_from_fixture(fx, dtype, lib, dev)
+    assert not any(p.requires_grad for p in m.parameters())  # a fresh model is the inference pipeline
+    m.train()
+    N = fx["pos"].shape[0]
+    graph = m.prepare_graph(fx["edge_index"].to(dev), fx["types"].to(dev), N, None if fx["shift_vec"] is None else fx["shift_vec"].to(dev))
+    out = m._training_evaluator().forward({"pos": fx["pos"].to(dev)}, graph)
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    for key in ("atomic_energy", "forces"):
+        want = fx["out"][key].to(dtype)
+        got = out[key].detach().cpu().reshape(want.shape)
+        assert (got - want).abs().max().item() <= tol * max(1.0, float(want.abs().max())), f"{name}: {key} vs the reference's golden output"
+    wf = torch.linspace(0.5, 1.5, 3 * N, dtype=dtype).reshape(N, 3)
+    names = [k for k, p in m.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad(_loss(out, wf.to(dev)), [p for p in m.parameters() if p.requires_grad])
+    # oracle: the same loss through the restatement, autograd to every float entry of the state_dict
+    sd = {k: v.clone() for k, v in fx["sd"].items()}
+    for k in names:
+        sd[k[len("func."):]].requires_grad_(True)
+    pos = fx["pos"].clone().requires_grad_(True)
+    e_atom = R.allegro_energy(fx["cfg"], sd, pos, fx["edge_index"], fx["types"], fx["shift_vec"])
+    (gp,) = torch.autograd.grad(e_atom.sum(), pos, create_graph=True)
+    ref = torch.autograd.grad(_loss({"forces": -gp, "total_energy": e_atom.sum()}, wf), [sd[k[len("func."):]] for k in names])
+    assert len(names) >= 8
+    for k, g, r in zip(names, grads, ref):
+        scale = max(1e-6, float(r.abs().max()))
+        assert (g.cpu() - r).abs().max().item() <= tol * scale, f"{name}: d loss / d {k}"
+    # back to inference: frozen parameters, the hand-written pipeline
+    m.eval()
+    assert not any(p.requires_grad for p in m.parameters())
+
+
+@pytest.mark.parametrize("name,dtype", [("t_coupled", torch.float64), ("t_uncoupled", torch.float64), ("t_spline_peredge", torch.float64),
+                                        ("t_acts", torch.float64), ("t_shared", torch.float32), ("c5_small", torch.float64)])
+def test_training_mode_gradients_match_oracle_autograd_emulated(name, dtype):
+    from tests.hip_utils import emu_lib
+
+    _training_case(name, dtype, emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype", [("t_coupled", torch.float64), ("t_peredge", torch.float32), ("c2", torch.float32), ("c2", torch.float64),
+                                        ("c2_spline", torch.float32), ("c2_uncoupled", torch.float64), ("c2_l3", torch.float32),
+                                        ("c2_L3", torch.float32), ("c2_u128", torch.float32), ("c5_small", torch.float64), ("c1_L2", torch.float32)])
+def test_training_mode_gradients_match_oracle_autograd_on_gpu(name, dtype):
+    _training_case(name, dtype, None, torch.device("cuda:0"))
+
+
+def _optimizer_case(lib, dev):
+    """Two Adam steps in training mode change the parameters in place; the inference pipeline then evaluates the UPDATED
+    model (the packed device weights follow `_version`), equal to the training-mode evaluation of the same parameters."""
+    fx = load_model_fixture("t_coupled", torch.float64)
+    m = model_from_fixture(fx, torch.float64, lib, dev).train()
+    N = fx["pos"].shape[0]
+    graph = m.prepare_graph(fx["edge_index"].to(dev), fx["types"].to(dev), N, fx["shift_vec"].to(dev))
+    pos = fx["pos"].to(dev)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-2)
+    target = torch.zeros(N, 3, dtype=torch.float64, device=dev)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = m._training_evaluator().forward({"pos": pos}, graph)
+        loss = (out["forces"] - target).square().mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+    f_train = m._training_evaluator().forward({"pos": pos}, graph)["forces"].detach()
+    m.eval()
+    _e, f_eval = m.energy_forces(pos, graph)
+    assert (f_eval - f_train).abs().max().item() <= 1e-9 * max(1.0, float(f_train.abs().max()))
+
+
+def test_optimizer_steps_then_inference_emulated():
+    from tests.hip_utils import emu_lib
+
+    _optimizer_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_optimizer_steps_then_inference_on_gpu():
+    _optimizer_case(None, torch.device("cuda:0"))
+
+
+def _public_route_case(lib, dev):
+    """`model.train(); model(data)` -- the AtomicDataDict route with a cell: forces equal the golden output, stress equals
+    the oracle's strain derivative / volume, and both stay attached to the graph."""
+    from oracle import restatement as R
+
+    fx = load_model_fixture("t_peredge", torch.float64)
+    m = model_from_fixture(fx, torch.float64, lib, dev).train()
+    cell = torch.eye(3, dtype=torch.float64) * 1.0  # shift_vec = edge_cell_shift @ cell with a unit cell
+    data = {"pos": fx["pos"].to(dev), "edge_index": fx["edge_index"].to(dev), "atom_types": fx["types"].to(dev),
+            "cell": cell.to(dev), "edge_cell_shift": fx["shift_vec"].to(dev)}
+    out = m(data)
+    want = fx["out"]["forces"].to(torch.float64)
+    assert (out["forces"].detach().cpu() - want).abs().max().item() <= 1e-9 * max(1.0, float(want.abs().max()))
+    vir = R.allegro_virial(fx["cfg"], fx["sd"], fx["pos"], fx["edge_index"], fx["types"], fx["shift_vec"])
+    assert (out["stress"].detach().cpu().reshape(3, 3) - vir).abs().max().item() <= 1e-9 * max(1.0, float(vir.abs().max()))
+    assert out["forces"].requires_grad and out["stress"].requires_grad and out["total_energy"].requires_grad
+    with torch.no_grad():  # validation inside a training loop: the inference pipeline
+        out2 = m(data)
+    assert not out2["forces"].requires_grad
+    assert (out2["forces"].cpu() - want).abs().max().item() <= 1e-9 * max(1.0, float(want.abs().max()))
+
+
+def test_training_mode_public_route_with_stress_emulated():
+    from tests.hip_utils import emu_lib
+
+    _public_route_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_training_mode_public_route_with_stress_on_gpu():
+    _public_route_case(None, torch.device("cuda:0"))
