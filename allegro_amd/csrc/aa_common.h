@@ -371,6 +371,13 @@ size_t tp_layer_wgrad_workspace_elems(const TpLayerDev& L, int64_t N);
 template <typename T>
 int launch_tp_layer_wgrad(const TpLayerDev& L, const TpLayerWgradArgs& a, hipStream_t stream);
 
+// s_waitcnt vmcnt(0) (gfx9 encoding: expcnt / lgkmcnt fields at 'no wait'): all of the wave's global loads have landed.
+// Used before a pipelined loop whose first trip would otherwise enter with prologue loads in flight: the compiler's
+// waitcnt insertion merges that state with the back edge's conservatively and then waits for the NEWEST prefetches in
+// front of every trip's first MFMA (seen in gemm_f64_rows_kernel: vmcnt(2) / vmcnt(0) ahead of MFMAs that read registers
+// written by v_mov).
+__device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 template <typename T>
 int launch_segment_sum(int64_t N, int64_t row, const void* x, const int32_t* rowptr, const int32_t* eids, double scale, void* out,
                        hipStream_t stream);

@@ -247,6 +247,65 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
 }
 
 // Pipelined variant for the model's shapes (every A segment a multiple of 16 columns wide, 16-B aligned rows):
+// Epilogue of one 16-column MFMA tile pair of a wave (v_mfma_f64_16x16x4 layout: register r of tile i = row 16 i + 4 r +
+// lane / 16, column lane % 16): out = (acc [+ add]) [* silu'(z)] [+ C].  The operand loads of the eight elements are issued
+// TOGETHER, ahead of the arithmetic -- element-by-element code waits out the full memory latency eight times per tile
+// (each load sits behind a wave-uniform branch, which the compiler does not hoist loads across).
+__device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int64_t m_base, int li, int lg, const v4d& acc0, const v4d& acc1) {
+  if (t0 >= g.N) return;
+  int cc = t0, si = -1;
+#pragma unroll
+  for (int s2 = 0; s2 < 3; ++s2) {
+    if (s2 < g.c.count && si < 0) {
+      if (cc < g.c.s[s2].n)
+        si = s2;
+      else
+        cc -= g.c.s[s2].n;
+    }
+  }
+  if (si < 0) return;
+  double* cp = static_cast<double*>(g.c.s[si].p);
+  if (!cp) return;
+  const int ldc = g.c.s[si].ld, col = cc + li;
+  const double* zp = g.has_z ? static_cast<const double*>(g.z.s[si].p) : nullptr;
+  const double* ap = g.has_add ? static_cast<const double*>(g.add.s[si].p) : nullptr;
+  const int ldz = g.has_z ? g.z.s[si].ld : 0, lda2 = g.has_add ? g.add.s[si].ld : 0;
+  const bool accum = g.c_accum[si] != 0;
+  int64_t gm[8], gl[8];  // row, row clamped for the loads
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    gm[e] = m_base + 16 * (e >> 2) + 4 * (e & 3) + lg;
+    gl[e] = gm[e] < g.M ? gm[e] : g.M - 1;
+  }
+  double v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (e >> 2) ? acc1[e & 3] : acc0[e & 3];
+  if (ap) {
+    double t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = ap[gl[e] * lda2 + col];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+  if (zp) {
+    double t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = zp[gl[e] * ldz + col];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= dsilu(t[e]);
+  }
+  if (accum) {
+    double t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = cp[gl[e] * ldc + col];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (gm[e] < g.M) cp[gm[e] * ldc + col] = v[e];
+}
+
 // 128 x 64 block tile, 16-deep steps; the next step's global loads are in flight while this step's 32 MFMAs per
 // wave issue, LDS double-buffered (one barrier per step).  Each wave owns 32 rows x 64 columns (2 x 4 MFMA tiles).
 constexpr int G6_BM = 128, G6_BN = 64, G6_BK = 16, G6_LDA = G6_BM + 4;
@@ -347,40 +406,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) 
   // epilogue: a 16-column tile never straddles a C segment here (widths are multiples of 16, checked by the
   // launcher), so the destination / z / add rows are resolved once per tile, wave-uniformly
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t0 = n0 + j * 16;
-    if (t0 >= g.N) continue;
-    int cc = t0, si = -1;
-#pragma unroll
-    for (int s2 = 0; s2 < 3; ++s2) {
-      if (s2 < g.c.count && si < 0) {
-        if (cc < g.c.s[s2].n)
-          si = s2;
-        else
-          cc -= g.c.s[s2].n;
-      }
-    }
-    if (si < 0) continue;
-    double* cp = static_cast<double*>(g.c.s[si].p);
-    if (!cp) continue;
-    const int ldc = g.c.s[si].ld, col = cc + (lane & 15);
-    const double* zp = g.has_z ? static_cast<const double*>(g.z.s[si].p) : nullptr;
-    const double* ap = g.has_add ? static_cast<const double*>(g.add.s[si].p) : nullptr;
-    const int ldz = g.has_z ? g.z.s[si].ld : 0, lda2 = g.has_add ? g.add.s[si].ld : 0;
-    const bool accum = g.c_accum[si] != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t gm = m0 + wv * 32 + i * 16 + 4 * r + (lane >> 4);
-        if (gm >= g.M) continue;
-        double v = acc[i][j][r];
-        if (ap) v += ap[gm * lda2 + col];
-        if (zp) v *= dsilu(zp[gm * ldz + col]);
-        if (accum) v += cp[gm * ldc + col];
-        cp[gm * ldc + col] = v;
-      }
-  }
+  for (int j = 0; j < 4; ++j) f64_tile_epilogue(g, n0 + j * 16, m0 + wv * 32, lane & 15, lane >> 4, acc[0][j], acc[1][j]);
   }  // column tiles
 }
 
@@ -448,12 +474,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     for (int i = 0; i < 2; ++i) {
       const double* ap = base + arow[i] * ld + 4 * lg;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        v2d v = *reinterpret_cast<const v2d*>(ap + 2 * h);
-        if (g.act_a) v = v2d{silu(v[0]), silu(v[1])};
-        a[i][h] = v;
-      }
+      for (int h = 0; h < 2; ++h) a[i][h] = *reinterpret_cast<const v2d*>(ap + 2 * h);
     }
+  };
+  // the activation of a fetched chunk, applied when the chunk is about to be used -- NOT next to its loads: there it
+  // makes every load wait out its own latency before the next one is issued
+  auto a_activate = [&](v2d (*a)[2]) {
+    if (!g.act_a) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) a[i][h] = v2d{silu(a[i][h][0]), silu(a[i][h][1])};
   };
   // 2 x JT x 4 MFMAs of one chunk against the staged weight block
   auto mma_chunk = [&](const double* bs, const v2d (*a)[2], v4d (*acc)[JT]) {
@@ -468,44 +499,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
         for (int j = 0; j < JT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][s >> 1][s & 1], b[j], acc[i][j], 0, 0, 0);
     }
   };
-  // epilogue of one pass: a 16-column tile never straddles a C segment (widths are multiples of 16, checked by the
-  // launcher), so the destination / z / add rows are resolved once per tile, wave-uniformly
   auto epilogue = [&](int n0, v4d (*acc)[JT]) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const int t0 = n0 + j * 16;
-      if (t0 >= g.N) continue;
-      int cc = t0, si = -1;
-#pragma unroll
-      for (int s2 = 0; s2 < 3; ++s2) {
-        if (s2 < g.c.count && si < 0) {
-          if (cc < g.c.s[s2].n)
-            si = s2;
-          else
-            cc -= g.c.s[s2].n;
-        }
-      }
-      if (si < 0) continue;
-      double* cp = static_cast<double*>(g.c.s[si].p);
-      if (!cp) continue;
-      const int ldc = g.c.s[si].ld, col = cc + li;
-      const double* zp = g.has_z ? static_cast<const double*>(g.z.s[si].p) : nullptr;
-      const double* ap = g.has_add ? static_cast<const double*>(g.add.s[si].p) : nullptr;
-      const int ldz = g.has_z ? g.z.s[si].ld : 0, lda2 = g.has_add ? g.add.s[si].ld : 0;
-      const bool accum = g.c_accum[si] != 0;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t gm = m_base + i * 16 + 4 * r + lg;
-          if (gm >= g.M) continue;
-          double v = acc[i][j][r];
-          if (ap) v += ap[gm * lda2 + col];
-          if (zp) v *= dsilu(zp[gm * ldz + col]);
-          if (accum) v += cp[gm * ldc + col];
-          cp[gm * ldc + col] = v;
-        }
-    }
+    for (int j = 0; j < JT; ++j) f64_tile_epilogue(g, n0 + j * 16, m_base, li, lg, acc[0][j], acc[1][j]);
   };
   v4d acc[2][JT];
   auto zero_acc = [&]() {
@@ -520,6 +516,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     for (int c = 0; c < KCMAX; ++c)
       if (c < KC) a_load(c, areg[c]);
     stage_load(0, 0);
+#pragma unroll
+    for (int c = 0; c < KCMAX; ++c)
+      if (c < KC) a_activate(areg[c]);
     stage_write(0);
     __syncthreads();
     int buf = 0;
@@ -545,6 +544,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     stage_load(0, 0);
     a_load(0, acur);
     stage_write(0);
+    wait_vmem_all();  // (enter the loop with nothing in flight, see wait_vmem_all)
+    a_activate(acur);
     __syncthreads();
     int buf = 0;
     for (int c = 0; c < KC; ++c) {
@@ -554,7 +555,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
         a_load(c + 1, anext);
       }
       mma_chunk(smem + buf * 16 * LDB, acur, acc);
-      if (more) stage_write(buf ^ 1);
+      if (more) {
+        stage_write(buf ^ 1);
+        a_activate(anext);
+      }
       __syncthreads();
       buf ^= 1;
 #pragma unroll

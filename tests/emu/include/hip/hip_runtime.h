@@ -273,6 +273,7 @@ inline emu_v4f_mfma __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_barrier() { emu::yield_block_barrier(); }
 #define __builtin_amdgcn_fence(...) ((void)0)  // (address-space scoped fences around a raw s_barrier)
 inline void __builtin_amdgcn_wave_barrier() { emu::wave_rendezvous(); }  // fibers of a wave run one after another here
