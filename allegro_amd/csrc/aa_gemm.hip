@@ -1729,13 +1729,13 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok && g.opt_f64_column_loop == 0 && g.opt_f64_rows != 2 && (g.K % 16) == 0 &&
-             (g.opt_f64_rows == 1 ? (g.N <= 128 || g.K <= 128) : (g.N <= 128 && (g.K > 128 || !(g.has_z || g.has_add))))) {
-    // row-resident kernels: every operand row is read from HBM once.  Measured at C5 (1.7 M rows, profiles/
-    // r02_v12_f64rows_*): the accumulator-resident form wins 4-9 % for K > 128 and for plain 128 x 128 layers, loses
-    // 10-20 % where the epilogue carries z / add operands (two waves per SIMD hide their latency worse than three);
-    // the operand-resident form (N > 128) is 5-30 % slower than the staged kernel although it reads A once instead
-    // of N / 64 times -- those re-reads are served by the infinity cache, not HBM -- so it only runs when forced
-    // (aa_plan_options.f64_rows = 1).
+             (g.opt_f64_rows == 1 ? (g.N <= 128 || g.K <= 128) : (g.N <= 128 || (g.K <= 128 && !(g.has_z || g.has_add))))) {
+    // row-resident kernels: every operand row is read from HBM once.  Measured at C5 (1.7 M rows; profiles/r03_*_stages_c5.log,
+    // after the epilogue loads were batched and the operand activation deferred): the accumulator-resident form (N <= 128)
+    // wins everywhere, 54-58 vs 45-52 TFLOP/s for K > 128 and 5-10 % on 128 x 128 layers with or without z / add operands;
+    // the operand-resident form (N > 128, K <= 128) wins 5-8 % on plain layers and loses 25-30 % where the epilogue carries
+    // z / add operands (its two waves per SIMD overlap the silu' arithmetic of one pass with the next pass's MFMAs worse
+    // than the staged kernel's three) -- those keep the staged kernel unless forced (aa_plan_options.f64_rows = 1).
     dim3 gridr((unsigned)((g.M + 127) / 128));
     if (g.N <= 128) {
       const size_t smemr = sizeof(double) * 2 * 16 * (128 + 4);

@@ -1,5 +1,5 @@
 # end-of-round evidence: GPU tests, smoke, stress, bench lines (C4 default incl. baselines, C5, C1, C2, C3), shard runs,
-# operator-seam training step, native-op overhead, profiles with PMC traffic
+# operator-seam and whole-model training steps, fp64 matrix-core probes, native-op overhead, profiles with PMC traffic
 cd /root/repo
 TAG=${1:-r03_final}
 mkdir -p gpurun_out
@@ -14,6 +14,12 @@ timeout 300 python bench.py --workload c3 --steps 100 --warmup 10 --no-cpu-basel
 timeout 600 python bench.py --shard-sweep 8 --steps 10 --warmup 3 > gpurun_out/${TAG}_shard_sweep8_c4.json 2> /dev/null
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 10 --warmup 3 --emulate-shard 3/8 --no-cpu-baseline --no-gpu-reference --no-profile --sustain 0 > gpurun_out/${TAG}_bench_torchrun1_shard3of8.log 2>&1
 timeout 900 python bench.py --mode train-op --workload c3 --steps 8 --warmup 2 > gpurun_out/${TAG}_train_op_c3.json 2>/dev/null
+timeout 900 python bench.py --mode train-op --workload c4 --steps 8 --warmup 2 > gpurun_out/${TAG}_train_op_c4.json 2>/dev/null
+AA_TP_GENERIC=1 timeout 900 python bench.py --mode train-op --workload c3 --steps 4 --warmup 1 > gpurun_out/${TAG}_train_op_c3_generic.json 2>/dev/null
+timeout 900 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 > gpurun_out/${TAG}_train_step_c3.json 2>/dev/null
+timeout 900 python bench.py --mode train-step --workload c4 --steps 3 --warmup 1 > gpurun_out/${TAG}_train_step_c4.json 2>/dev/null
+for b in f64_gemm_loop mfma_f64_bcast_probe; do timeout 120 tools/ubench/$b.bin > gpurun_out/${TAG}_ubench_$b.log 2>&1; done
+timeout 120 tools/ubench/mfma_f64_bcast_map.bin > /dev/null 2> gpurun_out/${TAG}_ubench_mfma_f64_bcast_map.log
 timeout 600 python tools/op_overhead.py > gpurun_out/${TAG}_op_overhead.json 2>/dev/null
 bash tools/profile_gpu.sh c4 ${TAG} > /dev/null 2>&1
 cp gpurun_out/prof_${TAG}_c4/summary.txt gpurun_out/${TAG}_rocprofv3_c4_summary.txt
@@ -25,4 +31,6 @@ for f in c4 c5 c1 c2 c3; do echo "$f $(grep -o '"ms_per_step": [0-9.]*' gpurun_o
 grep -o '"speedup_vs_gpu_reference": [0-9.]*' gpurun_out/${TAG}_bench_c4.log gpurun_out/${TAG}_bench_c5.log
 grep -o '"sustained": {[^}]*}' gpurun_out/${TAG}_bench_c4.log
 grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_bench_torchrun1_shard3of8.log
+for f in train_op_c3 train_op_c4 train_step_c3 train_step_c4; do echo "$f $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_$f.json | head -1)"; done
+cat gpurun_out/${TAG}_ubench_f64_gemm_loop.log
 tail -2 gpurun_out/${TAG}_rocprofv3_c4_summary.txt
