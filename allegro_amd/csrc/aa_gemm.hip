@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
 // Epilogue of one 16-column MFMA tile pair of a wave (v_mfma_f64_16x16x4 layout: register r of tile i = row 16 i + 4 r +
 // lane / 16, column lane % 16): out = (acc [+ add]) [* silu'(z)] [+ C].  The operand loads of the eight elements are issued
 // TOGETHER, ahead of the arithmetic -- element-by-element code waits out the full memory latency eight times per tile
-// (each load sits behind a wave-uniform branch, which the compiler does not hoist loads across).
+// (each load sits behind a wave-uniform branch, which the compiler does not hoist loads across).  Also tried: the loads of
+// tile j + 1 issued before the arithmetic and stores of tile j (two operand sets in flight) -- 3 % on the accumulator-
+// resident kernel's z layers, but 57-150 spilled registers in the staged and the operand-resident kernel, whose K loops
+// then run 25-50 % slower (profiles/r03_n_stages_c5.log); not kept.
 __device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int64_t m_base, int li, int lg, const v4d& acc0, const v4d& acc1) {
   if (t0 >= g.N) return;
   int cc = t0, si = -1;
@@ -1725,16 +1728,20 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   bool pipe_ok = (g.N % 2) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
   for (int s2 = 0; s2 < g.a.count; ++s2)
     pipe_ok = pipe_ok && (g.a.s[s2].n % 16) == 0 && (g.a.s[s2].ld % 2) == 0 && (reinterpret_cast<uintptr_t>(g.a.s[s2].p) & 15) == 0;
-  for (int s2 = 0; s2 < g.c.count; ++s2) pipe_ok = pipe_ok && (g.c.s[s2].n % 16) == 0;
+  bool epilogue_reads = g.has_z || g.has_add;  // operands the epilogue has to FETCH (z, add, accumulated-into C)
+  for (int s2 = 0; s2 < g.c.count; ++s2) {
+    pipe_ok = pipe_ok && (g.c.s[s2].n % 16) == 0;
+    epilogue_reads = epilogue_reads || g.c_accum[s2] != 0;
+  }
   if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok && g.opt_f64_column_loop == 0 && g.opt_f64_rows != 2 && (g.K % 16) == 0 &&
-             (g.opt_f64_rows == 1 ? (g.N <= 128 || g.K <= 128) : (g.N <= 128 || (g.K <= 128 && !(g.has_z || g.has_add))))) {
+             (g.opt_f64_rows == 1 ? (g.N <= 128 || g.K <= 128) : (g.N <= 128 || (g.K <= 128 && !epilogue_reads)))) {
     // row-resident kernels: every operand row is read from HBM once.  Measured at C5 (1.7 M rows; profiles/r03_*_stages_c5.log,
     // after the epilogue loads were batched and the operand activation deferred): the accumulator-resident form (N <= 128)
     // wins everywhere, 54-58 vs 45-52 TFLOP/s for K > 128 and 5-10 % on 128 x 128 layers with or without z / add operands;
-    // the operand-resident form (N > 128, K <= 128) wins 5-8 % on plain layers and loses 25-30 % where the epilogue carries
-    // z / add operands (its two waves per SIMD overlap the silu' arithmetic of one pass with the next pass's MFMAs worse
+    // the operand-resident form (N > 128, K <= 128) wins 5-8 % on plain layers and loses 25-30 % where the epilogue fetches
+    // z / add operands or accumulates into C (its two waves per SIMD overlap the silu' arithmetic of one pass with the next pass's MFMAs worse
     // than the staged kernel's three) -- those keep the staged kernel unless forced (aa_plan_options.f64_rows = 1).
     dim3 gridr((unsigned)((g.M + 127) / 128));
     if (g.N <= 128) {
