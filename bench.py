@@ -151,7 +151,11 @@ def profile_stages(model, pos, graph, reps=5):
 
 # kernel symbol behind each stage-name prefix
 _SYMBOLS = (("gc_", "gemm_chain_bf16x3_kernel"), ("gemm_", "gemm_bf16x3_kernel"))
-_SYMBOLS_F64 = (("gemm_", "gemm_mfma_f64_pipe_kernel"),)
+# the fp64 linear layers of one step run on three kernels (launch_gemm<double>: accumulator-resident rows kernel for N <= 128,
+# operand-resident rows kernel for plain N > 128 layers, staged kernel for the rest); they are priced as one group
+_F64_GEMM_GROUP = "fp64 linear layers (gemm_f64_rows_kernel<false>, gemm_f64_rows_kernel<true>, gemm_mfma_f64_pipe_kernel)"
+_F64_GEMM_KEYS = ("gemm_f64_rows_kernel<false>", "gemm_f64_rows_kernel<true>", "gemm_mfma_f64_pipe")
+_SYMBOLS_F64 = (("gemm_", _F64_GEMM_GROUP),)
 
 
 def roofline_from_stages(stages, dtype, workload="c4"):
@@ -184,7 +188,7 @@ def roofline_from_stages(stages, dtype, workload="c4"):
         tf = d["flops"] / n / t / 1e12
         roof.update(bound="mfma", achieved=tf, peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F32_TFLOPS,
                     algorithmic_flops_per_launch=d["flops"] / n, hbm_GBps=ach)
-    if dtype == "float64" and sym.startswith("gemm_") and d["flops"] > 0:
+    if dtype == "float64" and sym == _F64_GEMM_GROUP and d["flops"] > 0:
         # the fp64 linear layers (K, N >= 128) run at >= 64 flop/B: bound by the fp64 matrix pipe, not by HBM
         tf = d["flops"] / n / t / 1e12
         roof.update(bound="mfma", achieved=tf, peak=PEAK_F64_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_F64_TFLOPS,
@@ -199,7 +203,14 @@ def roofline_from_stages(stages, dtype, workload="c4"):
         pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{workload}.json")))
         key = next((k for k in pj["per_launch"] if k in sym or sym.startswith(k)), None)
         have, want = pj.get("source_hash"), source_hash()
-        if key is None:
+        group = [e for k, e in pj["per_launch"].items() if any(g in k for g in _F64_GEMM_KEYS)] if sym == _F64_GEMM_GROUP else []
+        if group and have == want:
+            # launch-weighted mean over the kernels of the group
+            nl = sum(e["launches"] for e in group)
+            roof["traffic"] = sum((e.get("fetch_bytes", 0.0) + e.get("write_bytes", 0.0)) * e["launches"] for e in group) / max(nl, 1)
+            roof["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, launch-weighted mean over the group's kernels, "
+                                      f"{pj['source']} (kernel sources {want})")
+        elif key is None and not group:
             roof["traffic_source"] = f"traffic: null -- {pj['source']} has no entry for {sym}"
         elif have != want:
             roof["traffic_source"] = (f"traffic: null -- committed PMC measurement {pj['source']} was taken on kernel sources "
