@@ -1,5 +1,9 @@
 cd /root/repo
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_hip_full_size.py tests/test_gemm_accuracy.py tests/test_hip_model.py -x -q -m gpu 2>&1 | tail -2
-timeout 900 python bench.py --workload c5 --steps 5 --warmup 2 --stages --no-cpu-baseline --no-gpu-reference --sustain 0 > gpurun_out/r03_o_bench_c5.log 2> gpurun_out/r03_o_stages_c5.log
-grep -o '"ms_per_step": [0-9.]*' gpurun_out/r03_o_bench_c5.log; grep "stage. gemm" gpurun_out/r03_o_stages_c5.log | cut -c1-110
+: > gpurun_out/r03_v11_pytest_gpu_x5.log
+for i in 1 2 3 4 5; do
+  echo "== full GPU suite, run $i" >> gpurun_out/r03_v11_pytest_gpu_x5.log
+  timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 >> gpurun_out/r03_v11_pytest_gpu_x5.log
+done
+python -c "from allegro_amd import build; print('kernel source hash', build.source_hash())" >> gpurun_out/r03_v11_pytest_gpu_x5.log
+cat gpurun_out/r03_v11_pytest_gpu_x5.log
