@@ -479,6 +479,22 @@ class DeviceNeighborList:
         return PreparedGraph(self.edge_index, atom_types, self.rowptr.numel() - 1, self.shift_vec, transposed=transposed,
                              rowptr=self.rowptr)
 
+    def ghost_layout(self, pos: torch.Tensor, atom_types: torch.Tensor):
+        """The same list in the ghost-atom layout of the reference's `pair_allegro` contract (allegro/_compile.py:28-63),
+        built on the device: every outside-cell edge gets its own ghost atom (not deduplicated) at `pos[nbr] + shift`,
+        ghosts are appended after the real atoms, no cell / shifts remain; edges keep their center-sorted order.
+        Returns (pos [N + G, 3], atom_types [N + G], edge_index int64 [2, E], ghost_source int64 [G]) -- forces on ghost
+        row g belong to atom ghost_source[g] (what LAMMPS reverse-communicates).  One host read: the ghost count."""
+        n = pos.shape[0]
+        ei = self.edge_index.long()
+        outside = (self.cell_shift != 0).any(dim=1)
+        slot = torch.cumsum(outside.to(torch.int64), 0) - 1  # running ghost index of each outside-cell edge
+        ghost_src = ei[1][outside]
+        nbr = torch.where(outside, n + slot, ei[1])
+        pos_ext = torch.cat((pos, pos.index_select(0, ghost_src) + self.shift_vec[outside].to(pos.dtype)), dim=0)
+        types_ext = torch.cat((atom_types, atom_types.index_select(0, ghost_src)), dim=0)
+        return pos_ext, types_ext, torch.stack((ei[0], nbr)), ghost_src
+
 
 def neighbor_list(pos: torch.Tensor, cell, pbc, r_cut: float, lib: Optional[_lib.AllegroLib] = None) -> DeviceNeighborList:
     """Cell-list neighbor list on the device the positions live on: every pair/image with |r| < r_cut, edges sorted by

@@ -163,3 +163,47 @@ def test_invalid_inputs_are_reported_not_crashed():
         neighbor_list(pos, np.zeros((3, 3)), True, 2.0, lib=lib)
     with pytest.raises(AllegroError, match="GPU"):
         neighbor_list(pos, np.eye(3) * 5, True, 2.0)  # default (gfx950) library: CPU tensors are refused
+
+
+def _ghost_layout_case(lib, dev):
+    """`DeviceNeighborList.ghost_layout` (device-side ghost construction of the `pair_allegro` contract,
+    allegro/_compile.py:28-63) against the host construction of allegro_amd/graph.py, and the model on it: local energies
+    equal the periodic evaluation, ghost-row forces folded back onto their source atoms equal the periodic forces."""
+    from allegro_amd import graph as G
+    from allegro_amd.nn import neighbor_list
+    from tests.golden_utils import load_model_fixture
+    from tests.hip_utils import model_from_fixture
+
+    fx = load_model_fixture("c2", torch.float64)
+    m = model_from_fixture(fx, torch.float64, lib, dev)
+    g = G.make_si_graph(2)
+    pos = torch.tensor(g.pos, device=dev)
+    types = torch.tensor(g.types, device=dev)
+    nl = neighbor_list(pos, torch.tensor(g.cell), True, 5.0, lib=lib)
+    pos_x, types_x, ei_x, src = nl.ghost_layout(pos, types)
+    gg = G.to_ghost_layout(g)
+    n = g.num_atoms
+    assert pos_x.shape[0] == gg.num_atoms and ei_x.shape[1] == g.num_edges
+    assert bool((ei_x[1] >= n).sum() == gg.num_atoms - n)
+    # same multiset of (center, neighbor position) pairs as the host construction
+    def key(p, ei):
+        v = p[ei[1]] - p[ei[0]]
+        return torch.sort((ei[0].double() * 1e3 + (v * torch.tensor([1.0, 7.0, 49.0], dtype=torch.float64, device=v.device)).sum(-1)))[0]
+    kd = key(pos_x, ei_x).cpu()
+    kh = key(torch.tensor(gg.pos), torch.tensor(gg.edge_index))
+    assert (kd - kh).abs().max().item() < 1e-9
+    e, f = m.energy_forces(pos_x, m.prepare_graph(ei_x, types_x, pos_x.shape[0]))
+    folded = f[:n].clone().index_add_(0, src, f[n:]).cpu()
+    assert (folded - fx["out"]["forces"]).abs().max().item() < 1e-9
+    assert (e[:n].cpu() - fx["out"]["atomic_energy"].reshape(-1)).abs().max().item() < 1e-9
+
+
+def test_device_ghost_layout_emulated():
+    from tests.hip_utils import emu_lib
+
+    _ghost_layout_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_device_ghost_layout_on_gpu():
+    _ghost_layout_case(None, torch.device("cuda:0"))
