@@ -70,6 +70,8 @@ template <class V>
 __device__ __forceinline__ void anchor(V& v) {
   asm volatile("" : "+v"(v)::"memory");
 }
+// a wave-uniform value the optimizer cannot see through from here on (stays in a scalar register; emits no instruction)
+__device__ __forceinline__ void opaque_scalar(int& v) { asm volatile("" : "+s"(v)); }
 #endif
 // DPP lane pattern applied to v (fused by the compiler into the consuming VALU op)
 constexpr int kDppRowRor8 = 0x128, kDppRowRor4 = 0x124, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
@@ -584,8 +586,14 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream);
 // fused per-atom-tile kernels (aa_fused.hip): the whole forward of the standard 2-layer, 64-wide stack in ONE launch
 // ----------------------------------------------------------------------------------------------
 constexpr int kFusedMaxSteps = 56;
+constexpr int kFusedMaxDegree = 128;  // longest edge segment the fused forward takes: a team of four 32-edge tiles
+constexpr int kFusedTeamTilesSmall = 4096;  // up to this many tiles the team form is chosen regardless of how full the tiles are
 struct FusedFwdArgs {
-  int64_t N, atom0, atom_end;  // atoms [atom0, atom_end) are evaluated (one wave each); every one has <= 32 edges
+  int64_t N, atom0, atom_end;  // atoms [atom0, atom_end) are evaluated: one wave each (every one has <= 32 edges), or -- with
+                               // tile_atoms -- teams of 1 / 2 / 4 waves (<= 128 edges)
+  int32_t* tile_atoms;         // nullptr | [3][tile_cap] class lists (scratch, filled by fused_classify_kernel)
+  int32_t* tile_counts;        // [4] class counters (scratch)
+  int64_t tile_cap;
   const int32_t *rowptr, *nbr, *types;
   const float* pos;
   const float* shift_vec;  // [E,3] or nullptr

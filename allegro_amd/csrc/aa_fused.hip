@@ -27,9 +27,16 @@
 // Weights stream L2 -> LDS once per workgroup (4 waves = 4 atoms share every 12-KB step, double buffered), exactly
 // the staging of gemm_chain_bf16x3_kernel.
 //
-// Limits of this first version: every center atom of the block has <= 32 edges (aa_graph.max_degree; larger
-// segments run the staged pipeline), u = S = all MLP widths = 64, embedding table path (<= 2 species, 8 basis
-// functions), fp32.
+// Segments longer than one tile (TEAMS = true, aa_graph.max_degree in 33..128): an atom with up to 64 / 128 edges is
+// owned by a TEAM of 2 / 4 waves of one workgroup, wave t of the team running edges [32 t, 32 t + 32) of the segment.
+// Everything per edge is unchanged; the two per-atom sums (x2s of either layer, linear in the moments) and the atom's
+// energy are completed across the team through LDS in team order (bit-reproducible), every member then derives the
+// per-atom vectors B from the complete x2s.  Atoms are dealt to workgroups by class (4 / 2 / 1 tiles: one / two / four
+// atoms per workgroup) from three lists that fused_classify_kernel fills with atomic counters -- which atom lands in which
+// slot varies from run to run, no result depends on it.
+//
+// Limits: every center atom of the block has <= 128 edges (larger segments run the staged pipeline), u = S = all MLP
+// widths = 64, embedding table path (<= 3 species, 8 basis functions), l_max <= 2, fp32.
 #include "aa_fused_tile.h"
 
 namespace aa {
@@ -47,6 +54,23 @@ __device__ unsigned long long g_fused_ticks[32];
 #define AA_TICK(i)
 #endif
 
+// x[D] (lane = channel) summed over the waves [first, first + tsize) of a team, in that order (every member ends up with the
+// same bits); tsize is workgroup-uniform, so the barrier is too.  The exchange area is reused by the next call only after
+// dozens of weight-pipeline barriers.
+template <int D>
+__device__ __forceinline__ void team_sum(float* sX, int wv, int first, int tsize, int lane, float* x) {
+  if (tsize == 1) return;
+#pragma unroll
+  for (int j = 0; j < D; ++j) sX[(wv * 16 + j) * 64 + lane] = x[j];
+  lds_barrier();
+#pragma unroll
+  for (int j = 0; j < D; ++j) x[j] = 0.f;
+  for (int m = 0; m < tsize; ++m) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] += sX[((first + m) * 16 + j) * 64 + lane];
+  }
+}
+
 // per-lane geometry inputs of one tile, fetched one iteration ahead of their use
 struct TileIn {
   int beg, cnt;   // edge segment of the wave's atom (cnt = 0: nothing to do)
@@ -55,7 +79,10 @@ struct TileIn {
   int ti, tj;
 };
 
-template <class Sig0, class Sig1, bool HOLD>
+// team exchange area behind the parked tiles: x2s partials [4 waves][D <= 16][64] + energy partials [4]
+constexpr int kTeamFloats = 4 * 16 * 64 + 4;
+
+template <class Sig0, class Sig1, bool HOLD, bool TEAMS>
 __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs A) {
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   static_assert(Sig0::D1 == D && Sig0::DOUT == D && Sig1::D1 == D && Sig1::DOUT == 1, "standard 2-layer stack");
@@ -75,6 +102,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   float* sBv = sW + kOffB;
   // parked tiles of this wave: two-body scalars (2 tiles) and lat0 (2 tiles)
   float* sPark = sTab + ntab + 4 * (kWaveRegion + 32 * kLdY) + wv * 4 * kTileFloats;
+  float* sTeam = sTab + ntab + 4 * (kWaveRegion + 32 * kLdY) + 4 * 4 * kTileFloats;  // (TEAMS only) [4][D][64] | [4]
 #define AA_PARK(i, t) park_tile(sPark + (i) * kTileFloats, t, lane)
 #define AA_FETCH(i) fetch_tile(sPark + (i) * kTileFloats, lane)
   for (int i = tid; i < 64; i += 256) sRo[i] = A.ro_w[i];
@@ -86,21 +114,57 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   p.tid = tid;
   p.lane = lane;
   p.stager = true;
+  p.zero = 0;
   {
     u32x4 r[3];
     pipe_load(A, tid, 0, r);
     pipe_store(wbuf, 0, tid, r);
     pipe_load(A, tid, 1, p.rb);  // (step 1 lands in LDS at the end of step 0)
   }
-  // ---- persistent loop over groups of 4 atoms; the inputs of the next tile are fetched during the current one
-  const int64_t ngroups = (A.atom_end - A.atom0 + 3) / 4;
-  auto atom_of = [&](int64_t it) { return A.atom0 + (int64_t(blockIdx.x) + it * gridDim.x) * 4 + wv; };
-  auto load_rows = [&](int64_t atom, int& beg, int& cnt) {
+  // ---- persistent loop over groups of 4 waves' worth of tiles; the inputs of the next tile are fetched during the current one
+  // TEAMS: groups [0, n4) hold one 4-tile atom each, [n4, n4 + g2) two 2-tile atoms, the rest four 1-tile atoms
+  int n4 = 0, n2 = 0, n1 = 0;
+  if constexpr (TEAMS) {
+    n4 = __builtin_amdgcn_readfirstlane(A.tile_counts[0]);
+    n2 = __builtin_amdgcn_readfirstlane(A.tile_counts[1]);
+    n1 = __builtin_amdgcn_readfirstlane(A.tile_counts[2]);
+  }
+  const int64_t g2 = (int64_t(n2) + 1) / 2, g1 = (int64_t(n1) + 3) / 4;
+  const int64_t ngroups = TEAMS ? int64_t(n4) + g2 + g1 : (A.atom_end - A.atom0 + 3) / 4;
+  auto group_of = [&](int64_t it) { return int64_t(blockIdx.x) + it * gridDim.x; };
+  // team geometry of the wave in group g: tiles per atom, this wave's tile.  Everything here is wave-uniform and kept in
+  // scalar registers (the kernel has no vector register to spare).
+  const int wvs = __builtin_amdgcn_readfirstlane(wv);
+  auto team_size = [&](int64_t g) { return !TEAMS ? 1 : (g < n4 ? 4 : (g < n4 + g2 ? 2 : 1)); };
+  auto tile_of = [&](int64_t g) { return !TEAMS ? 0 : (g < n4 ? wvs : (g < n4 + g2 ? (wvs & 1) : 0)); };
+  auto atom_of = [&](int64_t it) -> int64_t {
+    const int64_t g = group_of(it);
+    if constexpr (!TEAMS) {
+      return A.atom0 + g * 4 + wv;
+    } else {
+      int at = int(A.atom_end);
+      if (g < ngroups) {
+        if (g < n4) {
+          at = A.tile_atoms[g];
+        } else if (g < n4 + g2) {
+          const int64_t i = (g - n4) * 2 + (wvs >> 1);
+          if (i < n2) at = A.tile_atoms[A.tile_cap + i];
+        } else {
+          const int64_t i = (g - n4 - g2) * 4 + wvs;
+          if (i < n1) at = A.tile_atoms[2 * A.tile_cap + i];
+        }
+      }
+      return __builtin_amdgcn_readfirstlane(at);
+    }
+  };
+  auto load_rows = [&](int64_t atom, int tile, int& beg, int& cnt) {
     beg = 0;
     cnt = 0;
     if (atom < A.atom_end) {
-      beg = A.rowptr[atom];
-      cnt = A.rowptr[atom + 1] - beg;
+      const int b0 = A.rowptr[atom], deg = A.rowptr[atom + 1] - b0;
+      beg = b0 + 32 * tile;
+      cnt = deg - 32 * tile;
+      cnt = cnt < 0 ? 0 : (cnt > 32 ? 32 : cnt);
     }
   };
   auto load_nbr = [&](int beg, int cnt) { return el < cnt ? A.nbr[int64_t(beg) + el] : 0; };
@@ -119,28 +183,34 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
       t.tj = A.types[t.j];
     }
   };
+  // atom ids travel three iterations ahead (TEAMS: they come from the class lists), row pointers two, neighbor ids and geometry one
+  int64_t a_cur = atom_of(0), a_nxt = atom_of(1), a_nn = atom_of(2);
   TileIn cur, nxt;
   int beg2 = 0, cnt2 = 0;
-  load_rows(atom_of(0), cur.beg, cur.cnt);
-  load_rows(atom_of(1), nxt.beg, nxt.cnt);
+  load_rows(a_cur, tile_of(group_of(0)), cur.beg, cur.cnt);
+  load_rows(a_nxt, tile_of(group_of(1)), nxt.beg, nxt.cnt);
   cur.j = load_nbr(cur.beg, cur.cnt);
-  load_geo(atom_of(0), cur);
+  load_geo(a_cur, cur);
   float wp0[Sig0::P], wp1[Sig1::P];
 #pragma unroll
   for (int q = 0; q < Sig0::P; ++q) wp0[q] = A.coupling ? A.tpw0[lane * Sig0::P + q] : A.tpw0[q];
 #pragma unroll
   for (int q = 0; q < Sig1::P; ++q) wp1[q] = A.coupling ? A.tpw1[lane * Sig1::P + q] : A.tpw1[q];
   lds_barrier();  // tables + first weight step staged
-  for (int64_t it = 0; blockIdx.x + it * gridDim.x < ngroups; ++it) {
+  for (int64_t it = 0; group_of(it) < ngroups; ++it) {
+    opaque_scalar(p.zero);  // (see pipe_load)
     AA_TICK(0)
-    const int64_t atom = atom_of(it);
+    const int64_t atom = a_cur;
     const bool atom_ok = atom < A.atom_end;
+    const int tsize = team_size(group_of(it)), tile = tile_of(group_of(it)), tfirst = wvs - tile;  // (tsize: workgroup-uniform)
+    const bool leader = tile == 0;
+    const int64_t a_n3 = atom_of(it + 3);
     const int beg = __builtin_amdgcn_readfirstlane(cur.beg), cnt = __builtin_amdgcn_readfirstlane(cur.cnt);
     const bool row_ok = el < cnt;
     const int64_t row0 = beg;
     // prefetch: neighbor ids of the next tile, row pointers of the one after
     nxt.j = load_nbr(nxt.beg, nxt.cnt);
-    load_rows(atom_of(it + 2), beg2, cnt2);
+    load_rows(a_nn, tile_of(group_of(it + 2)), beg2, cnt2);
     // ---- geometry of the lane's edge (rows beyond the segment: a harmless dummy that is masked everywhere)
     float Y[D], basis[8];
     int pair = 0;
@@ -240,7 +310,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
       float M[D];
       tile_moments<D>(sW, sY, em0, em1, lane, M);
       project_moments<S_P0, NS, D, R>(A, p, sW, M, A.sf, x2s0);
-      if (atom_ok) {
+      if constexpr (TEAMS) team_sum<D>(sTeam, wvs, tfirst, tsize, lane, x2s0);
+      if (atom_ok && leader) {
 #pragma unroll
         for (int j = 0; j < D; ++j) A.x2s0[(atom * D + j) * 64 + lane] = x2s0[j];
       }
@@ -302,7 +373,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
       float M[D], x2s1[D];
       tile_moments<D>(sW, sY, k0, k1, lane, M);
       project_moments<S_P1, NS, D, R>(A, p, sW, M, A.sf, x2s1);
-      if (atom_ok) {
+      if constexpr (TEAMS) team_sum<D>(sTeam, wvs, tfirst, tsize, lane, x2s1);
+      if (atom_ok && leader) {
 #pragma unroll
         for (int j = 0; j < D; ++j) A.x2s1[(atom * D + j) * 64 + lane] = x2s1[j];
       }
@@ -326,7 +398,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   }
                                 });
     // inputs of the next tile (its neighbor ids arrived long ago): positions, shifts, types
-    load_geo(atom_of(it + 1), nxt);
+    load_geo(a_nxt, nxt);
     AA_TICK(9)
     // ---- L5: layer-1 scalars with B1 -- from the held w0 tiles, or from w0 recomputed out of the embedding
 #pragma unroll
@@ -392,7 +464,16 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   float tot = row_ok ? part : 0.f;
 #pragma unroll
                                   for (int m = 32; m >= 1; m >>= 1) tot += __shfl_xor(tot, m);
-                                  if (atom_ok && lane == 0) {
+                                  if constexpr (TEAMS) {
+                                    if (tsize > 1) {  // (workgroup-uniform) the team's tiles, added in tile order
+                                      float* sE = sTeam + 4 * 16 * 64;
+                                      if (lane == 0) sE[wvs] = tot;
+                                      lds_barrier();
+                                      tot = 0.f;
+                                      for (int m = 0; m < tsize; ++m) tot += sE[tfirst + m];
+                                    }
+                                  }
+                                  if (atom_ok && leader && lane == 0) {
                                     float en = tot * A.ro_factor;
                                     const int t = A.types[atom];
                                     if (A.scales) en *= A.scales[t];
@@ -405,7 +486,22 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     cur = nxt;
     nxt.beg = beg2;
     nxt.cnt = cnt2;
+    a_cur = a_nxt;
+    a_nxt = a_nn;
+    a_nn = a_n3;
   }
+}
+
+// the class lists of the TEAMS form: atoms with 65..128 / 33..64 / 0..32 edges -> lists 0 / 1 / 2 ([3][cap]) through atomic
+// counters (zeroed by the launcher).  Slot order is arbitrary; nothing depends on it.
+__global__ __launch_bounds__(256) void fused_classify_kernel(int64_t a0, int64_t a1, const int32_t* rowptr, int64_t cap, int32_t* atoms,
+                                                             int32_t* counts) {
+  const int64_t n = a0 + int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (n >= a1) return;
+  const int deg = rowptr[n + 1] - rowptr[n];
+  const int cls = deg > 64 ? 0 : (deg > 32 ? 1 : 2);
+  const int idx = atomicAdd(&counts[cls], 1);
+  atoms[cls * cap + idx] = int32_t(n);
 }
 
 // atoms outside the block the fused kernel covers (other ranks' blocks of an atom partition): E_i = shift_t
@@ -415,9 +511,10 @@ __global__ __launch_bounds__(256) void fused_fill_energy_kernel(int64_t N, int64
   if (n < N && (n < a0 || n >= a1)) atom_energy[n] = shifts ? shifts[types[n]] : 0.f;
 }
 
-size_t fused_fwd_lds_bytes(int num_types) {
+size_t fused_fwd_lds_bytes(int num_types, bool teams) {
   return sizeof(u32x4) * 2 * kWStep +
-         sizeof(float) * (64 + 32 + size_t(num_types) * num_types * 512 + 4 * (kWaveRegion + 32 * kLdY) + (kFusedOcc == 1 ? 4 * 4 * kTileFloats : 0));
+         sizeof(float) * (64 + 32 + size_t(num_types) * num_types * 512 + 4 * (kWaveRegion + 32 * kLdY) + (kFusedOcc == 1 ? 4 * 4 * kTileFloats : 0) +
+                          (teams ? kTeamFloats : 0));
 }
 
 // number of weight-pipeline steps of the program for R irreps (see the kernel)
@@ -425,7 +522,8 @@ int fused_fwd_num_steps(int R, bool hold) { return 8 + (2 + 2 * R) + 4 + 4 + 2 +
 
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;
-  const size_t smem = fused_fwd_lds_bytes(a.num_types);
+  const bool teams = a.tile_atoms != nullptr;
+  const size_t smem = fused_fwd_lds_bytes(a.num_types, teams);
   if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "fused forward: LDS budget exceeded");
   if (a.N > 0 && (a.atom0 > 0 || a.atom_end < a.N)) {
     hipLaunchKernelGGL(fused_fill_energy_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, stream, a.N, a.atom0, a.atom_end,
@@ -439,14 +537,22 @@ int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t 
     AA_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
     num_cu = n > 0 ? n : 256;
   }
-  const int64_t ngroups = (a.atom_end - a.atom0 + 3) / 4;
+  // TEAMS: the number of groups is only known on the device (class counters): at most one group per atom
+  const int64_t ngroups = teams ? a.atom_end - a.atom0 : (a.atom_end - a.atom0 + 3) / 4;
   dim3 grid((unsigned)std::min<int64_t>(ngroups, int64_t(num_cu) * kFusedOcc));
-#define AA_FUSED_LAUNCH(S0_, S1_, H_)                                                                          \
-  {                                                                                                            \
-    const void* fn = (const void*)fused_fwd_kernel<cg::S0_, cg::S1_, H_>;                                      \
-    AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));              \
-    hipLaunchKernelGGL((fused_fwd_kernel<cg::S0_, cg::S1_, H_>), grid, dim3(256), smem, stream, a);            \
+  if (teams) {
+    AA_CHECK_HIP(hipMemsetAsync(a.tile_counts, 0, 4 * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(fused_classify_kernel, dim3((unsigned)((a.atom_end - a.atom0 + 255) / 256)), dim3(256), 0, stream, a.atom0, a.atom_end,
+                       a.rowptr, a.tile_cap, a.tile_atoms, a.tile_counts);
   }
+#define AA_FUSED_LAUNCH1(S0_, S1_, H_, T_)                                                                     \
+  {                                                                                                            \
+    const void* fn = (const void*)fused_fwd_kernel<cg::S0_, cg::S1_, H_, T_>;                                  \
+    AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));              \
+    hipLaunchKernelGGL((fused_fwd_kernel<cg::S0_, cg::S1_, H_, T_>), grid, dim3(256), smem, stream, a);        \
+  }
+#define AA_FUSED_LAUNCH(S0_, S1_, H_) \
+  if (teams) AA_FUSED_LAUNCH1(S0_, S1_, H_, true) else AA_FUSED_LAUNCH1(S0_, S1_, H_, false)
   if (pair == 0) {
     if (hold_w0) AA_FUSED_LAUNCH(Sig1, Sig0, true) else AA_FUSED_LAUNCH(Sig1, Sig0, false)
   } else if (pair == 1) {
@@ -455,6 +561,7 @@ int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t 
     return fail(AA_ERR_INVALID, "fused forward: unsupported signature pair");
   }
 #undef AA_FUSED_LAUNCH
+#undef AA_FUSED_LAUNCH1
   AA_CHECK_HIP(hipGetLastError());
 #ifdef AA_FUSED_TIMING
   {

@@ -33,6 +33,7 @@ struct FusedPipe {
   u32x4* wbuf;  // [2][kWStep]
   int tid, lane;
   bool stager;  // this wave takes part in staging the weight blocks (the first four waves of the workgroup: 256 x 48 B = 12 KB)
+  int zero;     // 0, opaque to the optimizer and refreshed once per trip of the persistent loop (see pipe_load)
 };
 
 
@@ -40,10 +41,14 @@ struct FusedPipe {
 //  offset register -- with per-lane base selects the compiler hoists ~140 loop-invariant 64-bit address pairs out of
 //  the persistent loop and spills them)
 //  What remains hoisted -- the block addresses of the ~46 steps -- costs two or three scratch reloads per step.)
+//  `zero` (an SGPR the optimizer cannot see through, set anew in every trip of the persistent loop) is added to the step
+//  index so that the two block addresses of a step are scalar loads from the argument block INSIDE the loop -- with a
+//  constant index they are loop-invariant, all ~90 address pairs are hoisted, and what does not fit the scalar file is
+//  spilled and reloaded from scratch two or three times per step.
 template <class Args>
-__device__ __forceinline__ void pipe_load(const Args& A, int tid, int t, u32x4* r) {
-  const u32x4* s0 = static_cast<const u32x4*>(A.wstep[t][0]);
-  const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t][1]);
+__device__ __forceinline__ void pipe_load(const Args& A, int tid, int t, u32x4* r, int zero = 0) {
+  const u32x4* s0 = static_cast<const u32x4*>(A.wstep[t + zero][0]);
+  const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t + zero][1]);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const u32x4* mid = wv < 2 ? s0 + 256 : s1 - 128;  // elements 256..383 of the first half | 0..127 of the second
   r[0] = s0[tid];
@@ -60,9 +65,9 @@ template <int S, int NS, class Args>
 __device__ __forceinline__ void pipe_issue(const Args& A, FusedPipe& p) {
   if (!p.stager) return;
   if constexpr ((S & 1) == 0)
-    pipe_load(A, p.tid, (S + 2) % NS, p.ra);
+    pipe_load(A, p.tid, (S + 2) % NS, p.ra, p.zero);
   else
-    pipe_load(A, p.tid, (S + 2) % NS, p.rb);
+    pipe_load(A, p.tid, (S + 2) % NS, p.rb, p.zero);
 }
 template <int S>
 __device__ __forceinline__ void pipe_commit(FusedPipe& p) {

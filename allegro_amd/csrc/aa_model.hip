@@ -806,7 +806,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, bvec_op, gm_op, mom_op, trev, dvec, vir_part;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, bvec_op, gm_op, mom_op, trev, dvec, vir_part, tiles;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -861,6 +861,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
   for (int i = 0; i < c.readout_mlp_depth; ++i) w.ro_h[i] = take(Ez * c.readout_mlp_width);
   if (p->chain_gemm) w.e_edge = take(Ez);
   if (p->embed_fused) w.trev = take(Ez * 8);
+  if (p->fused_fwd) w.tiles = take(((3 * Nz + 8) * sizeof(int32_t) + es - 1) / es);  // class lists + counters of the team form
   if (with_forces) {
     w.dvec = take(Ez * 4);
     w.vir_part = take((size_t(kVirialBlocks) * 9 * sizeof(double) + es - 1) / es);
@@ -1248,7 +1249,15 @@ struct Runner {
 
   // the whole forward in one launch (aa_fused.hip): every center atom's edge segment fits one 32-row MFMA tile
   bool use_fused_fwd(const aa_graph* g) const {
-    return sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= 32;
+    if (!(sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= kFusedMaxDegree)) return false;
+    if (g->max_degree <= 32) return true;  // one full-ish tile per atom: faster than the staged forward at every size
+    // Team form (2 / 4 tiles per atom): a tile costs the same whether 32 or 12 of its rows carry an edge, so it pays where
+    // the step is latency-bound (few tiles: one launch instead of seven) or the tiles are nearly full.  Measured on Si boxes
+    // at r_max 6 / 7 (44 / 73 edges per atom, profiles/r03_p_*): 216-512 atoms 17-27 % faster than the staged step, 1 728
+    // atoms -2 % / +8 %, 10 648 atoms +10 % / +18 % slower (69 % / 57 % of the tile rows in use).
+    const int64_t n_active = g->atom_end > g->atom_begin ? g->atom_end - g->atom_begin : g->num_atoms;
+    const int64_t tiles = n_active * (g->max_degree <= 64 ? 2 : 4);  // (upper bound: every atom at the class of the longest segment)
+    return tiles <= kFusedTeamTilesSmall || double(g->num_edges) >= 0.85 * 32.0 * double(tiles);
   }
   // the reverse tail in one launch (aa_fused_bwd.hip): same eligibility as the fused forward + the two-body table of the reverse
   bool use_fused_tail(const aa_graph* g) const { return use_fused_fwd(g) && p->fused_tail; }
@@ -1358,6 +1367,15 @@ struct Runner {
     a.types = g->types;
     a.pos = static_cast<const float*>(pos);
     a.shift_vec = static_cast<const float*>(g->shift_vec);
+    // segments of more than one 32-edge tile: teams of waves, dealt from class lists in the workspace
+    a.tile_atoms = nullptr;
+    a.tile_counts = nullptr;
+    a.tile_cap = 0;
+    if (g->max_degree > 32) {
+      a.tile_counts = reinterpret_cast<int32_t*>(buf(w.tiles));
+      a.tile_atoms = a.tile_counts + 8;
+      a.tile_cap = g->num_atoms;
+    }
     a.num_types = c.num_types;
     a.embed_kind = c.embed_kind;
     a.spline_span = c.spline_span;

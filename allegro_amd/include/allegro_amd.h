@@ -182,11 +182,11 @@ typedef struct {
    * atom-block partition.  Per-atom kernels are then launched over that range only.  0,0 = all atoms.
    * The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
   int64_t atom_begin, atom_end;
-  /* optional hint: no center atom has more than max_degree edges (0 = unknown).  With 0 < max_degree <= 32 the standard
+  /* optional hint: no center atom has more than max_degree edges (0 = unknown).  With 0 < max_degree <= 128 the standard
    * 2-layer 64-wide fp32 stack runs the fused per-atom-tile forward (one launch instead of seven, 2.1 instead of 7.3 KB
-   * of HBM traffic per edge; faster at every size, most where the step is launch-latency-bound -- see
-   * aa_plan_options.fused_forward and DESIGN.md section 9.1); otherwise the staged pipeline.  The caller guarantees it
-   * (allegro_amd.nn.PreparedGraph derives it from rowptr). */
+   * of HBM traffic per edge; up to 32: one wave per atom; 33..128: teams of 2 / 4 waves per atom, dealt from class lists
+   * that one extra small launch builds -- chosen where it is faster: small systems (<= 4096 tiles) or nearly full tiles;
+   * see aa_plan_options.fused_forward and DESIGN.md section 9.1); otherwise the staged pipeline.  The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
   int64_t max_degree;
 } aa_graph;
 

@@ -68,8 +68,10 @@ WORKLOADS = {
 def make_workload(name):
     w = WORKLOADS[name]
     if w["kind"] == "si":
-        g = G.make_si_graph(int(os.environ.get("AA_BENCH_CELLS", w["cells"])))  # (AA_BENCH_CELLS: size sweeps, experiments only)
+        rcut = float(os.environ.get("AA_BENCH_RCUT", "5.0"))  # (experiments only: denser neighbor lists, e.g. 6.5 -> ~60 edges per atom)
+        g = G.make_si_graph(int(os.environ.get("AA_BENCH_CELLS", w["cells"])), r_cut=rcut)  # (AA_BENCH_CELLS: size sweeps, experiments only)
         cfg = si_model_cfg(g.num_edges / g.num_atoms)
+        cfg["r_max"] = rcut
         cfg["l_max"] = w.get("l_max", cfg["l_max"])
         cfg["num_tensor_features"] = w.get("u", cfg["num_tensor_features"])
         if os.environ.get("AA_BENCH_LMAX"):  # experiments only: the same box and widths at another l_max

@@ -4,7 +4,8 @@ stack in one launch, one wave per center atom's edge tile.
 CPU: the unmodified kernel source in the test-only emulation build, against the reference's golden vectors, against
 the fp64 oracle on ragged graphs (partial tiles, an atom without edges, two species, per-type scale/shift), and on
 atom-block sub-ranges (the multi-GPU partition).  GPU: the same checks on hardware plus the staged pipeline as A/B.
-The fused path needs `aa_graph.max_degree <= 32` (larger segments fall back to the staged pipeline) and is the DEFAULT
+The fused path needs `aa_graph.max_degree <= 128` (up to 32: one wave per atom; above: teams of waves; larger segments fall
+back to the staged pipeline) and is the DEFAULT
 forward wherever the graph allows it; AA_FUSED=0 selects the staged pipeline."""
 import numpy as np
 import pytest
@@ -21,7 +22,7 @@ def _opt_in(monkeypatch, mode="tile32"):
     monkeypatch.setenv("AA_FUSED", "1")
 
 
-from tests.fastpath_utils import _cfg, _ragged  # noqa: E402,F401
+from tests.fastpath_utils import _assert_launched, _cfg, _ragged, _vs_oracle64  # noqa: E402,F401
 
 
 def _check_vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev, blocks=None):
@@ -121,30 +122,133 @@ def test_three_species_run_the_fused_forward_on_gpu(embed, monkeypatch):
     _three_species((8, 8, 7), 6, embed, None, torch.device("cuda:0"), monkeypatch)
 
 
-def test_degree_above_32_falls_back_to_the_staged_pipeline_emulated(monkeypatch):
-    _opt_in(monkeypatch)
-    rng = np.random.default_rng(9)
-    grid = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(3), indexing="ij"), -1).reshape(-1, 3)[:40]
-    pos = grid * 0.7 + rng.uniform(-0.05, 0.05, size=(40, 3)) + 20.0
+def _mixed_degree_cluster(cut=2.2, per_class=(3, 3, 2, 1)):
+    """110 atoms on a jittered 0.7 grid + one isolated atom; the edge segments of a few center atoms of every tile class
+    (1..32, 33..64, 65..96, 97..128 edges) are kept, the other atoms are neighbors only (emulation time)."""
+    rng = np.random.default_rng(3)
+    grid = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3)[:110]
+    pos = grid * 0.7 + rng.uniform(-0.05, 0.05, size=(110, 3)) + 20.0
+    pos = np.concatenate([pos, [[50.0, 50.0, 50.0]]])
     cell = np.eye(3) * 60.0
-    ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
-    deg = np.bincount(ei[0], minlength=40)
-    assert deg.max() > 32
-    from oracle import restatement as R
+    ei, shift = G.neighbor_list_pbc(pos, cell, cut)
+    deg = np.bincount(ei[0], minlength=111)
+    pick = []
+    for (lo, hi), k in zip(((1, 32), (33, 64), (65, 96), (97, 128)), per_class):
+        pick += [int(i) for i in np.argsort(deg, kind="stable") if lo <= deg[i] <= hi][:k]
+    keep = np.isin(ei[0], pick)
+    return pos, cell, ei[:, keep], shift[keep], rng.integers(0, 2, size=111), sorted(int(deg[i]) for i in pick)
 
-    cfg = _cfg(avg=float(deg.mean()), scale_shift=False)
-    m = HipAllegroModel(**cfg)
-    m._bind_library(emu_lib())
-    tt = torch.tensor(rng.integers(0, 2, size=40))
-    sv = torch.tensor(shift @ cell, dtype=torch.float32)
-    g = m.prepare_graph(torch.tensor(ei), tt, 40, sv)
-    assert g.max_degree > 32
-    e, f = m.energy_forces(torch.tensor(pos, dtype=torch.float32), g)
-    sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
-    cfg64 = dict(cfg, model_dtype="float64")
-    ref = R.allegro_energy_forces(cfg64, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()},
-                                  torch.tensor(pos), torch.tensor(ei), tt, sv.double())
-    assert (f.double() - ref["forces"]).abs().max().item() < 2e-4 * max(1.0, float(ref["forces"].abs().max()))
+
+def _teams_case(lib, dev, monkeypatch, cut=2.2, per_class=(3, 3, 2, 1)):
+    """Segments of more than one 32-edge tile run the TEAM form of the fused forward (2 / 4 waves per atom, per-atom sums
+    completed through LDS): against the fp64 oracle, against the staged pipeline on the same graph, bit-reproducible although
+    the slot assignment comes from atomic counters, and the launch list names the kernel."""
+    monkeypatch.delenv("AA_FUSED", raising=False)
+    pos, cell, ei, shift, types, degs = _mixed_degree_cluster(cut, per_class)
+    assert degs[0] <= 32 and any(32 < d <= 64 for d in degs) and any(64 < d <= 128 for d in degs), degs
+    cfg = _cfg(avg=float(np.mean(degs)), scale_shift=True)
+    m = _vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev)
+    sv = torch.tensor(shift @ cell, dtype=torch.float32, device=dev)
+    g = m.prepare_graph(torch.tensor(ei).to(dev), torch.tensor(types).to(dev), pos.shape[0], sv)
+    assert 32 < g.max_degree <= 128
+    p = torch.tensor(pos, dtype=torch.float32, device=dev)
+    e1, f1 = (t.clone() for t in m.energy_forces(p, g))
+    e2, f2 = (t.clone() for t in m.energy_forces(p, g))
+    assert torch.equal(e1, e2) and torch.equal(f1, f2)
+    import bench
+
+    names = [s[0] for s in bench.profile_stages(m, p, g, reps=1)]
+    assert "fused_fwd" in names, names
+    monkeypatch.setenv("AA_FUSED", "0")
+    ms = HipAllegroModel(**cfg).to(dev)
+    ms.load_state_dict(m.state_dict())
+    if lib is not None:
+        ms._bind_library(lib)
+    es, fs = ms.energy_forces(p, g)
+    names = [s[0] for s in bench.profile_stages(ms, p, g, reps=1)]
+    assert "fused_fwd" not in names, names
+    assert (e1 - es).abs().max().item() <= 2e-5 * max(1.0, float(es.abs().max()))
+    assert (f1 - fs).abs().max().item() <= 2e-5 * max(1.0, float(fs.abs().max()))
+
+
+def test_segments_of_several_tiles_run_the_team_form_emulated(monkeypatch):
+    _teams_case(emu_lib(), torch.device("cpu"), monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cut,per_class", [(2.2, (3, 3, 2, 1)), (2.6, (0, 40, 70, 10)), (2.0, (40, 70, 10, 0))])
+def test_segments_of_several_tiles_run_the_team_form_on_gpu(cut, per_class, monkeypatch):
+    _teams_case_gpu(cut, per_class, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_team_form_against_the_staged_pipeline_on_gpu(monkeypatch):
+    _teams_case(None, torch.device("cuda:0"), monkeypatch)
+
+
+def _teams_case_gpu(cut, per_class, monkeypatch):
+    # (the class mix asserted by _teams_case needs all three; the wide selections keep every center atom of the cluster)
+    monkeypatch.delenv("AA_FUSED", raising=False)
+    dev = torch.device("cuda:0")
+    pos, cell, ei, shift, types, degs = _mixed_degree_cluster(cut, per_class)
+    cfg = _cfg(avg=float(np.mean(degs)), scale_shift=True)
+    m = _vs_oracle64(cfg, pos, cell, ei, shift, types, None, dev)
+    sv = torch.tensor(shift @ cell, dtype=torch.float32, device=dev)
+    g = m.prepare_graph(torch.tensor(ei).to(dev), torch.tensor(types).to(dev), pos.shape[0], sv)
+    assert 32 < g.max_degree <= 128
+    p = torch.tensor(pos, dtype=torch.float32, device=dev)
+    ref = [t.clone() for t in m.energy_forces(p, g)]
+    for _ in range(5):  # slot assignment comes from atomic counters: results must not depend on it
+        e, f = m.energy_forces(p, g)
+        assert torch.equal(e, ref[0]) and torch.equal(f, ref[1])
+    import bench
+
+    assert "fused_fwd" in [s[0] for s in bench.profile_stages(m, p, g, reps=1)]
+
+
+@pytest.mark.gpu
+def test_team_form_is_selected_where_it_pays_on_gpu(monkeypatch):
+    """Dense Si boxes (r_max 6: 44 edges per atom, two tiles 69 % full): the team form runs up to 4096 tiles (1 728 atoms),
+    the staged forward beyond (4 096 atoms) -- aa_model.hip: use_fused_fwd; both agree with each other."""
+    import bench
+
+    monkeypatch.delenv("AA_FUSED", raising=False)
+    dev = torch.device("cuda:0")
+    for cells, fused in ((6, True), (8, False)):
+        g = G.make_si_graph(cells, r_cut=6.0)
+        cfg = _cfg(avg=g.num_edges / g.num_atoms, scale_shift=False)
+        cfg["r_max"] = 6.0
+        m = HipAllegroModel(**cfg).to(dev)
+        pg = m.prepare_graph(torch.tensor(g.edge_index, device=dev), torch.tensor(g.types, device=dev), g.num_atoms,
+                             torch.tensor(g.shift_vec(), dtype=torch.float32, device=dev))
+        assert 32 < pg.max_degree <= 64
+        pos = torch.tensor(g.pos, dtype=torch.float32, device=dev)
+        names = [s[0] for s in bench.profile_stages(m, pos, pg, reps=1)]
+        assert ("fused_fwd" in names) == fused, (cells, names)
+        e, f = (t.clone() for t in m.energy_forces(pos, pg))
+        monkeypatch.setenv("AA_FUSED", "0")
+        ms = HipAllegroModel(**cfg).to(dev)
+        ms.load_state_dict(m.state_dict())
+        es, fs = ms.energy_forces(pos, pg)
+        monkeypatch.delenv("AA_FUSED", raising=False)
+        assert (f - fs).abs().max().item() <= 2e-5 * max(1.0, float(fs.abs().max()))
+        assert (e - es).abs().max().item() <= 2e-5 * max(1.0, float(es.abs().max()))
+
+
+def test_degree_above_128_falls_back_to_the_staged_pipeline_emulated(monkeypatch):
+    _opt_in(monkeypatch)
+    rng = np.random.default_rng(5)
+    grid = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3)
+    pos = grid * 0.7 + rng.uniform(-0.05, 0.05, size=(150, 3)) + 20.0
+    cell = np.eye(3) * 60.0
+    ei_all, shift_all = G.neighbor_list_pbc(pos, cell, 6.0)
+    deg = np.bincount(ei_all[0], minlength=150)
+    assert deg.max() > 128
+    keep = np.isin(ei_all[0], [0, 75])  # two center atoms keep their 149-edge segments (emulation time)
+    types = rng.integers(0, 2, size=150)
+    cfg = _cfg(avg=75.0, scale_shift=False)
+    m = _vs_oracle64(cfg, pos, cell, ei_all[:, keep], shift_all[keep], types, emu_lib(), torch.device("cpu"))
+    _assert_launched(m, pos, cell, ei_all[:, keep], shift_all[keep], types, present=[], absent=["fused_fwd"])
 
 
 def _launches(m, data, g):

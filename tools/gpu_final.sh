@@ -20,6 +20,12 @@ timeout 900 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2
 timeout 900 python bench.py --mode train-step --workload c4 --steps 3 --warmup 1 > gpurun_out/${TAG}_train_step_c4.json 2>/dev/null
 for b in f64_gemm_loop mfma_f64_bcast_probe; do timeout 120 tools/ubench/$b.bin > gpurun_out/${TAG}_ubench_$b.log 2>&1; done
 timeout 120 tools/ubench/mfma_f64_bcast_map.bin > /dev/null 2> gpurun_out/${TAG}_ubench_mfma_f64_bcast_map.log
+# dense small systems: team form of the fused forward (default) vs the staged forward
+for rc in 6.0 7.0; do for cells in 3 4 6; do
+  a=$(AA_BENCH_RCUT=$rc AA_BENCH_CELLS=$cells timeout 300 python bench.py --workload c2 --steps 100 --warmup 10 --no-cpu-baseline --no-gpu-reference --no-profile --sustain 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+  b=$(AA_FUSED=0 AA_BENCH_RCUT=$rc AA_BENCH_CELLS=$cells timeout 300 python bench.py --workload c2 --steps 100 --warmup 10 --no-cpu-baseline --no-gpu-reference --no-profile --sustain 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+  echo "r_max $rc cells $cells default: $a staged: $b"
+done; done > gpurun_out/${TAG}_dense_small.log
 timeout 600 python tools/op_overhead.py > gpurun_out/${TAG}_op_overhead.json 2>/dev/null
 bash tools/profile_gpu.sh c4 ${TAG} > /dev/null 2>&1
 cp gpurun_out/prof_${TAG}_c4/summary.txt gpurun_out/${TAG}_rocprofv3_c4_summary.txt
@@ -33,4 +39,5 @@ grep -o '"sustained": {[^}]*}' gpurun_out/${TAG}_bench_c4.log
 grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_bench_torchrun1_shard3of8.log
 for f in train_op_c3 train_op_c4 train_step_c3 train_step_c4; do echo "$f $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_$f.json | head -1)"; done
 cat gpurun_out/${TAG}_ubench_f64_gemm_loop.log
+cat gpurun_out/${TAG}_dense_small.log
 tail -2 gpurun_out/${TAG}_rocprofv3_c4_summary.txt
