@@ -1,7 +1,11 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_fused.py tests/test_hip_model.py -x -q -m gpu 2>&1 | tail -3
-for rc in 6.0 7.0; do for cells in 3 4 6 8; do
-  a=$(AA_BENCH_RCUT=$rc AA_BENCH_CELLS=$cells timeout 300 python bench.py --workload c2 --steps 100 --warmup 10 --no-cpu-baseline --no-gpu-reference --no-profile --sustain 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
-  b=$(AA_FUSED=0 AA_BENCH_RCUT=$rc AA_BENCH_CELLS=$cells timeout 300 python bench.py --workload c2 --steps 100 --warmup 10 --no-cpu-baseline --no-gpu-reference --no-profile --sustain 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
-  echo "r_max $rc cells $cells default: $a staged: $b"
-done; done
+export AA_BUILD_EXPERIMENTAL=1
+for wl in "c1 0" "c2 0" "c2 3" "c2 4" "c2 6" "c2 8"; do set -- $wl; w=$1; cells=$2
+  for t in 0 1; do
+    if [ $cells = 0 ]; then unset AA_BENCH_CELLS; else export AA_BENCH_CELLS=$cells; fi
+    r=$(AA_FUSED_TAIL=$t timeout 300 python bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --no-gpu-reference --no-profile --sustain 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+    echo "workload $w cells $cells fused_tail=$t $r"
+  done
+done
+unset AA_BENCH_CELLS
+AA_FUSED_TAIL=1 timeout 300 python bench.py --workload c2 --steps 50 --warmup 10 --stages --no-cpu-baseline --no-gpu-reference --sustain 0 2>&1 >/dev/null | grep stage | cut -c1-70
