@@ -244,20 +244,30 @@ __device__ __forceinline__ void project_moments(const Args& A, FusedPipe& p, flo
     constexpr int S = S0 + c;
     pipe_issue<S, NS>(A, p);
     const float* wf = reinterpret_cast<const float*>(p.wbuf + (S & 1) * kWStep) + lane;
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float w[R], m[16];
+    // rows are fetched one row ahead of the nine FMAs that consume them (two operand sets): fetched and consumed in the same
+    // breath, every row waited out a full LDS latency -- 128 exposed waits per tile, ~15 % of the kernel (ISA: `ds_read x5;
+    // s_waitcnt lgkmcnt(0); 9 x v_fma` per row)
+    constexpr int Q = (D + 3) / 4;
+    auto fetch = [&](int kk, float* w, v4f* m) {
 #pragma unroll
       for (int r = 0; r < R; ++r) w[r] = wf[(kk * R + r) * 64];
 #pragma unroll
-      for (int q = 0; q < (D + 3) / 4; ++q) {
-        const v4f mm = *reinterpret_cast<const v4f*>(sM + (16 * c + kk) * kLdY + 4 * q);
+      for (int q = 0; q < Q; ++q) m[q] = *reinterpret_cast<const v4f*>(sM + (16 * c + kk) * kLdY + 4 * q);
+    };
+    auto consume = [&](const float* w, const v4f* m) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) m[4 * q + t] = mm[t];
-      }
+      for (int j = 0; j < D; ++j) x2s[j] += m[j >> 2][j & 3] * w[r_of<0>(j)];
+    };
+    float wa[R], wb[R];
+    v4f ma[Q], mb[Q];
+    fetch(0, wa, ma);
 #pragma unroll
-      for (int j = 0; j < D; ++j) x2s[j] += m[j] * w[r_of<0>(j)];
-      if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 4 rows' LDS operands in flight
+    for (int kk = 0; kk < 16; kk += 2) {
+      fetch(kk + 1, wb, mb);
+      consume(wa, ma);
+      if (kk + 2 < 16) fetch(kk + 2, wa, ma);
+      consume(wb, mb);
+      __builtin_amdgcn_sched_barrier(0);  // at most two rows' LDS operands in flight beyond the ones being consumed
     }
     pipe_commit<S>(p);
   });

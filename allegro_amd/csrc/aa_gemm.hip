@@ -1158,6 +1158,13 @@ constexpr int kEpLd = 36;          // row stride (floats) of the store-transpose
 // of a step uses it, and it costs registers the other chains should not pay for.
 template <bool PRE, bool EMB>
 __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(ChainDev c) {
+  // (which split: see split3_pack_masked)
+  auto chain_split = [](const v4f* a, u32x4* l1, u32x4* l2, u32x4* l3) {
+    if constexpr (PRE)
+      split3_pack_masked(a, l1, l2, l3);
+    else
+      split3_pack(a, l1, l2, l3);
+  };
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);  // [2][kWStep]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
@@ -1366,7 +1373,7 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
               load_a(L, kc, a);
               finish_a(L, kc, a);
             }
-            split3_pack(a, ps1[kc], ps2[kc], ps3[kc]);
+            chain_split(a, ps1[kc], ps2[kc], ps3[kc]);
           }
         }
       }
@@ -1394,10 +1401,10 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
           if (kc >= KCg) {
             v4f a[4];
             kept_a(L, kc - KCg, a);
-            split3_pack(a, x1, x2, x3);
+            chain_split(a, x1, x2, x3);
           } else {
             finish_a(L, kc, a0);
-            split3_pack(a0, x1, x2, x3);
+            chain_split(a0, x1, x2, x3);
           }
         }
         // rows of the next streamed step (next chunk / next pair / next layer), in flight during this step's MFMAs

@@ -16,8 +16,37 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
 
-// 16 floats -> three levels of 8 packed bf16 pairs (element 2q in the low half, 2q+1 in the high half)
+// the high halves of two words as one word: {hi[31:16], lo[31:16]} (one v_perm_b32)
+__device__ __forceinline__ unsigned pack_high_halves(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+// 16 floats -> three levels of 8 packed bf16 pairs (element 2q in the low half, 2q+1 in the high half).  Level l holds the
+// top 16 bits of what levels < l left over; the pairs are packed straight from the unmasked words (the mask is only needed
+// for the value that is subtracted), 5.5 instead of 8 VALU operations per float -- the splits are a third of the fused
+// kernels' vector instructions.
 __device__ __forceinline__ void split3_pack(const v4f* a, u32x4* lv1, u32x4* lv2, u32x4* lv3) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    u32x4 o1, o2, o3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i0 = half * 8 + q * 2, i1 = i0 + 1;
+      const float x0 = a[i0 >> 2][i0 & 3], x1 = a[i1 >> 2][i1 & 3];
+      o1[q] = pack_high_halves(f2u(x0), f2u(x1));
+      const float r0 = x0 - u2f(f2u(x0) & 0xFFFF0000u), r1 = x1 - u2f(f2u(x1) & 0xFFFF0000u);
+      o2[q] = pack_high_halves(f2u(r0), f2u(r1));
+      const float s0 = r0 - u2f(f2u(r0) & 0xFFFF0000u), s1 = r1 - u2f(f2u(r1) & 0xFFFF0000u);
+      o3[q] = pack_high_halves(f2u(s0), f2u(s1));
+    }
+    lv1[half] = o1;
+    lv2[half] = o2;
+    lv3[half] = o3;
+  }
+}
+
+// the same split with the pairs packed from the MASKED words (shift + or): 8 operations per float, but lower register
+// pressure in the scheduler's hands -- the chain kernel's PRE variants (255 of 256 VGPRs at two waves per SIMD) spill 35-37
+// registers with the form above and lose 60 % (gc_64x64_64x128 at C4: 1.01 -> 1.62 ms), so they keep this one
+__device__ __forceinline__ void split3_pack_masked(const v4f* a, u32x4* lv1, u32x4* lv2, u32x4* lv3) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     u32x4 o1, o2, o3;

@@ -274,6 +274,16 @@ inline emu_v4f_mfma __builtin_amdgcn_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {  // v_perm_b32: byte i of the result = byte sel[i] of {a, b} (0..3: b, 4..7: a)
+  const unsigned long long ab = (static_cast<unsigned long long>(a) << 32) | b;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) {
+    const unsigned k = (sel >> (8 * i)) & 0xFF;
+    const unsigned byte = k < 8 ? unsigned((ab >> (8 * k)) & 0xFF) : (k == 0x0C ? 0x00u : 0xFFu);
+    r |= byte << (8 * i);
+  }
+  return r;
+}
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_s_barrier() { emu::yield_block_barrier(); }
 #define __builtin_amdgcn_fence(...) ((void)0)  // (address-space scoped fences around a raw s_barrier)
