@@ -153,8 +153,9 @@ def _teams_case(lib, dev, monkeypatch, cut=2.2, per_class=(3, 3, 2, 1)):
     assert 32 < g.max_degree <= 128
     p = torch.tensor(pos, dtype=torch.float32, device=dev)
     e1, f1 = (t.clone() for t in m.energy_forces(p, g))
+    v1 = m.virial(g).clone()
     e2, f2 = (t.clone() for t in m.energy_forces(p, g))
-    assert torch.equal(e1, e2) and torch.equal(f1, f2)
+    assert torch.equal(e1, e2) and torch.equal(f1, f2) and torch.equal(v1, m.virial(g))
     import bench
 
     names = [s[0] for s in bench.profile_stages(m, p, g, reps=1)]
@@ -165,8 +166,10 @@ def _teams_case(lib, dev, monkeypatch, cut=2.2, per_class=(3, 3, 2, 1)):
     if lib is not None:
         ms._bind_library(lib)
     es, fs = ms.energy_forces(p, g)
+    vs = ms.virial(g).clone()
     names = [s[0] for s in bench.profile_stages(ms, p, g, reps=1)]
     assert "fused_fwd" not in names, names
+    assert (v1 - vs).abs().max().item() <= 5e-5 * max(1.0, float(vs.abs().max()))  # strain derivative of the same step
     assert (e1 - es).abs().max().item() <= 2e-5 * max(1.0, float(es.abs().max()))
     assert (f1 - fs).abs().max().item() <= 2e-5 * max(1.0, float(fs.abs().max()))
 
