@@ -84,3 +84,39 @@ def test_native_op_matches_reference_golden_on_gpu(name, dtype, tol, forward_mod
     buf.seek(0)
     e2, _, f2, _v2 = torch.export.load(buf).module()(data["pos"], data["edge_index"], data["atom_types"], sv)
     assert (f2.cpu() - ref["forces"]).abs().max().item() <= tol * max(1.0, float(ref["forces"].abs().max()))
+
+
+@pytest.mark.gpu
+def test_native_op_on_a_dense_neighbour_list_matches_the_model_on_gpu():
+    """The C++ op sizes its own workspace and decides the forward from `max_degree` like the Python host: on a list with
+    33..128 edges per atom (team form of the fused forward) it reproduces `HipAllegroModel.energy_forces` and the virial,
+    also with the edges shuffled (the op sorts them)."""
+    import numpy as np
+
+    from allegro_amd import graph as G
+    from allegro_amd.export import ExportableAllegro
+    from allegro_amd.nn import HipAllegroModel
+    from tests.fastpath_utils import _cfg
+
+    dev = torch.device("cuda:0")
+    g = G.make_si_graph(3, r_cut=6.0)  # 216 atoms, 44.5 edges per atom
+    cfg = _cfg(avg=g.num_edges / g.num_atoms, scale_shift=True)
+    cfg["r_max"] = 6.0
+    m = HipAllegroModel(**cfg).to(dev)
+    pos = torch.tensor(g.pos, dtype=torch.float32, device=dev)
+    ei = torch.tensor(g.edge_index, device=dev)
+    types = torch.tensor(g.types, device=dev)
+    sv = torch.tensor(g.shift_vec(), dtype=torch.float32, device=dev)
+    pg = m.prepare_graph(ei, types, g.num_atoms, sv)
+    assert 32 < pg.max_degree <= 128
+    e, f = m.energy_forces(pos, pg)
+    w = m.virial(pg)
+    ex = ExportableAllegro(m, dev)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(2)).to(dev)
+    for idx in (None, perm):
+        ei_x, sv_x = (ei, sv) if idx is None else (ei[:, idx], sv[idx])
+        ea, et, fo, vir = ex(pos, ei_x, types, sv_x)
+        # (fp32 rounding level: the op's plan and the Python host's are two plan objects with their own weight packing)
+        assert (ea.reshape(-1) - e).abs().max().item() <= 5e-6 * max(1.0, float(e.abs().max()))
+        assert (fo - f).abs().max().item() <= 5e-6 * max(1.0, float(f.abs().max()))
+        assert (vir.reshape(3, 3) + w).abs().max().item() <= 2e-5 * max(1.0, float(w.abs().max()))  # (virial = -dE/d strain)
