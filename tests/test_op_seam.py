@@ -289,3 +289,23 @@ def test_contracter_forward_itself_traces_under_export_and_compile(assume_sorted
     fc = torch.compile(Wrap(), backend="aot_eager", fullgraph=True)
     assert torch.equal(fc(x1, x2, idxs), want)
     torch.library.opcheck(torch.ops.allegro_amd.segments, (idxs, N, assume_sorted), test_utils=("test_schema", "test_faketensor"))
+
+
+def test_training_path_ops_contract_opcheck():
+    """The single-gradient and segment-sum ops of the training path (allegro_amd/ops.py): schema and fake kernels agree with the
+    real ones (`torch.library.opcheck`), so they trace under `torch.export` / `torch.compile` like the forward op."""
+    c = _contracter()
+    E, N = 11, 4
+    g = torch.Generator().manual_seed(2)
+    x1 = torch.randn(E, 4, 9, dtype=torch.float64, generator=g)
+    x2 = torch.randn(E, 4, 9, dtype=torch.float64, generator=g)
+    go = torch.randn(E, 4, 9, dtype=torch.float64, generator=g)
+    idxs = torch.randint(0, N, (E,), generator=g)
+    rowptr, eids = segments_from_index(idxs, N)
+    plan, lib_id = c._plan(torch.float64), c._lib_id
+    x2s = torch.ops.allegro_amd.segment_sum(x2, rowptr, eids, N, 0.25, lib_id)
+    torch.library.opcheck(torch.ops.allegro_amd.segment_sum, (x2, rowptr, eids, N, 0.25, lib_id), test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.allegro_amd.tp_backward_x1, (go, x2s, c.weights.detach(), rowptr, eids, N, 0.25, plan, lib_id, 9),
+                          test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.allegro_amd.tp_backward_x2, (go, x1, c.weights.detach(), rowptr, eids, N, 0.25, plan, lib_id, 9),
+                          test_utils=("test_schema", "test_faketensor"))
