@@ -106,8 +106,57 @@ __device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, boo
   }
 }
 
-// Two independent D-value sums (the two edges of a pair) in one pass: the butterflies are interleaved so that each
-// one's dependent exchange -> add chain hides the other's latency, and the permlane swaps are issued four to a block.
+// One level of a reduce-scatter over the lane bit BIT: of the N values a lane holds it keeps ceil(N / 2) (the lower ones if its
+// bit is clear, the upper ones -- padded with a zero when N is odd -- if it is set) and adds its partner's partial sums of the
+// same values.  N == 1: a plain sum over the bit.  Bits 5 / 4: v_permlane32/16_swap (the swap leaves each half holding exactly
+// the two addends it keeps); bits 3..0: DPP-fused adds of the value selected for sending.
+template <int BIT, int N>
+__device__ __forceinline__ void scatter_level(const float* in, float* out, int lane) {
+  constexpr int H = (N + 1) / 2;
+  if constexpr (N == 1) {
+    if constexpr (BIT >= 4) {
+      out[0] = in[0] + __shfl_xor(in[0], 1 << BIT);
+    } else if constexpr (BIT == 3) {
+      out[0] = in[0] + dpp_move<kDppRowRor8>(in[0]);
+    } else if constexpr (BIT == 2) {
+      out[0] = in[0] + dpp_move<kDppHalfMirror>(in[0]);
+    } else if constexpr (BIT == 1) {
+      out[0] = in[0] + dpp_move<kDppQuad2301>(in[0]);
+    } else {
+      out[0] = in[0] + dpp_move<kDppQuad1032>(in[0]);
+    }
+  } else if constexpr (BIT >= 4) {
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      float a = in[i], b = i + H < N ? in[i + H] : 0.f;
+      if constexpr (BIT == 5)
+        permlane32_swap(a, b);
+      else
+        permlane16_swap(a, b);
+      out[i] = a + b;
+    }
+  } else {
+    const bool hi = lane & (1 << BIT);
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const float lo_v = in[i], hi_v = i + H < N ? in[i + H] : 0.f;
+      const float send = hi ? lo_v : hi_v, keep = hi ? hi_v : lo_v;
+      if constexpr (BIT == 3)
+        out[i] = keep + dpp_move<kDppRowRor8>(send);
+      else if constexpr (BIT == 2)
+        out[i] = keep + dpp_move<kDppHalfMirror>(send);
+      else if constexpr (BIT == 1)
+        out[i] = keep + dpp_move<kDppQuad2301>(send);
+      else
+        out[i] = keep + dpp_move<kDppQuad1032>(send);
+    }
+  }
+}
+
+// Two independent D-value sums (the two edges of a pair) in ONE reduce-scatter of 2 D values: bit 5 separates the edges (the
+// swap pairs value i of edge a with value i of edge b), every further bit halves what a lane holds -- 9 + 5 + 3 + 2 + 1 + 1
+// exchanges for D = 9 instead of 2 x (8 + 4 + 2 + 1 + 1 + 1) with each edge padded to 16 values.  Total j of its edge ends
+// up in the lanes whose bits 4..0 spell j in the mixed radix of the level sizes; one lane per total stores it.
 template <typename T, int D>
 __device__ __forceinline__ void wave_sum_store2(const T* va, const T* vb, T* dsta, T* dstb, bool acta, bool actb) {
   static_assert(D <= 16, "at most 16 values");
@@ -116,57 +165,47 @@ __device__ __forceinline__ void wave_sum_store2(const T* va, const T* vb, T* dst
     wave_sum_store<T, D>(vb, dstb, actb, false);
   } else {
     const int lane = threadIdx.x & 63;
-    float xa[16], xb[16];
+    constexpr int N4 = D, N3 = (N4 + 1) / 2, N2 = (N3 + 1) / 2, N1 = (N2 + 1) / 2, N0 = (N1 + 1) / 2;
+    float x4[N4], x3[N3], x2[N2], x1[N1], x0[N0], r[1];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      xa[k] = k < D ? va[k] : 0.f;
-      xb[k] = k < D ? vb[k] : 0.f;
+    for (int i = 0; i < D; ++i) {
+      float a = va[i], b = vb[i];
+      permlane32_swap(a, b);  // lower half: both halves' partial sums of edge a, upper half: of edge b
+      x4[i] = a + b;
     }
-    float ya[8], yb[8], za[4], zb[4], qa[2], qb[2];
-    // bit 5: {x[k], x[k+8]} -> y[k]
-    permlane32_swap4(xa, xa + 8);
-    permlane32_swap4(xb, xb + 8);
-    permlane32_swap4(xa + 4, xa + 12);
-    permlane32_swap4(xb + 4, xb + 12);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      ya[k] = xa[k] + xa[k + 8];
-      yb[k] = xb[k] + xb[k + 8];
-    }
-    // bit 4
-    permlane16_swap4(ya, ya + 4);
-    permlane16_swap4(yb, yb + 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      za[k] = ya[k] + ya[k + 4];
-      zb[k] = yb[k] + yb[k + 4];
-    }
-    {
-      const bool hi = lane & 8;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float sa = hi ? za[k] : za[k + 2], ka_ = hi ? za[k + 2] : za[k];
-        const float sb = hi ? zb[k] : zb[k + 2], kb_ = hi ? zb[k + 2] : zb[k];
-        qa[k] = ka_ + dpp_move<kDppRowRor8>(sa);
-        qb[k] = kb_ + dpp_move<kDppRowRor8>(sb);
+    scatter_level<4, N4>(x4, x3, lane);
+    scatter_level<3, N3>(x3, x2, lane);
+    scatter_level<2, N2>(x2, x1, lane);
+    scatter_level<1, N1>(x1, x0, lane);
+    scatter_level<0, N0>(x0, r, lane);
+    // which total the lane holds: at a level that still had N > 1 values, a set bit selected the upper part (index offset =
+    // size of the lower part H, and N - H values, one fewer than H when N is odd: the pad); at a level with one value the
+    // lanes of both bit values hold copies and the clear one owns the store
+    int j = 0, cnt = D;
+    bool owner = true;
+    auto level = [&](bool bit, int n, int h) {
+      if (n > 1) {
+        if (bit) {
+          j += h;
+          cnt -= h;
+        } else {
+          cnt = cnt < h ? cnt : h;
+        }
+      } else {
+        owner = owner && !bit;
       }
-    }
-    float ra, rb;
-    {
-      const bool hi = lane & 4;
-      const float sa = hi ? qa[0] : qa[1], ka_ = hi ? qa[1] : qa[0];
-      const float sb = hi ? qb[0] : qb[1], kb_ = hi ? qb[1] : qb[0];
-      ra = ka_ + dpp_move<kDppHalfMirror>(sa);
-      rb = kb_ + dpp_move<kDppHalfMirror>(sb);
-    }
-    ra += dpp_move<kDppQuad1032>(ra);
-    rb += dpp_move<kDppQuad1032>(rb);
-    ra += dpp_move<kDppQuad2301>(ra);
-    rb += dpp_move<kDppQuad2301>(rb);
-    const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    if ((lane & 3) == 0 && idx < D) {
-      if (acta) dsta[idx] = ra;
-      if (actb) dstb[idx] = rb;
+    };
+    level(lane & 16, N4, N3);
+    level(lane & 8, N3, N2);
+    level(lane & 4, N2, N1);
+    level(lane & 2, N1, N0);
+    level(lane & 1, N0, (N0 + 1) / 2);
+    if (owner && cnt >= 1) {
+      if (lane & 32) {
+        if (actb) dstb[j] = r[0];
+      } else {
+        if (acta) dsta[j] = r[0];
+      }
     }
   }
 }
