@@ -135,6 +135,8 @@ class AllegroLib:
         L.aa_model_plan_enable_graph.restype = C.c_int
         L.aa_model_plan_enable_taps.argtypes = [C.c_void_p, C.c_int]
         L.aa_model_plan_enable_taps.restype = C.c_int
+        L.aa_model_check.argtypes = [C.c_void_p, C.c_void_p]
+        L.aa_model_check.restype = C.c_int
         L.aa_model_virial.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.aa_model_virial.restype = C.c_int
         L.aa_nl_workspace_bytes.argtypes = [C.c_int64]

@@ -622,6 +622,7 @@ struct FusedFwdArgs {
   float* fcat;     // [E,192] EDGE_FEATURES or nullptr
   float *x2s0, *x2s1;  // [N][D][64]
   float* atom_energy;  // [N]
+  int32_t* status;     // nullable, host-visible: set to the offending degree when a segment exceeds what the max_degree hint promised
 };
 // reverse tail (aa_fused_bwd.hip): layer-0 tensor product reverse + first-stage / scalar_embed_mlp reverse + edge reverse
 struct FusedTailArgs {
@@ -711,6 +712,8 @@ struct ForceGatherArgs {
 };
 template <typename T>
 int launch_force_gather(const ForceGatherArgs& a, hipStream_t stream);
+// verifies the aa_graph.atom_begin / atom_end promise (no edge segment outside the block): *status = -2 otherwise
+int launch_graph_hint_check(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status, hipStream_t stream);
 template <typename T>
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t stream);
 

@@ -553,6 +553,15 @@ int launch_force_gather(const ForceGatherArgs& a, hipStream_t stream) {
   return AA_OK;
 }
 
+__global__ void graph_hint_check_kernel(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status) {
+  if (threadIdx.x == 0 && (rowptr[a0] != rowptr[0] || rowptr[a1] != rowptr[N])) *reinterpret_cast<volatile int32_t*>(status) = -2;
+}
+int launch_graph_hint_check(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status, hipStream_t stream) {
+  hipLaunchKernelGGL(graph_hint_check_kernel, dim3(1), dim3(64), 0, stream, rowptr, N, a0, a1, status);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
 template <typename T>
 int launch_readout_reduce(const ReadoutArgs& a, hipStream_t stream) {
   if (a.N == 0) return AA_OK;

@@ -165,6 +165,14 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
       beg = b0 + 32 * tile;
       cnt = deg - 32 * tile;
       cnt = cnt < 0 ? 0 : (cnt > 32 ? 32 : cnt);
+      // A segment longer than this instantiation covers means the caller's aa_graph.max_degree hint was stale.  Never a
+      // silent truncation: the atom is skipped (cnt < 0: every row masked), its energy becomes NaN and the plan's status
+      // word makes the next aa_model_energy_forces / aa_model_check fail (the reference takes any segment length,
+      // allegro/nn/_strided/_contract.py:195-205 -- the host then has to pass the true degree and gets the staged pipeline).
+      if (deg > (TEAMS ? kFusedMaxDegree : 32)) {
+        cnt = -1;
+        if (A.status && lane == 0) *reinterpret_cast<volatile int32_t*>(A.status) = deg;
+      }
     }
   };
   auto load_nbr = [&](int beg, int cnt) { return el < cnt ? A.nbr[int64_t(beg) + el] : 0; };
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                     const int t = A.types[atom];
                                     if (A.scales) en *= A.scales[t];
                                     if (A.shifts) en += A.shifts[t];
+                                    if (cnt < 0) en = __builtin_nanf("");  // (segment beyond the max_degree hint: see load_rows)
                                     A.atom_energy[atom] = en;
                                   }
                                 });

@@ -240,7 +240,27 @@ struct aa_model_plan {
     } key{};
   };
   mutable StepGraph sg;
+  // Host-visible status word (pinned host memory, written by kernels, read by the host without a synchronisation): a step
+  // whose graph contradicts the caller's hints (aa_graph.max_degree, atom_begin / atom_end) sets it, the offending atoms'
+  // energies become NaN, and the NEXT aa_model_energy_forces on the plan -- or aa_model_check, which synchronises first --
+  // returns AA_ERR_INVALID.  > 0: degree of a center atom beyond max_degree; -2: edges outside [atom_begin, atom_end).
+  int32_t* status = nullptr;
 };
+
+// reads and clears the status word; AA_OK when clean
+static int consume_status(const aa_model_plan* plan, const char* who) {
+  if (!plan->status) return AA_OK;
+  const int32_t v = *reinterpret_cast<volatile int32_t*>(plan->status);
+  if (v == 0) return AA_OK;
+  *reinterpret_cast<volatile int32_t*>(plan->status) = 0;
+  char msg[256];
+  if (v > 0)
+    snprintf(msg, sizeof msg, "%s: a step on this plan met a center atom with %d edges, more than aa_graph.max_degree promised "
+             "(its energy was set to NaN; pass the true maximum, or 0 for \"unknown\")", who, int(v));
+  else
+    snprintf(msg, sizeof msg, "%s: a step on this plan met edges whose center lies outside [aa_graph.atom_begin, atom_end)", who);
+  return fail(AA_ERR_INVALID, msg);
+}
 
 static std::vector<int> mlp_dims(int in, int depth, int width, int out) {
   std::vector<int> d{in};
@@ -454,8 +474,23 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
 #endif
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
   }
+  {
+    void* st = nullptr;
+    if (hipHostMalloc(&st, 64, hipHostMallocDefault) != hipSuccess || !st) {
+      aa_model_plan_destroy(p);
+      return fail(AA_ERR_HIP, "aa_model_plan_create: cannot allocate the status word");
+    }
+    std::memset(st, 0, 64);
+    p->status = static_cast<int32_t*>(st);
+  }
   *out = p;
   return AA_OK;
+}
+
+extern "C" int aa_model_check(const aa_model_plan* plan, aa_stream stream) {
+  AA_REQUIRE(plan, "aa_model_check: null plan");
+  AA_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  return consume_status(plan, "aa_model_check");
 }
 
 extern "C" int aa_model_plan_enable_graph(aa_model_plan* plan, int on) {
@@ -488,6 +523,7 @@ extern "C" void aa_model_plan_destroy(aa_model_plan* plan) {
   if (plan->sg.graph) (void)hipGraphDestroy(plan->sg.graph);
   if (plan->sg.cap_stream) (void)hipStreamDestroy(plan->sg.cap_stream);
   for (void* q : plan->owned) (void)hipFree(q);
+  if (plan->status) (void)hipHostFree(plan->status);
   delete plan;
 }
 
@@ -1435,6 +1471,7 @@ struct Runner {
     a.x2s0 = bf(w.x2s[0]);
     a.x2s1 = bf(w.x2s[1]);
     a.atom_energy = static_cast<float*>(atom_energy);
+    a.status = p->status;
     if (int rc = mark("begin")) return rc;
     if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
     // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;
@@ -1886,6 +1923,9 @@ int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g
   r.w = layout_workspace(p, r.N, r.E, forces != nullptr);
   if (r.w.total > ws_bytes) return fail(AA_ERR_WORKSPACE, "aa_model_energy_forces: workspace too small");
   if (p->opt.poison_workspace) AA_CHECK_HIP(hipMemsetAsync(workspace, 0xFF, r.w.total, stream));  // debugging: NaN everywhere
+  // the atom-block hint is the caller's promise (per-atom kernels skip the rest): two row pointers verify it on the device
+  if (g->atom_end > g->atom_begin && (g->atom_begin > 0 || g->atom_end < g->num_atoms) && p->status)
+    if (int rc = launch_graph_hint_check(g->rowptr, g->num_atoms, g->atom_begin, g->atom_end, p->status, stream)) return rc;
   if (int rc = r.forward(g, pos, atom_energy)) return rc;
   if (forces) return r.backward(g, pos, forces);
   return AA_OK;
@@ -1904,6 +1944,7 @@ extern "C" int aa_model_energy_forces(const aa_model_plan* plan, const void* dev
                  (graph->atom_end >= graph->atom_begin || graph->atom_end == 0),
              "aa_model_energy_forces: atom_begin/atom_end out of range");
   AA_REQUIRE(workspace || workspace_bytes == 0, "aa_model_energy_forces: null workspace");
+  if (int rc = consume_status(plan, "aa_model_energy_forces")) return rc;  // (an EARLIER step contradicted the graph hints)
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto run = [&](hipStream_t st) {
     if (plan->cfg.dtype == AA_F32)

@@ -376,3 +376,58 @@ extern "C" int aa_nl_fill(const aa_nl_input* in, void* workspace, size_t workspa
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// content fingerprint of a neighbour list (aa_graph_fingerprint): lets a host that caches graph structure by tensor
+// IDENTITY (csrc/torch_ops.cpp) notice that the contents behind an unchanged tensor were rewritten through a raw pointer
+// ---------------------------------------------------------------------------------------------------------------------
+namespace aa {
+namespace {
+__device__ __forceinline__ unsigned long long fp_mix(unsigned long long x) {  // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// fp[0] += sum_k mix(center_k, nbr_k, k), fp[1] += sum_i mix(type_i, i): integer sums, hence independent of the order the
+// workgroups arrive in (bit-reproducible), yet every term depends on its position, so a permutation changes the result
+template <typename TT>
+__global__ __launch_bounds__(256) void graph_fingerprint_kernel(const int64_t* e0, const int64_t* e1, int64_t E, const TT* types, int64_t N,
+                                                                unsigned long long* fp) {
+  unsigned long long h0 = 0, h1 = 0;
+  const int64_t stride = int64_t(gridDim.x) * 256;
+  for (int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x; k < E; k += stride)
+    h0 += fp_mix(fp_mix((unsigned long long)e0[k] * 0xD6E8FEB86659FD93ull + (unsigned long long)e1[k]) ^ (unsigned long long)k);
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < N; i += stride)
+    h1 += fp_mix(((unsigned long long)(int64_t)types[i] << 40) ^ (unsigned long long)i);
+  for (int m = 32; m >= 1; m >>= 1) {
+    h0 += __shfl_xor(h0, m);
+    h1 += __shfl_xor(h1, m);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (h0) atomicAdd(&fp[0], h0);
+    if (h1) atomicAdd(&fp[1], h1);
+  }
+}
+}  // namespace
+}  // namespace aa
+
+extern "C" int aa_graph_fingerprint(const int64_t* edge_index, int64_t row_stride, int64_t num_edges, const void* atom_types,
+                                    int types_are_int64, int64_t num_atoms, uint64_t* fp2, aa_stream stream) {
+  AA_REQUIRE(fp2 && num_edges >= 0 && num_atoms >= 0 && (num_edges == 0 || edge_index) && (num_atoms == 0 || atom_types),
+             "aa_graph_fingerprint: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AA_CHECK_HIP(hipMemsetAsync(fp2, 0, 2 * sizeof(uint64_t), s));
+  const int64_t work = std::max(num_edges, num_atoms);
+  if (work == 0) return AA_OK;
+  const unsigned nb = unsigned(std::min<int64_t>((work + 255) / 256, 2048));
+  auto* out = reinterpret_cast<unsigned long long*>(fp2);
+  if (types_are_int64)
+    hipLaunchKernelGGL(aa::graph_fingerprint_kernel<int64_t>, dim3(nb), dim3(256), 0, s, edge_index, edge_index + row_stride, num_edges,
+                       static_cast<const int64_t*>(atom_types), num_atoms, out);
+  else
+    hipLaunchKernelGGL(aa::graph_fingerprint_kernel<int32_t>, dim3(nb), dim3(256), 0, s, edge_index, edge_index + row_stride, num_edges,
+                       static_cast<const int32_t*>(atom_types), num_atoms, out);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}

@@ -17,6 +17,7 @@
 #include <torch/library.h>
 
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -27,7 +28,7 @@
 
 namespace {
 
-constexpr int64_t kMagic = 0x414c4c4547524f31;  // "ALLEGRO1"
+constexpr int64_t kMagic = 0x414c4c4547524f32;  // "ALLEGRO2" (format 2: blob without the 16x16x32 weight copies, layout digest mandatory)
 constexpr int kHeader = 30;
 
 struct PlanEntry {
@@ -52,7 +53,7 @@ double as_double(int64_t bits) {
 //   embed_dim, embed_mlp_depth, embed_mlp_width, latent_mlp_depth, latent_mlp_width, readout_mlp_depth,
 //   readout_mlp_width, forward_weight_init, has_scales, has_shifts, embed_kind, spline_span,
 //   bits(poly_p), bits(avg_num_neighbors), bits(act_const), env_shared_weights, act_kind[0..2] (one byte each),
-//   bits(act_consts[0..2]), bessel_convention, layout digest of the blob (aa_model_plan_layout_hash; 0 = unchecked)]
+//   bits(act_consts[0..2]), bessel_convention, layout digest of the blob (aa_model_plan_layout_hash; mandatory)]
 //   then per layer
 //   [mul, d1, d2, dout, num_paths, coupling, nnz, i[nnz], j[nnz], k[nnz], path[nnz], bits(val)[nnz]]
 // (a plan owns Clebsch-Gordan tables in the memory of the device that was current when it was created: the cache
@@ -60,7 +61,9 @@ double as_double(int64_t bits) {
 const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
   const int64_t* w = config.data();
   const int64_t n = int64_t(config.size());
-  TORCH_CHECK(n >= kHeader && w[0] == kMagic, "allegro_amd: not a serialized model config");
+  TORCH_CHECK(n >= kHeader && (w[0] >> 8) == (kMagic >> 8), "allegro_amd: not a serialized model config");
+  TORCH_CHECK(w[0] == kMagic, "allegro_amd: this package was exported by another version of allegro_amd (config format '",
+              char(w[0] & 0xff), "', this library reads '", char(kMagic & 0xff), "'): its weight blob has another layout; re-export the model");
   std::string key(reinterpret_cast<const char*>(w), size_t(n) * 8);
   key.append(reinterpret_cast<const char*>(&device_index), sizeof(device_index));
   std::lock_guard<std::mutex> lock(g_mu);
@@ -125,24 +128,32 @@ const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
   const int rc = aa_model_plan_create(&c, &e->plan);
   TORCH_CHECK(rc == 0, "aa_model_plan_create failed (", rc, "): ", aa_last_error());
   // the weight blob travels with the config: it must have been packed for THIS plan's layout (default options)
-  TORCH_CHECK(w[29] == 0 || uint64_t(w[29]) == aa_model_plan_layout_hash(e->plan),
+  TORCH_CHECK(w[29] != 0, "allegro_amd: the config carries no blob-layout digest; re-export the model");
+  TORCH_CHECK(uint64_t(w[29]) == aa_model_plan_layout_hash(e->plan),
               "allegro_amd: the weight blob was packed for another plan layout (kernel-selection options differ); "
               "re-export the model (allegro_amd.export.ExportableAllegro packs for the default options)");
   return *(g_plans[key] = std::move(e));
 }
 
-// Center-sorted CSR view of an edge list + the step's workspace, kept between calls.  An MD driver that holds its
-// neighbour list for several steps hands the op the SAME `edge_index` / `atom_types` tensors each time: the sortedness
-// check, the sort, both CSR builds, the degree reduction (two host syncs) and the workspace allocation are then paid
-// once per list instead of once per step.  Keyed on identity + in-place version of the two tensors, which the entry
-// keeps alive so that their addresses cannot be recycled (the scheme of HipAllegroModel._graph_for).  One entry per
-// device: a driver that rebuilds its list every step simply replaces it.
+// Center-sorted CSR view of an edge list, kept between calls.  An MD driver that holds its neighbour list for several
+// steps hands the op the SAME `edge_index` / `atom_types` tensors each time: the sortedness check, the sort, both CSR
+// builds and the degree reduction (two host syncs) are then paid once per list instead of once per step.  Keyed on
+// identity + in-place version of the two tensors, which the entry keeps alive so that their addresses cannot be
+// recycled (the scheme of HipAllegroModel._graph_for).  Identity + version do not see writes through data_ptr() /
+// accessors / from_blob memory (a C++ host refilling a persistent tensor), so every HIT is also validated by content:
+// the list's 128-bit fingerprint (aa_graph_fingerprint, one pass over the list, no host sync) is compared ON THE DEVICE
+// with the one taken when the entry was built; a mismatch turns this call's outputs into NaN and raises on the next
+// call (the flag travels through pinned host memory).  One entry per device: a driver that rebuilds its list every
+// step simply replaces it.  The workspace is NOT part of the entry: it comes from the caching allocator per call, which
+// is what keeps two host threads / streams evaluating the same list apart.
 struct GraphEntry {
   at::Tensor key_ei, key_types;  // kept alive
   uint32_t ver_ei = 0, ver_types = 0;
   int64_t N = -1;
   bool permuted = false;
-  at::Tensor perm, center, nbr, rowptr, trow, tperm, types, ws;
+  at::Tensor perm, center, nbr, rowptr, trow, tperm, types;
+  at::Tensor fp;          // int64 [2] device: content fingerprint at build time
+  at::Tensor stale_host;  // bool [1] pinned host: set (asynchronously) by a hit whose fingerprint differed
   int64_t max_degree = 0;
 };
 std::map<int, GraphEntry> g_graphs;  // device index -> most recent graph (guarded by g_mu)
@@ -154,6 +165,20 @@ bool tensor_version(const at::Tensor& t, uint32_t* v) {
   } catch (...) {  // inference tensors carry no version counter: never cached
     return false;
   }
+}
+
+// fingerprint of the caller's tensors as they are (no copies): int64 edge_index with unit column stride, int32 / int64 types
+bool fingerprintable(const at::Tensor& edge_index, const at::Tensor& atom_types) {
+  return edge_index.scalar_type() == at::kLong && (edge_index.size(1) == 0 || edge_index.stride(1) == 1) &&
+         (atom_types.scalar_type() == at::kLong || atom_types.scalar_type() == at::kInt) && atom_types.is_contiguous();
+}
+at::Tensor fingerprint(const at::Tensor& edge_index, const at::Tensor& atom_types, hipStream_t stream) {
+  at::Tensor fp = at::empty({2}, edge_index.options().dtype(at::kLong));
+  const int rc = aa_graph_fingerprint(edge_index.data_ptr<int64_t>(), edge_index.size(1) > 0 ? edge_index.stride(0) : 0, edge_index.size(1),
+                                      atom_types.data_ptr(), atom_types.scalar_type() == at::kLong ? 1 : 0, atom_types.numel(),
+                                      reinterpret_cast<uint64_t*>(fp.data_ptr<int64_t>()), stream);
+  TORCH_CHECK(rc == 0, "aa_graph_fingerprint failed (", rc, "): ", aa_last_error());
+  return fp;
 }
 
 GraphEntry build_graph(const at::Tensor& edge_index, const at::Tensor& atom_types, int64_t N, const at::TensorOptions& popt) {
@@ -200,37 +225,48 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tenso
   const int64_t dt = config[1];
   TORCH_CHECK(pos.scalar_type() == (dt == AA_F32 ? at::kFloat : at::kDouble), "positions must be in the model dtype");
   at::Tensor p = pos.contiguous();
+  hipStream_t stream = c10::hip::getCurrentHIPStream(pos.get_device()).stream();
   // graph structure: from the cache when the caller hands the same (unmodified) tensors again
   GraphEntry ge;
+  at::Tensor stale;  // defined on a cache hit: device bool, true when the list's contents changed behind the tensors
   {
     uint32_t ve = 0, vt = 0;
-    const bool keyed = tensor_version(edge_index, &ve) && tensor_version(atom_types, &vt);
+    const bool keyed = tensor_version(edge_index, &ve) && tensor_version(atom_types, &vt) && fingerprintable(edge_index, atom_types);
     bool hit = false;
     if (keyed) {
       std::lock_guard<std::mutex> lock(g_mu);
       auto it = g_graphs.find(int(pos.get_device()));
       if (it != g_graphs.end() && it->second.key_ei.is_same(edge_index) && it->second.key_types.is_same(atom_types) &&
           it->second.ver_ei == ve && it->second.ver_types == vt && it->second.N == N) {
+        if (*it->second.stale_host.data_ptr<bool>()) {  // an EARLIER hit found other contents behind these tensors
+          g_graphs.erase(it);
+          TORCH_CHECK(false, "allegro_amd::energy_forces: the contents of edge_index / atom_types changed although the tensors and "
+                             "their versions did not (written through a raw pointer?): the previous call on this list returned "
+                             "NaN.  Hand over a new tensor, or modify it with a tensor operation, whenever the list changes.");
+        }
         ge = it->second;
         hit = true;
       }
     }
-    if (!hit) {
+    if (hit) {
+      stale = at::ne(fingerprint(edge_index, atom_types, stream), ge.fp).any();
+      ge.stale_host.copy_(stale.reshape({1}), /*non_blocking=*/true);
+    } else {
       ge = build_graph(edge_index, atom_types, N, pos.options());
-      const size_t wsb0 = aa_model_workspace_bytes(pe.plan, N, E, 1);
-      ge.ws = at::empty({int64_t(wsb0)}, pos.options().dtype(at::kByte));
       if (keyed) {
         ge.key_ei = edge_index;
         ge.key_types = atom_types;
         ge.ver_ei = ve;
         ge.ver_types = vt;
+        ge.fp = fingerprint(edge_index, atom_types, stream);
+        ge.stale_host = at::zeros({1}, at::TensorOptions().dtype(at::kBool).pinned_memory(true));
         std::lock_guard<std::mutex> lock(g_mu);
         g_graphs[int(pos.get_device())] = ge;
       }
     }
   }
   const size_t wsb = aa_model_workspace_bytes(pe.plan, N, E, 1);
-  if (size_t(ge.ws.numel()) < wsb) ge.ws = at::empty({int64_t(wsb)}, pos.options().dtype(at::kByte));  // (another model on the same list)
+  at::Tensor ws = at::empty({int64_t(wsb)}, pos.options().dtype(at::kByte));  // per call: stream-safe (caching allocator)
   // what depends on VALUES that change while the list stays put is rebuilt every call: the periodic shift vectors
   at::Tensor svc;
   if (shift_vec.has_value()) {
@@ -249,11 +285,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tenso
   g.t_rowptr = ge.trow.data_ptr<int32_t>();
   g.t_perm = ge.tperm.data_ptr<int32_t>();
   g.max_degree = ge.max_degree;
-  at::Tensor& ws = ge.ws;
   at::Tensor e_atom = at::empty({N}, pos.options()), forces = at::empty({N, 3}, pos.options());
   TORCH_CHECK(size_t(weights.numel()) * weights.element_size() >= aa_model_weights_bytes(pe.plan),
               "allegro_amd::energy_forces: weight blob too small for this config");
-  hipStream_t stream = c10::hip::getCurrentHIPStream(pos.get_device()).stream();
   const int rc = aa_model_energy_forces(pe.plan, weights.data_ptr(), &g, p.data_ptr(), ws.data_ptr(), wsb,
                                         e_atom.data_ptr(), forces.data_ptr(), stream);
   TORCH_CHECK(rc == 0, "aa_model_energy_forces failed (", rc, "): ", aa_last_error());
@@ -262,7 +296,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tenso
   at::Tensor w9 = at::empty({9}, pos.options());
   const int rv = aa_model_virial(pe.plan, &g, ws.data_ptr(), wsb, w9.data_ptr(), stream);
   TORCH_CHECK(rv == 0, "aa_model_virial failed (", rv, "): ", aa_last_error());
-  return {e_atom, forces, w9.neg().reshape({1, 3, 3})};
+  at::Tensor virial = w9.neg().reshape({1, 3, 3});
+  if (stale.defined()) {  // (no host sync: a list whose contents changed under the cache yields NaN, never a plausible number)
+    const at::Tensor nan = at::full({}, std::numeric_limits<double>::quiet_NaN(), pos.options());
+    e_atom = at::where(stale, nan, e_atom);
+    forces = at::where(stale, nan, forces);
+    virial = at::where(stale, nan, virial);
+  }
+  return {e_atom, forces, virial};
 }
 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_meta(const at::Tensor& pos, const at::Tensor& edge_index,

@@ -18,7 +18,7 @@ from . import _lib
 from .build import build_torch_ops
 
 _LOADED = False
-_MAGIC = 0x414C4C4547524F31
+_MAGIC = 0x414C4C4547524F32  # "ALLEGRO2": config format 2 (torch_ops.cpp rejects packages of other formats: their blob layout differs)
 
 
 def load_native_ops() -> None:
@@ -35,7 +35,7 @@ def _bits(x: float) -> int:
 
 def serialize_config(model, layout_hash: int = 0) -> list:
     """`aa_model_config` of a HipAllegroModel as the int64 word list torch_ops.cpp parses; `layout_hash` is the digest of
-    the blob layout the weights were packed for (aa_model_plan_layout_hash; 0 = unchecked)."""
+    the blob layout the weights were packed for (aa_model_plan_layout_hash; mandatory: the op refuses 0)."""
     model._ensure_plan()
     cfg, _keep = model._plan_keep
     w = [_MAGIC, cfg.dtype, cfg.num_types, cfg.num_bessels, cfg.l_max, cfg.num_layers, cfg.num_scalar, cfg.num_tensor,

@@ -186,7 +186,11 @@ typedef struct {
    * 2-layer 64-wide fp32 stack runs the fused per-atom-tile forward (one launch instead of seven, 2.1 instead of 7.3 KB
    * of HBM traffic per edge; up to 32: one wave per atom; 33..128: teams of 2 / 4 waves per atom, dealt from class lists
    * that one extra small launch builds -- chosen where it is faster: small systems (<= 4096 tiles) or nearly full tiles;
-   * see aa_plan_options.fused_forward and DESIGN.md section 9.1); otherwise the staged pipeline.  The caller guarantees it (allegro_amd.nn.PreparedGraph derives it from rowptr). */
+   * see aa_plan_options.fused_forward and DESIGN.md section 9.1); otherwise the staged pipeline.  The caller states it
+   * (allegro_amd.nn.PreparedGraph derives it from rowptr) and the kernels CHECK it: the reference accepts any segment length
+   * (_contract.py:195-205), so a segment longer than the hint is never silently truncated -- that atom's energy comes back
+   * NaN, the plan's host-visible status word is set, and the next aa_model_energy_forces on the plan (or aa_model_check)
+   * returns AA_ERR_INVALID naming the degree that was found. */
   int64_t max_degree;
 } aa_graph;
 
@@ -253,6 +257,12 @@ int aa_model_energy_forces(const aa_model_plan* plan, const void* dev_weights, c
                            const void* pos, void* workspace, size_t workspace_bytes,
                            void* atom_energy, void* forces, aa_stream stream);
 
+/* Synchronises `stream` and reports whether any step enqueued on this plan since the last report contradicted the graph
+ * hints it was given (aa_graph.max_degree too small, center atoms with edges outside [atom_begin, atom_end)):
+ * AA_ERR_INVALID + aa_last_error() then, AA_OK otherwise; the condition is cleared.  aa_model_energy_forces performs the
+ * same test (without synchronising) on entry, so a host that never calls this still gets the error one step late. */
+int aa_model_check(const aa_model_plan* plan, aa_stream stream);
+
 /* same as aa_model_energy_forces, additionally timing every kernel launch of the pass with HIP events
  * recorded on `stream` (synchronises the stream before returning).  stage_names is a
  * [max_stages][32] char buffer; stage i is the i-th launch, named after its kernel.  stage_bytes /
@@ -301,6 +311,14 @@ int aa_nl_count(const aa_nl_input* in, void* workspace, size_t workspace_bytes, 
                 aa_stream stream);
 int aa_nl_fill(const aa_nl_input* in, void* workspace, size_t workspace_bytes, const int32_t* rowptr, int32_t* center,
                int32_t* nbr, int32_t* cell_shift, void* shift_vec, aa_stream stream);
+
+/* 128-bit content fingerprint of a neighbour list as the pair_allegro contract hands it over (allegro/_compile.py:10-14):
+ * edge_index int64 [2,E] (second row at edge_index + row_stride) and atom_types [N] (int64 or int32), both in device
+ * memory; fp2: uint64[2] in device memory, overwritten.  Position-dependent (a permutation of the edges changes it) and
+ * bit-reproducible.  For hosts that cache the CSR of a list by tensor identity: csrc/torch_ops.cpp compares it on the
+ * device on every cache hit, so contents rewritten through a raw pointer are noticed (its outputs turn NaN, the next call fails). */
+int aa_graph_fingerprint(const int64_t* edge_index, int64_t row_stride, int64_t num_edges, const void* atom_types,
+                         int types_are_int64, int64_t num_atoms, uint64_t* fp2, aa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 4. Debug entry points (parity tests; not part of the drop-in surface).

@@ -577,7 +577,7 @@ class HipAllegroModel(torch.nn.Module):
                                       "allegro.nn.TwoBodySplineScalarEmbed exist in the reference (scalarembed.py)")
         if rce.get("bessel_trainable", False) and bessel_convention == "auto":
             raise NotImplementedError("trained Bessel roots cannot be told apart by their values: pass bessel_convention='sinc' "
-                                      "or 'npi' (this model evaluates them; it does not train them)")
+                                      "or 'npi'")
         self.dtype = {"float32": torch.float32, "float64": torch.float64}[model_dtype]
         self.type_names = list(type_names)
         T = len(self.type_names)
@@ -631,8 +631,9 @@ class HipAllegroModel(torch.nn.Module):
             add("radial_chemical_embed.spline.class_embed.weight",
                 torch.empty(T * T, S0 * B, dtype=dt).uniform_(-bound, bound), "param")
         else:
+            # nequip's BesselEdgeLengthEncoding (EXT) holds its roots as a Parameter when `trainable`, as a buffer otherwise
             add("radial_chemical_embed.bessel_encode.bessel_weights",
-                (torch.linspace(1.0, B, B, dtype=dt) * math.pi).unsqueeze(0), "buffer")
+                (torch.linspace(1.0, B, B, dtype=dt) * math.pi).unsqueeze(0), "param" if rce.get("bessel_trainable", False) else "buffer")
             add("radial_chemical_embed.type_embed.center_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
             add("radial_chemical_embed.type_embed.neighbor_embed.weight", torch.randn(T, S0 // 2, dtype=dt), "param")
             add("radial_chemical_embed.type_embed.basis_linear.mlp.0.weight", rng_u(B, S0), "param")
@@ -712,9 +713,21 @@ class HipAllegroModel(torch.nn.Module):
         weights; per-type scales / shifts only with `per_type_energy_*_trainable`, allegro_models.py:251-260) and `forward`
         returns energies, forces and stress attached to the autograd graph (allegro_amd/training.py).  `.eval()` returns to
         the inference pipeline; the packed device weights follow in-place optimizer updates (`_ensure_weights`)."""
+        mode = bool(mode)
+        was = self.training
         super().train(mode)
-        for k, p in self.named_parameters():
-            p.requires_grad_(bool(mode) and k not in self._frozen_keys)
+        if mode == was:
+            return self  # (a repeated .train() / .eval(), as training loops issue every epoch, leaves the user's freezes alone)
+        if mode:
+            # the parameters that were trainable when training mode was last left (so a user's requires_grad_(False) on a
+            # sub-module survives an eval() / train() round trip); the first time: everything the reference trains
+            on = getattr(self, "_trainable_keys", None)
+            for k, p in self.named_parameters():
+                p.requires_grad_(k not in self._frozen_keys if on is None else k in on)
+        else:
+            self._trainable_keys = {k for k, p in self.named_parameters() if p.requires_grad}
+            for p in self.parameters():
+                p.requires_grad_(False)
         return self
 
     def _training_evaluator(self):
@@ -900,6 +913,17 @@ class HipAllegroModel(torch.nn.Module):
                                                  forces.data_ptr() if with_forces else None, _stream_ptr(pos)),
                   "aa_model_energy_forces")
         return e_atom, forces
+
+    def check(self, device=None) -> None:
+        """`aa_model_check`: waits for the steps enqueued so far and raises if one of them contradicted the hints of its graph
+        (a `max_degree` smaller than a real segment, edges outside the atom block).  `PreparedGraph` derives both hints from
+        the row pointers, so this can only fire for hand-made graphs -- the raw C ABI has the same guard."""
+        lib = self._get_lib()
+        if getattr(self, "_plan_handle", None) is None:
+            return
+        dev = device if device is not None else (self._workspace.device if self._workspace is not None else None)
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev is not None and dev.type == "cuda" else None
+        lib.check(lib.lib.aa_model_check(self._plan_handle, stream), "aa_model_check")
 
     def virial(self, graph: PreparedGraph) -> torch.Tensor:
         """dE/d(strain) [3,3] of the LAST `energy_forces(..., with_forces=True)` call on `graph` (stress = virial / volume,

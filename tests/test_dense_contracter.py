@@ -7,7 +7,7 @@ import pytest
 import torch
 
 
-def _standard_layer_case(l_max, L, layer, mul, dtype, lib, dev, sorted_idxs, monkeypatch):
+def _standard_layer_case(l_max, L, layer, mul, dtype, lib, dev, sorted_idxs, monkeypatch, coupling=True):
     """`Contracter.forward` + input gradients on the irreps of a standard Allegro layer (allegro/nn/_allegro.py:101-160):
     the specialised dense-operand kernels (aa_tp_dense.hip) against the table-driven general kernels (AA_TP_GENERIC=1)
     and against the oracle's eager contraction."""
@@ -29,7 +29,7 @@ def _standard_layer_case(l_max, L, layer, mul, dtype, lib, dev, sorted_idxs, mon
         prev = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
-            c = HipContracter(str(irreps[layer]), str(env), str(irreps[layer + 1]), mul=mul, path_channel_coupling=True, scatter_factor=0.37)
+            c = HipContracter(str(irreps[layer]), str(env), str(irreps[layer + 1]), mul=mul, path_channel_coupling=coupling, scatter_factor=0.37)
         finally:
             torch.set_default_dtype(prev)
         c = c.to(dev).eval()
@@ -50,7 +50,7 @@ def _standard_layer_case(l_max, L, layer, mul, dtype, lib, dev, sorted_idxs, mon
         if generic == "0":
             xr1, xr2 = x1.detach().cpu().requires_grad_(True), x2.detach().cpu().requires_grad_(True)
             wr = c.weights.detach().cpu().requires_grad_(True)
-            yr = R.contracter_forward(xr1, xr2, idxs, N, wr, c.w3j.cpu(), True, 0.37)
+            yr = R.contracter_forward(xr1, xr2, idxs, N, wr, c.w3j.cpu(), coupling, 0.37)
             gr1, gr2, grw = torch.autograd.grad(yr, [xr1, xr2, wr], gy.cpu())
             ref = (yr.detach(), gr1, gr2, grw)
     tol = 1e-10 if dtype == torch.float64 else 2e-5
@@ -67,6 +67,24 @@ def test_standard_layers_run_the_dense_specialised_kernels_emulated(l_max, L, la
     from tests.hip_utils import emu_lib
 
     _standard_layer_case(l_max, L, layer, mul, dtype, emu_lib(), torch.device("cpu"), sorted_idxs, monkeypatch)
+
+
+# path_channel_coupling=False ("p" mode, weights [p] shared by all channels: _contract.py:172-177,244-249; the reference's kernel
+# test runs both modes, tests/nn/test_contract_kernels.py:37-40) through the specialised kernels' uncoupled branch
+@pytest.mark.parametrize("l_max,L,layer,mul,dtype,sorted_idxs", [
+    (2, 2, 0, 64, torch.float64, False), (2, 2, 1, 64, torch.float32, True), (1, 2, 0, 128, torch.float32, False)])
+def test_standard_layers_uncoupled_path_weights_emulated(l_max, L, layer, mul, dtype, sorted_idxs, monkeypatch):
+    from tests.hip_utils import emu_lib
+
+    _standard_layer_case(l_max, L, layer, mul, dtype, emu_lib(), torch.device("cpu"), sorted_idxs, monkeypatch, coupling=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("l_max,L,layer,mul,dtype,sorted_idxs", [
+    (2, 2, 0, 64, torch.float32, True), (2, 2, 1, 64, torch.float64, False), (1, 2, 0, 128, torch.float64, False),
+    (2, 3, 1, 64, torch.float32, False), (3, 3, 1, 64, torch.float64, True), (1, 2, 1, 256, torch.float32, False)])
+def test_standard_layers_uncoupled_path_weights_on_gpu(l_max, L, layer, mul, dtype, sorted_idxs, monkeypatch):
+    _standard_layer_case(l_max, L, layer, mul, dtype, None, torch.device("cuda:0"), sorted_idxs, monkeypatch, coupling=False)
 
 
 @pytest.mark.gpu

@@ -342,3 +342,48 @@ def test_fused_and_staged_forward_agree_on_gpu(mode, name, monkeypatch):
     assert (e - e2).abs().max().item() < 5e-6 and (f - f2).abs().max().item() < 2e-5
     for got, want in ((e.cpu(), fx["out"]["atomic_energy"].reshape(-1)), (f.cpu(), fx["out"]["forces"])):
         assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
+
+
+def _stale_hint_case(lib, dev):
+    """A C host that passes a stale aa_graph.max_degree (the hint the fused forward trusts for its tile shape) must get an
+    error, not energies that silently ignore edges: every edge of the c2 cell listed twice = 56 edges
+    per atom, hint left at 28.  The reference takes any segment length (_strided/_contract.py:195-205)."""
+    fx = load_model_fixture("c2", torch.float32)
+    m = model_from_fixture(fx, torch.float32, lib, device=dev)
+    data, sv = fixture_data(fx, torch.float32, dev)
+    ei = torch.cat([data["edge_index"], data["edge_index"]], 1)
+    sv2 = torch.cat([sv, sv], 0)
+    g = m.prepare_graph(ei, data["atom_types"], data["pos"].shape[0], sv2)
+    assert g.max_degree == 56
+    e_ok, f_ok = m.energy_forces(data["pos"], g)  # true hint: team form of the fused forward
+    m.check()
+    assert torch.isfinite(e_ok).all() and torch.isfinite(f_ok).all()
+    g.max_degree = 28  # stale
+    e_bad, _ = m.energy_forces(data["pos"], g)
+    with pytest.raises(RuntimeError, match="max_degree"):
+        m.check()
+    assert torch.isnan(e_bad).all()  # every atom has 56 > 32 edges: none is evaluated on a truncated segment
+    # the condition is reported once; without aa_model_check the NEXT step reports it
+    e_bad, _ = m.energy_forces(data["pos"], g)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="56 edges"):
+        m.energy_forces(data["pos"], g)
+    g.max_degree = 56
+    e2, f2 = m.energy_forces(data["pos"], g)
+    m.check()
+    assert torch.equal(e2, e_ok) and torch.equal(f2, f_ok)
+    # the atom-block hint is verified the same way: a block that leaves centers with edges outside
+    g.atom_begin, g.atom_end = 8, 40
+    m.energy_forces(data["pos"], g)
+    with pytest.raises(RuntimeError, match="atom_begin"):
+        m.check()
+
+
+def test_stale_max_degree_hint_fails_loudly_emulated():
+    _stale_hint_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_stale_max_degree_hint_fails_loudly():
+    _stale_hint_case(None, torch.device("cuda:0"))

@@ -89,3 +89,33 @@ def test_bench_prices_the_fused_forward_against_the_matrix_roofline():
     roof, _ = bench.roofline_from_stages(stages, "float32", workload="none")
     assert roof["kernel"] == "fused_fwd" and roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == bench.PEAK_F32_TFLOPS
     assert abs(roof["achieved"] - 60.0) < 1e-9 and abs(roof["frac"] - 60.0 / 157.3) < 1e-9 and abs(roof["hbm_GBps"] - 1200.0) < 1e-6
+
+
+def test_train_mode_keeps_user_freezes_and_bessel_roots_are_a_parameter_when_trainable():
+    """`train()` must not re-enable what the user froze, and `bessel_trainable=True` must register the
+    roots as a Parameter (nequip's BesselEdgeLengthEncoding trains them; the training evaluator differentiates through them)."""
+    from allegro_amd.nn import HipAllegroModel
+    from tests.fastpath_utils import _cfg
+
+    cfg = _cfg("bessel", True)
+    m = HipAllegroModel(**cfg)
+    key = "func.radial_chemical_embed.bessel_encode.bessel_weights"
+    assert key not in dict(m.named_parameters()) and key in dict(m.named_buffers())
+    cfg["radial_chemical_embed"] = dict(cfg["radial_chemical_embed"], bessel_trainable=True)
+    m = HipAllegroModel(**cfg, bessel_convention="npi")
+    assert key in dict(m.named_parameters())
+    assert not m.training and not any(p.requires_grad for p in m.parameters())  # inference pipeline by default
+    m.train()
+    assert all(p.requires_grad for k, p in m.named_parameters() if k not in m._frozen_keys)  # (per-type scales / shifts: only when declared trainable)
+    frozen = [k for k, _ in m.named_parameters() if ".edge_readout." in k] + sorted(m._frozen_keys)
+    assert frozen
+    for k, p in m.named_parameters():
+        if k in frozen:
+            p.requires_grad_(False)
+    m.train()  # (every epoch of a training loop)
+    assert not any(p.requires_grad for k, p in m.named_parameters() if k in frozen)
+    m.eval()
+    assert not any(p.requires_grad for p in m.parameters())
+    m.train()
+    on = {k for k, p in m.named_parameters() if p.requires_grad}
+    assert on == {k for k, _ in m.named_parameters()} - set(frozen)

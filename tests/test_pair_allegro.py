@@ -126,3 +126,60 @@ def test_aotinductor_package_round_trip_on_reference_ghost_data(tmp_path):
     _check(gx, dtype, got[0], got[2], "AOTInductor package")
     want = ex(*args)
     assert torch.equal(got[2], want[2]) and torch.equal(got[3], want[3])
+
+
+@pytest.mark.gpu
+def test_native_op_notices_a_list_rewritten_behind_the_same_tensors():
+    """the op caches the CSR of a list by tensor identity + version, which a C++ MD host that refills a
+    persistent edge_index through data_ptr() never changes.  Every cache hit is therefore validated by content on the
+    device (aa_graph_fingerprint): the call after a raw rewrite returns NaN -- never numbers computed on the stale CSR --
+    and the one after that raises."""
+    import ctypes
+
+    from allegro_amd.export import ExportableAllegro
+
+    dev = torch.device("cuda:0")
+    dtype = torch.float32
+    gx = load_ghost_fixture(dtype)
+    m = model_from_fixture(gx["base"], dtype, device=dev)
+    ex = ExportableAllegro(m, dev)
+    pos, ei, types = gx["pos"].to(dev), gx["edge_index"].to(dev).contiguous(), gx["types"].to(dev)
+    e0, _, f0, _ = ex(pos, ei, types)
+    e1, _, f1, _ = ex(pos, ei, types)  # hit, contents unchanged
+    assert torch.equal(e0, e1) and torch.equal(f0, f1)
+    # rewrite the contents WITHOUT touching the version counter: reverse the edge order through a raw device copy
+    rev = ei.flip(1).contiguous()
+    ver = ei._version
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(ei.data_ptr(), rev.data_ptr(), ei.numel() * 8, 3) == 0  # hipMemcpyDeviceToDevice
+    assert ei._version == ver
+    e2, _, f2, _ = ex(pos, ei, types)
+    assert torch.isnan(e2).all() and torch.isnan(f2).all()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="contents of edge_index"):
+        ex(pos, ei, types)
+    # the entry is gone: the same (rewritten) tensors are now a new list, evaluated correctly (same edges, other order)
+    e3, _, f3, _ = ex(pos, ei, types)
+    _check(dict(gx, edge_index=ei.cpu()), dtype, e3, f3, "rebuilt after rewrite")
+
+
+@pytest.mark.gpu
+def test_native_op_rejects_packages_of_another_format():
+    """a config written by an earlier blob format must fail loudly, not be read with the new offsets."""
+    from allegro_amd.export import ExportableAllegro
+
+    dev = torch.device("cuda:0")
+    gx = load_ghost_fixture(torch.float32)
+    m = model_from_fixture(gx["base"], torch.float32, device=dev)
+    ex = ExportableAllegro(m, dev)
+    args = (gx["pos"].to(dev), gx["edge_index"].to(dev), gx["types"].to(dev))
+    old = list(ex.config)
+    old[0] = 0x414C4C4547524F31  # "ALLEGRO1"
+    with pytest.raises(RuntimeError, match="another version"):
+        torch.ops.allegro_amd_native.energy_forces(*args, None, old, ex.weights)
+    nodigest = list(ex.config)
+    nodigest[29] = 0
+    with pytest.raises(RuntimeError, match="digest"):
+        torch.ops.allegro_amd_native.energy_forces(*args, None, nodigest, ex.weights)
