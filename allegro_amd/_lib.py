@@ -135,6 +135,20 @@ class AllegroLib:
         L.aa_model_plan_enable_graph.restype = C.c_int
         L.aa_model_plan_enable_taps.argtypes = [C.c_void_p, C.c_int]
         L.aa_model_plan_enable_taps.restype = C.c_int
+        L.aa_graph_fingerprint.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        L.aa_graph_fingerprint.restype = C.c_int
+        L.aa_model_file_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.aa_model_file_open.restype = C.c_int
+        L.aa_model_file_from_words.argtypes = [C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_void_p)]
+        L.aa_model_file_from_words.restype = C.c_int
+        L.aa_model_file_config.argtypes = [C.c_void_p]
+        L.aa_model_file_config.restype = C.POINTER(ModelConfig)
+        L.aa_model_file_weights.argtypes = [C.c_void_p]
+        L.aa_model_file_weights.restype = C.POINTER(RawWeights)
+        L.aa_model_file_layout_digest.argtypes = [C.c_void_p]
+        L.aa_model_file_layout_digest.restype = C.c_uint64
+        L.aa_model_file_close.argtypes = [C.c_void_p]
+        L.aa_model_file_close.restype = None
         L.aa_model_check.argtypes = [C.c_void_p, C.c_void_p]
         L.aa_model_check.restype = C.c_int
         L.aa_model_virial.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -33,31 +33,19 @@ constexpr int kHeader = 30;
 
 struct PlanEntry {
   aa_model_plan* plan = nullptr;
-  std::vector<std::vector<int32_t>> ints;
-  std::vector<std::vector<double>> vals;
+  aa_model_file* file = nullptr;  // owns the parsed config (Clebsch-Gordan tables) the plan was created from
   ~PlanEntry() {
     if (plan) aa_model_plan_destroy(plan);
+    if (file) aa_model_file_close(file);
   }
 };
 
 std::mutex g_mu;
 std::map<std::string, std::unique_ptr<PlanEntry>> g_plans;
 
-double as_double(int64_t bits) {
-  double d;
-  std::memcpy(&d, &bits, 8);
-  return d;
-}
-
-// config layout (int64 words): [magic, dtype, num_types, num_bessels, l_max, num_layers, num_scalar, num_tensor,
-//   embed_dim, embed_mlp_depth, embed_mlp_width, latent_mlp_depth, latent_mlp_width, readout_mlp_depth,
-//   readout_mlp_width, forward_weight_init, has_scales, has_shifts, embed_kind, spline_span,
-//   bits(poly_p), bits(avg_num_neighbors), bits(act_const), env_shared_weights, act_kind[0..2] (one byte each),
-//   bits(act_consts[0..2]), bessel_convention, layout digest of the blob (aa_model_plan_layout_hash; mandatory)]
-//   then per layer
-//   [mul, d1, d2, dout, num_paths, coupling, nnz, i[nnz], j[nnz], k[nnz], path[nnz], bits(val)[nnz]]
-// (a plan owns Clebsch-Gordan tables in the memory of the device that was current when it was created: the cache
-//  key carries the device index and the caller holds a device guard)
+// `config`: the serialized aa_model_config written by allegro_amd/export.py: serialize_config and parsed by the C ABI
+// (aa_model_file_from_words; word layout in csrc/aa_hostfile.hip).  A plan owns Clebsch-Gordan tables in the memory of the
+// device that was current when it was created: the cache key carries the device index and the caller holds a device guard.
 const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
   const int64_t* w = config.data();
   const int64_t n = int64_t(config.size());
@@ -70,66 +58,14 @@ const PlanEntry& plan_for(at::IntArrayRef config, int device_index) {
   auto it = g_plans.find(key);
   if (it != g_plans.end()) return *it->second;
   auto e = std::make_unique<PlanEntry>();
-  aa_model_config c{};
-  c.dtype = int32_t(w[1]);
-  c.num_types = int32_t(w[2]);
-  c.num_bessels = int32_t(w[3]);
-  c.l_max = int32_t(w[4]);
-  c.num_layers = int32_t(w[5]);
-  c.num_scalar = int32_t(w[6]);
-  c.num_tensor = int32_t(w[7]);
-  c.embed_dim = int32_t(w[8]);
-  c.embed_mlp_depth = int32_t(w[9]);
-  c.embed_mlp_width = int32_t(w[10]);
-  c.latent_mlp_depth = int32_t(w[11]);
-  c.latent_mlp_width = int32_t(w[12]);
-  c.readout_mlp_depth = int32_t(w[13]);
-  c.readout_mlp_width = int32_t(w[14]);
-  c.forward_weight_init = int32_t(w[15]);
-  c.has_scales = int32_t(w[16]);
-  c.has_shifts = int32_t(w[17]);
-  c.embed_kind = int32_t(w[18]);
-  c.spline_span = int32_t(w[19]);
-  c.poly_p = as_double(w[20]);
-  c.avg_num_neighbors = as_double(w[21]);
-  c.act_const = as_double(w[22]);
-  c.env_shared_weights = int32_t(w[23]);
-  for (int i = 0; i < 3; ++i) {
-    c.act_kind[i] = int32_t((w[24] >> (8 * i)) & 0xff);
-    c.act_consts[i] = as_double(w[25 + i]);
-  }
-  c.bessel_convention = int32_t(w[28]);
-  TORCH_CHECK(c.num_layers >= 1 && c.num_layers <= AA_MAX_LAYERS, "allegro_amd: bad layer count in config");
-  int64_t o = kHeader;
-  for (int l = 0; l < c.num_layers; ++l) {
-    TORCH_CHECK(o + 7 <= n, "allegro_amd: truncated config");
-    aa_tp_desc& d = c.tps[l];
-    d.mul = int32_t(w[o]);
-    d.d1 = int32_t(w[o + 1]);
-    d.d2 = int32_t(w[o + 2]);
-    d.dout = int32_t(w[o + 3]);
-    d.num_paths = int32_t(w[o + 4]);
-    d.coupling = int32_t(w[o + 5]);
-    d.nnz = int32_t(w[o + 6]);
-    o += 7;
-    TORCH_CHECK(d.nnz >= 0 && o + 5 * int64_t(d.nnz) <= n, "allegro_amd: truncated config");
-    const int32_t** dst[4] = {&d.nz_i, &d.nz_j, &d.nz_k, &d.nz_path};
-    for (int q = 0; q < 4; ++q) {
-      e->ints.emplace_back(d.nnz);
-      for (int t = 0; t < d.nnz; ++t) e->ints.back()[t] = int32_t(w[o + t]);
-      *dst[q] = e->ints.back().data();
-      o += d.nnz;
-    }
-    e->vals.emplace_back(d.nnz);
-    for (int t = 0; t < d.nnz; ++t) e->vals.back()[t] = as_double(w[o + t]);
-    d.nz_val = e->vals.back().data();
-    o += d.nnz;
-  }
-  const int rc = aa_model_plan_create(&c, &e->plan);
+  int rc = aa_model_file_from_words(w, n, &e->file);
+  TORCH_CHECK(rc == 0, "allegro_amd: bad model config (", rc, "): ", aa_last_error());
+  rc = aa_model_plan_create(aa_model_file_config(e->file), &e->plan);
   TORCH_CHECK(rc == 0, "aa_model_plan_create failed (", rc, "): ", aa_last_error());
   // the weight blob travels with the config: it must have been packed for THIS plan's layout (default options)
-  TORCH_CHECK(w[29] != 0, "allegro_amd: the config carries no blob-layout digest; re-export the model");
-  TORCH_CHECK(uint64_t(w[29]) == aa_model_plan_layout_hash(e->plan),
+  const uint64_t digest = aa_model_file_layout_digest(e->file);
+  TORCH_CHECK(digest != 0, "allegro_amd: the config carries no blob-layout digest; re-export the model");
+  TORCH_CHECK(digest == aa_model_plan_layout_hash(e->plan),
               "allegro_amd: the weight blob was packed for another plan layout (kernel-selection options differ); "
               "re-export the model (allegro_amd.export.ExportableAllegro packs for the default options)");
   return *(g_plans[key] = std::move(e));

@@ -36,8 +36,7 @@ def _bits(x: float) -> int:
 def serialize_config(model, layout_hash: int = 0) -> list:
     """`aa_model_config` of a HipAllegroModel as the int64 word list torch_ops.cpp parses; `layout_hash` is the digest of
     the blob layout the weights were packed for (aa_model_plan_layout_hash; mandatory: the op refuses 0)."""
-    model._ensure_plan()
-    cfg, _keep = model._plan_keep
+    cfg, _keep = model._plan_keep if getattr(model, "_plan_keep", None) else model._build_config()  # (no library call: works without a GPU)
     w = [_MAGIC, cfg.dtype, cfg.num_types, cfg.num_bessels, cfg.l_max, cfg.num_layers, cfg.num_scalar, cfg.num_tensor,
          cfg.embed_dim, cfg.embed_mlp_depth, cfg.embed_mlp_width, cfg.latent_mlp_depth, cfg.latent_mlp_width,
          cfg.readout_mlp_depth, cfg.readout_mlp_width, cfg.forward_weight_init, cfg.has_scales, cfg.has_shifts,
@@ -52,6 +51,27 @@ def serialize_config(model, layout_hash: int = 0) -> list:
             w += [int(arr[t]) for t in range(d.nnz)]
         w += [_bits(d.nz_val[t]) for t in range(d.nnz)]
     return [int(v) for v in w]
+
+
+def write_host_model(model, path: str) -> None:
+    """Model file for Python-free hosts (`aa_model_file_open`, include/allegro_amd.h section 5; layout in
+    csrc/aa_hostfile.hip): the serialized `aa_model_config` (hyper-parameters + Clebsch-Gordan non-zeros) followed by every
+    parameter as float64 in the reference's own state_dict layout.  Needs no GPU.  A C host then runs
+    `aa_model_plan_create(aa_model_file_config(f))` / `aa_model_pack_weights(plan, aa_model_file_weights(f), ...)`
+    (tests/host/host_c99.c)."""
+    import numpy as np
+
+    words = np.asarray(serialize_config(model, 0), dtype="<i8")
+    tensors = model._raw_tensors()
+    with open(path, "wb") as f:
+        f.write(b"AAMODEL1")
+        f.write(np.asarray([words.size], dtype="<i8").tobytes())
+        f.write(words.tobytes())
+        f.write(np.asarray([len(tensors)], dtype="<i8").tobytes())
+        for slot, t in tensors:
+            a = np.ascontiguousarray(t.detach().cpu().double().numpy().reshape(-1)).astype("<f8")
+            f.write(np.asarray([slot, a.size], dtype="<i8").tobytes())
+            f.write(a.tobytes())
 
 
 class ExportableAllegro(torch.nn.Module):

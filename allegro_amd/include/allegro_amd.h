@@ -321,6 +321,24 @@ int aa_graph_fingerprint(const int64_t* edge_index, int64_t row_stride, int64_t 
                          int types_are_int64, int64_t num_atoms, uint64_t* fp2, aa_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 5. Host-side model files: what a Python-free host (a LAMMPS pair style, the C driver of INTEGRATION.md section 3) passes
+ *    to aa_model_plan_create / aa_model_pack_weights, read from ONE flat file that allegro_amd.export.write_host_model
+ *    writes from a model holding a reference checkpoint (same state_dict keys as allegro.model.AllegroModel,
+ *    allegro/model/allegro_models.py:112-300): hyper-parameters, the Clebsch-Gordan non-zeros of every layer
+ *    (Contracter.__init__, _contract.py:95-119) and every parameter as float64 in the reference's own layout.
+ *    Pure host code, no GPU needed.  The returned pointers live until aa_model_file_close.
+ *    aa_model_file_from_words parses the int64 word list alone (the `config` argument of the exported dispatcher op,
+ *    csrc/torch_ops.cpp; weights all NULL then).  File layout: csrc/aa_hostfile.hip.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct aa_model_file aa_model_file;
+int aa_model_file_open(const char* path, aa_model_file** out);
+int aa_model_file_from_words(const int64_t* words, int64_t num_words, aa_model_file** out);
+const aa_model_config* aa_model_file_config(const aa_model_file* file);
+const aa_model_raw_weights* aa_model_file_weights(const aa_model_file* file);
+uint64_t aa_model_file_layout_digest(const aa_model_file* file); /* aa_model_plan_layout_hash of the plan the exporter packed for; 0: none */
+void aa_model_file_close(aa_model_file* file);
+
+/* ---------------------------------------------------------------------------------------------
  * 4. Debug entry points (parity tests; not part of the drop-in surface).
  *    aa_debug_gemm_f32: C[M,N] = A[M,K] @ W[K,N] (A, C device fp32 row-major; W HOST fp32 row-major) through one of
  *    the fp32 linear-layer kernels of the scalar MLPs: 0 = bf16x3 split-precision MFMA, 1 = native fp32-input MFMA,

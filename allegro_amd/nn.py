@@ -787,6 +787,13 @@ class HipAllegroModel(torch.nn.Module):
                                 else torch.device("cpu"))
         if self._plan_handle is not None:
             return
+        cfg, keep = self._build_config()
+        self._plan_handle = self._get_lib().model_plan_create(cfg)
+        self._plan_keep = (cfg, keep)
+
+    def _build_config(self):
+        """(`aa_model_config`, keep-alive list) of this model: hyper-parameters + the Clebsch-Gordan non-zeros of every layer.
+        Pure host work (no library call)."""
         hp = self.hparams
         cfg = _lib.ModelConfig()
         cfg.dtype = _TORCH2AA[self.dtype]
@@ -815,14 +822,44 @@ class HipAllegroModel(torch.nn.Module):
                                   m["diag"], hp["coupling"])
             cfg.tps[l] = desc
             keep.append(k)
-        self._plan_handle = self._get_lib().model_plan_create(cfg)
-        self._plan_keep = (cfg, keep)
+        return cfg, keep
 
     def _ensure_weights(self, device):
         key = (str(device), tuple(int(p._version) for p in self.parameters()), tuple(p.data_ptr() for p in self.parameters()))
         if self._blob is not None and self._blob_key == key:
             return
         self._blob, self._blob_key = self._pack_blob(self._plan_handle, device), key
+
+    def _raw_tensors(self, sd=None):
+        """[(slot, float64 tensor)]: the parameters aa_model_pack_weights consumes, in the reference's own state_dict layout; slot =
+        position of the pointer in `aa_model_raw_weights` (include/allegro_amd.h) -- also the tensor ids of a host model file
+        (allegro_amd.export.write_host_model, csrc/aa_hostfile.hip)."""
+        hp = self.hparams
+        if sd is None:
+            sd = {k: v.detach().to("cpu", torch.float64).contiguous() for k, v in self._sd().items()}
+        ML, LL = _lib.AA_MAX_MLP_LAYERS, _lib.AA_MAX_LAYERS
+        T = len(self.type_names)
+        rr = sd["edge_norm.rmax_recip"]
+        out = [(0, rr.expand(T, T).contiguous() if rr.numel() == 1 else rr)]
+        if self.embed_kind == 1:
+            out.append((7 + 2 * ML + LL * ML + LL + 2, sd["radial_chemical_embed.spline.class_embed.weight"]))
+        else:
+            out += [(1, sd["radial_chemical_embed.bessel_encode.bessel_weights"]),
+                    (2, sd["radial_chemical_embed.type_embed.center_embed.weight"]),
+                    (3, sd["radial_chemical_embed.type_embed.neighbor_embed.weight"]),
+                    (4, sd["radial_chemical_embed.type_embed.basis_linear.mlp.0.weight"])]
+        out += [(5 + i, sd[f"scalar_embed_mlp.mlp.mlp.{i}.weight"]) for i in range(hp["embed_depth"] + 1)]
+        out += [(5 + ML, sd["tensor_embed.env_embed_linear.mlp.0.weight"]),
+                (6 + ML, sd["allegro.first_layer_env_embed_projection.mlp.0.weight"])]
+        for l in range(hp["num_layers"]):
+            out += [(7 + ML + l * ML + i, sd[f"allegro.latents.{l}.mlp.{i}.weight"]) for i in range(hp["latent_depth"] + 1)]
+            out.append((7 + ML + LL * ML + l, sd[f"allegro.tps.{l}.weights"]))
+        out += [(7 + ML + LL * ML + LL + i, sd[f"edge_readout.mlp.mlp.{i}.weight"]) for i in range(hp["readout_depth"] + 1)]
+        if self.has_scales:
+            out.append((7 + 2 * ML + LL * ML + LL, sd["per_type_energy_scale_shift.scales"]))
+        if self.has_shifts:
+            out.append((7 + 2 * ML + LL * ML + LL + 1, sd["per_type_energy_scale_shift.shifts"]))
+        return sorted(out, key=lambda kv: kv[0])
 
     def _pack_blob(self, plan_handle, device) -> torch.Tensor:
         """The model's state_dict packed for `plan_handle` (aa_model_pack_weights): the blob's layout belongs to that plan
@@ -838,30 +875,23 @@ class HipAllegroModel(torch.nn.Module):
             return a.ctypes.data_as(C.POINTER(C.c_double))
 
         raw = _lib.RawWeights()
-        T = len(self.type_names)
-        rr = sd["edge_norm.rmax_recip"]
-        raw.rmax_recip = ptr(rr.expand(T, T).contiguous() if rr.numel() == 1 else rr)
-        if self.embed_kind == 1:
-            raw.spline_weights = ptr(sd["radial_chemical_embed.spline.class_embed.weight"])
-        else:
-            raw.bessel_weights = ptr(sd["radial_chemical_embed.bessel_encode.bessel_weights"])
-            raw.center_embed = ptr(sd["radial_chemical_embed.type_embed.center_embed.weight"])
-            raw.neighbor_embed = ptr(sd["radial_chemical_embed.type_embed.neighbor_embed.weight"])
-            raw.basis_linear = ptr(sd["radial_chemical_embed.type_embed.basis_linear.mlp.0.weight"])
-        for i in range(hp["embed_depth"] + 1):
-            raw.embed_mlp[i] = ptr(sd[f"scalar_embed_mlp.mlp.mlp.{i}.weight"])
-        raw.env_embed_linear = ptr(sd["tensor_embed.env_embed_linear.mlp.0.weight"])
-        raw.first_proj = ptr(sd["allegro.first_layer_env_embed_projection.mlp.0.weight"])
-        for l in range(hp["num_layers"]):
-            for i in range(hp["latent_depth"] + 1):
-                raw.latent[l][i] = ptr(sd[f"allegro.latents.{l}.mlp.{i}.weight"])
-            raw.tp_weights[l] = ptr(sd[f"allegro.tps.{l}.weights"])
-        for i in range(hp["readout_depth"] + 1):
-            raw.readout[i] = ptr(sd[f"edge_readout.mlp.mlp.{i}.weight"])
-        if self.has_scales:
-            raw.scales = ptr(sd["per_type_energy_scale_shift.scales"])
-        if self.has_shifts:
-            raw.shifts = ptr(sd["per_type_energy_scale_shift.shifts"])
+        ML, LL = _lib.AA_MAX_MLP_LAYERS, _lib.AA_MAX_LAYERS
+        for slot, t in self._raw_tensors(sd):
+            p = ptr(t)
+            if slot < 5:
+                setattr(raw, ("rmax_recip", "bessel_weights", "center_embed", "neighbor_embed", "basis_linear")[slot], p)
+            elif slot < 5 + ML:
+                raw.embed_mlp[slot - 5] = p
+            elif slot < 7 + ML:
+                setattr(raw, ("env_embed_linear", "first_proj")[slot - 5 - ML], p)
+            elif slot < 7 + ML + LL * ML:
+                raw.latent[(slot - 7 - ML) // ML][(slot - 7 - ML) % ML] = p
+            elif slot < 7 + ML + LL * ML + LL:
+                raw.tp_weights[slot - 7 - ML - LL * ML] = p
+            elif slot < 7 + 2 * ML + LL * ML + LL:
+                raw.readout[slot - 7 - ML - LL * ML - LL] = p
+            else:
+                setattr(raw, ("scales", "shifts", "spline_weights")[slot - 7 - 2 * ML - LL * ML - LL], p)
         nbytes = lib.lib.aa_model_weights_bytes(plan_handle)
         blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0

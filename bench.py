@@ -232,7 +232,7 @@ def roofline_from_stages(stages, dtype, workload="c4"):
     return roof, table
 
 
-def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3):
+def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3, vs_fp64=True):
     """The oracle restatement (a port: kind='port') timed on this host's cores on a bounded sample:
     the first contiguous block of center atoms holding ~target_edges edges, evaluated in chunks of
     <=12k edges (exact by strict locality).  Thread count: min(cores, 32) -- eager PyTorch CPU slows
@@ -279,7 +279,57 @@ def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3):
                   against="oracle/restatement.py (CPU, same dtype) on the same edge subset; tolerances: forces 1e-4 eV/A "
                           "(north star) in fp32, 1e-9 x scale in fp64; energies 5e-5 / 1e-9 x scale "
                           "(tests/model/test_allegro.py:72-74 of the reference)")
+    if vs_fp64 and dtype == torch.float32:
+        # whose error is it?  The fp32 HIP path and the fp32 CPU oracle each against the fp64 oracle on the same (upcast)
+        # weights and the same edge subset: the HIP arithmetic (bf16x3 split products, fp32 accumulation, its own summation
+        # orders) is as close to the exact answer as the reference's own fp32 arithmetic is
+        cfg64 = dict(ocfg, model_dtype="float64")
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        o64 = R.allegro_energy_forces_chunked(cfg64, sd64, pos.double(), ei, types, None if sv is None else sv.double(), 12000)
+        f64, e64 = o64["forces"], o64["atomic_energy"].reshape(-1)[:a1]
+        hip_f, cpu_f = float((f_h.cpu().double() - f64).abs().max()), float((f_o.double() - f64).abs().max())
+        hip_e, cpu_e = float((e_h[:a1].cpu().double() - e64).abs().max()), float((e_o.double() - e64).abs().max())
+        parity["vs_fp64"] = dict(hip=dict(max_dF=hip_f, max_dE=hip_e), oracle_fp32=dict(max_dF=cpu_f, max_dE=cpu_e),
+                                 hip_over_oracle_fp32_dF=hip_f / max(cpu_f, 1e-30),
+                                 what="max abs deviation from oracle/restatement.py in float64 (weights upcast) on the same edge subset")
     return base, parity
+
+
+def secondary_workload(name, dev, steps, warmup, cpu_edges):
+    """Compact record of another BASELINE workload for the default line (`secondary`): timed exactly like the headline
+    (W warm-ups, K steps between synchronisations, inputs resident), dominant kernel against its roofline from a separate
+    HIP-event pass, parity of the timed path against the CPU oracle on a bounded edge subset."""
+    g, cfg = make_workload(name)
+    dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
+    model = HipAllegroModel(**cfg).to(dev)
+    N, E, L = g.num_atoms, g.num_edges, cfg["num_layers"]
+    sv = g.shift_vec()
+    pos = torch.tensor(g.pos, dtype=dtype, device=dev)
+    graph = PreparedGraph(torch.tensor(g.edge_index, device=dev), torch.tensor(g.types, device=dev), N,
+                          torch.tensor(sv, dtype=dtype, device=dev) if sv is not None else None)
+    for _ in range(warmup):
+        model.energy_forces(pos, graph)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.energy_forces(pos, graph)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / steps
+    model.check()
+    stages = profile_stages(model, pos, graph, reps=3)
+    roof, _ = roofline_from_stages(stages, cfg["model_dtype"], name)
+    base, parity = cpu_baseline(g, cfg, model, target_edges=cpu_edges, reps=1, vs_fp64=True)
+    rec = dict(workload=f"{name}: {WORKLOADS[name]['desc']}", atoms=N, edges=E, dtype="f32" if dtype == torch.float32 else "f64",
+               steps=steps, warmup=warmup, ms_per_step=t_step * 1e3, value=E * L / t_step, unit="edge-TP/s",
+               roofline={k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_per_step")},
+               step_frac_of_fused_compute_roof=step_roofline(cfg, E, t_step, stages, cfg["model_dtype"])["frac_of_fused_compute_roof"],
+               parity_sample={k: parity[k] for k in ("atoms", "edges", "max_dE", "max_dF", "tol_dE", "tol_dF", "ok") if k in parity},
+               cpu_baseline=dict(value=base["value"], unit=base["unit"], cores=base["cores"], kind=base["kind"]))
+    if "vs_fp64" in parity:
+        rec["parity_sample"]["vs_fp64"] = {k: parity["vs_fp64"][k] for k in ("hip", "oracle_fp32")}
+    del model, graph, pos
+    torch.cuda.empty_cache()
+    return rec
 
 
 def gpu_reference_baseline(g: G.Graph, cfg, model, dev, target_edges=60000, reps=3):
@@ -501,6 +551,8 @@ def main():
                     help="seconds of additional back-to-back steps AFTER the timed region (reported as config.sustained): "
                          "long enough for an external sampler (rocm-smi every few seconds) to witness the GPU busy; 0 = off")
     ap.add_argument("--stages", action="store_true", help="also print every launch of one step with its HIP-event time")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default C4 line only: skip the compact C3 / C5 records (`secondary`: ms/step, roofline fraction, parity sample)")
     ap.add_argument("--emulate-shard", default=None, metavar="R/W",
                     help="analysis only: run rank R's atom block of a W-way partition on this one GPU (no collective)")
     ap.add_argument("--shard-sweep", type=int, default=0, metavar="W",
@@ -647,6 +699,8 @@ def main():
             line["roofline"] = roof
             line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])
             line["stage_ms"] = table
+            line["stage_ms_note"] = ("per-launch HIP-event times of a SEPARATE instrumented pass (aa_model_energy_forces_profiled, mean of 5): "
+                                     "the event pairs serialise the launches, so their sum runs ~2 % above ms_per_step of the timed loop")
             if args.stages:
                 for nm, ms, nb, fl in stages:
                     print(f"[stage] {nm:24s} {ms * 1e3:9.1f} us {nb / max(ms, 1e-9) / 1e6:8.0f} GB/s (algorithmic)"
@@ -684,6 +738,15 @@ def main():
             line["gpu_reference_baseline"] = gpu_reference_baseline(g, cfg, model, dev,
                                                                     target_edges=60000 if cfg["l_max"] <= 2 else 12000)
             line["speedup_vs_gpu_reference"] = line["value"] / line["gpu_reference_baseline"]["value"]
+        if (world == 1 and args.workload == "c4" and not args.no_secondary and not args.no_cpu_baseline and not args.emulate_shard
+                and not os.environ.get("AA_BENCH_CELLS")):
+            # the other BASELINE workloads in front of the driver: same model family at 10^4 atoms (C3), and the
+            # fp64 / l_max 3 / 3-layer / 128-feature / 2-species water box (C5) with its own kernel family
+            del graph
+            torch.cuda.empty_cache()
+            line["secondary"] = {"c3": secondary_workload("c3", dev, steps=50, warmup=5, cpu_edges=60000),
+                                 "c5": secondary_workload("c5", dev, steps=5, warmup=2, cpu_edges=12000)}
+            parity_failed = parity_failed or not all(v["parity_sample"]["ok"] for v in line["secondary"].values())
         print(json.dumps(line), flush=True)
         if parity_failed:
             print("bench.py: parity_sample outside the north-star tolerance -- the measured number is INVALID", file=sys.stderr)

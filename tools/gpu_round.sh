@@ -1,0 +1,70 @@
+#!/bin/bash
+# ONE entry point for everything that runs ON THE GPU BOX (through gpurun), by sub-command; results go to gpurun_out/<tag>_*.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh tests r04_v1'
+#
+#   tests   <tag>          pytest -m gpu (whole suite) + smoke()
+#   quick   <tag> <expr>   pytest -m gpu -k <expr>
+#   bench   <tag> [wl]     the driver's command line (default line incl. `secondary`, cpu_baseline, parity) [+ --workload wl]
+#   stages  <tag> [wl]     per-launch HIP-event table of one step (no baselines)
+#   ab      <tag> [wl]     same-box A/B: allegro_amd/liballegro_amd_old.so vs the product library, alternated 3 times
+#   profile <tag> [wl]     rocprofv3 --kernel-trace --stats, then separate --pmc passes, summary + hashed traffic JSON
+#   hosts   <tag>          the Python-free hosts (tests/host): C99 driver and C++ AOTInductor package consumer
+#   ubench  <tag> <name>   tools/ubench/<name>.bin (hipcc -o it on the build box first: it travels with the snapshot)
+#   shards  <tag> [W]      every rank's compact shard of a W-way partition of C4, one after the other (load balance)
+#   final   <tag>          tests + bench (c4, c5, c3, c2, c1) + stages + shards + profile c4 / c5: the end-of-round evidence
+cd "$(dirname "$0")/.."
+CMD=${1:-tests}; TAG=${2:-r04}; ARG=${3:-}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+case $CMD in
+  tests)
+    timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/${TAG}_pytest_gpu.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1
+    tail -4 gpurun_out/${TAG}_pytest_gpu.log; tail -1 gpurun_out/${TAG}_smoke.log ;;
+  quick)
+    timeout 1500 python -m pytest tests -m gpu -q -x -k "$ARG" 2>&1 | tail -25 | tee gpurun_out/${TAG}_pytest_quick.log ;;
+  bench)
+    WL=${ARG:-c4}
+    timeout 1200 python bench.py --workload $WL --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_$WL.log 2> gpurun_out/${TAG}_bench_$WL.err
+    python tools/bench_brief.py gpurun_out/${TAG}_bench_$WL.log ;;
+  stages)
+    WL=${ARG:-c4}
+    timeout 900 python bench.py --workload $WL --steps 20 --warmup 5 --stages --no-cpu-baseline --no-gpu-reference --no-secondary --sustain 0 \
+      > gpurun_out/${TAG}_stagesline_$WL.log 2> gpurun_out/${TAG}_stages_$WL.log
+    grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_stagesline_$WL.log | head -1; grep '^\[stage\]' gpurun_out/${TAG}_stages_$WL.log ;;
+  ab)
+    WL=${ARG:-c4}
+    for rep in 1 2 3; do for lib in old new; do
+      if [ $lib = old ]; then export ALLEGRO_AMD_LIBRARY=$PWD/allegro_amd/liballegro_amd_old.so; else unset ALLEGRO_AMD_LIBRARY; fi
+      r=$(timeout 600 python bench.py --workload $WL --steps 20 --warmup 5 --stages --no-cpu-baseline --no-gpu-reference --no-secondary --sustain 0 2> gpurun_out/${TAG}_ab_$lib.log | grep -o '"ms_per_step": [0-9.]*' | head -1)
+      echo "$lib $r | $(grep '^\[stage\]' gpurun_out/${TAG}_ab_$lib.log | awk '{printf "%s %s  ", $2, $3}')"
+    done; done | tee gpurun_out/${TAG}_ab_$WL.txt ;;
+  profile)
+    WL=${ARG:-c4}
+    bash tools/profile_gpu.sh $WL $TAG > /dev/null 2>&1
+    cp gpurun_out/prof_${TAG}_$WL/summary.txt gpurun_out/${TAG}_rocprofv3_${WL}_summary.txt
+    python tools/pmc_to_json.py gpurun_out/${TAG}_rocprofv3_${WL}_summary.txt $WL > gpurun_out/${TAG}_pmc_traffic_$WL.json 2> gpurun_out/${TAG}_pmc_to_json.err
+    rm -rf gpurun_out/prof_${TAG}_$WL/trace gpurun_out/prof_${TAG}_$WL/pmc_*
+    tail -30 gpurun_out/${TAG}_rocprofv3_${WL}_summary.txt ;;
+  hosts)
+    timeout 1500 python -m pytest tests/test_host_programs.py tests/test_pair_allegro.py -m gpu -q -x -s 2>&1 | grep -E 'host_|passed|failed|Error' | tee gpurun_out/${TAG}_hosts.log ;;
+  ubench)
+    timeout 300 tools/ubench/$ARG.bin > gpurun_out/${TAG}_ubench_$ARG.log 2>&1; cat gpurun_out/${TAG}_ubench_$ARG.log ;;
+  shards)
+    W=${ARG:-8}
+    timeout 900 python bench.py --shard-sweep $W --steps 10 --warmup 3 > gpurun_out/${TAG}_shard_sweep${W}_c4.json 2> /dev/null
+    python -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_shard_sweep${W}_c4.json')); print({k: d[k] for k in ('max_ms','mean_ms','imbalance_max_over_mean')})" ;;
+  final)
+    bash $0 tests $TAG
+    bash $0 bench $TAG c4
+    for wl in c5 c3 c2 c1; do
+      timeout 900 python bench.py --workload $wl --steps $([ $wl = c5 ] && echo 5 || echo 100) --warmup 5 --stages --no-secondary --sustain 0 \
+        > gpurun_out/${TAG}_bench_$wl.log 2> gpurun_out/${TAG}_stages_$wl.log
+      echo "$wl $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_bench_$wl.log | head -1)"
+    done
+    bash $0 stages $TAG c4
+    bash $0 shards $TAG 8
+    bash $0 profile $TAG c4
+    bash $0 profile $TAG c5 ;;
+  *) echo "unknown sub-command $CMD"; exit 2 ;;
+esac

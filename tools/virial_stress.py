@@ -7,7 +7,7 @@ under conditions that make a read-before-write or a missing ordering determinist
   * the Python model runs with aa_plan_options.poison_workspace (AA_POISON=1: the library NaN-fills the workspace before
     every step) through the default (fused) and the staged forward;
   * calls alternate between two HIP streams with unrelated work in flight on the other one;
-  * run it again under AMD_SERIALIZE_KERNEL=3 (tools/gpu_round3_a.sh does) to separate ordering from data problems.
+  * run it again under AMD_SERIALIZE_KERNEL=3 (`AMD_SERIALIZE_KERNEL=3 python tools/virial_stress.py 100`) to separate ordering from data problems.
 
     python tools/virial_stress.py [iterations]      ->  one line per fixture, exit code 1 on any mismatch"""
 import os
