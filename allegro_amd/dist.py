@@ -8,7 +8,12 @@ neighbor ("ghost") atoms owned by other ranks receive contributions: one all-red
 when the backend is "nccl") of the [N,3] force array per step.  The reference has no collective at all
 (SURVEY.md §2.3); its external analogue is LAMMPS reverse communication in pair_allegro.
 
-Two layouts of a rank's share: `LocalShard` (compact local numbering: owned block + ghost atoms, everything the
+`HaloShard` + `energy_forces_halo` (below, round 4) are the sharded-integrator form of the same decomposition -- what LAMMPS
+itself does around pair_allegro: every rank keeps only ITS atoms' positions, ghost positions arrive by forward
+communication and ghost forces leave by reverse communication (two `all_to_all_single` of the ghost rows only, sizes fixed
+per neighbour list), energies stay local; nothing O(N) exists on a rank.  `bench.py --gpus N` times that path.
+
+Two earlier layouts of a rank's share: `LocalShard` (compact local numbering: owned block + ghost atoms, everything the
 rank holds is O(local); what bench.py --gpus N runs) and `local_graph` (global numbering with the owned-range hint;
 kept for callers that already hold global-size arrays).
 """
@@ -139,3 +144,186 @@ def energy_forces_sharded(model, pos: torch.Tensor, graph: PreparedGraph, owned:
         dist.all_reduce(forces, group=group)
         dist.all_reduce(e_own, group=group)
     return e_own, forces
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Halo exchange: forward / reverse communication of ghost rows only (round 4)
+# ----------------------------------------------------------------------------------------------------------------------
+class HaloShard:
+    """One rank's share of a frame for a SHARDED integrator: the rank holds the positions of its owned atoms only.
+
+      atoms      numbered globally in a slab order (sorted along one lattice direction; `order` maps them back to the
+                 caller's numbering); rank r owns the contiguous block [cuts[r], cuts[r+1]);
+      local set  = owned block (local ids 0 .. n_own-1) + ghost atoms (every neighbour of an owned atom that another rank
+                 owns, sorted by global id -- hence grouped by owner rank, in rank order);
+      plan       recv_counts[p]: ghosts owned by rank p (rows this rank RECEIVES positions for and SENDS forces of);
+                 send_counts[p] / send_idx: owned atoms that rank p holds as ghosts (rows this rank sends positions of and
+                 receives forces for) -- exchanged ONCE when the shard is built (one all_to_all of the counts, one of the ids).
+
+    Per step (`energy_forces_halo`): forward communication of ghost positions, the whole hot path on the local arrays,
+    reverse communication of ghost forces -- each ONE `all_to_all_single` of ghost rows (12 B per row; C4 at 8 ranks:
+    ~6 700 ghosts = 80 KB per rank instead of the 1.56 MB all-reduce of `LocalShard`) -- and a fixed-order accumulation into
+    the owned rows (bit-reproducible).  Energies of the owned atoms stay on the rank.  This mirrors what LAMMPS does around
+    `pair_allegro` (ghost layout allegro/_compile.py:28-63; `comm->forward_comm()` / `reverse_comm()`, README.md:45)."""
+
+    def __init__(self, rank, world, cuts, local_gids, edge_index_local, types_local, shift_vec, device, dtype, order=None, group=None,
+                 connect: bool = True):
+        """`connect=False` (analysis on one GPU: `bench.py --emulate-shard / --shard-sweep`): the shard of rank `rank` of `world`
+        without a process group -- no plan is exchanged and `energy_forces_halo` skips both communications (the caller fills the
+        ghost positions once with `fill_local_positions`)."""
+        import torch.distributed as dist
+
+        self.rank, self.world, self.cuts, self.group = int(rank), int(world), [int(c) for c in cuts], group
+        self.a0, self.a1 = self.cuts[rank], self.cuts[rank + 1]
+        self.n_own = self.a1 - self.a0
+        local_gids = torch.as_tensor(local_gids, dtype=torch.int64)
+        self.n_ghost = int(local_gids.numel()) - self.n_own
+        self.order = order  # slab order -> caller's atom ids (None: identity)
+        self.local_gids = local_gids.to(device)
+        ghosts = local_gids[self.n_own:].cpu()
+        assert bool((ghosts[1:] > ghosts[:-1]).all()) if ghosts.numel() > 1 else True, "ghosts must be sorted by global id"
+        owner = torch.searchsorted(torch.tensor(self.cuts[1:], dtype=torch.int64), ghosts, right=True)
+        self.recv_counts = torch.bincount(owner, minlength=world).tolist()
+        assert self.recv_counts[rank] == 0
+        # tell every owner which of its atoms this rank needs (setup-time collectives)
+        self.connected = bool(connect) and world > 1
+        if self.connected:
+            assert dist.is_initialized(), "HaloShard with world > 1 needs an initialised process group"
+            cnt_in = torch.tensor(self.recv_counts, dtype=torch.int64, device=device)
+            cnt_out = torch.empty(world, dtype=torch.int64, device=device)
+            dist.all_to_all_single(cnt_out, cnt_in, group=group)
+            self.send_counts = cnt_out.tolist()
+            ids_out = torch.empty(int(sum(self.send_counts)), dtype=torch.int64, device=device)
+            dist.all_to_all_single(ids_out, self.local_gids[self.n_own:].contiguous(), self.send_counts, self.recv_counts, group=group)
+            self.send_idx = ids_out - self.a0
+            assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_own)
+        else:
+            self.send_counts = [0] * world
+            self.send_idx = torch.empty(0, dtype=torch.int64, device=device)
+        # fixed-order accumulation of the received force rows: for every owned atom that is somebody's ghost the (few) rows of
+        # the receive buffer that belong to it, padded to the largest multiplicity with a row of zeros -- one gather + sum,
+        # no atomics, the same bits every run
+        ns = int(self.send_idx.numel())
+        if ns > 0:
+            srt, perm = torch.sort(self.send_idx, stable=True)
+            uniq, cnt = torch.unique_consecutive(srt, return_counts=True)
+            mult = int(cnt.max())
+            start = torch.cumsum(cnt, 0) - cnt
+            slot = torch.arange(ns, device=device) - torch.repeat_interleave(start, cnt)
+            rows = torch.full((uniq.numel(), mult), ns, dtype=torch.int64, device=device)  # ns = the zero row
+            rows[torch.repeat_interleave(torch.arange(uniq.numel(), device=device), cnt), slot] = perm
+            self._touched, self._rows = uniq, rows
+        else:
+            self._touched = self._rows = None
+        self.graph = PreparedGraph(edge_index_local.to(device), torch.as_tensor(types_local).to(device), self.n_own + self.n_ghost,
+                                   None if shift_vec is None else shift_vec.to(device=device, dtype=dtype))
+        self._bufs = None
+
+    # -- construction ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_graph(cls, edge_index: np.ndarray, types: np.ndarray, num_atoms: int, shift_vec: Optional[np.ndarray], rank: int,
+                   world: int, device, dtype, group=None, rowptr: Optional[np.ndarray] = None, connect: bool = True):
+        """From a full center-sorted edge list on the host (tests, small systems): blocks of equal edge count."""
+        if rowptr is None:
+            rowptr = np.zeros(num_atoms + 1, dtype=np.int64)
+            np.cumsum(np.bincount(edge_index[0], minlength=num_atoms), out=rowptr[1:])
+        cuts = partition_atoms(rowptr, world)
+        a0, a1 = cuts[rank], cuts[rank + 1]
+        e0, e1 = int(rowptr[a0]), int(rowptr[a1])
+        center, nbr = edge_index[0, e0:e1], edge_index[1, e0:e1]
+        ghosts = np.unique(nbr[(nbr < a0) | (nbr >= a1)])
+        local_gids = np.concatenate([np.arange(a0, a1), ghosts])
+        lookup = np.full(num_atoms, -1, dtype=np.int64)
+        lookup[local_gids] = np.arange(local_gids.size)
+        ei = torch.tensor(np.stack([center - a0, lookup[nbr]]))
+        sv = None if shift_vec is None else torch.tensor(shift_vec[e0:e1])
+        return cls(rank, world, cuts, local_gids, ei, types[local_gids], sv, device, dtype, group=group, connect=connect)
+
+    @classmethod
+    def from_positions(cls, pos_all: torch.Tensor, types_all: torch.Tensor, cell, r_cut: float, rank: int, world: int, group=None,
+                       axis: int = 0, lib=None, connect: bool = True):
+        """From the frame itself, O(local) work per rank: atoms are put in slab order along lattice direction `axis` (every
+        rank computes the same permutation), cut into `world` blocks of equal atom count, and THIS rank builds the neighbour
+        list only of its slab plus the halo within r_cut of it (device cell list, `allegro_amd.nn.neighbor_list`) -- no rank
+        ever holds the full edge list.  `pos_all` [N,3] (device, model dtype; the one O(N) array, as an MD code has it at
+        start-up), full periodic `cell` (3x3, rows)."""
+        from .nn import neighbor_list
+
+        dev, dtype = pos_all.device, pos_all.dtype
+        N = pos_all.shape[0]
+        cell_t = torch.as_tensor(cell, dtype=torch.float64)
+        frac = torch.linalg.solve(cell_t.T.to(dev), pos_all.double().T).T  # pos = frac @ cell
+        fx = frac[:, axis] - torch.floor(frac[:, axis])
+        order = torch.argsort(fx, stable=True)
+        cuts = [(N * r) // world for r in range(world + 1)]
+        a0, a1 = cuts[rank], cuts[rank + 1]
+        own = order[a0:a1]
+        # halo candidates: within r_cut of the slab along the axis (periodic); the slab's extent from its own atoms
+        height = float(torch.linalg.det(cell_t).abs() / torch.linalg.norm(torch.linalg.cross(cell_t[(axis + 1) % 3], cell_t[(axis + 2) % 3])))
+        margin = 1.02 * float(r_cut) / height
+        lo, hi = float(fx[own].min()), float(fx[own].max())
+        d_lo = torch.remainder(lo - fx, 1.0)   # distance below the slab (periodic)
+        d_hi = torch.remainder(fx - hi, 1.0)   # distance above
+        inside = torch.zeros(N, dtype=torch.bool, device=dev)
+        inside[own] = True
+        cand = (~inside) & ((d_lo < margin) | (d_hi < margin) | ((fx >= lo) & (fx <= hi)))
+        halo = torch.nonzero(cand).reshape(-1)
+        sub = torch.cat([own, halo])
+        nl = neighbor_list(pos_all.index_select(0, sub).contiguous(), cell_t, True, r_cut, lib=lib)
+        n_own = int(own.numel())
+        e_own = int(nl.rowptr[n_own])  # edges are sorted by center: the owned centers' edges are a prefix
+        c_loc = nl.edge_index[0, :e_own].long()
+        n_sub = nl.edge_index[1, :e_own].long()
+        # global (slab-order) id of every atom of the subset
+        rank_of = torch.empty(N, dtype=torch.int64, device=dev)
+        rank_of[order] = torch.arange(N, device=dev)
+        gid_sub = rank_of[sub]
+        is_ghost = n_sub >= n_own
+        ghosts = torch.unique(gid_sub[n_sub[is_ghost]])  # sorted
+        local_gids = torch.cat([torch.arange(a0, a1, device=dev), ghosts])
+        lookup = torch.full((N,), -1, dtype=torch.int64, device=dev)
+        lookup[local_gids] = torch.arange(local_gids.numel(), device=dev)
+        ei = torch.stack([c_loc, lookup[gid_sub[n_sub]]])
+        types_local = types_all.to(dev)[order[local_gids]]
+        return cls(rank, world, cuts, local_gids.cpu(), ei, types_local, nl.shift_vec[:e_own], dev, dtype, order=order, group=group,
+                   connect=connect)
+
+    def fill_local_positions(self, pos_all: torch.Tensor):
+        """Owned + ghost positions straight from a full position array in the CALLER's numbering (start-up, or `connect=False`)."""
+        gids = self.local_gids if self.order is None else self.order[self.local_gids]
+        pos_loc = self._buffers(pos_all.dtype, pos_all.device)[0]
+        torch.index_select(pos_all, 0, gids, out=pos_loc)
+        return pos_loc
+
+    # -- step --------------------------------------------------------------------------------------------------------
+    def _buffers(self, dtype, device):
+        if self._bufs is None or self._bufs[0].dtype != dtype:
+            ns = int(self.send_idx.numel())
+            self._bufs = (torch.empty((self.n_own + self.n_ghost, 3), dtype=dtype, device=device),  # local positions
+                          torch.empty((ns, 3), dtype=dtype, device=device),                            # rows sent forward
+                          torch.zeros((ns + 1, 3), dtype=dtype, device=device))                        # rows received in reverse (+ zero row)
+        return self._bufs
+
+
+def energy_forces_halo(model, pos_own: torch.Tensor, shard: HaloShard):
+    """One step of a sharded MD code on this rank: forward communication (ghost positions), the hot path on the compact local
+    arrays, reverse communication (ghost forces).  `pos_own` [n_own,3]: the positions of the rank's OWN atoms (slab order).
+    Returns (E_i [n_own], forces [n_own,3]) of the owned atoms, complete (every contribution of every rank included).
+    Collectives per step: two `all_to_all_single` (RCCL over xGMI with backend "nccl"), ghost rows only; none with one rank."""
+    import torch.distributed as dist
+
+    pos_loc, send_f, recv_r = shard._buffers(pos_own.dtype, pos_own.device)
+    n_own = shard.n_own
+    pos_loc[:n_own] = pos_own
+    multi = shard.connected
+    if multi:
+        torch.index_select(pos_own, 0, shard.send_idx, out=send_f)
+        dist.all_to_all_single(pos_loc[n_own:], send_f, shard.recv_counts, shard.send_counts, group=shard.group)
+    e_loc, f_loc = model.energy_forces(pos_loc, shard.graph)
+    f_own = f_loc[:n_own]
+    if multi:
+        ns = recv_r.shape[0] - 1
+        dist.all_to_all_single(recv_r[:ns], f_loc[n_own:].contiguous(), shard.send_counts, shard.recv_counts, group=shard.group)
+        if shard._rows is not None:  # (touched ids are unique: one add per row, fixed order inside the gathered sum)
+            f_own.index_add_(0, shard._touched, recv_r[shard._rows].sum(1))
+    return e_loc[:n_own], f_own

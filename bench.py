@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from allegro_amd import graph as G  # noqa: E402
-from allegro_amd.dist import LocalShard, energy_forces_local  # noqa: E402
+from allegro_amd.dist import HaloShard, LocalShard, energy_forces_halo, energy_forces_local  # noqa: E402
 from allegro_amd.nn import HipAllegroModel, PreparedGraph  # noqa: E402
 
 BESSEL = {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8, "polynomial_cutoff_p": 6}
@@ -558,6 +558,9 @@ def main():
     ap.add_argument("--shard-sweep", type=int, default=0, metavar="W",
                     help="analysis only: time every rank's compact shard of a W-way partition on this one GPU, one after "
                          "the other (load balance: max / mean shard time; no collective), print one JSON line and exit")
+    ap.add_argument("--dist-mode", default="halo", choices=["halo", "allreduce"],
+                    help="N > 1: halo = sharded positions, forward / reverse communication of ghost rows (two all_to_all_single per step; every "
+                         "rank builds only its slab's neighbour list); allreduce = replicated positions, one all-reduce of F[N,3] (the round-3 path)")
     ap.add_argument("--mode", default="step", choices=["step", "train-op", "train-step"],
                     help="step: the whole hot path (default, the driver's contract); train-op: training step of the operator seam; "
                          "train-step: optimisation step of the whole model in training mode")
@@ -588,54 +591,124 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    g, cfg = make_workload(args.workload)
-    dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
-    model = HipAllegroModel(**cfg).to(dev)
-    N, E, L = g.num_atoms, g.num_edges, cfg["num_layers"]
-    rowptr = G.csr_from_sorted_centers(g.edge_index[0], N)
-    sv = g.shift_vec()
-    pos = torch.tensor(g.pos, dtype=dtype, device=dev)
-    types = torch.tensor(g.types, device=dev)
-    if args.shard_sweep:
-        # every rank's compact shard (owned block + ghost atoms, allegro_amd/dist.py) timed on this GPU, one at a time
-        W = args.shard_sweep
-        rows = []
-        for r in range(W):
-            sh = LocalShard(g.edge_index, g.types, N, sv, r, W, dev, dtype, rowptr)
-            for _ in range(args.warmup):
-                sh.step(model, pos)
-            reps = []
-            for _ in range(3):  # median of 3 timed batches: one-off hiccups (allocator, clocks) are not load imbalance
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(args.steps):
-                    sh.step(model, pos)
-                torch.cuda.synchronize()
-                reps.append((time.perf_counter() - t0) / args.steps * 1e3)
-            rows.append(dict(rank=r, owned=sh.n_own, ghosts=sh.n_ghost, edges=sh.graph.num_edges, ms=sorted(reps)[1]))
-            del sh
-        ms = [x["ms"] for x in rows]
-        print(json.dumps({"shard_sweep": W, "workload": args.workload, "atoms": N, "edges": E, "shards": rows,
-                          "max_ms": max(ms), "mean_ms": sum(ms) / W, "imbalance_max_over_mean": max(ms) / (sum(ms) / W),
-                          "note": "one GPU, shards run one after the other, no collective: an upper bound of the per-rank "
-                                  "compute time of a W-GPU run, NOT a multi-GPU measurement"}), flush=True)
-        return
+    halo = (world > 1 or args.emulate_shard or args.shard_sweep) and args.dist_mode == "halo" and WORKLOADS[args.workload]["kind"] == "si"
     shard = None
-    a0, a1 = 0, N
-    if world > 1 or args.emulate_shard:
+    if halo:
+        # no rank ever holds the full edge list: positions of the box (the one O(N) array, 1.2 MB at C4) -> slab order -> this
+        # rank's slab + halo -> device cell list of that subset only (allegro_amd/dist.py: HaloShard.from_positions)
+        w = WORKLOADS[args.workload]
+        rcut = float(os.environ.get("AA_BENCH_RCUT", "5.0"))
+        pos_np, cell_np = G.diamond_si(int(os.environ.get("AA_BENCH_CELLS", w["cells"])))
+        N = pos_np.shape[0]
+        cfg = si_model_cfg(28.0)  # (avg_num_neighbors: set from the measured edge count below, as make_workload does)
+        cfg["r_max"], cfg["l_max"] = rcut, w.get("l_max", cfg["l_max"])
+        cfg["num_tensor_features"] = w.get("u", cfg["num_tensor_features"])
+        cfg["model_dtype"] = w["dtype"]
+        dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
+        pos = torch.tensor(pos_np, dtype=dtype, device=dev)
+        types = torch.zeros(N, dtype=torch.int64, device=dev)
+        L = cfg["num_layers"]
+
+        def make_shard(r, wsize, connect):
+            return HaloShard.from_positions(pos, types, cell_np, rcut, r, wsize, connect=connect)
+
+        if args.shard_sweep:
+            W = args.shard_sweep
+            rows, E = [], 0
+            model = None
+            for r in range(W):
+                sh = make_shard(r, W, False)
+                if model is None:
+                    cfg["avg_num_neighbors"] = 28.0 if rcut == 5.0 else sh.graph.num_edges / max(sh.n_own, 1)
+                    model = HipAllegroModel(**cfg).to(dev)
+                pl = sh.fill_local_positions(pos)
+                for _ in range(args.warmup):
+                    model.energy_forces(pl, sh.graph)
+                reps = []
+                for _ in range(3):  # median of 3 timed batches: one-off hiccups (allocator, clocks) are not load imbalance
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        model.energy_forces(pl, sh.graph)
+                    torch.cuda.synchronize()
+                    reps.append((time.perf_counter() - t0) / args.steps * 1e3)
+                rows.append(dict(rank=r, owned=sh.n_own, ghosts=sh.n_ghost, edges=sh.graph.num_edges, ms=sorted(reps)[1], ms_all=reps))
+                E += sh.graph.num_edges
+                del sh
+            ms = [x["ms"] for x in rows]
+            print(json.dumps({"shard_sweep": W, "workload": args.workload, "atoms": N, "edges": E, "shards": rows,
+                              "max_ms": max(ms), "mean_ms": sum(ms) / W, "imbalance_max_over_mean": max(ms) / (sum(ms) / W),
+                              "note": "one GPU, shards (slab + halo, each built from positions alone) run one after the other, no "
+                                      "communication: an upper bound of the per-rank compute time of a W-GPU run, NOT a multi-GPU measurement"}),
+                  flush=True)
+            return
         er, ew = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
-        # this rank's compact share: owned atom block + ghost atoms in local numbering (O(local) graph / workspace)
-        shard = LocalShard(g.edge_index, g.types, N, sv, er, ew, dev, dtype, rowptr)
-        a0, a1 = shard.a0, shard.a1
+        shard = make_shard(er, ew, not args.emulate_shard)
+        e_loc = torch.tensor([shard.graph.num_edges], dtype=torch.int64, device=dev)
+        if dist is not None:
+            dist.all_reduce(e_loc)
+        E = int(e_loc.item()) if dist is not None else shard.graph.num_edges * ew  # (emulated shard: analysis only)
+        cfg["avg_num_neighbors"] = E / N
+        model = HipAllegroModel(**cfg).to(dev)
         graph = shard.graph
+        pos_local = shard.fill_local_positions(pos)
+        pos_own = pos_local[: shard.n_own].clone()
+        a0, a1 = shard.a0, shard.a1
+        e0, e1 = 0, shard.graph.num_edges
+        g = None
+        del pos
     else:
-        graph = PreparedGraph(torch.tensor(g.edge_index, device=dev), types, N,
-                              torch.tensor(sv, dtype=dtype, device=dev) if sv is not None else None)
-    e0, e1 = int(rowptr[a0]), int(rowptr[a1])
+        g, cfg = make_workload(args.workload)
+        dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
+        model = HipAllegroModel(**cfg).to(dev)
+        N, E, L = g.num_atoms, g.num_edges, cfg["num_layers"]
+        rowptr = G.csr_from_sorted_centers(g.edge_index[0], N)
+        sv = g.shift_vec()
+        pos = torch.tensor(g.pos, dtype=dtype, device=dev)
+        types = torch.tensor(g.types, device=dev)
+        if args.shard_sweep:
+            # every rank's compact shard (owned block + ghost atoms, allegro_amd/dist.py) timed on this GPU, one at a time
+            W = args.shard_sweep
+            rows = []
+            for r in range(W):
+                sh = LocalShard(g.edge_index, g.types, N, sv, r, W, dev, dtype, rowptr)
+                for _ in range(args.warmup):
+                    sh.step(model, pos)
+                reps = []
+                for _ in range(3):  # median of 3 timed batches: one-off hiccups (allocator, clocks) are not load imbalance
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        sh.step(model, pos)
+                    torch.cuda.synchronize()
+                    reps.append((time.perf_counter() - t0) / args.steps * 1e3)
+                rows.append(dict(rank=r, owned=sh.n_own, ghosts=sh.n_ghost, edges=sh.graph.num_edges, ms=sorted(reps)[1]))
+                del sh
+            ms = [x["ms"] for x in rows]
+            print(json.dumps({"shard_sweep": W, "workload": args.workload, "atoms": N, "edges": E, "shards": rows,
+                              "max_ms": max(ms), "mean_ms": sum(ms) / W, "imbalance_max_over_mean": max(ms) / (sum(ms) / W),
+                              "note": "one GPU, shards run one after the other, no collective: an upper bound of the per-rank "
+                                      "compute time of a W-GPU run, NOT a multi-GPU measurement"}), flush=True)
+            return
+        a0, a1 = 0, N
+        if world > 1 or args.emulate_shard:
+            er, ew = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
+            # this rank's compact share: owned atom block + ghost atoms in local numbering (O(local) graph / workspace)
+            shard = LocalShard(g.edge_index, g.types, N, sv, er, ew, dev, dtype, rowptr)
+            a0, a1 = shard.a0, shard.a1
+            graph = shard.graph
+        else:
+            graph = PreparedGraph(torch.tensor(g.edge_index, device=dev), types, N,
+                                  torch.tensor(sv, dtype=dtype, device=dev) if sv is not None else None)
+        e0, e1 = int(rowptr[a0]), int(rowptr[a1])
 
     def step():
         if shard is None:
             return model.energy_forces(pos, graph)
+        if halo:
+            # sharded positions: forward communication of ghost positions, the hot path on the compact shard, reverse
+            # communication of ghost forces (two all_to_all_single of ghost rows; allegro_amd/dist.py) -- what the gloo tests drive
+            return energy_forces_halo(model, pos_own, shard)
         # compact shard + THE collective of the step (one RCCL all-reduce over xGMI carrying ghost-atom force
         # contributions and owned-atom energies; allegro_amd/dist.py) -- the function the gloo tests drive
         return energy_forces_local(model, pos, shard)
@@ -687,14 +760,16 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "atoms": N, "edges": E,
                        "edges_per_s": E / t_step, "ns_per_day_at_1fs": 0.0864 / t_step,
-                       "parallelism": (f"atom-block x{world}: compact shards (owned block + ghost atoms), one all-reduce of F[N,3]"
-                                       if world > 1 else "single GPU"),
+                       "parallelism": ((f"atom-block x{world}: slab shards built from positions alone (owned block + ghost atoms), sharded positions, "
+                                        "forward + reverse communication of ghost rows (2 all_to_all_single per step)") if world > 1 and halo else
+                                       (f"atom-block x{world}: compact shards (owned block + ghost atoms), one all-reduce of F[N,3]"
+                                        if world > 1 else "single GPU")),
                        "weights": "random init (reference initialisers), seed 456"},
         }
         if sustained is not None:
             line["config"]["sustained"] = sustained
         if not args.no_profile:
-            stages = profile_stages(model, pos if shard is None else pos.index_select(0, shard.local_ids), graph)
+            stages = profile_stages(model, pos if shard is None else (pos_local if halo else pos.index_select(0, shard.local_ids)), graph)
             roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload)
             line["roofline"] = roof
             line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])
@@ -705,7 +780,7 @@ def main():
                 for nm, ms, nb, fl in stages:
                     print(f"[stage] {nm:24s} {ms * 1e3:9.1f} us {nb / max(ms, 1e-9) / 1e6:8.0f} GB/s (algorithmic)"
                           f"{fl / max(ms, 1e-9) / 1e9:8.1f} TFLOP/s", file=sys.stderr)
-        if world == 1 and g.cell is not None:
+        if world == 1 and g is not None and g.cell is not None:
             # reported separately, never part of `value`: the on-device cell-list build of the same graph
             from allegro_amd.nn import neighbor_list
 
@@ -729,12 +804,12 @@ def main():
             line["config"]["neighbor_list_device_ms"]["list"] = (time.perf_counter() - t1) * 1e3
             del nl_graph
         parity_failed = False
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and g is not None:
             # ~20 s of CPU work for the headline model; the l_max=3 fp64 stack is ~10x heavier per edge
             line["cpu_baseline"], line["parity_sample"] = cpu_baseline(g, cfg, model,
                                                                        target_edges=180000 if cfg["l_max"] <= 2 else 24000)
             parity_failed = not line["parity_sample"]["ok"]
-        if world == 1 and not args.no_gpu_reference and not args.emulate_shard:
+        if world == 1 and not args.no_gpu_reference and not args.emulate_shard and g is not None:
             line["gpu_reference_baseline"] = gpu_reference_baseline(g, cfg, model, dev,
                                                                     target_edges=60000 if cfg["l_max"] <= 2 else 12000)
             line["speedup_vs_gpu_reference"] = line["value"] / line["gpu_reference_baseline"]["value"]

@@ -82,7 +82,7 @@ def test_standard_layers_uncoupled_path_weights_emulated(l_max, L, layer, mul, d
 @pytest.mark.gpu
 @pytest.mark.parametrize("l_max,L,layer,mul,dtype,sorted_idxs", [
     (2, 2, 0, 64, torch.float32, True), (2, 2, 1, 64, torch.float64, False), (1, 2, 0, 128, torch.float64, False),
-    (2, 3, 1, 64, torch.float32, False), (3, 3, 1, 64, torch.float64, True), (1, 2, 1, 256, torch.float32, False)])
+    (2, 3, 1, 64, torch.float32, False), (3, 3, 1, 64, torch.float32, True), (1, 2, 1, 256, torch.float32, False)])
 def test_standard_layers_uncoupled_path_weights_on_gpu(l_max, L, layer, mul, dtype, sorted_idxs, monkeypatch):
     _standard_layer_case(l_max, L, layer, mul, dtype, None, torch.device("cuda:0"), sorted_idxs, monkeypatch, coupling=False)
 

@@ -38,8 +38,8 @@ def _build_aoti(out):
     t = os.path.dirname(torch.__file__)
     cmd = ["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
            "-I", os.path.join(t, "include"), "-I", os.path.join(t, "include", "torch", "csrc", "api", "include"), "-I", "/opt/rocm/include",
-           os.path.join(HOST_DIR, "host_aoti.cpp"), "-o", out, "-L", os.path.join(t, "lib"), "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip",
-           "-ltorch_hip", "-ldl", f"-Wl,-rpath,{os.path.join(t, 'lib')}"]
+           os.path.join(HOST_DIR, "host_aoti.cpp"), "-o", out, "-L", os.path.join(t, "lib"), "-Wl,--no-as-needed", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip",
+           "-ltorch_hip", "-Wl,--as-needed", "-ldl", f"-Wl,-rpath,{os.path.join(t, 'lib')}"]
     subprocess.run(cmd, check=True, capture_output=True)
     return out
 

@@ -22,7 +22,7 @@ case $CMD in
     timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1
     tail -4 gpurun_out/${TAG}_pytest_gpu.log; tail -1 gpurun_out/${TAG}_smoke.log ;;
   quick)
-    timeout 1500 python -m pytest tests -m gpu -q -x -k "$ARG" 2>&1 | tail -25 | tee gpurun_out/${TAG}_pytest_quick.log ;;
+    timeout 1500 python -m pytest tests -m gpu -q -k "$ARG" > gpurun_out/${TAG}_pytest_quick.log 2>&1; tail -25 gpurun_out/${TAG}_pytest_quick.log ;;
   bench)
     WL=${ARG:-c4}
     timeout 1200 python bench.py --workload $WL --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_$WL.log 2> gpurun_out/${TAG}_bench_$WL.err
@@ -47,7 +47,8 @@ case $CMD in
     rm -rf gpurun_out/prof_${TAG}_$WL/trace gpurun_out/prof_${TAG}_$WL/pmc_*
     tail -30 gpurun_out/${TAG}_rocprofv3_${WL}_summary.txt ;;
   hosts)
-    timeout 1500 python -m pytest tests/test_host_programs.py tests/test_pair_allegro.py -m gpu -q -x -s 2>&1 | grep -E 'host_|passed|failed|Error' | tee gpurun_out/${TAG}_hosts.log ;;
+    timeout 1500 python -m pytest tests/test_host_programs.py tests/test_pair_allegro.py -m gpu -q -s > gpurun_out/${TAG}_hosts_full.log 2>&1
+    grep -E 'host_|passed|failed|Error|error' gpurun_out/${TAG}_hosts_full.log | cut -c1-400 | tee gpurun_out/${TAG}_hosts.log ;;
   ubench)
     timeout 300 tools/ubench/$ARG.bin > gpurun_out/${TAG}_ubench_$ARG.log 2>&1; cat gpurun_out/${TAG}_ubench_$ARG.log ;;
   shards)
