@@ -624,6 +624,7 @@ struct FusedFwdArgs {
   float* atom_energy;  // [N]
   int32_t* status;     // nullable, host-visible: set to the offending degree when a segment exceeds what the max_degree hint promised
 };
+size_t fused_fwd_lds_bytes(int num_types, bool teams);  // dynamic LDS of the fused forward (aa_fused.hip); the CU has 160 KB
 // reverse tail (aa_fused_bwd.hip): layer-0 tensor product reverse + first-stage / scalar_embed_mlp reverse + edge reverse
 struct FusedTailArgs {
   int64_t N, atom0, atom_end;  // atoms [atom0, atom_end), one wave each; every one has <= 32 edges

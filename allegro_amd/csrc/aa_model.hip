@@ -1286,6 +1286,8 @@ struct Runner {
   // the whole forward in one launch (aa_fused.hip): every center atom's edge segment fits one 32-row MFMA tile
   bool use_fused_fwd(const aa_graph* g) const {
     if (!(sizeof(T) == 4 && p->fused_fwd && !p->taps && g->max_degree > 0 && g->max_degree <= kFusedMaxDegree)) return false;
+    // (three species + the team exchange area exceed the 160 KB of LDS: such graphs run the staged pipeline)
+    if (fused_fwd_lds_bytes(p->cfg.num_types, g->max_degree > 32) > size_t(160) * 1024) return false;
     if (g->max_degree <= 32) return true;  // one full-ish tile per atom: faster than the staged forward at every size
     // Team form (2 / 4 tiles per atom): a tile costs the same whether 32 or 12 of its rows carry an edge, so it pays where
     // the step is latency-bound (few tiles: one launch instead of seven) or the tiles are nearly full.  Measured on Si boxes

@@ -387,3 +387,31 @@ def test_stale_max_degree_hint_fails_loudly_emulated():
 @pytest.mark.gpu
 def test_stale_max_degree_hint_fails_loudly():
     _stale_hint_case(None, torch.device("cuda:0"))
+
+
+def _three_species_long_segments(lib, dev, monkeypatch):
+    """Three species AND segments of more than one tile: the 18-KB two-body table plus the team exchange area do not fit
+    the 160 KB of LDS, so such graphs must take the staged pipeline -- found in round 4: the plan used to select the team form
+    and the launch then failed with "LDS budget exceeded" instead of falling back."""
+    monkeypatch.delenv("AA_FUSED", raising=False)
+    pos, cell, ei, shift, _, degs = _mixed_degree_cluster(2.2, (2, 2, 1, 0))
+    types = np.random.default_rng(8).integers(0, 3, size=pos.shape[0])
+    cfg = _cfg(avg=float(np.mean(degs)), scale_shift=False)
+    cfg.update(type_names=["A", "B", "C"], per_type_energy_scales=[1.3, 0.6, 0.9], per_type_energy_shifts=[-2.0, 0.25, 1.0])
+    m = _vs_oracle64(cfg, pos, cell, ei, shift, types, lib, dev)
+    sv = torch.tensor(shift @ cell, dtype=torch.float32, device=dev)
+    g = m.prepare_graph(torch.tensor(ei).to(dev), torch.tensor(types).to(dev), pos.shape[0], sv)
+    assert 32 < g.max_degree <= 128
+    import bench
+
+    names = [s[0] for s in bench.profile_stages(m, torch.tensor(pos, dtype=torch.float32, device=dev), g, reps=1)]
+    assert "fused_fwd" not in names, names
+
+
+def test_three_species_with_long_segments_fall_back_to_the_staged_forward_emulated(monkeypatch):
+    _three_species_long_segments(emu_lib(), torch.device("cpu"), monkeypatch)
+
+
+@pytest.mark.gpu
+def test_three_species_with_long_segments_fall_back_to_the_staged_forward_on_gpu(monkeypatch):
+    _three_species_long_segments(None, torch.device("cuda:0"), monkeypatch)
