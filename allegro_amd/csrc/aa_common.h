@@ -586,6 +586,7 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream);
 // fused per-atom-tile kernels (aa_fused.hip): the whole forward of the standard 2-layer, 64-wide stack in ONE launch
 // ----------------------------------------------------------------------------------------------
 constexpr int kFusedMaxSteps = 56;
+constexpr int kFusedKeepDefault = 2;  // FusedFwdArgs::keep when aa_plan_options.fused_keep_split is 0
 constexpr int kFusedMaxDegree = 128;  // longest edge segment the fused forward takes: a team of four 32-edge tiles
 constexpr int kFusedTeamTilesSmall = 4096;  // up to this many tiles the team form is chosen regardless of how full the tiles are
 struct FusedFwdArgs {
@@ -622,6 +623,7 @@ struct FusedFwdArgs {
   float* fcat;     // [E,192] EDGE_FEATURES or nullptr
   float *x2s0, *x2s1;  // [N][D][64]
   float* atom_energy;  // [N]
+  int keep;            // split tile pairs held in registers by the one-tile w0-holding form: 0 none, 1 two-body scalars, 2 + lat0
   int32_t* status;     // nullable, host-visible: set to the offending degree when a segment exceeds what the max_degree hint promised
 };
 size_t fused_fwd_lds_bytes(int num_types, bool teams);  // dynamic LDS of the fused forward (aa_fused.hip); the CU has 160 KB

@@ -82,7 +82,11 @@ struct TileIn {
 // team exchange area behind the parked tiles: x2s partials [4 waves][D <= 16][64] + energy partials [4]
 constexpr int kTeamFloats = 4 * 16 * 64 + 4;
 
-template <class Sig0, class Sig1, bool HOLD, bool TEAMS>
+// KEEP: tile pairs that feed several later layers and are therefore split into their bf16 levels ONCE, where they are produced,
+// and held in registers as MFMA operands (48 registers per pair) instead of being parked raw in LDS and split again by every
+// layer that reads them: 0 none (LDS parking), 1 the two-body scalars (read by L3, L6, L8), 2 also lat0 (L6, L8).  The
+// one-tile, w0-holding instantiation has the registers to spare (366 of 512 before).
+template <class Sig0, class Sig1, bool HOLD, bool TEAMS, int KEEP = 0>
 __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs A) {
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   static_assert(Sig0::D1 == D && Sig0::DOUT == D && Sig1::D1 == D && Sig1::DOUT == 1, "standard 2-layer stack");
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     }
     v16f k0, k1, sc0, sc1;
     v16f w0t[HOLD ? 2 * R : 1];
+    XSplit tb[KEEP >= 1 ? 2 : 1], l0x[KEEP >= 2 ? 2 : 1];  // held split tiles (see KEEP)
     AA_TICK(2)
     // ---- L0: scalar_embed_mlp layer 0 (pre-activation kept for the reverse pass)
     fused_layer<S_L0, NS, 2, 2>(A, p,
@@ -344,8 +349,13 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                         [&](auto ntp, const v16f& a0, const v16f& a1) {
                                           constexpr int q = decltype(ntp)::value;
                                           if constexpr (q == 0) {
-                                            AA_PARK(0, a0);
-                                            AA_PARK(1, a1);
+                                            if constexpr (KEEP >= 1) {
+                                              xsplit_from_acc(a0, tb[0]);
+                                              xsplit_from_acc(a1, tb[1]);
+                                            } else {
+                                              AA_PARK(0, a0);
+                                              AA_PARK(1, a1);
+                                            }
                                             if (A.fcat) {
                                               tile_store_rows(sW, a0, A.fcat, row0, cnt, 192, lane);
                                               tile_store_rows(sW, a1, A.fcat + 32, row0, cnt, 192, lane);
@@ -365,9 +375,15 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     AA_TICK(6)
     // ---- L3: latent 0, hidden layer: [two-body | scal0] -> h (pre-activation stored), a1 = silu(h)
     fused_layer<S_L3, NS, 4, 2>(A, p,
-                                [&](auto kc) -> v16f {
+                                [&](auto kc) {
                                   constexpr int k = decltype(kc)::value;
-                                  if constexpr (k < 2) return AA_FETCH(k); else if constexpr (k == 2) return sc0; else return sc1;
+                                  if constexpr (k < 2) {
+                                    if constexpr (KEEP >= 1) return tb[k]; else return v16f(AA_FETCH(k));
+                                  } else if constexpr (k == 2) {
+                                    return sc0;
+                                  } else {
+                                    return sc1;
+                                  }
                                 },
                                 [&](auto, const v16f& a0, const v16f& a1) {
                                   tile_store_rows(sW, a0, A.lat_h0, row0, cnt, 64, lane);
@@ -398,8 +414,13 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     fused_layer<S_L4, NS, 2, 2>(A, p,
                                 [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
                                 [&](auto, const v16f& a0, const v16f& a1) {
-                                  AA_PARK(2, a0);
-                                  AA_PARK(3, a1);
+                                  if constexpr (KEEP >= 2) {
+                                    xsplit_from_acc(a0, l0x[0]);
+                                    xsplit_from_acc(a1, l0x[1]);
+                                  } else {
+                                    AA_PARK(2, a0);
+                                    AA_PARK(3, a1);
+                                  }
                                   if (A.fcat) {
                                     tile_store_rows(sW, a0, A.fcat + 64, row0, cnt, 192, lane);
                                     tile_store_rows(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
@@ -428,9 +449,17 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     AA_TICK(10)
     // ---- L6: latent 1, hidden layer: [two-body | lat0 | scal1]
     fused_layer<S_L6, NS, 6, 2>(A, p,
-                                [&](auto kc) -> v16f {
+                                [&](auto kc) {
                                   constexpr int k = decltype(kc)::value;
-                                  if constexpr (k < 4) return AA_FETCH(k); else if constexpr (k == 4) return sc0; else return sc1;
+                                  if constexpr (k < 2) {
+                                    if constexpr (KEEP >= 1) return tb[k]; else return v16f(AA_FETCH(k));
+                                  } else if constexpr (k < 4) {
+                                    if constexpr (KEEP >= 2) return l0x[k - 2]; else return v16f(AA_FETCH(k));
+                                  } else if constexpr (k == 4) {
+                                    return sc0;
+                                  } else {
+                                    return sc1;
+                                  }
                                 },
                                 [&](auto, const v16f& a0, const v16f& a1) {
                                   tile_store_rows(sW, a0, A.lat_h1, row0, cnt, 64, lane);
@@ -453,9 +482,17 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     AA_TICK(12)
     // ---- L8: edge readout hidden layer on [two-body | lat0 | lat1]; last linear layer + edge sum in the epilogue
     fused_layer<S_L8, NS, 6, 2>(A, p,
-                                [&](auto kc) -> v16f {
+                                [&](auto kc) {
                                   constexpr int k = decltype(kc)::value;
-                                  if constexpr (k < 4) return AA_FETCH(k); else if constexpr (k == 4) return k0; else return k1;
+                                  if constexpr (k < 2) {
+                                    if constexpr (KEEP >= 1) return tb[k]; else return v16f(AA_FETCH(k));
+                                  } else if constexpr (k < 4) {
+                                    if constexpr (KEEP >= 2) return l0x[k - 2]; else return v16f(AA_FETCH(k));
+                                  } else if constexpr (k == 4) {
+                                    return k0;
+                                  } else {
+                                    return k1;
+                                  }
                                 },
                                 [&](auto, const v16f& a0, const v16f& a1) {
                                   tile_store_rows(sW, a0, A.ro_h, row0, cnt, 64, lane);
@@ -560,8 +597,18 @@ int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t 
     AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));              \
     hipLaunchKernelGGL((fused_fwd_kernel<cg::S0_, cg::S1_, H_, T_>), grid, dim3(256), smem, stream, a);        \
   }
-#define AA_FUSED_LAUNCH(S0_, S1_, H_) \
-  if (teams) AA_FUSED_LAUNCH1(S0_, S1_, H_, true) else AA_FUSED_LAUNCH1(S0_, S1_, H_, false)
+#define AA_FUSED_LAUNCHK(S0_, S1_, K_)                                                                          \
+  {                                                                                                            \
+    const void* fn = (const void*)fused_fwd_kernel<cg::S0_, cg::S1_, true, false, K_>;                         \
+    AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));              \
+    hipLaunchKernelGGL((fused_fwd_kernel<cg::S0_, cg::S1_, true, false, K_>), grid, dim3(256), smem, stream, a); \
+  }
+  // (the one-tile, w0-holding form keeps split tile pairs in registers: a.keep, see the kernel's KEEP)
+#define AA_FUSED_LAUNCH(S0_, S1_, H_)                                                                            \
+  if (teams) AA_FUSED_LAUNCH1(S0_, S1_, H_, true)                                                                \
+  else if (H_ && a.keep == 1) AA_FUSED_LAUNCHK(S0_, S1_, 1)                                                      \
+  else if (H_ && a.keep == 2) AA_FUSED_LAUNCHK(S0_, S1_, 2)                                                      \
+  else AA_FUSED_LAUNCH1(S0_, S1_, H_, false)
   if (pair == 0) {
     if (hold_w0) AA_FUSED_LAUNCH(Sig1, Sig0, true) else AA_FUSED_LAUNCH(Sig1, Sig0, false)
   } else if (pair == 1) {
@@ -570,6 +617,7 @@ int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t 
     return fail(AA_ERR_INVALID, "fused forward: unsupported signature pair");
   }
 #undef AA_FUSED_LAUNCH
+#undef AA_FUSED_LAUNCHK
 #undef AA_FUSED_LAUNCH1
   AA_CHECK_HIP(hipGetLastError());
 #ifdef AA_FUSED_TIMING

@@ -127,6 +127,11 @@ __device__ __forceinline__ void fused_mma_step(const u32x4* wb, int lane, const 
 // (op(kc) -> the v16f tile that is chunk kc), NT output tiles in pairs (epi(pair, acc0, acc1) after each pair).
 // Operand splits are software-pipelined: chunk kc + 1 is split while the MFMAs of chunk kc execute (layers with few
 // chunks and several pairs split all chunks once up front).
+// an operand chunk is either a tile in accumulator layout (split here) or an XSplit that was split when it was produced
+// (tiles that feed several layers -- the two-body scalars, lat0 -- are split ONCE and held)
+__device__ __forceinline__ void to_xsplit(const v16f& t, XSplit& x) { xsplit_from_acc(t, x); }
+__device__ __forceinline__ void to_xsplit(const XSplit& t, XSplit& x) { x = t; }
+
 template <int S0, int NS, int KC, int NT, class Args, class OpF, class EpiF>
 __device__ __forceinline__ void fused_layer(const Args& A, FusedPipe& p, OpF&& op, EpiF&& epi) {
   static_assert(NT % 2 == 0, "output tiles come in pairs");
@@ -134,13 +139,9 @@ __device__ __forceinline__ void fused_layer(const Args& A, FusedPipe& p, OpF&& o
   constexpr bool PIPE = true;
   XSplit xs[PRE ? KC : 2];
   if constexpr (PRE) {
-    static_for<0, KC>([&](auto kc) {
-      const v16f t = op(kc);
-      xsplit_from_acc(t, xs[kc]);
-    });
+    static_for<0, KC>([&](auto kc) { to_xsplit(op(kc), xs[kc]); });
   } else if constexpr (PIPE) {
-    const v16f t = op(std::integral_constant<int, 0>{});
-    xsplit_from_acc(t, xs[0]);
+    to_xsplit(op(std::integral_constant<int, 0>{}), xs[0]);
   }
   static_for<0, NT / 2>([&](auto ntp) {
     v16f acc0, acc1;
@@ -153,14 +154,12 @@ __device__ __forceinline__ void fused_layer(const Args& A, FusedPipe& p, OpF&& o
       constexpr int kc = decltype(kcc)::value;
       constexpr int S = S0 + decltype(ntp)::value * KC + kc;
       pipe_issue<S, NS>(A, p);
-      if constexpr (!PRE && !PIPE) {
-        const v16f t = op(kcc);
-        xsplit_from_acc(t, xs[kc & 1]);
-      }
+      if constexpr (!PRE && !PIPE) to_xsplit(op(kcc), xs[kc & 1]);
       fused_mma_step(p.wbuf + (S & 1) * kWStep, p.lane, xs[PRE ? kc : (kc & 1)], acc0, acc1);
       if constexpr (!PRE && PIPE && kc + 1 < KC) {
-        const v16f t = op(std::integral_constant<int, kc + 1>{});
-        xsplit_from_acc(t, xs[(kc + 1) & 1]);
+        to_xsplit(op(std::integral_constant<int, kc + 1>{}), xs[(kc + 1) & 1]);
+        // (measured, round 4: asking the scheduler to interleave this split with the step's MFMAs -- sched_group_barrier
+        //  "1 MFMA, 4 VALU" x 24 -- does produce that pattern in the ISA and is 1 % SLOWER on MI355X; left to the compiler)
       }
       pipe_commit<S>(p);
     });

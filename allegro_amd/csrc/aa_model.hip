@@ -1474,6 +1474,7 @@ struct Runner {
     a.x2s1 = bf(w.x2s[1]);
     a.atom_energy = static_cast<float*>(atom_energy);
     a.status = p->status;
+    a.keep = p->opt.fused_keep_split == 0 ? kFusedKeepDefault : p->opt.fused_keep_split - 1;
     if (int rc = mark("begin")) return rc;
     if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
     // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;

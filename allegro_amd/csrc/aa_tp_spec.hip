@@ -753,32 +753,86 @@ __device__ __forceinline__ void mom_project(const T* sM, int ka, int ka_lds, con
 }
 
 // GM[j] (k = kb + lane) = sum_ch g[j][ch] * Wt[r(j)][ch][k]   (g already carries the scatter factor)
+// Instruction-issue-bound (a fifth of the reverse kernels' vector instructions): the components of one irrep share their weight,
+// so they are accumulated two per instruction (v_pk_fma_f32: the g pair comes from LDS as an aligned 8-B cell, the weight is
+// broadcast), and the weight rows are double-buffered by unrolling instead of being copied.  sG holds the per-atom gradient
+// as [ch][kGmLd] with the PAIRS of every irrep first (components base+1+2i, base+2+2i of irrep r, i < r) and the leftover
+// component of every irrep (base = r^2) behind them: gm_slot() below.
+template <int R>
+__device__ __forceinline__ constexpr int gm_num_pairs() {
+  return R * (R - 1) / 2;
+}
+template <int R>
+__device__ __forceinline__ constexpr int gm_ld() {
+  return (R * R + 3) / 4 * 4;  // row stride (floats): 16-B cells
+}
+// position of component j inside a row of sG
+template <int R>
+__device__ __forceinline__ constexpr int gm_slot(int j) {
+  const int r = j < 1 ? 0 : (j < 4 ? 1 : (j < 9 ? 2 : 3));
+  const int base = r * r, off = j - base;
+  if (off == 0) return 2 * gm_num_pairs<R>() + r;  // the leftover of irrep r
+  return 2 * (r * (r - 1) / 2) + (off - 1);        // pairs of the irreps before + (off - 1)
+}
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_gm_store(T* sG, const T* g2acc, int lane) {
+  static_assert(64 * gm_ld<R>() <= D * (64 + 64), "the staging area is the wave's moments + gradient region: D x (ka_lds + 64), ka_lds >= 64");
+#pragma unroll
+  for (int j = 0; j < D; ++j) sG[lane * gm_ld<R>() + gm_slot<R>(j)] = g2acc[j];
+}
 template <typename T, int D, int R>
 __device__ __forceinline__ void mom_gm(const T* sG, const T* Wt, int ka, int kb, int lane, T* gm) {
-  constexpr int CB = 8;
+  typedef typename Pk<T>::type T2;
+  constexpr int CB = 4, NP = gm_num_pairs<R>(), LD = gm_ld<R>();
+  static_assert(64 % (2 * CB) == 0 && D == R * R, "spherical-harmonics-ordered components");
+  T2 gp[NP > 0 ? NP : 1];
+  T gs[R];
 #pragma unroll
-  for (int j = 0; j < D; ++j) gm[j] = T(0);
-  T wc[CB][R], wn[CB][R];
+  for (int i = 0; i < NP; ++i) gp[i] = T2{T(0), T(0)};
+#pragma unroll
+  for (int r = 0; r < R; ++r) gs[r] = T(0);
+  T wa[CB][R], wb[CB][R];
   auto loadw = [&](int c0, T(*w)[R]) {
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
-      const int ch = c0 + i < 64 ? c0 + i : 63;
 #pragma unroll
-      for (int r = 0; r < R; ++r) w[i][r] = Wt[(int64_t(r) * 64 + ch) * ka + kb + lane];
+      for (int r = 0; r < R; ++r) w[i][r] = Wt[(int64_t(r) * 64 + c0 + i) * ka + kb + lane];
     }
   };
-  loadw(0, wc);
-  for (int c0 = 0; c0 < 64; c0 += CB) {
-    loadw(c0 + CB, wn);
+  auto consume = [&](int c0, const T(*w)[R]) {
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
+      const T* row = sG + (c0 + i) * LD;  // (wave-uniform address: broadcast reads)
+      T2 gpair[NP > 0 ? NP : 1];
 #pragma unroll
-      for (int j = 0; j < D; ++j) gm[j] += sG[j * 64 + c0 + i] * wc[i][r_of<0>(j)];
+      for (int q = 0; q < NP; ++q) gpair[q] = *reinterpret_cast<const T2*>(row + 2 * q);
+      T gsing[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) gsing[r] = row[2 * NP + r];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        gs[r] += gsing[r] * w[i][r];
+#pragma unroll
+        for (int q = 0; q < r; ++q) gp[r * (r - 1) / 2 + q] += gpair[r * (r - 1) / 2 + q] * T2{w[i][r], w[i][r]};
+      }
     }
+  };
+  loadw(0, wa);
+#pragma unroll 1
+  for (int c0 = 0; c0 < 64; c0 += 2 * CB) {  // (not unrolled further: the reverse kernels run at up to 4 waves per SIMD, 128 registers)
+    loadw(c0 + CB, wb);
+    consume(c0, wa);
+    if (c0 + 2 * CB < 64) loadw(c0 + 2 * CB, wa);
+    consume(c0 + CB, wb);
+  }
 #pragma unroll
-    for (int i = 0; i < CB; ++i)
+  for (int r = 0; r < R; ++r) {
+    gm[r * r] = gs[r];
 #pragma unroll
-      for (int r = 0; r < R; ++r) wc[i][r] = wn[i][r];
+    for (int q = 0; q < r; ++q) {
+      gm[r * r + 1 + 2 * q] = gp[r * (r - 1) / 2 + q][0];
+      gm[r * r + 2 + 2 * q] = gp[r * (r - 1) / 2 + q][1];
+    }
   }
 }
 
@@ -791,8 +845,7 @@ __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const
   typedef typename Pk<T>::type T2;
   constexpr int B = 4;  // pairs per batch here (two channel blocks may be live)
   __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int j = 0; j < D; ++j) sG[j * 64 + lane] = g2acc[j];
+  mom_gm_store<T, D, R>(sG, g2acc, lane);
   __builtin_amdgcn_wave_barrier();
   T gm0[D], gm1[D];
   mom_gm<T, D, R>(sG, Wt, ka, 0, lane, gm0);
@@ -1161,7 +1214,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? (KA2 ? 3
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
   mom_backward_edges<T, D, R, KA2>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, g2acc,
-                              static_cast<const T*>(ma.wt1), beg, end, lane, sG, sY, staged_cb, static_cast<T*>(ma.g_a),
+                              static_cast<const T*>(ma.wt1), beg, end, lane, sM /* [64][gm_ld]: spans the (here unused) moments area and sG */, sY, staged_cb, static_cast<T*>(ma.g_a),
                               ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
 
@@ -1267,7 +1320,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
   mom_backward_edges<T, D, R, KA2>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, g2acc,
-                              static_cast<const T*>(ma.wt0), beg, end, lane, sG, sY, staged_cb, static_cast<T*>(ma.g_a),
+                              static_cast<const T*>(ma.wt0), beg, end, lane, sM /* [64][gm_ld]: spans the (here unused) moments area and sG */, sY, staged_cb, static_cast<T*>(ma.g_a),
                               ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
 

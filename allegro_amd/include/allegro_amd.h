@@ -222,6 +222,9 @@ typedef struct {
   int32_t fused_tail;      /* experimental builds only (AA_BUILD_EXPERIMENTAL=1): 1 = the fused per-atom-tile
                             * reverse tail (aa_fused_bwd.hip) where the fused forward runs, 2 = ... leaving the edge reverse to
                             * edge_backward; measured slower than the staged tail on MI355X, ignored by the product build      */
+  int32_t fused_keep_split; /* fused forward, one-tile form: tile pairs that feed several layers are split into their bf16 levels once and
+                             * held in registers: 0 = the default (2), 1 = none (parked raw in LDS, split by every reader), 2 = the two-body
+                             * scalars, 3 = two-body scalars and lat0 */
   int32_t poison_workspace; /* debugging: every step first fills the whole workspace with 0xFF bytes (NaN in fp32 and fp64), so
                              * that a kernel reading a cell no earlier kernel of the SAME step wrote shows up as NaN       */
 } aa_plan_options;
