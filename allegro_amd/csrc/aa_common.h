@@ -586,7 +586,17 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream);
 // fused per-atom-tile kernels (aa_fused.hip): the whole forward of the standard 2-layer, 64-wide stack in ONE launch
 // ----------------------------------------------------------------------------------------------
 constexpr int kFusedMaxSteps = 56;
-constexpr int kFusedKeepDefault = 2;  // FusedFwdArgs::keep when aa_plan_options.fused_keep_split is 0
+constexpr int kFusedKeepDefault = 2;
+// The first layer of scalar_embed_mlp is LINEAR in the two-body embedding, and the embedding is linear in the 8 radial basis
+// functions (emb0[c] = sum_n basis[n] tab[pair][n][c], scalarembed.py:60-81 / :157-175), so its pre-activation is
+// h[k] = sum_n basis[n] T[pair][n][k] with T = tab[pair] @ W0 -- a table of the same size, folded at pack time.  The fused
+// forward then has no 64x64 layer L0 (2 of its 32 MFMA steps and 2 tile splits) and the last reverse chain no layer W0^T
+// (2 of 12 steps): d basis[n] = sum_k d_h[k] T[pair][n][k].  -DAA_NO_FOLD_EMBED builds the unfolded form (A/B).
+#ifdef AA_NO_FOLD_EMBED
+constexpr bool kFoldEmbed = false;
+#else
+constexpr bool kFoldEmbed = true;
+#endif  // FusedFwdArgs::keep when aa_plan_options.fused_keep_split is 0
 constexpr int kFusedMaxDegree = 128;  // longest edge segment the fused forward takes: a team of four 32-edge tiles
 constexpr int kFusedTeamTilesSmall = 4096;  // up to this many tiles the team form is chosen regardless of how full the tiles are
 struct FusedFwdArgs {

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   static_assert(Sig0::D1 == D && Sig0::DOUT == D && Sig1::D1 == D && Sig1::DOUT == 1, "standard 2-layer stack");
   static_assert(D <= 16, "l_max <= 3");
   // the program: L0 L1 | Wenv0 | L2 | L3 | Wenv1 | L4 | (L5: w0 again, unless held) | L6 L7 L8
-  constexpr int S_L0 = 0, S_L1 = 2, S_P0 = 4, S_L2 = 8, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L4 = S_P1 + 4,
+  constexpr int S_L0 = 0, S_L1 = kFoldEmbed ? 0 : 2, S_P0 = S_L1 + 2, S_L2 = S_P0 + 4, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L4 = S_P1 + 4,
                 S_L5 = S_L4 + 2, S_L6 = S_L5 + (HOLD ? 0 : 2 * R), S_L7 = S_L6 + 6, S_L8 = S_L7 + 2, NS = S_L8 + 6;
   static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps, "the two LDS buffers alternate consistently across iterations");
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
@@ -297,15 +297,23 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     v16f w0t[HOLD ? 2 * R : 1];
     XSplit tb[KEEP >= 1 ? 2 : 1], l0x[KEEP >= 2 ? 2 : 1];  // held split tiles (see KEEP)
     AA_TICK(2)
-    // ---- L0: scalar_embed_mlp layer 0 (pre-activation kept for the reverse pass)
-    fused_layer<S_L0, NS, 2, 2>(A, p,
-                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
-                                [&](auto, const v16f& a0, const v16f& a1) {
-                                  tile_store_rows(sW, a0, A.se_h, row0, cnt, 64, lane);
-                                  tile_store_rows(sW, a1, A.se_h + 32, row0, cnt, 64, lane);
-                                  keep_tile<true>(a0, k0);
-                                  keep_tile<true>(a1, k1);
-                                });
+    // ---- L0: scalar_embed_mlp layer 0 (pre-activation kept for the reverse pass).  Folded into the table (kFoldEmbed): em0 / em1
+    //      ARE its pre-activation, no GEMM
+    if constexpr (kFoldEmbed) {
+      tile_store_rows(sW, em0, A.se_h, row0, cnt, 64, lane);
+      tile_store_rows(sW, em1, A.se_h + 32, row0, cnt, 64, lane);
+      keep_tile<true>(em0, k0);
+      keep_tile<true>(em1, k1);
+    } else {
+      fused_layer<S_L0, NS, 2, 2>(A, p,
+                                  [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return em0; else return em1; },
+                                  [&](auto, const v16f& a0, const v16f& a1) {
+                                    tile_store_rows(sW, a0, A.se_h, row0, cnt, 64, lane);
+                                    tile_store_rows(sW, a1, A.se_h + 32, row0, cnt, 64, lane);
+                                    keep_tile<true>(a0, k0);
+                                    keep_tile<true>(a1, k1);
+                                  });
+    }
     AA_TICK(3)
     // ---- L1: scalar_embed_mlp layer 1 -> EDGE_EMBEDDING
     fused_layer<S_L1, NS, 2, 2>(A, p,
@@ -564,7 +572,7 @@ size_t fused_fwd_lds_bytes(int num_types, bool teams) {
 }
 
 // number of weight-pipeline steps of the program for R irreps (see the kernel)
-int fused_fwd_num_steps(int R, bool hold) { return 8 + (2 + 2 * R) + 4 + 4 + 2 + (hold ? 0 : 2 * R) + 6 + 2 + 6; }
+int fused_fwd_num_steps(int R, bool hold) { return (kFoldEmbed ? 6 : 8) + (2 + 2 * R) + 4 + 4 + 2 + (hold ? 0 : 2 * R) + 6 + 2 + 6; }
 
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;

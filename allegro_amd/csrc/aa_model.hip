@@ -215,6 +215,7 @@ struct aa_model_plan {
   bool embed_fused;                  // reverse pass: d(two-body embedding) [E,S0] never materialised, the last reverse chain
                                      // contracts it back to the 8 basis functions in its epilogue (embrev_out in aa_common.h)
   size_t o_embtab;                   // [T*T][8][64] type_embed(c | pair) * basis_linear[n][c]
+  size_t o_embtab_h;                 // [T*T][8][64] the same table times the first scalar_embed_mlp layer (kFoldEmbed), or 0
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
 #ifdef AA_EXPERIMENTAL_TAIL
@@ -446,6 +447,8 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     const bool tab_ok = p->chain_gemm && T <= 3 && B == 8 && S0 == 64;
     p->embed_fused = tab_ok && T <= 2 && !opt.embed_no_fuse;
     p->o_embtab = (tab_ok || cfg->embed_kind == 1) ? take(size_t(T) * T * B * S0) : 0;
+    // (the fold needs a hidden layer of 64 behind the embedding: what the chains / the fused forward require anyway)
+    p->o_embtab_h = (kFoldEmbed && tab_ok && cfg->embed_mlp_depth >= 1 && p->embed.dims.size() >= 2 && p->embed.dims[1] == 64) ? take(size_t(T) * T * B * 64) : 0;
   }
   if (p->chain_gemm) {
     // merged reverse chain "readout' o latent_{L-1}'" (see Runner::backward): the readout-reverse columns that feed
@@ -465,7 +468,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     // 4096, 4.5 % at 10 648, 0.5 % at 97 336 atoms, and it moves 2.1 instead of 7.3 KB/edge (profiles/r02_v23_fused_sweep.log).
     // aa_plan_options.fused_forward: 0 / 1 = whenever the graph allows (max_degree <= 32), 3 = never (staged pipeline).
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                          u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0;
+                          u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0 && (!kFoldEmbed || p->o_embtab_h != 0);
     p->fused_fwd = eligible && opt.fused_forward != 3;
 #ifdef AA_EXPERIMENTAL_TAIL
     p->fused_tail = p->fused_fwd && p->embed_fused && (opt.fused_tail == 1 || opt.fused_tail == 2);
@@ -555,7 +558,7 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
                      uint64_t(p->n_elems)})
     mix(v);
   for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
-                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab})
+                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h})
     mix(v);
   for (int l = 0; l < c.num_layers; ++l) {
     mix(p->o_tpw[l]);
@@ -792,6 +795,17 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
             const double te = cc < half ? h[p->o_cemb + size_t(ti) * half + cc] : h[p->o_nemb + size_t(tj) * half + (cc - half)];
             h[p->o_embtab + ((size_t(ti) * T + tj) * B + n) * S0 + cc] = te * h[p->o_basis + size_t(n) * S0 + cc];
           }
+  }
+  if (p->o_embtab_h) {
+    // T[pair][n][k] = sum_c tab[pair][n][c] * W0[c][k]  (W0: the packed first layer of scalar_embed_mlp, normalisation folded)
+    const int H = p->embed.dims[1];
+    for (int cls = 0; cls < T * T; ++cls)
+      for (int n = 0; n < B; ++n)
+        for (int k = 0; k < H; ++k) {
+          double acc = 0.0;
+          for (int cc = 0; cc < S0; ++cc) acc += h[p->o_embtab + (size_t(cls) * B + n) * S0 + cc] * h[p->embed.w[0] + size_t(cc) * H + k];
+          h[p->o_embtab_h + (size_t(cls) * B + n) * H + k] = acc;
+        }
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c.dtype == AA_F64) {
@@ -1422,7 +1436,7 @@ struct Runner {
     auto bf = [&](size_t off) { return reinterpret_cast<float*>(buf(off)); };
     a.rmax_recip = wf(p->o_rmax);
     a.bessel_w = wf(p->o_bessel);
-    a.emb_tab = wf(p->o_embtab);
+    a.emb_tab = wf(kFoldEmbed ? p->o_embtab_h : p->o_embtab);  // (folded: the table yields the first layer's pre-activation)
     // the weight program of the kernel (see fused_fwd_kernel): 12-KB blocks in execution order
     int ns = 0;
     auto add_layer = [&](const float* Wq, int KC, int tile0, int ntiles) {
@@ -1441,7 +1455,7 @@ struct Runner {
       }
     };
     const bool hold = p->fused_hold_w0;
-    add_layer(wf(p->embed.wq[0]), 2, 0, 2);
+    if (!kFoldEmbed) add_layer(wf(p->embed.wq[0]), 2, 0, 2);
     add_layer(wf(p->embed.wq[1]), 2, 0, 2);
     add_env(wf(p->o_wk[0]));
     add_layer(wf(p->o_g0q), 2, 0, 2 + 2 * p->R);
@@ -1860,7 +1874,17 @@ struct Runner {
       ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0tq), p->ng0, S, cn, nullptr, nullptr, &ad, 0, 0, 0);
       ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wtq[1]), S, 64, cn, nullptr, &zz, nullptr, 1, 0, 0);
       ca.L[2] = chain_layer(E, none, 0, wt(p->embed.wtq[0]), 64, c.embed_dim, ce, nullptr, nullptr, nullptr, 1, -1, 0);
-      if (p->embed_fused) {
+      if (p->embed_fused && p->o_embtab_h) {
+        // folded table (kFoldEmbed): d_h, the output of the second layer, is contracted straight back to the 8 basis functions
+        // with T = tab @ W0 -- the layer W0^T and d emb0 do not exist
+        ca.nlayers = 2;
+        ca.L[1].embrev_out = buf(w.trev);
+        ca.emb_table = wt(p->o_embtab_h);
+        ca.num_types = c.num_types;
+        ca.types = g->types;
+        ca.center = g->center;
+        ca.nbr = g->nbr;
+      } else if (p->embed_fused) {
         // d emb0 is contracted straight back to the 8 basis functions in the epilogue and never stored
         ca.L[2].g.c = SegList{1, {seg(nullptr, c.embed_dim, c.embed_dim)}};
         ca.L[2].embrev_out = buf(w.trev);

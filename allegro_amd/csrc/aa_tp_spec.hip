@@ -752,6 +752,38 @@ __device__ __forceinline__ void mom_project(const T* sM, int ka, int ka_lds, con
   __builtin_amdgcn_wave_barrier();
 }
 
+// plain form of mom_gm below (sG as [j][ch], weight rows copied between two register sets): what tp_mom_bwd_first keeps --
+// same-box A/B on MI355X (profiles/r04_v6_ab_c4.txt): the packed form is 6.5 % faster in tp_mom_bwd_last (1.019 -> 0.952 ms)
+// and 3 % slower in tp_mom_bwd_first (220 instead of 204 registers at two waves per SIMD)
+template <typename T, int D, int R>
+__device__ __forceinline__ void mom_gm_plain(const T* sG, const T* Wt, int ka, int kb, int lane, T* gm) {
+  constexpr int CB = 8;
+#pragma unroll
+  for (int j = 0; j < D; ++j) gm[j] = T(0);
+  T wc[CB][R], wn[CB][R];
+  auto loadw = [&](int c0, T(*w)[R]) {
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int ch = c0 + i < 64 ? c0 + i : 63;
+#pragma unroll
+      for (int r = 0; r < R; ++r) w[i][r] = Wt[(int64_t(r) * 64 + ch) * ka + kb + lane];
+    }
+  };
+  loadw(0, wc);
+  for (int c0 = 0; c0 < 64; c0 += CB) {
+    loadw(c0 + CB, wn);
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) gm[j] += sG[j * 64 + c0 + i] * wc[i][r_of<0>(j)];
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+#pragma unroll
+      for (int r = 0; r < R; ++r) wc[i][r] = wn[i][r];
+  }
+}
+
 // GM[j] (k = kb + lane) = sum_ch g[j][ch] * Wt[r(j)][ch][k]   (g already carries the scatter factor)
 // Instruction-issue-bound (a fifth of the reverse kernels' vector instructions): the components of one irrep share their weight,
 // so they are accumulated two per instruction (v_pk_fma_f32: the g pair comes from LDS as an aligned 8-B cell, the weight is
@@ -838,19 +870,29 @@ __device__ __forceinline__ void mom_gm(const T* sG, const T* Wt, int ka, int kb,
 
 // adjoint of the moments for every edge of the segment:
 //   d_a[e,k] = sum_j sh[e,j] * GM[j][k]        d_sh[e,j] = sum_k act(a[e,k]) * GM[j][k]
-template <typename T, int D, int R, bool KA2>
+template <typename T, int D, int R, bool KA2, bool PACKED_GM>
 __device__ __forceinline__ void mom_backward_edges(const T* sh, int ld_sh, const T* a, int ld_a, int ka, bool act,
                                                    const T* g2acc, const T* Wt, int beg, int end, int lane, T* sG, T* sY,
                                                    int& staged_cb, T* g_a, int ld_ga, T* gsh, int ld_gsh) {
   typedef typename Pk<T>::type T2;
   constexpr int B = 4;  // pairs per batch here (two channel blocks may be live)
   __builtin_amdgcn_wave_barrier();
-  mom_gm_store<T, D, R>(sG, g2acc, lane);
+  if constexpr (PACKED_GM) {
+    mom_gm_store<T, D, R>(sG, g2acc, lane);
+  } else {
+#pragma unroll
+    for (int j = 0; j < D; ++j) sG[j * 64 + lane] = g2acc[j];
+  }
   __builtin_amdgcn_wave_barrier();
   T gm0[D], gm1[D];
-  mom_gm<T, D, R>(sG, Wt, ka, 0, lane, gm0);
   const bool two = KA2 && ka > 64;
-  if (two) mom_gm<T, D, R>(sG, Wt, ka, 64, lane, gm1);
+  if constexpr (PACKED_GM) {
+    mom_gm<T, D, R>(sG, Wt, ka, 0, lane, gm0);
+    if (two) mom_gm<T, D, R>(sG, Wt, ka, 64, lane, gm1);
+  } else {
+    mom_gm_plain<T, D, R>(sG, Wt, ka, 0, lane, gm0);
+    if (two) mom_gm_plain<T, D, R>(sG, Wt, ka, 64, lane, gm1);
+  }
   const T2* sY2 = reinterpret_cast<const T2*>(sY);
   auto loadb = [&](int s0, int ce, T2* v0, T2* v1) {
 #pragma unroll
@@ -1213,7 +1255,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? (KA2 ? 3
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
-  mom_backward_edges<T, D, R, KA2>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, g2acc,
+  mom_backward_edges<T, D, R, KA2, true>(sh, a.ld_sh, static_cast<const T*>(ma.a1), ma.ld_a1, ma.ka1, true, g2acc,
                               static_cast<const T*>(ma.wt1), beg, end, lane, sM /* [64][gm_ld]: spans the (here unused) moments area and sG */, sY, staged_cb, static_cast<T*>(ma.g_a),
                               ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
@@ -1319,8 +1361,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
   const T sf = T(a.sf);
 #pragma unroll
   for (int j = 0; j < D; ++j) g2acc[j] *= sf;
-  mom_backward_edges<T, D, R, KA2>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, g2acc,
-                              static_cast<const T*>(ma.wt0), beg, end, lane, sM /* [64][gm_ld]: spans the (here unused) moments area and sG */, sY, staged_cb, static_cast<T*>(ma.g_a),
+  mom_backward_edges<T, D, R, KA2, false>(sh, a.ld_sh, static_cast<const T*>(ma.a0), ma.ld_a0, ma.ka0, false, g2acc,
+                              static_cast<const T*>(ma.wt0), beg, end, lane, sG, sY, staged_cb, static_cast<T*>(ma.g_a),
                               ma.ld_ga, static_cast<T*>(a.gsh_env), a.ld_gsh);
 }
 
