@@ -596,6 +596,31 @@ constexpr int kFusedKeepDefault = 2;
 constexpr bool kFoldEmbed = false;
 #else
 constexpr bool kFoldEmbed = true;
+#endif
+// The same algebra one level up.  The OUTPUT layer of a latent ScalarMLPFunction is linear and its result only ever enters
+// linear first layers (dense-net concat, _allegro.py:272-300: lat_l is a K-block of the next latent MLP and of edge_readout),
+// so lat_l = a_l @ Wout_l never has to be formed in the forward pass: the consumers take the hidden activation a_l against
+// Wout_l @ W_in[lat_l rows], folded at pack time (fp64, then rounded once).  The fused forward loses the two 64x64 output
+// layers L4 and L7 (26 instead of 30 MFMA steps); the reverse pass only needs the stored pre-activations and is unchanged,
+// except that the readout-reverse chain merges "d lat1 = d ro_h @ Wro[lat1]^T" and "@ Wout_1^T" into one 64x64 layer.
+// -DAA_NO_FOLD_LATENT builds the unfolded form (A/B).
+#ifdef AA_NO_FOLD_LATENT
+constexpr bool kFoldLatent = false;
+#else
+constexpr bool kFoldLatent = true;
+#endif
+// ... and at the front: EDGE_EMBEDDING = a_e @ W1 (the linear output layer of scalar_embed_mlp, a_e = silu(h)) only ever enters
+// linear maps -- env_embed_linear / first_layer_env_embed_projection (tensorembed.py:88-89, _allegro.py:251-258) and, through
+// the moments, the env weights of layer 0.  With W1 folded into all of them (first stage: W1 @ [proj | env]; env weights:
+// W1 @ Wenv0) the fused forward has no layer L1 either (24 MFMA steps), works on a_e wherever it used the embedding and stores
+// a_e in the embedding's slot; the reverse pass that FOLLOWS A FUSED FORWARD reads a_e there: tp_mom_bwd_first with the folded
+// transposed env weights, and the last reverse chain is ONE 256 -> 64 layer ((W1 @ G0)^T, + d a_e of the moments, x silu'(h),
+// contracted against the folded two-body table).  After a staged forward (true embedding stored) the unfolded reverse runs.
+// -DAA_NO_FOLD_EMB1 builds without (A/B); the experimental reverse tail reads the true embedding: no fold there.
+#if defined(AA_NO_FOLD_EMB1) || defined(AA_NO_FOLD_EMBED) || defined(AA_EXPERIMENTAL_TAIL)
+constexpr bool kFoldEmb1 = false;
+#else
+constexpr bool kFoldEmb1 = true;
 #endif  // FusedFwdArgs::keep when aa_plan_options.fused_keep_split is 0
 constexpr int kFusedMaxDegree = 128;  // longest edge segment the fused forward takes: a team of four 32-edge tiles
 constexpr int kFusedTeamTilesSmall = 4096;  // up to this many tiles the team form is chosen regardless of how full the tiles are

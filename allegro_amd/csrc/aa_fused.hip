@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   static_assert(Sig0::D1 == D && Sig0::DOUT == D && Sig1::D1 == D && Sig1::DOUT == 1, "standard 2-layer stack");
   static_assert(D <= 16, "l_max <= 3");
   // the program: L0 L1 | Wenv0 | L2 | L3 | Wenv1 | L4 | (L5: w0 again, unless held) | L6 L7 L8
-  constexpr int S_L0 = 0, S_L1 = kFoldEmbed ? 0 : 2, S_P0 = S_L1 + 2, S_L2 = S_P0 + 4, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L4 = S_P1 + 4,
-                S_L5 = S_L4 + 2, S_L6 = S_L5 + (HOLD ? 0 : 2 * R), S_L7 = S_L6 + 6, S_L8 = S_L7 + 2, NS = S_L8 + 6;
+  constexpr int S_L0 = 0, S_L1 = kFoldEmbed ? 0 : 2, S_P0 = S_L1 + (kFoldEmb1 ? 0 : 2), S_L2 = S_P0 + 4, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L4 = S_P1 + 4,
+                S_L5 = S_L4 + (kFoldLatent ? 0 : 2), S_L6 = S_L5 + (HOLD ? 0 : 2 * R), S_L7 = S_L6 + 6, S_L8 = S_L7 + (kFoldLatent ? 0 : 2), NS = S_L8 + 6;
   static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps, "the two LDS buffers alternate consistently across iterations");
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);            // [64] last readout weights
@@ -315,15 +315,23 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   });
     }
     AA_TICK(3)
-    // ---- L1: scalar_embed_mlp layer 1 -> EDGE_EMBEDDING
-    fused_layer<S_L1, NS, 2, 2>(A, p,
-                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-                                [&](auto, const v16f& a0, const v16f& a1) {
-                                  tile_store_rows(sW, a0, A.emb, row0, cnt, 64, lane);
-                                  tile_store_rows(sW, a1, A.emb + 32, row0, cnt, 64, lane);
-                                  em0 = a0;
-                                  em1 = a1;
-                                });
+    // ---- L1: scalar_embed_mlp layer 1 -> EDGE_EMBEDDING.  Folded (kFoldEmb1): every consumer of the embedding is linear, so they
+    //      take a_e = silu(h) (k0, k1) against W1-folded weights; a_e is stored in the embedding's slot for the reverse pass
+    if constexpr (kFoldEmb1) {
+      em0 = k0;
+      em1 = k1;
+      tile_store_rows(sW, em0, A.emb, row0, cnt, 64, lane);
+      tile_store_rows(sW, em1, A.emb + 32, row0, cnt, 64, lane);
+    } else {
+      fused_layer<S_L1, NS, 2, 2>(A, p,
+                                  [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+                                  [&](auto, const v16f& a0, const v16f& a1) {
+                                    tile_store_rows(sW, a0, A.emb, row0, cnt, 64, lane);
+                                    tile_store_rows(sW, a1, A.emb + 32, row0, cnt, 64, lane);
+                                    em0 = a0;
+                                    em1 = a1;
+                                  });
+    }
     AA_TICK(4)
     // ---- per-atom part of layer 0: moments of the embedding -> x2s0 -> B0 = Sig0^T_x1(e_0, x2s0)
     float x2s0[D];
@@ -418,22 +426,33 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
       __builtin_amdgcn_wave_barrier();
     }
     AA_TICK(8)
-    // ---- L4: latent 0, output layer -> lat0
-    fused_layer<S_L4, NS, 2, 2>(A, p,
-                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-                                [&](auto, const v16f& a0, const v16f& a1) {
-                                  if constexpr (KEEP >= 2) {
-                                    xsplit_from_acc(a0, l0x[0]);
-                                    xsplit_from_acc(a1, l0x[1]);
-                                  } else {
-                                    AA_PARK(2, a0);
-                                    AA_PARK(3, a1);
-                                  }
-                                  if (A.fcat) {
-                                    tile_store_rows(sW, a0, A.fcat + 64, row0, cnt, 192, lane);
-                                    tile_store_rows(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
-                                  }
-                                });
+    // ---- L4: latent 0, output layer -> lat0.  Folded (kFoldLatent): lat0 is never formed -- its consumers L6 / L8 take the hidden
+    //      activation a1 = silu(h) (k0, k1) against Wout_0 @ their lat0 row blocks; a1 is what is held / parked instead
+    if constexpr (kFoldLatent) {
+      if constexpr (KEEP >= 2) {
+        xsplit_from_acc(k0, l0x[0]);
+        xsplit_from_acc(k1, l0x[1]);
+      } else {
+        AA_PARK(2, k0);
+        AA_PARK(3, k1);
+      }
+    } else {
+      fused_layer<S_L4, NS, 2, 2>(A, p,
+                                  [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+                                  [&](auto, const v16f& a0, const v16f& a1) {
+                                    if constexpr (KEEP >= 2) {
+                                      xsplit_from_acc(a0, l0x[0]);
+                                      xsplit_from_acc(a1, l0x[1]);
+                                    } else {
+                                      AA_PARK(2, a0);
+                                      AA_PARK(3, a1);
+                                    }
+                                    if (A.fcat) {
+                                      tile_store_rows(sW, a0, A.fcat + 64, row0, cnt, 192, lane);
+                                      tile_store_rows(sW, a1, A.fcat + 96, row0, cnt, 192, lane);
+                                    }
+                                  });
+    }
     // inputs of the next tile (its neighbor ids arrived long ago): positions, shifts, types
     load_geo(a_nxt, nxt);
     AA_TICK(9)
@@ -476,17 +495,19 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
                                   keep_tile<true>(a1, k1);
                                 });
     AA_TICK(11)
-    // ---- L7: latent 1, output layer -> lat1
-    fused_layer<S_L7, NS, 2, 2>(A, p,
-                                [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
-                                [&](auto, const v16f& a0, const v16f& a1) {
-                                  k0 = a0;
-                                  k1 = a1;
-                                  if (A.fcat) {
-                                    tile_store_rows(sW, a0, A.fcat + 128, row0, cnt, 192, lane);
-                                    tile_store_rows(sW, a1, A.fcat + 160, row0, cnt, 192, lane);
-                                  }
-                                });
+    // ---- L7: latent 1, output layer -> lat1.  Folded (kFoldLatent): the readout takes silu(h) of latent 1 (k0, k1) directly
+    if constexpr (!kFoldLatent) {
+      fused_layer<S_L7, NS, 2, 2>(A, p,
+                                  [&](auto kc) -> const v16f& { if constexpr (decltype(kc)::value == 0) return k0; else return k1; },
+                                  [&](auto, const v16f& a0, const v16f& a1) {
+                                    k0 = a0;
+                                    k1 = a1;
+                                    if (A.fcat) {
+                                      tile_store_rows(sW, a0, A.fcat + 128, row0, cnt, 192, lane);
+                                      tile_store_rows(sW, a1, A.fcat + 160, row0, cnt, 192, lane);
+                                    }
+                                  });
+    }
     AA_TICK(12)
     // ---- L8: edge readout hidden layer on [two-body | lat0 | lat1]; last linear layer + edge sum in the epilogue
     fused_layer<S_L8, NS, 6, 2>(A, p,
@@ -572,7 +593,9 @@ size_t fused_fwd_lds_bytes(int num_types, bool teams) {
 }
 
 // number of weight-pipeline steps of the program for R irreps (see the kernel)
-int fused_fwd_num_steps(int R, bool hold) { return (kFoldEmbed ? 6 : 8) + (2 + 2 * R) + 4 + 4 + 2 + (hold ? 0 : 2 * R) + 6 + 2 + 6; }
+int fused_fwd_num_steps(int R, bool hold) {
+  return (kFoldEmbed ? (kFoldEmb1 ? 4 : 6) : 8) + (2 + 2 * R) + 4 + 4 + (kFoldLatent ? 0 : 2) + (hold ? 0 : 2 * R) + 6 + (kFoldLatent ? 0 : 2) + 6;
+}
 
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;

@@ -216,6 +216,11 @@ struct aa_model_plan {
                                      // contracts it back to the 8 basis functions in its epilogue (embrev_out in aa_common.h)
   size_t o_embtab;                   // [T*T][8][64] type_embed(c | pair) * basis_linear[n][c]
   size_t o_embtab_h;                 // [T*T][8][64] the same table times the first scalar_embed_mlp layer (kFoldEmbed), or 0
+  size_t o_lat1in_fq, o_ro0_fq;      // (kFoldLatent, 2-layer 64-wide stacks) bf16x3 copies of the first layers of latent 1 / edge_readout with the
+                                     // latent output layers folded into their lat_l row blocks, or 0
+  size_t o_b3af_q;                   // ... and of the merged first layer of the readout-reverse chain, or 0
+  size_t o_g0fq, o_g0tfq;            // (kFoldEmb1) bf16x3 copies of W1 @ G0 [64, ng0] and of its transpose, or 0
+  size_t o_wk0f, o_wt0f;             // (kFoldEmb1) W1 @ Wenv0 as [k][R][u] and [R][u][k], or 0
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
 #ifdef AA_EXPERIMENTAL_TAIL
@@ -440,6 +445,19 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     p->o_ro_last = take(p->ro_last_dim);
   }
   p->o_b3a_q = p->o_b3b_q = p->o_b3c_q = 0;
+  p->o_lat1in_fq = p->o_ro0_fq = p->o_b3af_q = 0;
+  p->o_g0fq = p->o_g0tfq = p->o_wk0f = p->o_wt0f = 0;
+  if (kFoldEmb1 && p->chain_gemm && p->env_mom && L == 2 && u == 64) {
+    p->o_g0fq = take(gemm_bf16x3_words(64, p->ng0));
+    p->o_g0tfq = take(gemm_bf16x3_words(p->ng0, 64));
+    p->o_wk0f = take(size_t(64) * p->W);
+    p->o_wt0f = take(size_t(64) * p->W);
+  }
+  if (kFoldLatent && p->chain_gemm && L == 2 && u == 64) {  // (chain_gemm: S = every MLP width = 64, one hidden layer each)
+    p->o_lat1in_fq = take(gemm_bf16x3_words(2 * S + u, 64));
+    p->o_ro0_fq = take(gemm_bf16x3_words(3 * S, 64));
+    p->o_b3af_q = take(gemm_bf16x3_words(64, 64));
+  }
   {
     // two-body table [T*T][B][S0] (type embedding x basis weights): the last reverse chain contracts against it (<= 2
     // species: its LDS copy must leave room for three workgroups per CU) and the fused forward evaluates the embedding
@@ -468,7 +486,8 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     // 4096, 4.5 % at 10 648, 0.5 % at 97 336 atoms, and it moves 2.1 instead of 7.3 KB/edge (profiles/r02_v23_fused_sweep.log).
     // aa_plan_options.fused_forward: 0 / 1 = whenever the graph allows (max_degree <= 32), 3 = never (staged pipeline).
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
-                          u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0 && (!kFoldEmbed || p->o_embtab_h != 0);
+                          u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0 && (!kFoldEmbed || p->o_embtab_h != 0) &&
+                          (!kFoldLatent || p->o_lat1in_fq != 0) && (!kFoldEmb1 || p->o_g0fq != 0);
     p->fused_fwd = eligible && opt.fused_forward != 3;
 #ifdef AA_EXPERIMENTAL_TAIL
     p->fused_tail = p->fused_fwd && p->embed_fused && (opt.fused_tail == 1 || opt.fused_tail == 2);
@@ -558,7 +577,7 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
                      uint64_t(p->n_elems)})
     mix(v);
   for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
-                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h})
+                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h, p->o_lat1in_fq, p->o_ro0_fq, p->o_b3af_q, p->o_g0fq, p->o_g0tfq, p->o_wk0f, p->o_wt0f})
     mix(v);
   for (int l = 0; l < c.num_layers; ++l) {
     mix(p->o_tpw[l]);
@@ -796,6 +815,19 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
             h[p->o_embtab + ((size_t(ti) * T + tj) * B + n) * S0 + cc] = te * h[p->o_basis + size_t(n) * S0 + cc];
           }
   }
+  if (p->o_wk0f) {
+    // (kFoldEmb1) env weights of layer 0 behind the output layer of scalar_embed_mlp: Wenv0'[k][r][ch] = sum_m W1[k][m] Wenv0[m][r][ch]
+    const double* w1 = &h[p->embed.w[1]];  // [64, S]
+    const int Rr_ = p->R, uu = c.num_tensor;
+    for (int k = 0; k < 64; ++k)
+      for (int r = 0; r < Rr_; ++r)
+        for (int ch = 0; ch < uu; ++ch) {
+          double v = 0.0;
+          for (int m = 0; m < S; ++m) v += w1[size_t(k) * S + m] * h[p->o_wk[0] + (size_t(m) * Rr_ + r) * uu + ch];
+          h[p->o_wk0f + (size_t(k) * Rr_ + r) * uu + ch] = v;
+          h[p->o_wt0f + (size_t(r) * uu + ch) * 64 + k] = v;
+        }
+  }
   if (p->o_embtab_h) {
     // T[pair][n][k] = sum_c tab[pair][n][c] * W0[c][k]  (W0: the packed first layer of scalar_embed_mlp, normalisation folded)
     const int H = p->embed.dims[1];
@@ -845,6 +877,56 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       gemm_pack_bf16x3(a.data(), 64, S, reinterpret_cast<unsigned*>(&hf[p->o_b3a_q]));
       gemm_pack_bf16x3(b.data(), 128, SL, reinterpret_cast<unsigned*>(&hf[p->o_b3b_q]));
       gemm_pack_bf16x3(cmat.data(), 64, c.num_tensor, reinterpret_cast<unsigned*>(&hf[p->o_b3c_q]));
+    }
+    if (p->o_g0fq) {
+      // (kFoldEmb1) first stage behind the output layer of scalar_embed_mlp: W1 @ G0 and its transpose
+      const int NG = p->ng0;
+      std::vector<float> gf(size_t(64) * NG), gft(size_t(NG) * 64);
+      for (int k = 0; k < 64; ++k)
+        for (int q = 0; q < NG; ++q) {
+          double v = 0.0;
+          for (int m = 0; m < S; ++m) v += h[p->embed.w[1] + size_t(k) * S + m] * h[p->o_g0 + size_t(m) * NG + q];
+          gf[size_t(k) * NG + q] = float(v);
+          gft[size_t(q) * 64 + k] = float(v);
+        }
+      gemm_pack_bf16x3(gf.data(), 64, NG, reinterpret_cast<unsigned*>(&hf[p->o_g0fq]));
+      gemm_pack_bf16x3(gft.data(), NG, 64, reinterpret_cast<unsigned*>(&hf[p->o_g0tfq]));
+    }
+    if (p->o_lat1in_fq) {
+      // folded first layers (kFoldLatent): row block "lat_l" of a consumer's first layer <- Wout_l @ that block, in fp64 from the
+      // normalised matrices, rounded once.  Row order of the consumers: [two-body | lat0 | scal1] (latent 1), [two-body | lat0 | lat1] (readout)
+      const double* wo0 = &h[p->latent[0].w[1]];  // [64, 64] output layer of latent 0
+      const double* wo1 = &h[p->latent[1].w[1]];  // [64, 64] output layer of latent 1
+      auto folded = [&](const double* win, int K, const double* const* fold /* per 64-row block: Wout or nullptr */) {
+        std::vector<float> out(size_t(K) * 64);
+        for (int blk = 0; blk < K / 64; ++blk)
+          for (int r = 0; r < 64; ++r)
+            for (int n = 0; n < 64; ++n) {
+              double v = 0.0;
+              if (fold[blk]) {
+                for (int m = 0; m < 64; ++m) v += fold[blk][size_t(r) * 64 + m] * win[size_t(blk * 64 + m) * 64 + n];
+              } else {
+                v = win[size_t(blk * 64 + r) * 64 + n];
+              }
+              out[size_t(blk * 64 + r) * 64 + n] = float(v);
+            }
+        return out;
+      };
+      const double* f1[3] = {nullptr, wo0, nullptr};
+      const double* f2[3] = {nullptr, wo0, wo1};
+      const std::vector<float> l1 = folded(&h[p->latent[1].w[0]], 2 * S + c.num_tensor, f1);
+      const std::vector<float> r0 = folded(&h[p->readout.w[0]], 3 * S, f2);
+      gemm_pack_bf16x3(l1.data(), 2 * S + c.num_tensor, 64, reinterpret_cast<unsigned*>(&hf[p->o_lat1in_fq]));
+      gemm_pack_bf16x3(r0.data(), 3 * S, 64, reinterpret_cast<unsigned*>(&hf[p->o_ro0_fq]));
+      // readout-reverse chain: d a1 = d ro_h @ (Wout_1 @ Wro[lat1 rows])^T, one layer instead of two
+      std::vector<float> af(size_t(64) * 64);
+      for (int k = 0; k < 64; ++k)       // readout hidden unit
+        for (int m = 0; m < 64; ++m) {   // hidden unit of latent 1
+          double v = 0.0;
+          for (int n = 0; n < 64; ++n) v += wo1[size_t(m) * 64 + n] * h[p->readout.w[0] + size_t(2 * S + n) * 64 + k];
+          af[size_t(k) * 64 + m] = float(v);
+        }
+      gemm_pack_bf16x3(af.data(), 64, 64, reinterpret_cast<unsigned*>(&hf[p->o_b3af_q]));
     }
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
   }
@@ -1455,17 +1537,19 @@ struct Runner {
       }
     };
     const bool hold = p->fused_hold_w0;
+    const bool folde = kFoldEmb1 && p->o_g0fq != 0;  // (see kFoldEmb1: no layer L1; first stage and env weights behind W1)
     if (!kFoldEmbed) add_layer(wf(p->embed.wq[0]), 2, 0, 2);
-    add_layer(wf(p->embed.wq[1]), 2, 0, 2);
-    add_env(wf(p->o_wk[0]));
-    add_layer(wf(p->o_g0q), 2, 0, 2 + 2 * p->R);
+    if (!folde) add_layer(wf(p->embed.wq[1]), 2, 0, 2);
+    add_env(wf(folde ? p->o_wk0f : p->o_wk[0]));
+    add_layer(wf(folde ? p->o_g0fq : p->o_g0q), 2, 0, 2 + 2 * p->R);
     add_layer(wf(p->latent[0].wq[0]), 4, 0, 2);
     add_env(wf(p->o_wk[1]));
-    add_layer(wf(p->latent[0].wq[1]), 2, 0, 2);
-    if (!hold) add_layer(wf(p->o_g0q), 2, 2, 2 * p->R);  // the w0 columns of the first-stage matrix again
-    add_layer(wf(p->latent[1].wq[0]), 6, 0, 2);
-    add_layer(wf(p->latent[1].wq[1]), 2, 0, 2);
-    add_layer(wf(p->readout.wq[0]), 6, 0, 2);
+    const bool foldl = kFoldLatent && p->o_lat1in_fq != 0;  // (see kFoldLatent: no output layers L4 / L7, folded consumers)
+    if (!foldl) add_layer(wf(p->latent[0].wq[1]), 2, 0, 2);
+    if (!hold) add_layer(wf(folde ? p->o_g0fq : p->o_g0q), 2, 2, 2 * p->R);  // the w0 columns of the first-stage matrix again
+    add_layer(wf(foldl ? p->o_lat1in_fq : p->latent[1].wq[0]), 6, 0, 2);
+    if (!foldl) add_layer(wf(p->latent[1].wq[1]), 2, 0, 2);
+    add_layer(wf(foldl ? p->o_ro0_fq : p->readout.wq[0]), 6, 0, 2);
     if (ns != fused_fwd_num_steps(p->R, hold) || ns > kFusedMaxSteps) return fail(AA_ERR_INVALID, "fused forward: program length mismatch");
     a.tpw0 = wf(p->o_tpw[0]);
     a.tpw1 = wf(p->o_tpw[1]);
@@ -1683,6 +1767,15 @@ struct Runner {
       ca.L[2] = chain_layer(E, in, 0, wt(p->o_b3b_q), 128, S * L, c2, nullptr, nullptr, nullptr, 1, -1, 0);
       ca.L[2].a_mode = 1;
       ca.L[3] = chain_layer(E, none, 0, wt(p->o_b3c_q), 64, u, c3, nullptr, nullptr, nullptr, 1, -1, 0);
+      if (kFoldLatent && p->o_b3af_q && L == 2) {
+        // "d lat1 = d ro_h @ Wro[lat1]^T" and "d a1 = d lat1 @ Wout_1^T" as ONE 64x64 layer (folded at pack time): 12 instead of 14 steps
+        ca.nlayers = 3;
+        ca.L[0] = chain_layer(E, in, 0, wt(p->o_b3af_q), 64, 64, cn, nullptr, &z1, nullptr, 0, 0, 0);
+        ca.L[0].a_mode = 1;
+        ca.L[1] = chain_layer(E, in, 0, wt(p->o_b3b_q), 128, S * L, c2, nullptr, nullptr, nullptr, 1, -1, 0);
+        ca.L[1].a_mode = 1;
+        ca.L[2] = chain_layer(E, none, 0, wt(p->o_b3c_q), 64, u, c3, nullptr, nullptr, nullptr, 1, -1, 0);
+      }
       if (int rc = run_chain(ca, "B3")) return rc;
     } else
     // readout
@@ -1774,6 +1867,9 @@ struct Runner {
           // (the fused reverse tail below takes it from here: layer-0 tensor product reverse + first-stage / embed-MLP reverse + edge reverse)
         } else {
           m.ld_ga = S;
+          // (after a fused forward the embedding's slot holds a_e = silu(h) of scalar_embed_mlp and the env weights are folded behind
+          //  its output layer, kFoldEmb1: d a_e comes out instead of d emb)
+          if (kFoldEmb1 && p->o_wt0f && use_fused_fwd(g)) m.wt0 = wt(p->o_wt0f);
           if (int rc = launch_tp_mom_bwd_first<T>(p->chain_pair, m, stream)) return rc;
           if (int rc = mark("tp_mom_bwd_first", p->D + 2 * W + 2 * u + 2 * m.ka0 + 2 * p->D, 2.0 * p->D * u)) return rc;
         }
@@ -1874,7 +1970,25 @@ struct Runner {
       ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0tq), p->ng0, S, cn, nullptr, nullptr, &ad, 0, 0, 0);
       ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wtq[1]), S, 64, cn, nullptr, &zz, nullptr, 1, 0, 0);
       ca.L[2] = chain_layer(E, none, 0, wt(p->embed.wtq[0]), 64, c.embed_dim, ce, nullptr, nullptr, nullptr, 1, -1, 0);
-      if (p->embed_fused && p->o_embtab_h) {
+      if (kFoldEmb1 && p->o_g0tfq && use_fused_fwd(g)) {
+        // everything in front of the hidden layer of scalar_embed_mlp folded (kFoldEmb1; the forward stored a_e, not the embedding):
+        // d h = ((d[two-body | w0] @ (W1 G0)^T) + d a_e of the moments) x silu'(h) -- ONE 256 -> 64 layer, 8 steps -- ...
+        ca.nlayers = 1;
+        ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0tfq), p->ng0, 64, cn, nullptr, &zz, &ad, 0, 0, 0);
+        if (p->embed_fused && p->o_embtab_h) {
+          // ... contracted against the folded two-body table in its epilogue
+          ca.L[0].embrev_out = buf(w.trev);
+          ca.emb_table = wt(p->o_embtab_h);
+          ca.num_types = c.num_types;
+          ca.types = g->types;
+          ca.center = g->center;
+          ca.nbr = g->nbr;
+        } else {
+          // ... (three species: no table in the chain's LDS) followed by W0^T -> d emb0 for the edge reverse
+          ca.nlayers = 2;
+          ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wtq[0]), 64, c.embed_dim, ce, nullptr, nullptr, nullptr, 1, -1, 0);
+        }
+      } else if (p->embed_fused && p->o_embtab_h) {
         // folded table (kFoldEmbed): d_h, the output of the second layer, is contracted straight back to the 8 basis functions
         // with T = tab @ W0 -- the layer W0^T and d emb0 do not exist
         ca.nlayers = 2;
