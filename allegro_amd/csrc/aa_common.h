@@ -260,6 +260,11 @@ struct ChainLayer {
   int keep_tile;     // first of the two output tiles kept for the next layer, or -1
   int keep_act;      // silu on the kept values
   int a_mode;        // 1: A[e,k] = ro_factor * scale(type(center e)) * ro_w[k] * silu'(a[e,k])  (readout reverse)
+                     // 2: A[e,k] = (a[e,k] + a2_add[e,k]) * silu'(a2_z[e,k]): the elementwise tail of a folded-away linear layer as the
+                     //    operand transform of the next one (layers whose operand is split once: <= 2 k chunks, > 2 output tiles)
+  const void* a2_add;  // [M, ld_a2add] (a_mode 2)
+  const void* a2_z;    // [M, ld_a2z]
+  int ld_a2add, ld_a2z;
   void* embrev_out;    // [M][8] or nullptr: out[e,n] = sum_c C[e,c] * emb_table[pair(e)][n][c] of this 64-wide layer -- the
                        // reverse of the two-body basis expansion folded into the epilogue (C itself need not be stored)
   void* edge_sum_out;  // [M] or nullptr: out[e] = sum_c silu(C[e,c]) * ro_w[c] of this (64-wide) layer -- the last linear
@@ -608,6 +613,14 @@ constexpr bool kFoldEmbed = true;
 constexpr bool kFoldLatent = false;
 #else
 constexpr bool kFoldLatent = true;
+#endif
+// reverse side of the lat0 fold: Wout_0^T rides in the lat0 columns of the readout-reverse chain's second layer, and what is left
+// of the output layer's reverse -- (d a_0 + d a_0 of the moments) x silu'(h) -- is the operand transform (a_mode 2) of the
+// latent-0 reverse chain, which is then ONE layer (4 steps instead of 6).  -DAA_NO_FOLD_LAT0_REV: A/B.
+#if defined(AA_NO_FOLD_LAT0_REV) || defined(AA_NO_FOLD_LATENT)
+constexpr bool kFoldLat0Rev = false;
+#else
+constexpr bool kFoldLat0Rev = true;
 #endif
 // ... and at the front: EDGE_EMBEDDING = a_e @ W1 (the linear output layer of scalar_embed_mlp, a_e = silu(h)) only ever enters
 // linear maps -- env_embed_linear / first_layer_env_embed_projection (tensorembed.py:88-89, _allegro.py:251-258) and, through

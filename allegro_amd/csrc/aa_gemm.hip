@@ -1124,6 +1124,8 @@ struct ChainLayerDev {
   int use_prev, pad2_;
   float* edge_sum_out;
   float* embrev_out;
+  const float *a2_add, *a2_z;  // a_mode 2 operand transform
+  int ld_a2add, ld_a2z;
   const float* a[kChainMaxBlocks];
   int lda[kChainMaxBlocks];
   ChainTileDev t[kChainMaxBlocks];
@@ -1223,6 +1225,22 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
         for (int e = 0; e < 4; ++e) a[q][e] = rofac * wv4[e] * dsilu(a[q][e]);
       }
     }
+  };
+  // a_mode 2 (only in layers whose operand is split once, OUTSIDE the step loop -- the streaming steps keep their uniform
+  // vector-memory sequence; launch_gemm_chain checks the shape): A = (a + add) * silu'(z)
+  auto finish_a2 = [&](const ChainLayerDev& L, int kc, v4f* a) {
+    const float* pa = L.a2_add + gmc * L.ld_a2add + kc * 32 + 4 * hh;
+    const float* pz = L.a2_z + gmc * L.ld_a2z + kc * 32 + 4 * hh;
+    v4f ad[4], zz[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ad[q] = *reinterpret_cast<const v4f*>(pa + 8 * q);
+      zz[q] = *reinterpret_cast<const v4f*>(pz + 8 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[q][e] = (a[q][e] + ad[q][e]) * dsilu(zz[q][e]);
   };
   // chained chunk j of a layer: the kept pair (use_prev)
   auto kept_a = [&](const ChainLayerDev& L, int j, v4f* a) {
@@ -1371,7 +1389,10 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
               kept_a(L, kc - KCg, a);
             } else {
               load_a(L, kc, a);
-              finish_a(L, kc, a);
+              if (L.a_mode == 2)
+                finish_a2(L, kc, a);
+              else
+                finish_a(L, kc, a);
             }
             chain_split(a, ps1[kc], ps2[kc], ps3[kc]);
           }
@@ -1568,6 +1589,14 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
     D.keep_tile = L.keep_tile;
     D.keep_act = L.keep_act;
     D.a_mode = L.a_mode;
+    if (L.a_mode == 2) {
+      if (!L.a2_add || !L.a2_z || (L.ld_a2add & 3) || (L.ld_a2z & 3) || L.use_prev || g.a.count != 1 || !(nchunk <= 2 && ntile > 2))
+        return fail(AA_ERR_INVALID, "gemm chain: a_mode 2 needs one A segment of <= 2 chunks, > 2 output tiles, and its add / z arrays");
+      D.a2_add = static_cast<const float*>(L.a2_add);
+      D.a2_z = static_cast<const float*>(L.a2_z);
+      D.ld_a2add = L.ld_a2add;
+      D.ld_a2z = L.ld_a2z;
+    }
     if (L.a_mode == 1) {
       if (!c.ro_w) return fail(AA_ERR_INVALID, "gemm chain: a_mode 1 needs ro_w");
       d.ro_n = std::max(d.ro_n, nchunk * 32);

@@ -219,6 +219,7 @@ struct aa_model_plan {
   size_t o_lat1in_fq, o_ro0_fq;      // (kFoldLatent, 2-layer 64-wide stacks) bf16x3 copies of the first layers of latent 1 / edge_readout with the
                                      // latent output layers folded into their lat_l row blocks, or 0
   size_t o_b3af_q;                   // ... and of the merged first layer of the readout-reverse chain, or 0
+  size_t o_b3bf_q;                   // ... and of its second layer with Wout_0^T folded into the lat0 columns (d a_0 instead of d lat0), or 0
   size_t o_g0fq, o_g0tfq;            // (kFoldEmb1) bf16x3 copies of W1 @ G0 [64, ng0] and of its transpose, or 0
   size_t o_wk0f, o_wt0f;             // (kFoldEmb1) W1 @ Wenv0 as [k][R][u] and [R][u][k], or 0
   int ng0;                           // output width of the fused first-stage GEMM
@@ -445,7 +446,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     p->o_ro_last = take(p->ro_last_dim);
   }
   p->o_b3a_q = p->o_b3b_q = p->o_b3c_q = 0;
-  p->o_lat1in_fq = p->o_ro0_fq = p->o_b3af_q = 0;
+  p->o_lat1in_fq = p->o_ro0_fq = p->o_b3af_q = p->o_b3bf_q = 0;
   p->o_g0fq = p->o_g0tfq = p->o_wk0f = p->o_wt0f = 0;
   if (kFoldEmb1 && p->chain_gemm && p->env_mom && L == 2 && u == 64) {
     p->o_g0fq = take(gemm_bf16x3_words(64, p->ng0));
@@ -457,6 +458,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     p->o_lat1in_fq = take(gemm_bf16x3_words(2 * S + u, 64));
     p->o_ro0_fq = take(gemm_bf16x3_words(3 * S, 64));
     p->o_b3af_q = take(gemm_bf16x3_words(64, 64));
+    if (kFoldLat0Rev) p->o_b3bf_q = take(gemm_bf16x3_words(128, S * L));
   }
   {
     // two-body table [T*T][B][S0] (type embedding x basis weights): the last reverse chain contracts against it (<= 2
@@ -577,7 +579,7 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
                      uint64_t(p->n_elems)})
     mix(v);
   for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
-                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h, p->o_lat1in_fq, p->o_ro0_fq, p->o_b3af_q, p->o_g0fq, p->o_g0tfq, p->o_wk0f, p->o_wt0f})
+                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h, p->o_lat1in_fq, p->o_ro0_fq, p->o_b3af_q, p->o_b3bf_q, p->o_g0fq, p->o_g0tfq, p->o_wk0f, p->o_wt0f})
     mix(v);
   for (int l = 0; l < c.num_layers; ++l) {
     mix(p->o_tpw[l]);
@@ -927,6 +929,33 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
           af[size_t(k) * 64 + m] = float(v);
         }
       gemm_pack_bf16x3(af.data(), 64, 64, reinterpret_cast<unsigned*>(&hf[p->o_b3af_q]));
+      // second layer of that chain, [readout' ; latent-1'] -> (d two-body | d lat0): with Wout_0^T folded into the lat0 columns it
+      // yields d a_0 (before the moments' share and silu'), and the latent-0 reverse chain needs no output-layer reverse
+      {
+        const int SL = S * L;
+        const float* rt = &hf[p->readout.wt[0]];
+        const float* lt = &hf[p->latent[L - 1].wt[0]];
+        const int N2 = SL + c.num_tensor, SL1_ = p->SL1;
+        if (p->o_b3bf_q) {
+        std::vector<double> b(size_t(128) * SL);
+        for (int k = 0; k < 64; ++k)
+          for (int n = 0; n < SL; ++n) {
+            b[size_t(k) * SL + n] = rt[size_t(k) * SL1_ + n];
+            b[size_t(64 + k) * SL + n] = lt[size_t(k) * N2 + n];
+          }
+        std::vector<float> bf(size_t(128) * SL);
+        for (int k = 0; k < 128; ++k)
+          for (int n = 0; n < SL; ++n) {
+            double v = b[size_t(k) * SL + n];
+            if (n >= S) {  // lat0 column block -> hidden unit m = n - S of latent 0
+              v = 0.0;
+              for (int q = 0; q < 64; ++q) v += b[size_t(k) * SL + S + q] * wo0[size_t(n - S) * 64 + q];
+            }
+            bf[size_t(k) * SL + n] = float(v);
+          }
+        gemm_pack_bf16x3(bf.data(), 128, SL, reinterpret_cast<unsigned*>(&hf[p->o_b3bf_q]));
+        }
+      }
     }
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, hf.data(), hf.size() * 4, hipMemcpyHostToDevice, s));
   }
@@ -1297,6 +1326,7 @@ struct Runner {
     for (int i = 0; i < ca.nlayers; ++i) {
       if (o < 28) o += snprintf(nm + o, sizeof(nm) - o, "_%dx%d", ca.L[i].g.K, ca.L[i].g.N);
       elems += gemm_row_elems(ca.L[i].g, true);  // a is an empty list for use_prev layers (kept tile in registers)
+      if (ca.L[i].a_mode == 2) elems += 2.0 * ca.L[i].g.a.s[0].n;  // (+ the add and z rows of the operand transform)
       fl += 2.0 * double(E) * ca.L[i].g.K * ca.L[i].g.N;
     }
     (void)tag;
@@ -1772,7 +1802,7 @@ struct Runner {
         ca.nlayers = 3;
         ca.L[0] = chain_layer(E, in, 0, wt(p->o_b3af_q), 64, 64, cn, nullptr, &z1, nullptr, 0, 0, 0);
         ca.L[0].a_mode = 1;
-        ca.L[1] = chain_layer(E, in, 0, wt(p->o_b3b_q), 128, S * L, c2, nullptr, nullptr, nullptr, 1, -1, 0);
+        ca.L[1] = chain_layer(E, in, 0, wt(p->o_b3bf_q ? p->o_b3bf_q : p->o_b3b_q), 128, S * L, c2, nullptr, nullptr, nullptr, 1, -1, 0);
         ca.L[1].a_mode = 1;
         ca.L[2] = chain_layer(E, none, 0, wt(p->o_b3c_q), 64, u, c3, nullptr, nullptr, nullptr, 1, -1, 0);
       }
@@ -1824,6 +1854,18 @@ struct Runner {
         int acc1[3] = {1, 0, 0};
         ca.L[0] = chain_layer(E, in, 0, wt(p->latent[l].wtq[1]), S, 64, cn, nullptr, &zz, &ad, 0, 0, 0);
         ca.L[1] = chain_layer(E, none, 0, wt(p->latent[l].wtq[0]), 64, S * (l + 1) + u, c1, acc1, nullptr, nullptr, 1, -1, 0);
+        if (kFoldLat0Rev && p->o_b3bf_q && L == 2 && l == 0) {
+          // the readout-reverse chain already applied Wout_0^T (folded into its lat0 columns): what is left of the output layer's
+          // reverse is elementwise -- d h = (d a_0 + d a_0 of the moments) x silu'(h) -- and rides as the operand transform of the
+          // first-layer reverse: ONE layer, 4 steps instead of 6
+          ca.nlayers = 1;
+          ca.L[0] = chain_layer(E, in, 0, wt(p->latent[l].wtq[0]), 64, S * (l + 1) + u, c1, acc1, nullptr, nullptr, 0, -1, 0);
+          ca.L[0].a_mode = 2;
+          ca.L[0].a2_add = buf(w.g_aenv);
+          ca.L[0].ld_a2add = 64;
+          ca.L[0].a2_z = buf(w.lat_h[l][0]);
+          ca.L[0].ld_a2z = 64;
+        }
         if (int rc = run_chain(ca, "B2")) return rc;
       } else {
       SegList go;
