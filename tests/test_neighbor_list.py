@@ -207,3 +207,36 @@ def test_device_ghost_layout_emulated():
 @pytest.mark.gpu
 def test_device_ghost_layout_on_gpu():
     _ghost_layout_case(None, torch.device("cuda:0"))
+
+
+def test_graph_fingerprint_is_position_dependent_and_reproducible_emulated():
+    """`aa_graph_fingerprint` (what the exported op validates its graph cache with): same contents -> same 128 bits, any change
+    of an entry OR of the order -> different; int32 and int64 type arrays."""
+    import ctypes as C
+
+    from tests.hip_utils import emu_lib
+
+    lib = emu_lib().lib
+    lib.aa_graph_fingerprint.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    g = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, 50, (2, 777), generator=g)
+    types = torch.randint(0, 3, (50,), generator=g)
+
+    def fp(e, t):
+        out = torch.zeros(2, dtype=torch.int64)
+        e = e.contiguous()
+        assert lib.aa_graph_fingerprint(e.data_ptr(), e.stride(0), e.shape[1], t.data_ptr(), int(t.dtype == torch.int64), t.numel(),
+                                        out.data_ptr(), None) == 0
+        return tuple(out.tolist())
+
+    base = fp(ei, types)
+    assert fp(ei.clone(), types.clone()) == base
+    e2 = ei.clone()
+    e2[1, 500] += 1
+    assert fp(e2, types)[0] != base[0] and fp(e2, types)[1] == base[1]
+    assert fp(ei.flip(1), types)[0] != base[0]  # a permutation of the same edges is another list (other CSR permutation)
+    t2 = types.clone()
+    t2[7] = (t2[7] + 1) % 3
+    assert fp(ei, t2)[1] != base[1] and fp(ei, t2)[0] == base[0]
+    assert fp(ei, types.to(torch.int32)) == base  # same values, other integer width
+    assert fp(ei[:, :0], types[:0]) == (0, 0)
