@@ -54,6 +54,13 @@ __device__ unsigned long long g_fused_ticks[32];
 #define AA_TICK(i)
 #endif
 
+// number of weight-pipeline steps of the program for R irreps: what the host builds (aa_model.hip: forward_fused) and what the
+// kernel consumes -- asserted against each other at compile time (a silent mismatch shifts every later layer's weights)
+constexpr int fused_fwd_steps(int R, bool hold) {
+  const int ps = kProjMfma ? 2 * R : 4;  // one env projection
+  return (kFoldEmbed ? (kFoldEmb1 ? 0 : 2) : 4) + ps + (2 + 2 * R) + 4 + ps + (kFoldLatent ? 0 : 2) + (hold ? 0 : 2 * R) + 6 + (kFoldLatent ? 0 : 2) + 6;
+}
+
 // x[D] (lane = channel) summed over the waves [first, first + tsize) of a team, in that order (every member ends up with the
 // same bits); tsize is workgroup-uniform, so the barrier is too.  The exchange area is reused by the next call only after
 // dozens of weight-pipeline barriers.
@@ -92,9 +99,11 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
   static_assert(Sig0::D1 == D && Sig0::DOUT == D && Sig1::D1 == D && Sig1::DOUT == 1, "standard 2-layer stack");
   static_assert(D <= 16, "l_max <= 3");
   // the program: L0 L1 | Wenv0 | L2 | L3 | Wenv1 | L4 | (L5: w0 again, unless held) | L6 L7 L8
-  constexpr int S_L0 = 0, S_L1 = kFoldEmbed ? 0 : 2, S_P0 = S_L1 + (kFoldEmb1 ? 0 : 2), S_L2 = S_P0 + 4, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L4 = S_P1 + 4,
+  constexpr int kPS = kProjMfma ? 2 * R : 4;  // pipeline steps of one env projection
+  constexpr int S_L0 = 0, S_L1 = kFoldEmbed ? 0 : 2, S_P0 = S_L1 + (kFoldEmb1 ? 0 : 2), S_L2 = S_P0 + kPS, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L4 = S_P1 + kPS,
                 S_L5 = S_L4 + (kFoldLatent ? 0 : 2), S_L6 = S_L5 + (HOLD ? 0 : 2 * R), S_L7 = S_L6 + 6, S_L8 = S_L7 + (kFoldLatent ? 0 : 2), NS = S_L8 + 6;
   static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps, "the two LDS buffers alternate consistently across iterations");
+  static_assert(NS == fused_fwd_steps(R, HOLD), "kernel and host disagree about the length of the weight program");
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);            // [64] last readout weights
   float* sRm = sRo + 64;                                               // [16: T*T <= 9 used] 1 / r_max per type pair, then [8] Bessel roots at 16
@@ -338,7 +347,10 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     {
       float M[D];
       tile_moments<D>(sW, sY, em0, em1, lane, M);
-      project_moments<S_P0, NS, D, R>(A, p, sW, M, A.sf, x2s0);
+      if constexpr (kProjMfma)
+        project_moments_mfma<S_P0, NS, D, R>(A, p, sW, M, A.sf, x2s0);
+      else
+        project_moments<S_P0, NS, D, R>(A, p, sW, M, A.sf, x2s0);
       if constexpr (TEAMS) team_sum<D>(sTeam, wvs, tfirst, tsize, lane, x2s0);
       if (atom_ok && leader) {
 #pragma unroll
@@ -412,7 +424,10 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     {
       float M[D], x2s1[D];
       tile_moments<D>(sW, sY, k0, k1, lane, M);
-      project_moments<S_P1, NS, D, R>(A, p, sW, M, A.sf, x2s1);
+      if constexpr (kProjMfma)
+        project_moments_mfma<S_P1, NS, D, R>(A, p, sW, M, A.sf, x2s1);
+      else
+        project_moments<S_P1, NS, D, R>(A, p, sW, M, A.sf, x2s1);
       if constexpr (TEAMS) team_sum<D>(sTeam, wvs, tfirst, tsize, lane, x2s1);
       if (atom_ok && leader) {
 #pragma unroll
@@ -593,9 +608,7 @@ size_t fused_fwd_lds_bytes(int num_types, bool teams) {
 }
 
 // number of weight-pipeline steps of the program for R irreps (see the kernel)
-int fused_fwd_num_steps(int R, bool hold) {
-  return (kFoldEmbed ? (kFoldEmb1 ? 4 : 6) : 8) + (2 + 2 * R) + 4 + 4 + (kFoldLatent ? 0 : 2) + (hold ? 0 : 2 * R) + 6 + (kFoldLatent ? 0 : 2) + 6;
-}
+int fused_fwd_num_steps(int R, bool hold) { return fused_fwd_steps(R, hold); }
 
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;

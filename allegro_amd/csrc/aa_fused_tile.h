@@ -274,5 +274,66 @@ __device__ __forceinline__ void project_moments(const Args& A, FusedPipe& p, flo
   for (int j = 0; j < D; ++j) x2s[j] *= sf;
 }
 
+// The same projection on the matrix cores (kProjMfma).  The moments go through sM [k][kLdY] into an operand tile pair in
+// accumulator layout whose 32 columns are the components j (columns >= D carry zeros) and whose features are k; irrep r's 64x64
+// env-weight matrix is an ordinary bf16x3 layer (steps S0 + 2 r, S0 + 2 r + 1) whose output columns j in irrep r are kept; the
+// result returns to the lane = channel view through sX [D][64] behind sM.
+template <int S0, int NS, int D, int R, class Args>
+__device__ __forceinline__ void project_moments_mfma(const Args& A, FusedPipe& p, float* sM, const float* M, float sf, float* x2s) {
+  const int lane = p.lane, el = lane & 31, hh = lane >> 5;
+  float* sX = sM + 64 * kLdY;
+  static_assert(64 * kLdY + 16 * 64 <= kWaveRegion, "moments + result patch must fit the wave region");
+#pragma unroll
+  for (int q = 0; q < (D + 3) / 4; ++q) {
+    v4f mm;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mm[i] = 4 * q + i < D ? M[4 * q + i] : 0.f;
+    *reinterpret_cast<v4f*>(sM + lane * kLdY + 4 * q) = mm;
+  }
+#pragma unroll
+  for (int q = (D + 3) / 4; q < kLdY / 4; ++q) *reinterpret_cast<v4f*>(sM + lane * kLdY + 4 * q) = v4f{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_wave_barrier();
+  XSplit xs[2];
+  {
+    v16f t0, t1;
+    const int col = el < kLdY ? el : kLdY - 1;  // (columns beyond the patch: any value, never read back)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int k = 8 * (s >> 2) + 4 * hh + (s & 3);
+      t0[s] = sM[k * kLdY + col];
+      t1[s] = sM[(32 + k) * kLdY + col];
+    }
+    xsplit_from_acc(t0, xs[0]);
+    xsplit_from_acc(t1, xs[1]);
+  }
+  static_for<0, R>([&](auto rr) {
+    constexpr int r = decltype(rr)::value;
+    v16f acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc0[q] = 0.f;
+      acc1[q] = 0.f;
+    }
+    static_for<0, 2>([&](auto kcc) {
+      constexpr int kc = decltype(kcc)::value;
+      constexpr int S = S0 + 2 * r + kc;
+      pipe_issue<S, NS>(A, p);
+      fused_mma_step(p.wbuf + (S & 1) * kWStep, p.lane, xs[kc], acc0, acc1);
+      pipe_commit<S>(p);
+    });
+    if (el >= r * r && el < (r + 1) * (r + 1)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<v4f*>(sX + el * 64 + 8 * q + 4 * hh) = v4f{acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]};
+        *reinterpret_cast<v4f*>(sX + el * 64 + 32 + 8 * q + 4 * hh) = v4f{acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]};
+      }
+    }
+  });
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < D; ++j) x2s[j] = sX[j * 64 + lane] * sf;
+  __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace
 }  // namespace aa

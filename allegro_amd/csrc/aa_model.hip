@@ -222,6 +222,7 @@ struct aa_model_plan {
   size_t o_b3bf_q;                   // ... and of its second layer with Wout_0^T folded into the lat0 columns (d a_0 instead of d lat0), or 0
   size_t o_g0fq, o_g0tfq;            // (kFoldEmb1) bf16x3 copies of W1 @ G0 [64, ng0] and of its transpose, or 0
   size_t o_wk0f, o_wt0f;             // (kFoldEmb1) W1 @ Wenv0 as [k][R][u] and [R][u][k], or 0
+  size_t o_wkq[AA_MAX_LAYERS];       // (kProjMfma, fused forward) Wenv_l as R bf16x3 64x64 layers [r][k -> ch] (layer 0: the folded one), or 0
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
 #ifdef AA_EXPERIMENTAL_TAIL
@@ -448,6 +449,9 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   p->o_b3a_q = p->o_b3b_q = p->o_b3c_q = 0;
   p->o_lat1in_fq = p->o_ro0_fq = p->o_b3af_q = p->o_b3bf_q = 0;
   p->o_g0fq = p->o_g0tfq = p->o_wk0f = p->o_wt0f = 0;
+  for (int l = 0; l < AA_MAX_LAYERS; ++l) p->o_wkq[l] = 0;
+  if (kProjMfma && p->chain_gemm && p->env_mom && L == 2 && u == 64)
+    for (int l = 0; l < L; ++l) p->o_wkq[l] = take(size_t(p->R) * gemm_bf16x3_words(64, 64));
   if (kFoldEmb1 && p->chain_gemm && p->env_mom && L == 2 && u == 64) {
     p->o_g0fq = take(gemm_bf16x3_words(64, p->ng0));
     p->o_g0tfq = take(gemm_bf16x3_words(p->ng0, 64));
@@ -489,7 +493,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     // aa_plan_options.fused_forward: 0 / 1 = whenever the graph allows (max_degree <= 32), 3 = never (staged pipeline).
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
                           u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0 && (!kFoldEmbed || p->o_embtab_h != 0) &&
-                          (!kFoldLatent || p->o_lat1in_fq != 0) && (!kFoldEmb1 || p->o_g0fq != 0);
+                          (!kFoldLatent || p->o_lat1in_fq != 0) && (!kFoldEmb1 || p->o_g0fq != 0) && (!kProjMfma || p->o_wkq[0] != 0);
     p->fused_fwd = eligible && opt.fused_forward != 3;
 #ifdef AA_EXPERIMENTAL_TAIL
     p->fused_tail = p->fused_fwd && p->embed_fused && (opt.fused_tail == 1 || opt.fused_tail == 2);
@@ -579,7 +583,7 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
                      uint64_t(p->n_elems)})
     mix(v);
   for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
-                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h, p->o_lat1in_fq, p->o_ro0_fq, p->o_b3af_q, p->o_b3bf_q, p->o_g0fq, p->o_g0tfq, p->o_wk0f, p->o_wt0f})
+                   p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h, p->o_lat1in_fq, p->o_ro0_fq, p->o_b3af_q, p->o_b3bf_q, p->o_g0fq, p->o_g0tfq, p->o_wk0f, p->o_wt0f, p->o_wkq[0], p->o_wkq[1]})
     mix(v);
   for (int l = 0; l < c.num_layers; ++l) {
     mix(p->o_tpw[l]);
@@ -879,6 +883,17 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       gemm_pack_bf16x3(a.data(), 64, S, reinterpret_cast<unsigned*>(&hf[p->o_b3a_q]));
       gemm_pack_bf16x3(b.data(), 128, SL, reinterpret_cast<unsigned*>(&hf[p->o_b3b_q]));
       gemm_pack_bf16x3(cmat.data(), 64, c.num_tensor, reinterpret_cast<unsigned*>(&hf[p->o_b3c_q]));
+    }
+    for (int l = 0; l < L && l < 2; ++l) {
+      if (!p->o_wkq[l]) continue;
+      // (kProjMfma) env weights of layer l as one 64x64 bf16x3 layer per irrep: W_r[k][ch] = Wenv_l[k][r][ch]
+      const size_t src = (l == 0 && p->o_wk0f) ? p->o_wk0f : p->o_wk[l];
+      std::vector<float> wr(size_t(64) * 64);
+      for (int r = 0; r < p->R; ++r) {
+        for (int k = 0; k < 64; ++k)
+          for (int ch = 0; ch < 64; ++ch) wr[size_t(k) * 64 + ch] = float(h[src + (size_t(k) * p->R + r) * 64 + ch]);
+        gemm_pack_bf16x3(wr.data(), 64, 64, reinterpret_cast<unsigned*>(&hf[p->o_wkq[l] + size_t(r) * gemm_bf16x3_words(64, 64)]));
+      }
     }
     if (p->o_g0fq) {
       // (kFoldEmb1) first stage behind the output layer of scalar_embed_mlp: W1 @ G0 and its transpose
@@ -1570,10 +1585,17 @@ struct Runner {
     const bool folde = kFoldEmb1 && p->o_g0fq != 0;  // (see kFoldEmb1: no layer L1; first stage and env weights behind W1)
     if (!kFoldEmbed) add_layer(wf(p->embed.wq[0]), 2, 0, 2);
     if (!folde) add_layer(wf(p->embed.wq[1]), 2, 0, 2);
-    add_env(wf(folde ? p->o_wk0f : p->o_wk[0]));
+    auto add_proj = [&](int l, const float* Wk) {  // one env projection: R bf16x3 64x64 layers (kProjMfma) or 4 blocks of env-weight rows
+      if (kProjMfma && p->o_wkq[l]) {
+        for (int r = 0; r < p->R; ++r) add_layer(wf(p->o_wkq[l]) + size_t(r) * gemm_bf16x3_words(64, 64), 2, 0, 2);
+      } else {
+        add_env(Wk);
+      }
+    };
+    add_proj(0, wf(folde ? p->o_wk0f : p->o_wk[0]));
     add_layer(wf(folde ? p->o_g0fq : p->o_g0q), 2, 0, 2 + 2 * p->R);
     add_layer(wf(p->latent[0].wq[0]), 4, 0, 2);
-    add_env(wf(p->o_wk[1]));
+    add_proj(1, wf(p->o_wk[1]));
     const bool foldl = kFoldLatent && p->o_lat1in_fq != 0;  // (see kFoldLatent: no output layers L4 / L7, folded consumers)
     if (!foldl) add_layer(wf(p->latent[0].wq[1]), 2, 0, 2);
     if (!hold) add_layer(wf(folde ? p->o_g0fq : p->o_g0q), 2, 2, 2 * p->R);  // the w0 columns of the first-stage matrix again

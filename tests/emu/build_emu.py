@@ -19,6 +19,13 @@ if EXPERIMENTAL:
     LIB = os.path.join(OUT_DIR, "liballegro_amd_emu_experimental.so")
 
 
+EXTRA = [d for d in os.environ.get("AA_EMU_DEFINES", "").split() if d]  # e.g. "-DAA_NO_PROJ_MFMA" (A/B debugging of kernel variants)
+if EXTRA:
+    import hashlib
+
+    LIB = LIB[:-3] + "_" + hashlib.sha1(" ".join(EXTRA).encode()).hexdigest()[:8] + ".so"
+
+
 def build_emu(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
@@ -27,7 +34,7 @@ def build_emu(force=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     cxx = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-    cmd = [cxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-Wno-unused-function", "-Wno-psabi"] + (["-DAA_EXPERIMENTAL_TAIL"] if EXPERIMENTAL else []) + [
+    cmd = [cxx, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-Wno-unused-function", "-Wno-psabi"] + EXTRA + (["-DAA_EXPERIMENTAL_TAIL"] if EXPERIMENTAL else []) + [
            "-I", os.path.join(HERE, "include"), "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "emu_runtime.cpp"), "-o", LIB]
     subprocess.run(cmd, check=True)
