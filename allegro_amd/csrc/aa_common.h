@@ -593,12 +593,14 @@ int launch_tp_spec_bwd(int sig, const TpSpecBwdArgs& a, hipStream_t stream);
 constexpr int kFusedMaxSteps = 56;
 constexpr int kFusedKeepDefault = 2;
 // Env projection of the fused forward, x2s[j][ch] = f sum_k M[j][k] Wenv[k][r(j)][ch], on the matrix cores: the per-atom moments
-// become an operand tile whose 32 "edge" columns are the components j, one 64x64 bf16x3 layer per irrep (2 R steps instead of 4
-// env-weight steps; 1152 FMAs + ~400 latency-bound LDS reads per projection before).  -DAA_NO_PROJ_MFMA: the vector form (A/B).
-#ifdef AA_NO_PROJ_MFMA
-constexpr bool kProjMfma = false;
-#else
+// become an operand tile whose 32 "edge" columns are the components j, one 64x64 bf16x3 layer per irrep (2 R MFMA steps instead
+// of 4 env-weight steps of 288 FMAs each).  Built, parity-green, and measured 2.5 % SLOWER than the vector form on MI355X
+// (same-box A/B, profiles/r04_v12_ab_c4_proj_mfma.txt: fused forward 4.01 -> 4.11 ms): 12 more MFMA steps per tile cost more
+// than the 2 300 FMAs they replace.  -DAA_PROJ_MFMA builds it (A/B); the product uses the vector form.
+#ifdef AA_PROJ_MFMA
 constexpr bool kProjMfma = true;
+#else
+constexpr bool kProjMfma = false;
 #endif
 // The first layer of scalar_embed_mlp is LINEAR in the two-body embedding, and the embedding is linear in the 8 radial basis
 // functions (emb0[c] = sum_n basis[n] tab[pair][n][c], scalarembed.py:60-81 / :157-175), so its pre-activation is
