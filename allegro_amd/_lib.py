@@ -150,6 +150,8 @@ class AllegroLib:
         L.aa_model_file_layout_digest.restype = C.c_uint64
         L.aa_model_file_close.argtypes = [C.c_void_p]
         L.aa_model_file_close.restype = None
+        L.aa_model_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.aa_model_plan_describe.restype = C.c_int
         L.aa_model_check.argtypes = [C.c_void_p, C.c_void_p]
         L.aa_model_check.restype = C.c_int
         L.aa_model_virial.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -515,6 +515,25 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   return AA_OK;
 }
 
+extern "C" int aa_model_plan_describe(const aa_model_plan* p, char* buf, size_t n) {
+  AA_REQUIRE(p && buf && n > 0, "aa_model_plan_describe: null argument");
+  const bool fused = p->fused_fwd;
+  // MFMA steps (one step = a 64-feature tile pair x a 32-deep chunk = 24 bf16 MFMAs per 32-edge tile) of the fused forward: executed
+  // (after the folds) vs the step-equivalents of the reference's linear layers (what `roofline.achieved` prices)
+  const int R = p->R;
+  const int ref_steps = 2 + 2 + (2 + 2 * R) + 4 + 2 + 6 + 2 + 6;
+  const int exec_steps = fused ? fused_fwd_num_steps(R, p->fused_hold_w0) - 8 /* env-projection steps: vector work */ : 0;
+  const int k = snprintf(buf, n,
+                         "{\"fused_forward\": %s, \"fold_embed_table\": %s, \"fold_embed_output\": %s, \"fold_latent_outputs\": %s, "
+                         "\"fold_lat0_reverse\": %s, \"fused_mfma_steps_executed\": %d, \"fused_mfma_steps_reference\": %d, "
+                         "\"chain_gemm\": %s, \"moments\": %s, \"operator_path\": %s}",
+                         fused ? "true" : "false", (fused && kFoldEmbed && p->o_embtab_h) ? "true" : "false",
+                         (fused && kFoldEmb1 && p->o_g0fq) ? "true" : "false", (fused && kFoldLatent && p->o_lat1in_fq) ? "true" : "false",
+                         (kFoldLat0Rev && p->o_b3bf_q) ? "true" : "false", exec_steps, fused ? ref_steps : 0, p->chain_gemm ? "true" : "false",
+                         p->env_mom ? "true" : "false", p->tp_op >= 0 ? "true" : "false");
+  return (k < 0 || size_t(k) >= n) ? fail(AA_ERR_INVALID, "aa_model_plan_describe: buffer too small") : k;
+}
+
 extern "C" int aa_model_check(const aa_model_plan* plan, aa_stream stream) {
   AA_REQUIRE(plan, "aa_model_check: null plan");
   AA_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));

@@ -260,6 +260,11 @@ int aa_model_energy_forces(const aa_model_plan* plan, const void* dev_weights, c
                            const void* pos, void* workspace, size_t workspace_bytes,
                            void* atom_energy, void* forces, aa_stream stream);
 
+/* One-line JSON description of what the plan runs (which forward, which algebraic folds, MFMA steps the fused forward executes
+ * per 32-edge tile against the step-equivalents of the reference's layers) -- for benchmark lines and bug reports.  Returns the
+ * length written (excluding the terminator), or < 0. */
+int aa_model_plan_describe(const aa_model_plan* plan, char* buf, size_t buf_bytes);
+
 /* Synchronises `stream` and reports whether any step enqueued on this plan since the last report contradicted the graph
  * hints it was given (aa_graph.max_degree too small, center atoms with edges outside [atom_begin, atom_end)):
  * AA_ERR_INVALID + aa_last_error() then, AA_OK otherwise; the condition is cleared.  aa_model_energy_forces performs the

@@ -944,6 +944,16 @@ class HipAllegroModel(torch.nn.Module):
                   "aa_model_energy_forces")
         return e_atom, forces
 
+    def describe_plan(self) -> dict:
+        """`aa_model_plan_describe`: which forward / folds the plan of the current device runs (benchmark lines, bug reports)."""
+        import json
+
+        lib = self._get_lib()
+        self._ensure_plan()
+        buf = C.create_string_buffer(1024)
+        lib.check(min(0, lib.lib.aa_model_plan_describe(self._plan_handle, buf, 1024)), "aa_model_plan_describe")
+        return json.loads(buf.value.decode())
+
     def check(self, device=None) -> None:
         """`aa_model_check`: waits for the steps enqueued so far and raises if one of them contradicted the hints of its graph
         (a `max_degree` smaller than a real segment, edges outside the atom block).  `PreparedGraph` derives both hints from

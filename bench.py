@@ -771,6 +771,15 @@ def main():
         if not args.no_profile:
             stages = profile_stages(model, pos if shard is None else (pos_local if halo else pos.index_select(0, shard.local_ids)), graph)
             roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload)
+            if roof.get("kernel", "").startswith("fused_fwd"):
+                # `achieved` prices the REFERENCE's linear-layer flops; the kernel executes fewer since the round-4 folds
+                # (DESIGN.md section 3.2): both are stated so that `frac` is not read as matrix-pipe utilisation
+                d = model.describe_plan()
+                roof["plan"] = d
+                if d.get("fused_mfma_steps_reference"):
+                    ex = d["fused_mfma_steps_executed"] / d["fused_mfma_steps_reference"]
+                    roof["executed_fp32_equiv_TFLOPs"] = roof["achieved"] * ex
+                    roof["executed_frac"] = roof["frac"] * ex
             line["roofline"] = roof
             line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])
             line["stage_ms"] = table
