@@ -240,7 +240,9 @@ struct GemmArgs {
   int c_accum[3];  // per C segment: 1 -> +=
   int has_z;       // multiply result by dsilu(z) (z split like c)
   SegList z;
-  int act_a;       // apply silu to A on load
+  int act_a;       // apply silu to A on load ...
+  int act_lo, act_hi;  // ... to columns [act_lo, act_hi) of A only (multiples of 32; act_hi == 0: every column) -- the folded first
+                       // layers of the slot form read [two-body | pre-activations of earlier latents | tensor scalars]
   int has_add;     // result += add (before the dsilu(z) factor); split like c
   SegList add;
   int force_kernel;  // 0: automatic; 1: native fp32-input MFMA kernel; 3: VALU kernel (aa_debug_gemm_f32 / A-B tests)
@@ -623,6 +625,13 @@ constexpr bool kFoldEmbed = true;
 constexpr bool kFoldLatent = false;
 #else
 constexpr bool kFoldLatent = true;
+#endif
+// The single-layer pipeline's version of all of the above for any depth ("slot form", see aa_model_plan::slot_form): run-time
+// switch aa_plan_options.no_slot_form, build-time -DAA_NO_SLOT_FORM.
+#ifdef AA_NO_SLOT_FORM
+constexpr bool kSlotForm = false;
+#else
+constexpr bool kSlotForm = true;
 #endif
 // reverse side of the lat0 fold: Wout_0^T rides in the lat0 columns of the readout-reverse chain's second layer, and what is left
 // of the output layer's reverse -- (d a_0 + d a_0 of the moments) x silu'(h) -- is the operand transform (a_mode 2) of the

@@ -28,6 +28,9 @@ __device__ __forceinline__ T seg_load(const SegList& sl, int64_t row, int col) {
   return T(0);
 }
 
+// is column k of A activated on load?  (wave-uniform wherever k is a chunk base: the range is 32-granular)
+__device__ __forceinline__ bool a_act(const GemmArgs& g, int k) { return g.act_a && (g.act_hi == 0 || (k >= g.act_lo && k < g.act_hi)); }
+
 template <typename T>
 __device__ __forceinline__ void seg_store(const GemmArgs& g, int64_t row, int col, T v) {
   int c = col;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
       float v = 0.f;
       if (gm < g.M && gk < g.K) {
         v = seg_load<float>(g.a, gm, gk);
-        if (g.act_a) v = silu(v);
+        if (a_act(g, gk)) v = silu(v);
       }
       As[k * GM_LDA + m] = v;
     }
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
       T v = T(0);
       if (gm < g.M && gk < g.K) {
         v = seg_load<T>(g.a, gm, gk);
-        if (g.act_a) v = act_apply(g.act_kind, v);
+        if (a_act(g, gk)) v = act_apply(g.act_kind, v);
       }
       As[k * GV_LDA + m] = v;
     }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
       double v = 0.0;
       if (gm < g.M && gk < g.K) {
         v = seg_load<double>(g.a, gm, gk);
-        if (g.act_a) v = silu(v);
+        if (a_act(g, gk)) v = silu(v);
       }
       As[k * GV_LDA + m] = v;
     }
@@ -330,7 +333,9 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) 
   const int64_t arow = m0 + ar < g.M ? m0 + ar : g.M - 1;
   const int bk = tid >> 4, bn = (tid & 15) * 4;
   v2d ra[4], rb[2];
+  int ra_k0 = 0;  // first column of the operand tile held in ra (its activation is decided when it is stored)
   auto load_tiles = [&](int k0, int nb0) {
+    ra_k0 = k0;
     // the segment holding columns [k0, k0+16): wave-uniform
     int c = k0;
     const double* base = nullptr;
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       double x0 = ra[q][0], x1 = ra[q][1];
-      if (g.act_a) {
+      if (a_act(g, ra_k0)) {
         x0 = silu(x0);
         x1 = silu(x1);
       }
@@ -482,8 +487,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
   };
   // the activation of a fetched chunk, applied when the chunk is about to be used -- NOT next to its loads: there it
   // makes every load wait out its own latency before the next one is issued
-  auto a_activate = [&](v2d (*a)[2]) {
-    if (!g.act_a) return;
+  auto a_activate = [&](int c, v2d (*a)[2]) {
+    if (!a_act(g, 16 * c)) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     stage_load(0, 0);
 #pragma unroll
     for (int c = 0; c < KCMAX; ++c)
-      if (c < KC) a_activate(areg[c]);
+      if (c < KC) a_activate(c, areg[c]);
     stage_write(0);
     __syncthreads();
     int buf = 0;
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     a_load(0, acur);
     stage_write(0);
     wait_vmem_all();  // (enter the loop with nothing in flight, see wait_vmem_all)
-    a_activate(acur);
+    a_activate(0, acur);
     __syncthreads();
     int buf = 0;
     for (int c = 0; c < KC; ++c) {
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
       mma_chunk(smem + buf * 16 * LDB, acur, acc);
       if (more) {
         stage_write(buf ^ 1);
-        a_activate(anext);
+        a_activate(c + 1, anext);
       }
       __syncthreads();
       buf ^= 1;
@@ -664,7 +669,7 @@ __device__ __forceinline__ void load_a_frag(const GemmArgs& g, int64_t gm, int k
   if (p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = reinterpret_cast<const v4f*>(p)[q];
-    if (g.act_a) {
+    if (a_act(g, k)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -921,7 +926,7 @@ __device__ __forceinline__ void load_a_frag_acc(const GemmArgs& g, int64_t gm, i
   if (p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(p + 8 * q + 4 * h);
-    if (g.act_a) {
+    if (a_act(g, chunk * 32)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1688,6 +1693,8 @@ static int check_args(const GemmArgs& g) {
   for (int s = 0; s < g.a.count; ++s) ka += g.a.s[s].n;
   for (int s = 0; s < g.c.count; ++s) nc += g.c.s[s].n;
   if (ka != g.K || nc != g.N) return fail(AA_ERR_INVALID, "gemm: segment widths do not sum to K/N");
+  if (g.act_a && g.act_hi != 0 && ((g.act_lo & 31) || (g.act_hi & 31) || g.act_lo < 0 || g.act_hi <= g.act_lo || g.act_hi > g.K))
+    return fail(AA_ERR_INVALID, "gemm: the activated column range of A must be 32-granular and inside [0, K)");
   if (g.has_add) {
     if (g.add.count != g.c.count) return fail(AA_ERR_INVALID, "gemm: add/c segment mismatch");
     for (int s = 0; s < g.c.count; ++s)

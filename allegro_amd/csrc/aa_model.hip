@@ -187,6 +187,12 @@ struct MlpLayout {
   std::vector<size_t> wq, wtq;  // ... and split into 3 bf16 levels (bf16x3 path; fp32 plans only)
 };
 
+// one linear layer's matrix in the three forms the single-layer kernels take (row-major, MFMA fragment order, bf16x3 levels)
+struct GemmMat {
+  size_t w = 0, wp = 0, wq = 0;
+  int K = 0, N = 0;
+};
+
 struct aa_model_plan {
   aa_model_config cfg;
   aa_plan_options opt{};
@@ -223,6 +229,21 @@ struct aa_model_plan {
   size_t o_g0fq, o_g0tfq;            // (kFoldEmb1) bf16x3 copies of W1 @ G0 [64, ng0] and of its transpose, or 0
   size_t o_wk0f, o_wt0f;             // (kFoldEmb1) W1 @ Wenv0 as [k][R][u] and [R][u][k], or 0
   size_t o_wkq[AA_MAX_LAYERS];       // (kProjMfma, fused forward) Wenv_l as R bf16x3 64x64 layers [r][k -> ch] (layer 0: the folded one), or 0
+  // "Slot form" of the single-layer pipeline (operator-kernel plans: C5 and every standard stack off the tuned 2-layer shape).
+  // The same algebra as kFoldEmb1 / kFoldLatent, for any depth: the output layer of scalar_embed_mlp and of every latent MLP is
+  // folded into its consumers at pack time, so slot l + 1 of the dense-net buffer holds the latent's hidden PRE-ACTIVATION z_l
+  // (consumers activate those columns on load, GemmArgs::act_lo / act_hi) and the layers "a -> lat_l" do not exist.  The reverse
+  // is evaluated BY SLOT, not by consumer: d z_l = ([d readout hidden | d z_{l+1} .. d z_{L-1}] @ stack_l + d a_l of the moments)
+  // * act'(z_l) -- one K-stacked layer with 128-wide output per latent (the accumulator-resident kernel's shape, every slot
+  // written once) instead of wide accumulate-into-the-dense-net layers.
+  bool slot_form;
+  GemmMat s_g0f, s_g0ft;             //   W_last(embed) @ G0 [He, ng0] and its transpose
+  GemmMat s_in[AA_MAX_LAYERS];       //   first layer of latent l with the row blocks of earlier latents folded  [S (l+1) + u, H]
+  GemmMat s_ro0;                     //   first readout layer, folded                                             [SL1, Hr]
+  GemmMat s_rs[AA_MAX_LAYERS];       //   reverse stack of slot l + 1: rows [readout | latent l+1 .. L-1] -> d a_l  [Hr + S (L-1-l), H]
+  GemmMat s_rstb;                    //   reverse stack of slot 0 (two-body): rows [readout | latent 0 .. L-1]      [Hr + S L, S]
+  GemmMat s_sct[AA_MAX_LAYERS];      //   d z_l -> d (tensor scalars of layer l)                                   [H, u]
+  size_t o_s_wk0, o_s_wt0;           //   W_last(embed) @ Wenv0 as [k][R][u] and [R][u][k]
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
 #ifdef AA_EXPERIMENTAL_TAIL
@@ -481,6 +502,34 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     p->o_b3b_q = take(gemm_bf16x3_words(128, S * L));
     p->o_b3c_q = take(gemm_bf16x3_words(64, u));
   }
+  {
+    const int De = cfg->embed_mlp_depth, Hr = cfg->readout_mlp_width, H = cfg->latent_mlp_width;
+    p->slot_form = kSlotForm && !opt.no_slot_form && !p->chain_gemm && p->tp_op >= 0 && p->env_mom && cfg->latent_mlp_depth == 1 && H == S &&
+                   cfg->readout_mlp_depth >= 1 && De >= 1 && cfg->embed_mlp_width == S && (Hr % 16) == 0;
+    p->o_s_wk0 = p->o_s_wt0 = 0;
+    if (p->slot_form) {
+      auto mat = [&](int K, int N) {
+        GemmMat m;
+        m.K = K;
+        m.N = N;
+        m.w = take(size_t(K) * N);
+        m.wp = take(gemm_packed_elems(K, N));
+        m.wq = take(gemm_bf16x3_words(K, N));
+        return m;
+      };
+      p->s_g0f = mat(S, p->ng0);
+      p->s_g0ft = mat(p->ng0, S);
+      for (int l = 0; l < L; ++l) {
+        p->s_in[l] = mat(S * (l + 1) + u, H);
+        p->s_rs[l] = mat(Hr + S * (L - 1 - l), H);
+        p->s_sct[l] = mat(H, u);
+      }
+      p->s_ro0 = mat(p->SL1, Hr);
+      p->s_rstb = mat(Hr + S * L, S);
+      p->o_s_wk0 = take(size_t(S) * p->W);
+      p->o_s_wt0 = take(size_t(S) * p->W);
+    }
+  }
   p->o_scales = take(T);
   p->o_shifts = take(T);
   p->n_elems = o;
@@ -526,11 +575,11 @@ extern "C" int aa_model_plan_describe(const aa_model_plan* p, char* buf, size_t 
   const int k = snprintf(buf, n,
                          "{\"fused_forward\": %s, \"fold_embed_table\": %s, \"fold_embed_output\": %s, \"fold_latent_outputs\": %s, "
                          "\"fold_lat0_reverse\": %s, \"fused_mfma_steps_executed\": %d, \"fused_mfma_steps_reference\": %d, "
-                         "\"chain_gemm\": %s, \"moments\": %s, \"operator_path\": %s}",
+                         "\"chain_gemm\": %s, \"moments\": %s, \"operator_path\": %s, \"slot_form\": %s}",
                          fused ? "true" : "false", (fused && kFoldEmbed && p->o_embtab_h) ? "true" : "false",
                          (fused && kFoldEmb1 && p->o_g0fq) ? "true" : "false", (fused && kFoldLatent && p->o_lat1in_fq) ? "true" : "false",
                          (kFoldLat0Rev && p->o_b3bf_q) ? "true" : "false", exec_steps, fused ? ref_steps : 0, p->chain_gemm ? "true" : "false",
-                         p->env_mom ? "true" : "false", p->tp_op >= 0 ? "true" : "false");
+                         p->env_mom ? "true" : "false", p->tp_op >= 0 ? "true" : "false", p->slot_form ? "true" : "false");
   return (k < 0 || size_t(k) >= n) ? fail(AA_ERR_INVALID, "aa_model_plan_describe: buffer too small") : k;
 }
 
@@ -599,8 +648,14 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
                      uint64_t(c.num_scalar), uint64_t(c.num_tensor), uint64_t(c.embed_dim), uint64_t(c.embed_mlp_width),
                      uint64_t(c.latent_mlp_width), uint64_t(c.readout_mlp_width), uint64_t(p->u_raw), uint64_t(p->use_spec),
                      uint64_t(p->env_mom), uint64_t(p->chain_gemm), uint64_t(p->chain_pair + 1), uint64_t(p->tp_op + 1), uint64_t(p->ng0),
-                     uint64_t(p->n_elems)})
+                     uint64_t(p->n_elems), uint64_t(p->slot_form)})
     mix(v);
+  if (p->slot_form) {
+    auto mixm = [&](const GemmMat& m) { mix(m.w); mix(m.wp); mix(m.wq); };
+    mixm(p->s_g0f); mixm(p->s_g0ft); mixm(p->s_ro0); mixm(p->s_rstb);
+    for (int l = 0; l < c.num_layers; ++l) { mixm(p->s_in[l]); mixm(p->s_rs[l]); mixm(p->s_sct[l]); }
+    mix(p->o_s_wk0); mix(p->o_s_wt0);
+  }
   for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
                    p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h, p->o_lat1in_fq, p->o_ro0_fq, p->o_b3af_q, p->o_b3bf_q, p->o_g0fq, p->o_g0tfq, p->o_wk0f, p->o_wt0f, p->o_wkq[0], p->o_wkq[1]})
     mix(v);
@@ -864,6 +919,95 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
           h[p->o_embtab_h + (size_t(cls) * B + n) * H + k] = acc;
         }
   }
+  std::vector<const GemmMat*> slot_mats;  // (fp32 plans: bf16x3 copies are split off the rounded matrices below)
+  if (p->slot_form) {
+    // slot form: every matrix below is a product / regrouping of the NORMALISED matrices packed above, formed in fp64
+    const int De = c.embed_mlp_depth, Hr = c.readout_mlp_width, H = c.latent_mlp_width, NG = p->ng0, SL1 = p->SL1;
+    auto put = [&](const GemmMat& m, const std::vector<double>& d) {
+      std::copy(d.begin(), d.end(), h.begin() + m.w);
+      gemm_pack_b(&h[m.w], m.K, m.N, &h[m.wp]);
+      slot_mats.push_back(&m);
+    };
+    const double* w1 = &h[p->embed.w[De]];  // [S(=He), S] output layer of scalar_embed_mlp
+    {
+      std::vector<double> gf(size_t(S) * NG), gft(size_t(NG) * S);
+      for (int k = 0; k < S; ++k)
+        for (int q = 0; q < NG; ++q) {
+          double v = 0.0;
+          for (int m = 0; m < S; ++m) v += w1[size_t(k) * S + m] * h[p->o_g0 + size_t(m) * NG + q];
+          gf[size_t(k) * NG + q] = v;
+          gft[size_t(q) * S + k] = v;
+        }
+      put(p->s_g0f, gf);
+      put(p->s_g0ft, gft);
+      for (int k = 0; k < S; ++k)
+        for (int r = 0; r < Rr; ++r)
+          for (int ch = 0; ch < u; ++ch) {
+            double v = 0.0;
+            for (int m = 0; m < S; ++m) v += w1[size_t(k) * S + m] * h[p->o_wk[0] + (size_t(m) * Rr + r) * u + ch];
+            h[p->o_s_wk0 + (size_t(k) * Rr + r) * u + ch] = v;
+            h[p->o_s_wt0 + (size_t(r) * u + ch) * S + k] = v;
+          }
+    }
+    // F(j -> consumer)[m][n] = sum_q Wout_j[m][q] Wc[S (j+1) + q][n]: the consumer's row block of lat_j behind latent j's output layer
+    auto fold_block = [&](int j, const double* wc, int Nc, std::vector<double>& out /* [H][Nc] */) {
+      const double* wo = &h[p->latent[j].w[1]];  // [H, S]
+      out.assign(size_t(H) * Nc, 0.0);
+      for (int m = 0; m < H; ++m)
+        for (int q = 0; q < S; ++q) {
+          const double a = wo[size_t(m) * S + q];
+          const double* row = wc + size_t(S * (j + 1) + q) * Nc;
+          for (int n = 0; n < Nc; ++n) out[size_t(m) * Nc + n] += a * row[n];
+        }
+    };
+    std::vector<double> blk;
+    // forward: folded first layers
+    for (int l = 0; l < L; ++l) {
+      const int K = S * (l + 1) + u;
+      const double* win = &h[p->latent[l].w[0]];  // [K, H]
+      std::vector<double> f(win, win + size_t(K) * H);
+      for (int j = 0; j < l; ++j) {
+        fold_block(j, win, H, blk);
+        std::copy(blk.begin(), blk.end(), f.begin() + size_t(S) * (j + 1) * H);
+      }
+      put(p->s_in[l], f);
+      std::vector<double> sc(size_t(H) * u);
+      for (int k = 0; k < H; ++k)
+        for (int n = 0; n < u; ++n) sc[size_t(k) * u + n] = win[size_t(S * (l + 1) + n) * H + k];
+      put(p->s_sct[l], sc);
+    }
+    const double* wro = &h[p->readout.w[0]];  // [SL1, Hr]
+    {
+      std::vector<double> f(wro, wro + size_t(SL1) * Hr);
+      for (int j = 0; j < L; ++j) {
+        fold_block(j, wro, Hr, blk);
+        std::copy(blk.begin(), blk.end(), f.begin() + size_t(S) * (j + 1) * Hr);
+      }
+      put(p->s_ro0, f);
+    }
+    // reverse, by slot: rows follow the operand [d readout hidden | d z_{l+1} .. d z_{L-1}], columns the hidden units of latent l
+    for (int l = 0; l < L; ++l) {
+      std::vector<double> rs(size_t(Hr + S * (L - 1 - l)) * H);
+      fold_block(l, wro, Hr, blk);
+      for (int k = 0; k < Hr; ++k)
+        for (int m = 0; m < H; ++m) rs[size_t(k) * H + m] = blk[size_t(m) * Hr + k];
+      for (int l2 = l + 1; l2 < L; ++l2) {
+        fold_block(l, &h[p->latent[l2].w[0]], H, blk);
+        for (int k = 0; k < H; ++k)
+          for (int m = 0; m < H; ++m) rs[size_t(Hr + S * (l2 - l - 1) + k) * H + m] = blk[size_t(m) * H + k];
+      }
+      put(p->s_rs[l], rs);
+    }
+    {
+      std::vector<double> tb(size_t(Hr + S * L) * S);
+      for (int k = 0; k < Hr; ++k)
+        for (int n = 0; n < S; ++n) tb[size_t(k) * S + n] = wro[size_t(n) * Hr + k];
+      for (int l2 = 0; l2 < L; ++l2)
+        for (int k = 0; k < H; ++k)
+          for (int n = 0; n < S; ++n) tb[size_t(Hr + S * l2 + k) * S + n] = h[p->latent[l2].w[0] + size_t(n) * H + k];
+      put(p->s_rstb, tb);
+    }
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c.dtype == AA_F64) {
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
@@ -884,6 +1028,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     splitw(p->o_g0t, p->ng0, S, p->o_g0tq);
     for (int l = 0; l < L; ++l) split_mlp(p->latent[l], c.latent_mlp_depth + 1);
     split_mlp(p->readout, c.readout_mlp_depth);
+    for (const GemmMat* m : slot_mats) splitw(m->w, m->K, m->N, m->wq);
     if (p->chain_gemm) {
       const int SL = S * L, SL1 = p->SL1, N2 = SL + c.num_tensor;
       const float* rt = &hf[p->readout.wt[0]];          // [64, SL1]  (transposed first readout layer)
@@ -1159,9 +1304,15 @@ struct Runner {
   T* buf(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   const T* wt(size_t off) const { return wts + off; }
 
+  int gemm(const SegList& a, int act_a, const GemmMat& m, const SegList& c, const SegList* z = nullptr, const SegList* add = nullptr, int act_lo = 0,
+           int act_hi = 0) {
+    return gemm(a, act_a, wt(m.w), wt(m.wp), wt(m.wq), m.K, m.N, c, nullptr, z, add, act_lo, act_hi);
+  }
   int gemm(const SegList& a, int act_a, const T* B, const T* Bp, const T* Bq, int K, int Nn, const SegList& c,
-           const int* accum, const SegList* z, const SegList* add = nullptr) {
+           const int* accum, const SegList* z, const SegList* add = nullptr, int act_lo = 0, int act_hi = 0) {
     GemmArgs g{};
+    g.act_lo = act_lo;
+    g.act_hi = act_hi;
     g.M = E;
     g.K = K;
     g.N = Nn;
@@ -1388,6 +1539,9 @@ struct Runner {
     return m;
   }
 
+  // slot form of the single-layer pipeline (aa_model_plan::slot_form); the debug taps name tensors it never forms
+  bool use_slot() const { return p->slot_form && !p->taps; }
+
   TpOpArgs op_args(const aa_graph* g, int l) const {
     const aa_model_config& c = p->cfg;
     TpOpArgs o{};
@@ -1417,6 +1571,20 @@ struct Runner {
     }
     o.wk = wt(p->o_wk[l]);
     o.wt = wt(p->o_wt[l]);
+    if (use_slot()) {
+      // env inputs are hidden pre-activations everywhere: scalar_embed_mlp's (env weights behind its output layer) for layer 0,
+      // slot l of the dense-net buffer (= z_{l-1}) afterwards
+      if (l == 0) {
+        o.a = buf(w.se_h[c.embed_mlp_depth - 1]);
+        o.ld_a = o.ka = c.embed_mlp_width;
+        o.act = 1;
+        o.wk = wt(p->o_s_wk0);
+        o.wt = wt(p->o_s_wt0);
+      } else {
+        o.a = buf(w.fcat) + size_t(c.num_scalar) * l;
+        o.ld_a = p->SL1;
+      }
+    }
     o.ld_scal = c.num_tensor;
     o.ld_gscal = c.num_tensor;
     o.q = buf(w.q_op);
@@ -1664,6 +1832,7 @@ struct Runner {
     if (int rc = launch_edge_prologue<T>(geom(g, pos), stream)) return rc;
     if (int rc = mark("edge_prologue", idx2 + 6 + (g->shift_vec ? 3 : 0) + 4 + p->D + c.embed_dim)) return rc;
     const SegList none{0, {}};
+    const bool slot = use_slot();
     if (p->chain_gemm) {
       // 3 + 4 + 5a as ONE kernel: emb0 -> h_e -> emb -> [two_body | w0]; hidden layers stay in registers
       ChainArgs ca{};
@@ -1676,6 +1845,15 @@ struct Runner {
       ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wq[1]), 64, S, c1, nullptr, nullptr, nullptr, 1, 0, 0);
       ca.L[2] = chain_layer(E, none, 0, wt(p->o_g0q), 64, p->ng0, c2, nullptr, nullptr, nullptr, 1, -1, 0);
       if (int rc = run_chain(ca, "F1")) return rc;
+    } else if (slot) {
+      // 3: hidden layers of scalar_embed_mlp; 4 + 5a on the activated last hidden layer (output layer folded into G0)
+      const int De = c.embed_mlp_depth, He = c.embed_mlp_width;
+      SegList in{1, {seg(buf(w.emb0), c.embed_dim, c.embed_dim)}};
+      SegList hid{1, {seg(buf(w.se_h[De - 1]), He, He)}};
+      if (int rc = mlp_fwd(p->embed, De, in, w.se_h, hid, 0)) return rc;
+      SegList out{2, {seg(buf(w.fcat), SL1, S), seg(buf(w.w0), W, W)}};
+      act_now = c.act_kind[0];
+      if (int rc = gemm(hid, 1, p->s_g0f, out)) return rc;
     } else {
     // 3: scalar_embed_mlp
     {
@@ -1779,6 +1957,15 @@ struct Runner {
         if (int rc = run_chain(ca, "F2")) return rc;
         continue;
       }
+      if (slot) {
+        // hidden pre-activation z_l straight into slot l + 1; the earlier slots are activated on load (their output layers are
+        // folded into this layer's row blocks)
+        SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
+        SegList zl{1, {seg(buf(w.fcat) + S * (l + 1), SL1, S)}};
+        act_now = c.act_kind[1];
+        if (int rc = gemm(in, l > 0, p->s_in[l], zl, nullptr, nullptr, S, S * (l + 1))) return rc;
+        continue;
+      }
       SegList in{2, {seg(buf(w.fcat), SL1, S * (l + 1)), seg(buf(w.scal[l]), u, u)}};
       SegList out;
       out.count = (l < L - 1 && !p->env_mom) ? 2 : 1;
@@ -1792,9 +1979,14 @@ struct Runner {
       SegList a{1, {seg(buf(w.fcat), SL1, SL1)}};
       for (int i = 0; i < c.readout_mlp_depth; ++i) {
         SegList cs{1, {seg(buf(w.ro_h[i]), c.readout_mlp_width, c.readout_mlp_width)}};
-        if (int rc = gemm(a, i > 0, wt(p->readout.w[i]), wt(p->readout.wp[i]), wt(p->readout.wq[i]), p->readout.dims[i], p->readout.dims[i + 1], cs,
-                          nullptr, nullptr))
+        if (slot && i == 0) {
+          act_now = c.act_kind[1];  // (the activated columns are the latents' hidden layers)
+          if (int rc = gemm(a, 1, p->s_ro0, cs, nullptr, nullptr, S, SL1)) return rc;
+          act_now = c.act_kind[2];
+        } else if (int rc = gemm(a, i > 0, wt(p->readout.w[i]), wt(p->readout.wp[i]), wt(p->readout.wq[i]), p->readout.dims[i], p->readout.dims[i + 1], cs,
+                                 nullptr, nullptr)) {
           return rc;
+        }
         a = cs;
       }
     }
@@ -1802,7 +1994,99 @@ struct Runner {
     return mark("readout_reduce", p->chain_gemm ? 1 : (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1), 1);
   }
 
+  // geometry reverse + force assembly (the end of every reverse pass)
+  int edge_tail(const aa_graph* g, const void* pos, void* forces) {
+    const aa_model_config& c = p->cfg;
+    const int num_gsh = num_gsh_slots(p);
+    EdgeBwdArgs eb{};
+    eb.g = geom(g, pos);
+    eb.g_emb0 = buf(w.g_emb0);
+    eb.g_sh = buf(w.g_sh);
+    eb.num_gsh = num_gsh;
+    eb.forces = forces;
+    if (p->embed_fused) eb.t_in = buf(w.trev);
+    const bool gather = g->t_rowptr && g->t_perm;
+    eb.dvec = buf(w.dvec);
+    eb.gather = gather ? 1 : 0;
+    if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
+    if (int rc = mark("edge_backward", 8.0 / sizeof(T) + 4 + (p->embed_fused ? c.num_bessels : c.embed_dim) + double(num_gsh) * p->D + (gather ? 4 : 6))) return rc;
+    if (gather) {
+      // deterministic force assembly: per atom, own segment minus transposed segment, fixed order (no atomics)
+      ForceGatherArgs fg{N, g->rowptr, g->t_rowptr, g->t_perm, buf(w.dvec), forces};
+      if (int rc = launch_force_gather<T>(fg, stream)) return rc;
+      return mark("force_gather", 8.0 + 4.0 / sizeof(T), 3 + 8.0 / sizeof(T));
+    }
+    return AA_OK;
+  }
+
+  // Reverse pass of the slot form (aa_model_plan::slot_form): per dense-net slot, top down.  Every layer here has a 128-wide (S)
+  // output -- the accumulator-resident kernel's shape -- and writes its slot once.
+  int backward_slot(const aa_graph* g, const void* pos, void* forces) {
+    const aa_model_config& c = p->cfg;
+    const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
+    const int De = c.embed_mlp_depth, He = c.embed_mlp_width, Dr = c.readout_mlp_depth, Hr = c.readout_mlp_width, H = c.latent_mlp_width;
+    if (!(g->t_rowptr && g->t_perm)) AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
+    if (int rc = mark("memset", 0, 3)) return rc;
+    // readout: d (last hidden) from the energy, then its hidden layers down to the first one
+    {
+      ReadoutArgs r = readout_args(g, nullptr);
+      r.g_h = buf(w.g_ro_h[Dr - 1]);
+      act_now = c.act_kind[2];
+      if (int rc = launch_readout_backward<T>(r, stream)) return rc;
+      if (int rc = mark("readout_backward", 2.0 * Hr)) return rc;
+      for (int i = Dr - 1; i >= 1; --i) {
+        SegList a{1, {seg(buf(w.g_ro_h[i]), Hr, Hr)}};
+        SegList cs{1, {seg(buf(w.g_ro_h[i - 1]), Hr, Hr)}};
+        SegList z{1, {seg(buf(w.ro_h[i - 1]), Hr, Hr)}};
+        if (int rc = gemm(a, 0, wt(p->readout.wt[i]), wt(p->readout.wtp[i]), wt(p->readout.wtq[i]), p->readout.dims[i + 1], p->readout.dims[i], cs, nullptr, &z))
+          return rc;
+      }
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      // d z_l = ([d readout hidden | d z_{l+1} .. d z_{L-1}] @ stack_l + d a_l of the next layer's moments) * act'(z_l)
+      SegList a{l < L - 1 ? 2 : 1, {seg(buf(w.g_ro_h[0]), Hr, Hr), seg(buf(w.g_fcat) + S * (l + 2), SL1, S * (L - 1 - l))}};
+      SegList dz{1, {seg(buf(w.g_fcat) + S * (l + 1), SL1, S)}};
+      SegList z{1, {seg(buf(w.fcat) + S * (l + 1), SL1, S)}};
+      SegList ad{1, {seg(buf(w.g_aenv), H, H)}};
+      act_now = c.act_kind[1];
+      if (int rc = gemm(a, 0, p->s_rs[l], dz, &z, l < L - 1 ? &ad : nullptr)) return rc;
+      SegList gs{1, {seg(buf(w.g_scal[l]), u, u)}};
+      if (int rc = gemm(dz, 0, p->s_sct[l], gs)) return rc;
+      // tensor-product layer reverse (per-atom operator kernels)
+      TpOpArgs o = op_args(g, l);
+      for (int m = 0; m < L; ++m) o.gscal[m] = buf(w.g_scal[m]);
+      o.g_w0 = buf(w.g_w0);
+      o.gsh_x1 = buf(w.g_sh);
+      size_t slot = size_t(u / 64);
+      for (int m = 0; m < l; ++m) slot += size_t(m == 0 ? S : H) / 64;
+      o.gsh_env = buf(w.g_sh) + slot * size_t(E) * p->D;
+      o.g_a = buf(w.g_aenv);
+      o.ld_ga = o.ka;
+      if (int rc = launch_tp_op<T>(p->tp_op, l, true, o, stream)) return rc;
+      if (int rc = mark("tp_op_bwd", p->D + W + u + 2 * o.ka + p->D + (l == 0 ? W + double(L - 1) * u + p->D : 0), double(L) * p->D * u)) return rc;
+    }
+    // slot 0 (two-body scalars): every consumer's share in one layer
+    {
+      SegList a{2, {seg(buf(w.g_ro_h[0]), Hr, Hr), seg(buf(w.g_fcat) + S, SL1, S * L)}};
+      SegList tb{1, {seg(buf(w.g_fcat), SL1, S)}};
+      if (int rc = gemm(a, 0, p->s_rstb, tb)) return rc;
+    }
+    // first stage + output layer of scalar_embed_mlp: d h = ([d two-body | d w0] @ (W_last G0)^T + d a_e of the moments) * act'(h)
+    {
+      SegList a{2, {seg(buf(w.g_fcat), SL1, S), seg(buf(w.g_w0), W, W)}};
+      SegList dh{1, {seg(buf(w.g_se_h[De - 1]), He, He)}};
+      SegList z{1, {seg(buf(w.se_h[De - 1]), He, He)}};
+      SegList ad{1, {seg(buf(w.g_aenv), He, He)}};
+      act_now = c.act_kind[0];
+      if (int rc = gemm(a, 0, p->s_g0ft, dh, &z, &ad)) return rc;
+      SegList gi{1, {seg(buf(w.g_emb0), c.embed_dim, c.embed_dim)}};
+      if (int rc = mlp_bwd(p->embed, De, dh, w.se_h, w.g_se_h, gi, nullptr, 0)) return rc;
+    }
+    return edge_tail(g, pos, forces);
+  }
+
   int backward(const aa_graph* g, const void* pos, void* forces) {
+    if (use_slot()) return backward_slot(g, pos, forces);
     const aa_model_config& c = p->cfg;
     const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W, SL1 = p->SL1;
     // spec path with u <= 64 writes every g_sh slot with plain stores; otherwise slots are accumulated into
@@ -2111,25 +2395,7 @@ struct Runner {
       if (int rc = mlp_bwd(p->embed, c.embed_mlp_depth + 1, go, w.se_h, w.g_se_h, gi, nullptr, 0)) return rc;
     }
     }
-    EdgeBwdArgs eb{};
-    eb.g = geom(g, pos);
-    eb.g_emb0 = buf(w.g_emb0);
-    eb.g_sh = buf(w.g_sh);
-    eb.num_gsh = num_gsh_slots(p);
-    eb.forces = forces;
-    if (p->embed_fused) eb.t_in = buf(w.trev);
-    const bool gather = g->t_rowptr && g->t_perm;
-    eb.dvec = buf(w.dvec);
-    eb.gather = gather ? 1 : 0;
-    if (int rc = launch_edge_backward<T>(eb, stream)) return rc;
-    if (int rc = mark("edge_backward", 8.0 / sizeof(T) + 4 + (p->embed_fused ? c.num_bessels : c.embed_dim) + double(num_gsh) * p->D + (gather ? 4 : 6))) return rc;
-    if (gather) {
-      // deterministic force assembly: per atom, own segment minus transposed segment, fixed order (no atomics)
-      ForceGatherArgs fg{N, g->rowptr, g->t_rowptr, g->t_perm, buf(w.dvec), forces};
-      if (int rc = launch_force_gather<T>(fg, stream)) return rc;
-      return mark("force_gather", 8.0 + 4.0 / sizeof(T), 3 + 8.0 / sizeof(T));
-    }
-    return AA_OK;
+    return edge_tail(g, pos, forces);
   }
 };
 

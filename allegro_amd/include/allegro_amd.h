@@ -227,6 +227,9 @@ typedef struct {
                              * scalars, 3 = two-body scalars and lat0 */
   int32_t poison_workspace; /* debugging: every step first fills the whole workspace with 0xFF bytes (NaN in fp32 and fp64), so
                              * that a kernel reading a cell no earlier kernel of the SAME step wrote shows up as NaN       */
+  int32_t no_slot_form;     /* operator-kernel plans (e.g. fp64, l_max 3, 3 layers): 1 = the unfolded single-layer pipeline instead of
+                             * the slot form (output layers of scalar_embed_mlp / the latent MLPs folded into their consumers, reverse
+                             * pass evaluated per dense-net slot) -- same results, A/B and tests                                   */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

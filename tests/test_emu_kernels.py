@@ -135,11 +135,16 @@ def test_moments_path_long_segments_vs_oracle():
     assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))
 
 
-@pytest.mark.parametrize("l_max,L,u,S,force", [(2, 3, 64, 64, False), (3, 3, 128, 128, False), (2, 2, 128, 64, False),
-                                                (2, 2, 64, 64, True)])
-def test_operator_path_vs_oracle(l_max, L, u, S, force, monkeypatch):
+@pytest.mark.parametrize("l_max,L,u,S,force,we,slot,extra", [
+    (2, 3, 64, 64, False, 32, True, {}), (3, 3, 128, 128, False, 32, False, {}), (3, 3, 128, 128, False, 128, True, {}),
+    (2, 2, 128, 64, False, 32, True, {}), (2, 2, 64, 64, True, 32, True, {}),
+    (2, 3, 64, 64, False, 64, True, dict(scalar_embed_mlp_hidden_layers_depth=2, readout_mlp_hidden_layers_depth=2)),
+    (2, 3, 64, 64, False, 64, False, dict(allegro_mlp_hidden_layers_depth=2))])
+def test_operator_path_vs_oracle(l_max, L, u, S, force, we, slot, extra, monkeypatch):
     """Per-atom operator form of the tensor-product track (aa_tp_op.hip): 3-layer stacks, two 64-channel slices,
-    and (forced) the 2-layer case the tuned kernels normally take.  fp64 against the oracle restatement."""
+    and (forced) the 2-layer case the tuned kernels normally take.  fp64 against the oracle restatement.  `slot`: whether the
+    plan takes the slot form of the linear layers (output layers of scalar_embed_mlp / the latent MLPs folded into their
+    consumers, reverse pass per dense-net slot: scalar_embed_mlp and latent hidden widths equal to S, one hidden latent layer)."""
     import numpy as np
 
     from oracle import restatement as R
@@ -158,10 +163,12 @@ def test_operator_path_vs_oracle(l_max, L, u, S, force, monkeypatch):
     assert deg[n - 1] == 0 and ei.shape[1] >= 10
     cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
                radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
-               radial_chemical_embed_dim=16, scalar_embed_mlp_hidden_layers_width=32, allegro_mlp_hidden_layers_width=S,
-               readout_mlp_hidden_layers_width=32, avg_num_neighbors=float(deg.mean()), seed=11, model_dtype="float64")
+               radial_chemical_embed_dim=16, scalar_embed_mlp_hidden_layers_width=we, allegro_mlp_hidden_layers_width=S,
+               readout_mlp_hidden_layers_width=32, avg_num_neighbors=float(deg.mean()), seed=11, model_dtype="float64", **extra)
     m = HipAllegroModel(**cfg)
     m._bind_library(emu_lib())
+    d = m.describe_plan()
+    assert d["operator_path"] and d["slot_form"] == slot, d
     types = torch.tensor(rng.integers(0, 2, size=n))
     g = m.prepare_graph(torch.tensor(ei), types, n, torch.tensor(shift @ cell))
     e, f = m.energy_forces(torch.tensor(pos), g)
@@ -169,6 +176,42 @@ def test_operator_path_vs_oracle(l_max, L, u, S, force, monkeypatch):
     ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, torch.tensor(shift @ cell))
     assert (e - ref["atomic_energy"].reshape(-1)).abs().max() < 1e-9 * max(1.0, float(ref["atomic_energy"].abs().max()))
     assert (f - ref["forces"]).abs().max() < 1e-9 * max(1.0, float(ref["forces"].abs().max()))
+
+
+@pytest.mark.parametrize("dt,tol", [("float64", 1e-11), ("float32", 1e-4)])
+def test_slot_form_matches_the_unfolded_pipeline(dt, tol, monkeypatch):
+    """Same model, same graph: the slot form (default) against aa_plan_options.no_slot_form -- two different launch sequences and
+    weight sets (folded at pack time vs the reference's own matrices) that must agree to rounding; energies, forces, virial."""
+    import numpy as np
+
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+
+    rng = np.random.default_rng(8)
+    n = 12
+    pos = rng.uniform(0, 6.0, size=(n, 3))
+    cell = np.eye(3) * 60.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
+    deg = np.bincount(ei[0], minlength=n)
+    cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=2, num_layers=3, num_scalar_features=64, num_tensor_features=64,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
+               radial_chemical_embed_dim=16, scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=64,
+               readout_mlp_hidden_layers_width=64, avg_num_neighbors=float(deg.mean()), seed=3, model_dtype=dt,
+               per_type_energy_scales=[1.3, 0.6], per_type_energy_shifts=[-2.0, 0.25])
+    tdt = getattr(torch, dt)
+    types = torch.tensor(rng.integers(0, 2, size=n))
+    out = []
+    for unfolded in (False, True):
+        if unfolded:
+            monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
+        m = HipAllegroModel(**cfg)
+        m._bind_library(emu_lib())
+        assert m.describe_plan()["slot_form"] == (not unfolded)
+        g = m.prepare_graph(torch.tensor(ei), types, n, torch.tensor(shift @ cell, dtype=tdt))
+        e, f = m.energy_forces(torch.tensor(pos, dtype=tdt), g)
+        out.append((e.double(), f.double(), m.virial(g).double()))
+    for a, b in zip(*out):
+        assert torch.isfinite(a).all() and (a - b).abs().max().item() <= tol * max(1.0, float(b.abs().max()))
 
 
 @pytest.mark.parametrize("dt", ["float32", "float64"])

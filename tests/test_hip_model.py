@@ -305,13 +305,18 @@ def test_fast_path_all_lmax_ragged_and_long_segments_vs_oracle(l_max, dtype, tol
         assert err_hip <= 2.0 * err_cpu32 + 1e-5 * scale, (err_hip, err_cpu32, scale)
 
 
-@pytest.mark.parametrize("l_max,L,u,S,dtype,tol,force", [
-    (1, 3, 64, 64, torch.float32, 5e-5, False), (2, 3, 64, 64, torch.float64, 1e-9, False),
-    (3, 3, 128, 128, torch.float64, 1e-9, False), (2, 2, 128, 64, torch.float32, 5e-5, False),
-    (2, 2, 64, 64, torch.float64, 1e-9, True), (3, 3, 64, 128, torch.float32, 5e-5, False)])
-def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, dev, monkeypatch):
+@pytest.mark.parametrize("l_max,L,u,S,dtype,tol,force,we,slot", [
+    (1, 3, 64, 64, torch.float32, 5e-5, False, 64, False), (2, 3, 64, 64, torch.float64, 1e-9, False, 64, True),
+    (2, 3, 64, 64, torch.float64, 1e-9, False, 64, False),
+    (3, 3, 128, 128, torch.float64, 1e-9, False, 64, False), (3, 3, 128, 128, torch.float64, 1e-9, False, 128, True),
+    (2, 2, 128, 64, torch.float32, 5e-5, False, 64, True), (2, 2, 128, 64, torch.float32, 5e-5, False, 64, False),
+    (2, 2, 64, 64, torch.float64, 1e-9, True, 64, True), (3, 3, 64, 128, torch.float32, 5e-5, False, 64, False),
+    (3, 3, 64, 128, torch.float32, 5e-5, False, 128, True)])
+def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, we, slot, dev, monkeypatch):
     """aa_tp_op.hip (per-atom operator form of the tensor-product track) on hardware: 3-layer stacks, 64- and
-    128-channel models (one wave per 64-channel slice), all l_max, both dtypes, ragged segments incl. degrees > 64."""
+    128-channel models (one wave per 64-channel slice), all l_max, both dtypes, ragged segments incl. degrees > 64.
+    `slot`: the slot form of the linear layers (needs scalar_embed_mlp width `we` == S) or the unfolded single-layer pipeline
+    (`we` != S, or aa_plan_options.no_slot_form where the shapes would allow the slot form)."""
     from oracle import restatement as R
     from allegro_amd import graph as G
     from allegro_amd.nn import HipAllegroModel
@@ -332,9 +337,13 @@ def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, dev, monkeyp
     name = {torch.float64: "float64", torch.float32: "float32"}[dtype]
     cfg = dict(type_names=["A", "B"], r_max=r_max, l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
                radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
-               radial_chemical_embed_dim=32, scalar_embed_mlp_hidden_layers_width=64, allegro_mlp_hidden_layers_width=S,
+               radial_chemical_embed_dim=32, scalar_embed_mlp_hidden_layers_width=we, allegro_mlp_hidden_layers_width=S,
                readout_mlp_hidden_layers_width=64, avg_num_neighbors=float(deg.mean()), seed=5, model_dtype=name)
+    if not slot and we == S:
+        monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
     m = HipAllegroModel(**cfg).to(dev)
+    d = m.describe_plan()
+    assert d["operator_path"] and d["slot_form"] == slot, d
     types = torch.tensor(rng.integers(0, 2, size=n))
     sv = torch.tensor(shift @ cell, dtype=dtype)
     g = m.prepare_graph(torch.tensor(ei).to(dev), types.to(dev), n, sv.to(dev))
