@@ -524,9 +524,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     for (int c = 0; c < KCMAX; ++c)
       if (c < KC) a_load(c, areg[c]);
     stage_load(0, 0);
-#pragma unroll
-    for (int c = 0; c < KCMAX; ++c)
-      if (c < KC) a_activate(c, areg[c]);
+    a_activate(0, areg[0]);
     stage_write(0);
     __syncthreads();
     int buf = 0;
@@ -539,6 +537,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
           const bool more = !last_c || n0 + NB < g.N;
           if (more) stage_load(last_c ? 0 : c + 1, last_c ? n0 + NB : n0);
           mma_chunk(smem + buf * 16 * LDB, areg[c], acc);
+          // (first column pass: the next resident chunk is activated behind this chunk's MFMAs -- all eight up front cost
+          //  0.8 ms on the 128 -> 640 first stage of C5, where nothing overlaps them)
+          if (n0 == 0 && c + 1 < KCMAX && c + 1 < KC) a_activate(c + 1, areg[c + 1]);
           if (more) stage_write(buf ^ 1);
           __syncthreads();
           buf ^= 1;
