@@ -248,6 +248,12 @@ struct GemmArgs {
   int force_kernel;  // 0: automatic; 1: native fp32-input MFMA kernel; 3: VALU kernel (aa_debug_gemm_f32 / A-B tests)
   int act_kind;      // activation behind act_a / has_z (AA_ACT_*); anything but SiLU runs the general VALU kernel
   int opt_v1, opt_lds_epilogue, opt_f64_column_loop, opt_f64_rows;  // aa_plan_options pass-throughs (A/B switches)
+  // Batched form (gridDim.z = batch <= 16 problems of the same shape in one launch; no z / add operands): problem b reads
+  // A + b a_bs, writes C + b c_bs (elements) and multiplies by weight matrix number bsel[b] of a set stored at uniform strides.
+  // (the env projections of the operator kernels: one problem per spherical-harmonic component, one matrix per irrep)
+  int batch;
+  int64_t a_bs, c_bs, b_bs, bp_bs, bq_bs;
+  unsigned char bsel[16];
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -540,10 +546,16 @@ struct TpOpArgs {
   void* gmbuf;           // [N][D][ka]     reverse: GM = d x2s . Wenv^T of the layer being reversed
   void* mbuf;            // [N][D][ka]     forward: moments M = sum_e Y[e] (x) act(a[e]) of the layer being evaluated
   int num_layers;
+  // The two env projections -- x2s = f M Wenv (forward) and GM = f d x2s Wenv^T (reverse) -- are per-irrep matrix products over
+  // all atoms.  proj_gemm: the caller runs them as batched linear-layer launches BETWEEN phase 1 and phase 2 of launch_tp_op
+  // (split form only); the per-atom kernels then read x2s from / write d x2s to HBM instead of streaming the whole Wenv
+  // (512 KB at C5) through every atom's wave.
+  int proj_gemm;
+  void* dx2s;            // [N][D][u]      reverse, proj_gemm: d x2s of the layer being reversed (unscaled)
 };
 int find_op_chain(const int* sigs, int num_layers);  // chain id or -1
 template <typename T>
-int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStream_t stream);
+int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStream_t stream, int phase = 0);  // phase: see TpOpArgs::proj_gemm
 
 template <typename T>
 int launch_tp_mom_fwd_first(int pair, const TpMomArgs& a, hipStream_t stream);

@@ -28,6 +28,21 @@ __device__ __forceinline__ T seg_load(const SegList& sl, int64_t row, int col) {
   return T(0);
 }
 
+// batched launch: shift the views of this workgroup's problem (GemmArgs::batch)
+template <typename T>
+__device__ __forceinline__ void batch_view(GemmArgs& g) {
+  if (g.batch <= 1) return;
+  const int b = blockIdx.z, sel = g.bsel[b];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (s < g.a.count) g.a.s[s].p = static_cast<T*>(g.a.s[s].p) + b * g.a_bs;
+    if (s < g.c.count && g.c.s[s].p) g.c.s[s].p = static_cast<T*>(g.c.s[s].p) + b * g.c_bs;
+  }
+  g.B = static_cast<const T*>(g.B) + sel * g.b_bs;
+  if (g.Bp) g.Bp = static_cast<const T*>(g.Bp) + sel * g.bp_bs;
+  if (g.Bq) g.Bq = static_cast<const T*>(g.Bq) + sel * g.bq_bs;
+}
+
 // is column k of A activated on load?  (wave-uniform wherever k is a chunk base: the range is 32-granular)
 __device__ __forceinline__ bool a_act(const GemmArgs& g, int k) { return g.act_a && (g.act_hi == 0 || (k >= g.act_lo && k < g.act_hi)); }
 
@@ -61,6 +76,7 @@ __device__ __forceinline__ void seg_store(const GemmArgs& g, int64_t row, int co
 constexpr int GM_BM = 128, GM_BN = 64, GM_BK = 32, GM_LDA = GM_BM + 1;
 
 __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
+  batch_view<float>(g);
   float* As = reinterpret_cast<float*>(aa_smem);  // [BK][LDA]
   float* Bs = As + GM_BK * GM_LDA;                // [BK][BN]
   const int tid = threadIdx.x;
@@ -127,6 +143,7 @@ constexpr int GV_BM = 64, GV_BN = 64, GV_BK = 16, GV_LDA = GV_BM + 1;
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
+  batch_view<T>(g);
   T* As = reinterpret_cast<T*>(aa_smem);  // [BK][LDA]
   T* Bs = As + GV_BK * GV_LDA;            // [BK][BN]
   const int tid = threadIdx.x;
@@ -191,6 +208,7 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
 // rows 4r..4r+3 across the four 16-lane groups).
 typedef double v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
+  batch_view<double>(g);
   double* As = reinterpret_cast<double*>(aa_smem);  // [BK][LDA]
   double* Bs = As + GV_BK * GV_LDA;                 // [BK][BN]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -317,6 +335,7 @@ __device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int
 constexpr int G6_BM = 128, G6_BN = 64, G6_BK = 16, G6_LDA = G6_BM + 4;
 typedef double v2d __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
+  batch_view<double>(g);
   double* smem = reinterpret_cast<double*>(aa_smem);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = int64_t(blockIdx.x) * G6_BM;
@@ -433,6 +452,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) 
 // one barrier per 32-64 MFMAs of 64 cycles each.
 template <bool ASTAT>
 __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
+  batch_view<double>(g);
   constexpr int NB = ASTAT ? 64 : 128;  // columns per pass
   constexpr int JT = NB / 16;           // MFMA column tiles per pass
   constexpr int LDB = NB + 4;           // (rows 4 g + s of the four lane groups land in different banks)
@@ -806,6 +826,7 @@ __device__ __forceinline__ void store_pair_lds(const GemmArgs& g, const v16f& ac
 // KCR == 0: fragments are streamed (and double-buffered) per k chunk.
 template <int KCR>
 __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int vec_ok) {
+  batch_view<float>(g);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
@@ -973,6 +994,8 @@ __device__ __forceinline__ void chunk_pair_bf16x3(const u32x4* w0, const u32x4* 
 // current step issue (also across tile-pair boundaries); streamed activations are fetched two chunks ahead.
 template <int KCR, bool LDS_EPI>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x4* __restrict__ Wq, int vec_ok) {
+  batch_view<float>(g);
+  if (g.batch > 1) Wq = static_cast<const u32x4*>(g.Bq);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
@@ -1694,6 +1717,7 @@ static int check_args(const GemmArgs& g) {
   for (int s = 0; s < g.a.count; ++s) ka += g.a.s[s].n;
   for (int s = 0; s < g.c.count; ++s) nc += g.c.s[s].n;
   if (ka != g.K || nc != g.N) return fail(AA_ERR_INVALID, "gemm: segment widths do not sum to K/N");
+  if (g.batch > 1 && (g.batch > 16 || g.has_z || g.has_add)) return fail(AA_ERR_INVALID, "gemm: batched launches take up to 16 problems and no z / add operands");
   if (g.act_a && g.act_hi != 0 && ((g.act_lo & 31) || (g.act_hi & 31) || g.act_lo < 0 || g.act_hi <= g.act_lo || g.act_hi > g.K))
     return fail(AA_ERR_INVALID, "gemm: the activated column range of A must be 32-granular and inside [0, K)");
   if (g.has_add) {
@@ -1713,13 +1737,16 @@ template <>
 int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
   if (g.M == 0) return AA_OK;
   if (int rc = check_args(g)) return rc;
+  const unsigned bz = g.batch > 1 ? unsigned(g.batch) : 1u;
   const bool v1_only = g.opt_v1 != 0;
   if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
+    grid.z = bz;
     size_t smem = sizeof(float) * (GV_BK * GV_LDA + GV_BK * GV_BN);
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
   } else if (g.Bp && !v1_only && seglist_frag_ok_host(g.a)) {
     dim3 grid((unsigned)((g.M + 127) / 128));
+    grid.z = bz;
     // 16-B epilogue accesses need every C/Z segment to be 4-column granular and 16-B aligned
     int vec_ok = 1;
     for (int s = 0; s < g.c.count; ++s) {
@@ -1756,6 +1783,7 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
       hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<0>, grid, dim3(256), 0, stream, g, vec_ok);
   } else {
     dim3 grid((unsigned)((g.M + GM_BM - 1) / GM_BM), (unsigned)((g.N + GM_BN - 1) / GM_BN));
+    grid.z = bz;
     size_t smem = sizeof(float) * (GM_BK * GM_LDA + GM_BK * GM_BN);
     hipLaunchKernelGGL(gemm_mfma_f32_kernel, grid, dim3(256), smem, stream, g);
   }
@@ -1767,7 +1795,9 @@ template <>
 int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   if (g.M == 0) return AA_OK;
   if (int rc = check_args(g)) return rc;
+  const unsigned bz = g.batch > 1 ? unsigned(g.batch) : 1u;
   dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
+  grid.z = bz;
   size_t smem = sizeof(double) * (GV_BK * GV_LDA + GV_BK * GV_BN);
   bool pipe_ok = (g.N % 2) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
   for (int s2 = 0; s2 < g.a.count; ++s2)
@@ -1788,6 +1818,7 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
     // z / add operands or accumulates into C (its two waves per SIMD overlap the silu' arithmetic of one pass with the next pass's MFMAs worse
     // than the staged kernel's three) -- those keep the staged kernel unless forced (aa_plan_options.f64_rows = 1).
     dim3 gridr((unsigned)((g.M + 127) / 128));
+    gridr.z = bz;
     if (g.N <= 128) {
       const size_t smemr = sizeof(double) * 2 * 16 * (128 + 4);
       hipLaunchKernelGGL(gemm_f64_rows_kernel<false>, gridr, dim3(256), smemr, stream, g);
@@ -1797,6 +1828,7 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
     }
   } else if (pipe_ok) {
     dim3 grid6((unsigned)((g.M + G6_BM - 1) / G6_BM), (unsigned)((g.N + G6_BN - 1) / G6_BN));
+    grid6.z = bz;
     // enough row tiles to fill the chip on their own: one workgroup per row tile looping over the column tiles
     // (aa_plan_options.f64_column_loop: 1 never, 2 always -- tests)
     if (g.opt_f64_column_loop == 2 || (g.opt_f64_column_loop == 0 && grid6.x >= 2048)) grid6.y = 1;

@@ -193,6 +193,12 @@ struct GemmMat {
   int K = 0, N = 0;
 };
 
+// a set of equally shaped matrices at uniform strides (GemmArgs::batch)
+struct GemmMatSet {
+  size_t w = 0, wp = 0, wq = 0, w_bs = 0, wp_bs = 0, wq_bs = 0;
+  int K = 0, N = 0, count = 0;
+};
+
 struct aa_model_plan {
   aa_model_config cfg;
   aa_plan_options opt{};
@@ -244,6 +250,10 @@ struct aa_model_plan {
   GemmMat s_rstb;                    //   reverse stack of slot 0 (two-body): rows [readout | latent 0 .. L-1]      [Hr + S L, S]
   GemmMat s_sct[AA_MAX_LAYERS];      //   d z_l -> d (tensor scalars of layer l)                                   [H, u]
   size_t o_s_wk0, o_s_wt0;           //   W_last(embed) @ Wenv0 as [k][R][u] and [R][u][k]
+  // operator-kernel plans: the env projections as batched linear-layer launches (TpOpArgs::proj_gemm) -- per layer the R matrices
+  // f Wenv_l[:, r, :] [ka, u] and their transposes [u, ka]; layer 0 also behind the output layer of scalar_embed_mlp (slot form)
+  bool op_proj;
+  GemmMatSet s_pr[AA_MAX_LAYERS], s_prt[AA_MAX_LAYERS], s_pr0f, s_prt0f;
   int ng0;                           // output width of the fused first-stage GEMM
   size_t o_wk[AA_MAX_LAYERS], o_wt[AA_MAX_LAYERS];  // Wenv of layer l as [ka][R][u] and [R][u][ka]
 #ifdef AA_EXPERIMENTAL_TAIL
@@ -530,6 +540,32 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
       p->o_s_wt0 = take(size_t(S) * p->W);
     }
   }
+  p->op_proj = p->tp_op >= 0 && opt.op_proj_gemm != 2;
+  if (p->op_proj) {
+    auto mset = [&](int K, int N, int count) {
+      GemmMatSet m;
+      m.K = K;
+      m.N = N;
+      m.count = count;
+      auto r64 = [](size_t n) { return (n + 63) / 64 * 64; };
+      m.w_bs = r64(size_t(K) * N);
+      m.wp_bs = r64(gemm_packed_elems(K, N));
+      m.wq_bs = r64(gemm_bf16x3_words(K, N));
+      m.w = take(m.w_bs * count);
+      m.wp = take(m.wp_bs * count);
+      m.wq = take(m.wq_bs * count);
+      return m;
+    };
+    for (int l = 0; l < L; ++l) {
+      const int ka = l == 0 ? S : cfg->latent_mlp_width;
+      p->s_pr[l] = mset(ka, u, p->R);
+      p->s_prt[l] = mset(u, ka, p->R);
+    }
+    if (p->slot_form) {
+      p->s_pr0f = mset(S, u, p->R);
+      p->s_prt0f = mset(u, S, p->R);
+    }
+  }
   p->o_scales = take(T);
   p->o_shifts = take(T);
   p->n_elems = o;
@@ -655,6 +691,11 @@ extern "C" uint64_t aa_model_plan_layout_hash(const aa_model_plan* p) {
     mixm(p->s_g0f); mixm(p->s_g0ft); mixm(p->s_ro0); mixm(p->s_rstb);
     for (int l = 0; l < c.num_layers; ++l) { mixm(p->s_in[l]); mixm(p->s_rs[l]); mixm(p->s_sct[l]); }
     mix(p->o_s_wk0); mix(p->o_s_wt0);
+  }
+  if (p->op_proj) {
+    auto mixs = [&](const GemmMatSet& m) { mix(m.w); mix(m.wp); mix(m.wq); mix(m.w_bs); };
+    for (int l = 0; l < c.num_layers; ++l) { mixs(p->s_pr[l]); mixs(p->s_prt[l]); }
+    mixs(p->s_pr0f); mixs(p->s_prt0f);
   }
   for (size_t v : {p->o_rmax, p->o_bessel, p->o_cemb, p->o_nemb, p->o_basis, p->o_g0, p->o_g0t, p->o_g0p, p->o_g0tp, p->o_g0q, p->o_g0tq,
                    p->o_b3a_q, p->o_b3b_q, p->o_b3c_q, p->o_ro_last, p->o_scales, p->o_shifts, p->o_embtab, p->o_embtab_h, p->o_lat1in_fq, p->o_ro0_fq, p->o_b3af_q, p->o_b3bf_q, p->o_g0fq, p->o_g0tfq, p->o_wk0f, p->o_wt0f, p->o_wkq[0], p->o_wkq[1]})
@@ -1008,6 +1049,27 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
       put(p->s_rstb, tb);
     }
   }
+  struct SetRef { const GemmMatSet* m; };
+  std::vector<SetRef> proj_sets;
+  if (p->op_proj) {
+    const double sf = 1.0 / std::sqrt(c.avg_num_neighbors);
+    auto put_set = [&](const GemmMatSet& fw, const GemmMatSet& bw, size_t wk_off, int ka) {
+      for (int r = 0; r < Rr; ++r) {
+        for (int k = 0; k < ka; ++k)
+          for (int ch = 0; ch < u; ++ch) {
+            const double v = sf * h[wk_off + (size_t(k) * Rr + r) * u + ch];
+            h[fw.w + r * fw.w_bs + size_t(k) * u + ch] = v;
+            h[bw.w + r * bw.w_bs + size_t(ch) * ka + k] = v;
+          }
+        gemm_pack_b(&h[fw.w + r * fw.w_bs], ka, u, &h[fw.wp + r * fw.wp_bs]);
+        gemm_pack_b(&h[bw.w + r * bw.w_bs], u, ka, &h[bw.wp + r * bw.wp_bs]);
+      }
+      proj_sets.push_back({&fw});
+      proj_sets.push_back({&bw});
+    };
+    for (int l = 0; l < L; ++l) put_set(p->s_pr[l], p->s_prt[l], p->o_wk[l], l == 0 ? S : c.latent_mlp_width);
+    if (p->slot_form) put_set(p->s_pr0f, p->s_prt0f, p->o_s_wk0, S);
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c.dtype == AA_F64) {
     AA_CHECK_HIP(hipMemcpyAsync(dev_blob, h.data(), h.size() * 8, hipMemcpyHostToDevice, s));
@@ -1029,6 +1091,8 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
     for (int l = 0; l < L; ++l) split_mlp(p->latent[l], c.latent_mlp_depth + 1);
     split_mlp(p->readout, c.readout_mlp_depth);
     for (const GemmMat* m : slot_mats) splitw(m->w, m->K, m->N, m->wq);
+    for (const SetRef& sr : proj_sets)
+      for (int r = 0; r < sr.m->count; ++r) splitw(sr.m->w + r * sr.m->w_bs, sr.m->K, sr.m->N, sr.m->wq + r * sr.m->wq_bs);
     if (p->chain_gemm) {
       const int SL = S * L, SL1 = p->SL1, N2 = SL + c.num_tensor;
       const float* rt = &hf[p->readout.wt[0]];          // [64, SL1]  (transposed first readout layer)
@@ -1146,7 +1210,7 @@ extern "C" int aa_model_pack_weights(const aa_model_plan* p, const aa_model_raw_
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 struct Workspace {
-  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, bvec_op, gm_op, mom_op, trev, dvec, vir_part, tiles;
+  size_t vec, sh, emb0, emb, w0, fcat, g_fcat, g_envw, g_w0, g_emb, g_emb0, g_sh, g_ro_last, g_aenv, e_edge, q_op, bvec_op, gm_op, mom_op, dx2s_op, trev, dvec, vir_part, tiles;
   size_t g_scal[AA_MAX_LAYERS];
   size_t se_h[AA_MAX_MLP_LAYERS], g_se_h[AA_MAX_MLP_LAYERS];
   size_t envw[AA_MAX_LAYERS], x2s[AA_MAX_LAYERS], tf[AA_MAX_LAYERS], scal[AA_MAX_LAYERS];
@@ -1229,6 +1293,7 @@ static Workspace layout_workspace(const aa_model_plan* p, int64_t N, int64_t E, 
     if (p->tp_op >= 0) {
       w.q_op = take(Nz * L * p->D * u);
       w.gm_op = take(Nz * p->D * size_t(std::max(c.num_scalar, c.latent_mlp_width)));
+      if (p->op_proj) w.dx2s_op = take(Nz * p->D * u);
     }
   }
   w.total = o;
@@ -1602,6 +1667,88 @@ struct Runner {
     return o;
   }
 
+  // env projections of the operator kernels as batched linear-layer launches (aa_model_plan::op_proj): where there are enough
+  // atoms to fill the chip with 128-row tiles
+  bool use_proj(const aa_graph* g) const {
+    if (!(p->op_proj && w.bvec_op && w.mom_op && !p->opt.tp_operator_fused)) return false;
+    if (p->opt.op_proj_gemm == 1) return true;
+    return atom_end(g) - atom_begin(g) >= 4096;
+  }
+  // one problem per spherical-harmonic component j (rows: atoms), weight matrix number r(j)
+  int proj_gemm(const TpOpArgs& o, const GemmMatSet& ms, const T* a_base, int64_t a_ld, int64_t a_bs, T* c_base, int64_t c_ld, int64_t c_bs) {
+    GemmArgs gm{};
+    gm.M = o.N - o.atom0;
+    gm.K = ms.K;
+    gm.N = ms.N;
+    gm.a = SegList{1, {seg(const_cast<T*>(a_base) + o.atom0 * a_ld, int(a_ld), ms.K)}};
+    gm.c = SegList{1, {seg(c_base + o.atom0 * c_ld, int(c_ld), ms.N)}};
+    gm.B = wt(ms.w);
+    gm.Bp = wt(ms.wp);
+    gm.Bq = sizeof(T) == 4 ? wt(ms.wq) : nullptr;
+    gm.act_kind = AA_ACT_SILU;
+    gm.force_kernel = p->opt.gemm_valu ? 3 : (p->opt.gemm_fp32_mfma ? 1 : 0);
+    gm.opt_v1 = p->opt.gemm_v1;
+    gm.opt_lds_epilogue = p->opt.gemm_lds_epilogue;
+    gm.opt_f64_column_loop = p->opt.f64_column_loop;
+    gm.opt_f64_rows = p->opt.f64_rows;
+    gm.batch = p->D;
+    gm.a_bs = a_bs;
+    gm.c_bs = c_bs;
+    gm.b_bs = int64_t(ms.w_bs);
+    gm.bp_bs = int64_t(ms.wp_bs);
+    gm.bq_bs = int64_t(ms.wq_bs);
+    for (int j = 0, r = 0; j < p->D; ++j) {
+      if (j >= (r + 1) * (r + 1)) ++r;
+      gm.bsel[j] = static_cast<unsigned char>(r);
+    }
+    if (int rc = launch_gemm<T>(gm, stream)) return rc;
+    return mark("op_proj_gemm", 0, double(p->D) * (ms.K + ms.N), 2.0 * double(gm.M) * p->D * ms.K * ms.N);
+  }
+  // forward of tensor-product layer l on the operator kernels
+  int run_op_fwd(const aa_graph* g, int l) {
+    const int u = p->cfg.num_tensor;
+    TpOpArgs o = op_args(g, l);
+    o.scal = buf(w.scal[l]);
+    if (use_proj(g)) {
+      o.proj_gemm = 1;
+      if (int rc = launch_tp_op<T>(p->tp_op, l, false, o, stream, 1)) return rc;
+      if (int rc = mark("tp_op_moments", p->D + o.ka)) return rc;
+      const GemmMatSet& ms = (l == 0 && use_slot()) ? p->s_pr0f : p->s_pr[l];
+      if (int rc = proj_gemm(o, ms, buf(w.mom_op), int64_t(p->D) * o.ka, o.ka, buf(w.x2s[l]), int64_t(p->D) * u, u)) return rc;
+      if (int rc = launch_tp_op<T>(p->tp_op, l, false, o, stream, 2)) return rc;
+      return mark("tp_op_fwd", p->W + u, double(l + 1) * p->D * u);
+    }
+    if (int rc = launch_tp_op<T>(p->tp_op, l, false, o, stream)) return rc;
+    return mark("tp_op_fwd", p->D + o.ka + p->W + u, double(l + 1) * p->D * u);
+  }
+  // reverse of tensor-product layer l on the operator kernels: d scal_m -> d w0 / d Y (layer 0), d (env input) -> g_aenv
+  int run_op_bwd(const aa_graph* g, int l) {
+    const aa_model_config& c = p->cfg;
+    const int S = c.num_scalar, u = c.num_tensor, L = c.num_layers, W = p->W;
+    TpOpArgs o = op_args(g, l);
+    for (int m = 0; m < L; ++m) o.gscal[m] = buf(w.g_scal[m]);
+    o.g_w0 = buf(w.g_w0);
+    o.gsh_x1 = buf(w.g_sh);
+    size_t slot = size_t(u / 64);
+    for (int m = 0; m < l; ++m) slot += size_t(m == 0 ? S : c.latent_mlp_width) / 64;
+    o.gsh_env = buf(w.g_sh) + slot * size_t(E) * p->D;
+    o.g_a = buf(w.g_aenv);
+    o.ld_ga = o.ka;
+    const double elems = p->D + W + u + 2 * o.ka + p->D + (l == 0 ? W + double(L - 1) * u + p->D : 0);
+    if (use_proj(g) && w.dx2s_op) {
+      o.proj_gemm = 1;
+      o.dx2s = buf(w.dx2s_op);
+      if (int rc = launch_tp_op<T>(p->tp_op, l, true, o, stream, 1)) return rc;
+      if (int rc = mark("tp_op_bwd", elems - 2 * o.ka - p->D, double(L) * p->D * u)) return rc;
+      const GemmMatSet& ms = (l == 0 && use_slot()) ? p->s_prt0f : p->s_prt[l];
+      if (int rc = proj_gemm(o, ms, buf(w.dx2s_op), int64_t(p->D) * u, u, buf(w.gm_op), int64_t(p->D) * o.ka, o.ka)) return rc;
+      if (int rc = launch_tp_op<T>(p->tp_op, l, true, o, stream, 2)) return rc;
+      return mark("tp_op_edge_env", 2 * o.ka + p->D);
+    }
+    if (int rc = launch_tp_op<T>(p->tp_op, l, true, o, stream)) return rc;
+    return mark("tp_op_bwd", elems, double(L) * p->D * u);
+  }
+
   TpOperand implicit(size_t w_off) const {
     TpOperand o{};
     o.sh = buf(w.sh);
@@ -1874,10 +2021,7 @@ struct Runner {
     const double sfac = 1.0 / std::sqrt(c.avg_num_neighbors);
     for (int l = 0; l < L; ++l) {
       if (p->tp_op >= 0) {
-        TpOpArgs o = op_args(g, l);
-        o.scal = buf(w.scal[l]);
-        if (int rc = launch_tp_op<T>(p->tp_op, l, false, o, stream)) return rc;
-        if (int rc = mark("tp_op_fwd", p->D + o.ka + W + u, double(l + 1) * p->D * u)) return rc;
+        if (int rc = run_op_fwd(g, l)) return rc;
       } else if (p->env_mom) {
         TpMomArgs m = mom_args(g);
         if (l == 0) {
@@ -2053,17 +2197,7 @@ struct Runner {
       SegList gs{1, {seg(buf(w.g_scal[l]), u, u)}};
       if (int rc = gemm(dz, 0, p->s_sct[l], gs)) return rc;
       // tensor-product layer reverse (per-atom operator kernels)
-      TpOpArgs o = op_args(g, l);
-      for (int m = 0; m < L; ++m) o.gscal[m] = buf(w.g_scal[m]);
-      o.g_w0 = buf(w.g_w0);
-      o.gsh_x1 = buf(w.g_sh);
-      size_t slot = size_t(u / 64);
-      for (int m = 0; m < l; ++m) slot += size_t(m == 0 ? S : H) / 64;
-      o.gsh_env = buf(w.g_sh) + slot * size_t(E) * p->D;
-      o.g_a = buf(w.g_aenv);
-      o.ld_ga = o.ka;
-      if (int rc = launch_tp_op<T>(p->tp_op, l, true, o, stream)) return rc;
-      if (int rc = mark("tp_op_bwd", p->D + W + u + 2 * o.ka + p->D + (l == 0 ? W + double(L - 1) * u + p->D : 0), double(L) * p->D * u)) return rc;
+      if (int rc = run_op_bwd(g, l)) return rc;
     }
     // slot 0 (two-body scalars): every consumer's share in one layer
     {
@@ -2205,17 +2339,7 @@ struct Runner {
       }
       // tensor-product layer reverse
       if (p->tp_op >= 0) {
-        TpOpArgs o = op_args(g, l);
-        for (int m = 0; m < L; ++m) o.gscal[m] = buf(w.g_scal[m]);
-        o.g_w0 = buf(w.g_w0);
-        o.gsh_x1 = buf(w.g_sh);
-        size_t slot = size_t(u / 64);
-        for (int m = 0; m < l; ++m) slot += size_t(m == 0 ? S : c.latent_mlp_width) / 64;
-        o.gsh_env = buf(w.g_sh) + slot * size_t(E) * p->D;
-        o.g_a = buf(w.g_aenv);
-        o.ld_ga = o.ka;
-        if (int rc = launch_tp_op<T>(p->tp_op, l, true, o, stream)) return rc;
-        if (int rc = mark("tp_op_bwd", p->D + W + u + 2 * o.ka + p->D + (l == 0 ? W + double(L - 1) * u + p->D : 0), double(L) * p->D * u)) return rc;
+        if (int rc = run_op_bwd(g, l)) return rc;
         continue;
       }
       if (p->env_mom) {

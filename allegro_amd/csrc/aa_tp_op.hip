@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void tp_op_fwd_kernel(TpOpArgs a) {
   const T* sh = static_cast<const T*>(a.sh);
   const T* av = static_cast<const T*>(a.a);
   const int ka = a.ka;
+  if (!a.proj_gemm) {  // (proj_gemm: x2s_LI is already in HBM, written by the batched projection launch)
   // moments M[j][k] = sum_e Y[e,j] act(a[e,k])   (every slice recomputes them: they do not depend on the channel)
   if (a.mbuf) {  // split form: tp_op_moments_kernel streamed the edges; fetch this atom's D x ka block
     const T* mp = static_cast<const T*>(a.mbuf) + (atom * D) * int64_t(ka);
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void tp_op_fwd_kernel(TpOpArgs a) {
   }
   // the chain reads x2s_LI back through the same lane's own store (same thread, same address: program order)
   __threadfence_block();
+  }
   T b[kOpMaxD];
   atom_vector<Ch, LI, T>(a, atom, ch, b);
   constexpr int D1 = SigAt<Ch, 0>::type::D1;
@@ -428,6 +430,12 @@ __global__ __launch_bounds__(256) void tp_op_bwd_mid_kernel(TpOpArgs a) {
 #pragma unroll
   for (int j = 0; j < D; ++j) g2[j] = T(0);
   x2s_grad_terms<Ch, LI, LI, T>(a, atom, ch, q, g2);
+  if (a.proj_gemm) {  // (the batched projection launch turns d x2s into GM; f rides in its weights)
+    T* dp = static_cast<T*>(a.dx2s) + atom * D * int64_t(u) + ch;
+#pragma unroll
+    for (int j = 0; j < D; ++j) dp[int64_t(j) * u] = g2[j];
+    return;
+  }
   {
     const T sf = T(a.sf);
 #pragma unroll
@@ -587,8 +595,10 @@ int find_op_chain(const int* sigs, int L) {
 }
 
 template <typename T>
-int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStream_t stream) {
+int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStream_t stream, int phase) {
   if (a.N <= a.atom0) return AA_OK;
+  if ((a.proj_gemm != 0) != (phase != 0) || (a.proj_gemm && !(a.bvec && a.mbuf && (!reverse || (a.gmbuf && a.dx2s)))))
+    return fail(AA_ERR_INVALID, "tp_op: the projection-by-GEMM form runs in two phases of the split form");
   if ((a.u & 63) || a.u > 256 || (a.ka & 63) || a.ka > kOpMaxKa || a.ka_lds < a.ka)
     return fail(AA_ERR_INVALID, "tp_op: needs u = 64..256 in steps of 64 and env widths of 64 or 128");
   const int nsl = a.u / 64;
@@ -621,14 +631,18 @@ int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStrea
       else                                                                                            \
         hipLaunchKernelGGL((tp_op_fwd_kernel<CH, LI, T>), grid, block, smem, stream, a);              \
     } else if (!reverse) {                                                                            \
-      if (a.mbuf) hipLaunchKernelGGL((tp_op_moments_kernel<T, DD_>), grid, dim3(a.ka), 0, stream, a); \
-      hipLaunchKernelGGL((tp_op_fwd_kernel<CH, LI, T>), grid, block, smem, stream, a);                \
-      AA_OP_EDGE(DD_, RR_, LL_)                                                                       \
+      if (a.mbuf && phase != 2) hipLaunchKernelGGL((tp_op_moments_kernel<T, DD_>), grid, dim3(a.ka), 0, stream, a); \
+      if (phase != 1) {                                                                               \
+        hipLaunchKernelGGL((tp_op_fwd_kernel<CH, LI, T>), grid, block, smem, stream, a);              \
+        AA_OP_EDGE(DD_, RR_, LL_)                                                                     \
+      }                                                                                               \
     } else {                                                                                          \
-      if (LI == 0) hipLaunchKernelGGL((tp_op_bvecs_kernel<CH, T>), grid, block, 0, stream, a);        \
-      AA_OP_EDGE(DD_, RR_, LL_)                                                                       \
-      hipLaunchKernelGGL((tp_op_bwd_mid_kernel<CH, LI, T>), grid, block, smem, stream, a);            \
-      AA_OP_ENV(DD_)                                                                                  \
+      if (phase != 2) {                                                                               \
+        if (LI == 0) hipLaunchKernelGGL((tp_op_bvecs_kernel<CH, T>), grid, block, 0, stream, a);      \
+        AA_OP_EDGE(DD_, RR_, LL_)                                                                     \
+        hipLaunchKernelGGL((tp_op_bwd_mid_kernel<CH, LI, T>), grid, block, smem, stream, a);          \
+      }                                                                                               \
+      if (phase != 1) AA_OP_ENV(DD_)                                                                  \
     }                                                                                                 \
   }
 #define AA_OP_CHAIN2(CH)                            \
@@ -653,7 +667,7 @@ int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStrea
   return AA_OK;
 }
 
-template int launch_tp_op<float>(int, int, bool, const TpOpArgs&, hipStream_t);
-template int launch_tp_op<double>(int, int, bool, const TpOpArgs&, hipStream_t);
+template int launch_tp_op<float>(int, int, bool, const TpOpArgs&, hipStream_t, int);
+template int launch_tp_op<double>(int, int, bool, const TpOpArgs&, hipStream_t, int);
 
 }  // namespace aa

@@ -230,6 +230,8 @@ typedef struct {
   int32_t no_slot_form;     /* operator-kernel plans (e.g. fp64, l_max 3, 3 layers): 1 = the unfolded single-layer pipeline instead of
                              * the slot form (output layers of scalar_embed_mlp / the latent MLPs folded into their consumers, reverse
                              * pass evaluated per dense-net slot) -- same results, A/B and tests                                   */
+  int32_t op_proj_gemm;     /* operator-kernel plans: the env projections (x2s = f M Wenv and its reverse) as batched linear-layer launches
+                             * over all atoms instead of inside the per-atom kernels: 0 = from 4096 atoms on, 1 = always, 2 = never       */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

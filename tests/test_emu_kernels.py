@@ -136,14 +136,14 @@ def test_moments_path_long_segments_vs_oracle():
 
 
 @pytest.mark.parametrize("l_max,L,u,S,force,we,slot,extra", [
-    (2, 3, 64, 64, False, 32, True, {}), (3, 3, 128, 128, False, 32, False, {}), (3, 3, 128, 128, False, 128, True, {}),
-    (2, 2, 128, 64, False, 32, True, {}), (2, 2, 64, 64, True, 32, True, {}),
+    (2, 3, 64, 64, False, 32, True, {}), (3, 3, 128, 128, False, 32, False, dict(proj=1)), (3, 3, 128, 128, False, 128, True, dict(proj=1)),
+    (2, 2, 128, 64, False, 32, True, {}), (2, 2, 64, 64, True, 32, True, dict(proj=1)),
     (2, 3, 64, 64, False, 64, True, dict(scalar_embed_mlp_hidden_layers_depth=2, readout_mlp_hidden_layers_depth=2)),
-    (2, 3, 64, 64, False, 64, False, dict(allegro_mlp_hidden_layers_depth=2))])
+    (2, 3, 64, 64, False, 64, False, dict(allegro_mlp_hidden_layers_depth=2, proj=1))])
 def test_operator_path_vs_oracle(l_max, L, u, S, force, we, slot, extra, monkeypatch):
     """Per-atom operator form of the tensor-product track (aa_tp_op.hip): 3-layer stacks, two 64-channel slices,
     and (forced) the 2-layer case the tuned kernels normally take.  fp64 against the oracle restatement.  `slot`: whether the
-    plan takes the slot form of the linear layers (output layers of scalar_embed_mlp / the latent MLPs folded into their
+    plan takes the slot form of the linear layers (`proj`: and the env projections as batched launches; output layers of scalar_embed_mlp / the latent MLPs folded into their
     consumers, reverse pass per dense-net slot: scalar_embed_mlp and latent hidden widths equal to S, one hidden latent layer)."""
     import numpy as np
 
@@ -153,6 +153,9 @@ def test_operator_path_vs_oracle(l_max, L, u, S, force, we, slot, extra, monkeyp
 
     if force:
         monkeypatch.setenv("AA_TP_OP", "1")
+    extra = dict(extra)
+    if extra.pop("proj", 0):  # the env projections as batched linear-layer launches (default from 4096 atoms on)
+        monkeypatch.setenv("AA_OP_PROJ", "1")
     rng = np.random.default_rng(5)
     n = 10
     pos = rng.uniform(0, 6.5, size=(n, 3))
@@ -201,7 +204,8 @@ def test_slot_form_matches_the_unfolded_pipeline(dt, tol, monkeypatch):
     tdt = getattr(torch, dt)
     types = torch.tensor(rng.integers(0, 2, size=n))
     out = []
-    for unfolded in (False, True):
+    for unfolded, proj in ((False, "1"), (True, "0")):  # (slot form + batched env projections) vs (neither)
+        monkeypatch.setenv("AA_OP_PROJ", proj)
         if unfolded:
             monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
         m = HipAllegroModel(**cfg)

@@ -1,12 +1,12 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out; export TMPDIR=/tmp
-TAG=r04_v15
+TAG=r04_v16
 timeout 900 python -m pytest tests -m gpu -q -k "operator_path or c5_full or gemm" > gpurun_out/${TAG}_pytest_quick.log 2>&1; tail -5 gpurun_out/${TAG}_pytest_quick.log
-for rep in 1 2; do for mode in slot unfolded; do
-  if [ $mode = unfolded ]; then export AA_NO_SLOT_FORM=1; else unset AA_NO_SLOT_FORM; fi
+for rep in 1 2; do for mode in proj noproj; do
+  if [ $mode = noproj ]; then export AA_OP_PROJ=0; else unset AA_OP_PROJ; fi
   r=$(timeout 600 python bench.py --workload c5 --steps 5 --warmup 3 --stages --no-cpu-baseline --no-gpu-reference --no-secondary --sustain 0 2> gpurun_out/${TAG}_ab_c5_$mode.log | grep -o '"ms_per_step": [0-9.]*' | head -1)
   echo "$mode $r"
 done; done | tee gpurun_out/${TAG}_ab_c5.txt
-unset AA_NO_SLOT_FORM
-grep '^\[stage\]' gpurun_out/${TAG}_ab_c5_slot.log
-bash tools/gpu_round.sh stages $TAG c4 | head -3
+unset AA_OP_PROJ
+grep '^\[stage\]' gpurun_out/${TAG}_ab_c5_proj.log
+grep '^\[stage\] tp_op' gpurun_out/${TAG}_ab_c5_noproj.log
