@@ -249,11 +249,13 @@ struct GemmArgs {
   int act_kind;      // activation behind act_a / has_z (AA_ACT_*); anything but SiLU runs the general VALU kernel
   int opt_v1, opt_lds_epilogue, opt_f64_column_loop, opt_f64_rows;  // aa_plan_options pass-throughs (A/B switches)
   // Batched form (gridDim.z = batch <= 16 problems of the same shape in one launch; no z / add operands): problem b reads
-  // A + b a_bs, writes C + b c_bs (elements) and multiplies by weight matrix number bsel[b] of a set stored at uniform strides.
+  // A + b a_bs, writes C + b c_bs (elements) and multiplies by weight matrix number (bsel4 >> 4 b) & 15 of a set stored at uniform
+  // strides (a packed word, not an array: a run-time-indexed kernel-argument array sends the WHOLE struct to scratch memory --
+  // every linear layer of C5 ran 35-40 % slower with `unsigned char bsel[16]` here).
   // (the env projections of the operator kernels: one problem per spherical-harmonic component, one matrix per irrep)
   int batch;
   int64_t a_bs, c_bs, b_bs, bp_bs, bq_bs;
-  unsigned char bsel[16];
+  unsigned long long bsel4;
 };
 template <typename T>
 int launch_gemm(const GemmArgs& g, hipStream_t stream);

@@ -28,21 +28,6 @@ __device__ __forceinline__ T seg_load(const SegList& sl, int64_t row, int col) {
   return T(0);
 }
 
-// batched launch: shift the views of this workgroup's problem (GemmArgs::batch)
-template <typename T>
-__device__ __forceinline__ void batch_view(GemmArgs& g) {
-  if (g.batch <= 1) return;
-  const int b = blockIdx.z, sel = g.bsel[b];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    if (s < g.a.count) g.a.s[s].p = static_cast<T*>(g.a.s[s].p) + b * g.a_bs;
-    if (s < g.c.count && g.c.s[s].p) g.c.s[s].p = static_cast<T*>(g.c.s[s].p) + b * g.c_bs;
-  }
-  g.B = static_cast<const T*>(g.B) + sel * g.b_bs;
-  if (g.Bp) g.Bp = static_cast<const T*>(g.Bp) + sel * g.bp_bs;
-  if (g.Bq) g.Bq = static_cast<const T*>(g.Bq) + sel * g.bq_bs;
-}
-
 // is column k of A activated on load?  (wave-uniform wherever k is a chunk base: the range is 32-granular)
 __device__ __forceinline__ bool a_act(const GemmArgs& g, int k) { return g.act_a && (g.act_hi == 0 || (k >= g.act_lo && k < g.act_hi)); }
 
@@ -76,7 +61,6 @@ __device__ __forceinline__ void seg_store(const GemmArgs& g, int64_t row, int co
 constexpr int GM_BM = 128, GM_BN = 64, GM_BK = 32, GM_LDA = GM_BM + 1;
 
 __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(GemmArgs g) {
-  batch_view<float>(g);
   float* As = reinterpret_cast<float*>(aa_smem);  // [BK][LDA]
   float* Bs = As + GM_BK * GM_LDA;                // [BK][BN]
   const int tid = threadIdx.x;
@@ -143,7 +127,6 @@ constexpr int GV_BM = 64, GV_BN = 64, GV_BK = 16, GV_LDA = GV_BM + 1;
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
-  batch_view<T>(g);
   T* As = reinterpret_cast<T*>(aa_smem);  // [BK][LDA]
   T* Bs = As + GV_BK * GV_LDA;            // [BK][BN]
   const int tid = threadIdx.x;
@@ -208,7 +191,6 @@ __global__ __launch_bounds__(256) void gemm_valu_kernel(GemmArgs g) {
 // rows 4r..4r+3 across the four 16-lane groups).
 typedef double v4d __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
-  batch_view<double>(g);
   double* As = reinterpret_cast<double*>(aa_smem);  // [BK][LDA]
   double* Bs = As + GV_BK * GV_LDA;                 // [BK][BN]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -275,7 +257,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
 // tile j + 1 issued before the arithmetic and stores of tile j (two operand sets in flight) -- 3 % on the accumulator-
 // resident kernel's z layers, but 57-150 spilled registers in the staged and the operand-resident kernel, whose K loops
 // then run 25-50 % slower (profiles/r03_n_stages_c5.log); not kept.
-__device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int64_t m_base, int li, int lg, const v4d& acc0, const v4d& acc1) {
+__device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int64_t m_base, int li, int lg, const v4d& acc0, const v4d& acc1,
+                                                  int64_t c_shift = 0) {
   if (t0 >= g.N) return;
   int cc = t0, si = -1;
 #pragma unroll
@@ -290,6 +273,7 @@ __device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int
   if (si < 0) return;
   double* cp = static_cast<double*>(g.c.s[si].p);
   if (!cp) return;
+  cp += c_shift;
   const int ldc = g.c.s[si].ld, col = cc + li;
   const double* zp = g.has_z ? static_cast<const double*>(g.z.s[si].p) : nullptr;
   const double* ap = g.has_add ? static_cast<const double*>(g.add.s[si].p) : nullptr;
@@ -335,7 +319,6 @@ __device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int
 constexpr int G6_BM = 128, G6_BN = 64, G6_BK = 16, G6_LDA = G6_BM + 4;
 typedef double v2d __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) {
-  batch_view<double>(g);
   double* smem = reinterpret_cast<double*>(aa_smem);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = int64_t(blockIdx.x) * G6_BM;
@@ -452,7 +435,6 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_f64_pipe_kernel(GemmArgs g) 
 // one barrier per 32-64 MFMAs of 64 cycles each.
 template <bool ASTAT>
 __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
-  batch_view<double>(g);
   constexpr int NB = ASTAT ? 64 : 128;  // columns per pass
   constexpr int JT = NB / 16;           // MFMA column tiles per pass
   constexpr int LDB = NB + 4;           // (rows 4 g + s of the four lane groups land in different banks)
@@ -462,7 +444,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int64_t m_base = (int64_t(blockIdx.x) * 4 + wv) * 32;
-  const double* B = static_cast<const double*>(g.B);
+  // batched launch (GemmArgs::batch): this workgroup's problem is blockIdx.z -- its operand / result views are the stated ones
+  // shifted by whole elements, its weights one matrix of the set.  (shifts applied where pointers are formed: a modified COPY of
+  // the argument struct would live in scratch memory, its segment tables are indexed at run time)
+  const int bz = g.batch > 1 ? int(blockIdx.z) : 0;
+  const int64_t a_sh = bz * g.a_bs, c_sh = bz * g.c_bs;
+  const double* B = static_cast<const double*>(g.B) + int64_t((g.bsel4 >> (4 * bz)) & 15ull) * g.b_bs;
   const int KC = g.K / 16;
   int64_t arow[2];
 #pragma unroll
@@ -491,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     for (int s2 = 0; s2 < 3; ++s2) {
       if (s2 < g.a.count && base == nullptr) {
         if (kk < g.a.s[s2].n) {
-          base = static_cast<const double*>(g.a.s[s2].p) + kk;
+          base = static_cast<const double*>(g.a.s[s2].p) + kk + a_sh;
           ld = g.a.s[s2].ld;
         } else {
           kk -= g.a.s[s2].n;
@@ -529,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
   };
   auto epilogue = [&](int n0, v4d (*acc)[JT]) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) f64_tile_epilogue(g, n0 + j * 16, m_base, li, lg, acc[0][j], acc[1][j]);
+    for (int j = 0; j < JT; ++j) f64_tile_epilogue(g, n0 + j * 16, m_base, li, lg, acc[0][j], acc[1][j], c_sh);
   };
   v4d acc[2][JT];
   auto zero_acc = [&]() {
@@ -667,7 +654,7 @@ __device__ __forceinline__ bool seglist_frag_ok(const SegList& sl) {
 }
 
 // pointer to A[gm][k .. k+15] (k multiple of 16) or nullptr when out of range
-__device__ __forceinline__ const float* a_half_ptr(const GemmArgs& g, int64_t gm, int k) {
+__device__ __forceinline__ const float* a_half_ptr(const GemmArgs& g, int64_t gm, int k, int64_t shift = 0) {
   const float* out = nullptr;
   if (gm < g.M && k < g.K) {
     int c = k;
@@ -676,7 +663,7 @@ __device__ __forceinline__ const float* a_half_ptr(const GemmArgs& g, int64_t gm
     for (int s = 0; s < 3; ++s) {
       const bool live = s < g.a.count;
       if (live && !done && c < g.a.s[s].n) {
-        out = static_cast<const float*>(g.a.s[s].p) + gm * g.a.s[s].ld + c;
+        out = static_cast<const float*>(g.a.s[s].p) + gm * g.a.s[s].ld + c + shift;
         done = true;
       }
       if (live) c -= g.a.s[s].n;
@@ -709,7 +696,7 @@ struct Dst4 {
   const float* add;
   int accum, nvalid;  // nvalid: how many of the 4 features exist (0..4)
 };
-__device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0) {
+__device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0, int64_t c_shift = 0) {
   Dst4 d;
   d.c = nullptr;
   d.z = nullptr;
@@ -723,7 +710,7 @@ __device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0) 
   for (int s = 0; s < 3; ++s) {
     const bool live = s < g.c.count;
     if (live && !done && c < g.c.s[s].n) {
-      d.c = g.c.s[s].p ? static_cast<float*>(g.c.s[s].p) + gm * g.c.s[s].ld + c : nullptr;
+      d.c = g.c.s[s].p ? static_cast<float*>(g.c.s[s].p) + gm * g.c.s[s].ld + c + c_shift : nullptr;
       d.accum = g.c_accum[s];
       if (g.has_z) d.z = static_cast<const float*>(g.z.s[s].p) + gm * g.z.s[s].ld + c;
       if (g.has_add) d.add = static_cast<const float*>(g.add.s[s].p) + gm * g.add.s[s].ld + c;
@@ -736,11 +723,11 @@ __device__ __forceinline__ Dst4 resolve4(const GemmArgs& g, int64_t gm, int f0) 
 }
 
 // acc holds C^T: column = row index (edge) lane&31, feature = n0 + (r&3) + 8*(r>>2) + 4*(lane>>5)
-__device__ __forceinline__ void store_tile_t(const GemmArgs& g, const v16f& acc, int64_t gm, int n0, int lane, bool vec_ok) {
+__device__ __forceinline__ void store_tile_t(const GemmArgs& g, const v16f& acc, int64_t gm, int n0, int lane, bool vec_ok, int64_t c_shift = 0) {
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
     const int f0 = n0 + 8 * gq + 4 * (lane >> 5);
-    const Dst4 d = resolve4(g, gm, f0);
+    const Dst4 d = resolve4(g, gm, f0, c_shift);
     if (d.nvalid == 0) continue;
     v4f v = {acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
     if (vec_ok && d.nvalid == 4) {
@@ -826,7 +813,6 @@ __device__ __forceinline__ void store_pair_lds(const GemmArgs& g, const v16f& ac
 // KCR == 0: fragments are streamed (and double-buffered) per k chunk.
 template <int KCR>
 __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int vec_ok) {
-  batch_view<float>(g);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
@@ -943,8 +929,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_v3_kernel(GemmArgs g, int v
 // feature k = 32c + 8*(s>>2) + 4h + (s&3) -- exactly the feature a lane holds in accumulator register s of the
 // swapped-operand C layout, so a layer's accumulators can be fed to the next layer's MFMAs without any data
 // movement (gemm_chain_bf16x3_kernel).  From global memory it is four 16-B pieces of the lane's own row.
-__device__ __forceinline__ void load_a_frag_acc(const GemmArgs& g, int64_t gm, int chunk, int h, v4f* a) {
-  const float* p = a_half_ptr(g, gm, chunk * 32);  // pointer to A[gm][32*chunk] (segments are 32-granular here)
+__device__ __forceinline__ void load_a_frag_acc(const GemmArgs& g, int64_t gm, int chunk, int h, v4f* a, int64_t shift = 0) {
+  const float* p = a_half_ptr(g, gm, chunk * 32, shift);  // pointer to A[gm][32*chunk] (segments are 32-granular here)
   if (p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const v4f*>(p + 8 * q + 4 * h);
@@ -994,14 +980,16 @@ __device__ __forceinline__ void chunk_pair_bf16x3(const u32x4* w0, const u32x4* 
 // current step issue (also across tile-pair boundaries); streamed activations are fetched two chunks ahead.
 template <int KCR, bool LDS_EPI>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x4* __restrict__ Wq, int vec_ok) {
-  batch_view<float>(g);
-  if (g.batch > 1) Wq = static_cast<const u32x4*>(g.Bq);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t m0 = (int64_t(blockIdx.x) * 4 + wv) * 32;
   const int64_t gm = m0 + (lane & 31);
   const int hh = lane >> 5;
   const int KC = (g.K + 31) >> 5;
   const int NT = (g.N + 31) >> 5;
+  // batched launch (GemmArgs::batch): problem blockIdx.z, see gemm_f64_rows_kernel
+  const int bz = g.batch > 1 ? int(blockIdx.z) : 0;
+  const int64_t a_sh = bz * g.a_bs, c_sh = bz * g.c_bs;
+  if (g.batch > 1) Wq = reinterpret_cast<const u32x4*>(static_cast<const float*>(g.Bq) + int64_t((g.bsel4 >> (4 * bz)) & 15ull) * g.bq_bs);
   const u32x4* Wl = Wq + lane;  // fragments are stored [tile][chunk][q][lane]
   const size_t chunk_stride = 64 * 6;                    // u32x4 units between chunks
   const size_t tile_stride = size_t(KC) * chunk_stride;  // between feature tiles
@@ -1011,7 +999,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
 #pragma unroll
     for (int kc = 0; kc < KCR; ++kc) {
       v4f a[4];
-      load_a_frag_acc(g, gm, kc, hh, a);
+      load_a_frag_acc(g, gm, kc, hh, a, a_sh);
       split3_pack(a, xr1[kc], xr2[kc], xr3[kc]);
     }
   }
@@ -1053,8 +1041,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
       }
     } else {
       v4f a0[4], a1[4];
-      load_a_frag_acc(g, gm, 0, hh, a0);
-      load_a_frag_acc(g, gm, KC > 1 ? 1 : 0, hh, a1);
+      load_a_frag_acc(g, gm, 0, hh, a0, a_sh);
+      load_a_frag_acc(g, gm, KC > 1 ? 1 : 0, hh, a1, a_sh);
       for (int kc = 0; kc < KC; ++kc) {
         // L2-resident weights are requested BEFORE the HBM activations: loads return in order, so the other
         // way round every step would wait a full HBM latency for its weights
@@ -1071,7 +1059,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
         __builtin_amdgcn_sched_barrier(0);
         v4f a2[4];
         const int k2 = kc + 2 < KC ? kc + 2 : KC - 1;
-        load_a_frag_acc(g, gm, k2, hh, a2);  // two chunks ahead
+        load_a_frag_acc(g, gm, k2, hh, a2, a_sh);  // two chunks ahead
         __builtin_amdgcn_sched_barrier(0);
         u32x4 x1[2], x2[2], x3[2];
         split3_pack(a0, x1, x2, x3);
@@ -1091,8 +1079,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g, const u32x
     if (LDS_EPI) {
       store_pair_lds(g, acc0, acc1, two, reinterpret_cast<float*>(aa_smem) + wv * 32 * EP_LD, m0, nt * 32, lane);
     } else {
-      store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok);
-      if (two) store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok);
+      store_tile_t(g, acc0, gm, nt * 32, lane, vec_ok, c_sh);
+      if (two) store_tile_t(g, acc1, gm, nt * 32 + 32, lane, vec_ok, c_sh);
     }
   }
 }
@@ -1733,20 +1721,36 @@ static int check_args(const GemmArgs& g) {
   return AA_OK;
 }
 
+// batched problem set on a kernel without the batched form: one launch per problem on shifted views
+template <typename T>
+static int launch_gemm_each(const GemmArgs& g, hipStream_t stream) {
+  for (int b = 0; b < g.batch; ++b) {
+    GemmArgs s = g;
+    s.batch = 0;
+    const int sel = int((g.bsel4 >> (4 * b)) & 15ull);
+    for (int q = 0; q < s.a.count; ++q) s.a.s[q].p = static_cast<T*>(s.a.s[q].p) + b * g.a_bs;
+    for (int q = 0; q < s.c.count; ++q)
+      if (s.c.s[q].p) s.c.s[q].p = static_cast<T*>(s.c.s[q].p) + b * g.c_bs;
+    s.B = static_cast<const T*>(g.B) + sel * g.b_bs;
+    if (g.Bp) s.Bp = static_cast<const T*>(g.Bp) + sel * g.bp_bs;
+    if (g.Bq) s.Bq = static_cast<const T*>(g.Bq) + sel * g.bq_bs;
+    if (int rc = launch_gemm<T>(s, stream)) return rc;
+  }
+  return AA_OK;
+}
+
 template <>
 int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
   if (g.M == 0) return AA_OK;
   if (int rc = check_args(g)) return rc;
-  const unsigned bz = g.batch > 1 ? unsigned(g.batch) : 1u;
   const bool v1_only = g.opt_v1 != 0;
   if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
+    if (g.batch > 1) return launch_gemm_each<float>(g, stream);
     dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
-    grid.z = bz;
     size_t smem = sizeof(float) * (GV_BK * GV_LDA + GV_BK * GV_BN);
     hipLaunchKernelGGL(gemm_valu_kernel<float>, grid, dim3(256), smem, stream, g);
   } else if (g.Bp && !v1_only && seglist_frag_ok_host(g.a)) {
     dim3 grid((unsigned)((g.M + 127) / 128));
-    grid.z = bz;
     // 16-B epilogue accesses need every C/Z segment to be 4-column granular and 16-B aligned
     int vec_ok = 1;
     for (int s = 0; s < g.c.count; ++s) {
@@ -1761,6 +1765,10 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
     if (g.Bq && g.force_kernel != 1 && seg32) {
       const u32x4* Wq = static_cast<const u32x4*>(g.Bq);
       const bool lds = vec_ok && !direct_epi;
+      if (g.batch > 1) {
+        if (lds) return launch_gemm_each<float>(g, stream);
+        grid.z = unsigned(g.batch);  // (the direct-epilogue kernel has the batched form)
+      }
       const size_t smem = lds ? sizeof(float) * 4 * 32 * EP_LD : 0;
 #define AA_LAUNCH_BF16(KCR)                                                                                   \
   if (lds)                                                                                                    \
@@ -1775,15 +1783,17 @@ int launch_gemm<float>(const GemmArgs& g, hipStream_t stream) {
         AA_LAUNCH_BF16(0)
       }
 #undef AA_LAUNCH_BF16
-    } else if (KC <= 2)
+    } else if (g.batch > 1)
+      return launch_gemm_each<float>(g, stream);
+    else if (KC <= 2)
       hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<2>, grid, dim3(256), 0, stream, g, vec_ok);
     else if (KC <= 4)
       hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<4>, grid, dim3(256), 0, stream, g, vec_ok);
     else
       hipLaunchKernelGGL(gemm_mfma_f32_v3_kernel<0>, grid, dim3(256), 0, stream, g, vec_ok);
   } else {
+    if (g.batch > 1) return launch_gemm_each<float>(g, stream);
     dim3 grid((unsigned)((g.M + GM_BM - 1) / GM_BM), (unsigned)((g.N + GM_BN - 1) / GM_BN));
-    grid.z = bz;
     size_t smem = sizeof(float) * (GM_BK * GM_LDA + GM_BK * GM_BN);
     hipLaunchKernelGGL(gemm_mfma_f32_kernel, grid, dim3(256), smem, stream, g);
   }
@@ -1795,9 +1805,7 @@ template <>
 int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
   if (g.M == 0) return AA_OK;
   if (int rc = check_args(g)) return rc;
-  const unsigned bz = g.batch > 1 ? unsigned(g.batch) : 1u;
   dim3 grid((unsigned)((g.M + GV_BM - 1) / GV_BM), (unsigned)((g.N + GV_BN - 1) / GV_BN));
-  grid.z = bz;
   size_t smem = sizeof(double) * (GV_BK * GV_LDA + GV_BK * GV_BN);
   bool pipe_ok = (g.N % 2) == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
   for (int s2 = 0; s2 < g.a.count; ++s2)
@@ -1807,6 +1815,9 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
     pipe_ok = pipe_ok && (g.c.s[s2].n % 16) == 0;
     epilogue_reads = epilogue_reads || g.c_accum[s2] != 0;
   }
+  const bool rows_ok = pipe_ok && g.opt_f64_column_loop == 0 && g.opt_f64_rows != 2 && (g.K % 16) == 0 &&
+                       (g.opt_f64_rows == 1 ? (g.N <= 128 || g.K <= 128) : (g.N <= 128 || (g.K <= 128 && !epilogue_reads)));
+  if (g.batch > 1 && (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU || !rows_ok)) return launch_gemm_each<double>(g, stream);  // (only the row-resident kernels have the batched form)
   if (g.force_kernel == 3 || g.act_kind != AA_ACT_SILU) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok && g.opt_f64_column_loop == 0 && g.opt_f64_rows != 2 && (g.K % 16) == 0 &&
@@ -1817,8 +1828,7 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
     // the operand-resident form (N > 128, K <= 128) wins 5-8 % on plain layers and loses 25-30 % where the epilogue fetches
     // z / add operands or accumulates into C (its two waves per SIMD overlap the silu' arithmetic of one pass with the next pass's MFMAs worse
     // than the staged kernel's three) -- those keep the staged kernel unless forced (aa_plan_options.f64_rows = 1).
-    dim3 gridr((unsigned)((g.M + 127) / 128));
-    gridr.z = bz;
+    dim3 gridr((unsigned)((g.M + 127) / 128), 1, g.batch > 1 ? unsigned(g.batch) : 1u);
     if (g.N <= 128) {
       const size_t smemr = sizeof(double) * 2 * 16 * (128 + 4);
       hipLaunchKernelGGL(gemm_f64_rows_kernel<false>, gridr, dim3(256), smemr, stream, g);
@@ -1828,7 +1838,6 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
     }
   } else if (pipe_ok) {
     dim3 grid6((unsigned)((g.M + G6_BM - 1) / G6_BM), (unsigned)((g.N + G6_BN - 1) / G6_BN));
-    grid6.z = bz;
     // enough row tiles to fill the chip on their own: one workgroup per row tile looping over the column tiles
     // (aa_plan_options.f64_column_loop: 1 never, 2 always -- tests)
     if (g.opt_f64_column_loop == 2 || (g.opt_f64_column_loop == 0 && grid6.x >= 2048)) grid6.y = 1;

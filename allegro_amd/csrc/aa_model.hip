@@ -1699,7 +1699,7 @@ struct Runner {
     gm.bq_bs = int64_t(ms.wq_bs);
     for (int j = 0, r = 0; j < p->D; ++j) {
       if (j >= (r + 1) * (r + 1)) ++r;
-      gm.bsel[j] = static_cast<unsigned char>(r);
+      gm.bsel4 |= static_cast<unsigned long long>(r) << (4 * j);
     }
     if (int rc = launch_gemm<T>(gm, stream)) return rc;
     return mark("op_proj_gemm", 0, double(p->D) * (ms.K + ms.N), 2.0 * double(gm.M) * p->D * ms.K * ms.N);

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out; export TMPDIR=/tmp
-TAG=r04_v16
+TAG=r04_v17
 timeout 900 python -m pytest tests -m gpu -q -k "operator_path or c5_full or gemm" > gpurun_out/${TAG}_pytest_quick.log 2>&1; tail -5 gpurun_out/${TAG}_pytest_quick.log
 for rep in 1 2; do for mode in proj noproj; do
   if [ $mode = noproj ]; then export AA_OP_PROJ=0; else unset AA_OP_PROJ; fi
