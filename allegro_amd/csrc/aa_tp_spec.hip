@@ -752,6 +752,12 @@ __device__ __forceinline__ void mom_project(const T* sM, int ka, int ka_lds, con
   __builtin_amdgcn_wave_barrier();
 }
 
+// (timing experiments only: -DAA_EXP_GM_SHORT contracts 8 of the 64 channels -- WRONG results, prices the projection)
+#ifdef AA_EXP_GM_SHORT
+constexpr int kGmChannels = 8;
+#else
+constexpr int kGmChannels = 64;
+#endif
 // plain form of mom_gm below (sG as [j][ch], weight rows copied between two register sets): what tp_mom_bwd_first keeps --
 // same-box A/B on MI355X (profiles/r04_v6_ab_c4.txt): the packed form is 6.5 % faster in tp_mom_bwd_last (1.019 -> 0.952 ms)
 // and 3 % slower in tp_mom_bwd_first (220 instead of 204 registers at two waves per SIMD)
@@ -770,7 +776,7 @@ __device__ __forceinline__ void mom_gm_plain(const T* sG, const T* Wt, int ka, i
     }
   };
   loadw(0, wc);
-  for (int c0 = 0; c0 < 64; c0 += CB) {
+  for (int c0 = 0; c0 < kGmChannels; c0 += CB) {
     loadw(c0 + CB, wn);
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
@@ -851,10 +857,10 @@ __device__ __forceinline__ void mom_gm(const T* sG, const T* Wt, int ka, int kb,
   };
   loadw(0, wa);
 #pragma unroll 1
-  for (int c0 = 0; c0 < 64; c0 += 2 * CB) {  // (not unrolled further: the reverse kernels run at up to 4 waves per SIMD, 128 registers)
+  for (int c0 = 0; c0 < kGmChannels; c0 += 2 * CB) {  // (not unrolled further: the reverse kernels run at up to 4 waves per SIMD, 128 registers)
     loadw(c0 + CB, wb);
     consume(c0, wa);
-    if (c0 + 2 * CB < 64) loadw(c0 + 2 * CB, wa);
+    if (c0 + 2 * CB < kGmChannels) loadw(c0 + 2 * CB, wa);
     consume(c0 + CB, wb);
   }
 #pragma unroll
