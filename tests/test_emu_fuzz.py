@@ -141,3 +141,55 @@ def test_random_irreps_contracter_vs_oracle(seed):
     r1, r2 = torch.autograd.grad(yr, [x1, x2], gy)
     for got, want in ((y, yr), (g1, r1), (g2, r2)):
         assert (got - want).abs().max().item() < 1e-10
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_slot_form_configuration_vs_oracle(seed, monkeypatch):
+    """The same sweep over the shapes that take the slot form of the linear layers on the operator kernels (S = latent width
+    = scalar_embed_mlp width in {64, 128}, 2-3 layers, channel counts that pad to 64 or 128, scalar_embed_mlp / readout depths
+    1-2, Bessel or spline bases), with the env projections inside the per-atom kernels or as batched launches, against the
+    oracle in fp64: energies, forces, strain derivative; unsorted edge lists, atoms without edges."""
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(5, 13))
+    rc = float(rng.uniform(2.6, 3.4))
+    pos = rng.uniform(0, 5.5, (n, 3))
+    pos[n - 1] = [40.0, 40.0, 40.0]  # no edges
+    cell = np.eye(3) * 80.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, rc)
+    assert ei.shape[1] > 0
+    T, l_max, L = int(rng.integers(1, 4)), int(rng.integers(1, 4)), int(rng.integers(2, 4))
+    S = int(rng.choice([64, 64, 128]))
+    u = int(rng.choice([32, 64, 96, 128]))
+    spline, B = bool(rng.integers(0, 2)), int(rng.choice([4, 8]))
+    rce = ({"_target_": "allegro.nn.TwoBodySplineScalarEmbed", "num_splines": B, "spline_span": int(rng.integers(1, B + 1))}
+           if spline else {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": B})
+    cfg = dict(type_names=["A", "B", "C"][:T], r_max=rc, l_max=l_max, num_layers=L, num_scalar_features=S,
+               num_tensor_features=u, radial_chemical_embed=rce, radial_chemical_embed_dim=int(rng.choice([16, 48])),
+               scalar_embed_mlp_hidden_layers_depth=int(rng.integers(1, 3)), scalar_embed_mlp_hidden_layers_width=S,
+               allegro_mlp_hidden_layers_depth=1, allegro_mlp_hidden_layers_width=S,
+               readout_mlp_hidden_layers_depth=int(rng.integers(1, 3)), readout_mlp_hidden_layers_width=int(rng.choice([16, 64, 128])),
+               tp_path_channel_coupling=bool(rng.integers(0, 2)), avg_num_neighbors=float(max(1, ei.shape[1] / n)),
+               seed=int(seed),
+               per_type_energy_scales=[float(x) for x in rng.uniform(0.5, 2, T)] if rng.integers(0, 2) else None,
+               per_type_energy_shifts=[float(x) for x in rng.uniform(-1, 1, T)] if rng.integers(0, 2) else None,
+               model_dtype="float64")
+    monkeypatch.setenv("AA_OP_PROJ", "1" if rng.integers(0, 2) else "0")
+    monkeypatch.setenv("AA_TP_OP", "1")  # (operator kernels also where the tuned 2-layer u = 64 kernels would apply)
+    m = HipAllegroModel(**cfg)
+    m._bind_library(emu_lib())
+    d = m.describe_plan()
+    assert d["operator_path"] and d["slot_form"], (cfg, d)
+    types = torch.tensor(rng.integers(0, T, size=n))
+    sv = torch.tensor(shift @ cell)
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(seed))
+    g = m.prepare_graph(torch.tensor(ei)[:, perm], types, n, sv[perm])
+    e, f = m.energy_forces(torch.tensor(pos), g)
+    w = m.virial(g)
+    sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
+    ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, sv)
+    wref = R.allegro_virial(cfg, sd, torch.tensor(pos), torch.tensor(ei), types, sv)
+    for got, want in ((e, ref["atomic_energy"].reshape(-1)), (f, ref["forces"]), (w, wref)):
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() <= 1e-9 * max(1.0, float(want.abs().max()))
