@@ -554,6 +554,7 @@ struct TpOpArgs {
   // (512 KB at C5) through every atom's wave.
   int proj_gemm;
   void* dx2s;            // [N][D][u]      reverse, proj_gemm: d x2s of the layer being reversed (unscaled)
+  int env_mfma;          // fp64: the adjoint of the moments on the edges (tp_op_edge_env) on the f64 matrix cores
 };
 int find_op_chain(const int* sigs, int num_layers);  // chain id or -1
 template <typename T>

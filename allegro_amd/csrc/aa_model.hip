@@ -1664,6 +1664,7 @@ struct Runner {
     o.ld_gw0 = p->W;
     o.ld_gsh = p->D;
     o.ka_lds = std::max(c.num_scalar, c.latent_mlp_width);
+    o.env_mfma = (sizeof(T) == 8 && !p->opt.op_env_vector && (o.ld_a % 2) == 0) ? 1 : 0;
     return o;
   }
 

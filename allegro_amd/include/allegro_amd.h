@@ -232,6 +232,8 @@ typedef struct {
                              * pass evaluated per dense-net slot) -- same results, A/B and tests                                   */
   int32_t op_proj_gemm;     /* operator-kernel plans: the env projections (x2s = f M Wenv and its reverse) as batched linear-layer launches
                              * over all atoms instead of inside the per-atom kernels: 0 = from 4096 atoms on, 1 = always, 2 = never       */
+  int32_t op_env_vector;    /* operator-kernel plans, fp64: 1 = the adjoint of the moments on the edges in its vector form instead of on the
+                             * f64 matrix cores (A/B, tests)                                                                       */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);
