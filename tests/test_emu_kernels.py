@@ -137,7 +137,7 @@ def test_moments_path_long_segments_vs_oracle():
 
 @pytest.mark.parametrize("l_max,L,u,S,force,we,slot,extra", [
     (2, 3, 64, 64, False, 32, True, {}), (3, 3, 128, 128, False, 32, False, dict(proj=1)), (3, 3, 128, 128, False, 128, True, dict(proj=1)),
-    (2, 2, 128, 64, False, 32, True, {}), (2, 2, 64, 64, True, 32, True, dict(proj=1)),
+    (2, 2, 128, 64, False, 32, True, dict(radial_chemical_embed_dim=128)), (2, 2, 64, 64, True, 32, True, dict(proj=1)),
     (2, 3, 64, 64, False, 64, True, dict(scalar_embed_mlp_hidden_layers_depth=2, readout_mlp_hidden_layers_depth=2)),
     (2, 3, 64, 64, False, 64, False, dict(allegro_mlp_hidden_layers_depth=2, proj=1))])
 def test_operator_path_vs_oracle(l_max, L, u, S, force, we, slot, extra, monkeypatch):
@@ -166,8 +166,9 @@ def test_operator_path_vs_oracle(l_max, L, u, S, force, we, slot, extra, monkeyp
     assert deg[n - 1] == 0 and ei.shape[1] >= 10
     cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
                radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
-               radial_chemical_embed_dim=16, scalar_embed_mlp_hidden_layers_width=we, allegro_mlp_hidden_layers_width=S,
-               readout_mlp_hidden_layers_width=32, avg_num_neighbors=float(deg.mean()), seed=11, model_dtype="float64", **extra)
+               scalar_embed_mlp_hidden_layers_width=we, allegro_mlp_hidden_layers_width=S,
+               readout_mlp_hidden_layers_width=32, avg_num_neighbors=float(deg.mean()), seed=11, model_dtype="float64",
+               **{"radial_chemical_embed_dim": 16, **extra})  # (embed dim 128: the 16-lanes-per-edge form of the geometry reverse)
     m = HipAllegroModel(**cfg)
     m._bind_library(emu_lib())
     d = m.describe_plan()

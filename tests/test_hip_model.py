@@ -337,7 +337,8 @@ def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, we, slot, de
     name = {torch.float64: "float64", torch.float32: "float32"}[dtype]
     cfg = dict(type_names=["A", "B"], r_max=r_max, l_max=l_max, num_layers=L, num_scalar_features=S, num_tensor_features=u,
                radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8},
-               radial_chemical_embed_dim=32, scalar_embed_mlp_hidden_layers_width=we, allegro_mlp_hidden_layers_width=S,
+               radial_chemical_embed_dim=128 if S == 128 else 32,  # (128: the 16-lanes-per-edge form of the geometry reverse)
+               scalar_embed_mlp_hidden_layers_width=we, allegro_mlp_hidden_layers_width=S,
                readout_mlp_hidden_layers_width=64, avg_num_neighbors=float(deg.mean()), seed=5, model_dtype=name)
     if not slot and we == S:
         monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
