@@ -279,6 +279,8 @@ struct ChainLayer {
                        // reverse of the two-body basis expansion folded into the epilogue (C itself need not be stored)
   void* edge_sum_out;  // [M] or nullptr: out[e] = sum_c silu(C[e,c]) * ro_w[c] of this (64-wide) layer -- the last linear
                        // readout layer folded into the epilogue, so the edge sum reads 4 B/edge instead of a row
+  void* kept_out;      // [M, ld_kept] or nullptr: the kept 64 features AS KEPT (activated if keep_act) are also stored -- the hidden
+  int ld_kept;         // activation a later launch consumes where the folded-away output layer's result used to be (staged forward)
 };
 struct ChainArgs {
   int64_t M;

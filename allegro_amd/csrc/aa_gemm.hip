@@ -1141,6 +1141,8 @@ struct ChainLayerDev {
   int use_prev, pad2_;
   float* edge_sum_out;
   float* embrev_out;
+  float* kept_out;
+  int ld_kept, pad3_;
   const float *a2_add, *a2_z;  // a_mode 2 operand transform
   int ld_a2add, ld_a2z;
   const float* a[kChainMaxBlocks];
@@ -1527,6 +1529,14 @@ __global__ __launch_bounds__(256, PRE ? 2 : 3) void gemm_chain_bf16x3_kernel(Cha
           kept0[r] = L.keep_act ? silu(acc0[r]) : acc0[r];
           kept1[r] = L.keep_act ? silu(acc1[r]) : acc1[r];
         }
+        if (L.kept_out && row_ok) {  // (accumulator layout: register 4 q + e of tile t holds feature 32 t + 8 q + 4 hh + e of this lane's row)
+          float* ko = L.kept_out + gm * L.ld_kept + 4 * hh;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<v4f*>(ko + 8 * q) = v4f{kept0[4 * q], kept0[4 * q + 1], kept0[4 * q + 2], kept0[4 * q + 3]};
+            *reinterpret_cast<v4f*>(ko + 32 + 8 * q) = v4f{kept1[4 * q], kept1[4 * q + 1], kept1[4 * q + 2], kept1[4 * q + 3]};
+          }
+        }
       }
     }
   }
@@ -1618,6 +1628,10 @@ int launch_gemm_chain(const ChainArgs& c, hipStream_t stream) {
       if (!c.ro_w) return fail(AA_ERR_INVALID, "gemm chain: a_mode 1 needs ro_w");
       d.ro_n = std::max(d.ro_n, nchunk * 32);
     }
+    D.kept_out = static_cast<float*>(L.kept_out);
+    D.ld_kept = L.ld_kept;
+    if (L.kept_out && (L.keep_tile < 0 || (L.ld_kept & 3) || (reinterpret_cast<uintptr_t>(L.kept_out) & 15)))
+      return fail(AA_ERR_INVALID, "gemm chain: kept_out needs a kept tile pair and 16-B aligned rows");
     D.embrev_out = static_cast<float*>(L.embrev_out);
     if (L.embrev_out && (!c.emb_table || g.N != 64)) return fail(AA_ERR_INVALID, "gemm chain: embrev_out needs the table and a 64-wide layer");
     D.edge_sum_out = static_cast<float*>(L.edge_sum_out);

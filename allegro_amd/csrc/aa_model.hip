@@ -1775,6 +1775,15 @@ struct Runner {
   }
   // the reverse tail in one launch (aa_fused_bwd.hip): same eligibility as the fused forward + the two-body table of the reverse
   bool use_fused_tail(const aa_graph* g) const { return use_fused_fwd(g) && p->fused_tail; }
+  // the staged forward chains in the same folded form as the fused forward (kFoldEmb1, kFoldLatent): the hidden activations a_e /
+  // a_0 are stored where the embedding / lat_0 used to be (ChainLayer::kept_out), consumers run on the folded matrices.  What
+  // graphs with long segments -- dense systems, too large for the team form -- run.
+  bool fold_staged() const {
+    return kFoldEmb1 && kFoldLatent && p->chain_gemm && p->tp_op < 0 && p->o_g0fq && p->o_lat1in_fq && p->o_wk0f && p->cfg.num_layers == 2 && !p->taps &&
+           !p->opt.staged_no_fold;
+  }
+  // did the forward of this step leave a_e in the embedding's slot (folded first stage / env weights in the reverse)?
+  bool folded_fwd(const aa_graph* g) const { return use_fused_fwd(g) || fold_staged(); }
 #ifdef AA_EXPERIMENTAL_TAIL
   int backward_fused_tail(const aa_graph* g, void* forces) {
     const aa_model_config& c = p->cfg;
@@ -1981,6 +1990,7 @@ struct Runner {
     if (int rc = mark("edge_prologue", idx2 + 6 + (g->shift_vec ? 3 : 0) + 4 + p->D + c.embed_dim)) return rc;
     const SegList none{0, {}};
     const bool slot = use_slot();
+    const bool fstaged = fold_staged();
     if (p->chain_gemm) {
       // 3 + 4 + 5a as ONE kernel: emb0 -> h_e -> emb -> [two_body | w0]; hidden layers stay in registers
       ChainArgs ca{};
@@ -1992,6 +2002,13 @@ struct Runner {
       ca.L[0] = chain_layer(E, in, 0, wt(p->embed.wq[0]), c.embed_dim, 64, c0, nullptr, nullptr, nullptr, 0, 0, 1);
       ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wq[1]), 64, S, c1, nullptr, nullptr, nullptr, 1, 0, 0);
       ca.L[2] = chain_layer(E, none, 0, wt(p->o_g0q), 64, p->ng0, c2, nullptr, nullptr, nullptr, 1, -1, 0);
+      if (fstaged) {
+        // folded: a_e = silu(h_e) is stored where the embedding used to be; [two_body | w0] = a_e @ (W1 G0)
+        ca.nlayers = 2;
+        ca.L[0].kept_out = buf(w.emb);
+        ca.L[0].ld_kept = S;
+        ca.L[1] = chain_layer(E, none, 0, wt(p->o_g0fq), 64, p->ng0, c2, nullptr, nullptr, nullptr, 1, -1, 0);
+      }
       if (int rc = run_chain(ca, "F1")) return rc;
     } else if (slot) {
       // 3: hidden layers of scalar_embed_mlp; 4 + 5a on the activated last hidden layer (output layer folded into G0)
@@ -2027,6 +2044,7 @@ struct Runner {
         TpMomArgs m = mom_args(g);
         if (l == 0) {
           m.c.scal1 = buf(w.scal[0]);  // the first-layer kernel writes its scalars through this field
+          if (fstaged) m.wk0 = wt(p->o_wk0f);  // (its env input is a_e: env weights behind the output layer of scalar_embed_mlp)
           if (int rc = launch_tp_mom_fwd_first<T>(p->chain_pair, m, stream)) return rc;
           if (int rc = mark("tp_mom_fwd_first", p->D + m.ka0 + W + u, double(p->D) * u)) return rc;
         } else {
@@ -2086,7 +2104,21 @@ struct Runner {
         SegList ch{1, {seg(buf(w.lat_h[l][0]), 64, 64)}};
         SegList cl{1, {seg(buf(w.fcat) + S * (l + 1), SL1, S)}};
         ca.L[0] = chain_layer(E, in, 0, wt(p->latent[l].wq[0]), S * (l + 1) + u, 64, ch, nullptr, nullptr, nullptr, 0, 0, 1);
-        if (l < L - 1) {
+        if (fstaged && l < L - 1) {
+          // folded: no output layer; a_l = silu(z_l) goes where lat_l used to be
+          ca.nlayers = 1;
+          ca.L[0].kept_out = buf(w.fcat) + S * (l + 1);
+          ca.L[0].ld_kept = SL1;
+        } else if (fstaged) {
+          // folded: latent 1 and the readout on [two-body | a_0 | ...] with the output layers folded into their row blocks; a_1 stays in registers
+          ca.nlayers = 2;
+          SegList fin{1, {seg(buf(w.fcat), SL1, S * L)}};
+          SegList cr{1, {seg(buf(w.ro_h[0]), 64, 64)}};
+          ca.L[0] = chain_layer(E, in, 0, wt(p->o_lat1in_fq), S * (l + 1) + u, 64, ch, nullptr, nullptr, nullptr, 0, 0, 1);
+          ca.L[1] = chain_layer(E, fin, 0, wt(p->o_ro0_fq), S * L + 64, 64, cr, nullptr, nullptr, nullptr, 1, -1, 0);
+          ca.L[1].edge_sum_out = buf(w.e_edge);
+          ca.ro_w = wt(p->o_ro_last);
+        } else if (l < L - 1) {
           ca.nlayers = 2;
           ca.L[1] = chain_layer(E, none, 0, wt(p->latent[l].wq[1]), 64, S, cl, nullptr, nullptr, nullptr, 1, -1, 0);
         } else {
@@ -2361,7 +2393,7 @@ struct Runner {
           m.ld_ga = S;
           // (after a fused forward the embedding's slot holds a_e = silu(h) of scalar_embed_mlp and the env weights are folded behind
           //  its output layer, kFoldEmb1: d a_e comes out instead of d emb)
-          if (kFoldEmb1 && p->o_wt0f && use_fused_fwd(g)) m.wt0 = wt(p->o_wt0f);
+          if (kFoldEmb1 && p->o_wt0f && folded_fwd(g)) m.wt0 = wt(p->o_wt0f);
           if (int rc = launch_tp_mom_bwd_first<T>(p->chain_pair, m, stream)) return rc;
           if (int rc = mark("tp_mom_bwd_first", p->D + 2 * W + 2 * u + 2 * m.ka0 + 2 * p->D, 2.0 * p->D * u)) return rc;
         }
@@ -2462,7 +2494,7 @@ struct Runner {
       ca.L[0] = chain_layer(E, in, 0, wt(p->o_g0tq), p->ng0, S, cn, nullptr, nullptr, &ad, 0, 0, 0);
       ca.L[1] = chain_layer(E, none, 0, wt(p->embed.wtq[1]), S, 64, cn, nullptr, &zz, nullptr, 1, 0, 0);
       ca.L[2] = chain_layer(E, none, 0, wt(p->embed.wtq[0]), 64, c.embed_dim, ce, nullptr, nullptr, nullptr, 1, -1, 0);
-      if (kFoldEmb1 && p->o_g0tfq && use_fused_fwd(g)) {
+      if (kFoldEmb1 && p->o_g0tfq && folded_fwd(g)) {
         // everything in front of the hidden layer of scalar_embed_mlp folded (kFoldEmb1; the forward stored a_e, not the embedding):
         // d h = ((d[two-body | w0] @ (W1 G0)^T) + d a_e of the moments) x silu'(h) -- ONE 256 -> 64 layer, 8 steps -- ...
         ca.nlayers = 1;

@@ -234,6 +234,8 @@ typedef struct {
                              * over all atoms instead of inside the per-atom kernels: 0 = from 4096 atoms on, 1 = always, 2 = never       */
   int32_t op_env_vector;    /* operator-kernel plans, fp64: 1 = the adjoint of the moments on the edges in its vector form instead of on the
                              * f64 matrix cores (A/B, tests)                                                                       */
+  int32_t staged_no_fold;   /* staged fp32 pipeline (graphs the fused forward does not take): 1 = forward chains with the reference's own layers
+                             * instead of the folded ones (A/B, tests)                                                             */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

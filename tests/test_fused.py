@@ -336,11 +336,18 @@ def test_fused_and_staged_forward_agree_on_gpu(mode, name, monkeypatch):
     m = model_from_fixture(fx, torch.float32, device=dev)
     g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
     e, f = m.energy_forces(data["pos"], g)
-    monkeypatch.setenv("AA_FUSED", "0")  # the staged pipeline
+    monkeypatch.setenv("AA_FUSED", "0")  # the staged pipeline: its chains in the folded form (default) ...
     m2 = model_from_fixture(fx, torch.float32, device=dev)
     e2, f2 = m2.energy_forces(data["pos"], g)
-    assert (e - e2).abs().max().item() < 5e-6 and (f - f2).abs().max().item() < 2e-5
-    for got, want in ((e.cpu(), fx["out"]["atomic_energy"].reshape(-1)), (f.cpu(), fx["out"]["forces"])):
+    monkeypatch.setenv("AA_STAGED_NOFOLD", "1")  # ... and with the reference's own layers
+    m3 = model_from_fixture(fx, torch.float32, device=dev)
+    e3, f3 = m3.energy_forces(data["pos"], g)
+    names2, names3 = _launches(m2, data, g), _launches(m3, data, g)
+    assert "fused_fwd" not in names2 and "fused_fwd" not in names3 and names2 != names3, (names2, names3)
+    for ex, fx_ in ((e2, f2), (e3, f3)):
+        assert (e - ex).abs().max().item() < 5e-6 and (f - fx_).abs().max().item() < 2e-5
+    for got, want in ((e.cpu(), fx["out"]["atomic_energy"].reshape(-1)), (f.cpu(), fx["out"]["forces"]), (e2.cpu(), fx["out"]["atomic_energy"].reshape(-1)),
+                      (f2.cpu(), fx["out"]["forces"]), (f3.cpu(), fx["out"]["forces"])):
         assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
@@ -415,3 +422,17 @@ def test_three_species_with_long_segments_fall_back_to_the_staged_forward_emulat
 @pytest.mark.gpu
 def test_three_species_with_long_segments_fall_back_to_the_staged_forward_on_gpu(monkeypatch):
     _three_species_long_segments(None, torch.device("cuda:0"), monkeypatch)
+
+
+@pytest.mark.parametrize("nofold", [False, True])
+def test_staged_pipeline_in_folded_and_unfolded_form_vs_fp64_oracle_emulated(nofold, monkeypatch):
+    """The staged fp32 pipeline (what graphs with long segments run) evaluates its forward chains in the folded form of the fused
+    forward -- a_e / a_0 stored where the embedding / lat_0 used to be (ChainLayer::kept_out), consumers on the folded matrices, the
+    last reverse chain one 256 -> 64 layer -- or, under aa_plan_options.staged_no_fold, with the reference's own layers."""
+    monkeypatch.setenv("AA_FUSED", "0")
+    if nofold:
+        monkeypatch.setenv("AA_STAGED_NOFOLD", "1")
+    pos, cell, ei, shift, types = _ragged(dims=(3, 3, 2))
+    m = _vs_oracle64(_cfg(), pos, cell, ei, shift, types, emu_lib(), torch.device("cpu"))
+    _assert_launched(m, pos, cell, ei, shift, types, present=["gc_64x64_64x64_64x256" if nofold else "gc_64x64_64x256",
+                                                                "gc_128x64_64x64" if nofold else "gc_128x64"], absent=["fused_fwd"])
