@@ -261,11 +261,11 @@ __global__ __launch_bounds__(256) void tp_op_edge_fwd_kernel(TpOpArgs a, int lay
     const T* y = sh + int64_t(s) * a.ld_sh;
     T wr[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) wr[r] = w0[int64_t(s) * a.ld_w0 + r * u];
+    for (int r = 0; r < R; ++r) wr[r] = ld_stream(w0 + int64_t(s) * a.ld_w0 + r * u);
     T acc = T(0);
 #pragma unroll
     for (int i = 0; i < D1; ++i) acc += (y[i] * wr[r_of<0>(i)]) * b[i];
-    sc[int64_t(s) * a.ld_scal] = acc;
+    st_stream(sc + int64_t(s) * a.ld_scal, acc);
   }
 }
 
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void tp_op_moments_kernel(TpOpArgs a) {
   for (int j = 0; j < D; ++j) m[j] = T(0);
 #pragma unroll 4
   for (int s = beg; s < end; ++s) {
-    T x = av[int64_t(s) * a.ld_a];
+    T x = ld_stream(av + int64_t(s) * a.ld_a);
     if (a.act) x = silu(x);
     const T* y = sh + int64_t(s) * a.ld_sh;
 #pragma unroll
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) void tp_op_edge_bwd_kernel(TpOpArgs a, int lay
     const T* y = sh + int64_t(s) * a.ld_sh;
     T wr[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) wr[r] = w0[int64_t(s) * a.ld_w0 + r * u];
-    const T g = gl[int64_t(s) * a.ld_gscal];
+    for (int r = 0; r < R; ++r) wr[r] = ld_stream(w0 + int64_t(s) * a.ld_w0 + r * u);
+    const T g = ld_stream(gl + int64_t(s) * a.ld_gscal);
 #pragma unroll
     for (int i = 0; i < D1; ++i) q[i] += g * (y[i] * wr[r_of<0>(i)]);
     if constexpr (FIRST) {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void tp_op_edge_bwd_kernel(TpOpArgs a, int lay
         gy[i] = gx * wr[r_of<0>(i)];
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) gw0[int64_t(s) * a.ld_gw0 + r * u] = gw[r];
+      for (int r = 0; r < R; ++r) st_stream(gw0 + int64_t(s) * a.ld_gw0 + r * u, gw[r]);
       wave_sum_store<T, D1>(gy, gsx + int64_t(s) * a.ld_gsh, true, false);
     }
   }

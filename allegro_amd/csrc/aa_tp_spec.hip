@@ -628,25 +628,6 @@ __global__ __launch_bounds__(256) void tp_chain_bwd_first_kernel(TpChainArgs a) 
 // math reads them as 2-vectors.
 // =============================================================================================
 namespace {
-// streamed-once operands of the moments kernels carry the non-temporal hint: each row is read by exactly one wave and
-// written rows are not read again before they have left the caches (C4: 2-4 % per kernel, profiles/r02_v12_nt_stages_*;
-// tools/ubench/hbm_stream.hip: +5-10 % for this one-row-per-instruction pattern; -DAA_NO_NT builds without)
-template <typename T>
-__device__ __forceinline__ T ld_stream(const T* p) {
-#ifndef AA_NO_NT
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-template <typename T>
-__device__ __forceinline__ void st_stream(T* p, T v) {
-#ifndef AA_NO_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
 constexpr int kMaxKa = 128;
 constexpr int kSegCap = 64;  // edges of a segment staged per pass (longer segments are walked in chunks of this size)
 constexpr int kPB = 8;       // edge pairs per load batch in the moment loops
