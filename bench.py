@@ -85,7 +85,7 @@ def make_workload(name):
     else:
         g = G.make_water_graph(w["side"], w["box"])
         cfg = water_model_cfg(g.num_edges / g.num_atoms)
-    cfg["model_dtype"] = w["dtype"]
+    cfg["model_dtype"] = os.environ.get("AA_BENCH_DTYPE", w["dtype"])  # (AA_BENCH_DTYPE: experiments only, e.g. C5's shapes in fp32)
     return g, cfg
 
 
