@@ -713,8 +713,10 @@ int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStrea
   }
 #define AA_OP_ENV(DD)                                                                                                           \
   if (sizeof(T) == 8 && a.env_mfma) {                                                                                           \
-    hipLaunchKernelGGL((tp_op_edge_env_mfma_kernel<DD>), dim3((unsigned)((a.N - a.atom0 + 3) / 4)), dim3(256),                  \
-                       sizeof(double) * 4 * DD * (a.ka + 2), stream, a);                                                        \
+    const size_t smem_env = sizeof(double) * 4 * DD * (a.ka + 2);                                                               \
+    if (smem_env > 48 * 1024)                                                                                                   \
+      AA_CHECK_HIP(hipFuncSetAttribute((const void*)tp_op_edge_env_mfma_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem_env))); \
+    hipLaunchKernelGGL((tp_op_edge_env_mfma_kernel<DD>), dim3((unsigned)((a.N - a.atom0 + 3) / 4)), dim3(256), smem_env, stream, a); \
   } else {                                                                                                                      \
     hipLaunchKernelGGL((tp_op_edge_env_kernel<T, DD>), grid, dim3(a.ka), 0, stream, a);                                         \
   }
