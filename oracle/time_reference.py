@@ -24,7 +24,7 @@ from oracle.ref_loader import import_reference  # noqa: E402
 from allegro_amd import graph as G  # noqa: E402
 
 
-def main(chunk_edges=2800, nchunks=4, reps=3):
+def main(chunk_edges=2800, nchunks=4, reps=3, threads=None):
     import bench
     from oracle import restatement as R
 
@@ -32,7 +32,7 @@ def main(chunk_edges=2800, nchunks=4, reps=3):
     from allegro.model import AllegroModel
     from nequip.data import AtomicDataDict as ADD
 
-    threads = min(os.cpu_count() or 1, 32)
+    threads = threads or min(os.cpu_count() or 1, 32)
     torch.set_num_threads(threads)
     g = G.make_si_graph(5)  # 1000 atoms / 28 000 edges of the C3 / C4 lattice
     cfg = bench.si_model_cfg(g.num_edges / g.num_atoms)
@@ -84,8 +84,20 @@ def main(chunk_edges=2800, nchunks=4, reps=3):
     res["chunk_edges"] = chunk_edges
     res["note"] = ("C2-C4 model (l_max 2, 2 layers, 64 features) on a 1000-atom Si box, fp32, forward + autograd forces, eager PyTorch CPU; "
                    "the reference's files run verbatim behind oracle/shim")
-    print(json.dumps(res))
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    if "--sweep" in sys.argv:
+        # the reference / port ratio at every power-of-two thread count of this host (the translation of
+        # `cpu_baseline` into "reference CPU path" was only established at 8 threads)
+        out = {}
+        n = 1
+        while n <= (os.cpu_count() or 1):
+            r = main(threads=n)
+            out[str(n)] = {k: r[k] for k in ("reference_over_port_time", "max_abs_force_difference")}
+            out[str(n)].update(reference_s=r["reference_verbatim"]["seconds"], port_s=r["port"]["seconds"])
+            n *= 2
+        print(json.dumps({"threads": out, "note": "python -m oracle.time_reference --sweep (build container)"}))
+    else:
+        print(json.dumps(main()))
