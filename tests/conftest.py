@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# Some tests import the reference verbatim from /root/reference (read-only by contract): neither this process nor any child
+# it spawns (xdist workers, gloo ranks, compile workers) may leave byte-code caches there.
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
 # Kernel selection: nothing is pinned here.  With AA_FUSED unset the plan is created with aa_plan_options.fused_forward = 0
 # ("automatic": the fused per-atom-tile forward whenever the graph allows it) -- the product's DEFAULT path, which is
 # therefore what every test runs unless it opts into another one.  The model-level GPU modules additionally run every
