@@ -557,6 +557,8 @@ struct TpOpArgs {
   int proj_gemm;
   void* dx2s;            // [N][D][u]      reverse, proj_gemm: d x2s of the layer being reversed (unscaled)
   int env_mfma;          // fp64: the adjoint of the moments on the edges (tp_op_edge_env) on the f64 matrix cores
+  int bvec_ready;        // reverse, split form: bvec already holds B_0 .. B_{L-1} of this step (the forward kernels of the same
+                         // step wrote them): tp_op_bvecs_kernel, which recomputes exactly those vectors, is not launched
 };
 int find_op_chain(const int* sigs, int num_layers);  // chain id or -1
 template <typename T>

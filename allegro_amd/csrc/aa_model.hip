@@ -1735,6 +1735,8 @@ struct Runner {
     o.gsh_env = buf(w.g_sh) + slot * size_t(E) * p->D;
     o.g_a = buf(w.g_aenv);
     o.ld_ga = o.ka;
+    // (split form: every forward kernel of this step stored its B_l next to the others -- the vectors the layer-0 reverse needs)
+    o.bvec_ready = (o.bvec && !p->opt.op_recompute_bvecs) ? 1 : 0;
     const double elems = p->D + W + u + 2 * o.ka + p->D + (l == 0 ? W + double(L - 1) * u + p->D : 0);
     if (use_proj(g) && w.dx2s_op) {
       o.proj_gemm = 1;

@@ -736,7 +736,7 @@ int launch_tp_op(int chain, int layer, bool reverse, const TpOpArgs& a, hipStrea
       }                                                                                               \
     } else {                                                                                          \
       if (phase != 2) {                                                                               \
-        if (LI == 0) hipLaunchKernelGGL((tp_op_bvecs_kernel<CH, T>), grid, block, 0, stream, a);      \
+        if (LI == 0 && !a.bvec_ready) hipLaunchKernelGGL((tp_op_bvecs_kernel<CH, T>), grid, block, 0, stream, a); \
         AA_OP_EDGE(DD_, RR_, LL_)                                                                     \
         hipLaunchKernelGGL((tp_op_bwd_mid_kernel<CH, LI, T>), grid, block, smem, stream, a);          \
       }                                                                                               \

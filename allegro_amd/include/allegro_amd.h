@@ -236,6 +236,8 @@ typedef struct {
                              * f64 matrix cores (A/B, tests)                                                                       */
   int32_t staged_no_fold;   /* staged fp32 pipeline (graphs the fused forward does not take): 1 = forward chains with the reference's own layers
                              * instead of the folded ones (A/B, tests)                                                             */
+  int32_t op_recompute_bvecs; /* operator-kernel plans: 1 = the layer-0 reverse recomputes the per-atom vectors B_l instead of reading
+                               * the ones the forward kernels of the same step stored (A/B, tests)                                 */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

@@ -209,6 +209,7 @@ def test_slot_form_matches_the_unfolded_pipeline(dt, tol, monkeypatch):
         monkeypatch.setenv("AA_OP_PROJ", proj)
         if unfolded:
             monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
+            monkeypatch.setenv("AA_OP_RECOMPUTE_BVECS", "1")  # (and the layer-0 reverse recomputing the per-atom vectors B_l)
         m = HipAllegroModel(**cfg)
         m._bind_library(emu_lib())
         assert m.describe_plan()["slot_form"] == (not unfolded)

@@ -342,6 +342,7 @@ def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, we, slot, de
                readout_mlp_hidden_layers_width=64, avg_num_neighbors=float(deg.mean()), seed=5, model_dtype=name)
     if not slot and we == S:
         monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
+        monkeypatch.setenv("AA_OP_RECOMPUTE_BVECS", "1")  # (and the layer-0 reverse recomputing the per-atom vectors B_l)
     if (l_max + L + u // 64 + int(slot)) % 2 == 0:  # half of the cases: the env projections as batched linear-layer launches
         monkeypatch.setenv("AA_OP_PROJ", "1")
     m = HipAllegroModel(**cfg).to(dev)
