@@ -514,6 +514,25 @@ __global__ __launch_bounds__(256) void readout_reduce_kernel(ReadoutArgs a) {
     } else
     for (int c = lane; c < a.H; c += 64) {
       T wc = w[c];
+      if (a.g_h) {
+        // forces requested: d E / d h[e, c] = factor * scale(type of the center) * w[c] * act'(h) depends on nothing but what this
+        // loop reads -- written here, so that no second kernel streams the hidden layer again (readout_backward_kernel)
+        T gf = T(a.factor) * wc;
+        if (a.scales) gf *= static_cast<const T*>(a.scales)[a.types[n]];
+        T* gh = static_cast<T*>(a.g_h) + c;
+        for (int s = beg; s < end; ++s) {
+          T h = static_cast<const T*>(a.h)[int64_t(s) * a.ld + c];
+          if (a.act && a.act_kind == AA_ACT_SILU) {
+            const T sg = sigmoid_(h);  // (one exponential for the value and the slope)
+            acc += h * sg * wc;
+            gh[int64_t(s) * a.H] = gf * sg * (T(1) + h * (T(1) - sg));
+          } else {
+            acc += (a.act ? act_apply(a.act_kind, h) : h) * wc;
+            gh[int64_t(s) * a.H] = a.act ? gf * act_grad(a.act_kind, h) : gf;
+          }
+        }
+        continue;
+      }
       for (int s = beg; s < end; ++s) {
         T h = static_cast<const T*>(a.h)[int64_t(s) * a.ld + c];
         acc += (a.act ? act_apply(a.act_kind, h) : h) * wc;

@@ -1345,6 +1345,8 @@ struct Runner {
   int64_t E, N;
   hipStream_t stream;
   StageProfile* prof = nullptr;
+  bool want_forces = false;    // (set by run_model before forward())
+  bool ro_grad_done = false;   // forward(): readout_reduce also wrote d E / d (last readout hidden layer) -- no readout_backward launch
 
   // per_edge / per_atom: operand elements the launch must move (each distinct operand row once); see DESIGN.md §5
   int mark(const char* name, double per_edge = 0, double per_atom = 0, double flops = 0) {
@@ -2169,8 +2171,11 @@ struct Runner {
         a = cs;
       }
     }
-    if (int rc = launch_readout_reduce<T>(readout_args(g, atom_energy), stream)) return rc;
-    return mark("readout_reduce", p->chain_gemm ? 1 : (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1), 1);
+    ReadoutArgs ra = readout_args(g, atom_energy);
+    ro_grad_done = want_forces && !p->chain_gemm && c.readout_mlp_depth > 0 && !p->opt.readout_two_pass;
+    if (ro_grad_done) ra.g_h = buf(w.g_ro_h[c.readout_mlp_depth - 1]);
+    if (int rc = launch_readout_reduce<T>(ra, stream)) return rc;
+    return mark("readout_reduce", (p->chain_gemm ? 1 : (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1)) * (ro_grad_done ? 2.0 : 1.0), 1);
   }
 
   // geometry reverse + force assembly (the end of every reverse pass)
@@ -2211,8 +2216,10 @@ struct Runner {
       ReadoutArgs r = readout_args(g, nullptr);
       r.g_h = buf(w.g_ro_h[Dr - 1]);
       act_now = c.act_kind[2];
-      if (int rc = launch_readout_backward<T>(r, stream)) return rc;
-      if (int rc = mark("readout_backward", 2.0 * Hr)) return rc;
+      if (!ro_grad_done) {
+        if (int rc = launch_readout_backward<T>(r, stream)) return rc;
+        if (int rc = mark("readout_backward", 2.0 * Hr)) return rc;
+      }
       for (int i = Dr - 1; i >= 1; --i) {
         SegList a{1, {seg(buf(w.g_ro_h[i]), Hr, Hr)}};
         SegList cs{1, {seg(buf(w.g_ro_h[i - 1]), Hr, Hr)}};
@@ -2308,8 +2315,10 @@ struct Runner {
       if (c.readout_mlp_depth > 0) {
         r.g_h = buf(w.g_ro_h[c.readout_mlp_depth - 1]);
         act_now = c.act_kind[2];
-        if (int rc = launch_readout_backward<T>(r, stream)) return rc;
-        if (int rc = mark("readout_backward", 2.0 * (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1))) return rc;
+        if (!ro_grad_done) {
+          if (int rc = launch_readout_backward<T>(r, stream)) return rc;
+          if (int rc = mark("readout_backward", 2.0 * (c.readout_mlp_depth > 0 ? c.readout_mlp_width : SL1))) return rc;
+        }
         SegList a{1, {seg(r.g_h, c.readout_mlp_width, c.readout_mlp_width)}};
         for (int i = c.readout_mlp_depth - 1; i >= 0; --i) {
           SegList cs, z;
@@ -2575,6 +2584,7 @@ int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g
   // the atom-block hint is the caller's promise (per-atom kernels skip the rest): two row pointers verify it on the device
   if (g->atom_end > g->atom_begin && (g->atom_begin > 0 || g->atom_end < g->num_atoms) && p->status)
     if (int rc = launch_graph_hint_check(g->rowptr, g->num_atoms, g->atom_begin, g->atom_end, p->status, stream)) return rc;
+  r.want_forces = forces != nullptr;
   if (int rc = r.forward(g, pos, atom_energy)) return rc;
   if (forces) return r.backward(g, pos, forces);
   return AA_OK;

@@ -238,6 +238,8 @@ typedef struct {
                              * instead of the folded ones (A/B, tests)                                                             */
   int32_t op_recompute_bvecs; /* operator-kernel plans: 1 = the layer-0 reverse recomputes the per-atom vectors B_l instead of reading
                                * the ones the forward kernels of the same step stored (A/B, tests)                                 */
+  int32_t readout_two_pass; /* single-layer pipeline: 1 = d E / d (readout hidden layer) by its own kernel in the reverse pass instead of
+                             * by the forward's energy reduction, which reads the same rows (A/B, tests)                          */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

@@ -210,6 +210,7 @@ def test_slot_form_matches_the_unfolded_pipeline(dt, tol, monkeypatch):
         if unfolded:
             monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
             monkeypatch.setenv("AA_OP_RECOMPUTE_BVECS", "1")  # (and the layer-0 reverse recomputing the per-atom vectors B_l)
+            monkeypatch.setenv("AA_READOUT_TWO_PASS", "1")    # (and d E / d readout hidden by its own kernel)
         m = HipAllegroModel(**cfg)
         m._bind_library(emu_lib())
         assert m.describe_plan()["slot_form"] == (not unfolded)

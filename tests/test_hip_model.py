@@ -343,6 +343,7 @@ def test_operator_path_vs_oracle(l_max, L, u, S, dtype, tol, force, we, slot, de
     if not slot and we == S:
         monkeypatch.setenv("AA_NO_SLOT_FORM", "1")
         monkeypatch.setenv("AA_OP_RECOMPUTE_BVECS", "1")  # (and the layer-0 reverse recomputing the per-atom vectors B_l)
+        monkeypatch.setenv("AA_READOUT_TWO_PASS", "1")    # (and d E / d readout hidden by its own kernel)
     if (l_max + L + u // 64 + int(slot)) % 2 == 0:  # half of the cases: the env projections as batched linear-layer launches
         monkeypatch.setenv("AA_OP_PROJ", "1")
     m = HipAllegroModel(**cfg).to(dev)
