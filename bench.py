@@ -780,6 +780,8 @@ def main():
                     ex = d["fused_mfma_steps_executed"] / d["fused_mfma_steps_reference"]
                     roof["executed_fp32_equiv_TFLOPs"] = roof["achieved"] * ex
                     roof["executed_frac"] = roof["frac"] * ex
+            roof["peak_note"] = ("peaks are the guide's, at the 2.4 GHz boost clock; rocm-smi samples during a 6000-step C4 loop show the shader "
+                                 "clock at 2.09-2.14 GHz at ~1250 W (profiles/r04_v29_power_clock_samples_c4.txt, tools/power_sample.sh)")
             line["roofline"] = roof
             line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])
             line["stage_ms"] = table
