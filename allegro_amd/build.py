@@ -93,7 +93,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
 
 OBJ_DIR = os.path.join(HERE, ".objcache")  # per-source objects keyed by content hash (git-ignored, rebuilt on demand)
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
 def _object_for(src: str, header_hash: str) -> str:
@@ -143,7 +143,8 @@ def _build_library_locked(verbose: bool) -> str:
         if os.path.join(OBJ_DIR, f) not in keep and f.endswith(".o"):
             os.remove(os.path.join(OBJ_DIR, f))
     tmp = LIB_PATH + f".tmp{os.getpid()}"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [objs[s] for s in SOURCES] + ["-o", tmp], check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
+                   + [objs[s] for s in SOURCES] + ["-o", tmp], check=True)
     os.replace(tmp, LIB_PATH)  # atomic: a concurrently starting process never maps a half-written library
     if verbose:
         print(f"[allegro_amd.build] built {LIB_PATH} in {time.time() - t0:.1f}s", flush=True)

@@ -802,7 +802,8 @@ struct ForceGatherArgs {
 template <typename T>
 int launch_force_gather(const ForceGatherArgs& a, hipStream_t stream);
 // verifies the aa_graph.atom_begin / atom_end promise (no edge segment outside the block): *status = -2 otherwise
-int launch_graph_hint_check(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status, hipStream_t stream);
+int launch_graph_hint_check(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status, void* atom_energy, void* forces,
+                            int esize, hipStream_t stream);
 template <typename T>
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t stream);
 

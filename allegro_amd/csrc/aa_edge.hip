@@ -645,11 +645,25 @@ int launch_force_gather(const ForceGatherArgs& a, hipStream_t stream) {
   return AA_OK;
 }
 
-__global__ void graph_hint_check_kernel(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status) {
-  if (threadIdx.x == 0 && (rowptr[a0] != rowptr[0] || rowptr[a1] != rowptr[N])) *reinterpret_cast<volatile int32_t*>(status) = -2;
+// Runs LAST in a step that carries an atom-block hint.  Edges whose center lies outside [a0, a1) were skipped by every
+// per-atom kernel, so the step's outputs are not the model's: besides raising the status word (reported by the next call /
+// aa_model_check) the outputs of THIS step are overwritten with NaN -- a host that integrates the forces before it looks at
+// the status sees the failure in the same step.  One small block; the fill is the failure path only.
+__global__ void graph_hint_check_kernel(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status, void* atom_energy,
+                                        void* forces, int esize) {
+  if (rowptr[a0] == rowptr[0] && rowptr[a1] == rowptr[N]) return;
+  if (threadIdx.x == 0) *reinterpret_cast<volatile int32_t*>(status) = -2;
+  for (int64_t i = threadIdx.x; i < 4 * N; i += blockDim.x) {
+    void* dst = i < N ? atom_energy : forces;
+    const int64_t k = i < N ? i : i - N;
+    if (!dst) continue;
+    if (esize == 4) static_cast<float*>(dst)[k] = __builtin_nanf("");
+    else static_cast<double*>(dst)[k] = __builtin_nan("");
+  }
 }
-int launch_graph_hint_check(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status, hipStream_t stream) {
-  hipLaunchKernelGGL(graph_hint_check_kernel, dim3(1), dim3(64), 0, stream, rowptr, N, a0, a1, status);
+int launch_graph_hint_check(const int32_t* rowptr, int64_t N, int64_t a0, int64_t a1, int32_t* status, void* atom_energy, void* forces,
+                            int esize, hipStream_t stream) {
+  hipLaunchKernelGGL(graph_hint_check_kernel, dim3(1), dim3(256), 0, stream, rowptr, N, a0, a1, status, atom_energy, forces, esize);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }

@@ -185,6 +185,11 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
       if (deg > (TEAMS ? kFusedMaxDegree : 32)) {
         cnt = -1;
         if (A.status && lane == 0) *reinterpret_cast<volatile int32_t*>(A.status) = deg;
+        // ... and the FORCES of this step must not look valid either (none of this atom's workspace rows are written,
+        // the reverse pass would combine leftovers of earlier steps into finite numbers): the direction rows of this tile
+        // become NaN -- edge_backward multiplies them into dE/dr of these edges, so the skipped atom's and its neighbours'
+        // forces (and the virial) are NaN in the same step
+        if (hh == 0 && 32 * tile + el < deg) *reinterpret_cast<v4f*>(A.vec + 4 * (int64_t(b0) + 32 * tile + el)) = v4f{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
       }
     }
   };

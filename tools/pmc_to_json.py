@@ -35,5 +35,6 @@ from allegro_amd.build import source_hash  # noqa: E402
 
 # source_hash: the kernel sources the measurement was taken on (run this right after profiling, before editing csrc/);
 # bench.py attaches `traffic` only when it matches the sources it runs
-print(json.dumps({"workload": workload, "source": path, "source_hash": sys.argv[3] if len(sys.argv) > 3 else source_hash(),
+# `source` names the TRACKED copy of the summary (tools/gpu_round.sh writes under gpurun_out/, the builder copies it to profiles/)
+print(json.dumps({"workload": workload, "source": "profiles/" + os.path.basename(path), "source_hash": sys.argv[3] if len(sys.argv) > 3 else source_hash(),
                   "per_launch": out}, indent=1))
