@@ -54,7 +54,9 @@ case $CMD in
   shards)
     W=${ARG:-8}
     timeout 900 python bench.py --shard-sweep $W --steps 10 --warmup 3 > gpurun_out/${TAG}_shard_sweep${W}_c4.json 2> /dev/null
-    python -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_shard_sweep${W}_c4.json')); print({k: d[k] for k in ('max_ms','mean_ms','imbalance_max_over_mean')})" ;;
+    # (RCCL prints its version banner to stdout after the JSON line: keep the first line only)
+    head -1 gpurun_out/${TAG}_shard_sweep${W}_c4.json > gpurun_out/.sweep.tmp && mv gpurun_out/.sweep.tmp gpurun_out/${TAG}_shard_sweep${W}_c4.json
+    python -c "import json,sys; d=json.load(open('gpurun_out/${TAG}_shard_sweep${W}_c4.json')); print({k: d[k] for k in ('max_ms','mean_ms','imbalance_max_over_mean','host_issue_over_gpu_max')})" ;;
   final)
     bash $0 tests $TAG
     bash $0 bench $TAG c4
