@@ -408,9 +408,20 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     p->tp_op = -1;
     bool sigs_ok = !opt.tp_generic;
     for (int l = 0; l < L; ++l) sigs_ok = sigs_ok && p->spec_sig[l] >= 0;
+    // Where the 2-layer moments kernels apply but the fused chains do NOT (fp64; S or the MLP widths 128; deeper MLPs), the operator
+    // kernels -- with the slot form of the linear layers where that applies -- are the faster pipeline: measured on the C3 box
+    // (profiles/r05_v3_shape_map_c3.md against r05_v7 / r05_v8 with the operator path forced): fp32 u 64 / S 128 7.41 -> 3.96 ms,
+    // fp64 u = S = 64 4.89 -> 4.14 ms, fp64 S 128 8.80 -> 6.82 ms; fp32 S 64 with 128-wide latents is a wash (3.70 vs 3.76 ms) and
+    // keeps the moments kernels.
+    const bool would_chain = cfg->dtype == AA_F32 && S == 64 && cfg->embed_mlp_depth == 1 && cfg->embed_mlp_width == 64 && cfg->latent_mlp_depth == 1 &&
+                             cfg->latent_mlp_width == 64 && cfg->readout_mlp_depth == 1 && cfg->readout_mlp_width == 64 && cfg->embed_dim % 32 == 0 &&
+                             !opt.gemm_no_chain && !opt.gemm_fp32_mfma && !opt.gemm_valu;
+    const bool would_slot = kSlotForm && !opt.no_slot_form && cfg->latent_mlp_depth == 1 && cfg->latent_mlp_width == S && cfg->readout_mlp_depth >= 1 &&
+                            cfg->embed_mlp_depth >= 1 && cfg->embed_mlp_width == S && (cfg->readout_mlp_width % 16) == 0;
+    const bool prefer_op = p->env_mom && !would_chain && (would_slot || cfg->dtype == AA_F64) && !opt.tp_prefer_moments;
     if (all_silu && sigs_ok && L >= 2 && L <= 3 && (u % 64) == 0 && u <= 256 && (S == 64 || S == 128) && cfg->latent_mlp_depth >= 1 &&
         (cfg->latent_mlp_width == 64 || cfg->latent_mlp_width == 128) && !opt.tp_no_moments && !opt.tp_no_operator &&
-        (!p->env_mom || opt.tp_force_operator)) {
+        (!p->env_mom || opt.tp_force_operator || prefer_op)) {
       const int chain = find_op_chain(p->spec_sig, L);
       if (chain >= 0) {
         p->tp_op = chain;

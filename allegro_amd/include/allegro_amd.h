@@ -107,6 +107,29 @@ int aa_tp_backward_weights(const aa_tp_plan* plan, int64_t E, int64_t N, const v
                            size_t workspace_bytes, void* gweights, aa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 1b. Training-mode building blocks around the operator.  The reference trains every
+ *    ScalarMLPFunction and every environment weighting through autograd (allegro/nn/_allegro.py:192-213,
+ *    _strided/_channels.py:44-63); these are the pieces of that graph whose library / eager forms are slow on this
+ *    device, as plain functions the Python host wraps into differentiable ops (allegro_amd/ops.py).
+ * ------------------------------------------------------------------------------------------ */
+/* Weight gradient of one bias-free linear layer y = x @ W (nequip ScalarMLPFunction, EXT): out[K,N] = sum_e x[e,:]^T g[e,:],
+ * x [E,K] with row stride ldx, g [E,N] with row stride ldg (elements), out dense [K,N].  The reduction over the edges is cut
+ * into slabs summed in a fixed order (bit-reproducible, no atomics); products are exact fp32 / fp64 on the matrix cores.
+ * `workspace`: caller scratch of aa_linear_wgrad_workspace_bytes() bytes. */
+size_t aa_linear_wgrad_workspace_bytes(aa_dtype dtype, int64_t E, int K, int N);
+int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const void* x, int64_t ldx, const void* g, int64_t ldg,
+                    void* workspace, size_t workspace_bytes, void* out, aa_stream stream);
+/* MakeWeightedChannels (_channels.py:44-63) as a bilinear form and its two partial contractions; sh [E,D], D = (l_max+1)^2,
+ * w [E,u,R] with R = l_max+1 weights per channel (shared != 0: R = 1, `weight_individual_irreps=False`), t [E,u,D]:
+ *   which 0:  out[E,u,D] = a=sh (x) b=w           out[e,c,i] = sh[e,i] w[e,c,r(i)]
+ *   which 1:  out[E,u,R] = a=t  . b=sh            out[e,c,r] = sum_{i in r} t[e,c,i] sh[e,i]
+ *   which 2:  out[E,D]   = a=t  . b=w             out[e,i]   = sum_c t[e,c,i] w[e,c,r(i)]
+ * Each is one pass over the [E,u,D] operand; the three are closed under differentiation (any derivative of one is another
+ * with operands substituted), which is what a force-matching loss needs. */
+int aa_weighted_channels(aa_dtype dtype, int which, int64_t E, int u, int l_max, int shared, const void* a, const void* b,
+                         void* out, aa_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * 2. Whole hot path: forward + forces  (seam B3 + ForceStressOutput)
  *    replaces the module chain of allegro/model/allegro_models.py:222-297 wrapped by
  *    ForceStressOutput (:101-103): two-body embedding -> SH tensor embed (tensorembed.py:85-96)
@@ -247,6 +270,8 @@ typedef struct {
                                * the ones the forward kernels of the same step stored (A/B, tests)                                 */
   int32_t readout_two_pass; /* single-layer pipeline: 1 = d E / d (readout hidden layer) by its own kernel in the reverse pass instead of
                              * by the forward's energy reduction, which reads the same rows (A/B, tests)                          */
+  int32_t tp_prefer_moments; /* 2-layer u = 64 stacks the fused chains do not cover (fp64; S or MLP widths of 128): 1 = the 2-layer moments
+                              * kernels + single linear layers (the selection up to round 4) instead of the operator kernels (A/B, tests) */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

@@ -383,3 +383,152 @@ def contract_segments_differentiable(x1: torch.Tensor, x2: torch.Tensor, weights
     derivatives of every order, on the segmented kernels (see _TriCtx): what training mode runs."""
     t = _TriCtx(plan, lib_id, d1, d2, dout, (rowptr, eids, idxs.reshape(-1), int(num_atoms), float(scatter_factor)))
     return _TriK.apply(x1.contiguous(), x2.contiguous(), weights, t)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Training path: linear layers and weighted channels, closed under differentiation
+# ------------------------------------------------------------------------------------------------------------------
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.AA_F32
+    if t.dtype == torch.float64:
+        return _lib.AA_F64
+    raise _lib.AllegroError(f"allegro_amd training ops: dtype {t.dtype}")
+
+
+@torch.library.custom_op("allegro_amd::linear_wgrad", mutates_args=())
+def linear_wgrad(x: torch.Tensor, g: torch.Tensor, lib_id: int) -> torch.Tensor:
+    """x [E,K]^T @ g [E,N] -> [K,N] (`aa_linear_wgrad`): the weight gradient of a bias-free linear layer, reduced over the edges
+    in fixed-order slabs on the matrix cores."""
+    lib = _resolve(lib_id)
+    _check_device(lib, x, "allegro_amd::linear_wgrad")
+    xc = x if x.stride(-1) == 1 and x.dim() == 2 else x.contiguous()
+    gc = g if g.stride(-1) == 1 and g.dim() == 2 else g.contiguous()
+    E, K, N = xc.shape[0], xc.shape[1], gc.shape[1]
+    out = torch.empty((K, N), dtype=x.dtype, device=x.device)
+    code = _dtype_code(x)
+    nbytes = lib.lib.aa_linear_wgrad_workspace_bytes(code, E, K, N)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    lib.check(lib.lib.aa_linear_wgrad(code, E, K, N, xc.data_ptr() if E else None, xc.stride(0) if E else K, gc.data_ptr() if E else None,
+                                      gc.stride(0) if E else N, ws.data_ptr(), nbytes, out.data_ptr(), _stream_ptr(x)), "aa_linear_wgrad")
+    return out
+
+
+@linear_wgrad.register_fake
+def _(x, g, lib_id):
+    return x.new_empty((x.shape[1], g.shape[1]))
+
+
+@torch.library.custom_op("allegro_amd::weighted_channels", mutates_args=())
+def weighted_channels_op(which: int, a: torch.Tensor, b: torch.Tensor, u: int, l_max: int, shared: bool, lib_id: int) -> torch.Tensor:
+    """`aa_weighted_channels`: which 0: sh [E,D] (x) w [E,u*R] -> [E,u,D];  1: t [E,u,D] . sh -> [E,u*R];  2: t . w -> [E,D]."""
+    lib = _resolve(lib_id)
+    _check_device(lib, a, "allegro_amd::weighted_channels")
+    ac, bc = a.contiguous(), b.contiguous()
+    E = ac.shape[0]
+    D, R = (l_max + 1) ** 2, (1 if shared else l_max + 1)
+    shape = ((E, u, D), (E, u * R), (E, D))[which]
+    out = torch.empty(shape, dtype=a.dtype, device=a.device)
+    lib.check(lib.lib.aa_weighted_channels(_dtype_code(a), which, E, u, l_max, int(shared), ac.data_ptr() if E else None,
+                                           bc.data_ptr() if E else None, out.data_ptr() if E else None, _stream_ptr(a)), "aa_weighted_channels")
+    return out
+
+
+@weighted_channels_op.register_fake
+def _(which, a, b, u, l_max, shared, lib_id):
+    E, D, R = a.shape[0], (l_max + 1) ** 2, (1 if shared else l_max + 1)
+    return a.new_empty(((E, u, D), (E, u * R), (E, D))[which])
+
+
+class _MM(torch.autograd.Function):
+    """y = x @ W for a per-edge linear layer (x [E,K], W [K,N]).  The products along the edges are library GEMMs; the one
+    product that reduces OVER the edges -- the weight gradient -- is `_XtG` (hand-written).  With `_XtG` the pair is closed
+    under differentiation, so forces (first derivatives) can be differentiated again by a force-matching loss."""
+
+    @staticmethod
+    def forward(ctx, x, W, lib_id):
+        ctx.lib_id = lib_id
+        ctx.save_for_backward(x, W)
+        return x @ W
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        return (_MM.apply(g, W.t(), ctx.lib_id) if n[0] else None, _XtG.apply(x, g, ctx.lib_id) if n[1] else None, None)
+
+
+class _XtG(torch.autograd.Function):
+    """x [E,K]^T @ g [E,N]."""
+
+    @staticmethod
+    def forward(ctx, x, g, lib_id):
+        ctx.lib_id = lib_id
+        ctx.save_for_backward(x, g)
+        return torch.ops.allegro_amd.linear_wgrad(x.detach(), g.detach(), lib_id)
+
+    @staticmethod
+    def backward(ctx, G):  # G [K,N]
+        x, g = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        return (_MM.apply(g, G.t(), ctx.lib_id) if n[0] else None, _MM.apply(x, G, ctx.lib_id) if n[1] else None, None)
+
+
+def linear(x: torch.Tensor, W: torch.Tensor, lib_id: int) -> torch.Tensor:
+    """Bias-free linear layer of a ScalarMLPFunction in training mode, differentiable to any order."""
+    return _MM.apply(x, W, lib_id)
+
+
+class _WcB(torch.autograd.Function):
+    """B(sh, w)[e,c,i] = sh[e,i] w[e,c,r(i)]."""
+
+    @staticmethod
+    def forward(ctx, sh, w, meta):
+        ctx.meta = meta
+        ctx.save_for_backward(sh, w)
+        return torch.ops.allegro_amd.weighted_channels(0, sh.detach(), w.detach(), *meta)
+
+    @staticmethod
+    def backward(ctx, g):
+        sh, w = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        return (_WcS.apply(g, w, ctx.meta) if n[0] else None, _WcW.apply(g, sh, ctx.meta) if n[1] else None, None)
+
+
+class _WcS(torch.autograd.Function):
+    """[e,i] = sum_c t[e,c,i] w[e,c,r(i)]  (the sh gradient)."""
+
+    @staticmethod
+    def forward(ctx, t, w, meta):
+        ctx.meta = meta
+        ctx.save_for_backward(t, w)
+        return torch.ops.allegro_amd.weighted_channels(2, t.detach(), w.detach(), *meta)
+
+    @staticmethod
+    def backward(ctx, h):
+        t, w = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        return (_WcB.apply(h, w, ctx.meta) if n[0] else None, _WcW.apply(t, h, ctx.meta) if n[1] else None, None)
+
+
+class _WcW(torch.autograd.Function):
+    """[e,c,r] = sum_{i in r} t[e,c,i] sh[e,i]  (the weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, t, sh, meta):
+        ctx.meta = meta
+        ctx.save_for_backward(t, sh)
+        return torch.ops.allegro_amd.weighted_channels(1, t.detach(), sh.detach(), *meta)
+
+    @staticmethod
+    def backward(ctx, q):
+        t, sh = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        return (_WcB.apply(sh, q, ctx.meta) if n[0] else None, _WcS.apply(t, q, ctx.meta) if n[1] else None, None)
+
+
+def weighted_channels(sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int, lib_id: int) -> torch.Tensor:
+    """MakeWeightedChannels (allegro/nn/_strided/_channels.py:44-63) -> [E,u,D], differentiable to any order, one kernel pass per
+    evaluation.  `w` [E, u (l_max+1)] (one weight per channel and irrep) or [E, u] (`weight_individual_irreps=False`)."""
+    shared = w.shape[1] == u and l_max > 0
+    return _WcB.apply(sh.contiguous(), w.contiguous(), (int(u), int(l_max), bool(shared), int(lib_id)))

@@ -48,15 +48,17 @@ def _real_sh(vec: torch.Tensor, l_max: int) -> torch.Tensor:
     return torch.stack(cols, dim=-1)
 
 
-def _mlp(x: torch.Tensor, weights: List[torch.Tensor], act: Optional[str], act_const: float, forward_init: bool) -> torch.Tensor:
+def _mlp(x: torch.Tensor, weights: List[torch.Tensor], act: Optional[str], act_const: float, forward_init: bool, lib_id: Optional[int] = None) -> torch.Tensor:
     """nequip ScalarMLPFunction (EXT; call sites _allegro.py:90-94,193-213, tensorembed.py:76-81, allegro_models.py:173,231):
     bias-free linears scaled by 1/sqrt(fan_in) (fan_out if not forward_normalize), the activation between layers followed by
-    its second-moment constant."""
+    its second-moment constant.  With `lib_id` the layers run through `ops.linear` (weight gradients on the hand-written
+    slab-reduction kernel `aa_linear_wgrad`), otherwise through plain matmuls (the checker of tests/test_training.py)."""
     carry = 1.0
     last = len(weights) - 1
     for i, w in enumerate(weights):
         fan = w.shape[0] if forward_init else w.shape[1]
-        x = x @ (w * (carry / math.sqrt(float(fan))))
+        ws = w * (carry / math.sqrt(float(fan)))
+        x = ops.linear(x, ws, lib_id) if lib_id is not None else x @ ws
         if i < last and act is not None:
             x = _ACT[act](x)
             carry = act_const
@@ -101,6 +103,11 @@ class TrainingEvaluator:
             torch.set_default_dtype(prev)
         self.act_consts = {nl: second_moment_const(nl) for nl in set(model.nonlinearities) | {"silu"}}
         self._bessel_conv = None
+        # hand-written training kernels around the tensor products (round 5: `aa_linear_wgrad`, `aa_weighted_channels`);
+        # AA_TRAIN_EAGER=1 keeps the library-GEMM / eager-elementwise forms of round 3 (the checker and the A/B baseline)
+        import os
+
+        self.lib_id = None if os.environ.get("AA_TRAIN_EAGER", "0")[:1] == "1" else self.contracters[0]._lib_id
 
     # ------------------------------------------------------------------------------------------------------------
     def _weights(self, prefix: str) -> List[torch.Tensor]:
@@ -118,6 +125,12 @@ class TrainingEvaluator:
         for part in dotted.split("."):
             node = getattr(node, part)
         return node
+
+    def _wc(self, sh, w, u, l_max):
+        if self.lib_id is None:
+            return _weighted_channels(sh, w, u, l_max)
+        with _device_guard(sh):
+            return ops.weighted_channels(sh, w, u, l_max, self.lib_id)
 
     def _two_body(self, x: torch.Tensor, tc: torch.Tensor, tn: torch.Tensor) -> torch.Tensor:
         m, hp = self.model, self.model.hparams
@@ -149,7 +162,7 @@ class TrainingEvaluator:
         cut = 1.0 - ((p + 1) * (p + 2) / 2) * x ** p + p * (p + 2) * x ** (p + 1) - (p * (p + 1) / 2) * x ** (p + 2)
         bessel = bessel * (cut * (x < 1.0))
         basis = _mlp(bessel, self._weights("radial_chemical_embed.type_embed.basis_linear.mlp"), "silu", self.act_consts["silu"],
-                     hp["forward_normalize"])
+                     hp["forward_normalize"], self.lib_id)
         # (index_select: its backward is an index_add, not the sort-based index_put of advanced indexing)
         pair = torch.cat((self._param("radial_chemical_embed.type_embed.center_embed.weight").index_select(0, tc),
                           self._param("radial_chemical_embed.type_embed.neighbor_embed.weight").index_select(0, tn)), dim=-1)
@@ -173,28 +186,28 @@ class TrainingEvaluator:
         x = (vec.norm(dim=-1) * (recip[tc, tn] if recip.numel() > 1 else recip.reshape(-1)[0])).unsqueeze(-1)
         emb = self._two_body(x, tc, tn)
         nl_embed, nl_latent, nl_readout = m.nonlinearities
-        emb = _mlp(emb, self._weights("scalar_embed_mlp.mlp.mlp"), nl_embed, self.act_consts[nl_embed], fwd)  # allegro_models.py:173-183
+        emb = _mlp(emb, self._weights("scalar_embed_mlp.mlp.mlp"), nl_embed, self.act_consts[nl_embed], fwd, self.lib_id)  # allegro_models.py:173-183
         silu_c = self.act_consts["silu"]
         # tensor embedding (tensorembed.py:85-96) and the first layer's environment weights (_allegro.py:251-258)
         sh = _real_sh(vec, l_max)
-        tf = _weighted_channels(sh, _mlp(emb, self._weights("tensor_embed.env_embed_linear.mlp"), "silu", silu_c, fwd), u, l_max)
+        tf = self._wc(sh, _mlp(emb, self._weights("tensor_embed.env_embed_linear.mlp"), "silu", silu_c, fwd, self.lib_id), u, l_max)
         We = (l_max + 1) * u if m.weight_individual_irreps else u
-        proj = _mlp(emb, self._weights("allegro.first_layer_env_embed_projection.mlp"), "silu", silu_c, fwd)
+        proj = _mlp(emb, self._weights("allegro.first_layer_env_embed_projection.mlp"), "silu", silu_c, fwd, self.lib_id)
         scalars, env_w = [proj[:, :S]], proj[:, S:S + We]
         for l in range(L):  # _allegro.py:262-294
             c = self.contracters[l]
-            env = _weighted_channels(sh, env_w, u, l_max)
+            env = self._wc(sh, env_w, u, l_max)
             with _device_guard(pos):
                 tf = ops.contract_segments_differentiable(tf.reshape(-1, u, c.base_dim1), env, self._param(f"allegro.tps.{l}.weights"),
                                                           graph.rowptr, None, center, N, self.sf, c._plan(pos.dtype, pos.device),
                                                           c._lib_id, c.base_dim1, c.base_dim2, c.base_dim_out)
             lat = _mlp(torch.cat(scalars + [tf[:, :, 0]], dim=-1), self._weights(f"allegro.latents.{l}.mlp"), nl_latent,
-                       self.act_consts[nl_latent], fwd)
+                       self.act_consts[nl_latent], fwd, self.lib_id)
             scalars.append(lat[:, :S])
             if l < L - 1:
                 env_w = lat[:, S:S + We]
         # edge readout, edge -> atom sum, per-type scale / shift (allegro_models.py:231-260; edgewise.py:40-60)
-        e_edge = _mlp(torch.cat(scalars, dim=-1), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd)
+        e_edge = _mlp(torch.cat(scalars, dim=-1), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd, self.lib_id)
         e_edge = e_edge * (1.0 / math.sqrt(2 * hp["avg_num_neighbors"]))
         e_atom = torch.zeros((N, 1), dtype=e_edge.dtype, device=e_edge.device).index_add(0, center, e_edge)
         if m.has_scales:

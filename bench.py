@@ -546,13 +546,16 @@ def train_step_bench(args, dev):
         loss.backward()
         opt_r.step()
 
-    step_ref()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    if args.no_gpu_reference:  # (profiling runs: only the product's kernels in the trace)
+        ms_ref = None
+    else:
         step_ref()
-    torch.cuda.synchronize()
-    ms_ref = (time.perf_counter() - t0) / 3 * 1e3
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step_ref()
+        torch.cuda.synchronize()
+        ms_ref = (time.perf_counter() - t0) / 3 * 1e3
     L = cfg["num_layers"]
     line = dict(metric="whole-model training step (forward, force+energy loss, backward into every parameter, Adam), edge tensor-products/s",
                 mode="train-step", value=E * L / ms * 1e3, unit="edge-TP/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
@@ -560,9 +563,9 @@ def train_step_bench(args, dev):
                 config=dict(workload=f"{args.workload}: {N} atoms / {E} edges, l_max {cfg['l_max']}, {L} layers, {cfg['num_tensor_features']} tensor features",
                             parameters=int(sum(p.numel() for p in params)), optimizer="Adam"),
                 final_loss=float(loss), peak_memory_GB=peak / 1e9, inference_ms_per_step=ms_inf, train_over_inference=ms / ms_inf,
-                eager_port_gpu=dict(ms_per_step=ms_ref, edges=e1, value=e1 * L / ms_ref * 1e3, unit="edge-TP/s", kind="port",
+                eager_port_gpu=None if ms_ref is None else dict(ms_per_step=ms_ref, edges=e1, value=e1 * L / ms_ref * 1e3, unit="edge-TP/s", kind="port",
                                     sample=f"first {a1} center atoms / {e1} edges of the same box"),
-                speedup_vs_eager_port=(E / ms) / (e1 / ms_ref))
+                speedup_vs_eager_port=None if ms_ref is None else (E / ms) / (e1 / ms_ref))
     print(json.dumps(line), flush=True)
 
 

@@ -1,0 +1,114 @@
+"""The training-path kernels of csrc/aa_train.hip against plain PyTorch (the checker): `aa_linear_wgrad` (weight gradient of a
+bias-free linear layer, reduced over the edges in fixed-order slabs on the matrix cores) and `aa_weighted_channels`
+(MakeWeightedChannels, allegro/nn/_strided/_channels.py:44-63, as a bilinear form with its two partial contractions), incl.
+their closure under differentiation: second derivatives through `ops.linear` / `ops.weighted_channels` equal autograd's
+through the eager forms.  CPU: the emulation build of the same sources; `-m gpu`: the gfx950 library."""
+import pytest
+import torch
+
+from allegro_amd import ops
+
+
+def _lib_id(lib):
+    return 0 if lib is None else ops.register_library(lib)
+
+
+def _wgrad_case(lib, dev):
+    lid = _lib_id(lib)
+    g = torch.Generator().manual_seed(4)
+    for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 1e-13)):
+        for E, K, N, pad in ((0, 8, 16, 0), (5, 8, 64, 0), (777, 64, 64, 0), (1030, 192, 64, 16), (2049, 17, 130, 3), (300, 256, 1, 0)):
+            xb = torch.randn(E, K + pad, generator=g, dtype=dtype).to(dev)
+            gb = torch.randn(E, N + pad, generator=g, dtype=dtype).to(dev)
+            x, gg = xb[:, :K], gb[:, pad:]  # row-strided views: the kernel takes the strides, no copy
+            got = torch.ops.allegro_amd.linear_wgrad(x, gg, lid)
+            want = x.double().t() @ gg.double()
+            scale = max(1.0, float(want.abs().max()))
+            assert got.shape == (K, N) and (got.double() - want).abs().max().item() <= tol * scale * max(1, E) ** 0.5, (dtype, E, K, N)
+            again = torch.ops.allegro_amd.linear_wgrad(x, gg, lid)
+            assert torch.equal(got, again)  # fixed summation order: the same bits every call
+
+
+def _second_order_case(lib, dev):
+    """A force-matching loss differentiates a first derivative again: grad-of-grad through the op pair (_MM, _XtG) and the
+    weighted-channel triple equals autograd through matmul / broadcasting."""
+    lid = _lib_id(lib)
+    dtype = torch.float64
+    g = torch.Generator().manual_seed(9)
+    E, K, H, N, u, l_max = 37, 8, 24, 12, 6, 2
+    D = (l_max + 1) ** 2
+    x0 = torch.randn(E, K, generator=g, dtype=dtype).to(dev)
+    W1 = torch.randn(K, H, generator=g, dtype=dtype).to(dev)
+    W2 = torch.randn(H, u * (l_max + 1), generator=g, dtype=dtype).to(dev)
+    sh0 = torch.randn(E, D, generator=g, dtype=dtype).to(dev)
+    c = torch.randn(E, u, D, generator=g, dtype=dtype).to(dev)
+
+    def run(hand):
+        x = x0.clone().requires_grad_(True)
+        sh = sh0.clone().requires_grad_(True)
+        w1, w2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
+        lin = (lambda a, b: ops.linear(a, b, lid)) if hand else (lambda a, b: a @ b)
+        h = torch.nn.functional.silu(lin(x, w1))
+        w = lin(h, w2)
+        if hand:
+            t = ops.weighted_channels(sh, w, u, l_max, lid)
+        else:
+            wr = w.reshape(E, u, l_max + 1)
+            t = sh.unsqueeze(1) * torch.cat([wr[:, :, l:l + 1].expand(-1, -1, 2 * l + 1) for l in range(l_max + 1)], dim=-1)
+        e = (t * c).sum() + (t ** 2).sum() * 0.1
+        gx, gsh = torch.autograd.grad(e, [x, sh], create_graph=True)
+        loss = (gx ** 2).sum() + (gsh * sh).sum()
+        return [e.detach(), gx.detach(), gsh.detach()] + [v.detach() for v in torch.autograd.grad(loss, [w1, w2, x, sh])]
+
+    for a, b in zip(run(True), run(False)):
+        assert (a - b).abs().max().item() <= 1e-10 * max(1.0, float(b.abs().max()))
+    # shared weights (`weight_individual_irreps=False`) and l_max = 3
+    for l_max_, shared in ((3, False), (2, True), (1, True)):
+        D_ = (l_max_ + 1) ** 2
+        sh = torch.randn(E, D_, generator=g, dtype=dtype).to(dev).requires_grad_(True)
+        w = torch.randn(E, u if shared else u * (l_max_ + 1), generator=g, dtype=dtype).to(dev).requires_grad_(True)
+        t = ops.weighted_channels(sh, w, u, l_max_, lid)
+        if shared:
+            ref = w.unsqueeze(-1) * sh.unsqueeze(1)
+        else:
+            wr = w.reshape(E, u, l_max_ + 1)
+            ref = sh.unsqueeze(1) * torch.cat([wr[:, :, l:l + 1].expand(-1, -1, 2 * l + 1) for l in range(l_max_ + 1)], dim=-1)
+        assert (t - ref).abs().max().item() <= 1e-13
+        cc = torch.randn(E, u, D_, generator=g, dtype=dtype).to(dev)
+        for a, b in zip(torch.autograd.grad((t * cc).sum(), [sh, w]), torch.autograd.grad((ref * cc).sum(), [sh, w])):
+            assert (a - b).abs().max().item() <= 1e-12
+
+
+def test_linear_wgrad_emulated():
+    from tests.hip_utils import emu_lib
+
+    _wgrad_case(emu_lib(), torch.device("cpu"))
+
+
+def test_training_ops_second_order_emulated():
+    from tests.hip_utils import emu_lib
+
+    _second_order_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_linear_wgrad_on_gpu():
+    _wgrad_case(None, torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
+def test_training_ops_second_order_on_gpu():
+    _second_order_case(None, torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
+def test_linear_wgrad_at_c3_size_on_gpu():
+    """[298 144 x 64]^T @ [298 144 x 192] in fp32 against an fp64 product: the slab partition at the size the training bench runs."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(298144, 64, device=dev, generator=g)
+    gg = torch.randn(298144, 192, device=dev, generator=g)
+    got = torch.ops.allegro_amd.linear_wgrad(x, gg, 0)
+    want = x.double().t() @ gg.double()
+    # (entries are ~ +-2000; fp32 accumulation: 291-term chains inside a slab, then 1024 slabs in order: <= ~1024 x 6e-8 x 600)
+    assert (got.double() - want).abs().max().item() <= 0.2
