@@ -1301,7 +1301,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) v
   };
   T* gw0 = static_cast<T*>(a.g_w0) + lane;
   T* gsx = static_cast<T*>(a.gsh_x1);
-  mom_pair_loop<T, D, R, 1>(sh, a.ld_sh, beg, end, lane, sY, staged_cb, fetch, [&](int s, bool vb, const T2* y, const PairIn<T, R>& cur) {
+#ifndef AA_MOM_FIRST_AHEAD
+#define AA_MOM_FIRST_AHEAD 1  // pairs of HBM operands in flight ahead of the contraction (A/B: profiles/r05_v10_ab_*)
+#endif
+  mom_pair_loop<T, D, R, AA_MOM_FIRST_AHEAD>(sh, a.ld_sh, beg, end, lane, sY, staged_cb, fetch, [&](int s, bool vb, const T2* y, const PairIn<T, R>& cur) {
     // go[e] = g1[e] * v + g0[e] * e_0 (v = dSig1/dtf1), so with the per-atom vectors B1 = Sig0^T_x1(v), B0 = Sig0^T_x1(e_0)
     //   d x1[e] = g1[e] * B1 + g0[e] * B0      and      d x2s0 = Sig0^T_x2(v, sum_e g1 x1) + Sig0^T_x2(e_0, sum_e g0 x1)
     T2 gw[R];

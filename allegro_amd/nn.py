@@ -737,6 +737,14 @@ class HipAllegroModel(torch.nn.Module):
             self._trainer = TrainingEvaluator(self)
         return self._trainer
 
+    def chunked_training_step(self, graph: "PreparedGraph", max_edges_per_chunk: int):
+        """Training on boxes whose whole differentiable graph does not fit: `step(pos, loss_fn)` of the returned object
+        accumulates the exact gradient of `loss_fn(forces, total_energy)` block of center atoms by block
+        (allegro_amd/training.py: ChunkedTrainingStep; peak memory ~ the block, not the frame)."""
+        from .training import ChunkedTrainingStep
+
+        return ChunkedTrainingStep(self._training_evaluator(), graph, max_edges_per_chunk)
+
     # -- library / plan -------------------------------------------------------------------------
     def _get_lib(self) -> _lib.AllegroLib:
         return self._bound_lib if self._bound_lib is not None else _lib.load()

@@ -260,6 +260,74 @@ class TrainingEvaluator:
         return out
 
 
+class ChunkedTrainingStep:
+    """Exact gradient of a loss L(forces, total_energy) with activations of ONE atom block at a time (large boxes: the
+    differentiable graph of a whole 10^5-atom frame needs ~1.5 KB of activations per edge and order of differentiation).
+
+    By strict locality E_tot = sum_B E_B over blocks B of center atoms and F = -sum_B dE_B/dpos, so with the cotangents
+    r_F = dL/dF, r_E = dL/dE_tot -- available after ONE evaluation of forces and energy, which the inference kernels deliver --
+
+        dL/dtheta = sum_B d/dtheta [ r_E E_B - <r_F, dE_B/dpos> ]           (r_F, r_E held constant)
+
+    Every term needs the graph of one block only (the block's edges; its atoms = the block + their neighbours, compact local
+    numbering); the terms are back-propagated one after the other and accumulate in the parameters' `.grad`.  Same numbers as
+    `loss_fn(forces, E).backward()` through the whole frame (tests/test_training.py), peak memory proportional to the block.
+    The reference has no counterpart (it differentiates the whole batch at once; allegro/nn/_allegro.py is agnostic of it)."""
+
+    def __init__(self, evaluator: "TrainingEvaluator", graph, max_edges_per_chunk: int):
+        from .nn import PreparedGraph
+
+        self.ev, self.graph = evaluator, graph
+        rowptr = graph.rowptr.cpu().long()
+        N, E = graph.num_atoms, graph.num_edges
+        cuts, a = [0], 0
+        while a < N:  # blocks of consecutive center atoms holding <= max_edges_per_chunk edges (at least one atom)
+            target = int(rowptr[a]) + int(max_edges_per_chunk)
+            b = int(torch.searchsorted(rowptr, torch.tensor(target), right=True)) - 1
+            b = max(a + 1, min(b, N))
+            cuts.append(b)
+            a = b
+        self.chunks = []
+        center, nbr = graph.center.long(), graph.nbr.long()
+        dev = center.device
+        for a0, a1 in zip(cuts[:-1], cuts[1:]):
+            e0, e1 = int(rowptr[a0]), int(rowptr[a1])
+            if e1 == e0:
+                continue
+            own = torch.arange(a0, a1, device=dev)
+            nb = nbr[e0:e1]
+            ghosts = torch.unique(nb[(nb < a0) | (nb >= a1)])
+            local = torch.cat([own, ghosts])
+            lookup = torch.full((N,), -1, dtype=torch.long, device=dev)
+            lookup[local] = torch.arange(local.numel(), device=dev)
+            ei = torch.stack([center[e0:e1] - a0, lookup[nb]])
+            sv = None if graph.shift_vec is None else graph.shift_vec[e0:e1]
+            g = PreparedGraph(ei, graph.types.long().index_select(0, local), int(local.numel()), sv, transposed=False)
+            self.chunks.append((local, a1 - a0, g))
+
+    def step(self, pos: torch.Tensor, loss_fn):
+        """`loss_fn(forces [N,3], total_energy [1,1]) -> scalar`.  Accumulates dL/dtheta into the parameters' `.grad`; returns
+        (loss, forces, total_energy), all detached."""
+        m = self.ev.model
+        with torch.no_grad():  # pass 1: the hand-written inference pipeline
+            e_atom, forces = m.energy_forces(pos.detach().to(m.dtype), self.graph)
+            e_atom, forces = e_atom.clone(), forces.clone()
+        f_leaf = forces.detach().requires_grad_(True)
+        e_leaf = e_atom.sum().reshape(1, 1).detach().requires_grad_(True)
+        loss = loss_fn(f_leaf, e_leaf)
+        r_f, r_e = torch.autograd.grad(loss, [f_leaf, e_leaf], allow_unused=True)
+        r_f = torch.zeros_like(f_leaf) if r_f is None else r_f
+        r_e = torch.zeros_like(e_leaf) if r_e is None else r_e
+        for local, n_own, g in self.chunks:  # pass 2: one block's graph at a time
+            p = pos.detach().to(m.dtype).index_select(0, local).requires_grad_(True)
+            e_loc = self.ev.atomic_energy(p, g, g.shift_vec)
+            e_blk = e_loc[:n_own].sum()
+            (gp,) = torch.autograd.grad(e_blk, p, create_graph=True)
+            s = r_e.reshape(()) * e_blk - (r_f.index_select(0, local) * gp).sum()
+            s.backward()
+        return loss.detach(), forces, e_leaf.detach()
+
+
 class _device_guard:
     """The HIP launches go to the device of `t` (no-op for the CPU emulation library of the tests)."""
 

@@ -495,11 +495,21 @@ def train_step_bench(args, dev):
     f_target = 0.1 * torch.randn(N, 3, dtype=dtype, device=dev, generator=gen)
     ev = model._training_evaluator()
 
+    def loss_fn(forces, total_energy):
+        return (forces - f_target).square().mean() + 1e-3 * (total_energy / N).square().sum()
+
+    # --train-chunk-edges: the exact gradient accumulated one block of center atoms at a time (ChunkedTrainingStep): boxes whose
+    # whole differentiable graph does not fit (C4: ~150 GB of activations in one piece)
+    chunked = model.chunked_training_step(graph, args.train_chunk_edges) if args.train_chunk_edges > 0 else None
+
     def step():
         opt.zero_grad(set_to_none=True)
-        out = ev.forward({"pos": pos}, graph)
-        loss = (out["forces"] - f_target).square().mean() + 1e-3 * (out["total_energy"] / N).square().sum()
-        loss.backward()
+        if chunked is not None:
+            loss, _, _ = chunked.step(pos, loss_fn)
+        else:
+            out = ev.forward({"pos": pos}, graph)
+            loss = loss_fn(out["forces"], out["total_energy"])
+            loss.backward()
         opt.step()
         return loss.detach()
 
@@ -561,7 +571,10 @@ def train_step_bench(args, dev):
                 mode="train-step", value=E * L / ms * 1e3, unit="edge-TP/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=ms,
                 higher_is_better=True, dtype="f32" if dtype == torch.float32 else "f64", data="synthetic",
                 config=dict(workload=f"{args.workload}: {N} atoms / {E} edges, l_max {cfg['l_max']}, {L} layers, {cfg['num_tensor_features']} tensor features",
-                            parameters=int(sum(p.numel() for p in params)), optimizer="Adam"),
+                            parameters=int(sum(p.numel() for p in params)), optimizer="Adam",
+                            kernels="eager / library GEMMs (AA_TRAIN_EAGER=1)" if os.environ.get("AA_TRAIN_EAGER", "0")[:1] == "1" else
+                                    "aa_linear_wgrad + aa_weighted_channels + tensor-product kernels",
+                            chunks=None if chunked is None else dict(max_edges=args.train_chunk_edges, count=len(chunked.chunks))),
                 final_loss=float(loss), peak_memory_GB=peak / 1e9, inference_ms_per_step=ms_inf, train_over_inference=ms / ms_inf,
                 eager_port_gpu=None if ms_ref is None else dict(ms_per_step=ms_ref, edges=e1, value=e1 * L / ms_ref * 1e3, unit="edge-TP/s", kind="port",
                                     sample=f"first {a1} center atoms / {e1} edges of the same box"),
@@ -593,6 +606,9 @@ def main():
     ap.add_argument("--dist-mode", default="halo", choices=["halo", "allreduce"],
                     help="N > 1: halo = sharded positions, forward / reverse communication of ghost rows (two all_to_all_single per step; every "
                          "rank builds only its slab's neighbour list); allreduce = replicated positions, one all-reduce of F[N,3] (the round-3 path)")
+    ap.add_argument("--train-chunk-edges", type=int, default=0,
+                    help="--mode train-step: accumulate the gradient one block of center atoms (<= this many edges) at a time "
+                         "(exact; peak memory ~ the block).  0 = the whole frame in one graph")
     ap.add_argument("--mode", default="step", choices=["step", "train-op", "train-step"],
                     help="step: the whole hot path (default, the driver's contract); train-op: training step of the operator seam; "
                          "train-step: optimisation step of the whole model in training mode")

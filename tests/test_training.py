@@ -66,6 +66,46 @@ def test_training_mode_gradients_match_oracle_autograd_on_gpu(name, dtype):
     _training_case(name, dtype, None, torch.device("cuda:0"))
 
 
+def _chunked_case(lib, dev, name="t_coupled", dtype=torch.float64, max_edges=70):
+    """`ChunkedTrainingStep`: the gradient of a force + energy loss accumulated one block of center atoms at a time equals
+    `loss.backward()` through the whole frame (and the forces / energy of its first pass are the inference pipeline's)."""
+    fx = load_model_fixture(name, dtype)
+    m = model_from_fixture(fx, dtype, lib, dev).train()
+    N = fx["pos"].shape[0]
+    graph = m.prepare_graph(fx["edge_index"].to(dev), fx["types"].to(dev), N, None if fx["shift_vec"] is None else fx["shift_vec"].to(dev))
+    pos = fx["pos"].to(dev)
+    tgt = torch.linspace(-0.3, 0.4, 3 * N, dtype=dtype).reshape(N, 3).to(dev)
+
+    def loss_fn(f, e):
+        return (f - tgt).square().mean() + 0.05 * (e / N - 0.2).square().sum()
+
+    params = [p for p in m.parameters() if p.requires_grad]
+    out = m._training_evaluator().forward({"pos": pos}, graph)
+    want = torch.autograd.grad(loss_fn(out["forces"], out["total_energy"]), params)
+    for p in params:
+        p.grad = None
+    step = m.chunked_training_step(graph, max_edges)
+    assert len(step.chunks) >= 3
+    loss, f, e = step.step(pos, loss_fn)
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
+    assert abs(float(loss) - float(loss_fn(out["forces"], out["total_energy"]).detach())) <= tol * max(1.0, abs(float(loss)))
+    assert (f - out["forces"].detach()).abs().max().item() <= tol * max(1.0, float(f.abs().max()))
+    for p, w in zip(params, want):
+        assert p.grad is not None and (p.grad - w).abs().max().item() <= tol * max(1e-6, float(w.abs().max()))
+
+
+def test_chunked_training_step_is_exact_emulated():
+    from tests.hip_utils import emu_lib
+
+    _chunked_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype,max_edges", [("t_coupled", torch.float64, 70), ("c2", torch.float32, 500)])
+def test_chunked_training_step_is_exact_on_gpu(name, dtype, max_edges):
+    _chunked_case(None, torch.device("cuda:0"), name, dtype, max_edges)
+
+
 def _optimizer_case(lib, dev):
     """Two Adam steps in training mode change the parameters in place; the inference pipeline then evaluates the UPDATED
     model (the packed device weights follow `_version`), equal to the training-mode evaluation of the same parameters."""

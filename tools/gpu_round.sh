@@ -7,6 +7,7 @@
 #   bench   <tag> [wl]     the driver's command line (default line incl. `secondary`, cpu_baseline, parity) [+ --workload wl]
 #   stages  <tag> [wl]     per-launch HIP-event table of one step (no baselines)
 #   ab      <tag> [wl]     same-box A/B: allegro_amd/liballegro_amd_old.so vs the product library, alternated 3 times
+#   abn     <tag> <wl> <name>...   same-box A/B/C: the product library vs allegro_amd/liballegro_amd_<name>.so for every name
 #   profile <tag> [wl]     rocprofv3 --kernel-trace --stats, then separate --pmc passes, summary + hashed traffic JSON
 #   hosts   <tag>          the Python-free hosts (tests/host): C99 driver and C++ AOTInductor package consumer
 #   ubench  <tag> <name>   tools/ubench/<name>.bin (hipcc -o it on the build box first: it travels with the snapshot)
@@ -39,6 +40,14 @@ case $CMD in
       r=$(timeout 600 python bench.py --workload $WL --steps 20 --warmup 5 --stages --no-cpu-baseline --no-gpu-reference --no-secondary --sustain 0 2> gpurun_out/${TAG}_ab_$lib.log | grep -o '"ms_per_step": [0-9.]*' | head -1)
       echo "$lib $r | $(grep '^\[stage\]' gpurun_out/${TAG}_ab_$lib.log | awk '{printf "%s %s  ", $2, $3}')"
     done; done | tee gpurun_out/${TAG}_ab_$WL.txt ;;
+  abn)
+    # same-box A/B/C...: the product library against allegro_amd/liballegro_amd_<name>.so for every further argument, alternated 3 times
+    WL=${ARG:-c4}; shift 3
+    for rep in 1 2 3; do for lib in new "$@"; do
+      if [ $lib = new ]; then unset ALLEGRO_AMD_LIBRARY; else export ALLEGRO_AMD_LIBRARY=$PWD/allegro_amd/liballegro_amd_$lib.so; fi
+      r=$(timeout 600 python bench.py --workload $WL --steps 20 --warmup 5 --stages --no-cpu-baseline --no-gpu-reference --no-secondary --sustain 0 2> gpurun_out/${TAG}_abn_$lib.log | grep -o '"ms_per_step": [0-9.]*' | head -1)
+      echo "$lib $r | $(grep '^\[stage\]' gpurun_out/${TAG}_abn_$lib.log | awk '{printf "%s %s  ", $2, $3}')"
+    done; done | tee gpurun_out/${TAG}_abn_$WL.txt ;;
   profile)
     WL=${ARG:-c4}
     bash tools/profile_gpu.sh $WL $TAG > /dev/null 2>&1
