@@ -532,3 +532,72 @@ def weighted_channels(sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int, lib
     evaluation.  `w` [E, u (l_max+1)] (one weight per channel and irrep) or [E, u] (`weight_individual_irreps=False`)."""
     shared = w.shape[1] == u and l_max > 0
     return _WcB.apply(sh.contiguous(), w.contiguous(), (int(u), int(l_max), bool(shared), int(lib_id)))
+
+
+class _EdgeDiff(torch.autograd.Function):
+    """vec[e] = x[nbr[e]] - x[center[e]] for per-atom rows x [N,c].  Its transpose is two deterministic segment sums (own CSR for
+    the centers, transposed CSR for the neighbours) instead of two atomic `index_add`s of E rows (0.65 ms each at C3,
+    profiles/r05_v9_train_c3_kernel_stats_first_kernels.txt); the pair (_EdgeDiff, _EdgeDiffT) is closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, x, csr):
+        ctx.csr = csr
+        center, nbr = csr[0], csr[1]
+        return x.index_select(0, nbr) - x.index_select(0, center)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _EdgeDiffT.apply(g, ctx.csr), None
+
+
+class _EdgeDiffT(torch.autograd.Function):
+    """out[a] = sum_{e: nbr[e] = a} g[e] - sum_{e: center[e] = a} g[e]."""
+
+    @staticmethod
+    def forward(ctx, g, csr):
+        ctx.csr = csr
+        _center, _nbr, rowptr, t_rowptr, t_perm, n, lib_id = csr
+        gd = g.detach()
+        own = torch.ops.allegro_amd.segment_sum(gd, rowptr, None, n, 1.0, lib_id)
+        other = torch.ops.allegro_amd.segment_sum(gd, t_rowptr, t_perm, n, 1.0, lib_id)
+        return other - own
+
+    @staticmethod
+    def backward(ctx, h):
+        return _EdgeDiff.apply(h, ctx.csr), None
+
+
+def edge_difference(x: torch.Tensor, graph, lib_id: int) -> torch.Tensor:
+    """`with_edge_vectors_` without the shift (called at allegro/nn/tensorembed.py:86): x[nbr] - x[center] on a center-sorted
+    `PreparedGraph` with its transposed CSR, differentiable to any order with segment-sum transposes."""
+    csr = (graph.center.long(), graph.nbr.long(), graph.rowptr, graph.t_rowptr, graph.t_perm, int(graph.num_atoms), int(lib_id))
+    return _EdgeDiff.apply(x, csr)
+
+
+class _SegSum(torch.autograd.Function):
+    """out[a] = sum over the edges of center a (EdgewiseReduce, allegro/nn/edgewise.py:40-60) on the segment-sum kernel; its
+    transpose is a gather."""
+
+    @staticmethod
+    def forward(ctx, x, center, rowptr, n, lib_id):
+        ctx.center, ctx.rowptr, ctx.n, ctx.lib_id = center, rowptr, n, lib_id
+        return torch.ops.allegro_amd.segment_sum(x.detach(), rowptr, None, n, 1.0, lib_id)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Gather.apply(g, ctx.center, ctx.rowptr, ctx.n, ctx.lib_id), None, None, None, None
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, center, rowptr, n, lib_id):
+        ctx.center, ctx.rowptr, ctx.n, ctx.lib_id = center, rowptr, n, lib_id
+        return x.index_select(0, center)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _SegSum.apply(g, ctx.center, ctx.rowptr, ctx.n, ctx.lib_id), None, None, None, None
+
+
+def edge_to_atom_sum(x: torch.Tensor, graph, lib_id: int) -> torch.Tensor:
+    return _SegSum.apply(x.contiguous(), graph.center.long(), graph.rowptr, int(graph.num_atoms), int(lib_id))

@@ -178,7 +178,12 @@ class TrainingEvaluator:
         N = graph.num_atoms
         types = graph.types.long()
         # edge vectors, normalised lengths (tensorembed.py:86; allegro_models.py:153-157)
-        vec = pos.index_select(0, nbr) - pos.index_select(0, center)
+        hand = self.lib_id is not None and graph.t_rowptr is not None and graph.t_perm is not None
+        if hand:
+            with _device_guard(pos):
+                vec = ops.edge_difference(pos, graph, self.lib_id)
+        else:
+            vec = pos.index_select(0, nbr) - pos.index_select(0, center)
         if shift_vec is not None:
             vec = vec + shift_vec
         tc, tn = types[center], types[nbr]
@@ -209,7 +214,11 @@ class TrainingEvaluator:
         # edge readout, edge -> atom sum, per-type scale / shift (allegro_models.py:231-260; edgewise.py:40-60)
         e_edge = _mlp(torch.cat(scalars, dim=-1), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd, self.lib_id)
         e_edge = e_edge * (1.0 / math.sqrt(2 * hp["avg_num_neighbors"]))
-        e_atom = torch.zeros((N, 1), dtype=e_edge.dtype, device=e_edge.device).index_add(0, center, e_edge)
+        if self.lib_id is not None:
+            with _device_guard(pos):
+                e_atom = ops.edge_to_atom_sum(e_edge, graph, self.lib_id)
+        else:
+            e_atom = torch.zeros((N, 1), dtype=e_edge.dtype, device=e_edge.device).index_add(0, center, e_edge)
         if m.has_scales:
             e_atom = e_atom * self._param("per_type_energy_scale_shift.scales").index_select(0, types).reshape(-1, 1)
         if m.has_shifts:
@@ -302,7 +311,7 @@ class ChunkedTrainingStep:
             lookup[local] = torch.arange(local.numel(), device=dev)
             ei = torch.stack([center[e0:e1] - a0, lookup[nb]])
             sv = None if graph.shift_vec is None else graph.shift_vec[e0:e1]
-            g = PreparedGraph(ei, graph.types.long().index_select(0, local), int(local.numel()), sv, transposed=False)
+            g = PreparedGraph(ei, graph.types.long().index_select(0, local), int(local.numel()), sv)
             self.chunks.append((local, a1 - a0, g))
 
     def step(self, pos: torch.Tensor, loss_fn):
