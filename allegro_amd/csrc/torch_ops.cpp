@@ -167,7 +167,12 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> energy_forces_gpu(const at::Tenso
   at::Tensor stale;  // defined on a cache hit: device bool, true when the list's contents changed behind the tensors
   {
     uint32_t ve = 0, vt = 0;
-    const bool keyed = tensor_version(edge_index, &ve) && tensor_version(atom_types, &vt) && fingerprintable(edge_index, atom_types);
+    const bool printable = fingerprintable(edge_index, atom_types);
+    const bool keyed = tensor_version(edge_index, &ve) && tensor_version(atom_types, &vt) && printable;
+    if (!printable)  // (such callers used to be cached before hits were validated by content; say what it costs, once)
+      TORCH_WARN_ONCE("allegro_amd::energy_forces: edge_index is not a contiguous int64 [2,E] tensor (or atom_types not contiguous "
+                      "int32/int64): the neighbour list cannot be fingerprinted, so its CSR is rebuilt (sort + two host reads) on "
+                      "EVERY call instead of once per list.  Pass edge_index.long().contiguous() to get the cache back.");
     bool hit = false;
     if (keyed) {
       std::lock_guard<std::mutex> lock(g_mu);

@@ -126,6 +126,17 @@ class TrainingEvaluator:
             node = getattr(node, part)
         return node
 
+    def _rows(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """table[idx] for a small trainable table (type / class embeddings).  The gradient of an `index_select` is an atomic
+        `index_add` of E rows onto a handful of table rows (one row for a single species: 1.9 ms per call at C3,
+        profiles/r05_v11_train_c3_kernel_stats.txt); as a product with the one-hot matrix of `idx` the same gradient is the
+        slab-reduced weight-gradient kernel -- deterministic, and 50x faster."""
+        rows = table.shape[0]
+        if self.lib_id is None or rows > 64:
+            return table.index_select(0, idx)
+        onehot = torch.nn.functional.one_hot(idx, rows).to(table.dtype)
+        return ops.linear(onehot, table, self.lib_id)
+
     def _wc(self, sh, w, u, l_max):
         if self.lib_id is None:
             return _weighted_channels(sh, w, u, l_max)
@@ -141,7 +152,7 @@ class TrainingEvaluator:
             k = 2 * math.pi / float(upper[0] - lower[0])
             t = k * (torch.minimum(torch.maximum(x, lower), upper) - lower)
             basis = 0.25 * (1 - torch.cos(t)).square()
-            w = self._param("radial_chemical_embed.spline.class_embed.weight").index_select(0, tc * T + tn).view(x.shape[0], -1, lower.numel())
+            w = self._rows(self._param("radial_chemical_embed.spline.class_embed.weight"), tc * T + tn).view(x.shape[0], -1, lower.numel())
             return torch.bmm(w, basis.unsqueeze(-1)).squeeze(-1)
         # TwoBodyBesselScalarEmbed (scalarembed.py:60-81): Bessel x polynomial cutoff -> linear, times the type-pair embedding
         # (ProductTypeEmbedding, _edgeembed.py:68-84)
@@ -164,8 +175,8 @@ class TrainingEvaluator:
         basis = _mlp(bessel, self._weights("radial_chemical_embed.type_embed.basis_linear.mlp"), "silu", self.act_consts["silu"],
                      hp["forward_normalize"], self.lib_id)
         # (index_select: its backward is an index_add, not the sort-based index_put of advanced indexing)
-        pair = torch.cat((self._param("radial_chemical_embed.type_embed.center_embed.weight").index_select(0, tc),
-                          self._param("radial_chemical_embed.type_embed.neighbor_embed.weight").index_select(0, tn)), dim=-1)
+        pair = torch.cat((self._rows(self._param("radial_chemical_embed.type_embed.center_embed.weight"), tc),
+                          self._rows(self._param("radial_chemical_embed.type_embed.neighbor_embed.weight"), tn)), dim=-1)
         return pair * basis
 
     def atomic_energy(self, pos: torch.Tensor, graph, shift_vec: Optional[torch.Tensor]) -> torch.Tensor:

@@ -459,3 +459,51 @@ def test_narrow_hidden_layers_run_zero_padded_on_the_fused_chains(widths, monkey
         assert any(n.startswith("gc_") for n in names) == (no_pad == "0"), names
         out[no_pad] = m.energy_forces(p32, g)
     assert (out["0"][1] - out["1"][1]).abs().max().item() < 2e-5 * max(1.0, float(out["1"][1].abs().max()))
+
+
+@pytest.mark.parametrize("dt,S,lat,tol", [("float32", 128, 128, 2e-4), ("float64", 64, 64, 1e-10), ("float64", 128, 128, 1e-10),
+                                          ("float32", 64, 128, 2e-4)])
+def test_two_layer_stacks_off_the_chain_shapes_take_the_operator_path(dt, S, lat, tol, monkeypatch):
+    """Round 5 (profiles/r05_v3 / v7 / v8 shape maps): 2-layer u = 64 stacks the fused chains do not cover -- fp64, or S / MLP widths
+    of 128 -- ran the 2-layer moments kernels + single linear layers; the operator kernels (+ slot form) are faster there (fp32
+    u 64 / S 128: 7.41 -> 3.96 ms at C3; fp64 u = S = 64: 4.89 -> 4.14 ms) and are now selected, except where the slot form does not
+    apply in fp32 (S 64 with 128-wide latents: a wash, keeps the moments kernels).  Both selections against the oracle."""
+    import numpy as np
+
+    from allegro_amd import graph as G
+    from allegro_amd.nn import HipAllegroModel
+    from oracle import restatement as R
+
+    rng = np.random.default_rng(21)
+    n = 9
+    pos = rng.uniform(0, 5.5, size=(n, 3))
+    cell = np.eye(3) * 60.0
+    ei, shift = G.neighbor_list_pbc(pos, cell, 3.4)
+    deg = np.bincount(ei[0], minlength=n)
+    cfg = dict(type_names=["A", "B"], r_max=3.4, l_max=2, num_layers=2, num_scalar_features=S, num_tensor_features=64,
+               radial_chemical_embed={"_target_": "allegro.nn.TwoBodyBesselScalarEmbed", "num_bessels": 8}, radial_chemical_embed_dim=S,
+               scalar_embed_mlp_hidden_layers_width=S, allegro_mlp_hidden_layers_width=lat, readout_mlp_hidden_layers_width=lat,
+               avg_num_neighbors=float(deg.mean()), seed=5, model_dtype=dt)
+    tdt = getattr(torch, dt)
+    types = torch.tensor(rng.integers(0, 2, size=n))
+    expect_op = not (dt == "float32" and S == 64)
+    outs = []
+    for prefer_moments in (False, True):
+        if prefer_moments:
+            monkeypatch.setenv("AA_TP_PREFER_MOM", "1")
+        m = HipAllegroModel(**cfg)
+        m._bind_library(emu_lib())
+        d = m.describe_plan()
+        assert d["operator_path"] == (expect_op and not prefer_moments), (d, prefer_moments)
+        if d["operator_path"]:
+            assert d["slot_form"] == (lat == S)
+        g = m.prepare_graph(torch.tensor(ei), types, n, torch.tensor(shift @ cell, dtype=tdt))
+        e, f = m.energy_forces(torch.tensor(pos, dtype=tdt), g)
+        outs.append((e.double(), f.double()))
+        if not prefer_moments:
+            sd = {k[len("func."):]: v.detach() for k, v in m.state_dict().items()}
+            ref = R.allegro_energy_forces(cfg, sd, torch.tensor(pos, dtype=tdt), torch.tensor(ei), types, torch.tensor(shift @ cell, dtype=tdt))
+            assert (e - ref["atomic_energy"].reshape(-1)).abs().max() <= tol * max(1.0, float(ref["atomic_energy"].abs().max()))
+            assert (f - ref["forces"]).abs().max() <= tol * max(1.0, float(ref["forces"].abs().max()))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= tol * max(1.0, float(b.abs().max()))
