@@ -3,10 +3,10 @@
 // The reference trains every ScalarMLPFunction through autograd (allegro/nn/_allegro.py:192-213): per linear layer the
 // backward needs d W = x^T g, a product whose REDUCTION runs over the edges (K = E ~ 10^5..10^7, output 64..512 wide).  Library
 // GEMMs pick a tile for the tiny output and walk the whole reduction in one or two workgroups (measured on MI355X: 0.73 ms for
-// [64 x 298 144] @ [298 144 x 64], 3 TFLOP/s, 210 GB/s -- profiles/r05_v6_train_c3_kernel_stats.txt); here the edges are cut
-// into slabs, one wave per slab and 64 x 64 output block, exact-fp32 / fp64 products on the matrix cores
-// (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64: no split-precision needed, the kernel is HBM-bound), and the slabs are
-// summed in a fixed order by a second small kernel: bit-reproducible, no atomics.
+// [64 x 298 144] @ [298 144 x 64], 3 TFLOP/s, 210 GB/s, and 16 ms in fp64 -- profiles/r05_v14_wgrad_bench.md); here the edges are
+// cut into slabs, one workgroup per slab and 64..128-wide output block, rows staged through LDS with full-line loads, exact-fp32 /
+// fp64 products on the matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64: no split-precision needed, the kernel is
+// HBM-bound), and the slabs are summed in a fixed order by a second small kernel: bit-reproducible, no atomics.
 //
 // The other half of this file is MakeWeightedChannels (allegro/nn/_strided/_channels.py:44-63) as a bilinear form
 // B(sh, w)[e,c,i] = sh[e,i] w[e,c,r(i)] with its two partial contractions -- three kernels that are closed under differentiation
@@ -34,208 +34,101 @@ struct WgradArgs {
   int slabs;
 };
 
-// The four waves of a workgroup take four consecutive slabs of rows and the same 64 x 64 output block; their accumulators are
-// combined through LDS in a fixed order ((w0 + w2) + (w1 + w3)) and ONE partial block per workgroup goes to the workspace.
-//
-// fp32: 2 x 2 tiles of v_mfma_f32_32x32x2_f32.  Lane l = (i = l & 31, kk = l >> 5) supplies A[i][kk] and B[kk][j = i]: one float2 of
-// row e + kk per operand (VEC: 512 contiguous bytes per load instruction) whose two elements feed two MFMAs, so MFMA (p, q) sees
-// the column sets {k0 + 2 i + p} x {n0 + 2 j + q}; without VEC (odd widths / strides) single floats and the sets {k0 + 32 p + i}.
-template <typename T, int NACC>
-__device__ __forceinline__ void wgrad_block_reduce(T* acc, int wv, int lane, T* lds) {
-  // acc: NACC values per lane.  Rounds: waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds.
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    const int writers_lo = round == 0 ? 2 : 1, nw = round == 0 ? 2 : 1;
-    __syncthreads();
-    if (wv >= writers_lo && wv < writers_lo + nw) {
-      T* d = lds + size_t(wv - writers_lo) * 64 * NACC;
-#pragma unroll
-      for (int r = 0; r < NACC; ++r) d[r * 64 + lane] = acc[r];
-    }
-    __syncthreads();
-    if (wv < nw) {
-      const T* d = lds + size_t(wv) * 64 * NACC;
-#pragma unroll
-      for (int r = 0; r < NACC; ++r) acc[r] += d[r * 64 + lane];
-    }
-  }
-}
+// A workgroup (4 waves, 2 x 2) owns a KB x NB block of the output and a slab of rows.  Rows are staged through LDS in groups of RS
+// with full-line 16-byte loads (each row of x / g is read once per workgroup, whatever the MFMA operand layout wants), and every
+// wave multiplies ITS (KB/2) x (NB/2) quarter: fp32 v_mfma_f32_32x32x2_f32 (A[i = l & 31][kk = l >> 5] = xs[2 s + kk][k + i],
+// B[kk][j] = gs[2 s + kk][n + j]), fp64 v_mfma_f64_16x16x4_f64 (A[i = l & 15][kk = l >> 4], four rows per step).  One partial
+// block per workgroup goes to the workspace; a second kernel sums the partial blocks in order.
+template <typename T>
+struct WgTile;
+template <>
+struct WgTile<float> {
+  static constexpr int TS = 32, RE = 2, NR = 16;  // tile side, rows per MFMA, accumulator registers per tile
+  typedef v16f_t acc_t;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int out_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+template <>
+struct WgTile<double> {
+  static constexpr int TS = 16, RE = 4, NR = 4;
+  typedef v4d_t acc_t;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int out_row(int r, int lane) { return 4 * r + (lane >> 4); }
+};
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void wgrad_f32_kernel(WgradArgs a) {
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int slab = blockIdx.x * 4 + wv;
-  const int k0 = blockIdx.y * 64, n0 = blockIdx.z * 64;
-  const int i = lane & 31, kk = lane >> 5;
-  const float* x = static_cast<const float*>(a.x);
-  const float* g = static_cast<const float*>(a.g);
-  const int64_t e0 = int64_t(slab) * a.rows_per_slab;
-  const int64_t e1 = slab >= a.slabs ? e0 : (e0 + a.rows_per_slab < a.E ? e0 + a.rows_per_slab : a.E);
-  // columns beyond K / N: clamped address, zero contribution
-  int kc[2], nc[2];
-  float km[2], nm[2];
+template <typename T, int KB, int NB, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  typedef WgTile<T> W;
+  constexpr int TS = W::TS, RE = W::RE, RS = sizeof(T) == 8 ? 16 : 32;  // RS rows per stage (<= 34 KB of LDS for every block shape)
+  constexpr int TK = KB / 2 / TS, TN = NB / 2 / TS;      // tiles per wave
+  constexpr int LDX = KB + 4, LDG = NB + 4;              // (+4: rows 2 s + kk of the two lane halves land in different banks)
+  constexpr int VW = 16 / sizeof(T);                     // elements per 16-byte load
+  T* xs = reinterpret_cast<T*>(aa_smem);                 // [RS][LDX]
+  T* gs = xs + RS * LDX;                                 // [RS][LDG]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k0 = blockIdx.y * KB, n0 = blockIdx.z * NB;
+  const int wk = (wv >> 1) * (KB / 2), wn = (wv & 1) * (NB / 2);  // this wave's quarter
+  const int ti = lane & (TS - 1), kk = lane / TS;
+  const T* x = static_cast<const T*>(a.x);
+  const T* g = static_cast<const T*>(a.g);
+  const int64_t e0 = int64_t(blockIdx.x) * a.rows_per_slab;
+  const int64_t e1 = e0 + a.rows_per_slab < a.E ? e0 + a.rows_per_slab : a.E;
+  typename W::acc_t acc[TK][TN];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int k = VEC ? k0 + 2 * i + b : k0 + 32 * b + i, n = VEC ? n0 + 2 * i + b : n0 + 32 * b + i;
-    kc[b] = k < a.K ? k : a.K - 1;
-    nc[b] = n < a.N ? n : a.N - 1;
-    km[b] = k < a.K ? 1.f : 0.f;
-    nm[b] = n < a.N ? 1.f : 0.f;
-  }
-  if (VEC) {  // (pairs never straddle the end: widths are even on this path) a pair beyond the end re-reads the last valid pair
-    kc[0] = kc[0] & ~1;
-    nc[0] = nc[0] & ~1;
-  }
-  v16f_t acc[2][2];
+  for (int p = 0; p < TK; ++p)
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+    for (int q = 0; q < TN; ++q)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+      for (int r = 0; r < W::NR; ++r) acc[p][q][r] = T(0);
+  // staging: thread t moves elements t, t + 256, ... of the RS x (KB | NB) tile; rows beyond the slab and columns beyond K / N are zero
+  auto stage = [&](const T* src, int64_t ld, int c0, int width, int CB, int LD, T* dst, int64_t eb) {
+    if (VEC) {
+      typedef T vec_t __attribute__((ext_vector_type(VW)));
+      const int per_row = CB / VW;
+      for (int idx = tid; idx < RS * per_row; idx += 256) {
+        const int r = idx / per_row, c = (idx - r * per_row) * VW;
+        vec_t v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
-  constexpr int UN = 8;  // edge pairs in flight
-  for (int64_t e = e0; e < e1; e += 2 * UN) {
-    float xv[UN][2], gv[UN][2];
+        for (int q = 0; q < VW; ++q) v[q] = T(0);
+        if (eb + r < e1 && c0 + c < width) v = *reinterpret_cast<const vec_t*>(src + (eb + r) * ld + c0 + c);  // (width % VW == 0 on this path)
 #pragma unroll
-    for (int s = 0; s < UN; ++s) {
-      const int64_t row = e + 2 * s + kk;
-      const int64_t rc = row < e1 ? row : e1 - 1;
-      const float m = row < e1 ? 1.f : 0.f;
-      if (VEC) {
-        const f2 xx = *reinterpret_cast<const f2*>(x + rc * a.ldx + kc[0]);
-        const f2 gg = *reinterpret_cast<const f2*>(g + rc * a.ldg + nc[0]);
-        xv[s][0] = xx[0] * (m * km[0]);
-        xv[s][1] = xx[1] * (m * km[1]);
-        gv[s][0] = gg[0] * nm[0];
-        gv[s][1] = gg[1] * nm[1];
-      } else {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          xv[s][b] = x[rc * a.ldx + kc[b]] * (m * km[b]);
-          gv[s][b] = g[rc * a.ldg + nc[b]] * nm[b];
-        }
+        for (int q = 0; q < VW; ++q) dst[r * LD + c + q] = v[q];
+      }
+    } else {
+      for (int idx = tid; idx < RS * CB; idx += 256) {
+        const int r = idx / CB, c = idx - r * CB;
+        dst[r * LD + c] = (eb + r < e1 && c0 + c < width) ? src[(eb + r) * ld + c0 + c] : T(0);
       }
     }
+  };
+  for (int64_t eb = e0; eb < e1; eb += RS) {
+    __syncthreads();  // (the previous stage has been consumed)
+    stage(x, a.ldx, k0, a.K, KB, LDX, xs, eb);
+    stage(g, a.ldg, n0, a.N, NB, LDG, gs, eb);
+    __syncthreads();
 #pragma unroll
-    for (int s = 0; s < UN; ++s)
+    for (int s = 0; s < RS / RE; ++s) {
+      T av[TK], bv[TN];
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
+      for (int p = 0; p < TK; ++p) av[p] = xs[(RE * s + kk) * LDX + wk + TS * p + ti];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s][p], gv[s][q], acc[p][q], 0, 0, 0);
-  }
-  float flat[64];
+      for (int q = 0; q < TN; ++q) bv[q] = gs[(RE * s + kk) * LDG + wn + TS * q + ti];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+      for (int p = 0; p < TK; ++p)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) flat[(p * 2 + q) * 16 + r] = acc[p][q][r];
-  wgrad_block_reduce<float, 64>(flat, wv, lane, reinterpret_cast<float*>(aa_smem));
-  if (wv != 0) return;
-  // D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
-  float* out = static_cast<float*>(a.partial) + int64_t(blockIdx.x) * a.K * a.N;
-#pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int n = VEC ? n0 + 2 * i + q : n0 + 32 * q + i;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ir = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const int k = VEC ? k0 + 2 * ir + p : k0 + 32 * p + ir;
-        if (k < a.K && n < a.N) out[int64_t(k) * a.N + n] = flat[(p * 2 + q) * 16 + r];
-      }
+        for (int q = 0; q < TN; ++q) acc[p][q] = W::mma(av[p], bv[q], acc[p][q]);
     }
-}
-
-// fp64: 4 x 4 tiles of v_mfma_f64_16x16x4_f64 (A[i = l & 15][kk = l >> 4], B[kk][j = l & 15], D[4 r + (l >> 4)][l & 15]): four rows per
-// step; VEC: one double2 per 32-column half, columns {k0 + 32 h + 2 i + b} for tile 2 h + b
-template <bool VEC>
-__global__ __launch_bounds__(256) void wgrad_f64_kernel(WgradArgs a) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int slab = blockIdx.x * 4 + wv;
-  const int k0 = blockIdx.y * 64, n0 = blockIdx.z * 64;
-  const int i = lane & 15, kk = lane >> 4;
-  const double* x = static_cast<const double*>(a.x);
-  const double* g = static_cast<const double*>(a.g);
-  const int64_t e0 = int64_t(slab) * a.rows_per_slab;
-  const int64_t e1 = slab >= a.slabs ? e0 : (e0 + a.rows_per_slab < a.E ? e0 + a.rows_per_slab : a.E);
-  auto col = [&](int base, int b) { return VEC ? base + 32 * (b >> 1) + 2 * i + (b & 1) : base + 16 * b + i; };
-  int kc[4], nc[4];
-  double km[4], nm[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int k = col(k0, b), n = col(n0, b);
-    kc[b] = k < a.K ? k : a.K - 1;
-    nc[b] = n < a.N ? n : a.N - 1;
-    km[b] = k < a.K ? 1.0 : 0.0;
-    nm[b] = n < a.N ? 1.0 : 0.0;
   }
-  if (VEC) {
-    kc[0] &= ~1; kc[2] &= ~1; nc[0] &= ~1; nc[2] &= ~1;
-  }
-  v4d_t acc[4][4];
+  T* out = static_cast<T*>(a.partial) + int64_t(blockIdx.x) * a.K * a.N;
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+  for (int p = 0; p < TK; ++p)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < TN; ++q) {
+      const int n = n0 + wn + TS * q + ti;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[p][q][r] = 0.0;
-  constexpr int UN = 2;
-  for (int64_t e = e0; e < e1; e += 4 * UN) {
-    double xv[UN][4], gv[UN][4];
-#pragma unroll
-    for (int s = 0; s < UN; ++s) {
-      const int64_t row = e + 4 * s + kk;
-      const int64_t rc = row < e1 ? row : e1 - 1;
-      const double m = row < e1 ? 1.0 : 0.0;
-      if (VEC) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const d2 xx = *reinterpret_cast<const d2*>(x + rc * a.ldx + kc[2 * h]);
-          const d2 gg = *reinterpret_cast<const d2*>(g + rc * a.ldg + nc[2 * h]);
-          xv[s][2 * h] = xx[0] * (m * km[2 * h]);
-          xv[s][2 * h + 1] = xx[1] * (m * km[2 * h + 1]);
-          gv[s][2 * h] = gg[0] * nm[2 * h];
-          gv[s][2 * h + 1] = gg[1] * nm[2 * h + 1];
-        }
-      } else {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          xv[s][b] = x[rc * a.ldx + kc[b]] * (m * km[b]);
-          gv[s][b] = g[rc * a.ldg + nc[b]] * nm[b];
-        }
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < UN; ++s)
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[s][p], gv[s][q], acc[p][q], 0, 0, 0);
-  }
-  double flat[64];
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) flat[(p * 4 + q) * 4 + r] = acc[p][q][r];
-  wgrad_block_reduce<double, 64>(flat, wv, lane, reinterpret_cast<double*>(aa_smem));
-  if (wv != 0) return;
-  double* out = static_cast<double*>(a.partial) + int64_t(blockIdx.x) * a.K * a.N;
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = col(n0, q);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ir = 4 * r + kk;
-        const int k = VEC ? k0 + 32 * (p >> 1) + 2 * ir + (p & 1) : k0 + 16 * p + ir;
-        if (k < a.K && n < a.N) out[int64_t(k) * a.N + n] = flat[(p * 4 + q) * 4 + r];
+      for (int r = 0; r < W::NR; ++r) {
+        const int k = k0 + wk + TS * p + W::out_row(r, lane);
+        if (k < a.K && n < a.N) out[int64_t(k) * a.N + n] = acc[p][q][r];
       }
     }
 }
@@ -255,16 +148,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const T* partial, int
   if (sl == 0 && idx < KN) out[idx] = (lds[o] + lds[64 + o]) + (lds[128 + o] + lds[192 + o]);
 }
 
-// rows per slab (one wave): enough slabs to fill the chip several times over for every output-block count, at least 128 rows
+// rows per workgroup: ~1024 workgroups along the rows (several per CU for every output-block count), at least 256 rows each
 int64_t wgrad_rows_per_slab(int64_t E) {
-  int64_t rows = (E + 4095) / 4096;
-  rows = std::max<int64_t>(rows, 128);
-  return (rows + 15) / 16 * 16;
+  int64_t rows = (E + 1023) / 1024;
+  rows = std::max<int64_t>(rows, 256);
+  return (rows + 31) / 32 * 32;
 }
 int wgrad_parts(int64_t E) {  // workgroups along the rows = partial blocks in the workspace
   const int64_t rows = wgrad_rows_per_slab(E);
-  const int64_t slabs = (E + rows - 1) / rows;
-  return int(std::max<int64_t>(1, (slabs + 3) / 4));
+  return int(std::max<int64_t>(1, (E + rows - 1) / rows));
+}
+
+template <typename T, int KB, int NB>
+int wgrad_launch(const WgradArgs& a, bool vec, int parts, hipStream_t s) {
+  dim3 grid((unsigned)parts, (unsigned)((a.K + KB - 1) / KB), (unsigned)((a.N + NB - 1) / NB));
+  const size_t lds = sizeof(T) * (sizeof(T) == 8 ? 16 : 32) * size_t(KB + 4 + NB + 4);
+  if (vec)
+    hipLaunchKernelGGL((wgrad_kernel<T, KB, NB, true>), grid, dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<T, KB, NB, false>), grid, dim3(256), lds, s, a);
+  return AA_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -362,29 +265,28 @@ extern "C" int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const vo
   a.ldg = ldg;
   a.partial = workspace;
   a.rows_per_slab = aa::wgrad_rows_per_slab(E);
-  a.slabs = int((E + a.rows_per_slab - 1) / a.rows_per_slab);
   const int parts = aa::wgrad_parts(E);
-  dim3 grid((unsigned)parts, (unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64));
+  a.slabs = parts;
   const int64_t KN = int64_t(K) * N;
-  // two-element loads need even widths and strides and 2-element-aligned bases
-  const bool vec = (K % 2 == 0) && (N % 2 == 0) && (ldx % 2 == 0) && (ldg % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % (2 * esize) == 0) &&
-                   (reinterpret_cast<uintptr_t>(g) % (2 * esize) == 0);
-  const size_t lds = 2 * 64 * 64 * esize;  // two waves' accumulators
+  // 16-byte loads need widths and strides that are multiples of the vector and 16-byte-aligned bases
+  const int vw = int(16 / esize);
+  const bool vec = (K % vw == 0) && (N % vw == 0) && (ldx % vw == 0) && (ldg % vw == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                   (reinterpret_cast<uintptr_t>(g) % 16 == 0);
+  // block shape: 128-wide where the dimension is wider than 64 (each operand is then re-read half as often)
+  const bool k128 = K > 64, n128 = N > 64;
+  int rc;
   if (dtype == AA_F32) {
-    if (vec)
-      hipLaunchKernelGGL(aa::wgrad_f32_kernel<true>, grid, dim3(256), lds, s, a);
-    else
-      hipLaunchKernelGGL(aa::wgrad_f32_kernel<false>, grid, dim3(256), lds, s, a);
+    rc = k128 ? (n128 ? aa::wgrad_launch<float, 128, 128>(a, vec, parts, s) : aa::wgrad_launch<float, 128, 64>(a, vec, parts, s))
+              : (n128 ? aa::wgrad_launch<float, 64, 128>(a, vec, parts, s) : aa::wgrad_launch<float, 64, 64>(a, vec, parts, s));
     hipLaunchKernelGGL(aa::wgrad_reduce_kernel<float>, dim3((unsigned)((KN + 63) / 64)), dim3(256), 256 * sizeof(float), s,
                        static_cast<const float*>(workspace), parts, KN, static_cast<float*>(out));
   } else {
-    if (vec)
-      hipLaunchKernelGGL(aa::wgrad_f64_kernel<true>, grid, dim3(256), lds, s, a);
-    else
-      hipLaunchKernelGGL(aa::wgrad_f64_kernel<false>, grid, dim3(256), lds, s, a);
+    rc = k128 ? (n128 ? aa::wgrad_launch<double, 128, 128>(a, vec, parts, s) : aa::wgrad_launch<double, 128, 64>(a, vec, parts, s))
+              : (n128 ? aa::wgrad_launch<double, 64, 128>(a, vec, parts, s) : aa::wgrad_launch<double, 64, 64>(a, vec, parts, s));
     hipLaunchKernelGGL(aa::wgrad_reduce_kernel<double>, dim3((unsigned)((KN + 63) / 64)), dim3(256), 256 * sizeof(double), s,
                        static_cast<const double*>(workspace), parts, KN, static_cast<double*>(out));
   }
+  (void)rc;
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
