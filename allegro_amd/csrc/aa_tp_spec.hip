@@ -1244,7 +1244,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? (KA2 ? 3
 }
 
 template <class Sig0, class Sig1, typename T, bool KA2>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? 2 : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
+#ifndef AA_MOM_FIRST_WAVES
+#define AA_MOM_FIRST_WAVES 2  // waves per SIMD the register budget is sized for (A/B: 3 = 168 VGPRs)
+#endif
+__global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? AA_MOM_FIRST_WAVES : 1) void tp_mom_bwd_first_kernel(TpMomArgs ma) {
   constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
   AA_MOM_PROLOGUE(D)
