@@ -14,7 +14,7 @@
 #   shards  <tag> [W]      every rank's compact shard of a W-way partition of C4, one after the other (load balance)
 #   final   <tag>          tests + bench (c4, c5, c3, c2, c1) + stages + shards + profile c4 / c5: the end-of-round evidence
 cd "$(dirname "$0")/.."
-CMD=${1:-tests}; TAG=${2:-r04}; ARG=${3:-}
+CMD=${1:-tests}; TAG=${2:-r05}; ARG=${3:-}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 case $CMD in
@@ -77,6 +77,11 @@ case $CMD in
     bash $0 stages $TAG c4
     bash $0 shards $TAG 8
     bash $0 profile $TAG c4
-    bash $0 profile $TAG c5 ;;
+    bash $0 profile $TAG c5
+    for wl in c4 c5; do python tools/pmc_bound_table.py gpurun_out/${TAG}_rocprofv3_${wl}_summary.txt > gpurun_out/${TAG}_bound_table_${wl}.md; done
+    timeout 600 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 > gpurun_out/${TAG}_train_step_c3.json 2> /dev/null
+    AA_TRAIN_EAGER=1 timeout 600 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 --no-gpu-reference > gpurun_out/${TAG}_train_step_c3_eager.json 2> /dev/null
+    timeout 900 python bench.py --mode train-step --workload c4 --steps 2 --warmup 1 --no-gpu-reference --train-chunk-edges 400000 > gpurun_out/${TAG}_train_step_c4_chunked.json 2> /dev/null
+    grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_train_step_c3.json gpurun_out/${TAG}_train_step_c3_eager.json gpurun_out/${TAG}_train_step_c4_chunked.json ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
 esac
