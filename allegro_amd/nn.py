@@ -933,7 +933,12 @@ class HipAllegroModel(torch.nn.Module):
         N, E = graph.num_atoms, graph.num_edges
         need = lib.lib.aa_model_workspace_bytes(self._plan_handle, N, E, int(with_forces))
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != pos.device:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=pos.device)
+            # The arena is the caller's (C ABI): this host grows it with 6 % of headroom and drops the old one FIRST.  In an MD loop
+            # the edge count creeps up and down with every neighbour list; an arena sized exactly for the largest list so far is
+            # re-allocated at every new maximum, and a fresh 30-GB device allocation costs ~0.5 s on this stack (two such steps in
+            # the first 25 fs of the C4 run of tools/md_loop.py: profiles/r05_v22_md_loop_c4.json) while old + new briefly coexist.
+            self._workspace = None
+            self._workspace = torch.empty(need + need // 16 + (1 << 20), dtype=torch.uint8, device=pos.device)
         pos = pos.detach().contiguous()
         if getattr(self, "_hip_graph", False):
             # replay mode: outputs live in persistent buffers so that every argument of the step keeps its address
