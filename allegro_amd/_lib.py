@@ -57,7 +57,7 @@ def options_from_env() -> PlanOptions:
     o.gemm_lds_epilogue = int(env.get("AA_GEMM_DIRECT_EPILOGUE", "1")[:1] == "0")
     o.f64_column_loop = {"0": 1, "2": 2}.get(env.get("AA_F64_NLOOP", "1")[:1], 0)
     o.embed_no_fuse = flag("AA_EMBED_NOFUSE")
-    o.fused_forward = {"0": 3, "1": 1}.get(env.get("AA_FUSED", "")[:1], 0)  # unset: whenever the graph allows
+    o.fused_forward = {"0": 3, "1": 1, "2": 2, "4": 4}.get(env.get("AA_FUSED", "")[:1], 0)  # unset: automatic; 2 / 4: pure team / mixed form for every graph with segments <= 128 (A/B)
     o.fused_recompute_w0 = flag("AA_FUSED_RECOMPUTE")
     o.moments_waves_per_block = int(env.get("AA_MOM_WPB", "0") or 0)
     o.no_channel_padding = flag("AA_NO_PAD")

@@ -711,6 +711,8 @@ struct FusedFwdArgs {
   float* atom_energy;  // [N]
   int keep;            // split tile pairs held in registers by the one-tile w0-holding form: 0 none, 1 two-body scalars, 2 + lat0
   int32_t* status;     // nullable, host-visible: set to the offending degree when a segment exceeds what the max_degree hint promised
+  int mixed;           // with the class lists set: one-tile pass over all atoms (long ones skipped) + team pass over the long ones only
+  int skip_long, long_only, fill_done;  // (set by launch_fused_fwd for the two passes of the mixed form)
 };
 size_t fused_fwd_lds_bytes(int num_types, bool teams);  // dynamic LDS of the fused forward (aa_fused.hip); the CU has 160 KB
 // reverse tail (aa_fused_bwd.hip): layer-0 tensor product reverse + first-stage / scalar_embed_mlp reverse + edge reverse

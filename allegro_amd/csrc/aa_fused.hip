@@ -182,7 +182,11 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
       // silent truncation: the atom is skipped (cnt < 0: every row masked), its energy becomes NaN and the plan's status
       // word makes the next aa_model_energy_forces / aa_model_check fail (the reference takes any segment length,
       // allegro/nn/_strided/_contract.py:195-205 -- the host then has to pass the true degree and gets the staged pipeline).
-      if (deg > (TEAMS ? kFusedMaxDegree : 32)) {
+      if (!TEAMS && A.skip_long && deg > 32 && deg <= kFusedMaxDegree) {
+        // mixed form (launch_fused_fwd): the few atoms with more than one tile of edges belong to the team pass that follows on
+        // the same stream; this pass leaves every row and every per-atom result of theirs alone
+        cnt = -2;
+      } else if (deg > (TEAMS ? kFusedMaxDegree : 32)) {
         cnt = -1;
         if (A.status && lane == 0) *reinterpret_cast<volatile int32_t*>(A.status) = deg;
         // ... and the FORCES of this step must not look valid either (none of this atom's workspace rows are written,
@@ -227,11 +231,11 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
     opaque_scalar(p.zero);  // (see pipe_load)
     AA_TICK(0)
     const int64_t atom = a_cur;
-    const bool atom_ok = atom < A.atom_end;
     const int tsize = team_size(group_of(it)), tile = tile_of(group_of(it)), tfirst = wvs - tile;  // (tsize: workgroup-uniform)
     const bool leader = tile == 0;
     const int64_t a_n3 = atom_of(it + 3);
     const int beg = __builtin_amdgcn_readfirstlane(cur.beg), cnt = __builtin_amdgcn_readfirstlane(cur.cnt);
+    const bool atom_ok = atom < A.atom_end && cnt != -2;  // (-2: an atom of the other pass of the mixed form)
     const bool row_ok = el < cnt;
     const int64_t row0 = beg;
     // prefetch: neighbor ids of the next tile, row pointers of the one after
@@ -590,10 +594,11 @@ __global__ __launch_bounds__(256, kFusedOcc) void fused_fwd_kernel(FusedFwdArgs 
 // the class lists of the TEAMS form: atoms with 65..128 / 33..64 / 0..32 edges -> lists 0 / 1 / 2 ([3][cap]) through atomic
 // counters (zeroed by the launcher).  Slot order is arbitrary; nothing depends on it.
 __global__ __launch_bounds__(256) void fused_classify_kernel(int64_t a0, int64_t a1, const int32_t* rowptr, int64_t cap, int32_t* atoms,
-                                                             int32_t* counts) {
+                                                             int32_t* counts, int min_deg) {
   const int64_t n = a0 + int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (n >= a1) return;
   const int deg = rowptr[n + 1] - rowptr[n];
+  if (deg <= min_deg) return;  // (mixed form: only the atoms the one-tile pass skipped)
   const int cls = deg > 64 ? 0 : (deg > 32 ? 1 : 2);
   const int idx = atomicAdd(&counts[cls], 1);
   atoms[cls * cap + idx] = int32_t(n);
@@ -615,12 +620,32 @@ size_t fused_fwd_lds_bytes(int num_types, bool teams) {
 // number of weight-pipeline steps of the program for R irreps (see the kernel)
 int fused_fwd_num_steps(int R, bool hold) { return fused_fwd_steps(R, hold); }
 
+static int launch_fused_fwd_one(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
+
+// Mixed form (a.mixed, with the class lists set): most atoms have one tile of edges, a FEW have more (thermal disorder pushes a
+// handful of Si atoms past 32 neighbours; profiles/r05_v23_md_loop_c4.json).  The team form costs every atom ~12 % (class lists,
+// exchange area, 2 fewer tile parkings), the staged pipeline ~12 % of the step: instead the one-tile kernel runs over all atoms at
+// full speed and SKIPS the long ones, and a second, small launch of the team form takes exactly those (its grid is the list).
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
+  if (!a.mixed || a.tile_atoms == nullptr) return launch_fused_fwd_one(pair, hold_w0, a, stream);
+  FusedFwdArgs one = a;
+  one.tile_atoms = nullptr;
+  one.tile_counts = nullptr;
+  one.tile_cap = 0;
+  one.skip_long = 1;
+  if (int rc = launch_fused_fwd_one(pair, hold_w0, one, stream)) return rc;
+  FusedFwdArgs team = a;
+  team.long_only = 1;
+  team.fill_done = 1;
+  return launch_fused_fwd_one(pair, hold_w0, team, stream);
+}
+
+static int launch_fused_fwd_one(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;
   const bool teams = a.tile_atoms != nullptr;
   const size_t smem = fused_fwd_lds_bytes(a.num_types, teams);
   if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "fused forward: LDS budget exceeded");
-  if (a.N > 0 && (a.atom0 > 0 || a.atom_end < a.N)) {
+  if (a.N > 0 && (a.atom0 > 0 || a.atom_end < a.N) && !a.fill_done) {
     hipLaunchKernelGGL(fused_fill_energy_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, stream, a.N, a.atom0, a.atom_end,
                        a.types, a.shifts, a.atom_energy);
   }
@@ -638,7 +663,7 @@ int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t 
   if (teams) {
     AA_CHECK_HIP(hipMemsetAsync(a.tile_counts, 0, 4 * sizeof(int32_t), stream));
     hipLaunchKernelGGL(fused_classify_kernel, dim3((unsigned)((a.atom_end - a.atom0 + 255) / 256)), dim3(256), 0, stream, a.atom0, a.atom_end,
-                       a.rowptr, a.tile_cap, a.tile_atoms, a.tile_counts);
+                       a.rowptr, a.tile_cap, a.tile_atoms, a.tile_counts, a.long_only ? 32 : -1);
   }
 #define AA_FUSED_LAUNCH1(S0_, S1_, H_, T_)                                                                     \
   {                                                                                                            \

@@ -589,7 +589,8 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     // anchored program order (aa::anchor -- the kernel used to carry 70-350 spilled VGPRs) the 32-edge-tile form beats the
     // staged forward at every size on MI355X: 22-24 % of the step on 64-1000 atoms (one launch instead of seven), 9 % at
     // 4096, 4.5 % at 10 648, 0.5 % at 97 336 atoms, and it moves 2.1 instead of 7.3 KB/edge (profiles/r02_v23_fused_sweep.log).
-    // aa_plan_options.fused_forward: 0 / 1 = whenever the graph allows (max_degree <= 32), 3 = never (staged pipeline).
+    // aa_plan_options.fused_forward: 0 / 1 = whenever the graph allows (automatic), 3 = never (staged pipeline); A/B: 2 = also for every
+    // graph with segments <= 128, in the pure team form, 4 = the same in the mixed form.
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
                           u == 64 && S == 64 && T <= 3 && B == 8 && S0 == 64 && p->o_embtab != 0 && (!kFoldEmbed || p->o_embtab_h != 0) &&
                           (!kFoldLatent || p->o_lat1in_fq != 0) && (!kFoldEmb1 || p->o_g0fq != 0) && (!kProjMfma || p->o_wkq[0] != 0);
@@ -1792,6 +1793,13 @@ struct Runner {
     // which the host does not hold, equals g->num_edges)
     const int64_t n_active = g->atom_end > g->atom_begin ? g->atom_end - g->atom_begin : g->num_atoms;
     const int64_t tiles = n_active * (g->max_degree <= 64 ? 2 : 4);  // (upper bound: every atom at the class of the longest segment)
+    if (p->opt.fused_forward == 2 || p->opt.fused_forward == 4) return true;  // (A/B: the team / mixed form whenever segments fit it)
+    // Round 5: a box whose AVERAGE atom fills most of one tile but whose longest segment is a little over 32 (thermal disorder: a
+    // handful of Si atoms with 33..37 neighbours after 50 fs at 300 K) takes the MIXED form -- one-tile kernel over all atoms, the
+    // team kernel over the long ones only (launch_fused_fwd) -- instead of giving up the fused forward for the whole box
+    // (tools/md_loop.py at C4: staged 11.3 ms, team form for every atom 12.2 ms per step; profiles/r05_v2*_md_loop_*).
+    const double fill = double(g->num_edges) / (32.0 * double(std::max<int64_t>(n_active, 1)));
+    if (fill >= 0.6 && fill <= 1.15) return true;
     return tiles <= kFusedTeamTilesSmall || double(g->num_edges) >= 0.85 * 32.0 * double(tiles);
   }
   // the reverse tail in one launch (aa_fused_bwd.hip): same eligibility as the fused forward + the two-body table of the reverse
@@ -1919,6 +1927,7 @@ struct Runner {
       a.tile_counts = reinterpret_cast<int32_t*>(buf(w.tiles));
       a.tile_atoms = a.tile_counts + 8;
       a.tile_cap = g->num_atoms;
+      a.mixed = p->opt.fused_forward == 2 ? 0 : 1;  // (2: the team form for every atom, A/B)
     }
     a.num_types = c.num_types;
     a.embed_kind = c.embed_kind;

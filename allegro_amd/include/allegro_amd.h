@@ -243,7 +243,8 @@ typedef struct {
   int32_t gemm_lds_epilogue; /* LDS-transposed epilogue in the single-layer bf16x3 kernel                       */
   int32_t f64_column_loop; /* fp64 linear layers: 0 automatic, 1 never, 2 always walk all column tiles per workgroup */
   int32_t embed_no_fuse;   /* reverse pass: materialise d(two-body embedding)                                   */
-  int32_t fused_forward;   /* fused per-atom-tile forward: 0 / 1 whenever aa_graph.max_degree allows; 3 never (staged pipeline) */
+  int32_t fused_forward;   /* fused per-atom-tile forward: 0 / 1 whenever aa_graph.max_degree allows; 3 never (staged pipeline);
+                            * A/B: 2 / 4 = for every graph with segments <= 128 in the pure team / the mixed form */
   int32_t fused_recompute_w0; /* fused forward: recompute w0 for the second layer instead of holding it         */
   int32_t moments_waves_per_block; /* 0 = 1                                                                      */
   int32_t f64_rows;        /* fp64 linear layers, row-resident kernels (operand rows read once): 0 where measured faster, 1 wherever applicable, 2 off */

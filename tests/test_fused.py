@@ -139,11 +139,16 @@ def _mixed_degree_cluster(cut=2.2, per_class=(3, 3, 2, 1)):
     return pos, cell, ei[:, keep], shift[keep], rng.integers(0, 2, size=111), sorted(int(deg[i]) for i in pick)
 
 
-def _teams_case(lib, dev, monkeypatch, cut=2.2, per_class=(3, 3, 2, 1)):
+def _teams_case(lib, dev, monkeypatch, cut=2.2, per_class=(3, 3, 2, 1), form=None):
     """Segments of more than one 32-edge tile run the TEAM form of the fused forward (2 / 4 waves per atom, per-atom sums
     completed through LDS): against the fp64 oracle, against the staged pipeline on the same graph, bit-reproducible although
-    the slot assignment comes from atomic counters, and the launch list names the kernel."""
-    monkeypatch.delenv("AA_FUSED", raising=False)
+    the slot assignment comes from atomic counters, and the launch list names the kernel.  `form`: None = what the plan selects
+    (since round 5 the MIXED form: the one-tile kernel over all atoms skipping the long ones + the team kernel over the long ones
+    only), "2" = the team kernel for every atom, "4" = the mixed form forced."""
+    if form is None:
+        monkeypatch.delenv("AA_FUSED", raising=False)
+    else:
+        monkeypatch.setenv("AA_FUSED", form)
     pos, cell, ei, shift, types, degs = _mixed_degree_cluster(cut, per_class)
     assert degs[0] <= 32 and any(32 < d <= 64 for d in degs) and any(64 < d <= 128 for d in degs), degs
     cfg = _cfg(avg=float(np.mean(degs)), scale_shift=True)
@@ -174,8 +179,40 @@ def _teams_case(lib, dev, monkeypatch, cut=2.2, per_class=(3, 3, 2, 1)):
     assert (f1 - fs).abs().max().item() <= 2e-5 * max(1.0, float(fs.abs().max()))
 
 
-def test_segments_of_several_tiles_run_the_team_form_emulated(monkeypatch):
-    _teams_case(emu_lib(), torch.device("cpu"), monkeypatch)
+@pytest.mark.parametrize("form", [None, "2"])
+def test_segments_of_several_tiles_run_the_team_form_emulated(form, monkeypatch):
+    _teams_case(emu_lib(), torch.device("cpu"), monkeypatch, form=form)
+
+
+def test_mixed_and_team_forms_agree_bitwise_emulated(monkeypatch):
+    """The mixed form (one-tile kernel, long atoms skipped + team kernel over the long atoms only) and the team form for every atom
+    run the same per-tile arithmetic in the same order: energies and forces are bit-equal; a graph with a single long atom among
+    short ones (the MD case: thermal disorder) is selected for the mixed form by its fill."""
+    pos, cell, ei, shift, types, degs = _mixed_degree_cluster(2.2, (6, 1, 0, 0))
+    assert sum(d > 32 for d in degs) == 1
+    cfg = _cfg(avg=float(np.mean(degs)), scale_shift=True)
+    outs = []
+    for form in (None, "2", "0"):
+        if form is None:
+            monkeypatch.delenv("AA_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("AA_FUSED", form)
+        m = HipAllegroModel(**cfg)
+        m._bind_library(emu_lib())
+        if outs:
+            m.load_state_dict(outs[0][2])
+        g = m.prepare_graph(torch.tensor(ei), torch.tensor(types), pos.shape[0], torch.tensor(shift @ cell, dtype=torch.float32))
+        p = torch.tensor(pos, dtype=torch.float32)
+        e, f = (t.clone() for t in m.energy_forces(p, g))
+        m.check()
+        import bench
+
+        names = [s[0] for s in bench.profile_stages(m, p, g, reps=1)]
+        assert ("fused_fwd" in names) == (form != "0"), (form, names)
+        outs.append((e, f, m.state_dict()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert (outs[0][0] - outs[2][0]).abs().max().item() <= 2e-5 * max(1.0, float(outs[2][0].abs().max()))
+    assert (outs[0][1] - outs[2][1]).abs().max().item() <= 2e-5 * max(1.0, float(outs[2][1].abs().max()))
 
 
 @pytest.mark.gpu
@@ -185,8 +222,9 @@ def test_segments_of_several_tiles_run_the_team_form_on_gpu(cut, per_class, monk
 
 
 @pytest.mark.gpu
-def test_team_form_against_the_staged_pipeline_on_gpu(monkeypatch):
-    _teams_case(None, torch.device("cuda:0"), monkeypatch)
+@pytest.mark.parametrize("form", [None, "2"])
+def test_team_form_against_the_staged_pipeline_on_gpu(form, monkeypatch):
+    _teams_case(None, torch.device("cuda:0"), monkeypatch, form=form)
 
 
 def _teams_case_gpu(cut, per_class, monkeypatch):
