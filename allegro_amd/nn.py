@@ -425,7 +425,8 @@ class PreparedGraph:
                  rowptr: Optional[torch.Tensor] = None):
         center = edge_index[0]
         self.perm = None
-        if center.numel() > 1 and not bool((center[1:] >= center[:-1]).all()):
+        # (a list that comes with its row pointers -- the device neighbour list -- is center-sorted by construction: no check, no sync)
+        if rowptr is None and center.numel() > 1 and not bool((center[1:] >= center[:-1]).all()):
             self.perm = torch.argsort(center, stable=True)
             edge_index = edge_index[:, self.perm]
             if shift_vec is not None:
@@ -445,9 +446,11 @@ class PreparedGraph:
         # the per-atom kernels only visit it.  One host read at graph-preparation time, none per step.
         self.atom_begin = self.atom_end = self.max_degree = 0
         if self.num_edges > 0:
-            self.atom_begin, self.atom_end = int(self.center[0]), int(self.center[-1]) + 1
-            # largest edge segment: <= 32 selects the fused per-atom-tile kernels (one wave = one atom's MFMA tile)
-            self.max_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max())
+            # largest edge segment: <= 32 selects the fused per-atom-tile kernels (one wave = one atom's MFMA tile); ONE host read
+            # for the three hints (an MD loop prepares a graph per neighbour list)
+            deg_max = (self.rowptr[1:] - self.rowptr[:-1]).max().to(torch.int32)
+            first, last, dmax = torch.stack([self.center[0], self.center[-1], deg_max]).tolist()
+            self.atom_begin, self.atom_end, self.max_degree = int(first), int(last) + 1, int(dmax)
         # transposed CSR (edges grouped by neighbor): lets the library gather forces per atom in a fixed order
         # (bit-reproducible); without it neighbor contributions are accumulated with floating-point atomics
         self.t_perm = self.t_rowptr = None

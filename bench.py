@@ -361,6 +361,90 @@ def secondary_workload(name, dev, steps, warmup, cpu_edges):
     return rec
 
 
+KB_EV = 8.617333262e-5     # eV / K
+ACC_UNIT = 9.64853321e-3   # (eV / A / amu) in A / fs^2
+
+
+def md_loop(model, pos0, types, cell, r_cut, steps=50, warmup=10, dt=1.0, temperature=300.0, skin=0.0, mass=28.0855, force_scale=0.0,
+            cross_check=None, cross_every=0):
+    """NVE velocity-Verlet loop with EVERYTHING on the device -- neighbour list (`aa_nl_*`) + graph preparation every step (or a
+    Verlet list with `skin`), the hot path, the integrator -- so that "ns/day for the box" is measured as a loop and not derived
+    from the step time, and its energy conservation: E_pot + E_kin of the trajectory moves only by the O(dt^2) of the integrator
+    when the forces are the gradient of the energies (tools/md_loop.py: 4x smaller per halving of dt at C4).  The model has random
+    weights: energies and forces are scaled so that the rms force is 1 eV/A; its potential has no repulsive core, keep runs short
+    (~100 fs at 300 K).  Returns a dict; `ns_per_day` is wall-clock, `ns_per_day_at_median` from the median step."""
+    from allegro_amd.nn import neighbor_list
+
+    dev = pos0.device
+    N = pos0.shape[0]
+    pos = pos0.clone()
+    gen = torch.Generator(device=dev).manual_seed(7)
+    vel = torch.randn(N, 3, device=dev, generator=gen, dtype=pos.dtype) * (KB_EV * temperature / mass * ACC_UNIT) ** 0.5  # A / fs
+    vel -= vel.mean(0, keepdim=True)
+    state = {"graph": None, "pos_ref": None, "rebuilds": 0, "edges": 0, "max_degree": 0}
+
+    def graph_for(p):
+        if state["graph"] is None or skin == 0.0 or float((p - state["pos_ref"]).square().sum(1).max()) > (0.5 * skin) ** 2:
+            nl = neighbor_list(p, cell, True, r_cut + skin)
+            state["graph"] = nl.prepare(types)
+            state["pos_ref"] = p.clone()
+            state["rebuilds"] += 1
+            state["edges"] = nl.num_edges
+            state["max_degree"] = max(state["max_degree"], state["graph"].max_degree)
+        return state["graph"]
+
+    e_atom, f = model.energy_forces(pos, graph_for(pos))
+    scale = force_scale or 1.0 / float(f.square().sum(1).mean().sqrt())
+    f = f * scale
+
+    def kinetic(v):
+        return 0.5 * mass / ACC_UNIT * float(v.double().square().sum())
+
+    e0 = float(e_atom.double().sum()) * scale + kinetic(vel)
+    trace, cross, step_ms = [], [], []
+    half = 0.5 * dt * ACC_UNIT / mass
+    t0 = t_prev = 0.0
+    for step in range(-warmup, steps):
+        if step == 0:
+            torch.cuda.synchronize()
+            t0 = t_prev = time.perf_counter()
+        vel = vel + half * f
+        pos = pos + dt * vel
+        e_atom, f = model.energy_forces(pos, graph_for(pos))
+        f = f * scale
+        vel = vel + half * f
+        if step >= 0:
+            torch.cuda.synchronize()  # (per-step wall times: the median is the robust figure)
+            t_now = time.perf_counter()
+            step_ms.append((t_now - t_prev) * 1e3)
+            t_prev = t_now
+            if (step + 1) % max(1, steps // 20) == 0 or step + 1 == steps:
+                trace.append((step + 1, float(e_atom.double().sum()) * scale, kinetic(vel), float(f.square().sum(1).max().sqrt())))
+                t_prev = time.perf_counter()
+            if cross_check is not None and cross_every and (step + 1) % cross_every == 0:
+                e2, f2 = cross_check.energy_forces(pos, state["graph"])
+                de = e2.double() - e_atom.double()
+                cross.append(dict(step=step + 1, max_degree=state["graph"].max_degree, dE_total=float(de.sum()) * scale,
+                                  max_dE_atom=float(de.abs().max()) * scale, max_dF=float((f2 * scale - f).abs().max())))
+                t_prev = time.perf_counter()
+    torch.cuda.synchronize()
+    wall = sum(step_ms) * 1e-3
+    model.check()
+    ke = [t[2] for t in trace]
+    drift = max(abs(t[1] + t[2] - e0) for t in trace)
+    ke_mean = sum(ke) / len(ke)
+    med = sorted(step_ms)[len(step_ms) // 2]
+    return dict(atoms=N, edges_last_list=state["edges"], steps=steps, warmup=warmup, dt_fs=dt, temperature_K=temperature, skin_A=skin,
+                list_rebuilds=state["rebuilds"], max_degree_seen=state["max_degree"], force_scale=scale,
+                ms_per_md_step=wall / steps * 1e3, ns_per_day=dt * 1e-6 * steps / wall * 86400.0, ms_per_md_step_median=med,
+                ns_per_day_at_median=dt * 1e-6 / (med * 1e-3) * 86400.0,
+                slowest_steps=sorted(((round(t, 2), i + 1) for i, t in enumerate(step_ms)), reverse=True)[:4],
+                includes="device neighbour list + graph preparation (every rebuild), hot path, velocity-Verlet update",
+                e_total_start_eV=e0, max_abs_drift_eV=drift, mean_kinetic_eV=ke_mean, drift_over_mean_kinetic=drift / max(ke_mean, 1e-30),
+                cross_check_vs_staged=cross or None,
+                trace=[dict(step=s, e_pot=p, e_kin=k, e_tot=p + k, max_force=mf) for s, p, k, mf in trace])
+
+
 def gpu_reference_baseline(g: G.Graph, cfg, model, dev, target_edges=60000, reps=3):
     """North-star denominator: the reference-equivalent eager PyTorch-ROCm path (oracle/restatement.py moved
     to the GPU) on a bounded contiguous block of center atoms, in chunks of <=20k edges as BASELINE.md
@@ -596,6 +680,7 @@ def main():
                     help="seconds of additional back-to-back steps AFTER the timed region (reported as config.sustained): "
                          "long enough for an external sampler (rocm-smi every few seconds) to witness the GPU busy; 0 = off")
     ap.add_argument("--stages", action="store_true", help="also print every launch of one step with its HIP-event time")
+    ap.add_argument("--no-md", action="store_true", help="skip the short NVE loop (config.md_loop: measured ns/day incl. neighbour lists)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default C4 line only: skip the compact C3 / C5 records (`secondary`: ms/step, roofline fraction, parity sample)")
     ap.add_argument("--emulate-shard", default=None, metavar="R/W",
@@ -916,6 +1001,12 @@ def main():
             torch.cuda.synchronize()
             line["config"]["neighbor_list_device_ms"]["list"] = (time.perf_counter() - t1) * 1e3
             del nl_graph
+        if world == 1 and g is not None and g.cell is not None and WORKLOADS[args.workload]["kind"] == "si" and not args.no_md and not args.emulate_shard:
+            # the metric's "ns/day for the box" as a measured LOOP (never `value`): list + preparation + hot path + integrator, 40 steps
+            md = md_loop(model, pos, types, torch.tensor(g.cell, dtype=torch.float64), float(cfg["r_max"]), steps=40, warmup=5)
+            line["config"]["md_loop"] = {k: md[k] for k in ("steps", "dt_fs", "temperature_K", "list_rebuilds", "max_degree_seen", "ms_per_md_step",
+                                                            "ms_per_md_step_median", "ns_per_day", "includes", "max_abs_drift_eV",
+                                                            "mean_kinetic_eV", "drift_over_mean_kinetic")}
         parity_failed = False
         if world == 1 and not args.no_cpu_baseline and g is not None:
             # ~20 s of CPU work for the headline model; the l_max=3 fp64 stack is ~10x heavier per edge

@@ -79,6 +79,9 @@ case $CMD in
     bash $0 profile $TAG c4
     bash $0 profile $TAG c5
     for wl in c4 c5; do python tools/pmc_bound_table.py gpurun_out/${TAG}_rocprofv3_${wl}_summary.txt > gpurun_out/${TAG}_bound_table_${wl}.md; done
+    timeout 600 python tools/md_loop.py --workload c4 --steps 100 > gpurun_out/${TAG}_md_loop_c4.json 2> /dev/null
+    timeout 600 python tools/md_loop.py --workload c4 --steps 200 --dt 0.5 > gpurun_out/${TAG}_md_loop_c4_dt0.5.json 2> /dev/null
+    timeout 600 python tools/md_loop.py --workload c3 --steps 100 > gpurun_out/${TAG}_md_loop_c3.json 2> /dev/null
     timeout 600 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 > gpurun_out/${TAG}_train_step_c3.json 2> /dev/null
     AA_TRAIN_EAGER=1 timeout 600 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 --no-gpu-reference > gpurun_out/${TAG}_train_step_c3_eager.json 2> /dev/null
     timeout 900 python bench.py --mode train-step --workload c4 --steps 2 --warmup 1 --no-gpu-reference --train-chunk-edges 400000 > gpurun_out/${TAG}_train_step_c4_chunked.json 2> /dev/null
