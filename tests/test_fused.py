@@ -179,9 +179,10 @@ def _teams_case(lib, dev, monkeypatch, cut=2.2, per_class=(3, 3, 2, 1), form=Non
     assert (f1 - fs).abs().max().item() <= 2e-5 * max(1.0, float(fs.abs().max()))
 
 
-@pytest.mark.parametrize("form", [None, "2"])
-def test_segments_of_several_tiles_run_the_team_form_emulated(form, monkeypatch):
-    _teams_case(emu_lib(), torch.device("cpu"), monkeypatch, form=form)
+def test_segments_of_several_tiles_run_the_team_form_emulated(monkeypatch):
+    # (what the plan selects: the mixed form; the team kernel for every atom is compared bit by bit in the next test and runs
+    #  through this case on the GPU)
+    _teams_case(emu_lib(), torch.device("cpu"), monkeypatch, form=None)
 
 
 def test_mixed_and_team_forms_agree_bitwise_emulated(monkeypatch):
