@@ -210,7 +210,7 @@ def test_halo_exchange_of_ghost_rows_matches_reference(world, mode):
     assert sum(s[2] for s in stats) == sum(s[4] for s in stats) > 0  # every ghost row has exactly one owner that serves it
 
 
-@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("world", [3])
 def test_in_process_halo_group_matches_reference(world):
     """`InProcessHaloGroup` (all shards of a frame in one process: what the GPU suite's `tests/test_dist_device.py` drives at C3
     size with real kernels) against the golden vectors, through the emulated kernels: the shards' own pack / accumulate code
