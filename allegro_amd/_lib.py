@@ -150,6 +150,11 @@ class AllegroLib:
         L.aa_model_plan_enable_graph.restype = C.c_int
         L.aa_model_plan_enable_taps.argtypes = [C.c_void_p, C.c_int]
         L.aa_model_plan_enable_taps.restype = C.c_int
+        L.aa_graph_transpose_workspace_bytes.argtypes = [C.c_int64]
+        L.aa_graph_transpose_workspace_bytes.restype = C.c_size_t
+        L.aa_graph_transpose.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]
+        L.aa_graph_transpose.restype = C.c_int
         L.aa_graph_fingerprint.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.aa_graph_fingerprint.restype = C.c_int
         L.aa_model_file_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]

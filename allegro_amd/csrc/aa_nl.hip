@@ -319,6 +319,61 @@ int plan_nl(const aa_nl_input* in, void* ws, size_t ws_bytes, NlDev& d) {
   return AA_OK;
 }
 
+// ---- transposed CSR of a center-sorted edge list (edges grouped by NEIGHBOUR atom, ascending edge id inside a group = the stable
+// ---- argsort of nbr) and the three graph hints, without leaving the device: counting sort by atomics + a per-atom sort of the
+// ---- (short) groups, which makes the result independent of the order the atomics were served in
+__global__ __launch_bounds__(256) void gt_count_kernel(const int32_t* nbr, int64_t E, int* cnt) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (e < E) atomicAdd(&cnt[nbr[e]], 1);
+}
+__global__ __launch_bounds__(256) void gt_place_kernel(const int32_t* nbr, int64_t E, const int32_t* t_rowptr, int* cursor, int32_t* t_perm) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int j = nbr[e];
+  t_perm[t_rowptr[j] + atomicAdd(&cursor[j], 1)] = int32_t(e);
+}
+__global__ __launch_bounds__(256) void gt_sort_kernel(int64_t N, const int32_t* t_rowptr, int32_t* t_perm) {
+  const int64_t a = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (a >= N) return;
+  const int lo = t_rowptr[a], hi = t_rowptr[a + 1];
+  for (int q = lo + 1; q < hi; ++q) {  // insertion sort: groups are a few dozen entries and arrive nearly sorted
+    const int v = t_perm[q];
+    int r = q - 1;
+    while (r >= lo && t_perm[r] > v) {
+      t_perm[r + 1] = t_perm[r];
+      --r;
+    }
+    t_perm[r + 1] = v;
+  }
+}
+// hints[0..2] = first atom with edges, one past the last atom with edges, largest segment (0, 0, 0 without edges)
+__global__ __launch_bounds__(256) void gt_hints_kernel(int64_t N, const int32_t* rowptr, int32_t* hints) {
+  int* s = reinterpret_cast<int*>(aa_smem);  // [3][256]
+  int first = int(N), last = 0, dmax = 0;
+  for (int64_t a = threadIdx.x; a < N; a += 256) {
+    const int d = rowptr[a + 1] - rowptr[a];
+    if (d > 0) {
+      first = first < int(a) ? first : int(a);
+      last = int(a) + 1;
+      dmax = dmax > d ? dmax : d;
+    }
+  }
+  s[threadIdx.x] = first;
+  s[256 + threadIdx.x] = last;
+  s[512 + threadIdx.x] = dmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int t = 1; t < 256; ++t) {
+      first = first < s[t] ? first : s[t];
+      last = last > s[256 + t] ? last : s[256 + t];
+      dmax = dmax > s[512 + t] ? dmax : s[512 + t];
+    }
+    hints[0] = last > 0 ? first : 0;
+    hints[1] = last;
+    hints[2] = dmax;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t aa_nl_workspace_bytes(int64_t num_atoms) {
@@ -381,6 +436,35 @@ extern "C" int aa_nl_fill(const aa_nl_input* in, void* workspace, size_t workspa
 // content fingerprint of a neighbour list (aa_graph_fingerprint): lets a host that caches graph structure by tensor
 // IDENTITY (csrc/torch_ops.cpp) notice that the contents behind an unchanged tensor were rewritten through a raw pointer
 // ---------------------------------------------------------------------------------------------------------------------
+extern "C" size_t aa_graph_transpose_workspace_bytes(int64_t num_atoms) {
+  const size_t N = size_t(std::max<int64_t>(0, num_atoms));
+  return 2 * align_up(sizeof(int) * (N + 1)) + align_up(sizeof(int) * (N / kScanBlock + 2));
+}
+
+extern "C" int aa_graph_transpose(int64_t num_atoms, int64_t num_edges, const int32_t* rowptr, const int32_t* nbr, int32_t* t_rowptr,
+                                  int32_t* t_perm, int32_t* hints3, void* workspace, size_t workspace_bytes, aa_stream stream) {
+  AA_REQUIRE(num_atoms >= 0 && num_edges >= 0 && num_edges < (int64_t(1) << 31) && num_atoms < (int64_t(1) << 31), "aa_graph_transpose: size out of range");
+  AA_REQUIRE(t_rowptr && (num_edges == 0 || (nbr && t_perm)) && workspace, "aa_graph_transpose: null argument");
+  AA_REQUIRE(workspace_bytes >= aa_graph_transpose_workspace_bytes(num_atoms), "aa_graph_transpose: workspace too small");
+  AA_REQUIRE(!hints3 || rowptr, "aa_graph_transpose: the hints need the row pointers");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t N = num_atoms, E = num_edges;
+  char* w = static_cast<char*>(workspace);
+  int* cnt = reinterpret_cast<int*>(w);
+  int* cursor = reinterpret_cast<int*>(w + align_up(sizeof(int) * (N + 1)));
+  int* scan_tmp = reinterpret_cast<int*>(w + 2 * align_up(sizeof(int) * (N + 1)));
+  AA_CHECK_HIP(hipMemsetAsync(w, 0, 2 * align_up(sizeof(int) * (N + 1)), s));
+  if (E > 0) hipLaunchKernelGGL(gt_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, E, cnt);
+  launch_scan(cnt, t_rowptr, N, scan_tmp, s);
+  if (E > 0) {
+    hipLaunchKernelGGL(gt_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, E, t_rowptr, cursor, t_perm);
+    hipLaunchKernelGGL(gt_sort_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, t_rowptr, t_perm);
+  }
+  if (hints3) hipLaunchKernelGGL(gt_hints_kernel, dim3(1), dim3(256), 3 * 256 * sizeof(int), s, N, rowptr, hints3);
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
 namespace aa {
 namespace {
 __device__ __forceinline__ unsigned long long fp_mix(unsigned long long x) {  // splitmix64 finaliser

@@ -422,7 +422,7 @@ class PreparedGraph:
 
     def __init__(self, edge_index: torch.Tensor, atom_types: torch.Tensor, num_atoms: int,
                  shift_vec: Optional[torch.Tensor] = None, transposed: bool = True,
-                 rowptr: Optional[torch.Tensor] = None):
+                 rowptr: Optional[torch.Tensor] = None, lib: Optional[_lib.AllegroLib] = None):
         center = edge_index[0]
         self.perm = None
         # (a list that comes with its row pointers -- the device neighbour list -- is center-sorted by construction: no check, no sync)
@@ -445,15 +445,33 @@ class PreparedGraph:
         # block of center atoms that have edges (the owned block of an atom-block partition, allegro_amd/dist.py):
         # the per-atom kernels only visit it.  One host read at graph-preparation time, none per step.
         self.atom_begin = self.atom_end = self.max_degree = 0
-        if self.num_edges > 0:
-            # largest edge segment: <= 32 selects the fused per-atom-tile kernels (one wave = one atom's MFMA tile); ONE host read
-            # for the three hints (an MD loop prepares a graph per neighbour list)
-            deg_max = (self.rowptr[1:] - self.rowptr[:-1]).max().to(torch.int32)
-            first, last, dmax = torch.stack([self.center[0], self.center[-1], deg_max]).tolist()
-            self.atom_begin, self.atom_end, self.max_degree = int(first), int(last) + 1, int(dmax)
         # transposed CSR (edges grouped by neighbor): lets the library gather forces per atom in a fixed order
         # (bit-reproducible); without it neighbor contributions are accumulated with floating-point atomics
         self.t_perm = self.t_rowptr = None
+        if lib is None and edge_index.is_cuda:
+            lib = _lib.load()
+        if transposed and lib is not None and (edge_index.is_cuda or lib.is_emulation):
+            # one library call per neighbour list (`aa_graph_transpose`: counting sort + per-atom group sort + the three hints) and
+            # ONE host read, instead of argsort / bincount / cumsum / max through a dozen tensor operations: an MD loop prepares a
+            # graph per list (0.28 -> ~0.1 ms; profiles/r05_*_md_loop_c3.json)
+            dev = edge_index.device
+            self.t_rowptr = torch.empty(num_atoms + 1, dtype=torch.int32, device=dev)
+            self.t_perm = torch.empty(self.num_edges, dtype=torch.int32, device=dev)
+            hints = torch.empty(3, dtype=torch.int32, device=dev)
+            nbytes = lib.lib.aa_graph_transpose_workspace_bytes(num_atoms)
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            with _device_ctx(dev):
+                lib.check(lib.lib.aa_graph_transpose(num_atoms, self.num_edges, self.rowptr.data_ptr(), self.nbr.data_ptr(), self.t_rowptr.data_ptr(),
+                                                     self.t_perm.data_ptr() if self.num_edges else None, hints.data_ptr(), ws.data_ptr(), nbytes,
+                                                     _stream_ptr(edge_index)), "aa_graph_transpose")
+            self.atom_begin, self.atom_end, self.max_degree = (int(v) for v in hints.tolist())
+            return
+        if self.num_edges > 0:
+            # largest edge segment: <= 32 selects the fused per-atom-tile kernels (one wave = one atom's MFMA tile); ONE host read
+            # for the three hints
+            deg_max = (self.rowptr[1:] - self.rowptr[:-1]).max().to(torch.int32)
+            first, last, dmax = torch.stack([self.center[0], self.center[-1], deg_max]).tolist()
+            self.atom_begin, self.atom_end, self.max_degree = int(first), int(last) + 1, int(dmax)
         if transposed:
             self.t_perm = torch.argsort(edge_index[1], stable=True).to(torch.int32).contiguous()
             self.t_rowptr = torch.zeros(num_atoms + 1, dtype=torch.int32, device=edge_index.device)
@@ -471,8 +489,8 @@ class PreparedGraph:
 class DeviceNeighborList:
     """Result of `neighbor_list`: center-sorted edges on the device (`aa_nl_count` / `aa_nl_fill`)."""
 
-    def __init__(self, edge_index, rowptr, cell_shift, shift_vec):
-        self.edge_index, self.rowptr, self.cell_shift, self.shift_vec = edge_index, rowptr, cell_shift, shift_vec
+    def __init__(self, edge_index, rowptr, cell_shift, shift_vec, lib=None):
+        self.edge_index, self.rowptr, self.cell_shift, self.shift_vec, self._lib = edge_index, rowptr, cell_shift, shift_vec, lib
 
     @property
     def num_edges(self) -> int:
@@ -480,7 +498,7 @@ class DeviceNeighborList:
 
     def prepare(self, atom_types: torch.Tensor, transposed: bool = True) -> PreparedGraph:
         return PreparedGraph(self.edge_index, atom_types, self.rowptr.numel() - 1, self.shift_vec, transposed=transposed,
-                             rowptr=self.rowptr)
+                             rowptr=self.rowptr, lib=self._lib)
 
     def ghost_layout(self, pos: torch.Tensor, atom_types: torch.Tensor):
         """The same list in the ghost-atom layout of the reference's `pair_allegro` contract (allegro/_compile.py:28-63),
@@ -532,7 +550,7 @@ def neighbor_list(pos: torch.Tensor, cell, pbc, r_cut: float, lib: Optional[_lib
         lib.check(lib.lib.aa_nl_fill(C.byref(inp), ws.data_ptr(), nbytes, rowptr.data_ptr(), edge_index[0].data_ptr(),
                                      edge_index[1].data_ptr(), cell_shift.data_ptr(), shift_vec.data_ptr(), stream),
                   "aa_nl_fill")
-    return DeviceNeighborList(edge_index, rowptr, cell_shift, shift_vec)
+    return DeviceNeighborList(edge_index, rowptr, cell_shift, shift_vec, lib)
 
 
 class HipAllegroModel(torch.nn.Module):
@@ -919,7 +937,7 @@ class HipAllegroModel(torch.nn.Module):
 
     # -- evaluation -----------------------------------------------------------------------------
     def prepare_graph(self, edge_index, atom_types, num_atoms, shift_vec=None) -> PreparedGraph:
-        return PreparedGraph(edge_index, atom_types, num_atoms, shift_vec)
+        return PreparedGraph(edge_index, atom_types, num_atoms, shift_vec, lib=self._bound_lib)
 
     def energy_forces(self, pos: torch.Tensor, graph: PreparedGraph, with_forces: bool = True):
         """One pass of the hot path: returns (atom_energy [N], forces [N,3] | None)."""

@@ -130,6 +130,38 @@ int main(int argc, char** argv) {
     fprintf(stderr, "device allocation failed\n");
     return 2;
   }
+  /* ---- the same transposed CSR and the graph hints from the library, on the device (what a host without a sort of its own calls once
+   *      per neighbour list): must equal the host's counting sort entry by entry */
+  {
+    const size_t tb = aa_graph_transpose_workspace_bytes(N);
+    void *d_tws = NULL, *d_trow2 = NULL, *d_tperm2 = NULL, *d_hints = NULL;
+    CHECK_HIP(hipMalloc(&d_tws, tb ? tb : 4));
+    CHECK_HIP(hipMalloc(&d_trow2, sizeof(int32_t) * ((size_t)N + 1)));
+    CHECK_HIP(hipMalloc(&d_tperm2, sizeof(int32_t) * (size_t)(E ? E : 1)));
+    CHECK_HIP(hipMalloc(&d_hints, sizeof(int32_t) * 3));
+    CHECK_AA(aa_graph_transpose(N, E, (const int32_t*)d_rowptr, (const int32_t*)d_nbr, (int32_t*)d_trow2, (int32_t*)d_tperm2, (int32_t*)d_hints,
+                                d_tws, tb, stream));
+    int32_t* trow2 = (int32_t*)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    int32_t* tperm2 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(E ? E : 1));
+    int32_t hints[3];
+    CHECK_HIP(hipStreamSynchronize(stream));
+    CHECK_HIP(hipMemcpy(trow2, d_trow2, sizeof(int32_t) * ((size_t)N + 1), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(tperm2, d_tperm2, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(hints, d_hints, sizeof hints, hipMemcpyDeviceToHost));
+    if (memcmp(trow2, trow, sizeof(int32_t) * ((size_t)N + 1)) != 0 || memcmp(tperm2, tperm, sizeof(int32_t) * (size_t)E) != 0 ||
+        hints[2] != (int32_t)max_degree) {
+      fprintf(stderr, "aa_graph_transpose disagrees with the host's counting sort (max_degree %d vs %d)\n", (int)hints[2], (int)max_degree);
+      return 1;
+    }
+    printf("host_c99: aa_graph_transpose == host counting sort (%lld edges), hints [%d, %d) max_degree %d\n", (long long)E, (int)hints[0],
+           (int)hints[1], (int)hints[2]);
+    free(trow2);
+    free(tperm2);
+    CHECK_HIP(hipFree(d_tws));
+    CHECK_HIP(hipFree(d_trow2));
+    CHECK_HIP(hipFree(d_tperm2));
+    CHECK_HIP(hipFree(d_hints));
+  }
   aa_graph g;
   memset(&g, 0, sizeof g);
   g.num_atoms = N;

@@ -240,3 +240,51 @@ def test_graph_fingerprint_is_position_dependent_and_reproducible_emulated():
     assert fp(ei, t2)[1] != base[1] and fp(ei, t2)[0] == base[0]
     assert fp(ei, types.to(torch.int32)) == base  # same values, other integer width
     assert fp(ei[:, :0], types[:0]) == (0, 0)
+
+
+def _transpose_case(lib, dev):
+    """`aa_graph_transpose` (counting sort by atomics + per-atom group sort + the three graph hints on the device) equals the stable
+    argsort / bincount / cumsum construction entry by entry, on ragged lists with empty atoms at both ends, repeated pairs and
+    no edges at all; `PreparedGraph` takes it whenever a library is at hand."""
+    import numpy as np
+
+    from allegro_amd.nn import PreparedGraph
+
+    rng = np.random.default_rng(12)
+    for n, e, lo, hi in ((50, 700, 5, 45), (7, 0, 0, 7), (300, 9000, 0, 300), (3, 40, 1, 2)):
+        center = np.sort(rng.integers(lo, max(hi, lo + 1), size=e)) if e else np.zeros(0, dtype=np.int64)
+        nbr = rng.integers(0, n, size=e)
+        ei = torch.tensor(np.stack([center, nbr]), dtype=torch.int64, device=dev)
+        types = torch.zeros(n, dtype=torch.int64, device=dev)
+        a = PreparedGraph(ei, types, n, None, lib=lib)
+        assert a.t_perm.dtype == torch.int32 and a.t_rowptr.dtype == torch.int32
+        want_perm = torch.argsort(ei[1], stable=True).to(torch.int32)
+        want_row = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        want_row[1:] = torch.cumsum(torch.bincount(ei[1], minlength=n), 0).to(torch.int32)
+        assert torch.equal(a.t_perm, want_perm) and torch.equal(a.t_rowptr, want_row), (n, e)
+        deg = np.bincount(center, minlength=n) if e else np.zeros(n, dtype=np.int64)
+        if e:
+            assert (a.atom_begin, a.atom_end, a.max_degree) == (int(center[0]), int(center[-1]) + 1, int(deg.max()))
+        else:
+            assert (a.atom_begin, a.atom_end, a.max_degree) == (0, 0, 0)
+
+
+def test_graph_transpose_matches_stable_argsort_emulated():
+    from tests.hip_utils import emu_lib
+
+    _transpose_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_graph_transpose_matches_stable_argsort_on_gpu():
+    _transpose_case(None, torch.device("cuda:0"))
+    # C4-sized list: 97 336 atoms, 2.7e6 edges, against the tensor-operation construction
+    import bench
+    from allegro_amd.nn import neighbor_list
+
+    g, cfg = bench.make_workload("c3")
+    dev = torch.device("cuda:0")
+    nl = neighbor_list(torch.tensor(g.pos, dtype=torch.float32, device=dev), torch.tensor(g.cell), True, 5.0)
+    pg = nl.prepare(torch.zeros(g.num_atoms, dtype=torch.int64, device=dev))
+    assert torch.equal(pg.t_perm, torch.argsort(nl.edge_index[1].long(), stable=True).to(torch.int32))
+    assert pg.max_degree == int((nl.rowptr[1:] - nl.rowptr[:-1]).max())
