@@ -332,19 +332,51 @@ __global__ __launch_bounds__(256) void gt_place_kernel(const int32_t* nbr, int64
   const int j = nbr[e];
   t_perm[t_rowptr[j] + atomicAdd(&cursor[j], 1)] = int32_t(e);
 }
+// one wave per atom: every entry's final position is its RANK inside the group (edge ids are distinct), counted with wave shuffles
+// from registers -- no data-dependent loop over memory, whatever order the atomics left the group in (groups of more than 256
+// entries: one lane sorts in place)
 __global__ __launch_bounds__(256) void gt_sort_kernel(int64_t N, const int32_t* t_rowptr, int32_t* t_perm) {
-  const int64_t a = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t a = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (a >= N) return;
-  const int lo = t_rowptr[a], hi = t_rowptr[a + 1];
-  for (int q = lo + 1; q < hi; ++q) {  // insertion sort: groups are a few dozen entries and arrive nearly sorted
-    const int v = t_perm[q];
-    int r = q - 1;
-    while (r >= lo && t_perm[r] > v) {
-      t_perm[r + 1] = t_perm[r];
-      --r;
+  const int lo = __builtin_amdgcn_readfirstlane(t_rowptr[a]), d = __builtin_amdgcn_readfirstlane(t_rowptr[a + 1]) - lo;
+  if (d <= 1) return;
+  if (d > 256) {
+    if (lane == 0) {
+      for (int q = lo + 1; q < lo + d; ++q) {
+        const int v = t_perm[q];
+        int r = q - 1;
+        while (r >= lo && t_perm[r] > v) {
+          t_perm[r + 1] = t_perm[r];
+          --r;
+        }
+        t_perm[r + 1] = v;
+      }
     }
-    t_perm[r + 1] = v;
+    return;
   }
+  int x[4], rank[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = lane + 64 * k;
+    x[k] = idx < d ? t_perm[lo + idx] : 0x7fffffff;
+    rank[k] = 0;
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    if (64 * kk < d) {  // (wave-uniform)
+      const int n = d - 64 * kk < 64 ? d - 64 * kk : 64;
+      for (int m = 0; m < n; ++m) {
+        const int y = __shfl(x[kk], m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rank[k] += y < x[k] ? 1 : 0;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // (every entry is in a register before the first one is written back)
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (lane + 64 * k < d) t_perm[lo + rank[k]] = x[k];
 }
 // hints[0..2] = first atom with edges, one past the last atom with edges, largest segment (0, 0, 0 without edges)
 __global__ __launch_bounds__(256) void gt_hints_kernel(int64_t N, const int32_t* rowptr, int32_t* hints) {
@@ -458,7 +490,7 @@ extern "C" int aa_graph_transpose(int64_t num_atoms, int64_t num_edges, const in
   launch_scan(cnt, t_rowptr, N, scan_tmp, s);
   if (E > 0) {
     hipLaunchKernelGGL(gt_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, E, t_rowptr, cursor, t_perm);
-    hipLaunchKernelGGL(gt_sort_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, t_rowptr, t_perm);
+    hipLaunchKernelGGL(gt_sort_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, N, t_rowptr, t_perm);
   }
   if (hints3) hipLaunchKernelGGL(gt_hints_kernel, dim3(1), dim3(256), 3 * 256 * sizeof(int), s, N, rowptr, hints3);
   AA_CHECK_HIP(hipGetLastError());

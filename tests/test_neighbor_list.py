@@ -251,7 +251,7 @@ def _transpose_case(lib, dev):
     from allegro_amd.nn import PreparedGraph
 
     rng = np.random.default_rng(12)
-    for n, e, lo, hi in ((50, 700, 5, 45), (7, 0, 0, 7), (300, 9000, 0, 300), (3, 40, 1, 2)):
+    for n, e, lo, hi in ((50, 700, 5, 45), (7, 0, 0, 7), (300, 9000, 0, 300), (3, 40, 1, 2), (5, 1500, 0, 5), (40, 6000, 0, 40)):
         center = np.sort(rng.integers(lo, max(hi, lo + 1), size=e)) if e else np.zeros(0, dtype=np.int64)
         nbr = rng.integers(0, n, size=e)
         ei = torch.tensor(np.stack([center, nbr]), dtype=torch.int64, device=dev)
