@@ -162,3 +162,47 @@ def test_two_ranks_on_one_device_through_energy_forces_halo():
     print(f"2 ranks on cuda:0 (gloo, host-staged rows): max|dE_i|={de:.2e} max|dF|={df:.2e} vs golden; (ghosts, sent) {stats}")
     assert de < 5e-5 and df < 5e-5
     assert sum(s[0] for s in stats) == sum(s[1] for s in stats) > 0
+
+
+def test_halo_shards_with_long_segments_take_the_mixed_forward_and_match():
+    """A disordered box (jitter 0.4 A: a few atoms with more than 32 neighbours, most with fewer) runs the MIXED form of the fused
+    forward (one-tile kernel over all atoms + team kernel over the long ones) -- in the whole box and in every shard, where the owned
+    block is a prefix of the local atoms and the per-atom kernels carry the atom-block hint.  Shards = the one-GPU step = the staged
+    pipeline."""
+    import bench
+    from allegro_amd import graph as G
+    from allegro_amd.dist import InProcessHaloGroup
+    from allegro_amd.nn import HipAllegroModel, PreparedGraph
+
+    dev = torch.device("cuda:0")
+    g = G.make_si_graph(8, r_cut=5.0, jitter=0.4, seed=4)  # 3 of 4096 atoms with 33 neighbours, the rest 18..32
+    cfg = bench.si_model_cfg(g.num_edges / g.num_atoms)
+    cfg["model_dtype"] = "float32"
+    model = HipAllegroModel(**cfg).to(dev)
+    pos = torch.tensor(g.pos, dtype=torch.float32, device=dev)
+    types = torch.tensor(g.types, device=dev)
+    graph = PreparedGraph(torch.tensor(g.edge_index, device=dev), types, g.num_atoms, torch.tensor(g.shift_vec(), dtype=torch.float32, device=dev))
+    assert 32 < graph.max_degree <= 128 and 0.6 <= g.num_edges / (32.0 * g.num_atoms) <= 1.15
+    names = [s[0] for s in bench.profile_stages(model, pos, graph, reps=1)]
+    assert "fused_fwd" in names, names
+    e_full, f_full = (t.clone() for t in model.energy_forces(pos, graph))
+    model.check()
+    os.environ["AA_FUSED"] = "0"
+    try:
+        staged = HipAllegroModel(**cfg).to(dev)
+        staged.load_state_dict(model.state_dict())
+        e_st, f_st = staged.energy_forces(pos, graph)
+    finally:
+        os.environ.pop("AA_FUSED")
+    assert (e_full - e_st).abs().max().item() <= 2e-5 * max(1.0, float(e_st.abs().max())) and (f_full - f_st).abs().max().item() <= 2e-5 * max(1.0, float(f_st.abs().max()))
+    grp = InProcessHaloGroup.from_positions(pos, types, g.cell, cfg["r_max"], 2)
+    assert any(s.graph.max_degree > 32 for s in grp.shards)
+    res = grp.step(model, [pos[s.owned_ids()] for s in grp.shards])
+    model.check()
+    e_all, f_all = torch.empty_like(e_full), torch.empty_like(f_full)
+    for s, (e, f) in zip(grp.shards, res):
+        e_all[s.owned_ids()] = e
+        f_all[s.owned_ids()] = f
+    dE, dF = float((e_all - e_full).abs().max()), float((f_all - f_full).abs().max())
+    print(f"disordered Si (max degree {graph.max_degree}): shards vs whole box max|dE_i|={dE:.2e} max|dF|={dF:.2e}")
+    assert dE <= 5e-5 * max(1.0, float(e_full.abs().max())) and dF <= 2e-5 * max(1.0, float(f_full.abs().max()))
