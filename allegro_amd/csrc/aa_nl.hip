@@ -322,15 +322,20 @@ int plan_nl(const aa_nl_input* in, void* ws, size_t ws_bytes, NlDev& d) {
 // ---- transposed CSR of a center-sorted edge list (edges grouped by NEIGHBOUR atom, ascending edge id inside a group = the stable
 // ---- argsort of nbr) and the three graph hints, without leaving the device: counting sort by atomics + a per-atom sort of the
 // ---- (short) groups, which makes the result independent of the order the atomics were served in
-__global__ __launch_bounds__(256) void gt_count_kernel(const int32_t* nbr, int64_t E, int* cnt) {
-  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (e < E) atomicAdd(&cnt[nbr[e]], 1);
-}
-__global__ __launch_bounds__(256) void gt_place_kernel(const int32_t* nbr, int64_t E, const int32_t* t_rowptr, int* cursor, int32_t* t_perm) {
+// (a neighbour id outside [0, N) -- a malformed list -- is skipped by both passes alike: its edge appears in no group, nothing is
+//  written out of bounds; the step itself reads pos[nbr] and is the caller's to keep valid)
+__global__ __launch_bounds__(256) void gt_count_kernel(const int32_t* nbr, int64_t E, int64_t N, int* cnt) {
   const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (e >= E) return;
   const int j = nbr[e];
-  t_perm[t_rowptr[j] + atomicAdd(&cursor[j], 1)] = int32_t(e);
+  if (j >= 0 && j < N) atomicAdd(&cnt[j], 1);
+}
+__global__ __launch_bounds__(256) void gt_place_kernel(const int32_t* nbr, int64_t E, int64_t N, const int32_t* t_rowptr, int* cursor,
+                                                       int32_t* t_perm) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int j = nbr[e];
+  if (j >= 0 && j < N) t_perm[t_rowptr[j] + atomicAdd(&cursor[j], 1)] = int32_t(e);
 }
 // one wave per atom: every entry's final position is its RANK inside the group (edge ids are distinct), counted with wave shuffles
 // from registers -- no data-dependent loop over memory, whatever order the atomics left the group in (groups of more than 256
@@ -486,10 +491,10 @@ extern "C" int aa_graph_transpose(int64_t num_atoms, int64_t num_edges, const in
   int* cursor = reinterpret_cast<int*>(w + align_up(sizeof(int) * (N + 1)));
   int* scan_tmp = reinterpret_cast<int*>(w + 2 * align_up(sizeof(int) * (N + 1)));
   AA_CHECK_HIP(hipMemsetAsync(w, 0, 2 * align_up(sizeof(int) * (N + 1)), s));
-  if (E > 0) hipLaunchKernelGGL(gt_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, E, cnt);
+  if (E > 0) hipLaunchKernelGGL(gt_count_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, E, N, cnt);
   launch_scan(cnt, t_rowptr, N, scan_tmp, s);
   if (E > 0) {
-    hipLaunchKernelGGL(gt_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, E, t_rowptr, cursor, t_perm);
+    hipLaunchKernelGGL(gt_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, nbr, E, N, t_rowptr, cursor, t_perm);
     hipLaunchKernelGGL(gt_sort_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, N, t_rowptr, t_perm);
   }
   if (hints3) hipLaunchKernelGGL(gt_hints_kernel, dim3(1), dim3(256), 3 * 256 * sizeof(int), s, N, rowptr, hints3);
