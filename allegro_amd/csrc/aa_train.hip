@@ -178,36 +178,17 @@ __device__ __forceinline__ int irrep_of(int i) { return i < 1 ? 0 : (i < 4 ? 1 :
 // One workgroup = 4 consecutive edges; rows of u * D elements are walked with compile-time D (no 64-bit divisions per element)
 template <typename T, int D>
 __global__ __launch_bounds__(256) void wc_forward_kernel(int64_t E, int u, int R, const T* sh, const T* w, T* out) {
-  constexpr int VW = 16 / sizeof(T);  // elements per 16-byte store
-  typedef T vec_t __attribute__((ext_vector_type(VW)));
+  // (write-bound: 2.15 TB/s of stores at C3 size; a 16-byte-store variant measured the same 319 us, tools/wc_probe.py)
   const int row = u * D;
-  const bool vec = (row % VW) == 0 && (reinterpret_cast<uintptr_t>(out) % 16) == 0;
   for (int q = 0; q < 4; ++q) {
     const int64_t e = int64_t(blockIdx.x) * 4 + q;
     if (e >= E) return;
+    const T* y = sh + e * D;
     const T* wr = w + e * int64_t(u) * R;
     T* o = out + e * int64_t(row);
-    T y[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) y[i] = sh[e * D + i];  // (wave-uniform addresses: scalar loads)
-    if (vec) {
-      for (int t = threadIdx.x; t < row / VW; t += 256) {
-        vec_t v;
-#pragma unroll
-        for (int k = 0; k < VW; ++k) {
-          const int idx = t * VW + k, c = idx / D, i = idx - c * D;
-          T yi = y[0];
-#pragma unroll
-          for (int m = 1; m < D; ++m) yi = i == m ? y[m] : yi;  // (register select: no dynamic indexing into y)
-          v[k] = yi * wr[c * R + (R == 1 ? 0 : irrep_of(i))];
-        }
-        *reinterpret_cast<vec_t*>(o + t * VW) = v;
-      }
-    } else {
-      for (int t = threadIdx.x; t < row; t += 256) {
-        const int c = t / D, i = t - c * D;
-        o[t] = sh[e * D + i] * wr[c * R + (R == 1 ? 0 : irrep_of(i))];
-      }
+    for (int t = threadIdx.x; t < row; t += 256) {
+      const int c = t / D, i = t - c * D;
+      o[t] = y[i] * wr[c * R + (R == 1 ? 0 : irrep_of(i))];
     }
   }
 }
