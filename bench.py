@@ -180,7 +180,7 @@ _F64_GEMM_KEYS = ("gemm_f64_rows_kernel<false>", "gemm_f64_rows_kernel<true>", "
 _SYMBOLS_F64 = (("gemm_", _F64_GEMM_GROUP),)
 
 
-def roofline_from_stages(stages, dtype, workload="c4"):
+def roofline_from_stages(stages, dtype, workload="c4", attach_traffic=True):
     """Aggregate the per-launch HIP-event times per kernel symbol and report the dominant symbol against its
     roofline.  Algorithmic work per launch comes from the library: every distinct operand
     row read or written once; 2*M*K*N flop per GEMM layer.  All kernels of this path are HBM-bound at their
@@ -220,6 +220,8 @@ def roofline_from_stages(stages, dtype, workload="c4"):
     # committed measurement of this workload is attached with its provenance
     # (attached only when the measurement was taken on THESE kernel sources: the JSON carries allegro_amd.build.source_hash())
     try:
+        if not attach_traffic:  # (a rank's shard of the box: the committed per-launch counters are the whole box's)
+            raise KeyError("shard")
         from allegro_amd.build import source_hash
 
         pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_traffic_{workload}.json")))
@@ -243,7 +245,8 @@ def roofline_from_stages(stages, dtype, workload="c4"):
             roof["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, mean per launch, {pj['source']} "
                                       f"(kernel sources {want})")
     except (OSError, ValueError, KeyError) as ex:
-        roof["traffic_source"] = f"traffic: null -- no committed PMC measurement for this workload ({type(ex).__name__})"
+        roof["traffic_source"] = ("traffic: null -- a shard of the box (the committed per-launch counters are the whole box's)" if not attach_traffic else
+                                  f"traffic: null -- no committed PMC measurement for this workload ({type(ex).__name__})")
     if d["flops"] > 0:
         roof["fp32_equiv_TFLOPs"] = d["flops"] / n / t / 1e12
         roof["mfma_bf16_TFLOPs"] = (6.0 if dtype == "float32" else 1.0) * d["flops"] / n / t / 1e12
@@ -954,7 +957,7 @@ def main():
             line["config"]["sustained"] = sustained
         if not args.no_profile:
             stages = profile_stages(model, pos if shard is None else (pos_local if halo else pos.index_select(0, shard.local_ids)), graph)
-            roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload)
+            roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload, attach_traffic=shard is None)
             if roof.get("kernel", "").startswith("fused_fwd"):
                 # `achieved` prices the REFERENCE's linear-layer flops; the kernel executes fewer since the round-4 folds
                 # (DESIGN.md section 3.2): both are stated so that `frac` is not read as matrix-pipe utilisation
