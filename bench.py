@@ -718,14 +718,20 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    # (AA_BENCH_BACKEND=gloo AA_BENCH_DEVICE=0: the N > 1 code path with all ranks on ONE device and host-staged rows -- how the
+    #  launch line of the driver's scaling run is exercised end to end on a one-GPU box; RCCL refuses two ranks on one GPU)
+    backend = os.environ.get("AA_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", int(os.environ.get("AA_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     halo = (world > 1 or args.emulate_shard or args.shard_sweep) and args.dist_mode == "halo" and WORKLOADS[args.workload]["kind"] == "si"
     shard = None
