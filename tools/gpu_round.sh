@@ -85,6 +85,13 @@ case $CMD in
     timeout 600 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 > gpurun_out/${TAG}_train_step_c3.json 2> /dev/null
     AA_TRAIN_EAGER=1 timeout 600 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 --no-gpu-reference > gpurun_out/${TAG}_train_step_c3_eager.json 2> /dev/null
     timeout 900 python bench.py --mode train-step --workload c4 --steps 2 --warmup 1 --no-gpu-reference --train-chunk-edges 400000 > gpurun_out/${TAG}_train_step_c4_chunked.json 2> /dev/null
-    grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_train_step_c3.json gpurun_out/${TAG}_train_step_c3_eager.json gpurun_out/${TAG}_train_step_c4_chunked.json ;;
+    grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_train_step_c3.json gpurun_out/${TAG}_train_step_c3_eager.json gpurun_out/${TAG}_train_step_c4_chunked.json
+    # the driver's N > 1 launch line on this one-GPU box: N ranks share cuda:0, rows staged through the host (gloo) -- exercises bench.py's
+    # sharded branch end to end (rendezvous, slab shards, both exchanges, barrier + max-over-ranks clock); its ms/step is N shards on ONE GPU
+    for N in 2 8; do
+      AA_BENCH_BACKEND=gloo AA_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
+        --master-port 2951$N bench.py --gpus $N --steps 5 --warmup 2 --sustain 0 2> /dev/null | grep '^{' | head -1 > gpurun_out/${TAG}_bench_launch_line_x$N.json
+      echo "launch line N=$N $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_bench_launch_line_x$N.json | head -1)"
+    done ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
 esac
