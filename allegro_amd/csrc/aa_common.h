@@ -406,6 +406,9 @@ int tp_wgrad_slots(int64_t N, int cap);
 constexpr int kDenseWgradSlots = 8192;  // one wave per slot and 64-channel slice: enough waves to fill the chip at 10^5 atoms
 template <typename T>
 int launch_tp_wgrad_reduce(const void* partial, int nslots, int u, int P, int coupling, void* gw, hipStream_t stream);
+// dst[m] = sum over rows of slabs[row][m], fixed order, two launches; OVERWRITES rows of `slabs` with chunk sums (aa_tp.hip)
+template <typename T>
+int launch_column_sum(T* slabs, int rows, int64_t M, T* dst, hipStream_t stream);
 
 int build_tp_layer(const aa_tp_desc& d, TpLayerDev* out, std::vector<void*>* owned);
 

@@ -340,24 +340,54 @@ __global__ __launch_bounds__(kWgThreads) void tp_layer_wgrad_kernel(TpLayerDev L
   }
 }
 
-// sum of the slot slabs, deterministic: thread (o, g) of a workgroup adds the slabs g, g + 16, g + 32, ... of output o in that
-// order, the 16 group sums are then added in group order.  64 outputs x 16 groups per workgroup.
+// Sum of the rows of a [rows, M] slab array, deterministic (the order depends on rows and M only) and parallel along BOTH axes: the
+// first launch adds the rows in chunks of 64 (workgroup (x, y): columns 64 x .. 64 x + 63 of the rows 64 y .. 64 y + 63; thread
+// (column, q) rows q, q + 4, ... with four independent partial sums so that sixteen loads are in flight per thread, combined
+// ((a0 + a1) + (a2 + a3)), the four q through LDS in order) and leaves each chunk's sum IN the chunk's first row -- nobody else reads
+// that row; the second launch adds the chunk sums the same way.  (The round-4 form walked all rows of 64 columns in one workgroup:
+// 11 workgroups x 512 dependent loads for a path-weight gradient at 10^4 atoms, 183 us for 23 MB.)
 template <typename T>
-__global__ __launch_bounds__(1024) void tp_layer_wgrad_reduce_kernel(const T* __restrict__ partial, int nslots, int nout, T* __restrict__ dst) {
-  T* sG = reinterpret_cast<T*>(aa_smem);  // [16][64]
-  const int o = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-  T v = T(0);
-  if (o < nout)
-    for (int b = g; b < nslots; b += 16) v += partial[int64_t(b) * nout + o];
-  sG[g * 64 + (threadIdx.x & 63)] = v;
-  __syncthreads();
-  if (g == 0 && o < nout) {
-    T r = T(0);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) r += sG[m * 64 + (threadIdx.x & 63)];
-    dst[o] = r;
+__global__ __launch_bounds__(256) void column_sum_kernel(const T* src, int rows, int64_t row_stride, int chunk, int64_t M, T* dst,
+                                                         int64_t dst_row_stride) {
+  T* lds = reinterpret_cast<T*>(aa_smem);  // [4][64]
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t col = int64_t(blockIdx.x) * 64 + c;
+  const int r0 = blockIdx.y * chunk, r1 = rows < r0 + chunk ? rows : r0 + chunk;
+  T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+  if (col < M) {
+    const T* p = src + col;
+    int r = r0 + q;
+    for (; r + 12 < r1; r += 16) {
+      a0 += p[int64_t(r) * row_stride];
+      a1 += p[int64_t(r + 4) * row_stride];
+      a2 += p[int64_t(r + 8) * row_stride];
+      a3 += p[int64_t(r + 12) * row_stride];
+    }
+    for (; r < r1; r += 4) a0 += p[int64_t(r) * row_stride];
   }
+  lds[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0 && col < M) dst[int64_t(blockIdx.y) * dst_row_stride + col] = (lds[c] + lds[64 + c]) + (lds[128 + c] + lds[192 + c]);
 }
+
+template <typename T>
+int launch_column_sum(T* slabs, int rows, int64_t M, T* dst, hipStream_t stream) {
+  constexpr int kChunk = 64;
+  const unsigned bx = (unsigned)((M + 63) / 64);
+  int left = rows;
+  int64_t stride = M;
+  if (rows > kChunk) {
+    left = (rows + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(column_sum_kernel<T>, dim3(bx, (unsigned)left), dim3(256), sizeof(T) * 256, stream, slabs, rows, M, kChunk, M, slabs,
+                       int64_t(kChunk) * M);
+    stride = int64_t(kChunk) * M;
+  }
+  hipLaunchKernelGGL(column_sum_kernel<T>, dim3(bx, 1), dim3(256), sizeof(T) * 256, stream, slabs, left, stride, left, M, dst, int64_t(0));
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+template int launch_column_sum<float>(float*, int, int64_t, float*, hipStream_t);
+template int launch_column_sum<double>(double*, int, int64_t, double*, hipStream_t);
 // uncoupled path weights: gw[p] = sum over channels (in channel order) of the per-channel sums
 template <typename T>
 __global__ __launch_bounds__(64) void tp_layer_wgrad_channels_kernel(const T* __restrict__ per_channel, int u, int P, T* __restrict__ gw) {
@@ -379,8 +409,7 @@ int launch_tp_wgrad_reduce(const void* partial, int nslots, int u, int P, int co
   const int nout = u * P;
   const T* part = static_cast<const T*>(partial);
   T* per_channel = coupling ? static_cast<T*>(gw) : const_cast<T*>(part) + size_t(nslots) * nout;  // the extra slab
-  hipLaunchKernelGGL(tp_layer_wgrad_reduce_kernel<T>, dim3((unsigned)((nout + 63) / 64)), dim3(1024), sizeof(T) * 16 * 64, stream, part, nslots, nout, per_channel);
-  AA_CHECK_HIP(hipGetLastError());
+  if (int rc = launch_column_sum<T>(const_cast<T*>(part), nslots, nout, per_channel, stream)) return rc;
   if (!coupling) {
     hipLaunchKernelGGL(tp_layer_wgrad_channels_kernel<T>, dim3(1), dim3(64), 0, stream, per_channel, u, P, static_cast<T*>(gw));
     AA_CHECK_HIP(hipGetLastError());

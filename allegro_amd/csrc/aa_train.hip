@@ -13,6 +13,7 @@
 // (allegro_amd/ops.py: weighted_channels), each ONE pass over the [E,u,D] tensor instead of the expand / cat / mul / sum chains
 // of eager autograd.
 #include "aa_common.h"
+#include "aa_wave.h"
 
 namespace aa {
 namespace {
@@ -133,21 +134,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// out[k][n] = sum of the workgroups' partial blocks, in order: 64 outputs x 4 interleaved partial sums per workgroup, combined
-// ((s0 + s1) + (s2 + s3)) through LDS
-template <typename T>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const T* partial, int parts, int64_t KN, T* out) {
-  T* lds = reinterpret_cast<T*>(aa_smem);
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int64_t idx = int64_t(blockIdx.x) * 64 + o;
-  T s = T(0);
-  if (idx < KN)
-    for (int b = sl; b < parts; b += 4) s += partial[int64_t(b) * KN + idx];
-  lds[threadIdx.x] = s;
-  __syncthreads();
-  if (sl == 0 && idx < KN) out[idx] = (lds[o] + lds[64 + o]) + (lds[128 + o] + lds[192 + o]);
-}
-
 // rows per workgroup: ~1024 workgroups along the rows (several per CU for every output-block count), at least 256 rows each
 int64_t wgrad_rows_per_slab(int64_t E) {
   int64_t rows = (E + 1023) / 1024;
@@ -175,21 +161,87 @@ int wgrad_launch(const WgradArgs& a, bool vec, int parts, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int irrep_of(int i) { return i < 1 ? 0 : (i < 4 ? 1 : (i < 9 ? 2 : 3)); }
 
-// One workgroup = 4 consecutive edges; rows of u * D elements are walked with compile-time D (no 64-bit divisions per element)
-template <typename T, int D>
-__global__ __launch_bounds__(256) void wc_forward_kernel(int64_t E, int u, int R, const T* sh, const T* w, T* out) {
-  // (write-bound: 2.15 TB/s of stores at C3 size; a 16-byte-store variant measured the same 319 us, tools/wc_probe.py)
-  const int row = u * D;
-  for (int q = 0; q < 4; ++q) {
-    const int64_t e = int64_t(blockIdx.x) * 4 + q;
-    if (e >= E) return;
-    const T* y = sh + e * D;
-    const T* wr = w + e * int64_t(u) * R;
-    T* o = out + e * int64_t(row);
-    for (int t = threadIdx.x; t < row; t += 256) {
-      const int c = t / D, i = t - c * D;
-      o[t] = y[i] * wr[c * R + (R == 1 ? 0 : irrep_of(i))];
+// Forward, slot form (rows of u D <= 256 kWcSlots elements).  A workgroup takes G consecutive edges: their sh rows (G D contiguous
+// elements) and weight rows (G u R contiguous elements) are copied to LDS with coalesced loads, then every thread walks the G output
+// rows through its slots -- thread `tid` owns the elements tid, tid + 256, ... of EVERY row; their (component, weight index) pairs are
+// computed once and kept in registers -- with two LDS reads, a multiply and a coalesced store per element.  TWO: out = sh (x) w +
+// sh2 (x) w2 in the same pass (the gradient of the fused pair of contractions with respect to their common operand: one store
+// stream instead of two stores, two loads and a third store of an addition).
+// History at C3 size (687 MB of stores), all forms reading the operands per element straight from global memory: 4 edges one after
+// the other with a load-multiply-store chain per element 316 us; batched loads 242 us; incrementally carried indices 244 us; slots
+// in registers with all loads of two edges in flight 292 us (TWO: 428 us) -- the time follows the NUMBER of per-lane gather loads
+// (each lane of a load hits one of 9 / 24 scattered words: the address unit serialises them), ~70 us per gather per element.
+constexpr int kWcSlots = 8, kWcMaxGroup = 16, kWcLdsBytes = 32768;
+template <typename T, int D, bool TWO, int NS>  // NS: slots per thread, 256 NS >= u D
+__global__ __launch_bounds__(256) void wc_forward_slots_kernel(int64_t E, int u, int R, int G, const T* __restrict__ sh,
+                                                               const T* __restrict__ w, const T* __restrict__ sh2, const T* __restrict__ w2,
+                                                               T* __restrict__ out) {
+  T* ly = reinterpret_cast<T*>(aa_smem);  // [G][D] | [G][u R] (| the same for the second term)
+  const int row = u * D, wrow = u * R;
+  T* lw = ly + G * D;
+  T* ly2 = lw + G * wrow;
+  T* lw2 = ly2 + G * D;
+  const int64_t e0 = int64_t(blockIdx.x) * G;
+  const int n = int(E - e0 < G ? E - e0 : int64_t(G));
+  for (int k = threadIdx.x; k < n * D; k += 256) {
+    ly[k] = sh[e0 * D + k];
+    if (TWO) ly2[k] = sh2[e0 * D + k];
+  }
+  for (int k = threadIdx.x; k < n * wrow; k += 256) {
+    lw[k] = w[e0 * wrow + k];
+    if (TWO) lw2[k] = w2[e0 * wrow + k];
+  }
+  int oy[NS], ow[NS];
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    const int t = int(threadIdx.x) + 256 * m, c = t / D, i = t - c * D;
+    // (slots past the end of the row read element 0 and store nothing)
+    oy[m] = t < row ? i : 0;
+    ow[m] = t < row ? c * R + (R == 1 ? 0 : irrep_of(i)) : 0;
+  }
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    T* o = out + (e0 + j) * row;
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      const int t = int(threadIdx.x) + 256 * m;
+      T v = ly[j * D + oy[m]] * lw[j * wrow + ow[m]];
+      if (TWO) v += ly2[j * D + oy[m]] * lw2[j * wrow + ow[m]];
+      if (t < row) o[t] = v;
     }
+  }
+}
+
+// Forward, general form (any row length): one workgroup = 8 consecutive edges = one contiguous span of outputs, four elements per
+// thread and batch, the operand loads of a batch in front of its stores.
+constexpr int kWcEdges = 8;
+template <typename T, int D, bool TWO>
+__global__ __launch_bounds__(256) void wc_forward_kernel(int64_t E, int u, int R, const T* __restrict__ sh, const T* __restrict__ w,
+                                                         const T* __restrict__ sh2, const T* __restrict__ w2, T* __restrict__ out) {
+  const int64_t e0 = int64_t(blockIdx.x) * kWcEdges;
+  const int row = u * D;
+  const int total = int(E - e0 < kWcEdges ? E - e0 : int64_t(kWcEdges)) * row;
+  const T* y = sh + e0 * D;
+  const T* wr = w + e0 * int64_t(u) * R;
+  const T* y2 = TWO ? sh2 + e0 * D : nullptr;
+  const T* wr2 = TWO ? w2 + e0 * int64_t(u) * R : nullptr;
+  T* o = out + e0 * int64_t(row);
+  for (int t0 = threadIdx.x; t0 < total; t0 += 1024) {
+    T v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = t0 + k * 256;
+      v[k] = T(0);
+      if (t < total) {
+        const int cg = t / D, i = t - cg * D;  // (channel of the span, component)
+        const int iy = (cg / u) * D + i, iw = cg * R + (R == 1 ? 0 : irrep_of(i));
+        v[k] = y[iy] * wr[iw];
+        if (TWO) v[k] += y2[iy] * wr2[iw];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (t0 + k * 256 < total) o[t0 + k * 256] = v[k];
   }
 }
 
@@ -227,12 +279,76 @@ __global__ __launch_bounds__(256) void wc_grad_sh_kernel(int64_t E, int u, int R
 #pragma unroll
     for (int i = 0; i < D; ++i) acc[i] += gr[i] * wv[R == 1 ? 0 : irrep_of(i)];
   }
+  wave_sum_store<T, D>(acc, gsh + e * D, true, false);
+}
+
+// Both contractions of one [E,u,D] operand in ONE pass over it: gsh[e,i] = sum_c t[e,c,i] w[e,c,r(i)] and
+// gw[e,c,r] = sum_{i in r} t[e,c,i] sh[e,i] (every first derivative of a weighted-channel tensor needs the pair, and so does every
+// derivative of the pair itself, with other second operands).  One wave per edge, lanes over channels: the weight-side sums are
+// lane-private, the harmonics-side sums D wave reductions.  The rows of 64 channels (64 D contiguous elements) are fetched with
+// coalesced loads into a wave-private LDS patch and read back channel-per-lane at an odd stride (no bank conflicts); reading the D
+// components of a lane's channel straight from global memory is one 64-way gather per component (229 us per call at C3 size).
+template <int D>
+__device__ __forceinline__ int wc_patch_index(int q) {  // element q of a 64-channel row block -> patch word (odd channel stride)
+  if (D & 1) return q;
+  constexpr int kShift = D == 4 ? 2 : (D == 16 ? 4 : (D == 2 ? 1 : 3));
+  return (q >> kShift) * (D + 1) + (q & (D - 1));
+}
+// (A first staged form -- one edge per wave and workgroup barriers around the patch -- was slower than the gathers, 356 us: a wave's
+//  whole life was one 2.3-KB row and two barriers.  This one: kWcPairEdges edges per wave, wave-level ordering only, the next row block's
+//  loads issued before the current one is consumed.)
+constexpr int kWcPairEdges = 4;
+template <typename T, int D>
+__global__ __launch_bounds__(256) void wc_grad_pair_kernel(int64_t E, int u, int R, const T* __restrict__ t, const T* __restrict__ sh,
+                                                           const T* __restrict__ w, T* __restrict__ gsh, T* __restrict__ gw) {
+  constexpr int DP = D | 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* patch = reinterpret_cast<T*>(aa_smem) + wave * 64 * DP;
+  const int64_t e_first = (int64_t(blockIdx.x) * 4 + wave) * kWcPairEdges;
+  if (e_first >= E) return;
+  const int n_e = int(E - e_first < kWcPairEdges ? E - e_first : int64_t(kWcPairEdges));
+  const int chunks = (u + 63) / 64, items = n_e * chunks;
+  // item = (edge of the wave, block of 64 channels); its 64 D contiguous elements as D coalesced loads (element lane + 64 m)
+  auto fetch = [&](int it, T* r) {
+    const int c0 = (it % chunks) * 64, nc = u - c0 < 64 ? u - c0 : 64;
+    const T* src = t + ((e_first + it / chunks) * u + c0) * D;
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    T v = acc[i];
+    for (int m = 0; m < D; ++m) r[m] = m * 64 + lane < nc * D ? src[m * 64 + lane] : T(0);
+  };
+  T r[D], acc[D];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) gsh[e * D + i] = v;
+  for (int i = 0; i < D; ++i) acc[i] = T(0);
+  fetch(0, r);
+  for (int it = 0; it < items; ++it) {
+    const int64_t e = e_first + it / chunks;
+    const int c = (it % chunks) * 64 + lane;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < D; ++m) patch[wc_patch_index<D>(m * 64 + lane)] = r[m];
+    __builtin_amdgcn_wave_barrier();
+    T x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) x[i] = patch[lane * DP + i];
+    if (it + 1 < items) fetch(it + 1, r);
+    if (c < u) {
+      const T* wr = w + (e * u + c) * R;
+      T wv[4], s4[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wv[q] = q < R ? wr[q] : T(0);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        acc[i] += x[i] * wv[R == 1 ? 0 : irrep_of(i)];
+        s4[R == 1 ? 0 : irrep_of(i)] += x[i] * sh[e * D + i];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < R) gw[(e * u + c) * R + q] = s4[q];
+    }
+    if (it % chunks == chunks - 1) {  // the edge is complete: D wave sums (reduce-scatter butterfly, aa_wave.h)
+      wave_sum_store<T, D>(acc, gsh + e * D, true, false);
+#pragma unroll
+      for (int i = 0; i < D; ++i) acc[i] = T(0);
+    }
   }
 }
 
@@ -279,53 +395,106 @@ extern "C" int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const vo
   if (dtype == AA_F32) {
     rc = k128 ? (n128 ? aa::wgrad_launch<float, 128, 128>(a, vec, parts, s) : aa::wgrad_launch<float, 128, 64>(a, vec, parts, s))
               : (n128 ? aa::wgrad_launch<float, 64, 128>(a, vec, parts, s) : aa::wgrad_launch<float, 64, 64>(a, vec, parts, s));
-    hipLaunchKernelGGL(aa::wgrad_reduce_kernel<float>, dim3((unsigned)((KN + 63) / 64)), dim3(256), 256 * sizeof(float), s,
-                       static_cast<const float*>(workspace), parts, KN, static_cast<float*>(out));
+    if (rc == AA_OK) rc = aa::launch_column_sum<float>(static_cast<float*>(workspace), parts, KN, static_cast<float*>(out), s);
   } else {
     rc = k128 ? (n128 ? aa::wgrad_launch<double, 128, 128>(a, vec, parts, s) : aa::wgrad_launch<double, 128, 64>(a, vec, parts, s))
               : (n128 ? aa::wgrad_launch<double, 64, 128>(a, vec, parts, s) : aa::wgrad_launch<double, 64, 64>(a, vec, parts, s));
-    hipLaunchKernelGGL(aa::wgrad_reduce_kernel<double>, dim3((unsigned)((KN + 63) / 64)), dim3(256), 256 * sizeof(double), s,
-                       static_cast<const double*>(workspace), parts, KN, static_cast<double*>(out));
+    if (rc == AA_OK) rc = aa::launch_column_sum<double>(static_cast<double*>(workspace), parts, KN, static_cast<double*>(out), s);
   }
-  (void)rc;
+  if (rc != AA_OK) return rc;
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
 
+template <typename T, int D, bool TWO, int NS>
+static void wc_launch_slots(int64_t E, int u, int R, const T* sh, const T* w, const T* sh2, const T* w2, T* out, hipStream_t s) {
+  const size_t per_edge = sizeof(T) * size_t(u * R + D) * (TWO ? 2 : 1);
+  const int G = int(std::max<size_t>(1, std::min<size_t>(aa::kWcMaxGroup, aa::kWcLdsBytes / per_edge)));
+  hipLaunchKernelGGL((aa::wc_forward_slots_kernel<T, D, TWO, NS>), dim3((unsigned)((E + G - 1) / G)), dim3(256), per_edge * G, s, E, u, R, G, sh, w,
+                     sh2, w2, out);
+}
+template <typename T, int D, bool TWO>
+static void wc_launch_forward(int64_t E, int u, int R, const T* sh, const T* w, const T* sh2, const T* w2, T* out, hipStream_t s) {
+  const int ns = (u * D + 255) / 256;
+  if (ns <= 1) wc_launch_slots<T, D, TWO, 1>(E, u, R, sh, w, sh2, w2, out, s);
+  else if (ns == 2) wc_launch_slots<T, D, TWO, 2>(E, u, R, sh, w, sh2, w2, out, s);
+  else if (ns == 3) wc_launch_slots<T, D, TWO, 3>(E, u, R, sh, w, sh2, w2, out, s);
+  else if (ns == 4) wc_launch_slots<T, D, TWO, 4>(E, u, R, sh, w, sh2, w2, out, s);
+  else if (ns == 5) wc_launch_slots<T, D, TWO, 5>(E, u, R, sh, w, sh2, w2, out, s);
+  else if (ns <= aa::kWcSlots) wc_launch_slots<T, D, TWO, aa::kWcSlots>(E, u, R, sh, w, sh2, w2, out, s);
+  else
+    hipLaunchKernelGGL((aa::wc_forward_kernel<T, D, TWO>), dim3((unsigned)((E + aa::kWcEdges - 1) / aa::kWcEdges)), dim3(256), 0, s, E, u, R, sh,
+                       w, sh2, w2, out);
+}
+
+// which 0..2: the three single forms; 3: out = p0 (x) p1 + p2 (x) p3; 4: the pair (out, out2) = (t . w, t . sh) with t = p0, sh = p1, w = p2
 template <typename T, int D>
-static int wc_launch_d(int which, int64_t E, int u, int R, const void* p0, const void* p1, void* out, hipStream_t s) {
+static int wc_launch_d(int which, int64_t E, int u, int R, const void* p0, const void* p1, const void* p2, const void* p3, void* out, void* out2,
+                       hipStream_t s) {
   const int64_t EC = E * u;
+  const T *a = static_cast<const T*>(p0), *b = static_cast<const T*>(p1), *c = static_cast<const T*>(p2), *d = static_cast<const T*>(p3);
   if (which == 0) {
-    hipLaunchKernelGGL((aa::wc_forward_kernel<T, D>), dim3((unsigned)((E + 3) / 4)), dim3(256), 0, s, E, u, R, static_cast<const T*>(p0),
-                       static_cast<const T*>(p1), static_cast<T*>(out));
+    wc_launch_forward<T, D, false>(E, u, R, a, b, nullptr, nullptr, static_cast<T*>(out), s);
+  } else if (which == 3) {
+    wc_launch_forward<T, D, true>(E, u, R, a, b, c, d, static_cast<T*>(out), s);
   } else if (which == 1) {
-    hipLaunchKernelGGL((aa::wc_grad_w_kernel<T, D>), dim3((unsigned)((EC + 255) / 256)), dim3(256), 0, s, EC, u, R, static_cast<const T*>(p0),
-                       static_cast<const T*>(p1), static_cast<T*>(out));
+    hipLaunchKernelGGL((aa::wc_grad_w_kernel<T, D>), dim3((unsigned)((EC + 255) / 256)), dim3(256), 0, s, EC, u, R, a, b, static_cast<T*>(out));
+  } else if (which == 2) {
+    hipLaunchKernelGGL((aa::wc_grad_sh_kernel<T, D>), dim3((unsigned)((E + 3) / 4)), dim3(256), 0, s, E, u, R, a, b, static_cast<T*>(out));
   } else {
-    hipLaunchKernelGGL((aa::wc_grad_sh_kernel<T, D>), dim3((unsigned)((E + 3) / 4)), dim3(256), 0, s, E, u, R, static_cast<const T*>(p0),
-                       static_cast<const T*>(p1), static_cast<T*>(out));
+    hipLaunchKernelGGL((aa::wc_grad_pair_kernel<T, D>), dim3((unsigned)((E + 4 * aa::kWcPairEdges - 1) / (4 * aa::kWcPairEdges))), dim3(256),
+                       sizeof(T) * 4 * 64 * (D | 1), s, E, u, R, a, b, c, static_cast<T*>(out),
+                       static_cast<T*>(out2));
   }
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
 
 template <typename T>
-static int wc_launch(int which, int64_t E, int u, int D, int R, const void* p0, const void* p1, void* out, hipStream_t s) {
+static int wc_launch(int which, int64_t E, int u, int D, int R, const void* p0, const void* p1, const void* p2, const void* p3, void* out,
+                     void* out2, hipStream_t s) {
   if (E == 0) return AA_OK;
   switch (D) {
-    case 1: return wc_launch_d<T, 1>(which, E, u, R, p0, p1, out, s);
-    case 4: return wc_launch_d<T, 4>(which, E, u, R, p0, p1, out, s);
-    case 9: return wc_launch_d<T, 9>(which, E, u, R, p0, p1, out, s);
-    default: return wc_launch_d<T, 16>(which, E, u, R, p0, p1, out, s);
+    case 1: return wc_launch_d<T, 1>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
+    case 4: return wc_launch_d<T, 4>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
+    case 9: return wc_launch_d<T, 9>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
+    default: return wc_launch_d<T, 16>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
   }
+}
+
+static int wc_check(const char* what, int64_t E, int u, int l_max) {
+  if (!(E >= 0 && u >= 1 && l_max >= 0 && l_max <= 3)) return aa::fail(AA_ERR_INVALID, std::string(what) + ": bad argument");
+  if (!(E * int64_t(u) * 16 < (int64_t(1) << 40))) return aa::fail(AA_ERR_INVALID, std::string(what) + ": too large");
+  return AA_OK;
 }
 
 extern "C" int aa_weighted_channels(aa_dtype dtype, int which, int64_t E, int u, int l_max, int shared, const void* a, const void* b, void* out,
                                     aa_stream stream) {
-  AA_REQUIRE(which >= 0 && which <= 2 && E >= 0 && u >= 1 && l_max >= 0 && l_max <= 3, "aa_weighted_channels: bad argument");
+  AA_REQUIRE(which >= 0 && which <= 2, "aa_weighted_channels: bad argument");
+  if (int rc = wc_check("aa_weighted_channels", E, u, l_max)) return rc;
   AA_REQUIRE(E == 0 || (a && b && out), "aa_weighted_channels: null argument");
-  AA_REQUIRE(E * int64_t(u) * 16 < (int64_t(1) << 40), "aa_weighted_channels: too large");
   const int D = (l_max + 1) * (l_max + 1), R = shared ? 1 : l_max + 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == AA_F32 ? wc_launch<float>(which, E, u, D, R, a, b, out, s) : wc_launch<double>(which, E, u, D, R, a, b, out, s);
+  return dtype == AA_F32 ? wc_launch<float>(which, E, u, D, R, a, b, nullptr, nullptr, out, nullptr, s)
+                         : wc_launch<double>(which, E, u, D, R, a, b, nullptr, nullptr, out, nullptr, s);
+}
+
+extern "C" int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, const void* sh2,
+                                        const void* w2, void* out, aa_stream stream) {
+  if (int rc = wc_check("aa_weighted_channels_sum", E, u, l_max)) return rc;
+  AA_REQUIRE(E == 0 || (sh && w && sh2 && w2 && out), "aa_weighted_channels_sum: null argument");
+  const int D = (l_max + 1) * (l_max + 1), R = shared ? 1 : l_max + 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AA_F32 ? wc_launch<float>(3, E, u, D, R, sh, w, sh2, w2, out, nullptr, s)
+                         : wc_launch<double>(3, E, u, D, R, sh, w, sh2, w2, out, nullptr, s);
+}
+
+extern "C" int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* t, const void* sh, const void* w,
+                                         void* out_sh, void* out_w, aa_stream stream) {
+  if (int rc = wc_check("aa_weighted_channels_pair", E, u, l_max)) return rc;
+  AA_REQUIRE(E == 0 || (t && sh && w && out_sh && out_w), "aa_weighted_channels_pair: null argument");
+  const int D = (l_max + 1) * (l_max + 1), R = shared ? 1 : l_max + 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == AA_F32 ? wc_launch<float>(4, E, u, D, R, t, sh, w, nullptr, out_sh, out_w, s)
+                         : wc_launch<double>(4, E, u, D, R, t, sh, w, nullptr, out_sh, out_w, s);
 }

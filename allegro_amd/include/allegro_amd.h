@@ -128,6 +128,13 @@ int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const void* x, int6
  * with operands substituted), which is what a force-matching loss needs. */
 int aa_weighted_channels(aa_dtype dtype, int which, int64_t E, int u, int l_max, int shared, const void* a, const void* b,
                          void* out, aa_stream stream);
+/* The two combinations every derivative of the forms above asks for, each in one pass over the [E,u,D] tensor instead of two or
+ * three:  _pair: out_sh[E,D] = t . w (which 2) AND out_w[E,u,R] = t . sh (which 1) from one read of t;
+ *         _sum:  out[E,u,D] = sh (x) w + sh2 (x) w2 (the gradient of the pair with respect to t) with one store stream. */
+int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* t, const void* sh, const void* w,
+                              void* out_sh, void* out_w, aa_stream stream);
+int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, const void* sh2,
+                             const void* w2, void* out, aa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Whole hot path: forward + forces  (seam B3 + ForceStressOutput)

@@ -440,6 +440,50 @@ def _(which, a, b, u, l_max, shared, lib_id):
     return a.new_empty(((E, u, D), (E, u * R), (E, D))[which])
 
 
+@torch.library.custom_op("allegro_amd::weighted_channels_pair", mutates_args=())
+def weighted_channels_pair_op(t: torch.Tensor, sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int, shared: bool,
+                              lib_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`aa_weighted_channels_pair`: (t . w [E,D], t . sh [E,u*R]) from one pass over t [E,u,D]."""
+    lib = _resolve(lib_id)
+    _check_device(lib, t, "allegro_amd::weighted_channels_pair")
+    tc, sc, wc = t.contiguous(), sh.contiguous(), w.contiguous()
+    E = tc.shape[0]
+    D, R = (l_max + 1) ** 2, (1 if shared else l_max + 1)
+    o_sh = torch.empty((E, D), dtype=t.dtype, device=t.device)
+    o_w = torch.empty((E, u * R), dtype=t.dtype, device=t.device)
+    p = (lambda x: x.data_ptr() if E else None)
+    lib.check(lib.lib.aa_weighted_channels_pair(_dtype_code(t), E, u, l_max, int(shared), p(tc), p(sc), p(wc), p(o_sh), p(o_w), _stream_ptr(t)),
+              "aa_weighted_channels_pair")
+    return o_sh, o_w
+
+
+@weighted_channels_pair_op.register_fake
+def _(t, sh, w, u, l_max, shared, lib_id):
+    E, D, R = t.shape[0], (l_max + 1) ** 2, (1 if shared else l_max + 1)
+    return t.new_empty((E, D)), t.new_empty((E, u * R))
+
+
+@torch.library.custom_op("allegro_amd::weighted_channels_sum", mutates_args=())
+def weighted_channels_sum_op(sh: torch.Tensor, w: torch.Tensor, sh2: torch.Tensor, w2: torch.Tensor, u: int, l_max: int, shared: bool,
+                             lib_id: int) -> torch.Tensor:
+    """`aa_weighted_channels_sum`: sh (x) w + sh2 (x) w2 -> [E,u,D], one store stream."""
+    lib = _resolve(lib_id)
+    _check_device(lib, sh, "allegro_amd::weighted_channels_sum")
+    a, b, c, d = sh.contiguous(), w.contiguous(), sh2.contiguous(), w2.contiguous()
+    E = a.shape[0]
+    D = (l_max + 1) ** 2
+    out = torch.empty((E, u, D), dtype=sh.dtype, device=sh.device)
+    p = (lambda x: x.data_ptr() if E else None)
+    lib.check(lib.lib.aa_weighted_channels_sum(_dtype_code(sh), E, u, l_max, int(shared), p(a), p(b), p(c), p(d), p(out), _stream_ptr(sh)),
+              "aa_weighted_channels_sum")
+    return out
+
+
+@weighted_channels_sum_op.register_fake
+def _(sh, w, sh2, w2, u, l_max, shared, lib_id):
+    return sh.new_empty((sh.shape[0], u, (l_max + 1) ** 2))
+
+
 class _MM(torch.autograd.Function):
     """y = x @ W for a per-edge linear layer (x [E,K], W [K,N]).  The products along the edges are library GEMMs; the one
     product that reduces OVER the edges -- the weight gradient -- is `_XtG` (hand-written).  With `_XtG` the pair is closed
@@ -492,6 +536,8 @@ class _WcB(torch.autograd.Function):
     def backward(ctx, g):
         sh, w = ctx.saved_tensors
         n = ctx.needs_input_grad
+        if n[0] and n[1]:  # (the usual case: both operands depend on the positions) one pass over g for both
+            return _WcPair.apply(g, sh, w, ctx.meta) + (None,)
         return (_WcS.apply(g, w, ctx.meta) if n[0] else None, _WcW.apply(g, sh, ctx.meta) if n[1] else None, None)
 
 
@@ -525,6 +571,66 @@ class _WcW(torch.autograd.Function):
         t, sh = ctx.saved_tensors
         n = ctx.needs_input_grad
         return (_WcB.apply(sh, q, ctx.meta) if n[0] else None, _WcS.apply(t, q, ctx.meta) if n[1] else None, None)
+
+
+class _WcPair(torch.autograd.Function):
+    """(S(t, w), W(t, sh)) = (sum_c t w, sum_{i in r} t sh) from ONE pass over t [E,u,D] -- the two gradients of B(sh, w).  Its own
+    derivative is the same pair with other second operands plus the two-term B: the family stays closed."""
+
+    @staticmethod
+    def forward(ctx, t, sh, w, meta):
+        ctx.meta = meta
+        ctx.set_materialize_grads(False)  # (an unused output arrives as None, not as a zero tensor to be multiplied through)
+        ctx.save_for_backward(t, sh, w)
+        return torch.ops.allegro_amd.weighted_channels_pair(t.detach(), sh.detach(), w.detach(), *meta)
+
+    @staticmethod
+    def backward(ctx, a_s, a_w):  # cotangents of S [E,D] and of W [E,u*R]
+        t, sh, w = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        meta = ctx.meta
+        gt = gsh = gw = None
+        if a_s is None and a_w is None:
+            return None, None, None, None
+        if n[0]:  # d/dt: B(a_s, w) + B(sh, a_w)
+            if a_s is not None and a_w is not None:
+                gt = _WcB2.apply(a_s, w, sh, a_w, meta)
+            elif a_s is not None:
+                gt = _WcB.apply(a_s, w, meta)
+            elif a_w is not None:
+                gt = _WcB.apply(sh, a_w, meta)
+        # d/dsh: S(t, a_w) (through W);  d/dw: W(t, a_s) (through S)
+        if n[1] and n[2] and a_s is not None and a_w is not None:
+            gsh, gw = _WcPair.apply(t, a_s, a_w, meta)
+        else:
+            if n[1] and a_w is not None:
+                gsh = _WcS.apply(t, a_w, meta)
+            if n[2] and a_s is not None:
+                gw = _WcW.apply(t, a_s, meta)
+        return gt, gsh, gw, None
+
+
+class _WcB2(torch.autograd.Function):
+    """B(sh, w) + B(sh2, w2) with one store stream."""
+
+    @staticmethod
+    def forward(ctx, sh, w, sh2, w2, meta):
+        ctx.meta = meta
+        ctx.save_for_backward(sh, w, sh2, w2)
+        return torch.ops.allegro_amd.weighted_channels_sum(sh.detach(), w.detach(), sh2.detach(), w2.detach(), *meta)
+
+    @staticmethod
+    def backward(ctx, g):
+        sh, w, sh2, w2 = ctx.saved_tensors
+        n = ctx.needs_input_grad
+        meta = ctx.meta
+
+        def pair(need_s, need_w, a, b):
+            if need_s and need_w:
+                return _WcPair.apply(g, a, b, meta)
+            return (_WcS.apply(g, b, meta) if need_s else None, _WcW.apply(g, a, meta) if need_w else None)
+
+        return pair(n[0], n[1], sh, w) + pair(n[2], n[3], sh2, w2) + (None,)
 
 
 def weighted_channels(sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int, lib_id: int) -> torch.Tensor:

@@ -65,6 +65,16 @@ def _mlp(x: torch.Tensor, weights: List[torch.Tensor], act: Optional[str], act_c
     return x
 
 
+def _head_columns(x: torch.Tensor, a: int, b: int):
+    """x[:, :a], x[:, a:a+b] as ONE autograd node (`split`: its backward is a single concatenation of the two gradients; two slices
+    are two zero-filled [E, width] buffers, two copies and an addition -- and again in the second derivative)."""
+    rest = x.shape[1] - a - b
+    if b == 0 and rest == 0:
+        return x, x[:, :0]
+    parts = torch.split(x, [a, b] + ([rest] if rest else []), dim=1)
+    return parts[0], parts[1]
+
+
 def _weighted_channels(sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int) -> torch.Tensor:
     """MakeWeightedChannels (allegro/nn/_strided/_channels.py:44-63): out[e,c,i] = sh[e,i] * w[e,c,irrep(i)] (one weight per
     irrep) or sh[e,i] * w[e,c] (`weight_individual_irreps=False`)."""
@@ -209,7 +219,8 @@ class TrainingEvaluator:
         tf = self._wc(sh, _mlp(emb, self._weights("tensor_embed.env_embed_linear.mlp"), "silu", silu_c, fwd, self.lib_id), u, l_max)
         We = (l_max + 1) * u if m.weight_individual_irreps else u
         proj = _mlp(emb, self._weights("allegro.first_layer_env_embed_projection.mlp"), "silu", silu_c, fwd, self.lib_id)
-        scalars, env_w = [proj[:, :S]], proj[:, S:S + We]
+        first, env_w = _head_columns(proj, S, We)
+        scalars = [first]
         for l in range(L):  # _allegro.py:262-294
             c = self.contracters[l]
             env = self._wc(sh, env_w, u, l_max)
@@ -219,9 +230,11 @@ class TrainingEvaluator:
                                                           c._lib_id, c.base_dim1, c.base_dim2, c.base_dim_out)
             lat = _mlp(torch.cat(scalars + [tf[:, :, 0]], dim=-1), self._weights(f"allegro.latents.{l}.mlp"), nl_latent,
                        self.act_consts[nl_latent], fwd, self.lib_id)
-            scalars.append(lat[:, :S])
             if l < L - 1:
-                env_w = lat[:, S:S + We]
+                head, env_w = _head_columns(lat, S, We)
+            else:
+                head, _ = _head_columns(lat, S, 0)
+            scalars.append(head)
         # edge readout, edge -> atom sum, per-type scale / shift (allegro_models.py:231-260; edgewise.py:40-60)
         e_edge = _mlp(torch.cat(scalars, dim=-1), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd, self.lib_id)
         e_edge = e_edge * (1.0 / math.sqrt(2 * hp["avg_num_neighbors"]))

@@ -17,7 +17,7 @@ def _wgrad_case(lib, dev):
     lid = _lib_id(lib)
     g = torch.Generator().manual_seed(4)
     for dtype, tol in ((torch.float32, 2e-6), (torch.float64, 1e-13)):
-        for E, K, N, pad in ((0, 8, 16, 0), (5, 8, 64, 0), (777, 64, 64, 0), (1030, 192, 64, 16), (2049, 17, 130, 3), (300, 256, 1, 0)):
+        for E, K, N, pad in ((0, 8, 16, 0), (5, 8, 64, 0), (777, 64, 64, 0), (1030, 192, 64, 16), (2049, 17, 130, 3), (300, 256, 1, 0), (17933, 4, 5, 0)):  # (last: 71 slabs -> both launches of the column sum, ragged last chunk)
             xb = torch.randn(E, K + pad, generator=g, dtype=dtype).to(dev)
             gb = torch.randn(E, N + pad, generator=g, dtype=dtype).to(dev)
             x, gg = xb[:, :K], gb[:, pad:]  # row-strided views: the kernel takes the strides, no copy
@@ -77,6 +77,28 @@ def _second_order_case(lib, dev):
         cc = torch.randn(E, u, D_, generator=g, dtype=dtype).to(dev)
         for a, b in zip(torch.autograd.grad((t * cc).sum(), [sh, w]), torch.autograd.grad((ref * cc).sum(), [sh, w])):
             assert (a - b).abs().max().item() <= 1e-12
+        # the fused forms against the single ones: one pass over t for both contractions, one store stream for a sum of two products
+        meta = (u, l_max_, shared, lid)
+        s1, w1 = torch.ops.allegro_amd.weighted_channels_pair(cc, sh.detach(), w.detach(), *meta)
+        assert torch.equal(s1, torch.ops.allegro_amd.weighted_channels(2, cc, w.detach(), *meta))
+        assert torch.equal(w1, torch.ops.allegro_amd.weighted_channels(1, cc, sh.detach(), *meta))
+        sh2, w2 = torch.randn_like(sh), torch.randn_like(w)
+        both = torch.ops.allegro_amd.weighted_channels_sum(sh.detach(), w.detach(), sh2, w2, *meta)
+        want = torch.ops.allegro_amd.weighted_channels(0, sh.detach(), w.detach(), *meta) + torch.ops.allegro_amd.weighted_channels(0, sh2, w2, *meta)
+        assert (both - want).abs().max().item() <= 1e-13
+    # rows longer than the register-slot form holds (u D > 2048): the general forward kernel, both with one and two terms
+    u_, l_ = 160, 3
+    sh = torch.randn(5, 16, generator=g, dtype=dtype).to(dev)
+    w = torch.randn(5, u_ * 4, generator=g, dtype=dtype).to(dev)
+    sh2, w2 = torch.randn_like(sh), torch.randn_like(w)
+    ref = lambda a, b: a.unsqueeze(1) * torch.cat([b.reshape(5, u_, 4)[:, :, l:l + 1].expand(-1, -1, 2 * l + 1) for l in range(4)], dim=-1)  # noqa: E731
+    assert (torch.ops.allegro_amd.weighted_channels(0, sh, w, u_, l_, False, lid) - ref(sh, w)).abs().max().item() <= 1e-13
+    assert (torch.ops.allegro_amd.weighted_channels_sum(sh, w, sh2, w2, u_, l_, False, lid) - ref(sh, w) - ref(sh2, w2)).abs().max().item() <= 1e-13
+    # ... and more than one 64-channel block per edge in the fused pair (160 = 64 + 64 + 32)
+    tt = torch.randn(5, u_, 16, generator=g, dtype=dtype).to(dev)
+    s1, w1 = torch.ops.allegro_amd.weighted_channels_pair(tt, sh, w, u_, l_, False, lid)
+    assert (s1 - torch.ops.allegro_amd.weighted_channels(2, tt, w, u_, l_, False, lid)).abs().max().item() <= 1e-12
+    assert torch.equal(w1, torch.ops.allegro_amd.weighted_channels(1, tt, sh, u_, l_, False, lid))
 
 
 def test_linear_wgrad_emulated():
