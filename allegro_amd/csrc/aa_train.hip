@@ -18,6 +18,18 @@
 namespace aa {
 namespace {
 
+template <typename T>
+struct Pk16;  // 16 bytes of T
+template <>
+struct Pk16<float> {
+  typedef float type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct Pk16<double> {
+  typedef double type __attribute__((ext_vector_type(2)));
+};
+
+
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 
@@ -352,6 +364,68 @@ __global__ __launch_bounds__(256) void wc_grad_pair_kernel(int64_t E, int u, int
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SiLU and its derivatives as ONE elementwise family: A_k(x, g) = g f^(k)(x), f = x sigmoid(x).  d A_k / dx = A_{k+1}(x, g .),
+// d A_k / dg = A_k(x, .): every derivative of a member is a member, so the hidden activations of the scalar MLPs cost one launch
+// in the energy, one in the forces and one (the pair form: both gradients from one read of x, g, h) in the gradient of a force loss --
+// autograd's own SiLU double-backward is a dozen elementwise launches per site.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T silu_order(T x, int k) {
+  const T s = sigmoid_(x), s1 = s * (T(1) - s), m = T(1) - T(2) * s;
+  switch (k) {
+    case 0: return x * s;
+    case 1: return s * (T(1) + x * (T(1) - s));
+    case 2: return s1 * (T(2) + x * m);
+    default: return s1 * (m * (T(2) + x * m) + m - T(2) * x * s1);
+  }
+}
+// h == nullptr: out0 = g f^(k)(x) (g == nullptr: f^(k)(x));  else: out0 = g h f^(k+1)(x), out1 = h f^(k)(x)
+template <typename T>
+__global__ __launch_bounds__(256) void silu_family_kernel(int64_t n, int k, const T* __restrict__ x, const T* __restrict__ g,
+                                                          const T* __restrict__ h, T* __restrict__ out0, T* __restrict__ out1) {
+  constexpr int V = 16 / sizeof(T);
+  const int64_t i0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * V;
+  if (i0 >= n) return;
+  T xv[V], gv[V], hv[V];
+  const bool full = i0 + V <= n;
+  if (full) {
+    using Vec = typename Pk16<T>::type;
+    *reinterpret_cast<Vec*>(xv) = *reinterpret_cast<const Vec*>(x + i0);
+    if (g) *reinterpret_cast<Vec*>(gv) = *reinterpret_cast<const Vec*>(g + i0);
+    if (h) *reinterpret_cast<Vec*>(hv) = *reinterpret_cast<const Vec*>(h + i0);
+  } else {
+    for (int j = 0; j < V; ++j) {
+      const bool ok = i0 + j < n;
+      xv[j] = ok ? x[i0 + j] : T(0);
+      gv[j] = ok && g ? g[i0 + j] : T(0);
+      hv[j] = ok && h ? h[i0 + j] : T(0);
+    }
+  }
+  T a[V], b[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const T gj = g ? gv[j] : T(1);
+    if (h) {
+      a[j] = gj * hv[j] * silu_order(xv[j], k + 1);
+      b[j] = hv[j] * silu_order(xv[j], k);
+    } else {
+      a[j] = gj * silu_order(xv[j], k);
+      b[j] = T(0);
+    }
+  }
+  if (full) {
+    using Vec = typename Pk16<T>::type;
+    *reinterpret_cast<Vec*>(out0 + i0) = *reinterpret_cast<const Vec*>(a);
+    if (h) *reinterpret_cast<Vec*>(out1 + i0) = *reinterpret_cast<const Vec*>(b);
+  } else {
+    for (int j = 0; j < V && i0 + j < n; ++j) {
+      out0[i0 + j] = a[j];
+      if (h) out1[i0 + j] = b[j];
+    }
+  }
+}
+
 }  // namespace
 }  // namespace aa
 
@@ -497,4 +571,34 @@ extern "C" int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == AA_F32 ? wc_launch<float>(4, E, u, D, R, t, sh, w, nullptr, out_sh, out_w, s)
                          : wc_launch<double>(4, E, u, D, R, t, sh, w, nullptr, out_sh, out_w, s);
+}
+
+static int silu_launch(const char* what, aa_dtype dtype, int order, int64_t n, const void* x, const void* g, const void* h, void* out0, void* out1,
+                       aa_stream stream) {
+  if (!(n >= 0 && order >= 0 && order + (h ? 1 : 0) <= 3)) return aa::fail(AA_ERR_INVALID, std::string(what) + ": bad argument (derivative orders 0..3)");
+  if (n == 0) return AA_OK;
+  if (!(x && out0 && (!h || (g && out1)))) return aa::fail(AA_ERR_INVALID, std::string(what) + ": null argument");
+  for (const void* p : {x, g, h, static_cast<const void*>(out0), static_cast<const void*>(out1)})
+    if (reinterpret_cast<uintptr_t>(p) % 16 != 0) return aa::fail(AA_ERR_INVALID, std::string(what) + ": pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t per_block = 256 * (dtype == AA_F32 ? 4 : 2);
+  const dim3 grid((unsigned)((n + per_block - 1) / per_block));
+  if (dtype == AA_F32)
+    hipLaunchKernelGGL(aa::silu_family_kernel<float>, grid, dim3(256), 0, s, n, order, static_cast<const float*>(x), static_cast<const float*>(g),
+                       static_cast<const float*>(h), static_cast<float*>(out0), static_cast<float*>(out1));
+  else
+    hipLaunchKernelGGL(aa::silu_family_kernel<double>, grid, dim3(256), 0, s, n, order, static_cast<const double*>(x), static_cast<const double*>(g),
+                       static_cast<const double*>(h), static_cast<double*>(out0), static_cast<double*>(out1));
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+extern "C" int aa_silu_derivative(aa_dtype dtype, int order, int64_t n, const void* x, const void* g, void* out, aa_stream stream) {
+  return silu_launch("aa_silu_derivative", dtype, order, n, x, g, nullptr, out, nullptr, stream);
+}
+
+extern "C" int aa_silu_derivative_pair(aa_dtype dtype, int order, int64_t n, const void* x, const void* g, const void* h, void* out_x, void* out_g,
+                                       aa_stream stream) {
+  if (!h && n > 0) return aa::fail(AA_ERR_INVALID, "aa_silu_derivative_pair: null argument");
+  return silu_launch("aa_silu_derivative_pair", dtype, order, n, x, g, h, out_x, out_g, stream);
 }

@@ -135,6 +135,13 @@ int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l_max, int s
                               void* out_sh, void* out_w, aa_stream stream);
 int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, const void* sh2,
                              const void* w2, void* out, aa_stream stream);
+/* The hidden activation of the scalar MLPs (ScalarMLPFunction with SiLU; _allegro.py:192-213) and its derivatives, elementwise over n
+ * values: A_k(x, g) = g f^(k)(x), f(x) = x sigmoid(x), k = `order` in 0..3; g may be NULL (= 1).  The family is closed under
+ * differentiation: d A_k/dx . h = A_{k+1}(x, g h), d A_k/dg . h = A_k(x, h); `_pair` returns both from one pass:
+ * out_x = g h f^(order+1)(x), out_g = h f^(order)(x) (order <= 2).  Pointers 16-byte aligned. */
+int aa_silu_derivative(aa_dtype dtype, int order, int64_t n, const void* x, const void* g, void* out, aa_stream stream);
+int aa_silu_derivative_pair(aa_dtype dtype, int order, int64_t n, const void* x, const void* g, const void* h, void* out_x, void* out_g,
+                            aa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Whole hot path: forward + forces  (seam B3 + ForceStressOutput)

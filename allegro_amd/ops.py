@@ -249,6 +249,36 @@ class _TriCtx:
     def __init__(self, plan: int, lib_id: int, d1: int, d2: int, dout: int, segments=None):
         self.plan, self.lib_id, self.d1, self.d2, self.dout = plan, lib_id, d1, d2, dout
         self.segments = segments  # None | (rowptr int32 [N+1], eids int32 [E] | None, idxs int64 [E], num_atoms, scatter_factor)
+        # M b of the b operands this contraction has seen: the forward kernel returns it, and the x1- and weight-gradient kernels of
+        # every later derivative take it as an input -- recomputing it was 14 segment sums of [E,u,d2] per training step at C3 (2.3 ms)
+        # for 4 distinct operands.  An entry holds its `b` (so that the address in the key cannot be re-used while the entry lives).
+        self.x2s_cache = {}
+        self.keep = False  # remember operands even when no graph is recorded (set for the duration of one backward call)
+
+    @staticmethod
+    def _key(b):
+        return (b.data_ptr(), b._version, tuple(b.shape), tuple(b.stride()), b.dtype)
+
+    def remember(self, b, x2s):
+        self.x2s_cache[self._key(b)] = (b, x2s)
+
+    def forget(self, b):
+        self.x2s_cache.pop(self._key(b), None)
+
+
+class _recording:
+    """Inside a member's forward: remember M b of its operands iff this node is part of a recorded graph (its inputs are saved and
+    stay alive until the graph is freed, so the cache extends no tensor's life).  (`torch.is_grad_enabled()` is always False there.)"""
+
+    def __init__(self, ctx, t):
+        self.t, self.on = t, any(ctx.needs_input_grad)
+
+    def __enter__(self):
+        self.prev = self.t.keep
+        self.t.keep = self.prev or self.on
+
+    def __exit__(self, *a):
+        self.t.keep = self.prev
 
 
 def _edge_rowptr(E: int, device) -> torch.Tensor:
@@ -256,15 +286,23 @@ def _edge_rowptr(E: int, device) -> torch.Tensor:
 
 
 def _segment_sum(t: _TriCtx, b):  # x2s = scale * scatter-sum of b over the scatter index  [N,u,d2]
+    hit = t.x2s_cache.get(t._key(b))
+    if hit is not None:
+        return hit[1]
     rowptr, eids, _idxs, n, sf = t.segments
-    return torch.ops.allegro_amd.segment_sum(b.detach(), rowptr, eids, n, sf, t.lib_id)
+    x2s = torch.ops.allegro_amd.segment_sum(b.detach(), rowptr, eids, n, sf, t.lib_id)
+    if t.keep:  # (only while a recorded graph keeps the operand alive anyway: see _recording)
+        t.remember(b, x2s)
+    return x2s
 
 
 def _raw_out(t: _TriCtx, a, b, w):  # [E,u,dout]
     E = a.shape[0]
     if t.segments is not None:
         rowptr, eids, _idxs, n, sf = t.segments
-        out, _ = torch.ops.allegro_amd.tp_forward(a.detach(), b.detach(), w.detach(), rowptr, eids, n, sf, t.plan, t.lib_id, t.d2, t.dout)
+        out, x2s = torch.ops.allegro_amd.tp_forward(a.detach(), b.detach(), w.detach(), rowptr, eids, n, sf, t.plan, t.lib_id, t.d2, t.dout)
+        if t.keep:
+            t.remember(b, x2s)
         return out
     out, _ = torch.ops.allegro_amd.tp_forward(a.detach(), b.detach(), w.detach(), _edge_rowptr(E, a.device), None, E, 1.0,
                                               t.plan, t.lib_id, t.d2, t.dout)
@@ -305,7 +343,8 @@ class _TriK(torch.autograd.Function):
     def forward(ctx, a, b, w, t):
         ctx.t = t
         ctx.save_for_backward(a, b, w)
-        return _raw_out(t, a, b, w)
+        with _recording(ctx, t):
+            return _raw_out(t, a, b, w)
 
     @staticmethod
     def backward(ctx, g):
@@ -323,7 +362,8 @@ class _TriI(torch.autograd.Function):
     def forward(ctx, c, b, w, t):
         ctx.t = t
         ctx.save_for_backward(c, b, w)
-        return _raw_grad_a(t, c, b, w)
+        with _recording(ctx, t):
+            return _raw_grad_a(t, c, b, w)
 
     @staticmethod
     def backward(ctx, h):
@@ -341,15 +381,24 @@ class _TriJ(torch.autograd.Function):
     def forward(ctx, c, a, w, t):
         ctx.t = t
         ctx.save_for_backward(c, a, w)
-        return _raw_grad_b(t, c, a, w)
+        with _recording(ctx, t):
+            return _raw_grad_b(t, c, a, w)
 
     @staticmethod
     def backward(ctx, h):
         c, a, w = ctx.saved_tensors
         t = ctx.t
         n = ctx.needs_input_grad
-        return (_TriK.apply(a, h, w, t) if n[0] else None, _TriI.apply(c, h, w, t) if n[1] else None,
-                _TriW.apply(c, a, h, w, t) if n[2] else None, None)
+        # (h enters the b slot of up to three members: its M h once, for the duration of this call when no graph is recorded)
+        temp = t.segments is not None and (n[1] or n[2]) and not torch.is_grad_enabled() and t._key(h) not in t.x2s_cache
+        t.keep = temp  # (the forward kernel of the first member returns M h: the other two take it from the cache)
+        try:
+            return (_TriK.apply(a, h, w, t) if n[0] else None, _TriI.apply(c, h, w, t) if n[1] else None,
+                    _TriW.apply(c, a, h, w, t) if n[2] else None, None)
+        finally:
+            if temp:
+                t.keep = False
+                t.forget(h)
 
 
 class _TriW(torch.autograd.Function):
@@ -359,7 +408,8 @@ class _TriW(torch.autograd.Function):
     def forward(ctx, c, a, b, w_like, t):
         ctx.t = t
         ctx.save_for_backward(c, a, b)
-        return _raw_wgrad(t, c, a, b, w_like)
+        with _recording(ctx, t):
+            return _raw_wgrad(t, c, a, b, w_like)
 
     @staticmethod
     def backward(ctx, hw):
@@ -482,6 +532,74 @@ def weighted_channels_sum_op(sh: torch.Tensor, w: torch.Tensor, sh2: torch.Tenso
 @weighted_channels_sum_op.register_fake
 def _(sh, w, sh2, w2, u, l_max, shared, lib_id):
     return sh.new_empty((sh.shape[0], u, (l_max + 1) ** 2))
+
+
+@torch.library.custom_op("allegro_amd::silu_derivative", mutates_args=())
+def silu_derivative_op(x: torch.Tensor, g: Optional[torch.Tensor], order: int, lib_id: int) -> torch.Tensor:
+    """`aa_silu_derivative`: g * f^(order)(x), f = SiLU, elementwise (g None: 1)."""
+    lib = _resolve(lib_id)
+    _check_device(lib, x, "allegro_amd::silu_derivative")
+    xc = x.contiguous()
+    gc = None if g is None else g.contiguous()
+    out = torch.empty_like(xc)
+    n = xc.numel()
+    lib.check(lib.lib.aa_silu_derivative(_dtype_code(x), order, n, xc.data_ptr() if n else None, gc.data_ptr() if (n and gc is not None) else None,
+                                         out.data_ptr() if n else None, _stream_ptr(x)), "aa_silu_derivative")
+    return out
+
+
+@silu_derivative_op.register_fake
+def _(x, g, order, lib_id):
+    return torch.empty_like(x, memory_format=torch.contiguous_format)
+
+
+@torch.library.custom_op("allegro_amd::silu_derivative_pair", mutates_args=())
+def silu_derivative_pair_op(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor, order: int, lib_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`aa_silu_derivative_pair`: (g h f^(order+1)(x), h f^(order)(x)) from one pass."""
+    lib = _resolve(lib_id)
+    _check_device(lib, x, "allegro_amd::silu_derivative_pair")
+    xc, gc, hc = x.contiguous(), g.contiguous(), h.contiguous()
+    ox, og = torch.empty_like(xc), torch.empty_like(xc)
+    n = xc.numel()
+    p = (lambda t: t.data_ptr() if n else None)
+    lib.check(lib.lib.aa_silu_derivative_pair(_dtype_code(x), order, n, p(xc), p(gc), p(hc), p(ox), p(og), _stream_ptr(x)), "aa_silu_derivative_pair")
+    return ox, og
+
+
+@silu_derivative_pair_op.register_fake
+def _(x, g, h, order, lib_id):
+    return torch.empty_like(x, memory_format=torch.contiguous_format), torch.empty_like(x, memory_format=torch.contiguous_format)
+
+
+class _Silu(torch.autograd.Function):
+    """A_k(x, g) = g f^(k)(x) with f = SiLU (g None: f^(k)(x)).  d/dx = A_{k+1}(x, g .), d/dg = A_k(x, .): closed under
+    differentiation, one launch per member; where no further derivative is recorded (the backward pass of the loss) both gradients
+    come from one pass (`silu_derivative_pair`)."""
+
+    @staticmethod
+    def forward(ctx, x, g, k, lib_id):
+        ctx.k, ctx.lib_id, ctx.has_g = k, lib_id, g is not None
+        ctx.save_for_backward(x, g)
+        return torch.ops.allegro_amd.silu_derivative(x.detach(), None if g is None else g.detach(), k, lib_id)
+
+    @staticmethod
+    def backward(ctx, h):
+        x, g = ctx.saved_tensors
+        k, lib_id = ctx.k, ctx.lib_id
+        need_x, need_g = ctx.needs_input_grad[0], ctx.has_g and ctx.needs_input_grad[1]
+        if k >= 3 and need_x:
+            raise NotImplementedError("allegro_amd: SiLU derivatives beyond the third are not implemented")
+        if need_x and need_g and not torch.is_grad_enabled():
+            gx, gg = torch.ops.allegro_amd.silu_derivative_pair(x, g, h, k, lib_id)
+            return gx, gg, None, None
+        gx = _Silu.apply(x, h if g is None else g * h, k + 1, lib_id) if need_x else None
+        gg = _Silu.apply(x, h, k, lib_id) if need_g else None
+        return gx, gg, None, None
+
+
+def silu(x: torch.Tensor, lib_id: int) -> torch.Tensor:
+    """SiLU of a hidden layer in training mode, differentiable to third order, on the elementwise family kernel."""
+    return _Silu.apply(x, None, 0, lib_id)
 
 
 class _MM(torch.autograd.Function):

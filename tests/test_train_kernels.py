@@ -48,7 +48,7 @@ def _second_order_case(lib, dev):
         sh = sh0.clone().requires_grad_(True)
         w1, w2 = W1.clone().requires_grad_(True), W2.clone().requires_grad_(True)
         lin = (lambda a, b: ops.linear(a, b, lid)) if hand else (lambda a, b: a @ b)
-        h = torch.nn.functional.silu(lin(x, w1))
+        h = ops.silu(lin(x, w1), lid) if hand else torch.nn.functional.silu(lin(x, w1))
         w = lin(h, w2)
         if hand:
             t = ops.weighted_channels(sh, w, u, l_max, lid)
@@ -99,6 +99,43 @@ def _second_order_case(lib, dev):
     s1, w1 = torch.ops.allegro_amd.weighted_channels_pair(tt, sh, w, u_, l_, False, lid)
     assert (s1 - torch.ops.allegro_amd.weighted_channels(2, tt, w, u_, l_, False, lid)).abs().max().item() <= 1e-12
     assert torch.equal(w1, torch.ops.allegro_amd.weighted_channels(1, tt, sh, u_, l_, False, lid))
+
+
+def _silu_case(lib, dev):
+    """Every member of the SiLU family against autograd through `torch.nn.functional.silu`, to third order, incl. the pair form."""
+    lid = _lib_id(lib)
+    g = torch.Generator().manual_seed(11)
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        for n in (1, 7, 1030):
+            x = (3.0 * torch.randn(n, generator=g, dtype=dtype)).to(dev).requires_grad_(True)
+            a = torch.randn(n, generator=g, dtype=dtype).to(dev).requires_grad_(True)
+            b = torch.randn(n, generator=g, dtype=dtype).to(dev)
+            outs = []
+            for hand in (True, False):
+                y = ops.silu(x, lid) if hand else torch.nn.functional.silu(x)
+                (d1,) = torch.autograd.grad((y * a).sum(), x, create_graph=True)  # a f1(x)
+                d2x, d2a = torch.autograd.grad((d1 * b).sum(), [x, a], create_graph=True)  # a b f2(x), b f1(x)
+                (d3,) = torch.autograd.grad(d2x.sum(), x)  # a b f3(x)
+                outs.append([y.detach(), d1.detach(), d2x.detach(), d2a.detach(), d3])
+            for p, q in zip(*outs):
+                assert (p - q).abs().max().item() <= tol * max(1.0, float(q.abs().max())), (dtype, n)
+            # the pair form (what the backward pass of the loss runs: no further derivative recorded)
+            y = ops.silu(x, lid)
+            (d1,) = torch.autograd.grad((y * a).sum(), x, create_graph=True)
+            px, pa = torch.autograd.grad((d1 * b).sum(), [x, a])
+            assert (px - outs[1][2]).abs().max().item() <= tol * max(1.0, float(outs[1][2].abs().max()))
+            assert (pa - outs[1][3]).abs().max().item() <= tol * max(1.0, float(outs[1][3].abs().max()))
+
+
+def test_silu_family_emulated():
+    from tests.hip_utils import emu_lib
+
+    _silu_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_silu_family_on_gpu():
+    _silu_case(None, torch.device("cuda:0"))
 
 
 def test_linear_wgrad_emulated():
