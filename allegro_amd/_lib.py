@@ -138,6 +138,11 @@ class AllegroLib:
         L.aa_linear_wgrad.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p]
         L.aa_linear_wgrad.restype = C.c_int
+        L.aa_linear_forward_workspace_bytes.argtypes = [C.c_int, C.c_int]
+        L.aa_linear_forward_workspace_bytes.restype = C.c_size_t
+        L.aa_linear_forward.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_int64, C.c_void_p]
+        L.aa_linear_forward.restype = C.c_int
         L.aa_weighted_channels.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_weighted_channels.restype = C.c_int
         L.aa_weighted_channels_pair.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

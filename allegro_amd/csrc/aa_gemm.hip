@@ -1867,6 +1867,82 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
 }  // namespace aa
 
 // ---------------------------------------------------------------------------------------------
+// aa_linear_forward: one bias-free linear layer y = x @ W along the edges with W a DEVICE matrix that changes every call (the
+// training path: the optimiser has just updated it).  Two small launches put W into the fragment orders of gemm_pack_b /
+// gemm_pack_bf16x3 (same arithmetic as the host packers: three truncated bf16 levels), then the rows run through the bf16x3 kernel
+// of the inference pipeline.
+// ---------------------------------------------------------------------------------------------
+namespace aa {
+namespace {
+// B[k][n] = W[k * ldk + n * ldn] (any strides: W or its transpose without a copy)
+__global__ __launch_bounds__(256) void pack_b_device_kernel(const float* __restrict__ W, int64_t ldk, int64_t ldn, int K, int N, float* __restrict__ bp,
+                                                            unsigned* __restrict__ bq) {
+  const int NT = (N + 31) / 32, KC = (K + 31) / 32;
+  const int item = blockIdx.x * 256 + threadIdx.x;  // (nt, kc, lane, half, q): 8 (half, q) per lane
+  if (item >= NT * KC * 64 * 8) return;
+  const int q = item & 3, half = (item >> 2) & 1, lane = (item >> 3) & 63, tile = item >> 9;
+  const int kc = tile % KC, nt = tile / KC;
+  const int n = nt * 32 + (lane & 31);
+  unsigned h[3][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int sidx = half * 8 + q * 2 + e;
+    const int k = kc * 32 + 8 * (sidx >> 2) + 4 * (lane >> 5) + (sidx & 3);  // accumulator order
+    const float x = (k < K && n < N) ? W[k * ldk + n * ldn] : 0.f;
+    const unsigned u0 = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+    const float r = x - __builtin_bit_cast(float, u0);
+    const unsigned u1 = __builtin_bit_cast(unsigned, r) & 0xFFFF0000u;
+    const float r2 = r - __builtin_bit_cast(float, u1);
+    h[0][e] = u0;
+    h[1][e] = u1;
+    h[2][e] = __builtin_bit_cast(unsigned, r2) & 0xFFFF0000u;
+    // the fp32 fragment order (gemm_pack_b): element s of the lane = row kc * 32 + (lane >> 5) * 16 + s
+    const int s2 = half * 8 + q * 2 + e, k2 = kc * 32 + (lane >> 5) * 16 + s2;
+    bp[(size_t(tile) * 64 + lane) * 16 + s2] = (k2 < K && n < N) ? W[k2 * ldk + n * ldn] : 0.f;
+  }
+  unsigned* o = bq + size_t(tile) * 64 * 24 + size_t(lane) * 4;
+#pragma unroll
+  for (int lv = 0; lv < 3; ++lv) o[size_t(lv * 2 + half) * 64 * 4 + q] = (h[lv][0] >> 16) | h[lv][1];
+}
+}  // namespace
+}  // namespace aa
+
+extern "C" size_t aa_linear_forward_workspace_bytes(int K, int N) {
+  if (K < 1 || N < 1) return 0;
+  return (aa::gemm_packed_elems(K, N) + aa::gemm_bf16x3_words(K, N)) * 4;
+}
+
+extern "C" int aa_linear_forward(int64_t E, int K, int N, const float* x, int64_t ldx, const float* W, int64_t ldk, int64_t ldn, void* workspace,
+                                 size_t workspace_bytes, float* out, int64_t ldo, aa_stream stream) {
+  using namespace aa;
+  AA_REQUIRE(E >= 0 && K >= 32 && N >= 32 && (K % 32) == 0 && (N % 32) == 0, "aa_linear_forward: K and N must be multiples of 32");
+  if (E == 0) return AA_OK;
+  AA_REQUIRE(x && W && out && workspace, "aa_linear_forward: null argument");
+  AA_REQUIRE(workspace_bytes >= aa_linear_forward_workspace_bytes(K, N), "aa_linear_forward: workspace too small");
+  AA_REQUIRE(ldx >= K && ldo >= N && (ldx % 4) == 0 && (ldo % 4) == 0 && ldx <= INT32_MAX && ldo <= INT32_MAX,
+             "aa_linear_forward: row strides must be multiples of 4 elements and at least the row length");
+  AA_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(workspace) % 16 == 0,
+             "aa_linear_forward: x, out and the workspace must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* bp = static_cast<float*>(workspace);
+  unsigned* bq = reinterpret_cast<unsigned*>(bp + gemm_packed_elems(K, N));
+  const int items = ((N + 31) / 32) * ((K + 31) / 32) * 64 * 8;
+  hipLaunchKernelGGL(pack_b_device_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, W, ldk, ldn, K, N, bp, bq);
+  AA_CHECK_HIP(hipGetLastError());
+  GemmArgs g{};
+  g.M = E;
+  g.K = K;
+  g.N = N;
+  g.a = SegList{1, {Seg{const_cast<float*>(x), int(ldx), K}}};
+  g.c = SegList{1, {Seg{out, int(ldo), N}}};
+  g.B = nullptr;  // (only the VALU kernel reads the plain matrix, and this shape never takes it)
+  g.Bp = bp;
+  g.Bq = bq;
+  g.act_kind = AA_ACT_SILU;
+  return launch_gemm<float>(g, s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // test hook (include/allegro_amd.h, "debug entry points"): one plain linear layer C = A @ W through a chosen fp32
 // GEMM kernel, so that the split-precision arithmetic can be bounded directly against an fp64 product
 // ---------------------------------------------------------------------------------------------

@@ -119,6 +119,14 @@ int aa_tp_backward_weights(const aa_tp_plan* plan, int64_t E, int64_t N, const v
 size_t aa_linear_wgrad_workspace_bytes(aa_dtype dtype, int64_t E, int K, int N);
 int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const void* x, int64_t ldx, const void* g, int64_t ldg,
                     void* workspace, size_t workspace_bytes, void* out, aa_stream stream);
+/* The products ALONG the edges of the same layers in training mode: out[E,N] = x[E,K] @ B, B[k][n] = W[k ldk + n ldn] a DEVICE fp32
+ * matrix that may change between calls (W or its transpose, no copy); fp32 through the split-bf16 matrix-core kernel of the inference
+ * pipeline (three exact levels, fp32 accumulation; bounded against fp64 in tests/test_gemm_accuracy.py).  K, N multiples of 32;
+ * row strides multiples of 4 elements, x / out / workspace 16-byte aligned; anything else: AA_ERR_INVALID (callers keep a library GEMM
+ * for those).  `workspace`: aa_linear_forward_workspace_bytes(K, N) bytes of scratch (W in fragment order). */
+size_t aa_linear_forward_workspace_bytes(int K, int N);
+int aa_linear_forward(int64_t E, int K, int N, const float* x, int64_t ldx, const float* W, int64_t ldk, int64_t ldn, void* workspace,
+                      size_t workspace_bytes, float* out, int64_t ldo, aa_stream stream);
 /* MakeWeightedChannels (_channels.py:44-63) as a bilinear form and its two partial contractions; sh [E,D], D = (l_max+1)^2,
  * w [E,u,R] with R = l_max+1 weights per channel (shared != 0: R = 1, `weight_individual_irreps=False`), t [E,u,D]:
  *   which 0:  out[E,u,D] = a=sh (x) b=w           out[e,c,i] = sh[e,i] w[e,c,r(i)]

@@ -571,6 +571,38 @@ def _(x, g, h, order, lib_id):
     return torch.empty_like(x, memory_format=torch.contiguous_format), torch.empty_like(x, memory_format=torch.contiguous_format)
 
 
+def _linear_forward_ok(x: torch.Tensor, W: torch.Tensor) -> bool:
+    return (x.dtype == torch.float32 and x.dim() == 2 and W.dim() == 2 and x.shape[1] % 32 == 0 and W.shape[1] % 32 == 0 and x.shape[1] >= 32
+            and W.shape[1] >= 32 and x.shape[0] > 0)
+
+
+@torch.library.custom_op("allegro_amd::linear_forward", mutates_args=())
+def linear_forward_op(x: torch.Tensor, W: torch.Tensor, lib_id: int) -> torch.Tensor:
+    """`aa_linear_forward`: x [E,K] @ W [K,N] (W any strides: a transposed view costs no copy) on the split-bf16 matrix-core kernel."""
+    lib = _resolve(lib_id)
+    _check_device(lib, x, "allegro_amd::linear_forward")
+    xc = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+    E, K, N = xc.shape[0], xc.shape[1], W.shape[1]
+    out = torch.empty((E, N), dtype=x.dtype, device=x.device)
+    nbytes = lib.lib.aa_linear_forward_workspace_bytes(K, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    lib.check(lib.lib.aa_linear_forward(E, K, N, xc.data_ptr(), xc.stride(0), W.data_ptr(), W.stride(0), W.stride(1), ws.data_ptr(), nbytes,
+                                        out.data_ptr(), N, _stream_ptr(x)), "aa_linear_forward")
+    return out
+
+
+@linear_forward_op.register_fake
+def _(x, W, lib_id):
+    return x.new_empty((x.shape[0], W.shape[1]))
+
+
+def _matmul(x: torch.Tensor, W: torch.Tensor, lib_id: int) -> torch.Tensor:
+    """x @ W for a per-edge layer: the hand-written kernel where its shape rules hold, the library GEMM otherwise."""
+    if _linear_forward_ok(x, W):
+        return torch.ops.allegro_amd.linear_forward(x, W, lib_id)
+    return x @ W
+
+
 class _Silu(torch.autograd.Function):
     """A_k(x, g) = g f^(k)(x) with f = SiLU (g None: f^(k)(x)).  d/dx = A_{k+1}(x, g .), d/dg = A_k(x, .): closed under
     differentiation, one launch per member; where no further derivative is recorded (the backward pass of the loss) both gradients
@@ -611,7 +643,7 @@ class _MM(torch.autograd.Function):
     def forward(ctx, x, W, lib_id):
         ctx.lib_id = lib_id
         ctx.save_for_backward(x, W)
-        return x @ W
+        return _matmul(x.detach(), W.detach(), lib_id)
 
     @staticmethod
     def backward(ctx, g):

@@ -127,6 +127,42 @@ def _silu_case(lib, dev):
             assert (pa - outs[1][3]).abs().max().item() <= tol * max(1.0, float(outs[1][3].abs().max()))
 
 
+def _linear_forward_case(lib, dev):
+    """`aa_linear_forward` (device weights packed per call, split-bf16 matrix-core kernel) against an fp64 product: plain, transposed
+    weight view, row-strided operand; and the library-GEMM fallback of `ops.linear` for shapes outside its rules."""
+    lid = _lib_id(lib)
+    g = torch.Generator().manual_seed(5)
+    for E, K, N, pad, transposed in ((300, 64, 192, 0, False), (513, 192, 64, 64, False), (129, 256, 64, 0, True), (77, 32, 32, 0, True)):
+        xb = torch.randn(E, K + pad, generator=g).to(dev)
+        x = xb[:, :K]
+        W = (torch.randn(N, K, generator=g).to(dev).t() if transposed else torch.randn(K, N, generator=g).to(dev))
+        got = torch.ops.allegro_amd.linear_forward(x, W, lid)
+        want = x.double() @ W.double()
+        assert got.shape == (E, N) and (got.double() - want).abs().max().item() <= 3e-6 * K ** 0.5 * float(want.abs().max()), (E, K, N)
+    # through the autograd pair, second order, against plain matmuls (fp32 tolerances)
+    x0 = torch.randn(200, 64, generator=g).to(dev)
+    W0 = torch.randn(64, 96, generator=g).to(dev)
+    res = []
+    for hand in (True, False):
+        x, W = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+        y = ops.linear(x, W, lid) if hand else x @ W
+        (gx,) = torch.autograd.grad((y ** 2).sum(), x, create_graph=True)
+        res.append([y.detach(), gx.detach()] + [v for v in torch.autograd.grad((gx ** 2).sum(), [x, W])])
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_linear_forward_emulated():
+    from tests.hip_utils import emu_lib
+
+    _linear_forward_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_linear_forward_on_gpu():
+    _linear_forward_case(None, torch.device("cuda:0"))
+
+
 def test_silu_family_emulated():
     from tests.hip_utils import emu_lib
 
