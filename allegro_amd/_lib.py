@@ -143,14 +143,17 @@ class AllegroLib:
         L.aa_linear_forward.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_int64, C.c_void_p]
         L.aa_linear_forward.restype = C.c_int
-        L.aa_weighted_channels.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_weighted_channels.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_void_p]
         L.aa_weighted_channels.restype = C.c_int
-        L.aa_weighted_channels_pair.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_void_p, C.c_void_p]
+        L.aa_weighted_channels_pair.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_weighted_channels_pair.restype = C.c_int
-        L.aa_weighted_channels_sum.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_void_p]
+        L.aa_weighted_channels_sum.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.aa_weighted_channels_sum.restype = C.c_int
+        L.aa_scalar_column.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_scalar_column.restype = C.c_int
         L.aa_silu_derivative.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_silu_derivative.restype = C.c_int
         L.aa_silu_derivative_pair.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

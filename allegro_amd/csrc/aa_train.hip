@@ -186,8 +186,8 @@ __device__ __forceinline__ int irrep_of(int i) { return i < 1 ? 0 : (i < 4 ? 1 :
 constexpr int kWcSlots = 8, kWcMaxGroup = 16, kWcLdsBytes = 32768;
 template <typename T, int D, bool TWO, int NS>  // NS: slots per thread, 256 NS >= u D
 __global__ __launch_bounds__(256) void wc_forward_slots_kernel(int64_t E, int u, int R, int G, const T* __restrict__ sh,
-                                                               const T* __restrict__ w, const T* __restrict__ sh2, const T* __restrict__ w2,
-                                                               T* __restrict__ out) {
+                                                               const T* __restrict__ w, int64_t ldw, const T* __restrict__ sh2,
+                                                               const T* __restrict__ w2, int64_t ldw2, T* __restrict__ out) {
   T* ly = reinterpret_cast<T*>(aa_smem);  // [G][D] | [G][u R] (| the same for the second term)
   const int row = u * D, wrow = u * R;
   T* lw = ly + G * D;
@@ -199,9 +199,10 @@ __global__ __launch_bounds__(256) void wc_forward_slots_kernel(int64_t E, int u,
     ly[k] = sh[e0 * D + k];
     if (TWO) ly2[k] = sh2[e0 * D + k];
   }
-  for (int k = threadIdx.x; k < n * wrow; k += 256) {
-    lw[k] = w[e0 * wrow + k];
-    if (TWO) lw2[k] = w2[e0 * wrow + k];
+  for (int k = threadIdx.x; k < n * wrow; k += 256) {  // (weight rows may be a column block of a wider matrix: row stride ldw)
+    const int j = k / wrow, c = k - j * wrow;
+    lw[k] = w[(e0 + j) * ldw + c];
+    if (TWO) lw2[k] = w2[(e0 + j) * ldw2 + c];
   }
   int oy[NS], ow[NS];
 #pragma unroll
@@ -229,14 +230,15 @@ __global__ __launch_bounds__(256) void wc_forward_slots_kernel(int64_t E, int u,
 constexpr int kWcEdges = 8;
 template <typename T, int D, bool TWO>
 __global__ __launch_bounds__(256) void wc_forward_kernel(int64_t E, int u, int R, const T* __restrict__ sh, const T* __restrict__ w,
-                                                         const T* __restrict__ sh2, const T* __restrict__ w2, T* __restrict__ out) {
+                                                         int64_t ldw, const T* __restrict__ sh2, const T* __restrict__ w2, int64_t ldw2,
+                                                         T* __restrict__ out) {
   const int64_t e0 = int64_t(blockIdx.x) * kWcEdges;
   const int row = u * D;
   const int total = int(E - e0 < kWcEdges ? E - e0 : int64_t(kWcEdges)) * row;
   const T* y = sh + e0 * D;
-  const T* wr = w + e0 * int64_t(u) * R;
+  const T* wr = w + e0 * ldw;
   const T* y2 = TWO ? sh2 + e0 * D : nullptr;
-  const T* wr2 = TWO ? w2 + e0 * int64_t(u) * R : nullptr;
+  const T* wr2 = TWO ? w2 + e0 * ldw2 : nullptr;
   T* o = out + e0 * int64_t(row);
   for (int t0 = threadIdx.x; t0 < total; t0 += 1024) {
     T v[4];
@@ -246,9 +248,9 @@ __global__ __launch_bounds__(256) void wc_forward_kernel(int64_t E, int u, int R
       v[k] = T(0);
       if (t < total) {
         const int cg = t / D, i = t - cg * D;  // (channel of the span, component)
-        const int iy = (cg / u) * D + i, iw = cg * R + (R == 1 ? 0 : irrep_of(i));
-        v[k] = y[iy] * wr[iw];
-        if (TWO) v[k] += y2[iy] * wr2[iw];
+        const int q = cg / u, iy = q * D + i, iw = (cg - q * u) * R + (R == 1 ? 0 : irrep_of(i));
+        v[k] = y[iy] * wr[q * ldw + iw];
+        if (TWO) v[k] += y2[iy] * wr2[q * ldw2 + iw];
       }
     }
 #pragma unroll
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void wc_grad_w_kernel(int64_t EC, int u, int R
 
 // gsh[e,i] = sum_c g[e,c,i] w[e,c,r(i)]: one wave per edge, lanes over channels, D wave sums
 template <typename T, int D>
-__global__ __launch_bounds__(256) void wc_grad_sh_kernel(int64_t E, int u, int R, const T* g, const T* w, T* gsh) {
+__global__ __launch_bounds__(256) void wc_grad_sh_kernel(int64_t E, int u, int R, const T* g, const T* w, int64_t ldw, T* gsh) {
   const int lane = threadIdx.x & 63;
   const int64_t e = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (e >= E) return;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void wc_grad_sh_kernel(int64_t E, int u, int R
   for (int i = 0; i < D; ++i) acc[i] = T(0);
   for (int c = lane; c < u; c += 64) {
     const T* gr = g + (e * u + c) * D;
-    const T* wr = w + (e * u + c) * R;
+    const T* wr = w + e * ldw + c * R;
     T wv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wv[r] = r < R ? wr[r] : T(0);
@@ -312,7 +314,7 @@ __device__ __forceinline__ int wc_patch_index(int q) {  // element q of a 64-cha
 constexpr int kWcPairEdges = 4;
 template <typename T, int D>
 __global__ __launch_bounds__(256) void wc_grad_pair_kernel(int64_t E, int u, int R, const T* __restrict__ t, const T* __restrict__ sh,
-                                                           const T* __restrict__ w, T* __restrict__ gsh, T* __restrict__ gw) {
+                                                           const T* __restrict__ w, int64_t ldw, T* __restrict__ gsh, T* __restrict__ gw) {
   constexpr int DP = D | 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* patch = reinterpret_cast<T*>(aa_smem) + wave * 64 * DP;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void wc_grad_pair_kernel(int64_t E, int u, int
     for (int i = 0; i < D; ++i) x[i] = patch[lane * DP + i];
     if (it + 1 < items) fetch(it + 1, r);
     if (c < u) {
-      const T* wr = w + (e * u + c) * R;
+      const T* wr = w + e * ldw + c * R;
       T wv[4], s4[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
       for (int q = 0; q < 4; ++q) wv[q] = q < R ? wr[q] : T(0);
@@ -426,6 +428,21 @@ __global__ __launch_bounds__(256) void silu_family_kernel(int64_t n, int k, cons
   }
 }
 
+// out[r, i] = a[r, i] + (i == 0 ? s[r] : 0) over rows of D elements (a == nullptr: zeros): the scalar (l = 0) components of a tensor
+// feature are ALSO an input of the next latent MLP (`features[:, :, 0]`, _allegro.py:275-283), so the feature's gradient is the sum of
+// the tensor-product gradient and the MLP's, padded -- one pass instead of a zero fill, a strided copy and an addition.
+template <typename T, int DC>  // DC: the row length when it is one of the usual ones, 0: any (run-time division)
+__global__ __launch_bounds__(256) void scalar_column_kernel(int64_t n, int d_any, const T* __restrict__ a, const T* __restrict__ s,
+                                                            T* __restrict__ out) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int D = DC ? DC : d_any;
+  const int64_t r = t / D;
+  const int i = int(t - r * D);
+  const T v = a ? a[t] : T(0);
+  out[t] = i == 0 ? v + s[r] : v;
+}
+
 }  // namespace
 }  // namespace aa
 
@@ -481,96 +498,100 @@ extern "C" int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const vo
 }
 
 template <typename T, int D, bool TWO, int NS>
-static void wc_launch_slots(int64_t E, int u, int R, const T* sh, const T* w, const T* sh2, const T* w2, T* out, hipStream_t s) {
+static void wc_launch_slots(int64_t E, int u, int R, const T* sh, const T* w, int64_t ldw, const T* sh2, const T* w2, int64_t ldw2, T* out,
+                            hipStream_t s) {
   const size_t per_edge = sizeof(T) * size_t(u * R + D) * (TWO ? 2 : 1);
   const int G = int(std::max<size_t>(1, std::min<size_t>(aa::kWcMaxGroup, aa::kWcLdsBytes / per_edge)));
   hipLaunchKernelGGL((aa::wc_forward_slots_kernel<T, D, TWO, NS>), dim3((unsigned)((E + G - 1) / G)), dim3(256), per_edge * G, s, E, u, R, G, sh, w,
-                     sh2, w2, out);
+                     ldw, sh2, w2, ldw2, out);
 }
 template <typename T, int D, bool TWO>
-static void wc_launch_forward(int64_t E, int u, int R, const T* sh, const T* w, const T* sh2, const T* w2, T* out, hipStream_t s) {
+static void wc_launch_forward(int64_t E, int u, int R, const T* sh, const T* w, int64_t ldw, const T* sh2, const T* w2, int64_t ldw2, T* out,
+                              hipStream_t s) {
   const int ns = (u * D + 255) / 256;
-  if (ns <= 1) wc_launch_slots<T, D, TWO, 1>(E, u, R, sh, w, sh2, w2, out, s);
-  else if (ns == 2) wc_launch_slots<T, D, TWO, 2>(E, u, R, sh, w, sh2, w2, out, s);
-  else if (ns == 3) wc_launch_slots<T, D, TWO, 3>(E, u, R, sh, w, sh2, w2, out, s);
-  else if (ns == 4) wc_launch_slots<T, D, TWO, 4>(E, u, R, sh, w, sh2, w2, out, s);
-  else if (ns == 5) wc_launch_slots<T, D, TWO, 5>(E, u, R, sh, w, sh2, w2, out, s);
-  else if (ns <= aa::kWcSlots) wc_launch_slots<T, D, TWO, aa::kWcSlots>(E, u, R, sh, w, sh2, w2, out, s);
+  if (ns <= 1) wc_launch_slots<T, D, TWO, 1>(E, u, R, sh, w, ldw, sh2, w2, ldw2, out, s);
+  else if (ns == 2) wc_launch_slots<T, D, TWO, 2>(E, u, R, sh, w, ldw, sh2, w2, ldw2, out, s);
+  else if (ns == 3) wc_launch_slots<T, D, TWO, 3>(E, u, R, sh, w, ldw, sh2, w2, ldw2, out, s);
+  else if (ns == 4) wc_launch_slots<T, D, TWO, 4>(E, u, R, sh, w, ldw, sh2, w2, ldw2, out, s);
+  else if (ns == 5) wc_launch_slots<T, D, TWO, 5>(E, u, R, sh, w, ldw, sh2, w2, ldw2, out, s);
+  else if (ns <= aa::kWcSlots) wc_launch_slots<T, D, TWO, aa::kWcSlots>(E, u, R, sh, w, ldw, sh2, w2, ldw2, out, s);
   else
     hipLaunchKernelGGL((aa::wc_forward_kernel<T, D, TWO>), dim3((unsigned)((E + aa::kWcEdges - 1) / aa::kWcEdges)), dim3(256), 0, s, E, u, R, sh,
-                       w, sh2, w2, out);
+                       w, ldw, sh2, w2, ldw2, out);
 }
 
-// which 0..2: the three single forms; 3: out = p0 (x) p1 + p2 (x) p3; 4: the pair (out, out2) = (t . w, t . sh) with t = p0, sh = p1, w = p2
+// which 0..2: the three single forms; 3: out = p0 (x) p1 + p2 (x) p3; 4: the pair (out, out2) = (t . w, t . sh) with t = p0, sh = p1, w = p2.
+// ldw / ldw2: row strides of the weight operands (which 0: p1, 2: p1, 3: p1 and p3, 4: p2)
 template <typename T, int D>
-static int wc_launch_d(int which, int64_t E, int u, int R, const void* p0, const void* p1, const void* p2, const void* p3, void* out, void* out2,
-                       hipStream_t s) {
+static int wc_launch_d(int which, int64_t E, int u, int R, const void* p0, const void* p1, const void* p2, const void* p3, int64_t ldw, int64_t ldw2,
+                       void* out, void* out2, hipStream_t s) {
   const int64_t EC = E * u;
   const T *a = static_cast<const T*>(p0), *b = static_cast<const T*>(p1), *c = static_cast<const T*>(p2), *d = static_cast<const T*>(p3);
   if (which == 0) {
-    wc_launch_forward<T, D, false>(E, u, R, a, b, nullptr, nullptr, static_cast<T*>(out), s);
+    wc_launch_forward<T, D, false>(E, u, R, a, b, ldw, nullptr, nullptr, 0, static_cast<T*>(out), s);
   } else if (which == 3) {
-    wc_launch_forward<T, D, true>(E, u, R, a, b, c, d, static_cast<T*>(out), s);
+    wc_launch_forward<T, D, true>(E, u, R, a, b, ldw, c, d, ldw2, static_cast<T*>(out), s);
   } else if (which == 1) {
     hipLaunchKernelGGL((aa::wc_grad_w_kernel<T, D>), dim3((unsigned)((EC + 255) / 256)), dim3(256), 0, s, EC, u, R, a, b, static_cast<T*>(out));
   } else if (which == 2) {
-    hipLaunchKernelGGL((aa::wc_grad_sh_kernel<T, D>), dim3((unsigned)((E + 3) / 4)), dim3(256), 0, s, E, u, R, a, b, static_cast<T*>(out));
+    hipLaunchKernelGGL((aa::wc_grad_sh_kernel<T, D>), dim3((unsigned)((E + 3) / 4)), dim3(256), 0, s, E, u, R, a, b, ldw, static_cast<T*>(out));
   } else {
     hipLaunchKernelGGL((aa::wc_grad_pair_kernel<T, D>), dim3((unsigned)((E + 4 * aa::kWcPairEdges - 1) / (4 * aa::kWcPairEdges))), dim3(256),
-                       sizeof(T) * 4 * 64 * (D | 1), s, E, u, R, a, b, c, static_cast<T*>(out),
-                       static_cast<T*>(out2));
+                       sizeof(T) * 4 * 64 * (D | 1), s, E, u, R, a, b, c, ldw, static_cast<T*>(out), static_cast<T*>(out2));
   }
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
 
 template <typename T>
-static int wc_launch(int which, int64_t E, int u, int D, int R, const void* p0, const void* p1, const void* p2, const void* p3, void* out,
-                     void* out2, hipStream_t s) {
+static int wc_launch(int which, int64_t E, int u, int D, int R, const void* p0, const void* p1, const void* p2, const void* p3, int64_t ldw,
+                     int64_t ldw2, void* out, void* out2, hipStream_t s) {
   if (E == 0) return AA_OK;
   switch (D) {
-    case 1: return wc_launch_d<T, 1>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
-    case 4: return wc_launch_d<T, 4>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
-    case 9: return wc_launch_d<T, 9>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
-    default: return wc_launch_d<T, 16>(which, E, u, R, p0, p1, p2, p3, out, out2, s);
+    case 1: return wc_launch_d<T, 1>(which, E, u, R, p0, p1, p2, p3, ldw, ldw2, out, out2, s);
+    case 4: return wc_launch_d<T, 4>(which, E, u, R, p0, p1, p2, p3, ldw, ldw2, out, out2, s);
+    case 9: return wc_launch_d<T, 9>(which, E, u, R, p0, p1, p2, p3, ldw, ldw2, out, out2, s);
+    default: return wc_launch_d<T, 16>(which, E, u, R, p0, p1, p2, p3, ldw, ldw2, out, out2, s);
   }
 }
 
-static int wc_check(const char* what, int64_t E, int u, int l_max) {
+static int wc_check(const char* what, int64_t E, int u, int l_max, int R, int64_t ldw, int64_t ldw2) {
   if (!(E >= 0 && u >= 1 && l_max >= 0 && l_max <= 3)) return aa::fail(AA_ERR_INVALID, std::string(what) + ": bad argument");
   if (!(E * int64_t(u) * 16 < (int64_t(1) << 40))) return aa::fail(AA_ERR_INVALID, std::string(what) + ": too large");
+  if (ldw < int64_t(u) * R || ldw2 < int64_t(u) * R) return aa::fail(AA_ERR_INVALID, std::string(what) + ": weight row stride shorter than u R");
   return AA_OK;
 }
 
-extern "C" int aa_weighted_channels(aa_dtype dtype, int which, int64_t E, int u, int l_max, int shared, const void* a, const void* b, void* out,
-                                    aa_stream stream) {
+extern "C" int aa_weighted_channels(aa_dtype dtype, int which, int64_t E, int u, int l_max, int shared, const void* a, const void* b, int64_t ldw,
+                                    void* out, aa_stream stream) {
   AA_REQUIRE(which >= 0 && which <= 2, "aa_weighted_channels: bad argument");
-  if (int rc = wc_check("aa_weighted_channels", E, u, l_max)) return rc;
-  AA_REQUIRE(E == 0 || (a && b && out), "aa_weighted_channels: null argument");
   const int D = (l_max + 1) * (l_max + 1), R = shared ? 1 : l_max + 1;
+  if (which == 1) ldw = int64_t(u) * R;  // (no weight operand)
+  if (int rc = wc_check("aa_weighted_channels", E, u, l_max, R, ldw, ldw)) return rc;
+  AA_REQUIRE(E == 0 || (a && b && out), "aa_weighted_channels: null argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == AA_F32 ? wc_launch<float>(which, E, u, D, R, a, b, nullptr, nullptr, out, nullptr, s)
-                         : wc_launch<double>(which, E, u, D, R, a, b, nullptr, nullptr, out, nullptr, s);
+  return dtype == AA_F32 ? wc_launch<float>(which, E, u, D, R, a, b, nullptr, nullptr, ldw, 0, out, nullptr, s)
+                         : wc_launch<double>(which, E, u, D, R, a, b, nullptr, nullptr, ldw, 0, out, nullptr, s);
 }
 
-extern "C" int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, const void* sh2,
-                                        const void* w2, void* out, aa_stream stream) {
-  if (int rc = wc_check("aa_weighted_channels_sum", E, u, l_max)) return rc;
-  AA_REQUIRE(E == 0 || (sh && w && sh2 && w2 && out), "aa_weighted_channels_sum: null argument");
+extern "C" int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, int64_t ldw,
+                                        const void* sh2, const void* w2, int64_t ldw2, void* out, aa_stream stream) {
   const int D = (l_max + 1) * (l_max + 1), R = shared ? 1 : l_max + 1;
+  if (int rc = wc_check("aa_weighted_channels_sum", E, u, l_max, R, ldw, ldw2)) return rc;
+  AA_REQUIRE(E == 0 || (sh && w && sh2 && w2 && out), "aa_weighted_channels_sum: null argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == AA_F32 ? wc_launch<float>(3, E, u, D, R, sh, w, sh2, w2, out, nullptr, s)
-                         : wc_launch<double>(3, E, u, D, R, sh, w, sh2, w2, out, nullptr, s);
+  return dtype == AA_F32 ? wc_launch<float>(3, E, u, D, R, sh, w, sh2, w2, ldw, ldw2, out, nullptr, s)
+                         : wc_launch<double>(3, E, u, D, R, sh, w, sh2, w2, ldw, ldw2, out, nullptr, s);
 }
 
 extern "C" int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* t, const void* sh, const void* w,
-                                         void* out_sh, void* out_w, aa_stream stream) {
-  if (int rc = wc_check("aa_weighted_channels_pair", E, u, l_max)) return rc;
-  AA_REQUIRE(E == 0 || (t && sh && w && out_sh && out_w), "aa_weighted_channels_pair: null argument");
+                                         int64_t ldw, void* out_sh, void* out_w, aa_stream stream) {
   const int D = (l_max + 1) * (l_max + 1), R = shared ? 1 : l_max + 1;
+  if (int rc = wc_check("aa_weighted_channels_pair", E, u, l_max, R, ldw, ldw)) return rc;
+  AA_REQUIRE(E == 0 || (t && sh && w && out_sh && out_w), "aa_weighted_channels_pair: null argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return dtype == AA_F32 ? wc_launch<float>(4, E, u, D, R, t, sh, w, nullptr, out_sh, out_w, s)
-                         : wc_launch<double>(4, E, u, D, R, t, sh, w, nullptr, out_sh, out_w, s);
+  return dtype == AA_F32 ? wc_launch<float>(4, E, u, D, R, t, sh, w, nullptr, ldw, ldw, out_sh, out_w, s)
+                         : wc_launch<double>(4, E, u, D, R, t, sh, w, nullptr, ldw, ldw, out_sh, out_w, s);
 }
 
 static int silu_launch(const char* what, aa_dtype dtype, int order, int64_t n, const void* x, const void* g, const void* h, void* out0, void* out1,
@@ -601,4 +622,24 @@ extern "C" int aa_silu_derivative_pair(aa_dtype dtype, int order, int64_t n, con
                                        aa_stream stream) {
   if (!h && n > 0) return aa::fail(AA_ERR_INVALID, "aa_silu_derivative_pair: null argument");
   return silu_launch("aa_silu_derivative_pair", dtype, order, n, x, g, h, out_x, out_g, stream);
+}
+
+extern "C" int aa_scalar_column(aa_dtype dtype, int64_t rows, int D, const void* a, const void* s, void* out, aa_stream stream) {
+  AA_REQUIRE(rows >= 0 && D >= 1 && D <= 4096, "aa_scalar_column: bad argument");
+  if (rows == 0) return AA_OK;
+  AA_REQUIRE(s && out, "aa_scalar_column: null argument");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t n = rows * D;
+  const dim3 grid((unsigned)((n + 255) / 256));
+#define AA_SC(T, DD)                                                                                                                         \
+  hipLaunchKernelGGL((aa::scalar_column_kernel<T, DD>), grid, dim3(256), 0, st, n, D, static_cast<const T*>(a), static_cast<const T*>(s), \
+                     static_cast<T*>(out))
+  if (dtype == AA_F32) {
+    if (D == 4) AA_SC(float, 4); else if (D == 9) AA_SC(float, 9); else if (D == 16) AA_SC(float, 16); else AA_SC(float, 0);
+  } else {
+    if (D == 4) AA_SC(double, 4); else if (D == 9) AA_SC(double, 9); else if (D == 16) AA_SC(double, 16); else AA_SC(double, 0);
+  }
+#undef AA_SC
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
 }

@@ -133,16 +133,20 @@ int aa_linear_forward(int64_t E, int K, int N, const float* x, int64_t ldx, cons
  *   which 1:  out[E,u,R] = a=t  . b=sh            out[e,c,r] = sum_{i in r} t[e,c,i] sh[e,i]
  *   which 2:  out[E,D]   = a=t  . b=w             out[e,i]   = sum_c t[e,c,i] w[e,c,r(i)]
  * Each is one pass over the [E,u,D] operand; the three are closed under differentiation (any derivative of one is another
- * with operands substituted), which is what a force-matching loss needs. */
-int aa_weighted_channels(aa_dtype dtype, int which, int64_t E, int u, int l_max, int shared, const void* a, const void* b,
+ * with operands substituted), which is what a force-matching loss needs.  `ldw`: row stride (elements, >= u R) of the weight operand
+ * (which 0 and 2: b) -- the weights are usually a column block of a wider MLP output; ignored for which 1. */
+int aa_weighted_channels(aa_dtype dtype, int which, int64_t E, int u, int l_max, int shared, const void* a, const void* b, int64_t ldw,
                          void* out, aa_stream stream);
 /* The two combinations every derivative of the forms above asks for, each in one pass over the [E,u,D] tensor instead of two or
  * three:  _pair: out_sh[E,D] = t . w (which 2) AND out_w[E,u,R] = t . sh (which 1) from one read of t;
  *         _sum:  out[E,u,D] = sh (x) w + sh2 (x) w2 (the gradient of the pair with respect to t) with one store stream. */
-int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* t, const void* sh, const void* w,
+int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* t, const void* sh, const void* w, int64_t ldw,
                               void* out_sh, void* out_w, aa_stream stream);
-int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, const void* sh2,
-                             const void* w2, void* out, aa_stream stream);
+int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, int64_t ldw, const void* sh2,
+                             const void* w2, int64_t ldw2, void* out, aa_stream stream);
+/* out[rows, D] = a (NULL: zeros) with s[rows] added to component 0 of every row: the gradient of a tensor feature whose scalar components
+ * also feed the next latent MLP (`features[:, :, 0]`, _allegro.py:275-283), in one pass. */
+int aa_scalar_column(aa_dtype dtype, int64_t rows, int D, const void* a, const void* s, void* out, aa_stream stream);
 /* The hidden activation of the scalar MLPs (ScalarMLPFunction with SiLU; _allegro.py:192-213) and its derivatives, elementwise over n
  * values: A_k(x, g) = g f^(k)(x), f(x) = x sigmoid(x), k = `order` in 0..3; g may be NULL (= 1).  The family is closed under
  * differentiation: d A_k/dx . h = A_{k+1}(x, g h), d A_k/dg . h = A_k(x, h); `_pair` returns both from one pass:

@@ -469,18 +469,44 @@ def _(x, g, lib_id):
     return x.new_empty((x.shape[1], g.shape[1]))
 
 
+def _rows_ok(w: torch.Tensor) -> torch.Tensor:
+    """`w` itself if its rows are contiguous runs (any row stride), a contiguous copy otherwise."""
+    return w if (w.dim() == 2 and w.stride(1) == 1 and w.stride(0) >= w.shape[1]) else w.contiguous()
+
+
+@torch.library.custom_op("allegro_amd::scalar_column", mutates_args=())
+def scalar_column_op(a: Optional[torch.Tensor], s: torch.Tensor, D: int, lib_id: int) -> torch.Tensor:
+    """`aa_scalar_column`: [E,u,D] = a (None: zeros) with s [E,u] added to component 0."""
+    lib = _resolve(lib_id)
+    _check_device(lib, s, "allegro_amd::scalar_column")
+    sc = s.contiguous()
+    ac = None if a is None else a.contiguous()
+    E, u = sc.shape
+    out = torch.empty((E, u, D), dtype=s.dtype, device=s.device)
+    lib.check(lib.lib.aa_scalar_column(_dtype_code(s), E * u, D, ac.data_ptr() if (ac is not None and E) else None, sc.data_ptr() if E else None,
+                                       out.data_ptr() if E else None, _stream_ptr(s)), "aa_scalar_column")
+    return out
+
+
+@scalar_column_op.register_fake
+def _(a, s, D, lib_id):
+    return s.new_empty((s.shape[0], s.shape[1], D))
+
+
 @torch.library.custom_op("allegro_amd::weighted_channels", mutates_args=())
 def weighted_channels_op(which: int, a: torch.Tensor, b: torch.Tensor, u: int, l_max: int, shared: bool, lib_id: int) -> torch.Tensor:
     """`aa_weighted_channels`: which 0: sh [E,D] (x) w [E,u*R] -> [E,u,D];  1: t [E,u,D] . sh -> [E,u*R];  2: t . w -> [E,D]."""
     lib = _resolve(lib_id)
     _check_device(lib, a, "allegro_amd::weighted_channels")
-    ac, bc = a.contiguous(), b.contiguous()
+    ac = a.contiguous()
+    bc = _rows_ok(b) if which != 1 else b.contiguous()  # (the weight operand keeps its row stride: a column block of an MLP output)
     E = ac.shape[0]
     D, R = (l_max + 1) ** 2, (1 if shared else l_max + 1)
     shape = ((E, u, D), (E, u * R), (E, D))[which]
     out = torch.empty(shape, dtype=a.dtype, device=a.device)
     lib.check(lib.lib.aa_weighted_channels(_dtype_code(a), which, E, u, l_max, int(shared), ac.data_ptr() if E else None,
-                                           bc.data_ptr() if E else None, out.data_ptr() if E else None, _stream_ptr(a)), "aa_weighted_channels")
+                                           bc.data_ptr() if E else None, bc.stride(0) if (E and which != 1) else u * R,
+                                           out.data_ptr() if E else None, _stream_ptr(a)), "aa_weighted_channels")
     return out
 
 
@@ -496,14 +522,14 @@ def weighted_channels_pair_op(t: torch.Tensor, sh: torch.Tensor, w: torch.Tensor
     """`aa_weighted_channels_pair`: (t . w [E,D], t . sh [E,u*R]) from one pass over t [E,u,D]."""
     lib = _resolve(lib_id)
     _check_device(lib, t, "allegro_amd::weighted_channels_pair")
-    tc, sc, wc = t.contiguous(), sh.contiguous(), w.contiguous()
+    tc, sc, wc = t.contiguous(), sh.contiguous(), _rows_ok(w)
     E = tc.shape[0]
     D, R = (l_max + 1) ** 2, (1 if shared else l_max + 1)
     o_sh = torch.empty((E, D), dtype=t.dtype, device=t.device)
     o_w = torch.empty((E, u * R), dtype=t.dtype, device=t.device)
     p = (lambda x: x.data_ptr() if E else None)
-    lib.check(lib.lib.aa_weighted_channels_pair(_dtype_code(t), E, u, l_max, int(shared), p(tc), p(sc), p(wc), p(o_sh), p(o_w), _stream_ptr(t)),
-              "aa_weighted_channels_pair")
+    lib.check(lib.lib.aa_weighted_channels_pair(_dtype_code(t), E, u, l_max, int(shared), p(tc), p(sc), p(wc), wc.stride(0) if E else u * R,
+                                                p(o_sh), p(o_w), _stream_ptr(t)), "aa_weighted_channels_pair")
     return o_sh, o_w
 
 
@@ -519,13 +545,13 @@ def weighted_channels_sum_op(sh: torch.Tensor, w: torch.Tensor, sh2: torch.Tenso
     """`aa_weighted_channels_sum`: sh (x) w + sh2 (x) w2 -> [E,u,D], one store stream."""
     lib = _resolve(lib_id)
     _check_device(lib, sh, "allegro_amd::weighted_channels_sum")
-    a, b, c, d = sh.contiguous(), w.contiguous(), sh2.contiguous(), w2.contiguous()
+    a, b, c, d = sh.contiguous(), _rows_ok(w), sh2.contiguous(), _rows_ok(w2)
     E = a.shape[0]
-    D = (l_max + 1) ** 2
+    D, R = (l_max + 1) ** 2, (1 if shared else l_max + 1)
     out = torch.empty((E, u, D), dtype=sh.dtype, device=sh.device)
     p = (lambda x: x.data_ptr() if E else None)
-    lib.check(lib.lib.aa_weighted_channels_sum(_dtype_code(sh), E, u, l_max, int(shared), p(a), p(b), p(c), p(d), p(out), _stream_ptr(sh)),
-              "aa_weighted_channels_sum")
+    lib.check(lib.lib.aa_weighted_channels_sum(_dtype_code(sh), E, u, l_max, int(shared), p(a), p(b), b.stride(0) if E else u * R, p(c), p(d),
+                                               d.stride(0) if E else u * R, p(out), _stream_ptr(sh)), "aa_weighted_channels_sum")
     return out
 
 
@@ -787,7 +813,76 @@ def weighted_channels(sh: torch.Tensor, w: torch.Tensor, u: int, l_max: int, lib
     """MakeWeightedChannels (allegro/nn/_strided/_channels.py:44-63) -> [E,u,D], differentiable to any order, one kernel pass per
     evaluation.  `w` [E, u (l_max+1)] (one weight per channel and irrep) or [E, u] (`weight_individual_irreps=False`)."""
     shared = w.shape[1] == u and l_max > 0
-    return _WcB.apply(sh.contiguous(), w.contiguous(), (int(u), int(l_max), bool(shared), int(lib_id)))
+    return _WcB.apply(sh.contiguous(), _rows_ok(w), (int(u), int(l_max), bool(shared), int(lib_id)))
+
+
+class _TakeCol0(torch.autograd.Function):
+    """t[:, :, 0] of a tensor feature [E,u,D] as a contiguous [E,u]; its transpose is the zero-padded form of `_AddCol0`."""
+
+    @staticmethod
+    def forward(ctx, t, lib_id):
+        ctx.D, ctx.lib_id = t.shape[2], lib_id
+        return t[:, :, 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _AddCol0.apply(None, g, ctx.D, ctx.lib_id), None
+
+
+class _AddCol0(torch.autograd.Function):
+    """a [E,u,D] (None: zeros) with s [E,u] added to component 0 -- one pass (`aa_scalar_column`)."""
+
+    @staticmethod
+    def forward(ctx, a, s, D, lib_id):
+        ctx.has_a, ctx.lib_id = a is not None, lib_id
+        return torch.ops.allegro_amd.scalar_column(None if a is None else a.detach(), s.detach(), D, lib_id)
+
+    @staticmethod
+    def backward(ctx, h):
+        n = ctx.needs_input_grad
+        return (h if (ctx.has_a and n[0]) else None, _TakeCol0.apply(h, ctx.lib_id) if n[1] else None, None, None)
+
+
+class _Fork0(torch.autograd.Function):
+    """(t, t[:, :, 0]) as ONE node: the tensor feature goes on to the next tensor product, its scalars to the next latent MLP
+    (_allegro.py:275-283); the two gradients meet here and are merged in one pass instead of autograd's zero fill + strided copy +
+    addition of two [E,u,D] buffers."""
+
+    @staticmethod
+    def forward(ctx, t, lib_id):
+        ctx.D, ctx.lib_id = t.shape[2], lib_id
+        ctx.set_materialize_grads(False)
+        return t.view_as(t), t[:, :, 0].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_t, g_s):
+        if g_s is None:
+            return g_t, None
+        return _AddCol0.apply(g_t, g_s, ctx.D, ctx.lib_id), None
+
+
+def fork_scalars(t: torch.Tensor, lib_id: int):
+    """(t, t[:, :, 0]) of a tensor feature [E,u,D], differentiable to any order."""
+    return _Fork0.apply(t, lib_id)
+
+
+class _Cat(torch.autograd.Function):
+    """Concatenation along the feature axis whose gradient is ONE `split` node (its own gradient: one concatenation).  `torch.cat`'s
+    gradient is a `narrow` per input, and each of those, differentiated again by a force loss, is a zero-filled full-width buffer,
+    a strided copy and an addition (1.2 ms per training step at C3, profiles/r05_v42_train_nodes.txt)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.sizes = [int(x.shape[1]) for x in xs]
+        return torch.cat(xs, dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.split(g, ctx.sizes, dim=1)
+
+
+def cat_features(xs) -> torch.Tensor:
+    return _Cat.apply(*xs)
 
 
 class _EdgeDiff(torch.autograd.Function):

@@ -147,6 +147,9 @@ class TrainingEvaluator:
         onehot = torch.nn.functional.one_hot(idx, rows).to(table.dtype)
         return ops.linear(onehot, table, self.lib_id)
 
+    def _cat(self, xs):
+        return torch.cat(xs, dim=-1) if self.lib_id is None else ops.cat_features(xs)
+
     def _wc(self, sh, w, u, l_max):
         if self.lib_id is None:
             return _weighted_channels(sh, w, u, l_max)
@@ -228,7 +231,13 @@ class TrainingEvaluator:
                 tf = ops.contract_segments_differentiable(tf.reshape(-1, u, c.base_dim1), env, self._param(f"allegro.tps.{l}.weights"),
                                                           graph.rowptr, None, center, N, self.sf, c._plan(pos.dtype, pos.device),
                                                           c._lib_id, c.base_dim1, c.base_dim2, c.base_dim_out)
-            lat = _mlp(torch.cat(scalars + [tf[:, :, 0]], dim=-1), self._weights(f"allegro.latents.{l}.mlp"), nl_latent,
+            if self.lib_id is None:
+                tf_scalars = tf[:, :, 0]
+            elif l < L - 1:
+                tf, tf_scalars = ops.fork_scalars(tf, self.lib_id)  # (one node: tf goes on to the next layer, its scalars to the MLP)
+            else:
+                tf_scalars = tf.reshape(tf.shape[0], u) if tf.shape[2] == 1 else tf[:, :, 0]
+            lat = _mlp(self._cat(scalars + [tf_scalars]), self._weights(f"allegro.latents.{l}.mlp"), nl_latent,
                        self.act_consts[nl_latent], fwd, self.lib_id)
             if l < L - 1:
                 head, env_w = _head_columns(lat, S, We)
@@ -236,7 +245,7 @@ class TrainingEvaluator:
                 head, _ = _head_columns(lat, S, 0)
             scalars.append(head)
         # edge readout, edge -> atom sum, per-type scale / shift (allegro_models.py:231-260; edgewise.py:40-60)
-        e_edge = _mlp(torch.cat(scalars, dim=-1), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd, self.lib_id)
+        e_edge = _mlp(self._cat(scalars), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd, self.lib_id)
         e_edge = e_edge * (1.0 / math.sqrt(2 * hp["avg_num_neighbors"]))
         if self.lib_id is not None:
             with _device_guard(pos):

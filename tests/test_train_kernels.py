@@ -163,6 +163,62 @@ def test_linear_forward_on_gpu():
     _linear_forward_case(None, torch.device("cuda:0"))
 
 
+def _fork_cat_case(lib, dev):
+    """`ops.fork_scalars` (tensor feature -> itself + its scalar components, gradients merged in one pass) and `ops.cat_features`
+    (concatenation with a split as gradient) against slicing / torch.cat, to second order; weights as a row-strided column block."""
+    lid = _lib_id(lib)
+    dtype = torch.float64
+    g = torch.Generator().manual_seed(21)
+    E, u, l_max = 29, 6, 2
+    D = (l_max + 1) ** 2
+    sh0 = torch.randn(E, D, generator=g, dtype=dtype).to(dev)
+    wide0 = torch.randn(E, 5 + u * (l_max + 1), generator=g, dtype=dtype).to(dev)  # [scalars | env weights]: w is a strided view
+    c = torch.randn(E, u, D, generator=g, dtype=dtype).to(dev)
+    Wm = torch.randn(5 + u, 4, generator=g, dtype=dtype).to(dev)
+    res = []
+    for hand in (True, False):
+        sh, wide = sh0.clone().requires_grad_(True), wide0.clone().requires_grad_(True)
+        first, w = wide[:, :5], wide[:, 5:]
+        t = ops.weighted_channels(sh, w, u, l_max, lid)
+        if hand:
+            t, s0 = ops.fork_scalars(t, lid)
+            feats = ops.cat_features([first, s0])
+        else:
+            s0 = t[:, :, 0]
+            feats = torch.cat([first, s0], dim=-1)
+        e = (t * c).sum() + ((feats @ Wm) ** 3).sum() + (t ** 2).sum() * 0.05
+        gsh, gw = torch.autograd.grad(e, [sh, wide], create_graph=True)
+        loss = (gsh ** 2).sum() + (gw ** 2).sum()
+        res.append([e.detach(), gsh.detach(), gw.detach()] + [v for v in torch.autograd.grad(loss, [sh, wide])])
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 1e-10 * max(1.0, float(b.abs().max()))
+    # the padded form alone (no other gradient of the feature)
+    t = torch.randn(E, u, D, generator=g, dtype=dtype).to(dev).requires_grad_(True)
+    _, s0 = ops.fork_scalars(t, lid)
+    (gt,) = torch.autograd.grad((s0 ** 2).sum(), t)
+    want = torch.zeros_like(t)
+    want[:, :, 0] = 2 * t.detach()[:, :, 0]
+    assert torch.equal(gt, want)
+    # features of a pruned layer: any row length (here 13 = 1 + 3 + 9 ... components)
+    t = torch.randn(7, u, 13, generator=g, dtype=dtype).to(dev).requires_grad_(True)
+    t2, s0 = ops.fork_scalars(t, lid)
+    (gt,) = torch.autograd.grad((s0 ** 2).sum() + t2.sum(), t)
+    want = torch.ones_like(t)
+    want[:, :, 0] += 2 * t.detach()[:, :, 0]
+    assert (gt - want).abs().max().item() <= 1e-14
+
+
+def test_fork_and_cat_emulated():
+    from tests.hip_utils import emu_lib
+
+    _fork_cat_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_fork_and_cat_on_gpu():
+    _fork_cat_case(None, torch.device("cuda:0"))
+
+
 def test_silu_family_emulated():
     from tests.hip_utils import emu_lib
 

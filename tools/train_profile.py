@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--top", type=int, default=70)
+    ap.add_argument("--stacks", default="", help="comma-separated operator names (e.g. aten::copy_,aten::add_): their device time by the autograd node they ran under")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g, cfg = bench.make_workload(args.workload)
@@ -47,10 +48,34 @@ def main():
     for _ in range(2):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+    if args.stacks:
+        # per operator and shape: device time by the autograd node (or forward-pass Python op) it ran under
+        want = set(args.stacks.split(","))
+        agg = {}
+        for e in prof.events():
+            if e.name not in want:
+                continue
+            t = getattr(e, "device_time_total", None)
+            if t is None:
+                t = getattr(e, "cuda_time_total", 0.0)
+            if t <= 0:
+                continue
+            par, node = e.cpu_parent, "(forward)"
+            while par is not None:
+                if par.name.startswith("autograd::engine::evaluate_function: "):
+                    node = par.name.split(": ", 1)[1]
+                    break
+                par = par.cpu_parent
+            key = (e.name, str(e.input_shapes)[:48], node)
+            ms, cnt = agg.get(key, (0.0, 0))
+            agg[key] = (ms + t / args.steps / 1e3, cnt + 1.0 / args.steps)
+        for (name, shapes, node), (ms, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:args.top]:
+            print(f"{ms:8.3f} ms {cnt:5.1f}x  {name:12s} {shapes:48s} {node}")
+        return
     rows = []
     for ev_ in prof.key_averages(group_by_input_shape=True):
         t = getattr(ev_, "self_device_time_total", None)
