@@ -145,7 +145,7 @@ int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l_max, int s
 int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int shared, const void* sh, const void* w, int64_t ldw, const void* sh2,
                              const void* w2, int64_t ldw2, void* out, aa_stream stream);
 /* out[rows, D] = a (NULL: zeros) with s[rows] added to component 0 of every row: the gradient of a tensor feature whose scalar components
- * also feed the next latent MLP (`features[:, :, 0]`, _allegro.py:275-283), in one pass. */
+ * also feed the next latent MLP (`features[:, :, 0]`, _allegro.py:275-283), in one pass.  a, out 16-byte aligned. */
 int aa_scalar_column(aa_dtype dtype, int64_t rows, int D, const void* a, const void* s, void* out, aa_stream stream);
 /* The hidden activation of the scalar MLPs (ScalarMLPFunction with SiLU; _allegro.py:192-213) and its derivatives, elementwise over n
  * values: A_k(x, g) = g f^(k)(x), f(x) = x sigmoid(x), k = `order` in 0..3; g may be NULL (= 1).  The family is closed under

@@ -660,7 +660,7 @@ def train_step_bench(args, dev):
                 config=dict(workload=f"{args.workload}: {N} atoms / {E} edges, l_max {cfg['l_max']}, {L} layers, {cfg['num_tensor_features']} tensor features",
                             parameters=int(sum(p.numel() for p in params)), optimizer="Adam",
                             kernels="eager / library GEMMs (AA_TRAIN_EAGER=1)" if os.environ.get("AA_TRAIN_EAGER", "0")[:1] == "1" else
-                                    "aa_linear_wgrad + aa_weighted_channels + tensor-product kernels",
+                                    "aa_linear_forward / _wgrad + aa_weighted_channels[_pair/_sum] + aa_silu_derivative + aa_scalar_column + tensor-product kernels",
                             chunks=None if chunked is None else dict(max_edges=args.train_chunk_edges, count=len(chunked.chunks))),
                 final_loss=float(loss), peak_memory_GB=peak / 1e9, inference_ms_per_step=ms_inf, train_over_inference=ms / ms_inf,
                 eager_port_gpu=None if ms_ref is None else dict(ms_per_step=ms_ref, edges=e1, value=e1 * L / ms_ref * 1e3, unit="edge-TP/s", kind="port",

@@ -86,6 +86,8 @@ case $CMD in
     AA_TRAIN_EAGER=1 timeout 600 python bench.py --mode train-step --workload c3 --steps 5 --warmup 2 --no-gpu-reference > gpurun_out/${TAG}_train_step_c3_eager.json 2> /dev/null
     timeout 900 python bench.py --mode train-step --workload c4 --steps 2 --warmup 1 --no-gpu-reference --train-chunk-edges 400000 > gpurun_out/${TAG}_train_step_c4_chunked.json 2> /dev/null
     grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_train_step_c3.json gpurun_out/${TAG}_train_step_c3_eager.json gpurun_out/${TAG}_train_step_c4_chunked.json
+    timeout 400 python tools/train_profile.py > gpurun_out/${TAG}_train_profile_c3.txt 2> /dev/null
+    timeout 400 python tools/train_profile.py --stacks aten::copy_,aten::add_,aten::add,aten::cat,aten::fill_,aten::mul --top 40 > gpurun_out/${TAG}_train_nodes_c3.txt 2> /dev/null
     # the driver's N > 1 launch line on this one-GPU box: N ranks share cuda:0, rows staged through the host (gloo) -- exercises bench.py's
     # sharded branch end to end (rendezvous, slab shards, both exchanges, barrier + max-over-ranks clock); its ms/step is N shards on ONE GPU
     for N in 2 8; do
