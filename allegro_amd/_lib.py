@@ -152,6 +152,9 @@ class AllegroLib:
         L.aa_weighted_channels_sum.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.aa_weighted_channels_sum.restype = C.c_int
+        L.aa_concat_columns.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_void_p,
+                                        C.c_int64, C.c_void_p]
+        L.aa_concat_columns.restype = C.c_int
         L.aa_scalar_column.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_scalar_column.restype = C.c_int
         L.aa_silu_derivative.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

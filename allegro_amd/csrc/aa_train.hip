@@ -146,14 +146,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     }
 }
 
-// rows per workgroup: ~1024 workgroups along the rows (several per CU for every output-block count), at least 256 rows each
-int64_t wgrad_rows_per_slab(int64_t E) {
-  int64_t rows = (E + 1023) / 1024;
-  rows = std::max<int64_t>(rows, 256);
+// Slabs: the workgroups of ONE launch should fill the chip exactly once -- 256 CUs x the workgroups a CU holds (8 by waves, fewer by
+// the LDS of the block shape).  The first rule (~1024 slabs of >= 256 rows whatever the block count) launched 1864 workgroups for
+// [3e5 x 192]^T [3e5 x 64] on 1536 slots: a second round at 21 % occupancy.  At least 64 rows per slab, at most 4096 slabs.
+constexpr int kChipCUs = 256;
+template <typename T>
+int wgrad_block_shape(int K, int N, int* kb, int* nb) {  // workgroups per slab; block widths
+  *kb = K > 64 ? 128 : 64;
+  *nb = N > 64 ? 128 : 64;
+  return ((K + *kb - 1) / *kb) * ((N + *nb - 1) / *nb);
+}
+template <typename T>
+int64_t wgrad_rows_per_slab(int64_t E, int K, int N) {
+  int kb, nb;
+  const int per_slab = wgrad_block_shape<T>(K, N, &kb, &nb);
+  const size_t lds = sizeof(T) * (sizeof(T) == 8 ? 16 : 32) * size_t(kb + 4 + nb + 4);
+  const int per_cu = int(std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds)));
+  const int64_t slabs = std::max<int64_t>(1, std::min<int64_t>(4096, int64_t(kChipCUs) * per_cu / per_slab));
+  int64_t rows = std::max<int64_t>((E + slabs - 1) / slabs, 64);
   return (rows + 31) / 32 * 32;
 }
-int wgrad_parts(int64_t E) {  // workgroups along the rows = partial blocks in the workspace
-  const int64_t rows = wgrad_rows_per_slab(E);
+template <typename T>
+int wgrad_parts(int64_t E, int K, int N) {  // workgroups along the rows = partial blocks in the workspace
+  const int64_t rows = wgrad_rows_per_slab<T>(E, K, N);
   return int(std::max<int64_t>(1, (E + rows - 1) / rows));
 }
 
@@ -471,12 +486,46 @@ __global__ __launch_bounds__(256) void scalar_column_kernel(int64_t n, int d_any
   }
 }
 
+// out[e, off_j + c] = x_j[e, c]: the per-edge scalar features of all layers side by side (the input of every latent MLP and of the
+// readout, _allegro.py:275-283) -- and the gradient of a column split.  Four columns per thread where widths, strides and bases allow
+// 16-byte accesses.
+constexpr int kCatMax = 8;
+struct CatArgs {
+  const void* x[kCatMax];
+  int64_t ld[kCatMax];
+  int width[kCatMax], off[kCatMax + 1];
+  int n, total;
+  int64_t E, ldo;
+  void* out;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void concat_columns_kernel(CatArgs a) {
+  const int per_row = a.total / V;
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= a.E * per_row) return;
+  const int64_t e = t / per_row;
+  const int c = int(t - e * per_row) * V;
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < kCatMax; ++q)
+    if (q < a.n && c >= a.off[q]) j = q;
+  const T* src = static_cast<const T*>(a.x[j]) + e * a.ld[j] + (c - a.off[j]);
+  T* dst = static_cast<T*>(a.out) + e * a.ldo + c;
+  if (V == 1) {
+    *dst = *src;
+  } else {
+    using Vec = typename Pk16<T>::type;
+    *reinterpret_cast<Vec*>(dst) = *reinterpret_cast<const Vec*>(src);
+  }
+}
+
 }  // namespace
 }  // namespace aa
 
 extern "C" size_t aa_linear_wgrad_workspace_bytes(aa_dtype dtype, int64_t E, int K, int N) {
   if (E < 0 || K < 1 || N < 1) return 0;
-  return size_t(aa::wgrad_parts(E)) * size_t(K) * size_t(N) * (dtype == AA_F32 ? 4 : 8);
+  const int parts = dtype == AA_F32 ? aa::wgrad_parts<float>(E, K, N) : aa::wgrad_parts<double>(E, K, N);
+  return size_t(parts) * size_t(K) * size_t(N) * (dtype == AA_F32 ? 4 : 8);
 }
 
 extern "C" int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const void* x, int64_t ldx, const void* g, int64_t ldg,
@@ -500,8 +549,8 @@ extern "C" int aa_linear_wgrad(aa_dtype dtype, int64_t E, int K, int N, const vo
   a.ldx = ldx;
   a.ldg = ldg;
   a.partial = workspace;
-  a.rows_per_slab = aa::wgrad_rows_per_slab(E);
-  const int parts = aa::wgrad_parts(E);
+  a.rows_per_slab = dtype == AA_F32 ? aa::wgrad_rows_per_slab<float>(E, K, N) : aa::wgrad_rows_per_slab<double>(E, K, N);
+  const int parts = dtype == AA_F32 ? aa::wgrad_parts<float>(E, K, N) : aa::wgrad_parts<double>(E, K, N);
   a.slabs = parts;
   const int64_t KN = int64_t(K) * N;
   // 16-byte loads need widths and strides that are multiples of the vector and 16-byte-aligned bases
@@ -669,6 +718,45 @@ extern "C" int aa_scalar_column(aa_dtype dtype, int64_t rows, int D, const void*
     if (D == 4) AA_SC(double, 4); else if (D == 9) AA_SC(double, 9); else if (D == 16) AA_SC(double, 16); else AA_SC(double, 0);
   }
 #undef AA_SC
+  AA_CHECK_HIP(hipGetLastError());
+  return AA_OK;
+}
+
+extern "C" int aa_concat_columns(aa_dtype dtype, int64_t E, int n, const void* const* xs, const int64_t* ldx, const int* widths, void* out, int64_t ldo,
+                                 aa_stream stream) {
+  AA_REQUIRE(E >= 0 && n >= 1 && n <= aa::kCatMax && xs && ldx && widths, "aa_concat_columns: 1..8 inputs");
+  aa::CatArgs a{};
+  const int esize = dtype == AA_F32 ? 4 : 8, vec = 16 / esize;
+  int total = 0;
+  bool v_ok = (ldo % vec == 0) && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  for (int j = 0; j < n; ++j) {
+    AA_REQUIRE(widths[j] >= 1 && ldx[j] >= widths[j] && (E == 0 || xs[j]), "aa_concat_columns: bad input");
+    a.x[j] = xs[j];
+    a.ld[j] = ldx[j];
+    a.width[j] = widths[j];
+    a.off[j] = total;
+    total += widths[j];
+    v_ok = v_ok && (widths[j] % vec == 0) && (ldx[j] % vec == 0) && reinterpret_cast<uintptr_t>(xs[j]) % 16 == 0;
+  }
+  a.off[n] = total;
+  AA_REQUIRE(ldo >= total, "aa_concat_columns: output row stride shorter than the row");
+  if (E == 0) return AA_OK;
+  AA_REQUIRE(out, "aa_concat_columns: null output");
+  a.n = n;
+  a.total = total;
+  a.E = E;
+  a.ldo = ldo;
+  a.out = out;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t items = E * (v_ok ? total / vec : total);
+  const dim3 grid((unsigned)((items + 255) / 256));
+  if (dtype == AA_F32) {
+    if (v_ok) hipLaunchKernelGGL((aa::concat_columns_kernel<float, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((aa::concat_columns_kernel<float, 1>), grid, dim3(256), 0, s, a);
+  } else {
+    if (v_ok) hipLaunchKernelGGL((aa::concat_columns_kernel<double, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((aa::concat_columns_kernel<double, 1>), grid, dim3(256), 0, s, a);
+  }
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }

@@ -147,6 +147,10 @@ int aa_weighted_channels_sum(aa_dtype dtype, int64_t E, int u, int l_max, int sh
 /* out[rows, D] = a (NULL: zeros) with s[rows] added to component 0 of every row: the gradient of a tensor feature whose scalar components
  * also feed the next latent MLP (`features[:, :, 0]`, _allegro.py:275-283), in one pass.  a, out 16-byte aligned. */
 int aa_scalar_column(aa_dtype dtype, int64_t rows, int D, const void* a, const void* s, void* out, aa_stream stream);
+/* out[e, off_j + c] = x_j[e, c] for n <= 8 inputs of `widths[j]` columns and row strides `ldx[j]` (elements): the scalar features of all
+ * layers side by side, the input of every latent MLP and of the readout (_allegro.py:275-283) -- and the gradient of a column split. */
+int aa_concat_columns(aa_dtype dtype, int64_t E, int n, const void* const* xs, const int64_t* ldx, const int* widths, void* out, int64_t ldo,
+                      aa_stream stream);
 /* The hidden activation of the scalar MLPs (ScalarMLPFunction with SiLU; _allegro.py:192-213) and its derivatives, elementwise over n
  * values: A_k(x, g) = g f^(k)(x), f(x) = x sigmoid(x), k = `order` in 0..3; g may be NULL (= 1).  The family is closed under
  * differentiation: d A_k/dx . h = A_{k+1}(x, g h), d A_k/dg . h = A_k(x, h); `_pair` returns both from one pass:

@@ -22,7 +22,7 @@ weights require grad -- the coverage of the reference's eager / cuEquivariance c
 `aa_tp_plan*` handle as an integer, `lib_id` selects the loaded library (0 = the gfx950 build; tests register the
 emulation build under another id).  There is no CPU implementation: the ops raise on CPU tensors.
 """
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -866,23 +866,70 @@ def fork_scalars(t: torch.Tensor, lib_id: int):
     return _Fork0.apply(t, lib_id)
 
 
+@torch.library.custom_op("allegro_amd::concat_columns", mutates_args=())
+def concat_columns_op(xs: List[torch.Tensor], lib_id: int) -> torch.Tensor:
+    """`aa_concat_columns`: [E, sum of widths] from up to 8 [E, w_j] tensors (row-strided views taken as they are)."""
+    import ctypes as C
+
+    lib = _resolve(lib_id)
+    _check_device(lib, xs[0], "allegro_amd::concat_columns")
+    xc = [_rows_ok(x) for x in xs]
+    E, n = xc[0].shape[0], len(xc)
+    total = sum(int(x.shape[1]) for x in xc)
+    out = torch.empty((E, total), dtype=xc[0].dtype, device=xc[0].device)
+    ptrs = (C.c_void_p * n)(*[x.data_ptr() if E else None for x in xc])
+    lds = (C.c_int64 * n)(*[x.stride(0) if E else x.shape[1] for x in xc])
+    ws = (C.c_int * n)(*[int(x.shape[1]) for x in xc])
+    lib.check(lib.lib.aa_concat_columns(_dtype_code(xc[0]), E, n, ptrs, lds, ws, out.data_ptr() if E else None, total, _stream_ptr(xc[0])),
+              "aa_concat_columns")
+    return out
+
+
+@concat_columns_op.register_fake
+def _(xs, lib_id):
+    return xs[0].new_empty((xs[0].shape[0], sum(int(x.shape[1]) for x in xs)))
+
+
+def _concat(xs, lib_id):
+    if lib_id is None or len(xs) > 8 or any(x.dim() != 2 or x.shape[1] == 0 for x in xs):
+        return torch.cat(list(xs), dim=1)
+    return torch.ops.allegro_amd.concat_columns(list(xs), lib_id)
+
+
+class _Split(torch.autograd.Function):
+    """Column blocks of x [E, sum] as views; the gradient is one concatenation (`_Cat`)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, lib_id):
+        ctx.lib_id = lib_id
+        return tuple(v.view_as(v) for v in torch.split(x, sizes, dim=1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return _Cat.apply(ctx.lib_id, *gs), None, None
+
+
+def split_columns(x: torch.Tensor, sizes, lib_id: int):
+    return _Split.apply(x, [int(v) for v in sizes], lib_id)
+
+
 class _Cat(torch.autograd.Function):
     """Concatenation along the feature axis whose gradient is ONE `split` node (its own gradient: one concatenation).  `torch.cat`'s
     gradient is a `narrow` per input, and each of those, differentiated again by a force loss, is a zero-filled full-width buffer,
     a strided copy and an addition (1.2 ms per training step at C3, profiles/r05_v42_train_nodes.txt)."""
 
     @staticmethod
-    def forward(ctx, *xs):
-        ctx.sizes = [int(x.shape[1]) for x in xs]
-        return torch.cat(xs, dim=1)
+    def forward(ctx, lib_id, *xs):
+        ctx.sizes, ctx.lib_id = [int(x.shape[1]) for x in xs], lib_id
+        return _concat([x.detach() for x in xs], lib_id)
 
     @staticmethod
     def backward(ctx, g):
-        return torch.split(g, ctx.sizes, dim=1)
+        return (None,) + _Split.apply(g, ctx.sizes, ctx.lib_id)
 
 
-def cat_features(xs) -> torch.Tensor:
-    return _Cat.apply(*xs)
+def cat_features(xs, lib_id: Optional[int] = None) -> torch.Tensor:
+    return _Cat.apply(lib_id, *xs)
 
 
 class _EdgeDiff(torch.autograd.Function):

@@ -65,13 +65,14 @@ def _mlp(x: torch.Tensor, weights: List[torch.Tensor], act: Optional[str], act_c
     return x
 
 
-def _head_columns(x: torch.Tensor, a: int, b: int):
+def _head_columns(x: torch.Tensor, a: int, b: int, lib_id: Optional[int] = None):
     """x[:, :a], x[:, a:a+b] as ONE autograd node (`split`: its backward is a single concatenation of the two gradients; two slices
     are two zero-filled [E, width] buffers, two copies and an addition -- and again in the second derivative)."""
     rest = x.shape[1] - a - b
     if b == 0 and rest == 0:
         return x, x[:, :0]
-    parts = torch.split(x, [a, b] + ([rest] if rest else []), dim=1)
+    sizes = [a, b] + ([rest] if rest else [])
+    parts = torch.split(x, sizes, dim=1) if lib_id is None else ops.split_columns(x, sizes, lib_id)
     return parts[0], parts[1]
 
 
@@ -148,7 +149,7 @@ class TrainingEvaluator:
         return ops.linear(onehot, table, self.lib_id)
 
     def _cat(self, xs):
-        return torch.cat(xs, dim=-1) if self.lib_id is None else ops.cat_features(xs)
+        return torch.cat(xs, dim=-1) if self.lib_id is None else ops.cat_features(xs, self.lib_id)
 
     def _wc(self, sh, w, u, l_max):
         if self.lib_id is None:
@@ -222,7 +223,7 @@ class TrainingEvaluator:
         tf = self._wc(sh, _mlp(emb, self._weights("tensor_embed.env_embed_linear.mlp"), "silu", silu_c, fwd, self.lib_id), u, l_max)
         We = (l_max + 1) * u if m.weight_individual_irreps else u
         proj = _mlp(emb, self._weights("allegro.first_layer_env_embed_projection.mlp"), "silu", silu_c, fwd, self.lib_id)
-        first, env_w = _head_columns(proj, S, We)
+        first, env_w = _head_columns(proj, S, We, self.lib_id)
         scalars = [first]
         for l in range(L):  # _allegro.py:262-294
             c = self.contracters[l]
@@ -240,9 +241,9 @@ class TrainingEvaluator:
             lat = _mlp(self._cat(scalars + [tf_scalars]), self._weights(f"allegro.latents.{l}.mlp"), nl_latent,
                        self.act_consts[nl_latent], fwd, self.lib_id)
             if l < L - 1:
-                head, env_w = _head_columns(lat, S, We)
+                head, env_w = _head_columns(lat, S, We, self.lib_id)
             else:
-                head, _ = _head_columns(lat, S, 0)
+                head, _ = _head_columns(lat, S, 0, self.lib_id)
             scalars.append(head)
         # edge readout, edge -> atom sum, per-type scale / shift (allegro_models.py:231-260; edgewise.py:40-60)
         e_edge = _mlp(self._cat(scalars), self._weights("edge_readout.mlp.mlp"), nl_readout, self.act_consts[nl_readout], fwd, self.lib_id)

@@ -182,7 +182,7 @@ def _fork_cat_case(lib, dev):
         t = ops.weighted_channels(sh, w, u, l_max, lid)
         if hand:
             t, s0 = ops.fork_scalars(t, lid)
-            feats = ops.cat_features([first, s0])
+            feats = ops.cat_features([first, s0], lid)
         else:
             s0 = t[:, :, 0]
             feats = torch.cat([first, s0], dim=-1)
@@ -192,6 +192,19 @@ def _fork_cat_case(lib, dev):
         res.append([e.detach(), gsh.detach(), gw.detach()] + [v for v in torch.autograd.grad(loss, [sh, wide])])
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 1e-10 * max(1.0, float(b.abs().max()))
+    # the concatenation kernel itself: row-strided views, widths that allow 16-byte accesses and widths that do not; split_columns
+    for widths, dt in (((64, 192), torch.float32), ((5, 6, 1), torch.float64), ((4, 8, 12, 4), torch.float32), ((2, 6), torch.float64)):
+        wide = torch.randn(31, sum(widths) + 8, generator=g, dtype=dt).to(dev)
+        parts, o = [], 4 if widths[0] % 4 == 0 else 3
+        for wd in widths:
+            parts.append(wide[:, o:o + wd])
+            o += wd
+        assert torch.equal(torch.ops.allegro_amd.concat_columns(parts, lid), torch.cat(parts, dim=1))
+    x = torch.randn(17, 20, generator=g, dtype=dtype).to(dev).requires_grad_(True)
+    a, b, c3 = ops.split_columns(x, [8, 8, 4], lid)
+    (gx,) = torch.autograd.grad((a * 2).sum() + (c3 ** 2).sum(), x)  # (b unused: its gradient block is zeros)
+    want = torch.cat([torch.full((17, 8), 2.0, dtype=dtype, device=dev), torch.zeros(17, 8, dtype=dtype, device=dev), 2 * x.detach()[:, 16:]], dim=1)
+    assert torch.equal(gx, want)
     # the padded form alone (no other gradient of the feature)
     t = torch.randn(E, u, D, generator=g, dtype=dtype).to(dev).requires_grad_(True)
     _, s0 = ops.fork_scalars(t, lid)
