@@ -13,7 +13,7 @@ s / 2 (the kernels apply the model's cutoff to every edge, so the longer list gi
 The model has random weights (reference initialisers): the potential is smooth but arbitrary and has NO repulsive core -- after
 ~150 fs at 300 K some atom pair of the 10^5 collapses (max |F| 3.6 -> 480 eV/A within 40 fs) and no time step integrates that; the
 default run therefore stops at 100 + 10 fs, where the total energy error is the O(dt^2) of velocity Verlet: it falls 4x per halving
-of dt (profiles/r05_v45_md_loop_c4*.json: 12.2 -> 3.07 eV of 21 900 eV kinetic for dt = 1 -> 0.5 fs)."""
+of dt (profiles/r05_v48_md_loop_c4*.json: 12.2 -> 3.07 eV of 21 900 eV kinetic for dt = 1 -> 0.5 fs)."""
 import argparse
 import json
 import os
