@@ -281,12 +281,18 @@ class _recording:
         self.t.keep = self.prev
 
 
+def _NO_X2S_CACHE() -> bool:  # AA_TP_NO_X2S_CACHE=1: recompute M b every time (A/B and the test of the cache)
+    import os
+
+    return os.environ.get("AA_TP_NO_X2S_CACHE", "0")[:1] == "1"
+
+
 def _edge_rowptr(E: int, device) -> torch.Tensor:
     return torch.arange(E + 1, dtype=torch.int32, device=device)
 
 
 def _segment_sum(t: _TriCtx, b):  # x2s = scale * scatter-sum of b over the scatter index  [N,u,d2]
-    hit = t.x2s_cache.get(t._key(b))
+    hit = None if _NO_X2S_CACHE() else t.x2s_cache.get(t._key(b))
     if hit is not None:
         return hit[1]
     rowptr, eids, _idxs, n, sf = t.segments

@@ -50,6 +50,37 @@ def _training_case(name, dtype, lib, dev):
     assert not any(p.requires_grad for p in m.parameters())
 
 
+def test_cached_segment_sums_change_no_bit_emulated(monkeypatch):
+    """The scaled segment sum of a tensor product's second operand is computed once per operand and reused by every later derivative
+    (`ops._TriCtx.x2s_cache`): the loss gradients are bit-identical to recomputing it every time, and the segment-sum op runs less often."""
+    from allegro_amd import ops
+    from tests.hip_utils import emu_lib
+
+    fx = load_model_fixture("t_coupled", torch.float64)
+    N = fx["pos"].shape[0]
+    wf = torch.linspace(0.5, 1.5, 3 * N, dtype=torch.float64).reshape(N, 3)
+    res, calls = [], []
+    real = ops._segment_sum
+    for off in ("0", "1"):
+        monkeypatch.setenv("AA_TP_NO_X2S_CACHE", off)
+        count = {"miss": 0}
+
+        def counted(t, b, _count=count):
+            hit = (not ops._NO_X2S_CACHE()) and t._key(b) in t.x2s_cache
+            _count["miss"] += 0 if hit else 1
+            return real(t, b)
+
+        monkeypatch.setattr(ops, "_segment_sum", counted)
+        m = model_from_fixture(fx, torch.float64, emu_lib(), torch.device("cpu"))
+        m.train()
+        graph = m.prepare_graph(fx["edge_index"], fx["types"], N, fx["shift_vec"])
+        out = m._training_evaluator().forward({"pos": fx["pos"]}, graph)
+        res.append(torch.autograd.grad(_loss(out, wf), [p for p in m.parameters() if p.requires_grad]))
+        calls.append(count["miss"])
+    assert all(torch.equal(a, b) for a, b in zip(*res))
+    assert calls[0] < calls[1], calls
+
+
 @pytest.mark.parametrize("name,dtype", [("t_coupled", torch.float64), ("t_uncoupled", torch.float64), ("t_spline_peredge", torch.float64),
                                         ("t_acts", torch.float64), ("t_shared", torch.float32)])  # (c5_small, l_max 3 / 3 layers: GPU list below; 2.5 min emulated)
 def test_training_mode_gradients_match_oracle_autograd_emulated(name, dtype):
