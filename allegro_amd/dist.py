@@ -285,7 +285,7 @@ class HaloShard:
         EDGE list, and everything the rank keeps afterwards is O(local).  The set-up itself is O(N) per rank: `pos_all` [N,3]
         (device, model dtype) and `types_all` are needed in full (as an MD code has them at start-up), and the slab sort
         (`frac`, `argsort`, `rank_of`, `lookup`: a few 8-byte words per atom) runs over all N atoms on every rank -- 97 336
-        atoms at C4, i.e. ~5 MB of transient arrays; a domain-decomposed host would hand over its slab instead.  Full periodic
+        atoms at C4, i.e. ~5 MB of transient arrays; a domain-decomposed host hands over its slab instead: `from_owned`.  Full periodic
         `cell` (3x3, rows).  Results come back in SLAB order: `shard.owned_ids()` maps them to the caller's numbering."""
         from .nn import neighbor_list
 
@@ -327,6 +327,87 @@ class HaloShard:
         types_local = types_all.to(dev)[order[local_gids]]
         return cls(rank, world, cuts, local_gids.cpu(), ei, types_local, nl.shift_vec[:e_own], dev, dtype, order=order, group=group,
                    connect=connect)
+
+    @classmethod
+    def from_owned(cls, pos_own: torch.Tensor, types_own: torch.Tensor, cell, r_cut: float, rank: int, world: int, group=None, axis: int = 0,
+                   bounds=None, lib=None):
+        """From a DOMAIN-DECOMPOSED host: this rank passes only the atoms it owns -- those whose fractional coordinate along lattice
+        direction `axis` lies in its slab [bounds[rank], bounds[rank+1]) (default: `world` slabs of equal width) -- and nothing here is
+        O(N): the ranks exchange their atom counts (the global numbering is rank-major: id = first id of the owner + index on the owner),
+        every rank sends each other rank the (position, type, index) rows of ITS atoms that lie within r_cut of that rank's slab (one
+        all_to_all of counts, three of rows), builds the neighbour list of its slab + the received candidates, keeps the candidates its
+        atoms actually see as ghosts, and the usual plan exchange follows (`__init__`).  Set-up traffic per rank: the halo candidates
+        only.  What `from_positions` does from a replicated frame, this does from slabs: what LAMMPS' domain decomposition hands to
+        `pair_allegro`.  `pos_own` / results stay in the rank's own atom order (`owned_ids()` = the global rank-major ids)."""
+        import torch.distributed as dist
+
+        from .nn import neighbor_list
+
+        dev, dtype = pos_own.device, pos_own.dtype
+        n_own = int(pos_own.shape[0])
+        cell_t = torch.as_tensor(cell, dtype=torch.float64)
+        if bounds is None:
+            bounds = [q / world for q in range(world + 1)]
+        bounds = [float(b) for b in bounds]
+        if len(bounds) != world + 1 or abs(bounds[0]) > 1e-12 or abs(bounds[-1] - 1.0) > 1e-12 or any(b1 <= b0 for b0, b1 in zip(bounds, bounds[1:])):
+            raise ValueError("HaloShard.from_owned: bounds must rise from 0 to 1 in world + 1 steps")
+        frac = torch.linalg.solve(cell_t.T.to(dev), pos_own.double().T).T if n_own else torch.zeros((0, 3), dtype=torch.float64, device=dev)
+        fx = frac[:, axis] - torch.floor(frac[:, axis])
+        if n_own and not bool(((fx >= bounds[rank] - 1e-9) & (fx < bounds[rank + 1] + 1e-9)).all()):
+            raise ValueError(f"HaloShard.from_owned: rank {rank} was handed atoms outside its slab [{bounds[rank]}, {bounds[rank + 1]}) along axis {axis}")
+        multi = world > 1
+        if multi:
+            assert dist.is_initialized(), "HaloShard.from_owned with world > 1 needs an initialised process group"
+        host_staged = multi and dev.type == "cuda" and dist.get_backend(group) == "gloo"
+        # global numbering: rank-major
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        if multi:
+            mine = torch.full((world,), n_own, dtype=torch.int64, device=dev)
+            _all_to_all_rows(counts, mine, None, None, group, host_staged)  # (counts[p] = atoms of rank p)
+        else:
+            counts[0] = n_own
+        cuts = [0] + torch.cumsum(counts, 0).tolist()
+        # candidates for every other rank: my atoms within r_cut (with a margin) of its slab, periodic along the axis
+        height = float(torch.linalg.det(cell_t).abs() / torch.linalg.norm(torch.linalg.cross(cell_t[(axis + 1) % 3], cell_t[(axis + 2) % 3])))
+        margin = 1.02 * float(r_cut) / height
+        send_ids = []
+        for q in range(world):
+            if q == rank or n_own == 0:
+                send_ids.append(torch.empty(0, dtype=torch.int64, device=dev))
+                continue
+            lo, hi = bounds[q], bounds[q + 1]
+            near = ((fx >= lo) & (fx <= hi)) | (torch.remainder(lo - fx, 1.0) < margin) | (torch.remainder(fx - hi, 1.0) < margin)
+            send_ids.append(torch.nonzero(near).reshape(-1))
+        n_send = [int(v.numel()) for v in send_ids]
+        n_recv = [0] * world
+        if multi:
+            t_in = torch.tensor(n_send, dtype=torch.int64, device=dev)
+            t_out = torch.empty(world, dtype=torch.int64, device=dev)
+            _all_to_all_rows(t_out, t_in, None, None, group, host_staged)
+            n_recv = t_out.tolist()
+        sel = torch.cat(send_ids) if multi else torch.empty(0, dtype=torch.int64, device=dev)
+        tot = int(sum(n_recv))
+        cand_pos = torch.empty((tot, 3), dtype=dtype, device=dev)
+        cand_meta = torch.empty((tot, 2), dtype=torch.int64, device=dev)  # (type, index on the owner)
+        if multi:
+            _all_to_all_rows(cand_pos, pos_own.index_select(0, sel).contiguous(), n_recv, n_send, group, host_staged)
+            meta = torch.stack([types_own.to(dev).long().index_select(0, sel), sel], dim=1).contiguous()
+            _all_to_all_rows(cand_meta, meta, n_recv, n_send, group, host_staged)
+        owner = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(n_recv, dtype=torch.int64, device=dev))
+        cand_gid = torch.tensor(cuts[:-1], dtype=torch.int64, device=dev)[owner] + cand_meta[:, 1]  # rising: grouped by owner, rising index
+        # this rank's list: centers = own atoms, neighbours among own + candidates
+        nl = neighbor_list(torch.cat([pos_own, cand_pos]).contiguous(), cell_t, True, r_cut, lib=lib)
+        e_own = int(nl.rowptr[n_own])
+        c_loc = nl.edge_index[0, :e_own].long()
+        n_sub = nl.edge_index[1, :e_own].long()
+        seen = torch.unique(n_sub[n_sub >= n_own])  # sorted: the candidates that are ghosts
+        lookup = torch.full((n_own + tot,), -1, dtype=torch.int64, device=dev)
+        lookup[:n_own] = torch.arange(n_own, device=dev)
+        lookup[seen] = n_own + torch.arange(seen.numel(), device=dev)
+        local_gids = torch.cat([torch.arange(cuts[rank], cuts[rank + 1], device=dev), cand_gid[seen - n_own]])
+        types_local = torch.cat([types_own.to(dev).long(), cand_meta[seen - n_own, 0]])
+        ei = torch.stack([c_loc, lookup[n_sub]])
+        return cls(rank, world, cuts, local_gids.cpu(), ei, types_local, nl.shift_vec[:e_own], dev, dtype, group=group, connect=True)
 
     def fill_local_positions(self, pos_all: torch.Tensor):
         """Owned + ghost positions straight from a full position array in the CALLER's numbering (start-up, or `connect=False`)."""

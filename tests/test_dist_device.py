@@ -110,7 +110,7 @@ def test_local_shards_with_in_process_all_reduce_match_the_one_gpu_step(world):
     assert dE <= 5e-5 * max(1.0, float(e_full.abs().max())) and dF <= 2e-5
 
 
-def _worker_two_ranks_one_device(rank, world, port, q):
+def _worker_two_ranks_one_device(rank, world, port, q, build="positions"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -126,14 +126,21 @@ def _worker_two_ranks_one_device(rank, world, port, q):
     n = fx["pos"].shape[0]
     cell = np.eye(3) * (2 * 5.431)
     pos = fx["pos"].to(dev)
-    sh = HaloShard.from_positions(pos, fx["types"].to(dev), cell, float(fx["cfg"]["r_max"]), rank, world)
+    if build == "owned":  # a domain-decomposed host: the rank is handed its slab's atoms only (`HaloShard.from_owned`)
+        fxx = torch.remainder(pos[:, 0].double() / (2 * 5.431), 1.0)
+        mine = torch.nonzero((fxx >= rank / world) & (fxx < (rank + 1) / world)).reshape(-1)
+        sh = HaloShard.from_owned(pos[mine].contiguous(), fx["types"].to(dev)[mine], cell, float(fx["cfg"]["r_max"]), rank, world)
+        ids = mine
+    else:
+        sh = HaloShard.from_positions(pos, fx["types"].to(dev), cell, float(fx["cfg"]["r_max"]), rank, world)
+        ids = sh.owned_ids()
     assert sh.connected and sh.host_staged
-    pos_own = pos[sh.owned_ids()].contiguous()
+    pos_own = pos[ids].contiguous()
     for k in range(6):  # back-to-back steps with alternating positions: a missing wait around a communication shows up here
         e, f = energy_forces_halo(m, pos_own + (0.01 if k % 2 == 0 else 0.0), sh)
     torch.cuda.synchronize()
     parts = [None] * world
-    dist.all_gather_object(parts, (sh.owned_ids().cpu(), e.cpu(), f.cpu(), sh.n_ghost, sum(sh.send_counts)))
+    dist.all_gather_object(parts, (ids.cpu(), e.cpu(), f.cpu(), sh.n_ghost, sum(sh.send_counts)))
     if rank == 0:
         e_all, f_all = torch.zeros(n), torch.zeros(n, 3)
         for ids, ee, ff, _, _ in parts:
@@ -146,20 +153,21 @@ def _worker_two_ranks_one_device(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_device_through_energy_forces_halo():
+@pytest.mark.parametrize("build", ["positions", "owned"])
+def test_two_ranks_on_one_device_through_energy_forces_halo(build):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker_two_ranks_one_device, args=(r, 2, port, q)) for r in range(2)]
+    port = 35500 + (os.getpid() + (0 if build == "positions" else 977)) % 2000
+    procs = [ctx.Process(target=_worker_two_ranks_one_device, args=(r, 2, port, q, build)) for r in range(2)]
     for p in procs:
         p.start()
     de, df, stats = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    print(f"2 ranks on cuda:0 (gloo, host-staged rows): max|dE_i|={de:.2e} max|dF|={df:.2e} vs golden; (ghosts, sent) {stats}")
+    print(f"2 ranks on cuda:0 (gloo, host-staged rows; shards from {build}): max|dE_i|={de:.2e} max|dF|={df:.2e} vs golden; (ghosts, sent) {stats}")
     assert de < 5e-5 and df < 5e-5
     assert sum(s[0] for s in stats) == sum(s[1] for s in stats) > 0
 

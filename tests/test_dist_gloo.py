@@ -157,6 +157,21 @@ def _worker_halo(rank, world, port, q, mode):
         n = fx["pos"].shape[0]
         sh = HaloShard.from_graph(fx["edge_index"].numpy(), fx["types"].numpy(), n, fx["shift_vec"].numpy(), rank, world, "cpu", dtype)
         order = torch.arange(n)
+    elif mode == "owned":  # a domain-decomposed host: every rank is handed ONLY the atoms of its slab (unequal counts), nothing O(N)
+        dtype = torch.float32
+        fx = load_model_fixture("c2", dtype)
+        m = model_from_fixture(fx, dtype, emu_lib())
+        n = fx["pos"].shape[0]
+        cell = np.eye(3) * (2 * 5.431)
+        bounds = [0.0] + [min(0.97, (q + 0.37) / world) for q in range(1, world)] + [1.0]  # (slabs of unequal width)
+        fxx = torch.remainder(fx["pos"][:, 0].double() / (2 * 5.431), 1.0)
+        mine = torch.nonzero((fxx >= bounds[rank]) & (fxx < bounds[rank + 1])).reshape(-1)
+        sh = HaloShard.from_owned(fx["pos"][mine].contiguous(), fx["types"][mine], cell, float(fx["cfg"]["r_max"]), rank, world, bounds=bounds,
+                                  lib=emu_lib())
+        assert sh.n_own == mine.numel() and sh.order is None
+        counts = [None] * world
+        dist.all_gather_object(counts, mine)
+        order = torch.cat(counts)  # rank-major global id -> the frame's atom id
     else:  # BASELINE config 1 (64-atom Si cell): every rank builds ONLY its slab's neighbour list from the positions
         dtype = torch.float32
         fx = load_model_fixture("c2", dtype)
@@ -174,7 +189,7 @@ def _worker_halo(rank, world, port, q, mode):
         e, f = energy_forces_halo(m, pos_own, sh)
     finally:
         dist.all_to_all_single = orig
-    assert len(calls) == (4 if world > 1 else 0)  # forward + reverse communication, nothing else, per step
+    assert len(calls) == (4 if world > 1 else 0), len(calls)  # forward + reverse communication, nothing else, per step
     parts = [None] * world
     dist.all_gather_object(parts, (sh.a0, sh.a1, e.clone(), f.clone(), sh.n_ghost, sh.graph.num_edges, sum(sh.send_counts)))
     if rank == 0:
@@ -189,14 +204,15 @@ def _worker_halo(rank, world, port, q, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "graph"), (8, "graph"), (2, "positions"), (8, "positions")])
+@pytest.mark.parametrize("world,mode", [(2, "graph"), (8, "graph"), (2, "positions"), (8, "positions"), (2, "owned"), (5, "owned")])
 def test_halo_exchange_of_ghost_rows_matches_reference(world, mode):
     """reverse communication of ghost rows only (two all_to_all_single per step, energies local) instead of
     the O(N) all-reduce; every rank holds its own atoms' positions only; with mode "positions" every rank builds its slab's
-    neighbour list itself (no rank sees the full edge list).  Results: the reference's golden vectors."""
+    neighbour list itself (no rank sees the full edge list); with mode "owned" every rank is handed only the atoms of its slab
+    (`HaloShard.from_owned`: halo candidates exchanged between the ranks, no replicated frame).  Results: the reference's golden vectors."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() + 41 * world + (7 if mode == "graph" else 0)) % 2000
+    port = 33500 + (os.getpid() + 41 * world + {"graph": 7, "positions": 0, "owned": 19}[mode]) % 2000
     procs = [ctx.Process(target=_worker_halo, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
