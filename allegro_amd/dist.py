@@ -353,8 +353,9 @@ class HaloShard:
             raise ValueError("HaloShard.from_owned: bounds must rise from 0 to 1 in world + 1 steps")
         frac = torch.linalg.solve(cell_t.T.to(dev), pos_own.double().T).T if n_own else torch.zeros((0, 3), dtype=torch.float64, device=dev)
         fx = frac[:, axis] - torch.floor(frac[:, axis])
-        if n_own and not bool(((fx >= bounds[rank] - 1e-9) & (fx < bounds[rank + 1] + 1e-9)).all()):
-            raise ValueError(f"HaloShard.from_owned: rank {rank} was handed atoms outside its slab [{bounds[rank]}, {bounds[rank + 1]}) along axis {axis}")
+        # (a rank-local defect must not leave the other ranks blocked in the first collective: the verdict travels WITH the counts --
+        #  a rank whose atoms lie outside its slab announces -1 atoms, and every rank raises after the exchange)
+        local_ok = not n_own or bool(((fx >= bounds[rank] - 1e-9) & (fx < bounds[rank + 1] + 1e-9)).all())
         multi = world > 1
         if multi:
             assert dist.is_initialized(), "HaloShard.from_owned with world > 1 needs an initialised process group"
@@ -362,10 +363,14 @@ class HaloShard:
         # global numbering: rank-major
         counts = torch.zeros(world, dtype=torch.int64, device=dev)
         if multi:
-            mine = torch.full((world,), n_own, dtype=torch.int64, device=dev)
+            mine = torch.full((world,), n_own if local_ok else -1, dtype=torch.int64, device=dev)
             _all_to_all_rows(counts, mine, None, None, group, host_staged)  # (counts[p] = atoms of rank p)
         else:
-            counts[0] = n_own
+            counts[0] = n_own if local_ok else -1
+        bad = [p for p, c in enumerate(counts.tolist()) if c < 0]
+        if bad:
+            raise ValueError(f"HaloShard.from_owned: rank(s) {bad} were handed atoms outside their slab along axis {axis} "
+                             f"(this rank: {rank}, slab [{bounds[rank]}, {bounds[rank + 1]}))")
         cuts = [0] + torch.cumsum(counts, 0).tolist()
         # candidates for every other rank: my atoms within r_cut (with a margin) of its slab, periodic along the axis
         height = float(torch.linalg.det(cell_t).abs() / torch.linalg.norm(torch.linalg.cross(cell_t[(axis + 1) % 3], cell_t[(axis + 2) % 3])))

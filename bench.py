@@ -715,14 +715,45 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches itself: one process per GPU under torch.distributed.run on this node (rendezvous on
+        # 127.0.0.1, a free port), same arguments; the ranks below read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL between processes needs dmabuf IPC on this stack)
+        os.environ.setdefault("OMP_NUM_THREADS", "4")
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # TEST-ONLY (tests/test_bench_launch.py): AA_BENCH_EMULATED=1 runs the N > 1 launch line on a box without a GPU -- CPU tensors through
+    # the CPU emulation build of the same kernel sources (tests/emu), gloo, no profile.  The line says so in `data`; never a measurement.
+    emulated = os.environ.get("AA_BENCH_EMULATED") == "1"
+    if emulated:
+        if not (world > 1 and WORKLOADS[args.workload]["kind"] == "si" and args.dist_mode == "halo"):
+            raise SystemExit("AA_BENCH_EMULATED=1 is the launch-line test of the sharded branch only (--gpus N > 1, a Si workload)")
+        from tests.hip_utils import emu_lib
+
+        os.environ["AA_BENCH_BACKEND"] = "gloo"
+        args.no_profile, args.sustain = True, 0.0
+        torch.cuda.synchronize = lambda *a, **k: None
+    assert emulated or torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # (AA_BENCH_BACKEND=gloo AA_BENCH_DEVICE=0: the N > 1 code path with all ranks on ONE device and host-staged rows -- how the
     #  launch line of the driver's scaling run is exercised end to end on a one-GPU box; RCCL refuses two ranks on one GPU)
     backend = os.environ.get("AA_BENCH_BACKEND", "nccl")
-    dev = torch.device("cuda", int(os.environ.get("AA_BENCH_DEVICE", local_rank)))
-    torch.cuda.set_device(dev)
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: {torch.cuda.device_count()} GPU(s) visible and RCCL takes one rank per device "
+                         "(AA_BENCH_BACKEND=gloo AA_BENCH_DEVICE=0 runs the same code path with all ranks on one device, rows staged "
+                         "through the host: a launch-line check, not a scaling measurement)")
+    dev = torch.device("cpu") if emulated else torch.device("cuda", int(os.environ.get("AA_BENCH_DEVICE", local_rank)))
+    if not emulated:
+        torch.cuda.set_device(dev)
+    bench_lib = emu_lib() if emulated else None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -735,6 +766,7 @@ def main():
 
     halo = (world > 1 or args.emulate_shard or args.shard_sweep) and args.dist_mode == "halo" and WORKLOADS[args.workload]["kind"] == "si"
     shard = None
+    owned_mode, pos_local = False, None
     if halo:
         # no rank ever holds the full edge list: positions of the box (the one O(N) array, 1.2 MB at C4) -> slab order -> this
         # rank's slab + halo -> device cell list of that subset only (allegro_amd/dist.py: HaloShard.from_positions)
@@ -747,12 +779,13 @@ def main():
         cfg["num_tensor_features"] = w.get("u", cfg["num_tensor_features"])
         cfg["model_dtype"] = w["dtype"]
         dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
-        pos = torch.tensor(pos_np, dtype=dtype, device=dev)
-        types = torch.zeros(N, dtype=torch.int64, device=dev)
+        owned_mode = world > 1 and not args.emulate_shard and not args.shard_sweep and os.environ.get("AA_BENCH_SHARDS", "owned") == "owned"
+        pos = None if owned_mode else torch.tensor(pos_np, dtype=dtype, device=dev)  # (owned mode: the frame never reaches a device)
+        types = None if owned_mode else torch.zeros(N, dtype=torch.int64, device=dev)
         L = cfg["num_layers"]
 
         def make_shard(r, wsize, connect):
-            return HaloShard.from_positions(pos, types, cell_np, rcut, r, wsize, connect=connect)
+            return HaloShard.from_positions(pos, types, cell_np, rcut, r, wsize, connect=connect, lib=bench_lib)
 
         if args.shard_sweep:
             # every rank's shard through the functions a W-rank job runs (pack_forward, the hot path, accumulate_reverse), with the
@@ -836,16 +869,30 @@ def main():
                   flush=True)
             return
         er, ew = (int(x) for x in args.emulate_shard.split("/")) if args.emulate_shard else (rank, world)
-        shard = make_shard(er, ew, not args.emulate_shard)
+        if owned_mode:
+            # a domain-decomposed host: the rank hands over ONLY the atoms of its slab (the synthetic generator stands in for the MD
+            # code that owns them); halo candidates are exchanged between the ranks, no rank holds the frame on its device
+            # (HaloShard.from_owned; AA_BENCH_SHARDS=positions keeps the replicated-frame constructor for A/B)
+            fx = pos_np @ np.linalg.inv(cell_np)
+            fx = fx[:, 0] - np.floor(fx[:, 0])
+            mine = (fx >= rank / world) & (fx < (rank + 1) / world)
+            pos_own = torch.tensor(pos_np[mine], dtype=dtype, device=dev)
+            shard = HaloShard.from_owned(pos_own, torch.zeros(int(mine.sum()), dtype=torch.int64, device=dev), cell_np, rcut, rank, world,
+                                         lib=bench_lib)
+        else:
+            shard = make_shard(er, ew, not args.emulate_shard)
         e_loc = torch.tensor([shard.graph.num_edges], dtype=torch.int64, device=dev)
         if dist is not None:
             dist.all_reduce(e_loc)
         E = int(e_loc.item()) if dist is not None else shard.graph.num_edges * ew  # (emulated shard: analysis only)
         cfg["avg_num_neighbors"] = E / N
         model = HipAllegroModel(**cfg).to(dev)
+        if bench_lib is not None:
+            model._bind_library(bench_lib)
         graph = shard.graph
-        pos_local = shard.fill_local_positions(pos)
-        pos_own = pos_local[: shard.n_own].clone()
+        if not owned_mode:
+            pos_local = shard.fill_local_positions(pos)
+            pos_own = pos_local[: shard.n_own].clone()
         a0, a1 = shard.a0, shard.a1
         e0, e1 = 0, shard.graph.num_edges
         g = None
@@ -915,13 +962,23 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0  # this rank's own K steps (its waits inside the collectives included), before the closing barrier
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tr = torch.zeros(world, dtype=torch.float64, device=dev)
+        tr[rank] = dt_rank / args.steps * 1e3
+        dist.all_reduce(tr)
+        ne = torch.zeros(world, dtype=torch.int64, device=dev)
+        ne[rank] = e1 - e0
+        dist.all_reduce(ne)
+        rank_ms = {"max": float(tr.max()), "mean": float(tr.mean()), "min": float(tr.min()), "per_rank": [round(float(x), 4) for x in tr],
+                   "edges_per_rank": [int(x) for x in ne]}
     ms_per_step = dt / args.steps * 1e3
     # sustained run (outside the timed region, same step): the K-step region of the contract is ~0.2 s at C4, too short
     # for an independent utilisation sampler; all ranks take part so the collective pattern is the same
@@ -950,18 +1007,26 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32" if dtype == torch.float32 else "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not emulated else "synthetic; EMULATED kernels on CPU (launch-line test, not a measurement)",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "atoms": N, "edges": E,
                        "edges_per_s": E / t_step, "ns_per_day_at_1fs": 0.0864 / t_step,
-                       "parallelism": ((f"atom-block x{world}: slab shards built from positions alone (owned block + ghost atoms), sharded positions, "
-                                        "forward + reverse communication of ghost rows (2 all_to_all_single per step)") if world > 1 and halo else
+                       "parallelism": ((f"atom-block x{dist.get_world_size()} over {dist.get_backend()}"
+                                        f"{' (RCCL)' if dist.get_backend() == 'nccl' else ''}: slab shards "
+                                        + ("from each rank's OWN atoms (HaloShard.from_owned: halo candidates exchanged, no replicated frame)"
+                                           if owned_mode else "built from positions alone (owned block + ghost atoms)")
+                                        + ", sharded positions, forward + reverse communication of ghost rows (2 all_to_all_single per step)")
+                                       if world > 1 and halo else
                                        (f"atom-block x{world}: compact shards (owned block + ghost atoms), one all-reduce of F[N,3]"
                                         if world > 1 else "single GPU")),
                        "weights": "random init (reference initialisers), seed 456"},
         }
         if sustained is not None:
             line["config"]["sustained"] = sustained
+        if rank_ms is not None:
+            line["config"]["rank_ms_per_step"] = rank_ms
         if not args.no_profile:
+            if halo and shard is not None and pos_local is None:
+                pos_local = shard._buffers(dtype, dev)[0]  # (owned + ghost rows as the last timed step left them)
             stages = profile_stages(model, pos if shard is None else (pos_local if halo else pos.index_select(0, shard.local_ids)), graph)
             roof, table = roofline_from_stages(stages, cfg["model_dtype"], args.workload, attach_traffic=shard is None)
             if roof.get("kernel", "").startswith("fused_fwd"):
