@@ -10,7 +10,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_tp_dense.hip", "aa_train.hip", "aa_edge.hip", "aa_fused.hip", "aa_model.hip", "aa_nl.hip", "aa_hostfile.hip"]
+SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_tp_dense.hip", "aa_train.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused8.hip", "aa_model.hip", "aa_nl.hip", "aa_hostfile.hip"]
 # public C ABI header: the package ships its own copy (package data, so that an installed package can rebuild itself);
 # in the source tree it is the same file as <repo>/include/allegro_amd.h (tests/test_lib_symbols.py checks identity)
 INCLUDE_DIR = os.path.join(HERE, "include")

@@ -749,7 +749,12 @@ int fused_bwd_tail_num_steps(int R);
 int fused_bwd_tail_chunk_order(int R, int i);
 int launch_fused_bwd_tail(int pair, const FusedTailArgs& a, hipStream_t stream);
 int fused_fwd_num_steps(int R, bool hold_w0);
-int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream);
+// `wide` (nullable): the same arguments with the weight program of the eight-wave form (aa_fused8.hip) -- it then takes the one-tile
+// pass (all atoms, or all but the long ones of the mixed form); the team pass keeps `a`
+int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream, const FusedFwdArgs* wide = nullptr);
+int fused_fwd8_num_steps(int R);
+size_t fused_fwd8_lds_bytes(int num_types);
+int launch_fused_fwd8(int pair, const FusedFwdArgs& a, hipStream_t stream);
 
 
 // ----------------------------------------------------------------------------------------------

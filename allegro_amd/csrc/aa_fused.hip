@@ -626,7 +626,27 @@ static int launch_fused_fwd_one(int pair, bool hold_w0, const FusedFwdArgs& a, h
 // handful of Si atoms past 32 neighbours; profiles/r05_v23_md_loop_c4.json).  The team form costs every atom ~12 % (class lists,
 // exchange area, 2 fewer tile parkings), the staged pipeline ~12 % of the step: instead the one-tile kernel runs over all atoms at
 // full speed and SKIPS the long ones, and a second, small launch of the team form takes exactly those (its grid is the list).
-int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream) {
+int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream, const FusedFwdArgs* wide) {
+  const bool teams = a.tile_atoms != nullptr;
+  if (wide && (!teams || a.mixed)) {
+    // the one-tile pass on the eight-wave form (two waves per SIMD); the team pass over the long atoms, if any, as below
+    if (a.atom_end <= a.atom0) return AA_OK;
+    if (a.N > 0 && (a.atom0 > 0 || a.atom_end < a.N) && !a.fill_done) {
+      hipLaunchKernelGGL(fused_fill_energy_kernel, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, stream, a.N, a.atom0, a.atom_end,
+                         a.types, a.shifts, a.atom_energy);
+    }
+    FusedFwdArgs one = *wide;
+    one.tile_atoms = nullptr;
+    one.tile_counts = nullptr;
+    one.tile_cap = 0;
+    one.skip_long = teams ? 1 : 0;
+    if (int rc = launch_fused_fwd8(pair, one, stream)) return rc;
+    if (!teams) return AA_OK;
+    FusedFwdArgs team = a;
+    team.long_only = 1;
+    team.fill_done = 1;
+    return launch_fused_fwd_one(pair, hold_w0, team, stream);
+  }
   if (!a.mixed || a.tile_atoms == nullptr) return launch_fused_fwd_one(pair, hold_w0, a, stream);
   FusedFwdArgs one = a;
   one.tile_atoms = nullptr;

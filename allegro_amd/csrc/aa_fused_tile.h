@@ -83,6 +83,45 @@ __device__ __forceinline__ void pipe_commit(FusedPipe& p) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// The same pipeline staged by EIGHT waves (512 threads x 24 B = 12 KB; aa_fused8.hip): thread t moves element t, threads 0..255
+// also element 512 + t.  Wave-uniform bases as above: elements 0..383 are the first 6-KB half, 384..767 the second.
+struct FusedPipe8 {
+  u32x4 ra[2], rb[2];
+  u32x4* wbuf;  // [2][kWStep]
+  int tid, lane;
+  int wv;    // wave of the workgroup (scalar)
+  int zero;  // (see FusedPipe)
+};
+template <class Args>
+__device__ __forceinline__ void pipe_load8(const Args& A, const FusedPipe8& p, int t, u32x4* r) {
+  const u32x4* s0 = static_cast<const u32x4*>(A.wstep[t + p.zero][0]);
+  const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t + p.zero][1]);
+  const u32x4* b0 = p.wv < 6 ? s0 : s1 - 384;
+  r[0] = b0[p.tid];
+  if (p.wv < 4) r[1] = (s1 + 128)[p.tid];
+}
+__device__ __forceinline__ void pipe_store8(const FusedPipe8& p, int b, const u32x4* r) {
+  u32x4* d = p.wbuf + b * kWStep;
+  d[p.tid] = r[0];
+  if (p.wv < 4) d[512 + p.tid] = r[1];
+}
+template <int S, int NS, class Args>
+__device__ __forceinline__ void pipe_issue(const Args& A, FusedPipe8& p) {
+  if constexpr ((S & 1) == 0)
+    pipe_load8(A, p, (S + 2) % NS, p.ra);
+  else
+    pipe_load8(A, p, (S + 2) % NS, p.rb);
+}
+template <int S>
+__device__ __forceinline__ void pipe_commit(FusedPipe8& p) {
+  if constexpr (((S + 1) & 1) == 0)
+    pipe_store8(p, 0, p.ra);
+  else
+    pipe_store8(p, 1, p.rb);
+  lds_barrier();
+  __builtin_amdgcn_sched_barrier(0);  // (one scheduling region per step: see pipe_commit above)
+}
+
 // 24 MFMAs of one step (6 cross products x 2 k halves x 2 tiles); weight levels read from LDS just in time
 __device__ __forceinline__ void fused_mma_step(const u32x4* wb, int lane, const XSplit& x, v16f& acc0, v16f& acc1) {
   const u32x4* w = wb + lane;
@@ -132,8 +171,8 @@ __device__ __forceinline__ void fused_mma_step(const u32x4* wb, int lane, const 
 __device__ __forceinline__ void to_xsplit(const v16f& t, XSplit& x) { xsplit_from_acc(t, x); }
 __device__ __forceinline__ void to_xsplit(const XSplit& t, XSplit& x) { x = t; }
 
-template <int S0, int NS, int KC, int NT, class Args, class OpF, class EpiF>
-__device__ __forceinline__ void fused_layer(const Args& A, FusedPipe& p, OpF&& op, EpiF&& epi) {
+template <int S0, int NS, int KC, int NT, class Args, class Pipe, class OpF, class EpiF>
+__device__ __forceinline__ void fused_layer(const Args& A, Pipe& p, OpF&& op, EpiF&& epi) {
   static_assert(NT % 2 == 0, "output tiles come in pairs");
   constexpr bool PRE = NT > 2;
   constexpr bool PIPE = true;
@@ -225,15 +264,15 @@ __device__ __forceinline__ void tile_moments(float* sA, const float* sY, const v
 
 // x2s[j] (lane = channel) = f * sum_k M[j][k] * Wk[k][r(j)][ch].  M is handed over through sM [k][D]; the env-weight
 // matrix Wk [64][R][64] arrives through the weight pipeline as 4 blocks of 16 rows (steps S0 .. S0 + 3).
-template <int S0, int NS, int D, int R, class Args>
-__device__ __forceinline__ void project_moments(const Args& A, FusedPipe& p, float* sM, const float* M, float sf, float* x2s) {
+template <int S0, int NS, int D, int R, int LDY = kLdY, class Args, class Pipe>
+__device__ __forceinline__ void project_moments(const Args& A, Pipe& p, float* sM, const float* M, float sf, float* x2s) {
   const int lane = p.lane;
 #pragma unroll
   for (int q = 0; q < (D + 3) / 4; ++q) {
     v4f mm;
 #pragma unroll
     for (int i = 0; i < 4; ++i) mm[i] = 4 * q + i < D ? M[4 * q + i] : 0.f;
-    *reinterpret_cast<v4f*>(sM + lane * kLdY + 4 * q) = mm;
+    *reinterpret_cast<v4f*>(sM + lane * LDY + 4 * q) = mm;
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -251,7 +290,7 @@ __device__ __forceinline__ void project_moments(const Args& A, FusedPipe& p, flo
 #pragma unroll
       for (int r = 0; r < R; ++r) w[r] = wf[(kk * R + r) * 64];
 #pragma unroll
-      for (int q = 0; q < Q; ++q) m[q] = *reinterpret_cast<const v4f*>(sM + (16 * c + kk) * kLdY + 4 * q);
+      for (int q = 0; q < Q; ++q) m[q] = *reinterpret_cast<const v4f*>(sM + (16 * c + kk) * LDY + 4 * q);
     };
     auto consume = [&](const float* w, const v4f* m) {
 #pragma unroll
@@ -266,6 +305,12 @@ __device__ __forceinline__ void project_moments(const Args& A, FusedPipe& p, flo
       consume(wa, ma);
       if (kk + 2 < 16) fetch(kk + 2, wa, ma);
       consume(wb, mb);
+      // (at 256 registers the rows of a whole block are still gathered at the front and spilled -- sched_barrier binds the machine
+      //  scheduler only; an anchor is a memory barrier to every pass)
+      if constexpr (std::is_same_v<Pipe, FusedPipe8>) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) anchor(x2s[j]);  // (every accumulation chain: an unpinned one is sunk below the block with its operands live)
+      }
       __builtin_amdgcn_sched_barrier(0);  // at most two rows' LDS operands in flight beyond the ones being consumed
     }
     pipe_commit<S>(p);
@@ -278,8 +323,8 @@ __device__ __forceinline__ void project_moments(const Args& A, FusedPipe& p, flo
 // accumulator layout whose 32 columns are the components j (columns >= D carry zeros) and whose features are k; irrep r's 64x64
 // env-weight matrix is an ordinary bf16x3 layer (steps S0 + 2 r, S0 + 2 r + 1) whose output columns j in irrep r are kept; the
 // result returns to the lane = channel view through sX [D][64] behind sM.
-template <int S0, int NS, int D, int R, class Args>
-__device__ __forceinline__ void project_moments_mfma(const Args& A, FusedPipe& p, float* sM, const float* M, float sf, float* x2s) {
+template <int S0, int NS, int D, int R, class Args, class Pipe>
+__device__ __forceinline__ void project_moments_mfma(const Args& A, Pipe& p, float* sM, const float* M, float sf, float* x2s) {
   const int lane = p.lane, el = lane & 31, hh = lane >> 5;
   float* sX = sM + 64 * kLdY;
   static_assert(64 * kLdY + 16 * 64 <= kWaveRegion, "moments + result patch must fit the wave region");

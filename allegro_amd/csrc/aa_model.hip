@@ -223,6 +223,7 @@ struct aa_model_plan {
   bool chain_gemm;                   // MLP chains fused into gemm_chain_bf16x3_kernel (hidden layers stay in registers)
   bool fused_fwd;                    // the whole forward as ONE per-atom-tile kernel when the graph allows (aa_fused.hip)
   bool fused_hold_w0;                // ... holding the w0 tiles in registers between the two layers (else: recomputed)
+  bool fused_wide = false;           // ... its one-tile pass on the eight-wave form (two waves per SIMD, aa_fused8.hip)
   mutable bool taps = false;         // aa_model_plan_enable_taps: staged pipeline so that every tap is materialised
   bool embed_fused;                  // reverse pass: d(two-body embedding) [E,S0] never materialised, the last reverse chain
                                      // contracts it back to the 8 basis functions in its epilogue (embrev_out in aa_common.h)
@@ -601,6 +602,10 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     p->fused_tail = false;
 #endif
     p->fused_hold_w0 = !opt.fused_recompute_w0;  // A/B: recompute w0 for the second layer instead of holding it
+    // the eight-wave form needs the folded program (every fold active), a two-body table that leaves 16.6 KB of LDS per wave
+    // (one species) and the w0 rows of the staged reverse pass (no fused tail)
+    p->fused_wide = p->fused_fwd && kFoldEmbed && kFoldEmb1 && kFoldLatent && !kProjMfma && p->o_embtab_h != 0 && p->o_g0fq != 0 &&
+                    p->o_lat1in_fq != 0 && !opt.fused_narrow && !p->fused_tail && fused_fwd8_lds_bytes(cfg->num_types) <= 160 * 1024;
   }
   {
     void* st = nullptr;
@@ -626,11 +631,12 @@ extern "C" int aa_model_plan_describe(const aa_model_plan* p, char* buf, size_t 
   const int k = snprintf(buf, n,
                          "{\"fused_forward\": %s, \"fold_embed_table\": %s, \"fold_embed_output\": %s, \"fold_latent_outputs\": %s, "
                          "\"fold_lat0_reverse\": %s, \"fused_mfma_steps_executed\": %d, \"fused_mfma_steps_reference\": %d, "
-                         "\"chain_gemm\": %s, \"moments\": %s, \"operator_path\": %s, \"slot_form\": %s}",
+                         "\"chain_gemm\": %s, \"moments\": %s, \"operator_path\": %s, \"slot_form\": %s, \"fused_wide\": %s}",
                          fused ? "true" : "false", (fused && kFoldEmbed && p->o_embtab_h) ? "true" : "false",
                          (fused && kFoldEmb1 && p->o_g0fq) ? "true" : "false", (fused && kFoldLatent && p->o_lat1in_fq) ? "true" : "false",
                          (kFoldLat0Rev && p->o_b3bf_q) ? "true" : "false", exec_steps, fused ? ref_steps : 0, p->chain_gemm ? "true" : "false",
-                         p->env_mom ? "true" : "false", p->tp_op >= 0 ? "true" : "false", p->slot_form ? "true" : "false");
+                         p->env_mom ? "true" : "false", p->tp_op >= 0 ? "true" : "false", p->slot_form ? "true" : "false",
+                         p->fused_wide ? "true" : "false");
   return (k < 0 || size_t(k) >= n) ? fail(AA_ERR_INVALID, "aa_model_plan_describe: buffer too small") : k;
 }
 
@@ -1940,18 +1946,19 @@ struct Runner {
     a.emb_tab = wf(kFoldEmbed ? p->o_embtab_h : p->o_embtab);  // (folded: the table yields the first layer's pre-activation)
     // the weight program of the kernel (see fused_fwd_kernel): 12-KB blocks in execution order
     int ns = 0;
+    FusedFwdArgs* prog = &a;  // (the program under construction: `a`, later the eight-wave form's copy)
     auto add_layer = [&](const float* Wq, int KC, int tile0, int ntiles) {
       for (int t = tile0; t < tile0 + ntiles; t += 2)
         for (int kc = 0; kc < KC; ++kc) {
-          a.wstep[ns][0] = Wq + (size_t(t) * KC + kc) * 64 * 24;
-          a.wstep[ns][1] = Wq + (size_t(t + 1) * KC + kc) * 64 * 24;
+          prog->wstep[ns][0] = Wq + (size_t(t) * KC + kc) * 64 * 24;
+          prog->wstep[ns][1] = Wq + (size_t(t + 1) * KC + kc) * 64 * 24;
           ++ns;
         }
     };
     auto add_env = [&](const float* Wk) {
       for (int cblk = 0; cblk < 4; ++cblk) {
-        a.wstep[ns][0] = Wk + size_t(cblk) * 16 * p->R * 64;
-        a.wstep[ns][1] = Wk + size_t(cblk) * 16 * p->R * 64 + 1536;  // (blocks are loaded as 2 x 6 KB; 16 R 256 B are used)
+        prog->wstep[ns][0] = Wk + size_t(cblk) * 16 * p->R * 64;
+        prog->wstep[ns][1] = Wk + size_t(cblk) * 16 * p->R * 64 + 1536;  // (blocks are loaded as 2 x 6 KB; 16 R 256 B are used)
         ++ns;
       }
     };
@@ -1999,8 +2006,35 @@ struct Runner {
     a.atom_energy = static_cast<float*>(atom_energy);
     a.status = p->status;
     a.keep = p->opt.fused_keep_split == 0 ? kFusedKeepDefault : p->opt.fused_keep_split - 1;
+    // the eight-wave form of the one-tile pass (aa_fused8.hip): its own step order -- Wenv0 | first stage | latent 0 | Wenv1 |
+    // latent 1: scal1 chunks | [lat0, two-body] chunks x {latent 1, readout} | readout: lat1 chunks
+    FusedFwdArgs a8{};
+    const bool wide = p->fused_wide && folde && foldl && a.w0 != nullptr && (a.tile_atoms == nullptr || a.mixed);
+    if (wide) {
+      a8 = a;
+      ns = 0;
+      prog = &a8;
+      auto add_step = [&](const float* Wq, int KC, int kc) {  // one step: the tile pair (0, 1) x chunk kc of a KC-chunk layer
+        prog->wstep[ns][0] = Wq + (size_t(0) * KC + kc) * 64 * 24;
+        prog->wstep[ns][1] = Wq + (size_t(1) * KC + kc) * 64 * 24;
+        ++ns;
+      };
+      add_env(wf(p->o_wk0f));
+      add_layer(wf(p->o_g0fq), 2, 0, 2 + 2 * p->R);
+      add_layer(wf(p->latent[0].wq[0]), 4, 0, 2);
+      add_env(wf(p->o_wk[1]));
+      add_step(wf(p->o_lat1in_fq), 6, 4);
+      add_step(wf(p->o_lat1in_fq), 6, 5);
+      for (int kc : {2, 3, 0, 1}) {
+        add_step(wf(p->o_lat1in_fq), 6, kc);
+        add_step(wf(p->o_ro0_fq), 6, kc);
+      }
+      add_step(wf(p->o_ro0_fq), 6, 4);
+      add_step(wf(p->o_ro0_fq), 6, 5);
+      if (ns != fused_fwd8_num_steps(p->R)) return fail(AA_ERR_INVALID, "fused forward (wide): program length mismatch");
+    }
     if (int rc = mark("begin")) return rc;
-    if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream)) return rc;
+    if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream, wide ? &a8 : nullptr)) return rc;
     // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;
     // position, two x2s blocks, energy, row pointer per atom.  Flops: the linear layers of the forward (w0 counted once).
     const double per_edge = 1 + (g->shift_vec ? 3 : 0) + 3 + 4 + p->D + 5 * 64 + p->W;

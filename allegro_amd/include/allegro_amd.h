@@ -303,6 +303,8 @@ typedef struct {
                              * by the forward's energy reduction, which reads the same rows (A/B, tests)                          */
   int32_t tp_prefer_moments; /* 2-layer u = 64 stacks the fused chains do not cover (fp64; S or MLP widths of 128): 1 = the 2-layer moments
                               * kernels + single linear layers (the selection up to round 4) instead of the operator kernels (A/B, tests) */
+  int32_t fused_narrow;     /* fused forward, one-tile pass: 1 = the four-wave workgroup form (one wave per SIMD, round 2-5) also where the
+                             * eight-wave form (two waves per SIMD, aa_fused8.hip: one species, folded program) applies (A/B, tests)        */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

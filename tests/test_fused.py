@@ -90,6 +90,40 @@ def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch
         assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
+def _wide_vs_narrow(name, lib, dev, monkeypatch):
+    """One-species plans take the eight-wave form of the one-tile pass (two waves per SIMD, aa_fused8.hip: its own weight program,
+    merged latent-1 / readout phase, w0 re-read from the stored rows); AA_FUSED_NARROW=1 keeps the four-wave form.  Same function:
+    both against the reference's golden vectors and against each other to rounding (the summation orders differ)."""
+    fx = load_model_fixture(name, torch.float32)
+    out = {}
+    for narrow in ("0", "1"):
+        monkeypatch.setenv("AA_FUSED_NARROW", narrow)
+        m = model_from_fixture(fx, torch.float32, lib, device=dev)
+        assert m.describe_plan()["fused_wide"] == (narrow == "0")
+        data, sv = fixture_data(fx, torch.float32, dev)
+        g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+        assert 0 < g.max_degree <= 32
+        e, f = m.energy_forces(data["pos"], g)
+        assert "fused_fwd" in _launches(m, data, g)
+        out[narrow] = (e.cpu().clone(), f.cpu().clone())
+        for got, want in ((out[narrow][0], fx["out"]["atomic_energy"].reshape(-1)), (out[narrow][1], fx["out"]["forces"])):
+            assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
+    for a, b in zip(out["0"], out["1"]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_eight_wave_form_matches_the_four_wave_form_and_the_golden_vectors_emulated(monkeypatch):
+    _opt_in(monkeypatch)
+    _wide_vs_narrow("c2", emu_lib(), torch.device("cpu"), monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c2", "c2_spline", "c2_l1", "c2_uncoupled", "c1_L2"])
+def test_eight_wave_form_matches_the_four_wave_form_and_the_golden_vectors_on_gpu(name, monkeypatch):
+    _opt_in(monkeypatch)
+    _wide_vs_narrow(name, None, torch.device("cuda"), monkeypatch)
+
+
 @pytest.mark.parametrize("mode,embed,coupling", [("tile32", "spline", False)])
 def test_fused_forward_ragged_graph_vs_fp64_oracle_emulated(mode, embed, coupling, monkeypatch):
     _opt_in(monkeypatch, mode)
