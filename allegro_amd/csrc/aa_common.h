@@ -716,6 +716,8 @@ struct FusedFwdArgs {
   int32_t* status;     // nullable, host-visible: set to the offending degree when a segment exceeds what the max_degree hint promised
   int mixed;           // with the class lists set: one-tile pass over all atoms (long ones skipped) + team pass over the long ones only
   int skip_long, long_only, fill_done;  // (set by launch_fused_fwd for the two passes of the mixed form)
+  int wide_proj_mfma;  // two-waves-per-SIMD form: env projections as bf16x3 layers on the matrix cores (its program then has 2 R steps per projection)
+  int wide_waves;      // two-waves-per-SIMD form (aa_fused8.hip): 4 = four-wave workgroups except on small boxes; -4 / -8: four / eight waves, forced
 };
 size_t fused_fwd_lds_bytes(int num_types, bool teams);  // dynamic LDS of the fused forward (aa_fused.hip); the CU has 160 KB
 // reverse tail (aa_fused_bwd.hip): layer-0 tensor product reverse + first-stage / scalar_embed_mlp reverse + edge reverse
@@ -752,9 +754,9 @@ int fused_fwd_num_steps(int R, bool hold_w0);
 // `wide` (nullable): the same arguments with the weight program of the eight-wave form (aa_fused8.hip) -- it then takes the one-tile
 // pass (all atoms, or all but the long ones of the mixed form); the team pass keeps `a`
 int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream, const FusedFwdArgs* wide = nullptr);
-int fused_fwd8_num_steps(int R);
-size_t fused_fwd8_lds_bytes(int num_types);
-int launch_fused_fwd8(int pair, const FusedFwdArgs& a, hipStream_t stream);
+int fused_fwd8_num_steps(int R, bool proj_mfma);
+size_t fused_fwd8_lds_bytes(int num_types, int waves);  // per workgroup of 8 waves (one per CU) or 4 waves (two per CU)
+int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t stream);
 
 
 // ----------------------------------------------------------------------------------------------

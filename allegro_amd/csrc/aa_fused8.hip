@@ -46,7 +46,7 @@ constexpr int kLdY8 = 12;                    // row stride of the harmonics rows
 constexpr int kOffB8 = 32 * kLdT;            // sB [D <= 9][64] behind the store / moments patch
 constexpr int kOffY8 = kOffB8 + 9 * 64;      // sY [32][12]
 constexpr int kOffPark8 = kOffY8 + 32 * kLdY8;  // two parked 32-feature tiles (the two-body scalars)
-constexpr int kWave8 = kOffPark8 + 2 * kTileFloats;  // floats of LDS per wave: 4160 = 16 640 B
+constexpr int fused_wave_floats(int waves) { return kOffPark8 + (waves == 8 ? 2 : 1) * kTileFloats; }  // 16 640 / 12 544 B per wave
 static_assert(64 * kLdY8 <= 32 * kLdT, "sM must fit the patch");
 
 // M[j] (lane = k) = sum over the tile's rows of Y[e][j] * a[e][k], one 32-feature tile at a time through the [32][kLdT]
@@ -95,8 +95,8 @@ __device__ __forceinline__ void tile_moments_half(float* sT, const float* sY, co
 
 // one weight step: the 24 MFMAs of chunk `x` into the accumulator pair, `between` (the split of the next chunk, a parked-tile
 // fetch) behind them, then the commit (next block into LDS, barrier)
-template <int S, int NS, class Args, class F>
-__device__ __forceinline__ void fused_step8(const Args& A, FusedPipe8& p, const XSplit& x, v16f& a0, v16f& a1, F&& between) {
+template <int S, int NS, class Args, class Pipe, class F>
+__device__ __forceinline__ void fused_step8(const Args& A, Pipe& p, const XSplit& x, v16f& a0, v16f& a1, F&& between) {
   pipe_issue<S, NS>(A, p);
   fused_mma_step(p.wbuf + (S & 1) * kWStep, p.lane, x, a0, a1);
   between();
@@ -181,16 +181,25 @@ struct TileIn8 {
 
 }  // namespace
 
-constexpr int fused_fwd8_steps(int R) { return 4 + (2 + 2 * R) + 4 + 4 + 2 + 8 + 2; }
+constexpr int fused_fwd8_steps(int R, bool pm) { return (pm ? 2 * R : 4) + (2 + 2 * R) + 4 + (pm ? 2 * R : 4) + 2 + 8 + 2; }
 
-template <class Sig0, class Sig1>
-__global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
+// WAVES = 8: one workgroup per CU, eight tiles in lock step (both two-body tiles parked in LDS: 16.6 KB per wave).
+// WAVES = 4: TWO independent workgroups per CU (78 KB of LDS each: one two-body tile parked, the other in 16 registers), each with
+//            its own weight pipeline -- the two waves of a SIMD drift apart, so one workgroup's MFMA steps run beside the other's
+//            vector / LDS phases instead of both hitting the same pipe at the same time.
+template <class Sig0, class Sig1, int WAVES, bool PM>
+__global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs A) {
+  static_assert(WAVES == 8 || WAVES == 4, "workgroup forms");
+  constexpr int NT = 64 * WAVES;                   // threads
+  constexpr int NPARK = WAVES == 8 ? 2 : 1;        // parked two-body tiles
+  constexpr int kWaveF = kOffPark8 + NPARK * kTileFloats;  // floats of LDS per wave
   constexpr int D = Sig0::D2, R = Sig0::LMAX + 1;
   static_assert(Sig0::D1 == D && Sig0::DOUT == D && Sig1::D1 == D && Sig1::DOUT == 1, "standard 2-layer stack");
   static_assert(D <= 9, "l_max <= 2");
-  static_assert(kFoldEmbed && kFoldEmb1 && kFoldLatent && !kProjMfma, "the wide form exists for the folded program only");
-  constexpr int S_P0 = 0, S_L2 = 4, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L6A = S_P1 + 4, S_M = S_L6A + 2, S_L8K = S_M + 8, NS = S_L8K + 2;
-  static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps && NS == fused_fwd8_steps(R), "program length");
+  static_assert(kFoldEmbed && kFoldEmb1 && kFoldLatent, "the wide form exists for the folded program only");
+  constexpr int kPS = PM ? 2 * R : 4;  // pipeline steps of one env projection
+  constexpr int S_P0 = 0, S_L2 = kPS, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L6A = S_P1 + kPS, S_M = S_L6A + 2, S_L8K = S_M + 8, NS = S_L8K + 2;
+  static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps && NS == fused_fwd8_steps(R, PM), "program length");
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);  // [64] last readout weights
   float* sRm = sRo + 64;                                     // [16] 1 / r_max per type pair, [8] Bessel roots at 16
@@ -198,29 +207,35 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
   const int ntab = A.num_types * A.num_types * 512;
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, el = lane & 31;
   const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* sW = sTab + ntab + wvs * kWave8;  // patch (store transpose / moments half / sM)
+  float* sW = sTab + ntab + wvs * kWaveF;  // patch (store transpose / moments half / sM)
   float* sBv = sW + kOffB8;
   float* sY = sW + kOffY8;
   float* sPark = sW + kOffPark8;
-  for (int i = tid; i < 64; i += 512) sRo[i] = A.ro_w[i];
+  for (int i = tid; i < 64; i += NT) sRo[i] = A.ro_w[i];
   if (tid < A.num_types * A.num_types) sRm[tid] = A.rmax_recip[tid];
   if (tid >= 16 && tid < 24) sRm[tid] = A.embed_kind == 0 ? A.bessel_w[tid - 16] : 0.f;
-  for (int i = tid; i < ntab; i += 512) sTab[i] = A.emb_tab[i];
-  FusedPipe8 p;
+  for (int i = tid; i < ntab; i += NT) sTab[i] = A.emb_tab[i];
+  std::conditional_t<WAVES == 8, FusedPipe8, FusedPipe> p;
   p.wbuf = wbuf;
   p.tid = tid;
   p.lane = lane;
-  p.wv = wvs;
   p.zero = 0;
-  {
+  if constexpr (WAVES == 8) {
+    p.wv = wvs;
     u32x4 r[2];
     pipe_load8(A, p, 0, r);
     pipe_store8(p, 0, r);
     pipe_load8(A, p, 1, p.rb);  // (step 1 lands in LDS at the end of step 0)
+  } else {
+    p.stager = true;
+    u32x4 r[3];
+    pipe_load(A, tid, 0, r);
+    pipe_store(wbuf, 0, tid, r);
+    pipe_load(A, tid, 1, p.rb);
   }
-  const int64_t ngroups = (A.atom_end - A.atom0 + 7) / 8;
+  const int64_t ngroups = (A.atom_end - A.atom0 + WAVES - 1) / WAVES;
   auto group_of = [&](int64_t it) { return int64_t(blockIdx.x) + it * gridDim.x; };
-  auto atom_of = [&](int64_t it) -> int64_t { return A.atom0 + group_of(it) * 8 + wvs; };
+  auto atom_of = [&](int64_t it) -> int64_t { return A.atom0 + group_of(it) * WAVES + wvs; };
   auto load_rows = [&](int64_t atom, int& beg, int& cnt) {
     beg = 0;
     cnt = 0;
@@ -371,7 +386,10 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
       for (int q = 0; q < Sig0::P; ++q) wp0[q] = load_pw(A.tpw0, Sig0::P, q);
       float M[D];
       tile_moments_half<D>(sW, sY, em0, em1, lane, M);
-      project_moments<S_P0, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s0);
+      if constexpr (PM)
+        project_moments_mfma<S_P0, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s0, sBv);
+      else
+        project_moments<S_P0, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s0);
       if (atom_ok) {
 #pragma unroll
         for (int j = 0; j < D; ++j) (A.x2s0 + (atom * D + j) * 64)[unsigned(lane)] = x2s0[j];
@@ -386,7 +404,18 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
     }
     AA_TICK8(3)
     // ---- first stage: [two-body scalars | w0 irrep 0 | 1 | ...] = a_e @ W; layer-0 tensor-track scalars behind each irrep's pair
+    // (the lane's harmonics row comes back from sY where it is used: 9 registers less across the MFMA and per-atom phases)
+    auto load_Y = [&](float* Yv) {
+#pragma unroll
+      for (int q = 0; q < (D + 3) / 4; ++q) {
+        const v4f yy = *reinterpret_cast<const v4f*>(sY + el * kLdY8 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * q + i < D) Yv[4 * q + i] = yy[i];
+      }
+    };
     v16f sc0, sc1;
+    v16f tbr;  // (WAVES == 4: the second two-body tile, in registers)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       sc0[r] = 0.f;
@@ -398,11 +427,16 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
                                           constexpr int q = decltype(ntp)::value;
                                           if constexpr (q == 0) {
                                             park_tile(sPark, a0, lane);
-                                            park_tile(sPark + kTileFloats, a1, lane);
+                                            if constexpr (NPARK == 2)
+                                              park_tile(sPark + kTileFloats, a1, lane);
+                                            else
+                                              tbr = a1;
                                           } else {
                                             tile_store_rows8(sW, a0, (A.w0 + (q - 1) * 64) + row0 * 64 * R, cnt, 64 * R, lane);
                                             tile_store_rows8(sW, a1, (A.w0 + (q - 1) * 64 + 32) + row0 * 64 * R, cnt, 64 * R, lane);
-                                            tile_scal_accumulate8<q - 1>(sBv + 4 * hh, Y, a0, a1, sc0, sc1);
+                                            float Yv[D];
+                                            load_Y(Yv);
+                                            tile_scal_accumulate8<q - 1>(sBv + 4 * hh, Yv, a0, a1, sc0, sc1);
                                           }
                                         });
     AA_TICK8(4)
@@ -411,8 +445,10 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
     fused_layer<S_L3, NS, 4, 2>(A, p,
                                 [&](auto kc) {
                                   constexpr int k = decltype(kc)::value;
-                                  if constexpr (k < 2) {
+                                  if constexpr (k < NPARK) {
                                     return v16f(fetch_tile(sPark + k * kTileFloats, lane));
+                                  } else if constexpr (k < 2) {
+                                    return tbr;
                                   } else if constexpr (k == 2) {
                                     return sc0;
                                   } else {
@@ -435,14 +471,19 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
       for (int q = 0; q < Sig1::P; ++q) wp1[q] = load_pw(A.tpw1, Sig1::P, q);
       float M[D], x2s1[D];
       tile_moments_half<D>(sW, sY, k0, k1, lane, M);
-      project_moments<S_P1, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s1);
+      if constexpr (PM)
+        project_moments_mfma<S_P1, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s1, sBv);
+      else
+        project_moments<S_P1, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s1);
       if (atom_ok) {
 #pragma unroll
         for (int j = 0; j < D; ++j) (A.x2s1 + (atom * D + j) * 64)[unsigned(lane)] = x2s1[j];
       }
-      float one[1] = {1.f}, v[D], B1[D];
+      float one[1] = {1.f}, v[D], B1[D], x2s0b[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) x2s0b[j] = atom_ok ? (A.x2s0 + (atom * D + j) * 64)[unsigned(lane)] : 0.f;  // (this wave's own store of layer 0)
       Sig1::template bx1<float>(one, x2s1, wp1, v);
-      Sig0::template bx1<float>(v, x2s0, wp0, B1);
+      Sig0::template bx1<float>(v, x2s0b, wp0, B1);
 #pragma unroll
       for (int a = 0; a < D; ++a) sBv[a * 64 + lane] = B1[a];
       __builtin_amdgcn_wave_barrier();
@@ -465,7 +506,9 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
           na = tile_load_rows8(A.w0 + row0 * (64 * R) + (r + 1) * 64, 64 * R, lane, row_ok);
           nb = tile_load_rows8(A.w0 + row0 * (64 * R) + (r + 1) * 64 + 32, 64 * R, lane, row_ok);
         }
-        tile_scal_accumulate8<r>(sBv + 4 * hh, Y, wa, wb, sc0, sc1);
+        float Yv[D];
+        load_Y(Yv);
+        tile_scal_accumulate8<r>(sBv + 4 * hh, Yv, wa, wb, sc0, sc1);
         wa = na;
         wb = nb;
       });
@@ -491,7 +534,9 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
       fused_step8<S_M + 1, NS>(A, p, xs[0], a80, a81, [&] { xsplit_from_acc(k1, xs[1]); });
       fused_step8<S_M + 2, NS>(A, p, xs[1], a60, a61, [&] { t = fetch_tile(sPark, lane); });
       fused_step8<S_M + 3, NS>(A, p, xs[1], a80, a81, [&] { xsplit_from_acc(t, xs[0]); });
-      fused_step8<S_M + 4, NS>(A, p, xs[0], a60, a61, [&] { t = fetch_tile(sPark + kTileFloats, lane); });
+      fused_step8<S_M + 4, NS>(A, p, xs[0], a60, a61, [&] {
+        if constexpr (NPARK == 2) t = fetch_tile(sPark + kTileFloats, lane); else t = tbr;
+      });
       fused_step8<S_M + 5, NS>(A, p, xs[0], a80, a81, [&] { xsplit_from_acc(t, xs[1]); });
       fused_step8<S_M + 6, NS>(A, p, xs[1], a60, a61, [&] {});
       fused_step8<S_M + 7, NS>(A, p, xs[1], a80, a81, [&] {});
@@ -550,15 +595,16 @@ __global__ __launch_bounds__(512) void fused_fwd8_kernel(FusedFwdArgs A) {
   }
 }
 
-size_t fused_fwd8_lds_bytes(int num_types) {
-  return sizeof(u32x4) * 2 * kWStep + sizeof(float) * (64 + 32 + size_t(num_types) * num_types * 512 + 8 * kWave8);
+size_t fused_fwd8_lds_bytes(int num_types, int waves) {
+  return sizeof(u32x4) * 2 * kWStep + sizeof(float) * (64 + 32 + size_t(num_types) * num_types * 512 + size_t(waves) * fused_wave_floats(waves));
 }
-int fused_fwd8_num_steps(int R) { return fused_fwd8_steps(R); }
+int fused_fwd8_num_steps(int R, bool proj_mfma) { return fused_fwd8_steps(R, proj_mfma); }
 
-int launch_fused_fwd8(int pair, const FusedFwdArgs& a, hipStream_t stream) {
+int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;
-  const size_t smem = fused_fwd8_lds_bytes(a.num_types);
-  if (smem > 160 * 1024) return fail(AA_ERR_INVALID, "fused forward (wide): LDS budget exceeded");
+  if (waves != 4 && waves != 8) return fail(AA_ERR_INVALID, "fused forward (wide): 4 or 8 waves per workgroup");
+  const size_t smem = fused_fwd8_lds_bytes(a.num_types, waves);
+  if (smem * (waves == 4 ? 2 : 1) > 160 * 1024) return fail(AA_ERR_INVALID, "fused forward (wide): LDS budget exceeded");
   if (!a.w0) return fail(AA_ERR_INVALID, "fused forward (wide): needs the w0 rows");
   static int num_cu = 0;
   if (num_cu == 0) {
@@ -567,14 +613,17 @@ int launch_fused_fwd8(int pair, const FusedFwdArgs& a, hipStream_t stream) {
     AA_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
     num_cu = n > 0 ? n : 256;
   }
-  const int64_t ngroups = (a.atom_end - a.atom0 + 7) / 8;
-  dim3 grid((unsigned)std::min<int64_t>(ngroups, int64_t(num_cu)));
-#define AA_FUSED8_LAUNCH(S0_, S1_)                                                                    \
-  {                                                                                                   \
-    const void* fn = (const void*)fused_fwd8_kernel<cg::S0_, cg::S1_>;                                \
-    AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));     \
-    hipLaunchKernelGGL((fused_fwd8_kernel<cg::S0_, cg::S1_>), grid, dim3(512), smem, stream, a);      \
+  const int64_t ngroups = (a.atom_end - a.atom0 + waves - 1) / waves;
+  dim3 grid((unsigned)std::min<int64_t>(ngroups, int64_t(num_cu) * (waves == 4 ? 2 : 1)));
+#define AA_FUSED8_LAUNCH1(S0_, S1_, W_, P_)                                                                     \
+  {                                                                                                           \
+    const void* fn = (const void*)fused_fwd8_kernel<cg::S0_, cg::S1_, W_, P_>;                                \
+    AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));             \
+    hipLaunchKernelGGL((fused_fwd8_kernel<cg::S0_, cg::S1_, W_, P_>), grid, dim3(64 * W_), smem, stream, a);  \
   }
+#define AA_FUSED8_LAUNCH(S0_, S1_) \
+  if (waves == 8 && a.wide_proj_mfma) AA_FUSED8_LAUNCH1(S0_, S1_, 8, true) else if (waves == 8) AA_FUSED8_LAUNCH1(S0_, S1_, 8, false) \
+  else if (a.wide_proj_mfma) AA_FUSED8_LAUNCH1(S0_, S1_, 4, true) else AA_FUSED8_LAUNCH1(S0_, S1_, 4, false)
   if (pair == 0) {
     AA_FUSED8_LAUNCH(Sig1, Sig0)
   } else if (pair == 1) {
@@ -582,6 +631,7 @@ int launch_fused_fwd8(int pair, const FusedFwdArgs& a, hipStream_t stream) {
   } else {
     return fail(AA_ERR_INVALID, "fused forward (wide): unsupported signature pair");
   }
+#undef AA_FUSED8_LAUNCH1
 #undef AA_FUSED8_LAUNCH
   AA_CHECK_HIP(hipGetLastError());
 #ifdef AA_FUSED_TIMING

@@ -323,30 +323,30 @@ __device__ __forceinline__ void project_moments(const Args& A, Pipe& p, float* s
 // accumulator layout whose 32 columns are the components j (columns >= D carry zeros) and whose features are k; irrep r's 64x64
 // env-weight matrix is an ordinary bf16x3 layer (steps S0 + 2 r, S0 + 2 r + 1) whose output columns j in irrep r are kept; the
 // result returns to the lane = channel view through sX [D][64] behind sM.
-template <int S0, int NS, int D, int R, class Args, class Pipe>
-__device__ __forceinline__ void project_moments_mfma(const Args& A, Pipe& p, float* sM, const float* M, float sf, float* x2s) {
+template <int S0, int NS, int D, int R, int LDY = kLdY, class Args, class Pipe>
+__device__ __forceinline__ void project_moments_mfma(const Args& A, Pipe& p, float* sM, const float* M, float sf, float* x2s, float* sX = nullptr) {
   const int lane = p.lane, el = lane & 31, hh = lane >> 5;
-  float* sX = sM + 64 * kLdY;
-  static_assert(64 * kLdY + 16 * 64 <= kWaveRegion, "moments + result patch must fit the wave region");
+  if (sX == nullptr) sX = sM + 64 * LDY;  // (result patch [D][64]: behind sM, or where the caller has room)
+  static_assert(LDY != kLdY || 64 * kLdY + 16 * 64 <= kWaveRegion, "moments + result patch must fit the wave region");
 #pragma unroll
   for (int q = 0; q < (D + 3) / 4; ++q) {
     v4f mm;
 #pragma unroll
     for (int i = 0; i < 4; ++i) mm[i] = 4 * q + i < D ? M[4 * q + i] : 0.f;
-    *reinterpret_cast<v4f*>(sM + lane * kLdY + 4 * q) = mm;
+    *reinterpret_cast<v4f*>(sM + lane * LDY + 4 * q) = mm;
   }
 #pragma unroll
-  for (int q = (D + 3) / 4; q < kLdY / 4; ++q) *reinterpret_cast<v4f*>(sM + lane * kLdY + 4 * q) = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int q = (D + 3) / 4; q < LDY / 4; ++q) *reinterpret_cast<v4f*>(sM + lane * LDY + 4 * q) = v4f{0.f, 0.f, 0.f, 0.f};
   __builtin_amdgcn_wave_barrier();
   XSplit xs[2];
   {
     v16f t0, t1;
-    const int col = el < kLdY ? el : kLdY - 1;  // (columns beyond the patch: any value, never read back)
+    const int col = el < LDY ? el : LDY - 1;  // (columns beyond the patch: any value, never read back)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int k = 8 * (s >> 2) + 4 * hh + (s & 3);
-      t0[s] = sM[k * kLdY + col];
-      t1[s] = sM[(32 + k) * kLdY + col];
+      t0[s] = sM[k * LDY + col];
+      t1[s] = sM[(32 + k) * LDY + col];
     }
     xsplit_from_acc(t0, xs[0]);
     xsplit_from_acc(t1, xs[1]);

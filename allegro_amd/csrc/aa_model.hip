@@ -496,7 +496,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
   p->o_lat1in_fq = p->o_ro0_fq = p->o_b3af_q = p->o_b3bf_q = 0;
   p->o_g0fq = p->o_g0tfq = p->o_wk0f = p->o_wt0f = 0;
   for (int l = 0; l < AA_MAX_LAYERS; ++l) p->o_wkq[l] = 0;
-  if (kProjMfma && p->chain_gemm && p->env_mom && L == 2 && u == 64)
+  if (p->chain_gemm && p->env_mom && L == 2 && u == 64)  // (kProjMfma, and the two-waves-per-SIMD fused forward: env projection on the matrix cores)
     for (int l = 0; l < L; ++l) p->o_wkq[l] = take(size_t(p->R) * gemm_bf16x3_words(64, 64));
   if (kFoldEmb1 && p->chain_gemm && p->env_mom && L == 2 && u == 64) {
     p->o_g0fq = take(gemm_bf16x3_words(64, p->ng0));
@@ -605,7 +605,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     // the eight-wave form needs the folded program (every fold active), a two-body table that leaves 16.6 KB of LDS per wave
     // (one species) and the w0 rows of the staged reverse pass (no fused tail)
     p->fused_wide = p->fused_fwd && kFoldEmbed && kFoldEmb1 && kFoldLatent && !kProjMfma && p->o_embtab_h != 0 && p->o_g0fq != 0 &&
-                    p->o_lat1in_fq != 0 && !opt.fused_narrow && !p->fused_tail && fused_fwd8_lds_bytes(cfg->num_types) <= 160 * 1024;
+                    p->o_lat1in_fq != 0 && opt.fused_narrow != 1 && !p->fused_tail && fused_fwd8_lds_bytes(cfg->num_types, 8) <= 160 * 1024;
   }
   {
     void* st = nullptr;
@@ -2012,6 +2012,7 @@ struct Runner {
     const bool wide = p->fused_wide && folde && foldl && a.w0 != nullptr && (a.tile_atoms == nullptr || a.mixed);
     if (wide) {
       a8 = a;
+      a8.wide_waves = p->opt.fused_narrow == 2 ? -8 : (p->opt.fused_narrow == 3 ? -4 : 4);  // (negative: forced, also on small boxes)
       ns = 0;
       prog = &a8;
       auto add_step = [&](const float* Wq, int KC, int kc) {  // one step: the tile pair (0, 1) x chunk kc of a KC-chunk layer
@@ -2019,10 +2020,20 @@ struct Runner {
         prog->wstep[ns][1] = Wq + (size_t(1) * KC + kc) * 64 * 24;
         ++ns;
       };
-      add_env(wf(p->o_wk0f));
+      // env projections: on the matrix cores (R bf16x3 64x64 layers, 2 steps each) -- at two waves per SIMD the vector form (4 blocks
+      // of env-weight rows) is a quarter of the kernel's issue slots and 40 % of its LDS instructions while the matrix pipe idles
+      a8.wide_proj_mfma = (p->o_wkq[0] && p->o_wkq[1] && p->opt.fused_narrow != 4) ? 1 : 0;
+      auto add_proj8 = [&](int l, const float* Wk) {
+        if (a8.wide_proj_mfma) {
+          for (int r = 0; r < p->R; ++r) add_layer(wf(p->o_wkq[l]) + size_t(r) * gemm_bf16x3_words(64, 64), 2, 0, 2);
+        } else {
+          add_env(Wk);
+        }
+      };
+      add_proj8(0, wf(p->o_wk0f));
       add_layer(wf(p->o_g0fq), 2, 0, 2 + 2 * p->R);
       add_layer(wf(p->latent[0].wq[0]), 4, 0, 2);
-      add_env(wf(p->o_wk[1]));
+      add_proj8(1, wf(p->o_wk[1]));
       add_step(wf(p->o_lat1in_fq), 6, 4);
       add_step(wf(p->o_lat1in_fq), 6, 5);
       for (int kc : {2, 3, 0, 1}) {
@@ -2031,7 +2042,7 @@ struct Runner {
       }
       add_step(wf(p->o_ro0_fq), 6, 4);
       add_step(wf(p->o_ro0_fq), 6, 5);
-      if (ns != fused_fwd8_num_steps(p->R)) return fail(AA_ERR_INVALID, "fused forward (wide): program length mismatch");
+      if (ns != fused_fwd8_num_steps(p->R, a8.wide_proj_mfma != 0)) return fail(AA_ERR_INVALID, "fused forward (wide): program length mismatch");
     }
     if (int rc = mark("begin")) return rc;
     if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream, wide ? &a8 : nullptr)) return rc;

@@ -303,8 +303,10 @@ typedef struct {
                              * by the forward's energy reduction, which reads the same rows (A/B, tests)                          */
   int32_t tp_prefer_moments; /* 2-layer u = 64 stacks the fused chains do not cover (fp64; S or MLP widths of 128): 1 = the 2-layer moments
                               * kernels + single linear layers (the selection up to round 4) instead of the operator kernels (A/B, tests) */
-  int32_t fused_narrow;     /* fused forward, one-tile pass: 1 = the four-wave workgroup form (one wave per SIMD, round 2-5) also where the
-                             * eight-wave form (two waves per SIMD, aa_fused8.hip: one species, folded program) applies (A/B, tests)        */
+  int32_t fused_narrow;     /* fused forward, one-tile pass, where the two-waves-per-SIMD form applies (aa_fused8.hip: one species, folded
+                             * program): 0 = that form as two independent four-wave workgroups per CU, 2 = as one eight-wave workgroup per CU
+                             * (lock step), 1 = the one-wave-per-SIMD kernel of rounds 2-5 (A/B, tests).  Boxes of at most 4 atoms per CU take the
+                             * round 2-5 kernel under 0 (every CU holds at most one workgroup anyway); 3 = the four-wave form there too (tests) */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

@@ -17,18 +17,23 @@ os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
 # Kernel selection: nothing is pinned here.  With AA_FUSED unset the plan is created with aa_plan_options.fused_forward = 0
 # ("automatic": the fused per-atom-tile forward whenever the graph allows it) -- the product's DEFAULT path, which is
 # therefore what every test runs unless it opts into another one.  The model-level GPU modules additionally run every
-# test twice through the `forward_mode` fixture below ("auto" and "staged"), so both pipelines stay certified against
+# test three times through the `forward_mode` fixture below ("auto", "staged", "wide"), so all pipelines stay certified against
 # the golden vectors, the oracle, finite differences, the ghost layout and the virial.
 os.environ.pop("AA_FUSED", None)
 
 
-@pytest.fixture(params=["auto", "staged"])
+@pytest.fixture(params=["auto", "staged", "wide"])
 def forward_mode(request, monkeypatch):
-    """AA_FUSED unset (automatic selection, the default) / AA_FUSED=0 (staged pipeline) for the plans a test creates."""
-    if request.param == "auto":
-        monkeypatch.delenv("AA_FUSED", raising=False)
-    else:
+    """AA_FUSED unset (automatic selection, the default) / AA_FUSED=0 (staged pipeline) for the plans a test creates; "wide": automatic
+    selection with the two-waves-per-SIMD form of the fused forward (aa_fused8.hip) also on the small fixture boxes, where the default
+    keeps the one-wave-per-SIMD kernel (it is what every box from 4 atoms per CU on runs)."""
+    monkeypatch.delenv("AA_FUSED_NARROW", raising=False)
+    if request.param == "staged":
         monkeypatch.setenv("AA_FUSED", "0")
+    else:
+        monkeypatch.delenv("AA_FUSED", raising=False)
+        if request.param == "wide":
+            monkeypatch.setenv("AA_FUSED_NARROW", "3")
     return request.param
 
 

@@ -91,15 +91,18 @@ def test_fused_forward_matches_reference_golden_emulated(mode, name, monkeypatch
 
 
 def _wide_vs_narrow(name, lib, dev, monkeypatch):
-    """One-species plans take the eight-wave form of the one-tile pass (two waves per SIMD, aa_fused8.hip: its own weight program,
-    merged latent-1 / readout phase, w0 re-read from the stored rows); AA_FUSED_NARROW=1 keeps the four-wave form.  Same function:
-    both against the reference's golden vectors and against each other to rounding (the summation orders differ)."""
+    """One-species plans take the two-waves-per-SIMD form of the one-tile pass (aa_fused8.hip: its own weight program, merged
+    latent-1 / readout phase, w0 re-read from the stored rows) as two four-wave workgroups per CU, or -- AA_FUSED_NARROW=2 -- one
+    eight-wave workgroup; AA_FUSED_NARROW=1 keeps the one-wave-per-SIMD kernel.  Same function: all against the reference's golden
+    vectors, the two workgroup forms bit-equal, the old kernel to rounding (the summation orders differ)."""
     fx = load_model_fixture(name, torch.float32)
     out = {}
-    for narrow in ("0", "1"):
+    # "3": two four-wave workgroups per CU, env projections on the matrix cores (the default from 4 atoms per CU on) | "4": ... projections
+    # in their vector form | "2": one eight-wave workgroup | "1": the one-wave-per-SIMD kernel
+    for narrow in ("3", "4", "2", "1"):
         monkeypatch.setenv("AA_FUSED_NARROW", narrow)
         m = model_from_fixture(fx, torch.float32, lib, device=dev)
-        assert m.describe_plan()["fused_wide"] == (narrow == "0")
+        assert m.describe_plan()["fused_wide"] == (narrow != "1")
         data, sv = fixture_data(fx, torch.float32, dev)
         g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
         assert 0 < g.max_degree <= 32
@@ -108,8 +111,11 @@ def _wide_vs_narrow(name, lib, dev, monkeypatch):
         out[narrow] = (e.cpu().clone(), f.cpu().clone())
         for got, want in ((out[narrow][0], fx["out"]["atomic_energy"].reshape(-1)), (out[narrow][1], fx["out"]["forces"])):
             assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
-    for a, b in zip(out["0"], out["1"]):
-        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, float(b.abs().max()))
+    for other in ("1", "4"):
+        for a, b in zip(out["3"], out[other]):
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, float(b.abs().max()))
+    for a, b in zip(out["3"], out["2"]):  # the same arithmetic in the same order: bit-equal
+        assert torch.equal(a, b)
 
 
 def test_eight_wave_form_matches_the_four_wave_form_and_the_golden_vectors_emulated(monkeypatch):

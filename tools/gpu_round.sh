@@ -8,7 +8,8 @@
 #   stages  <tag> [wl]     per-launch HIP-event table of one step (no baselines)
 #   ab      <tag> [wl]     same-box A/B: allegro_amd/liballegro_amd_old.so vs the product library, alternated 3 times
 #   abn     <tag> <wl> <name>...   same-box A/B/C: the product library vs allegro_amd/liballegro_amd_<name>.so for every name
-#   abenv   <tag> <wl> VAR=val...   same-box A/B of an environment switch of the Python host (product library both times)
+#   abenv   <tag> <wl> VAR=val ...  same-box A/B/C of environment switches of the Python host (product library; one arm per argument,
+#                                   quote several assignments of one arm together)
 #   profile <tag> [wl]     rocprofv3 --kernel-trace --stats, then separate --pmc passes, summary + hashed traffic JSON
 #   hosts   <tag>          the Python-free hosts (tests/host): C99 driver and C++ AOTInductor package consumer
 #   ubench  <tag> <name>   tools/ubench/<name>.bin (hipcc -o it on the build box first: it travels with the snapshot)
@@ -53,7 +54,7 @@ case $CMD in
     # same-box A/B of a host switch: the product library with and without the environment assignment(s) given after the workload
     # (e.g. AA_FUSED_NARROW=1), alternated 3 times
     WL=${ARG:-c4}; shift 3
-    for rep in 1 2 3; do for arm in default "$*"; do
+    for rep in 1 2 3; do for arm in default "$@"; do
       if [ "$arm" = default ]; then pre=""; else pre="$arm"; fi
       r=$(env $pre timeout 600 python bench.py --workload $WL --steps 20 --warmup 5 --stages --no-cpu-baseline --no-gpu-reference --no-secondary --no-md --sustain 0 2> gpurun_out/${TAG}_abenv.log | grep -o '"ms_per_step": [0-9.]*' | head -1)
       echo "[$arm] $r | $(grep '^\[stage\]' gpurun_out/${TAG}_abenv.log | awk '{printf "%s %s  ", $2, $3}')"
