@@ -2020,9 +2020,10 @@ struct Runner {
         prog->wstep[ns][1] = Wq + (size_t(1) * KC + kc) * 64 * 24;
         ++ns;
       };
-      // env projections: on the matrix cores (R bf16x3 64x64 layers, 2 steps each) -- at two waves per SIMD the vector form (4 blocks
-      // of env-weight rows) is a quarter of the kernel's issue slots and 40 % of its LDS instructions while the matrix pipe idles
-      a8.wide_proj_mfma = (p->o_wkq[0] && p->o_wkq[1] && p->opt.fused_narrow != 4) ? 1 : 0;
+      // env projections: 4 blocks of env-weight rows (vector form), or -- fused_narrow 5, A/B -- on the matrix cores (R bf16x3 64x64
+      // layers, 2 steps each): the vector form is a quarter of the kernel's issue slots and 40 % of its LDS instructions while the
+      // matrix pipe idles, and the matrix form still measured 11 % slower (3.50 vs 3.16 ms at C4, profiles/r06_v6_ab_c4_*)
+      a8.wide_proj_mfma = (p->o_wkq[0] && p->o_wkq[1] && p->opt.fused_narrow == 5) ? 1 : 0;  // (A/B only: measured 11 % slower, HISTORY.md)
       auto add_proj8 = [&](int l, const float* Wk) {
         if (a8.wide_proj_mfma) {
           for (int r = 0; r < p->R; ++r) add_layer(wf(p->o_wkq[l]) + size_t(r) * gemm_bf16x3_words(64, 64), 2, 0, 2);

@@ -306,7 +306,8 @@ typedef struct {
   int32_t fused_narrow;     /* fused forward, one-tile pass, where the two-waves-per-SIMD form applies (aa_fused8.hip: one species, folded
                              * program): 0 = that form as two independent four-wave workgroups per CU, 2 = as one eight-wave workgroup per CU
                              * (lock step), 1 = the one-wave-per-SIMD kernel of rounds 2-5 (A/B, tests).  Boxes of at most 4 atoms per CU take the
-                             * round 2-5 kernel under 0 (every CU holds at most one workgroup anyway); 3 = the four-wave form there too (tests) */
+                             * round 2-5 kernel under 0 (every CU holds at most one workgroup anyway); 3 = the four-wave form there too (tests); 5 = 3 with the env
+                             * projections as bf16x3 layers on the matrix cores (A/B: measured slower) */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

@@ -97,9 +97,9 @@ def _wide_vs_narrow(name, lib, dev, monkeypatch):
     vectors, the two workgroup forms bit-equal, the old kernel to rounding (the summation orders differ)."""
     fx = load_model_fixture(name, torch.float32)
     out = {}
-    # "3": two four-wave workgroups per CU, env projections on the matrix cores (the default from 4 atoms per CU on) | "4": ... projections
-    # in their vector form | "2": one eight-wave workgroup | "1": the one-wave-per-SIMD kernel
-    for narrow in ("3", "4", "2", "1"):
+    # "3": two four-wave workgroups per CU (the default from 4 atoms per CU on) | "5": ... env projections on the matrix cores (A/B form)
+    # | "2": one eight-wave workgroup | "1": the one-wave-per-SIMD kernel
+    for narrow in ("3", "5", "2", "1"):
         monkeypatch.setenv("AA_FUSED_NARROW", narrow)
         m = model_from_fixture(fx, torch.float32, lib, device=dev)
         assert m.describe_plan()["fused_wide"] == (narrow != "1")
@@ -111,7 +111,7 @@ def _wide_vs_narrow(name, lib, dev, monkeypatch):
         out[narrow] = (e.cpu().clone(), f.cpu().clone())
         for got, want in ((out[narrow][0], fx["out"]["atomic_energy"].reshape(-1)), (out[narrow][1], fx["out"]["forces"])):
             assert (got - want).abs().max().item() <= 5e-5 * max(1.0, float(want.abs().max()))
-    for other in ("1", "4"):
+    for other in ("1", "5"):
         for a, b in zip(out["3"], out[other]):
             assert (a - b).abs().max().item() <= 2e-5 * max(1.0, float(b.abs().max()))
     for a, b in zip(out["3"], out["2"]):  # the same arithmetic in the same order: bit-equal

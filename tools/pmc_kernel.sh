@@ -10,7 +10,9 @@ OUTF=$ROOT/gpurun_out/${TAG}_pmc_${KER}.txt
 : > $OUTF
 PASSES=("SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"
         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INSTS_SALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM"
-        "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES SQ_INST_CYCLES_SALU")
+        "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES SQ_INST_CYCLES_SALU"
+        "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQC_TC_INST_REQ SQC_ICACHE_BUSY_CYCLES")
+if [ -n "${PMC_ONLY_LAST:-}" ]; then PASSES=("${PASSES[3]}"); fi
 for arm in default "$@"; do
   if [ "$arm" = default ]; then pre=""; else pre="$arm"; fi
   echo "== arm [$arm]" >> $OUTF
