@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_tp_dense.hip", "aa_train.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused8.hip", "aa_model.hip", "aa_nl.hip", "aa_hostfile.hip"]
-# public C ABI header: the package ships its own copy (package data, so that an installed package can rebuild itself);
-# in the source tree it is the same file as <repo>/include/allegro_amd.h (tests/test_lib_symbols.py checks identity)
+# public C ABI header: the package carries a copy (package data, so that an installed package can rebuild itself); in the source
+# tree that copy is GENERATED from <repo>/include/allegro_amd.h at build time and not tracked (tests/test_lib_symbols.py checks identity)
 INCLUDE_DIR = os.path.join(HERE, "include")
 LIB_PATH = os.path.join(HERE, "liballegro_amd.so")
 # Measured-and-rejected kernels stay out of the product library; AA_BUILD_EXPERIMENTAL=1 adds them (their own opt-in
@@ -49,6 +49,7 @@ def _stale() -> bool:
 
 def _source_deps():
     """Files the device library is compiled from (not __pycache__, generators or the host-only torch_ops.cpp)."""
+    _sync_public_header()  # (the package's copy of the C ABI header is generated from <repo>/include: not tracked, see .gitignore)
     deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h") or f in SOURCES]
     return deps + [os.path.join(INCLUDE_DIR, "allegro_amd.h")]
 

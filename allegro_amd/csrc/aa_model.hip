@@ -1933,7 +1933,12 @@ struct Runner {
       a.tile_counts = reinterpret_cast<int32_t*>(buf(w.tiles));
       a.tile_atoms = a.tile_counts + 8;
       a.tile_cap = g->num_atoms;
-      a.mixed = p->opt.fused_forward == 2 ? 0 : 1;  // (2: the team form for every atom, A/B)
+      // mixed form (one-tile pass over all atoms + team pass over the long ones) where long atoms are the minority -- boxes whose
+      // average atom fits one tile; dense boxes that took the team path because they are small or their tiles are full run the pure
+      // team form: there the one-tile launch would only skip.  2 / 4: the team / mixed form for every graph (A/B)
+      const int64_t n_act = g->atom_end > g->atom_begin ? g->atom_end - g->atom_begin : g->num_atoms;
+      const double fill = double(g->num_edges) / (32.0 * double(std::max<int64_t>(n_act, 1)));
+      a.mixed = p->opt.fused_forward == 2 ? 0 : (p->opt.fused_forward == 4 || fill <= 1.15) ? 1 : 0;
     }
     a.num_types = c.num_types;
     a.embed_kind = c.embed_kind;

@@ -251,7 +251,9 @@ class _TriCtx:
         self.segments = segments  # None | (rowptr int32 [N+1], eids int32 [E] | None, idxs int64 [E], num_atoms, scatter_factor)
         # M b of the b operands this contraction has seen: the forward kernel returns it, and the x1- and weight-gradient kernels of
         # every later derivative take it as an input -- recomputing it was 14 segment sums of [E,u,d2] per training step at C3 (2.3 ms)
-        # for 4 distinct operands.  An entry holds its `b` (so that the address in the key cannot be re-used while the entry lives).
+        # for 4 distinct operands.  An entry holds a WEAK reference to its `b`: while the tensor lives its address cannot be re-used, so
+        # key equality means the same memory at the same version; once autograd releases the operand ([E,u,d2]: the large one) the
+        # entry is dead and the buffer is free -- a strong reference kept it until every ctx of the recorded graph died.
         self.x2s_cache = {}
         self.keep = False  # remember operands even when no graph is recorded (set for the duration of one backward call)
 
@@ -260,7 +262,20 @@ class _TriCtx:
         return (b.data_ptr(), b._version, tuple(b.shape), tuple(b.stride()), b.dtype)
 
     def remember(self, b, x2s):
-        self.x2s_cache[self._key(b)] = (b, x2s)
+        import weakref
+
+        for k in [k for k, (r, _) in self.x2s_cache.items() if r() is None]:
+            del self.x2s_cache[k]
+        self.x2s_cache[self._key(b)] = (weakref.ref(b), x2s)
+
+    def lookup(self, b):
+        hit = self.x2s_cache.get(self._key(b))
+        if hit is None:
+            return None
+        if hit[0]() is None:  # (the operand is gone: whatever sits at that address now is another tensor)
+            del self.x2s_cache[self._key(b)]
+            return None
+        return hit[1]
 
     def forget(self, b):
         self.x2s_cache.pop(self._key(b), None)
@@ -292,9 +307,9 @@ def _edge_rowptr(E: int, device) -> torch.Tensor:
 
 
 def _segment_sum(t: _TriCtx, b):  # x2s = scale * scatter-sum of b over the scatter index  [N,u,d2]
-    hit = None if _NO_X2S_CACHE() else t.x2s_cache.get(t._key(b))
+    hit = None if _NO_X2S_CACHE() else t.lookup(b)
     if hit is not None:
-        return hit[1]
+        return hit
     rowptr, eids, _idxs, n, sf = t.segments
     x2s = torch.ops.allegro_amd.segment_sum(b.detach(), rowptr, eids, n, sf, t.lib_id)
     if t.keep:  # (only while a recorded graph keeps the operand alive anyway: see _recording)
@@ -396,7 +411,7 @@ class _TriJ(torch.autograd.Function):
         t = ctx.t
         n = ctx.needs_input_grad
         # (h enters the b slot of up to three members: its M h once, for the duration of this call when no graph is recorded)
-        temp = t.segments is not None and (n[1] or n[2]) and not torch.is_grad_enabled() and t._key(h) not in t.x2s_cache
+        temp = t.segments is not None and (n[1] or n[2]) and not torch.is_grad_enabled() and t.lookup(h) is None
         t.keep = temp  # (the forward kernel of the first member returns M h: the other two take it from the cache)
         try:
             return (_TriK.apply(a, h, w, t) if n[0] else None, _TriI.apply(c, h, w, t) if n[1] else None,
@@ -485,8 +500,8 @@ def scalar_column_op(a: Optional[torch.Tensor], s: torch.Tensor, D: int, lib_id:
     """`aa_scalar_column`: [E,u,D] = a (None: zeros) with s [E,u] added to component 0."""
     lib = _resolve(lib_id)
     _check_device(lib, s, "allegro_amd::scalar_column")
-    sc = s.contiguous()
-    ac = None if a is None else a.contiguous()
+    sc = _dense16(s)
+    ac = None if a is None else _dense16(a)
     E, u = sc.shape
     out = torch.empty((E, u, D), dtype=s.dtype, device=s.device)
     lib.check(lib.lib.aa_scalar_column(_dtype_code(s), E * u, D, ac.data_ptr() if (ac is not None and E) else None, sc.data_ptr() if E else None,
@@ -566,13 +581,20 @@ def _(sh, w, sh2, w2, u, l_max, shared, lib_id):
     return sh.new_empty((sh.shape[0], u, (l_max + 1) ** 2))
 
 
+def _dense16(t: torch.Tensor) -> torch.Tensor:
+    """Contiguous AND 16-byte aligned: the elementwise kernels use 16-byte vector accesses (AA_REQUIRE on the pointers).  A contiguous
+    view with a storage offset -- a row slice, one output of a split -- is contiguous but may start anywhere."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 @torch.library.custom_op("allegro_amd::silu_derivative", mutates_args=())
 def silu_derivative_op(x: torch.Tensor, g: Optional[torch.Tensor], order: int, lib_id: int) -> torch.Tensor:
     """`aa_silu_derivative`: g * f^(order)(x), f = SiLU, elementwise (g None: 1)."""
     lib = _resolve(lib_id)
     _check_device(lib, x, "allegro_amd::silu_derivative")
-    xc = x.contiguous()
-    gc = None if g is None else g.contiguous()
+    xc = _dense16(x)
+    gc = None if g is None else _dense16(g)
     out = torch.empty_like(xc)
     n = xc.numel()
     lib.check(lib.lib.aa_silu_derivative(_dtype_code(x), order, n, xc.data_ptr() if n else None, gc.data_ptr() if (n and gc is not None) else None,
@@ -590,7 +612,7 @@ def silu_derivative_pair_op(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor, o
     """`aa_silu_derivative_pair`: (g h f^(order+1)(x), h f^(order)(x)) from one pass."""
     lib = _resolve(lib_id)
     _check_device(lib, x, "allegro_amd::silu_derivative_pair")
-    xc, gc, hc = x.contiguous(), g.contiguous(), h.contiguous()
+    xc, gc, hc = _dense16(x), _dense16(g), _dense16(h)
     ox, og = torch.empty_like(xc), torch.empty_like(xc)
     n = xc.numel()
     p = (lambda t: t.data_ptr() if n else None)

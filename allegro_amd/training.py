@@ -333,9 +333,13 @@ class ChunkedTrainingStep:
         self.chunks = []
         center, nbr = graph.center.long(), graph.nbr.long()
         dev = center.device
+        # atoms of edge-free blocks (isolated atoms: E_i = shift of their type) have no graph to back-propagate through, but their
+        # share of dL/dshifts = r_E * (count per type) belongs to the gradient: counted here, added in `step`
+        self.edge_free_types = torch.zeros(0, dtype=torch.long, device=dev)
         for a0, a1 in zip(cuts[:-1], cuts[1:]):
             e0, e1 = int(rowptr[a0]), int(rowptr[a1])
             if e1 == e0:
+                self.edge_free_types = torch.cat([self.edge_free_types, graph.types.long()[a0:a1]])
                 continue
             own = torch.arange(a0, a1, device=dev)
             nb = nbr[e0:e1]
@@ -368,6 +372,11 @@ class ChunkedTrainingStep:
             (gp,) = torch.autograd.grad(e_blk, p, create_graph=True)
             s = r_e.reshape(()) * e_blk - (r_f.index_select(0, local) * gp).sum()
             s.backward()
+        if m.has_shifts and self.edge_free_types.numel():
+            sh = self.ev._param("per_type_energy_scale_shift.shifts")
+            if sh.requires_grad:
+                cnt = torch.bincount(self.edge_free_types, minlength=sh.shape[0]).to(sh.dtype) * r_e.reshape(()).to(sh.dtype)
+                sh.grad = cnt.reshape(sh.shape) if sh.grad is None else sh.grad + cnt.reshape(sh.shape)
         return loss.detach(), forces, e_leaf.detach()
 
 

@@ -258,8 +258,8 @@ def roofline_from_stages(stages, dtype, workload="c4", attach_traffic=True):
 def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3, vs_fp64=True):
     """The oracle restatement (a port: kind='port') timed on this host's cores on a bounded sample:
     the first contiguous block of center atoms holding ~target_edges edges, evaluated in chunks of
-    <=12k edges (exact by strict locality).  Thread count: min(cores, 32) -- eager PyTorch CPU slows
-    down badly when oversubscribed on these small matrices (measured: 256 threads 70x slower than 8)."""
+    <=12k edges (exact by strict locality).  Thread counts: min(cores, 32), 8 and 1 (sweep; the best rate is `value`) -- eager
+    PyTorch CPU slows down badly when oversubscribed on these small matrices (measured: 256 threads 70x slower than 8)."""
     from oracle import restatement as R
 
     dtype = {"float32": torch.float32, "float64": torch.float64}[cfg["model_dtype"]]
@@ -277,27 +277,48 @@ def cpu_baseline(g: G.Graph, cfg, model, target_edges=180000, reps=3, vs_fp64=Tr
     sv = torch.tensor(g.shift_vec()[:e1], dtype=dtype) if g.cell_shift is not None else None
     ocfg = dict(cfg)
     R.allegro_energy_forces_chunked(ocfg, sd, pos, ei[:, :min(e1, 12000)], types, None if sv is None else sv[:min(e1, 12000)], 12000)
+    L = cfg["num_layers"]
+
+    def one_pass(nthreads, edges):
+        torch.set_num_threads(nthreads)
+        t0 = time.perf_counter()
+        o = R.allegro_energy_forces_chunked(ocfg, sd, pos, ei[:, :edges], types, None if sv is None else sv[:edges], 12000)
+        return time.perf_counter() - t0, o
+
+    # thread sweep (the port gains 3 % from 8 -> 32 threads): 1 / 8 / min(cores, 32) threads -- the low counts on a
+    # contiguous fraction of the sample (the rate per edge is what is compared) -- and the BEST rate is the one quoted
     ts = []
     out = None
     for _ in range(reps):
-        t0 = time.perf_counter()
-        out = R.allegro_energy_forces_chunked(ocfg, sd, pos, ei, types, sv, 12000)
-        ts.append(time.perf_counter() - t0)
+        t, out = one_pass(threads, e1)
+        ts.append(t)
     t = float(np.median(ts))
-    L = cfg["num_layers"]
-    base = dict(value=e1 * L / t, unit="edge-TP/s", cores=threads, kind="port",
+    sweep = [dict(threads=threads, edges=e1, seconds=t, value=e1 * L / t)]
+    if reps > 1:
+        for nt, frac in ((8, 1.0), (1, 0.125)):
+            if nt >= threads:
+                continue
+            ee = int(rowptr[max(1, int(np.searchsorted(rowptr, int(e1 * frac), side="left")))]) if frac < 1.0 else e1
+            tt, _ = one_pass(nt, ee)
+            sweep.append(dict(threads=nt, edges=ee, seconds=tt, value=ee * L / tt))
+    torch.set_num_threads(threads)
+    best = max(sweep, key=lambda r: r["value"])
+    # the reference's own files (verbatim, eager) against this port on the build host, fp32, same chunks:
+    # reference / port time = 2.2 / 3.4 / 1.8 / 4.1 at 1 / 2 / 4 / 8 threads (profiles/r04_cpu_reference_vs_port_threads.json) -- the
+    # smallest ratio gives the most favourable figure for the reference
+    ref_ratio = 1.8
+    base = dict(value=best["value"], unit="edge-TP/s", cores=best["threads"], kind="port",
                 sample=f"first {a1} center atoms / {e1} edges of the same box in chunks of <=12k edges, "
-                       f"oracle/restatement.py eager PyTorch CPU {cfg['model_dtype']}, {threads} threads of {cores} cores, "
-                       f"median of {reps}, {t:.2f} s per pass")
+                       f"oracle/restatement.py eager PyTorch CPU {cfg['model_dtype']}, best of a thread sweep on {cores} cores "
+                       f"({', '.join(str(r['threads']) for r in sweep)} threads), median of {reps} at {threads} threads, {t:.2f} s per pass",
+                thread_sweep=sweep,
+                reference_equivalent=dict(value=best["value"] / ref_ratio, ratio=ref_ratio, ratio_measured_at_threads="1-8 (build host)",
+                                          note="port rate / (reference-verbatim time / port time); the reference cannot travel to this box, the "
+                                               "ratio is BASELINE.md section 3's smallest (1.8 at 4 threads; 2.2-4.1 at 1, 2, 8)"))
     if threads > 8 and reps > 1:
-        # BASELINE.md section 3 calibrates the reference-verbatim / port ratio at 1-8 threads: the same sample at 8 threads, so that
-        # the ratio can be applied at a thread count it was measured at
-        torch.set_num_threads(8)
-        t0 = time.perf_counter()
-        R.allegro_energy_forces_chunked(ocfg, sd, pos, ei, types, sv, 12000)
-        t8 = time.perf_counter() - t0
-        torch.set_num_threads(threads)
-        base["at_8_threads"] = dict(value=e1 * L / t8, unit="edge-TP/s", cores=8, seconds=t8)
+        r8 = [r for r in sweep if r["threads"] == 8]
+        if r8:
+            base["at_8_threads"] = dict(value=r8[0]["value"], unit="edge-TP/s", cores=8, seconds=r8[0]["seconds"])
     # parity of the timed HIP path against this oracle pass (same edge subset: the first a1 center atoms' edges)
     dev = next(model.parameters()).device
     gsub = PreparedGraph(ei.to(dev), types.to(dev), g.num_atoms, None if sv is None else sv.to(dev))
@@ -1020,6 +1041,11 @@ def main():
                                         if world > 1 else "single GPU")),
                        "weights": "random init (reference initialisers), seed 456"},
         }
+        ws = getattr(model, "_workspace", None)
+        if ws is not None:
+            # the caller-owned arena of the stage-materialised design: its size for this frame, incl. the host's 6 % headroom
+            line["config"]["workspace_bytes"] = int(ws.numel())
+            line["config"]["workspace_bytes_per_edge"] = float(ws.numel()) / max(1, (e1 - e0))
         if sustained is not None:
             line["config"]["sustained"] = sustained
         if rank_ms is not None:
@@ -1098,7 +1124,7 @@ def main():
             del graph
             torch.cuda.empty_cache()
             line["secondary"] = {"c3": secondary_workload("c3", dev, steps=50, warmup=5, cpu_edges=60000),
-                                 "c5": secondary_workload("c5", dev, steps=5, warmup=2, cpu_edges=12000)}
+                                 "c5": secondary_workload("c5", dev, steps=5, warmup=2, cpu_edges=56000)}  # (>= 1000 center atoms of the water box)
             parity_failed = parity_failed or not all(v["parity_sample"]["ok"] for v in line["secondary"].values())
         print(json.dumps(line), flush=True)
         if parity_failed:

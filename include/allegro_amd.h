@@ -401,11 +401,6 @@ int aa_nl_count(const aa_nl_input* in, void* workspace, size_t workspace_bytes, 
 int aa_nl_fill(const aa_nl_input* in, void* workspace, size_t workspace_bytes, const int32_t* rowptr, int32_t* center,
                int32_t* nbr, int32_t* cell_shift, void* shift_vec, aa_stream stream);
 
-/* 128-bit content fingerprint of a neighbour list as the pair_allegro contract hands it over (allegro/_compile.py:10-14):
- * edge_index int64 [2,E] (second row at edge_index + row_stride) and atom_types [N] (int64 or int32), both in device
- * memory; fp2: uint64[2] in device memory, overwritten.  Position-dependent (a permutation of the edges changes it) and
- * bit-reproducible.  For hosts that cache the CSR of a list by tensor identity: csrc/torch_ops.cpp compares it on the
- * device on every cache hit, so contents rewritten through a raw pointer are noticed (its outputs turn NaN, the next call fails). */
 /* Transposed CSR of a center-sorted edge list on the device -- `t_rowptr` [N+1], `t_perm` [E]: edge ids grouped by NEIGHBOUR atom in
  * ascending order (= the stable argsort of `nbr`), what aa_graph.t_rowptr / t_perm ask for so that forces are gathered per atom in a
  * fixed order -- and, with `hints3` != NULL (device int32[3]; needs `rowptr`), the three graph hints {atom_begin, atom_end,
@@ -416,6 +411,11 @@ size_t aa_graph_transpose_workspace_bytes(int64_t num_atoms);
 int aa_graph_transpose(int64_t num_atoms, int64_t num_edges, const int32_t* rowptr, const int32_t* nbr, int32_t* t_rowptr, int32_t* t_perm,
                        int32_t* hints3, void* workspace, size_t workspace_bytes, aa_stream stream);
 
+/* 128-bit content fingerprint of a neighbour list as the pair_allegro contract hands it over (allegro/_compile.py:10-14):
+ * edge_index int64 [2,E] (second row at edge_index + row_stride) and atom_types [N] (int64 or int32), both in device
+ * memory; fp2: uint64[2] in device memory, overwritten.  Position-dependent (a permutation of the edges changes it) and
+ * bit-reproducible.  For hosts that cache the CSR of a list by tensor identity: csrc/torch_ops.cpp compares it on the
+ * device on every cache hit, so contents rewritten through a raw pointer are noticed (its outputs turn NaN, the next call fails). */
 int aa_graph_fingerprint(const int64_t* edge_index, int64_t row_stride, int64_t num_edges, const void* atom_types,
                          int types_are_int64, int64_t num_atoms, uint64_t* fp2, aa_stream stream);
 

@@ -125,6 +125,51 @@ def _chunked_case(lib, dev, name="t_coupled", dtype=torch.float64, max_edges=70)
         assert p.grad is not None and (p.grad - w).abs().max().item() <= tol * max(1e-6, float(w.abs().max()))
 
 
+def _chunked_isolated_atom_case(lib, dev):
+    """An atom without edges that ends up in a block of its own (E_i = shift of its type) contributes r_E to dL/dshifts although
+    there is no graph to back-propagate through: the block-wise gradient still equals `loss.backward()` of the frame."""
+    from allegro_amd.nn import HipAllegroModel
+
+    fx = load_model_fixture("t_coupled", torch.float64)
+    cfg = dict(fx["cfg"], model_dtype="float64", per_type_energy_shifts=[0.3] * len(fx["cfg"]["type_names"]),
+               per_type_energy_shifts_trainable=True)
+    torch.manual_seed(5)
+    m = HipAllegroModel(**cfg).to(dev)
+    if lib is not None:
+        m._bind_library(lib)
+    m.train()
+    N = fx["pos"].shape[0] + 1  # (the extra atom sits far away: no edges)
+    pos = torch.cat([fx["pos"], fx["pos"].max(0, keepdim=True).values + 50.0]).to(dev)
+    types = torch.cat([fx["types"], fx["types"][:1]]).to(dev)
+    graph = m.prepare_graph(fx["edge_index"].to(dev), types, N, fx["shift_vec"].to(dev))
+
+    def loss_fn(f, e):
+        return f.square().mean() + 0.05 * (e / N - 0.2).square().sum()
+
+    params = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    assert any("shifts" in n for n, _ in params)
+    out = m._training_evaluator().forward({"pos": pos}, graph)
+    want = torch.autograd.grad(loss_fn(out["forces"], out["total_energy"]), [p for _, p in params])
+    for _, p in params:
+        p.grad = None
+    step = m.chunked_training_step(graph, 3)  # (fewer edges than any atom's segment: one block per atom, the isolated one alone)
+    assert step.edge_free_types.numel() == 1
+    step.step(pos, loss_fn)
+    for (n, p), w in zip(params, want):
+        assert p.grad is not None and (p.grad - w).abs().max().item() <= 1e-9 * max(1e-6, float(w.abs().max())), n
+
+
+def test_chunked_training_step_counts_edge_free_blocks_emulated():
+    from tests.hip_utils import emu_lib
+
+    _chunked_isolated_atom_case(emu_lib(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_chunked_training_step_counts_edge_free_blocks_on_gpu():
+    _chunked_isolated_atom_case(None, torch.device("cuda:0"))
+
+
 def test_chunked_training_step_is_exact_emulated():
     from tests.hip_utils import emu_lib
 
