@@ -716,6 +716,7 @@ struct FusedFwdArgs {
   int32_t* status;     // nullable, host-visible: set to the offending degree when a segment exceeds what the max_degree hint promised
   int mixed;           // with the class lists set: one-tile pass over all atoms (long ones skipped) + team pass over the long ones only
   int skip_long, long_only, fill_done;  // (set by launch_fused_fwd for the two passes of the mixed form)
+  int wide_one_per_cu; // two-waves-per-SIMD form, four-wave workgroups: ONE per CU (half the registers and LDS of a CU stay free for kernels of other streams)
   int wide_proj_mfma;  // two-waves-per-SIMD form: env projections as bf16x3 layers on the matrix cores (its program then has 2 R steps per projection)
   int wide_waves;      // two-waves-per-SIMD form (aa_fused8.hip): 4 = four-wave workgroups except on small boxes; -4 / -8: four / eight waves, forced
 };

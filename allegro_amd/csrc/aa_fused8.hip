@@ -614,7 +614,7 @@ int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t st
     num_cu = n > 0 ? n : 256;
   }
   const int64_t ngroups = (a.atom_end - a.atom0 + waves - 1) / waves;
-  dim3 grid((unsigned)std::min<int64_t>(ngroups, int64_t(num_cu) * (waves == 4 ? 2 : 1)));
+  dim3 grid((unsigned)std::min<int64_t>(ngroups, int64_t(num_cu) * ((waves == 4 && !a.wide_one_per_cu) ? 2 : 1)));
 #define AA_FUSED8_LAUNCH1(S0_, S1_, W_, P_)                                                                     \
   {                                                                                                           \
     const void* fn = (const void*)fused_fwd8_kernel<cg::S0_, cg::S1_, W_, P_>;                                \

@@ -265,6 +265,8 @@ struct aa_model_plan {
   size_t esize() const { return cfg.dtype == AA_F32 ? 4 : 8; }
   // optional hipGraph replay of the whole step (aa_model_plan_enable_graph): the launch sequence is captured once per
   // distinct argument set and replayed with one hipGraphLaunch -- for launch-bound (small) systems
+  mutable void* ev_wait = nullptr;    // aa_model_plan_set_forward_events
+  mutable void* ev_record = nullptr;
   struct StepGraph {
     bool enabled = false;
     hipStream_t cap_stream = nullptr;
@@ -644,6 +646,13 @@ extern "C" int aa_model_check(const aa_model_plan* plan, aa_stream stream) {
   AA_REQUIRE(plan, "aa_model_check: null plan");
   AA_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   return consume_status(plan, "aa_model_check");
+}
+
+extern "C" int aa_model_plan_set_forward_events(aa_model_plan* plan, void* wait_event, void* record_event) {
+  AA_REQUIRE(plan, "aa_model_plan_set_forward_events: null plan");
+  plan->ev_wait = wait_event;
+  plan->ev_record = record_event;
+  return AA_OK;
 }
 
 extern "C" int aa_model_plan_enable_graph(aa_model_plan* plan, int on) {
@@ -2018,6 +2027,7 @@ struct Runner {
     if (wide) {
       a8 = a;
       a8.wide_waves = p->opt.fused_narrow == 2 ? -8 : (p->opt.fused_narrow == 3 ? -4 : 4);  // (negative: forced, also on small boxes)
+      a8.wide_one_per_cu = p->opt.fused_narrow == 6 ? 1 : 0;
       ns = 0;
       prog = &a8;
       auto add_step = [&](const float* Wq, int KC, int kc) {  // one step: the tile pair (0, 1) x chunk kc of a KC-chunk layer
@@ -2659,7 +2669,9 @@ int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g
   if (r.w.total > ws_bytes) return fail(AA_ERR_WORKSPACE, "aa_model_energy_forces: workspace too small");
   if (p->opt.poison_workspace) AA_CHECK_HIP(hipMemsetAsync(workspace, 0xFF, r.w.total, stream));  // debugging: NaN everywhere
   r.want_forces = forces != nullptr;
+  if (p->ev_wait) AA_CHECK_HIP(hipStreamWaitEvent(stream, static_cast<hipEvent_t>(p->ev_wait), 0));
   if (int rc = r.forward(g, pos, atom_energy)) return rc;
+  if (p->ev_record) AA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(p->ev_record), stream));
   if (forces)
     if (int rc = r.backward(g, pos, forces)) return rc;
   // the atom-block hint is the caller's promise (per-atom kernels skip the rest): two row pointers verify it on the device, as the

@@ -317,6 +317,12 @@ void aa_model_plan_destroy(aa_model_plan* plan);
  * arguments (all pointers and sizes) and replays it with one hipGraphLaunch afterwards -- for launch-bound (small)
  * systems in MD loops whose buffers stay put.  The plan then carries mutable state: one caller thread per plan. */
 int aa_model_plan_enable_graph(aa_model_plan* plan, int on);
+/* Forward / reverse hand-over points for hosts that PIPELINE atom blocks of one frame on several streams (one plan + workspace per
+ * block in flight): `wait_event` (a hipEvent_t, nullable) is waited for on the step's stream before the first launch of the forward,
+ * `record_event` (nullable) is recorded after its last launch, before the reverse pass.  With block i's forward waiting for block
+ * i-1's record_event the forwards of consecutive blocks run one after the other while each block's reverse pass overlaps the next
+ * block's forward (allegro_amd.nn.PipelinedStep).  Persistent until set again; not captured by aa_model_plan_enable_graph. */
+int aa_model_plan_set_forward_events(aa_model_plan* plan, void* wait_event, void* record_event);
 /* on != 0: every step materialises the per-edge intermediates that aa_model_debug_tap exposes (the staged pipeline is
  * used; the fused kernels keep them on chip).  Parity tests only. */
 int aa_model_plan_enable_taps(aa_model_plan* plan, int on);

@@ -73,6 +73,7 @@ inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 typedef int hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = 0; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
