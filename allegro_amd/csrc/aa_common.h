@@ -84,7 +84,7 @@ __device__ __forceinline__ float dpp_move(float v) {
 // |r| <= ln2/2 (remainder < 4e-18) + ldexp -- ~20 fp64 instructions instead of the ~150 of the generic libm exp with
 // its special-case handling, < 1.5 ulp (tests/test_host_logic.py).  fp64 models evaluate SiLU / SiLU' for every
 // element of every hidden layer in the GEMM operand staging, the epilogues and the moment kernels: with the libm
-// sequence those were 5 VALU instructions per MFMA in the fp64 linear layers (profiles/r02_v7_rocprofv3_c5_summary.txt).
+// sequence those were 5 VALU instructions per MFMA in the fp64 linear layers (profiles/archive/r02_v7_rocprofv3_c5_summary.txt).
 __device__ __forceinline__ double aa_exp_f64(double x) {
   x = x > 709.0 ? 709.0 : (x < -745.0 ? -745.0 : x);
   const double k = rint(x * 1.44269504088896338700e+00);

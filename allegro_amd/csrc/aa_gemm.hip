@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
 // (each load sits behind a wave-uniform branch, which the compiler does not hoist loads across).  Also tried: the loads of
 // tile j + 1 issued before the arithmetic and stores of tile j (two operand sets in flight) -- 3 % on the accumulator-
 // resident kernel's z layers, but 57-150 spilled registers in the staged and the operand-resident kernel, whose K loops
-// then run 25-50 % slower (profiles/r03_n_stages_c5.log); not kept.
+// then run 25-50 % slower (profiles/archive/r03_n_stages_c5.log); not kept.
 __device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int64_t m_base, int li, int lg, const v4d& acc0, const v4d& acc1,
                                                   int64_t c_shift = 0) {
   if (t0 >= g.N) return;
@@ -1836,7 +1836,7 @@ int launch_gemm<double>(const GemmArgs& g, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_valu_kernel<double>, grid, dim3(256), smem, stream, g);
   } else if (pipe_ok && g.opt_f64_column_loop == 0 && g.opt_f64_rows != 2 && (g.K % 16) == 0 &&
              (g.opt_f64_rows == 1 ? (g.N <= 128 || g.K <= 128) : (g.N <= 128 || (g.K <= 128 && !epilogue_reads)))) {
-    // row-resident kernels: every operand row is read from HBM once.  Measured at C5 (1.7 M rows; profiles/r03_*_stages_c5.log,
+    // row-resident kernels: every operand row is read from HBM once.  Measured at C5 (1.7 M rows; profiles/archive/r03_*_stages_c5.log,
     // after the epilogue loads were batched and the operand activation deferred): the accumulator-resident form (N <= 128)
     // wins everywhere, 54-58 vs 45-52 TFLOP/s for K > 128 and 5-10 % on 128 x 128 layers with or without z / add operands;
     // the operand-resident form (N > 128, K <= 128) wins 5-8 % on plain layers and loses 25-30 % where the epilogue fetches

@@ -591,7 +591,7 @@ extern "C" int aa_model_plan_create_with_options(const aa_model_config* cfg_in, 
     // two-body table in LDS; same parity tests as the staged pipeline.  With the tensor-track scalars accumulated in
     // anchored program order (aa::anchor -- the kernel used to carry 70-350 spilled VGPRs) the 32-edge-tile form beats the
     // staged forward at every size on MI355X: 22-24 % of the step on 64-1000 atoms (one launch instead of seven), 9 % at
-    // 4096, 4.5 % at 10 648, 0.5 % at 97 336 atoms, and it moves 2.1 instead of 7.3 KB/edge (profiles/r02_v23_fused_sweep.log).
+    // 4096, 4.5 % at 10 648, 0.5 % at 97 336 atoms, and it moves 2.1 instead of 7.3 KB/edge (profiles/archive/r02_v23_fused_sweep.log).
     // aa_plan_options.fused_forward: 0 / 1 = whenever the graph allows (automatic), 3 = never (staged pipeline); A/B: 2 = also for every
     // graph with segments <= 128, in the pure team form, 4 = the same in the mixed form.
     const bool eligible = p->chain_gemm && p->env_mom && p->tp_op < 0 && (p->chain_pair == 0 || p->chain_pair == 1) && L == 2 &&
@@ -1801,7 +1801,7 @@ struct Runner {
     if (g->max_degree <= 32) return true;  // one full-ish tile per atom: faster than the staged forward at every size
     // Team form (2 / 4 tiles per atom): a tile costs the same whether 32 or 12 of its rows carry an edge, so it pays where
     // the step is latency-bound (few tiles: one launch instead of seven) or the tiles are nearly full.  Measured on Si boxes
-    // at r_max 6 / 7 (44 / 73 edges per atom, profiles/r03_p_*): 216-512 atoms 17-27 % faster than the staged step, 1 728
+    // at r_max 6 / 7 (44 / 73 edges per atom, profiles/archive/r03_p_*): 216-512 atoms 17-27 % faster than the staged step, 1 728
     // atoms -2 % / +8 %, 10 648 atoms +10 % / +18 % slower (69 % / 57 % of the tile rows in use).
     // (num_edges IS the edge count of the active block: the atom-block hint promises that every center with edges lies in
     // [atom_begin, atom_end) -- verified on the device by graph_hint_check_kernel -- so rowptr[atom_end] - rowptr[atom_begin],

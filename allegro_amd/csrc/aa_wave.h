@@ -212,7 +212,7 @@ __device__ __forceinline__ void wave_sum_store2(const T* va, const T* vb, T* dst
 
 
 // streamed-once operands of the per-atom edge loops (moments / operator kernels) carry the non-temporal hint: each row is read by exactly one wave and
-// written rows are not read again before they have left the caches (C4: 2-4 % per kernel, profiles/r02_v12_nt_stages_*;
+// written rows are not read again before they have left the caches (C4: 2-4 % per kernel, profiles/archive/r02_v12_nt_stages_*;
 // tools/ubench/hbm_stream.hip: +5-10 % for this one-row-per-instruction pattern; -DAA_NO_NT builds without)
 template <typename T>
 __device__ __forceinline__ T ld_stream(const T* p) {

@@ -1,7 +1,7 @@
 """Extract per-kernel HBM traffic from a tools/summarize_prof.py summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 passes) into the small JSON that bench.py attaches to its roofline as `traffic`.
 
-    python tools/pmc_to_json.py profiles/r01_v13_rocprofv3_c4_summary.txt c4 > profiles/pmc_traffic_c4.json
+    python tools/pmc_to_json.py profiles/archive/r01_v13_rocprofv3_c4_summary.txt c4 > profiles/pmc_traffic_c4.json
 
 Units and corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 prints both counters in KB; on gfx950 FETCH_SIZE
 reports exactly half of the bytes of a wide coalesced streaming read and is doubled; WRITE_SIZE is taken as is (the

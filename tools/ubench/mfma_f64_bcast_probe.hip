@@ -1,5 +1,5 @@
 // fp64 matrix cores on gfx950: v_mfma_f64_16x16x4_f64 sustains 46-47 TFLOP/s, the 4-block v_mfma_f64_4x4x4_4b_f64 70-76
-// (profiles/r02_v14_mfma_peak.log).  cbsz / abid are IGNORED by the 4-block f64 form (tools/ubench/mfma_f64_bcast_map.hip),
+// (profiles/archive/r02_v14_mfma_peak.log).  cbsz / abid are IGNORED by the 4-block f64 form (tools/ubench/mfma_f64_bcast_map.hip),
 // so a 16x16x4 product needs the A blocks ROTATED against the B blocks: four issues with A rotated by 0/4/8/12 lanes inside
 // each 16-lane row (DPP row_ror) give the sixteen 4x4 block products.  This probe checks the result against the 16x16x4
 // instruction (incl. the de-rotation of the accumulator registers) and measures the rate in the register pattern of
