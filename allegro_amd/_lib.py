@@ -162,6 +162,10 @@ class AllegroLib:
         L.aa_silu_derivative.restype = C.c_int
         L.aa_silu_derivative_pair.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_silu_derivative_pair.restype = C.c_int
+        L.aa_act_derivative.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_act_derivative.restype = C.c_int
+        L.aa_act_derivative_pair.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.aa_act_derivative_pair.restype = C.c_int
         L.aa_debug_gemm_f32.argtypes = [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.aa_debug_gemm_f32.restype = C.c_int
         L.aa_model_plan_create.argtypes = [C.POINTER(ModelConfig), C.POINTER(C.c_void_p)]

@@ -2669,9 +2669,9 @@ int run_model(const aa_model_plan* p, const void* dev_weights, const aa_graph* g
   if (r.w.total > ws_bytes) return fail(AA_ERR_WORKSPACE, "aa_model_energy_forces: workspace too small");
   if (p->opt.poison_workspace) AA_CHECK_HIP(hipMemsetAsync(workspace, 0xFF, r.w.total, stream));  // debugging: NaN everywhere
   r.want_forces = forces != nullptr;
-  if (p->ev_wait) AA_CHECK_HIP(hipStreamWaitEvent(stream, static_cast<hipEvent_t>(p->ev_wait), 0));
+  if (p->ev_wait) AA_CHECK_HIP(hipStreamWaitEvent(stream, (hipEvent_t)(uintptr_t)(p->ev_wait), 0));
   if (int rc = r.forward(g, pos, atom_energy)) return rc;
-  if (p->ev_record) AA_CHECK_HIP(hipEventRecord(static_cast<hipEvent_t>(p->ev_record), stream));
+  if (p->ev_record) AA_CHECK_HIP(hipEventRecord((hipEvent_t)(uintptr_t)(p->ev_record), stream));
   if (forces)
     if (int rc = r.backward(g, pos, forces)) return rc;
   // the atom-block hint is the caller's promise (per-atom kernels skip the rest): two row pointers verify it on the device, as the

@@ -397,10 +397,37 @@ __device__ __forceinline__ T silu_order(T x, int k) {
     default: return s1 * (m * (T(2) + x * m) + m - T(2) * x * s1);
   }
 }
+// The same family for the other two nonlinearities the reference offers (allegro_models.py:49-60), evaluated in double (these MLPs
+// are not on the fp32 fast paths; an elementwise pass is bandwidth-bound either way):
+//   mish: f = x t, t = tanh(softplus x); with s = sigmoid x, w = 1 - t^2, q = 1 - s - 2 t s:
+//         t1 = t' = w s, t2 = t'' = w s q, t3 = w s (q^2 + q'), q' = -s (1 - s) - 2 (w s^2 + t s (1 - s));  f^(k) = k t_(k-1) + x t_k
+//   gelu (erf form): f = x Phi; f' = Phi + x phi, f'' = phi (2 - x^2), f^(3) = x phi (x^2 - 4)
+template <typename T>
+__device__ __forceinline__ T act_order(int act, T x, int k) {
+  if (act == AA_ACT_SILU) return silu_order(x, k);
+  const double xd = double(x);
+  if (act == AA_ACT_MISH) {
+    const double sp = xd > 30.0 ? xd : log1p(exp(xd));
+    const double t = tanh(sp), s = 1.0 / (1.0 + exp(-xd)), w = 1.0 - t * t;
+    if (k == 0) return T(xd * t);
+    const double t1 = w * s;
+    if (k == 1) return T(t + xd * t1);
+    const double q = 1.0 - s - 2.0 * t * s, t2 = t1 * q;
+    if (k == 2) return T(2.0 * t1 + xd * t2);
+    const double q1 = -s * (1.0 - s) - 2.0 * (w * s * s + t * s * (1.0 - s));
+    const double t3 = t1 * (q * q + q1);
+    return T(3.0 * t2 + xd * t3);
+  }
+  const double phi = 0.39894228040143267794 * exp(-0.5 * xd * xd);
+  if (k == 0) return T(0.5 * xd * (1.0 + erf(xd * 0.70710678118654752440)));
+  if (k == 1) return T(0.5 * (1.0 + erf(xd * 0.70710678118654752440)) + xd * phi);
+  if (k == 2) return T(phi * (2.0 - xd * xd));
+  return T(xd * phi * (xd * xd - 4.0));
+}
 // h == nullptr: out0 = g f^(k)(x) (g == nullptr: f^(k)(x));  else: out0 = g h f^(k+1)(x), out1 = h f^(k)(x)
 template <typename T>
 __global__ __launch_bounds__(256) void silu_family_kernel(int64_t n, int k, const T* __restrict__ x, const T* __restrict__ g,
-                                                          const T* __restrict__ h, T* __restrict__ out0, T* __restrict__ out1) {
+                                                          const T* __restrict__ h, T* __restrict__ out0, T* __restrict__ out1, int act) {
   constexpr int V = 16 / sizeof(T);
   const int64_t i0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * V;
   if (i0 >= n) return;
@@ -424,10 +451,10 @@ __global__ __launch_bounds__(256) void silu_family_kernel(int64_t n, int k, cons
   for (int j = 0; j < V; ++j) {
     const T gj = g ? gv[j] : T(1);
     if (h) {
-      a[j] = gj * hv[j] * silu_order(xv[j], k + 1);
-      b[j] = hv[j] * silu_order(xv[j], k);
+      a[j] = gj * hv[j] * act_order(act, xv[j], k + 1);
+      b[j] = hv[j] * act_order(act, xv[j], k);
     } else {
-      a[j] = gj * silu_order(xv[j], k);
+      a[j] = gj * act_order(act, xv[j], k);
       b[j] = T(0);
     }
   }
@@ -672,8 +699,9 @@ extern "C" int aa_weighted_channels_pair(aa_dtype dtype, int64_t E, int u, int l
 }
 
 static int silu_launch(const char* what, aa_dtype dtype, int order, int64_t n, const void* x, const void* g, const void* h, void* out0, void* out1,
-                       aa_stream stream) {
+                       aa_stream stream, int act = aa::AA_ACT_SILU) {
   if (!(n >= 0 && order >= 0 && order + (h ? 1 : 0) <= 3)) return aa::fail(AA_ERR_INVALID, std::string(what) + ": bad argument (derivative orders 0..3)");
+  if (!(act == aa::AA_ACT_SILU || act == aa::AA_ACT_MISH || act == aa::AA_ACT_GELU)) return aa::fail(AA_ERR_INVALID, std::string(what) + ": activation 0 (silu), 1 (mish) or 2 (gelu)");
   if (n == 0) return AA_OK;
   if (!(x && out0 && (!h || (g && out1)))) return aa::fail(AA_ERR_INVALID, std::string(what) + ": null argument");
   for (const void* p : {x, g, h, static_cast<const void*>(out0), static_cast<const void*>(out1)})
@@ -683,10 +711,10 @@ static int silu_launch(const char* what, aa_dtype dtype, int order, int64_t n, c
   const dim3 grid((unsigned)((n + per_block - 1) / per_block));
   if (dtype == AA_F32)
     hipLaunchKernelGGL(aa::silu_family_kernel<float>, grid, dim3(256), 0, s, n, order, static_cast<const float*>(x), static_cast<const float*>(g),
-                       static_cast<const float*>(h), static_cast<float*>(out0), static_cast<float*>(out1));
+                       static_cast<const float*>(h), static_cast<float*>(out0), static_cast<float*>(out1), act);
   else
     hipLaunchKernelGGL(aa::silu_family_kernel<double>, grid, dim3(256), 0, s, n, order, static_cast<const double*>(x), static_cast<const double*>(g),
-                       static_cast<const double*>(h), static_cast<double*>(out0), static_cast<double*>(out1));
+                       static_cast<const double*>(h), static_cast<double*>(out0), static_cast<double*>(out1), act);
   AA_CHECK_HIP(hipGetLastError());
   return AA_OK;
 }
@@ -699,6 +727,16 @@ extern "C" int aa_silu_derivative_pair(aa_dtype dtype, int order, int64_t n, con
                                        aa_stream stream) {
   if (!h && n > 0) return aa::fail(AA_ERR_INVALID, "aa_silu_derivative_pair: null argument");
   return silu_launch("aa_silu_derivative_pair", dtype, order, n, x, g, h, out_x, out_g, stream);
+}
+
+extern "C" int aa_act_derivative(aa_dtype dtype, int act, int order, int64_t n, const void* x, const void* g, void* out, aa_stream stream) {
+  return silu_launch("aa_act_derivative", dtype, order, n, x, g, nullptr, out, nullptr, stream, act);
+}
+
+extern "C" int aa_act_derivative_pair(aa_dtype dtype, int act, int order, int64_t n, const void* x, const void* g, const void* h, void* out_x,
+                                      void* out_g, aa_stream stream) {
+  if (!h && n > 0) return aa::fail(AA_ERR_INVALID, "aa_act_derivative_pair: null argument");
+  return silu_launch("aa_act_derivative_pair", dtype, order, n, x, g, h, out_x, out_g, stream, act);
 }
 
 extern "C" int aa_scalar_column(aa_dtype dtype, int64_t rows, int D, const void* a, const void* s, void* out, aa_stream stream) {

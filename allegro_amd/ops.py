@@ -657,6 +657,77 @@ def _matmul(x: torch.Tensor, W: torch.Tensor, lib_id: int) -> torch.Tensor:
     return x @ W
 
 
+@torch.library.custom_op("allegro_amd::act_derivative", mutates_args=())
+def act_derivative_op(x: torch.Tensor, g: Optional[torch.Tensor], act: int, order: int, lib_id: int) -> torch.Tensor:
+    """`aa_act_derivative`: g * f^(order)(x), f = silu (act 0) / mish (1) / gelu (2), elementwise (g None: 1)."""
+    lib = _resolve(lib_id)
+    _check_device(lib, x, "allegro_amd::act_derivative")
+    xc = _dense16(x)
+    gc = None if g is None else _dense16(g)
+    out = torch.empty_like(xc)
+    n = xc.numel()
+    lib.check(lib.lib.aa_act_derivative(_dtype_code(x), act, order, n, xc.data_ptr() if n else None,
+                                        gc.data_ptr() if (n and gc is not None) else None, out.data_ptr() if n else None, _stream_ptr(x)),
+              "aa_act_derivative")
+    return out
+
+
+@act_derivative_op.register_fake
+def _(x, g, act, order, lib_id):
+    return torch.empty_like(x, memory_format=torch.contiguous_format)
+
+
+@torch.library.custom_op("allegro_amd::act_derivative_pair", mutates_args=())
+def act_derivative_pair_op(x: torch.Tensor, g: torch.Tensor, h: torch.Tensor, act: int, order: int, lib_id: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`aa_act_derivative_pair`: (g h f^(order+1)(x), h f^(order)(x)) from one pass."""
+    lib = _resolve(lib_id)
+    _check_device(lib, x, "allegro_amd::act_derivative_pair")
+    xc, gc, hc = _dense16(x), _dense16(g), _dense16(h)
+    ox, og = torch.empty_like(xc), torch.empty_like(xc)
+    n = xc.numel()
+    p = (lambda t: t.data_ptr() if n else None)
+    lib.check(lib.lib.aa_act_derivative_pair(_dtype_code(x), act, order, n, p(xc), p(gc), p(hc), p(ox), p(og), _stream_ptr(x)), "aa_act_derivative_pair")
+    return ox, og
+
+
+@act_derivative_pair_op.register_fake
+def _(x, g, h, act, order, lib_id):
+    return torch.empty_like(x, memory_format=torch.contiguous_format), torch.empty_like(x, memory_format=torch.contiguous_format)
+
+
+class _Act(torch.autograd.Function):
+    """`_Silu` for any of the reference's nonlinearities: A_k(x, g) = g f^(k)(x), f = silu / mish / gelu (`act` 0 / 1 / 2)."""
+
+    @staticmethod
+    def forward(ctx, x, g, k, act, lib_id):
+        ctx.k, ctx.act, ctx.lib_id, ctx.has_g = k, act, lib_id, g is not None
+        ctx.save_for_backward(x, g)
+        return torch.ops.allegro_amd.act_derivative(x.detach(), None if g is None else g.detach(), act, k, lib_id)
+
+    @staticmethod
+    def backward(ctx, h):
+        x, g = ctx.saved_tensors
+        k, act, lib_id = ctx.k, ctx.act, ctx.lib_id
+        need_x, need_g = ctx.needs_input_grad[0], ctx.has_g and ctx.needs_input_grad[1]
+        if k >= 3 and need_x:
+            raise NotImplementedError("allegro_amd: activation derivatives beyond the third are not implemented")
+        if need_x and need_g and not torch.is_grad_enabled():
+            gx, gg = torch.ops.allegro_amd.act_derivative_pair(x, g, h, act, k, lib_id)
+            return gx, gg, None, None, None
+        gx = _Act.apply(x, h if g is None else g * h, k + 1, act, lib_id) if need_x else None
+        gg = _Act.apply(x, h, k, act, lib_id) if need_g else None
+        return gx, gg, None, None, None
+
+
+ACT_CODES = {"silu": 0, "mish": 1, "gelu": 2}
+
+
+def activation(x: torch.Tensor, kind: str, lib_id: int) -> torch.Tensor:
+    """The hidden nonlinearity of a scalar MLP in training mode (silu / mish / gelu), differentiable to third order, on the
+    elementwise family kernel (`aa_act_derivative`)."""
+    return _Silu.apply(x, None, 0, lib_id) if kind == "silu" else _Act.apply(x, None, 0, ACT_CODES[kind], lib_id)
+
+
 class _Silu(torch.autograd.Function):
     """A_k(x, g) = g f^(k)(x) with f = SiLU (g None: f^(k)(x)).  d/dx = A_{k+1}(x, g .), d/dg = A_k(x, .): closed under
     differentiation, one launch per member; where no further derivative is recorded (the backward pass of the loss) both gradients

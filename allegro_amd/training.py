@@ -60,7 +60,7 @@ def _mlp(x: torch.Tensor, weights: List[torch.Tensor], act: Optional[str], act_c
         ws = w * (carry / math.sqrt(float(fan)))
         x = ops.linear(x, ws, lib_id) if lib_id is not None else x @ ws
         if i < last and act is not None:
-            x = ops.silu(x, lib_id) if (lib_id is not None and act == "silu") else _ACT[act](x)
+            x = ops.activation(x, act, lib_id) if (lib_id is not None and act in ops.ACT_CODES) else _ACT[act](x)
             carry = act_const
     return x
 

@@ -158,6 +158,11 @@ int aa_concat_columns(aa_dtype dtype, int64_t E, int n, const void* const* xs, c
 int aa_silu_derivative(aa_dtype dtype, int order, int64_t n, const void* x, const void* g, void* out, aa_stream stream);
 int aa_silu_derivative_pair(aa_dtype dtype, int order, int64_t n, const void* x, const void* g, const void* h, void* out_x, void* out_g,
                             aa_stream stream);
+/* The same family for every nonlinearity the reference's MLPs offer (allegro_models.py:49-60): act = 0 silu, 1 mish (x tanh softplus x),
+ * 2 gelu (erf form, torch's default); orders 0..3 as above. */
+int aa_act_derivative(aa_dtype dtype, int act, int order, int64_t n, const void* x, const void* g, void* out, aa_stream stream);
+int aa_act_derivative_pair(aa_dtype dtype, int act, int order, int64_t n, const void* x, const void* g, const void* h, void* out_x, void* out_g,
+                           aa_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * 2. Whole hot path: forward + forces  (seam B3 + ForceStressOutput)

@@ -101,18 +101,21 @@ def _second_order_case(lib, dev):
     assert torch.equal(w1, torch.ops.allegro_amd.weighted_channels(1, tt, sh, u_, l_, False, lid))
 
 
-def _silu_case(lib, dev):
-    """Every member of the SiLU family against autograd through `torch.nn.functional.silu`, to third order, incl. the pair form."""
+def _silu_case(lib, dev, kind="silu"):
+    """Every member of the activation family (SiLU; mish / gelu: `aa_act_derivative`) against autograd through torch's own function, to
+    third order, incl. the pair form."""
     lid = _lib_id(lib)
     g = torch.Generator().manual_seed(11)
-    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+    ref = {"silu": torch.nn.functional.silu, "mish": torch.nn.functional.mish, "gelu": torch.nn.functional.gelu}[kind]
+    hand_fn = (lambda t: ops.silu(t, lid)) if kind == "silu" else (lambda t: ops.activation(t, kind, lid))
+    for dtype, tol in ((torch.float64, 1e-12 if kind == "silu" else 1e-11), (torch.float32, 2e-5)):
         for n in (1, 7, 1030):
             x = (3.0 * torch.randn(n, generator=g, dtype=dtype)).to(dev).requires_grad_(True)
             a = torch.randn(n, generator=g, dtype=dtype).to(dev).requires_grad_(True)
             b = torch.randn(n, generator=g, dtype=dtype).to(dev)
             outs = []
             for hand in (True, False):
-                y = ops.silu(x, lid) if hand else torch.nn.functional.silu(x)
+                y = hand_fn(x) if hand else ref(x)
                 (d1,) = torch.autograd.grad((y * a).sum(), x, create_graph=True)  # a f1(x)
                 d2x, d2a = torch.autograd.grad((d1 * b).sum(), [x, a], create_graph=True)  # a b f2(x), b f1(x)
                 (d3,) = torch.autograd.grad(d2x.sum(), x)  # a b f3(x)
@@ -120,7 +123,7 @@ def _silu_case(lib, dev):
             for p, q in zip(*outs):
                 assert (p - q).abs().max().item() <= tol * max(1.0, float(q.abs().max())), (dtype, n)
             # the pair form (what the backward pass of the loss runs: no further derivative recorded)
-            y = ops.silu(x, lid)
+            y = hand_fn(x)
             (d1,) = torch.autograd.grad((y * a).sum(), x, create_graph=True)
             px, pa = torch.autograd.grad((d1 * b).sum(), [x, a])
             assert (px - outs[1][2]).abs().max().item() <= tol * max(1.0, float(outs[1][2].abs().max()))
@@ -230,6 +233,19 @@ def test_fork_and_cat_emulated():
 @pytest.mark.gpu
 def test_fork_and_cat_on_gpu():
     _fork_cat_case(None, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("kind", ["mish", "gelu"])
+def test_mish_gelu_family_emulated(kind):
+    from tests.hip_utils import emu_lib
+
+    _silu_case(emu_lib(), torch.device("cpu"), kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mish", "gelu"])
+def test_mish_gelu_family_on_gpu(kind):
+    _silu_case(None, torch.device("cuda:0"), kind)
 
 
 def test_silu_family_emulated():

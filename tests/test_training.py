@@ -82,7 +82,7 @@ def test_cached_segment_sums_change_no_bit_emulated(monkeypatch):
 
 
 @pytest.mark.parametrize("name,dtype", [("t_coupled", torch.float64), ("t_uncoupled", torch.float64), ("t_spline_peredge", torch.float64),
-                                        ("t_acts", torch.float64), ("t_shared", torch.float32)])  # (c5_small, l_max 3 / 3 layers: GPU list below; 2.5 min emulated)
+                                        ("t_acts", torch.float64), ("t_mish", torch.float64), ("t_shared", torch.float32)])  # (t_acts / t_mish: gelu / mish MLPs on the activation family kernel; c5_small, l_max 3 / 3 layers: GPU list below; 2.5 min emulated)
 def test_training_mode_gradients_match_oracle_autograd_emulated(name, dtype):
     from tests.hip_utils import emu_lib
 
@@ -92,7 +92,8 @@ def test_training_mode_gradients_match_oracle_autograd_emulated(name, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,dtype", [("t_coupled", torch.float64), ("t_peredge", torch.float32), ("c2", torch.float32), ("c2", torch.float64),
                                         ("c2_spline", torch.float32), ("c2_uncoupled", torch.float64), ("c2_l3", torch.float32),
-                                        ("c2_L3", torch.float32), ("c2_u128", torch.float32), ("c5_small", torch.float64), ("c1_L2", torch.float32)])
+                                        ("c2_L3", torch.float32), ("c2_u128", torch.float32), ("c5_small", torch.float64), ("c1_L2", torch.float32),
+                                        ("t_acts", torch.float64), ("t_mish", torch.float32)])
 def test_training_mode_gradients_match_oracle_autograd_on_gpu(name, dtype):
     _training_case(name, dtype, None, torch.device("cuda:0"))
 
