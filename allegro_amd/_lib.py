@@ -70,7 +70,7 @@ def options_from_env() -> PlanOptions:
     o.op_recompute_bvecs = flag("AA_OP_RECOMPUTE_BVECS")  # A/B: tp_op_bvecs_kernel in the layer-0 reverse
     o.readout_two_pass = flag("AA_READOUT_TWO_PASS")  # A/B: readout_backward_kernel instead of the fused energy + slope pass
     o.tp_prefer_moments = flag("AA_TP_PREFER_MOM")  # A/B: the round-4 selection (moments kernels) where the operator kernels are now preferred
-    o.fused_narrow = {"1": 1, "2": 2, "3": 3, "5": 5, "6": 6}.get(env.get("AA_FUSED_NARROW", "")[:1], 0)  # A/B: 1 = the one-wave-per-SIMD fused forward, 2 = the eight-wave lock-step form, 3 = the four-wave form on small boxes too, 5 = ... with the env projections on the matrix cores
+    o.fused_narrow = {"1": 1, "2": 2, "3": 3, "5": 5, "6": 6, "7": 7}.get(env.get("AA_FUSED_NARROW", "")[:1], 0)  # A/B: 1 = the one-wave-per-SIMD fused forward, 2 = the eight-wave lock-step form, 3 = the four-wave form on small boxes too, 5 = ... with the env projections on the matrix cores
     o.poison_workspace = flag("AA_POISON")  # debugging: NaN-filled workspace before every step
     o.f64_rows = {"0": 2, "2": 1}.get(env.get("AA_F64_ROWS", "")[:1], 0)  # 0: off, 2: wherever applicable
     return o

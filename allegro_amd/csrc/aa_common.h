@@ -72,6 +72,8 @@ __device__ __forceinline__ void anchor(V& v) {
 }
 // a wave-uniform value the optimizer cannot see through from here on (stays in a scalar register; emits no instruction)
 __device__ __forceinline__ void opaque_scalar(int& v) { asm volatile("" : "+s"(v)); }
+// the same for a per-lane value: what is derived from it afterwards is recomputed where it is used, not hoisted out of a loop
+__device__ __forceinline__ void opaque_vector(unsigned& v) { asm volatile("" : "+v"(v)); }
 #endif
 // DPP lane pattern applied to v (fused by the compiler into the consuming VALU op)
 constexpr int kDppRowRor8 = 0x128, kDppRowRor4 = 0x124, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
@@ -677,6 +679,7 @@ constexpr bool kFoldEmb1 = false;
 constexpr bool kFoldEmb1 = true;
 #endif  // FusedFwdArgs::keep when aa_plan_options.fused_keep_split is 0
 constexpr int kFusedMaxDegree = 128;  // longest edge segment the fused forward takes: a team of four 32-edge tiles
+constexpr int kFusedTailAtomsPerCu = 64;   // from this many atoms per CU on the fused forward runs as eight-wave workgroups with the readout-reverse chain in its tail
 constexpr int kFusedTeamTilesSmall = 4096;  // up to this many tiles the team form is chosen regardless of how full the tiles are
 struct FusedFwdArgs {
   int64_t N, atom0, atom_end;  // atoms [atom0, atom_end) are evaluated: one wave each (every one has <= 32 edges), or -- with
@@ -716,6 +719,11 @@ struct FusedFwdArgs {
   int32_t* status;     // nullable, host-visible: set to the offending degree when a segment exceeds what the max_degree hint promised
   int mixed;           // with the class lists set: one-tile pass over all atoms (long ones skipped) + team pass over the long ones only
   int skip_long, long_only, fill_done;  // (set by launch_fused_fwd for the two passes of the mixed form)
+  // two-waves-per-SIMD form with the readout-reverse chain in its tail (`tail` != 0; aa_fused8.hip): d EDGE_FEATURES[:, :128] and the
+  // gradient of the layer-1 tensor-track scalars leave the forward kernel, the pre-activations of latent 1 / the readout do not
+  float* g_fcat;
+  float* g_scal1;
+  int ld_gfcat, tail;
   int wide_one_per_cu; // two-waves-per-SIMD form, four-wave workgroups: ONE per CU (half the registers and LDS of a CU stay free for kernels of other streams)
   int wide_proj_mfma;  // two-waves-per-SIMD form: env projections as bf16x3 layers on the matrix cores (its program then has 2 R steps per projection)
   int wide_waves;      // two-waves-per-SIMD form (aa_fused8.hip): 4 = four-wave workgroups except on small boxes; -4 / -8: four / eight waves, forced
@@ -754,8 +762,9 @@ int launch_fused_bwd_tail(int pair, const FusedTailArgs& a, hipStream_t stream);
 int fused_fwd_num_steps(int R, bool hold_w0);
 // `wide` (nullable): the same arguments with the weight program of the eight-wave form (aa_fused8.hip) -- it then takes the one-tile
 // pass (all atoms, or all but the long ones of the mixed form); the team pass keeps `a`
-int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream, const FusedFwdArgs* wide = nullptr);
-int fused_fwd8_num_steps(int R, bool proj_mfma);
+int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream, const FusedFwdArgs* wide = nullptr, bool* ran_wide = nullptr);
+int fused_fwd8_num_steps(int R, bool proj_mfma, bool tail = false);
+int fused_num_cus();  // CUs of the current device (the small-box rule of launch_fused_fwd)
 size_t fused_fwd8_lds_bytes(int num_types, int waves);  // per workgroup of 8 waves (one per CU) or 4 waves (two per CU)
 int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t stream);
 

@@ -626,16 +626,21 @@ static int launch_fused_fwd_one(int pair, bool hold_w0, const FusedFwdArgs& a, h
 // handful of Si atoms past 32 neighbours; profiles/r05_v23_md_loop_c4.json).  The team form costs every atom ~12 % (class lists,
 // exchange area, 2 fewer tile parkings), the staged pipeline ~12 % of the step: instead the one-tile kernel runs over all atoms at
 // full speed and SKIPS the long ones, and a second, small launch of the team form takes exactly those (its grid is the list).
-int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream, const FusedFwdArgs* wide) {
-  const bool teams = a.tile_atoms != nullptr;
-  // (boxes that leave a CU at most one workgroup run one wave per SIMD whatever the kernel: there the register-rich one-tile form --
-  //  w0 held, operands kept split -- is the faster one: 64 atoms 44 vs 48 us, profiles/r06_v4_ab_c2_*)
+int fused_num_cus() {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n; else cus = 256;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
   }
-  if (wide && wide->wide_waves > 0 && a.atom_end - a.atom0 <= int64_t(4) * cus) wide = nullptr;
+  return cus;
+}
+
+int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t stream, const FusedFwdArgs* wide, bool* ran_wide) {
+  if (ran_wide) *ran_wide = false;
+  const bool teams = a.tile_atoms != nullptr;
+  // (boxes that leave a CU at most one workgroup run one wave per SIMD whatever the kernel: there the register-rich one-tile form --
+  //  w0 held, operands kept split -- is the faster one: 64 atoms 44 vs 48 us, profiles/r06_v4_ab_c2_*)
+  if (wide && wide->wide_waves > 0 && a.atom_end - a.atom0 <= int64_t(4) * fused_num_cus()) wide = nullptr;
   if (wide && (!teams || a.mixed)) {
     // the one-tile pass on the eight-wave form (two waves per SIMD); the team pass over the long atoms, if any, as below
     if (a.atom_end <= a.atom0) return AA_OK;
@@ -649,6 +654,7 @@ int launch_fused_fwd(int pair, bool hold_w0, const FusedFwdArgs& a, hipStream_t 
     one.tile_cap = 0;
     one.skip_long = teams ? 1 : 0;
     if (int rc = launch_fused_fwd8(pair, wide->wide_waves == -8 ? 8 : 4, one, stream)) return rc;
+    if (ran_wide) *ran_wide = true;
     if (!teams) return AA_OK;
     FusedFwdArgs team = a;
     team.long_only = 1;

@@ -110,7 +110,9 @@ __device__ __forceinline__ void fused_step8(const Args& A, Pipe& p, const XSplit
 
 // a 32-feature tile (accumulator layout) of rows [0, 32) of the row-major rows at `base` (row stride ld); rows beyond the segment: zeros
 __device__ __forceinline__ v16f tile_load_rows8(const float* base, unsigned ld, int lane, bool row_ok) {
-  const unsigned el = lane & 31, hh = lane >> 5;
+  unsigned el = lane & 31;
+  const unsigned hh = lane >> 5;
+  opaque_vector(el);  // (see tile_store_rows8)
   v16f t;
   const unsigned off = el * ld + 4u * hh;
 #pragma unroll
@@ -136,7 +138,11 @@ __device__ __forceinline__ void tile_store_rows8(float* sT, const v16f& acc, flo
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const v4f*>(sT + (8 * q + pr) * kTileLdT + pc);
   __builtin_amdgcn_wave_barrier();
-  const unsigned off = unsigned(pr) * ld + unsigned(pc);
+  // (the row offsets are RE-derived from an opaque copy of the lane's row at every call: as loop invariants -- two or three per row
+  //  stride -- they are hoisted out of the persistent loop, spilled in its prologue and reloaded from scratch at every store)
+  unsigned pro = unsigned(pr);
+  opaque_vector(pro);
+  const unsigned off = pro * ld + unsigned(pc);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     if (pr + 8 * q < cnt) *reinterpret_cast<v4f*>(base + (off + 8u * q * ld)) = v[q];
@@ -181,13 +187,17 @@ struct TileIn8 {
 
 }  // namespace
 
-constexpr int fused_fwd8_steps(int R, bool pm) { return (pm ? 2 * R : 4) + (2 + 2 * R) + 4 + (pm ? 2 * R : 4) + 2 + 8 + 2; }
+constexpr int fused_fwd8_steps(int R, bool pm, bool tail = false) { return (pm ? 2 * R : 4) + (2 + 2 * R) + 4 + (pm ? 2 * R : 4) + 2 + 8 + 2 + (tail ? 12 : 0); }
 
 // WAVES = 8: one workgroup per CU, eight tiles in lock step (both two-body tiles parked in LDS: 16.6 KB per wave).
 // WAVES = 4: TWO independent workgroups per CU (78 KB of LDS each: one two-body tile parked, the other in 16 registers), each with
 //            its own weight pipeline -- the two waves of a SIMD drift apart, so one workgroup's MFMA steps run beside the other's
 //            vector / LDS phases instead of both hitting the same pipe at the same time.
-template <class Sig0, class Sig1, int WAVES, bool PM>
+// TAIL: the readout-reverse chain of the reverse pass (Runner::backward "B3": d ro_h = factor scale w silu'(ro_h); d h1 = (d ro_h W_a)
+//       silu'(h1); d EDGE_FEATURES[:, :128] = [d ro_h | d h1] W_b; d scal1 = d h1 W_c -- 12 more steps on the same weight fragments the
+//       chain kernel uses) runs here, where its operands are in registers: the total energy is a plain sum, so the gradient seeds of
+//       every edge-local layer are known at the end of the edge's own forward.
+template <class Sig0, class Sig1, int WAVES, bool PM, bool TAIL = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs A) {
   static_assert(WAVES == 8 || WAVES == 4, "workgroup forms");
   constexpr int NT = 64 * WAVES;                   // threads
@@ -198,8 +208,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
   static_assert(D <= 9, "l_max <= 2");
   static_assert(kFoldEmbed && kFoldEmb1 && kFoldLatent, "the wide form exists for the folded program only");
   constexpr int kPS = PM ? 2 * R : 4;  // pipeline steps of one env projection
-  constexpr int S_P0 = 0, S_L2 = kPS, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L6A = S_P1 + kPS, S_M = S_L6A + 2, S_L8K = S_M + 8, NS = S_L8K + 2;
-  static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps && NS == fused_fwd8_steps(R, PM), "program length");
+  constexpr int S_P0 = 0, S_L2 = kPS, S_L3 = S_L2 + 2 + 2 * R, S_P1 = S_L3 + 4, S_L6A = S_P1 + kPS, S_M = S_L6A + 2, S_L8K = S_M + 8, S_T = S_L8K + 2,
+                NS = S_T + (TAIL ? 12 : 0);
+  static_assert(NS % 2 == 0 && NS <= kFusedMaxSteps && NS == fused_fwd8_steps(R, PM, TAIL), "program length");
   u32x4* wbuf = reinterpret_cast<u32x4*>(aa_smem);
   float* sRo = reinterpret_cast<float*>(wbuf + 2 * kWStep);  // [64] last readout weights
   float* sRm = sRo + 64;                                     // [16] 1 / r_max per type pair, [8] Bessel roots at 16
@@ -517,6 +528,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
     // ---- latent 1 hidden layer (acc6) and readout hidden layer (acc8): scal1 chunks into acc6; then the chunks both layers
     //      share -- lat0 (registers), two-body scalars (parked) -- each fetched and split ONCE for both; lat1 chunks into acc8
     v16f a60, a61, a80, a81;
+    v16f dk0, dk1;  // (TAIL) silu'(latent-1 pre-activation)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       a60[r] = 0.f;
@@ -542,8 +554,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
       fused_step8<S_M + 7, NS>(A, p, xs[1], a80, a81, [&] {});
       AA_TICK8(8)
       // latent 1: pre-activation stored, a_1 = silu(h) feeds the readout (its output layer is folded: kFoldLatent)
-      tile_store_rows8(sW, a60, (A.lat_h1) + row0 * 64, cnt, 64, lane);
-      tile_store_rows8(sW, a61, (A.lat_h1 + 32) + row0 * 64, cnt, 64, lane);
+      if constexpr (TAIL) {  // (the reverse of this layer runs below: its pre-activation is needed there, not in HBM)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          dk0[r] = dsilu(a60[r]);
+          dk1[r] = dsilu(a61[r]);
+        }
+      } else {
+        tile_store_rows8(sW, a60, (A.lat_h1) + row0 * 64, cnt, 64, lane);
+        tile_store_rows8(sW, a61, (A.lat_h1 + 32) + row0 * 64, cnt, 64, lane);
+      }
       keep_tile<true>(a60, k0);
       keep_tile<true>(a61, k1);
       xsplit_from_acc(k0, xs[0]);
@@ -553,8 +573,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
     AA_TICK8(9)
     // ---- readout: hidden pre-activation stored; last linear layer + edge sum
     {
-      tile_store_rows8(sW, a80, (A.ro_h) + row0 * 64, cnt, 64, lane);
-      tile_store_rows8(sW, a81, (A.ro_h + 32) + row0 * 64, cnt, 64, lane);
+      if constexpr (!TAIL) {
+        tile_store_rows8(sW, a80, (A.ro_h) + row0 * 64, cnt, 64, lane);
+        tile_store_rows8(sW, a81, (A.ro_h + 32) + row0 * 64, cnt, 64, lane);
+      }
       float part = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -574,6 +596,57 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
         if (cnt < 0) en = __builtin_nanf("");  // (segment beyond the max_degree hint)
         A.atom_energy[atom] = en;
       }
+    }
+    if constexpr (TAIL) {
+      // ---- readout-reverse chain (see TAIL): d ro_h in place of ro_h
+      float rofac = A.ro_factor;
+      if (A.scales && atom_ok) rofac *= A.scales[A.types[atom]];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4f w0v = *reinterpret_cast<const v4f*>(sRo + 8 * q + 4 * hh);
+        const v4f w1v = *reinterpret_cast<const v4f*>(sRo + 32 + 8 * q + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a80[4 * q + i] = rofac * w0v[i] * dsilu(a80[4 * q + i]);
+          a81[4 * q + i] = rofac * w1v[i] * dsilu(a81[4 * q + i]);
+        }
+      }
+      XSplit xd[2], xh[2];
+      xsplit_from_acc(a80, xd[0]);
+      xsplit_from_acc(a81, xd[1]);
+      v16f t0, t1;
+      auto zero = [&] {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          t0[r] = 0.f;
+          t1[r] = 0.f;
+        }
+      };
+      zero();  // d h1 = (d ro_h @ W_a) * silu'(h1)
+      fused_step8<S_T + 0, NS>(A, p, xd[0], t0, t1, [&] {});
+      fused_step8<S_T + 1, NS>(A, p, xd[1], t0, t1, [&] {});
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        t0[r] *= dk0[r];
+        t1[r] *= dk1[r];
+      }
+      xsplit_from_acc(t0, xh[0]);
+      xsplit_from_acc(t1, xh[1]);
+      static_for<0, 2>([&](auto pp) {  // d EDGE_FEATURES[:, 64 pp .. 64 pp + 63] = [d ro_h | d h1] @ W_b
+        constexpr int pr = decltype(pp)::value;
+        zero();
+        fused_step8<S_T + 2 + 4 * pr + 0, NS>(A, p, xd[0], t0, t1, [&] {});
+        fused_step8<S_T + 2 + 4 * pr + 1, NS>(A, p, xd[1], t0, t1, [&] {});
+        fused_step8<S_T + 2 + 4 * pr + 2, NS>(A, p, xh[0], t0, t1, [&] {});
+        fused_step8<S_T + 2 + 4 * pr + 3, NS>(A, p, xh[1], t0, t1, [&] {});
+        tile_store_rows8(sW, t0, (A.g_fcat + 64 * pr) + row0 * A.ld_gfcat, cnt, unsigned(A.ld_gfcat), lane);
+        tile_store_rows8(sW, t1, (A.g_fcat + 64 * pr + 32) + row0 * A.ld_gfcat, cnt, unsigned(A.ld_gfcat), lane);
+      });
+      zero();  // d scal1 = d h1 @ W_c
+      fused_step8<S_T + 10, NS>(A, p, xh[0], t0, t1, [&] {});
+      fused_step8<S_T + 11, NS>(A, p, xh[1], t0, t1, [&] {});
+      tile_store_rows8(sW, t0, (A.g_scal1) + row0 * 64, cnt, 64, lane);
+      tile_store_rows8(sW, t1, (A.g_scal1 + 32) + row0 * 64, cnt, 64, lane);
     }
     AA_TICK8(10)
     cur.beg = nxt.beg;
@@ -598,7 +671,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
 size_t fused_fwd8_lds_bytes(int num_types, int waves) {
   return sizeof(u32x4) * 2 * kWStep + sizeof(float) * (64 + 32 + size_t(num_types) * num_types * 512 + size_t(waves) * fused_wave_floats(waves));
 }
-int fused_fwd8_num_steps(int R, bool proj_mfma) { return fused_fwd8_steps(R, proj_mfma); }
+int fused_fwd8_num_steps(int R, bool proj_mfma, bool tail) { return fused_fwd8_steps(R, proj_mfma, tail); }
 
 int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t stream) {
   if (a.atom_end <= a.atom0) return AA_OK;
@@ -615,6 +688,15 @@ int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t st
   }
   const int64_t ngroups = (a.atom_end - a.atom0 + waves - 1) / waves;
   dim3 grid((unsigned)std::min<int64_t>(ngroups, int64_t(num_cu) * ((waves == 4 && !a.wide_one_per_cu) ? 2 : 1)));
+  // (the tail exists for the eight-wave form: with four-wave workgroups -- 24 instead of 16 staging registers, one two-body tile in
+  //  registers -- it spills 186 registers and the kernel takes 5.1-5.3 instead of 4.3 ms at C4, profiles/r06_v19_*)
+  if (a.tail && (waves != 8 || a.wide_proj_mfma || !a.g_fcat || !a.g_scal1)) return fail(AA_ERR_INVALID, "fused forward (wide): the reverse tail exists for the eight-wave form with vector projections");
+#define AA_FUSED8_LAUNCHT(S0_, S1_)                                                                                       \
+  {                                                                                                                        \
+    const void* fn = (const void*)fused_fwd8_kernel<cg::S0_, cg::S1_, 8, false, true>;                                     \
+    AA_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(smem)));                          \
+    hipLaunchKernelGGL((fused_fwd8_kernel<cg::S0_, cg::S1_, 8, false, true>), grid, dim3(512), smem, stream, a);           \
+  }
 #define AA_FUSED8_LAUNCH1(S0_, S1_, W_, P_)                                                                     \
   {                                                                                                           \
     const void* fn = (const void*)fused_fwd8_kernel<cg::S0_, cg::S1_, W_, P_>;                                \
@@ -622,7 +704,7 @@ int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t st
     hipLaunchKernelGGL((fused_fwd8_kernel<cg::S0_, cg::S1_, W_, P_>), grid, dim3(64 * W_), smem, stream, a);  \
   }
 #define AA_FUSED8_LAUNCH(S0_, S1_) \
-  if (waves == 8 && a.wide_proj_mfma) AA_FUSED8_LAUNCH1(S0_, S1_, 8, true) else if (waves == 8) AA_FUSED8_LAUNCH1(S0_, S1_, 8, false) \
+  if (a.tail) AA_FUSED8_LAUNCHT(S0_, S1_) else if (waves == 8 && a.wide_proj_mfma) AA_FUSED8_LAUNCH1(S0_, S1_, 8, true) else if (waves == 8) AA_FUSED8_LAUNCH1(S0_, S1_, 8, false) \
   else if (a.wide_proj_mfma) AA_FUSED8_LAUNCH1(S0_, S1_, 4, true) else AA_FUSED8_LAUNCH1(S0_, S1_, 4, false)
   if (pair == 0) {
     AA_FUSED8_LAUNCH(Sig1, Sig0)
@@ -632,6 +714,7 @@ int launch_fused_fwd8(int pair, int waves, const FusedFwdArgs& a, hipStream_t st
     return fail(AA_ERR_INVALID, "fused forward (wide): unsupported signature pair");
   }
 #undef AA_FUSED8_LAUNCH1
+#undef AA_FUSED8_LAUNCHT
 #undef AA_FUSED8_LAUNCH
   AA_CHECK_HIP(hipGetLastError());
 #ifdef AA_FUSED_TIMING

@@ -1377,6 +1377,7 @@ struct Runner {
   StageProfile* prof = nullptr;
   bool want_forces = false;    // (set by run_model before forward())
   bool ro_grad_done = false;   // forward(): readout_reduce also wrote d E / d (last readout hidden layer) -- no readout_backward launch
+  bool fwd_b3_done = false;    // forward_fused(): the readout-reverse chain ran in the tail of the fused forward (FusedFwdArgs::tail)
 
   // per_edge / per_atom: operand elements the launch must move (each distinct operand row once); see DESIGN.md §5
   int mark(const char* name, double per_edge = 0, double per_atom = 0, double flops = 0) {
@@ -2058,15 +2059,40 @@ struct Runner {
       }
       add_step(wf(p->o_ro0_fq), 6, 4);
       add_step(wf(p->o_ro0_fq), 6, 5);
-      if (ns != fused_fwd8_num_steps(p->R, a8.wide_proj_mfma != 0)) return fail(AA_ERR_INVALID, "fused forward (wide): program length mismatch");
+      // the readout-reverse chain (Runner::backward "B3", folded form) in the forward's tail: eight-wave form, vector projections, no
+      // team pass (its atoms would miss it), forces requested.  Taken from kFusedTailAtomsPerCu atoms per CU on (there the eight-wave
+      // form is as fast as two four-wave workgroups and the chain's 0.75 ms of streaming disappear: C4 -0.45 ms same box,
+      // profiles/r06_v19_*); fused_narrow 2 forces it, 3 / 7 keep it off.
+      const bool tail_ok = want_forces && a.tile_atoms == nullptr && !a8.wide_proj_mfma && !a8.wide_one_per_cu && p->chain_gemm && kFoldLatent &&
+                           p->o_b3af_q && p->o_b3c_q && c.num_layers == 2 && p->opt.fused_narrow != 7 && p->opt.fused_narrow != 3;
+      if (tail_ok && (a8.wide_waves == -8 || (a8.wide_waves == 4 && a.atom_end - a.atom0 >= int64_t(kFusedTailAtomsPerCu) * fused_num_cus()))) {
+        a8.wide_waves = -8;
+        a8.tail = 1;
+      }
+      if (a8.tail) {
+        add_layer(wf(p->o_b3af_q), 2, 0, 2);
+        add_layer(wf(p->o_b3bf_q ? p->o_b3bf_q : p->o_b3b_q), 4, 0, 4);
+        add_layer(wf(p->o_b3c_q), 2, 0, 2);
+        a8.g_fcat = bf(w.g_fcat);
+        a8.ld_gfcat = p->SL1;
+        a8.g_scal1 = bf(w.g_scal[1]);
+      }
+      if (ns != fused_fwd8_num_steps(p->R, a8.wide_proj_mfma != 0, a8.tail != 0)) return fail(AA_ERR_INVALID, "fused forward (wide): program length mismatch");
     }
     if (int rc = mark("begin")) return rc;
-    if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream, wide ? &a8 : nullptr)) return rc;
+    bool ran_wide = false;
+    if (int rc = launch_fused_fwd(p->chain_pair, hold, a, stream, wide ? &a8 : nullptr, &ran_wide)) return rc;
+    fwd_b3_done = ran_wide && a8.tail;
+    if (wide && a8.tail && !ran_wide) return fail(AA_ERR_INVALID, "fused forward: the tail was planned for a launch that took the one-wave kernel");
     // algorithmic traffic: neighbor id + shift in; unit vector, harmonics, five 64-wide rows and w0 out per edge;
     // position, two x2s blocks, energy, row pointer per atom.  Flops: the linear layers of the forward (w0 counted once).
     const double per_edge = 1 + (g->shift_vec ? 3 : 0) + 3 + 4 + p->D + 5 * 64 + p->W;
     const double per_atom = 3 + 2.0 * p->D * u + 1 + 1;
-    const double fl = 2.0 * double(E) * (2.0 * 64 * 64 + 64.0 * p->ng0 + double(S + u) * 64 + 64.0 * S + double(2 * S + u) * 64 + 64.0 * S + 3.0 * S * 64);
+    double fl = 2.0 * double(E) * (2.0 * 64 * 64 + 64.0 * p->ng0 + double(S + u) * 64 + 64.0 * S + double(2 * S + u) * 64 + 64.0 * S + 3.0 * S * 64);
+    if (fwd_b3_done) {  // (+ the readout-reverse chain: 192 gradient columns out instead of two 64-wide pre-activation rows)
+      fl += 2.0 * double(E) * (64.0 * 64 + 128.0 * 128 + 64.0 * 64);
+      return mark("fused_fwd", per_edge + 64, per_atom, fl);
+    }
     return mark("fused_fwd", per_edge, per_atom, fl);
   }
 
@@ -2359,7 +2385,9 @@ struct Runner {
     if (!(g->t_rowptr && g->t_perm)) AA_CHECK_HIP(hipMemsetAsync(forces, 0, size_t(N) * 3 * sizeof(T), stream));
     if (int rc = mark("memset", gsh_stores ? 0 : p->D * num_gsh, 3)) return rc;
     const SegList none{0, {}};
-    if (p->chain_gemm) {
+    if (p->chain_gemm && fwd_b3_done) {
+      // (the fused forward of this step ran this chain in its tail: d EDGE_FEATURES[:, :S L] and d scal_{L-1} are in the workspace)
+    } else if (p->chain_gemm) {
       // readout reverse + last latent reverse in ONE kernel; d_lat_{L-1} and d_h never leave registers
       ReadoutArgs r = readout_args(g, nullptr);
       ChainArgs ca{};

@@ -167,6 +167,7 @@ inline void permlane16_swap4(float* a, float* b) {
 template <class V>
 inline void anchor(V&) {}  // (a scheduling anchor on the device: no semantics)
 inline void opaque_scalar(int&) {}
+inline void opaque_vector(unsigned&) {}
 }  // namespace aa
 inline int __builtin_amdgcn_update_dpp(int, int v, int ctrl, int, int, bool) {
   const int l = emu::lane();
