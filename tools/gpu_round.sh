@@ -16,7 +16,7 @@
 #   shards  <tag> [W]      every rank's compact shard of a W-way partition of C4, one after the other (load balance)
 #   final   <tag>          tests + bench (c4, c5, c3, c2, c1) + stages + shards + profile c4 / c5: the end-of-round evidence
 cd "$(dirname "$0")/.."
-CMD=${1:-tests}; TAG=${2:-r05}; ARG=${3:-}
+CMD=${1:-tests}; TAG=${2:-r06}; ARG=${3:-}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 case $CMD in
@@ -102,8 +102,8 @@ case $CMD in
     # the driver's N > 1 launch line on this one-GPU box: N ranks share cuda:0, rows staged through the host (gloo) -- exercises bench.py's
     # sharded branch end to end (rendezvous, slab shards, both exchanges, barrier + max-over-ranks clock); its ms/step is N shards on ONE GPU
     for N in 2 8; do
-      AA_BENCH_BACKEND=gloo AA_BENCH_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
-        --master-port 2951$N bench.py --gpus $N --steps 5 --warmup 2 --sustain 0 2> /dev/null | grep '^{' | head -1 > gpurun_out/${TAG}_bench_launch_line_x$N.json
+      # (round 6: bench.py launches itself under torch.distributed.run when WORLD_SIZE is unset -- the driver's own command shape)
+      AA_BENCH_BACKEND=gloo AA_BENCH_DEVICE=0 timeout 600 python bench.py --gpus $N --steps 5 --warmup 2 --sustain 0 2> /dev/null | grep '^{' | head -1 > gpurun_out/${TAG}_bench_launch_line_x$N.json
       echo "launch line N=$N $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/${TAG}_bench_launch_line_x$N.json | head -1)"
     done ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
