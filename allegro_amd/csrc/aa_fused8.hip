@@ -114,11 +114,11 @@ __device__ __forceinline__ v16f tile_load_rows8(const float* base, unsigned ld, 
   const unsigned hh = lane >> 5;
   opaque_vector(el);  // (see tile_store_rows8)
   v16f t;
-  const unsigned off = el * ld + 4u * hh;
+  const unsigned off = (el * ld + 4u * hh) * 4u;  // (bytes: see at_bytes)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     v4f v = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok) v = *reinterpret_cast<const v4f*>(base + (off + 8u * q));
+    if (row_ok) v = *reinterpret_cast<const v4f*>(at_bytes(base, off + 32u * q));
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[4 * q + i] = v[i];
   }
@@ -142,10 +142,10 @@ __device__ __forceinline__ void tile_store_rows8(float* sT, const v16f& acc, flo
   //  stride -- they are hoisted out of the persistent loop, spilled in its prologue and reloaded from scratch at every store)
   unsigned pro = unsigned(pr);
   opaque_vector(pro);
-  const unsigned off = pro * ld + unsigned(pc);
+  const unsigned off = (pro * ld + unsigned(pc)) * 4u;  // (bytes)
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    if (pr + 8 * q < cnt) *reinterpret_cast<v4f*>(base + (off + 8u * q * ld)) = v[q];
+    if (pr + 8 * q < cnt) *reinterpret_cast<v4f*>(at_bytes(base, off + 32u * q * ld)) = v[q];
 }
 
 // tile_scal_accumulate (aa_mfma.h) with ONE cell buffer: s[e][ch] += w[e][r][ch] * sum_{a in irrep RR} Y[e][a] * B[a][ch].  The
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
 #pragma unroll
       for (int m = 0; m < D; ++m) Y[m] = row_ok ? Yf[m] : 0.f;
       if (row_ok && hh == 0) {
-        *reinterpret_cast<v4f*>((A.vec + 4 * row0) + 4u * unsigned(el)) = v4f{nx, ny, nz, rr};
+        *reinterpret_cast<v4f*>(at_bytes(A.vec + 4 * row0, 16u * unsigned(el))) = v4f{nx, ny, nz, rr};
         if (A.sh) {
           float* shb = A.sh + row0 * D;
 #pragma unroll
-          for (int m = 0; m < D; ++m) shb[unsigned(el) * D + m] = Yf[m];
+          for (int m = 0; m < D; ++m) *at_bytes(shb, 4u * (unsigned(el) * D + m)) = Yf[m];
         }
       }
       __builtin_amdgcn_wave_barrier();  // (the previous tile's readers of sY are done: program order + wave-private region)
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
         project_moments<S_P0, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s0);
       if (atom_ok) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) (A.x2s0 + (atom * D + j) * 64)[unsigned(lane)] = x2s0[j];
+        for (int j = 0; j < D; ++j) *at_bytes(A.x2s0 + (atom * D + j) * 64, 4u * unsigned(lane)) = x2s0[j];
       }
       float e0[D], B0[D];
 #pragma unroll
@@ -488,11 +488,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fused_fwd8_kernel(FusedFwdArgs 
         project_moments<S_P1, NS, D, R, kLdY8>(A, p, sW, M, A.sf, x2s1);
       if (atom_ok) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) (A.x2s1 + (atom * D + j) * 64)[unsigned(lane)] = x2s1[j];
+        for (int j = 0; j < D; ++j) *at_bytes(A.x2s1 + (atom * D + j) * 64, 4u * unsigned(lane)) = x2s1[j];
       }
       float one[1] = {1.f}, v[D], B1[D], x2s0b[D];
 #pragma unroll
-      for (int j = 0; j < D; ++j) x2s0b[j] = atom_ok ? (A.x2s0 + (atom * D + j) * 64)[unsigned(lane)] : 0.f;  // (this wave's own store of layer 0)
+      for (int j = 0; j < D; ++j) x2s0b[j] = atom_ok ? *at_bytes(A.x2s0 + (atom * D + j) * 64, 4u * unsigned(lane)) : 0.f;  // (this wave's own store of layer 0)
       Sig1::template bx1<float>(one, x2s1, wp1, v);
       Sig0::template bx1<float>(v, x2s0b, wp0, B1);
 #pragma unroll

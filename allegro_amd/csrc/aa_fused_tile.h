@@ -28,6 +28,13 @@ static_assert(kOffB + 16 * 64 <= kWaveRegion, "per-atom vectors must fit behind 
 // of step S + 1, i.e. every load has two full steps to arrive (the kernel runs one wave per SIMD: nothing else hides
 // L2 latency).  Barriers are raw s_barrier with LDS-only fences, so that they do not drain the loads in flight
 // (__syncthreads() carries a vmcnt(0)).  All indices are compile-time: the whole program is unrolled.
+// element of `base` at a 32-bit byte offset (see pipe_load)
+template <class T>
+__device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
+  using B = std::conditional_t<std::is_const_v<T>, const char, char>;
+  return reinterpret_cast<T*>(reinterpret_cast<B*>(base) + byte_off);  // (a byte GEP with a zero-extended 32-bit index: the saddr + voffset pattern)
+}
+
 struct FusedPipe {
   u32x4 ra[3], rb[3];
   u32x4* wbuf;  // [2][kWStep]
@@ -51,9 +58,13 @@ __device__ __forceinline__ void pipe_load(const Args& A, int tid, int t, u32x4* 
   const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t + zero][1]);
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const u32x4* mid = wv < 2 ? s0 + 256 : s1 - 128;  // elements 256..383 of the first half | 0..127 of the second
-  r[0] = s0[tid];
-  r[1] = mid[tid];
-  r[2] = (s1 + 128)[tid];
+  // (a 32-bit BYTE offset: base + zero-extended offset is ONE saddr + voffset load; an element index -- signed or not -- is scaled in
+  //  64 bits and costs a v_lshl_add_u64 per load)
+  unsigned ob = unsigned(tid) * 16u;
+  opaque_vector(ob);  // (keeps the zero-extension next to the load: hoisted out of the loop as a 64-bit pair it defeats the saddr pattern)
+  r[0] = *at_bytes(s0, ob);
+  r[1] = *at_bytes(mid, ob);
+  r[2] = *at_bytes(s1 + 128, ob);
 }
 __device__ __forceinline__ void pipe_store(u32x4* wbuf, int b, int tid, const u32x4* r) {
   u32x4* d = wbuf + b * kWStep;
@@ -97,8 +108,10 @@ __device__ __forceinline__ void pipe_load8(const Args& A, const FusedPipe8& p, i
   const u32x4* s0 = static_cast<const u32x4*>(A.wstep[t + p.zero][0]);
   const u32x4* s1 = static_cast<const u32x4*>(A.wstep[t + p.zero][1]);
   const u32x4* b0 = p.wv < 6 ? s0 : s1 - 384;
-  r[0] = b0[p.tid];
-  if (p.wv < 4) r[1] = (s1 + 128)[p.tid];
+  unsigned ob = unsigned(p.tid) * 16u;
+  opaque_vector(ob);  // (keeps the zero-extension next to the load: hoisted out of the loop as a 64-bit pair it defeats the saddr pattern)
+  r[0] = *at_bytes(b0, ob);
+  if (p.wv < 4) r[1] = *at_bytes(s1 + 128, ob);
 }
 __device__ __forceinline__ void pipe_store8(const FusedPipe8& p, int b, const u32x4* r) {
   u32x4* d = p.wbuf + b * kWStep;
