@@ -41,7 +41,7 @@ class PlanOptions(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "tp_generic", "tp_no_chain", "tp_no_moments", "tp_no_operator", "tp_force_operator", "tp_operator_fused",
         "gemm_no_chain", "gemm_fp32_mfma", "gemm_valu", "gemm_v1", "gemm_lds_epilogue", "f64_column_loop",
-        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "f64_rows", "no_channel_padding", "fused_tail", "fused_keep_split", "poison_workspace", "no_slot_form", "op_proj_gemm", "op_env_vector", "staged_no_fold", "op_recompute_bvecs", "readout_two_pass", "tp_prefer_moments", "fused_narrow")]
+        "embed_no_fuse", "fused_forward", "fused_recompute_w0", "moments_waves_per_block", "f64_rows", "no_channel_padding", "fused_tail", "fused_keep_split", "poison_workspace", "no_slot_form", "op_proj_gemm", "op_env_vector", "staged_no_fold", "op_recompute_bvecs", "readout_two_pass", "tp_prefer_moments", "fused_narrow", "chain_staged_weights")]
 
 
 def options_from_env() -> PlanOptions:
@@ -71,6 +71,7 @@ def options_from_env() -> PlanOptions:
     o.readout_two_pass = flag("AA_READOUT_TWO_PASS")  # A/B: readout_backward_kernel instead of the fused energy + slope pass
     o.tp_prefer_moments = flag("AA_TP_PREFER_MOM")  # A/B: the round-4 selection (moments kernels) where the operator kernels are now preferred
     o.fused_narrow = {"1": 1, "2": 2, "3": 3, "5": 5, "6": 6, "7": 7}.get(env.get("AA_FUSED_NARROW", "")[:1], 0)  # A/B: 1 = the one-wave-per-SIMD fused forward, 2 = the eight-wave lock-step form, 3 = the four-wave form on small boxes too, 5 = ... with the env projections on the matrix cores
+    o.chain_staged_weights = flag("AA_CHAIN_STAGED")  # A/B: the general chain kernel for the one-layer reverse chains
     o.poison_workspace = flag("AA_POISON")  # debugging: NaN-filled workspace before every step
     o.f64_rows = {"0": 2, "2": 1}.get(env.get("AA_F64_ROWS", "")[:1], 0)  # 0: off, 2: wherever applicable
     return o

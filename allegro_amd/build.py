@@ -10,7 +10,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_tp_dense.hip", "aa_train.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused8.hip", "aa_model.hip", "aa_nl.hip", "aa_hostfile.hip"]
+SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_tp_dense.hip", "aa_train.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused8.hip", "aa_chain_res.hip", "aa_model.hip", "aa_nl.hip", "aa_hostfile.hip"]
 # public C ABI header: the package carries a copy (package data, so that an installed package can rebuild itself); in the source
 # tree that copy is GENERATED from <repo>/include/allegro_amd.h at build time and not tracked (tests/test_lib_symbols.py checks identity)
 INCLUDE_DIR = os.path.join(HERE, "include")

@@ -298,6 +298,20 @@ struct ChainArgs {
   int num_types;
 };
 int launch_gemm_chain(const ChainArgs& c, hipStream_t stream);  // fp32 only
+// The one-layer latent-0 reverse chain with LDS-resident weights (aa_chain_res.hip): out = ((a + add) silu'(z)) @ W, K = 64, N = 128;
+// columns 0..63 are ACCUMULATED into c0, columns 64..127 stored to c1.  Row strides in floats (multiples of 4).
+struct ChainB2Args {
+  int64_t M;
+  const float* a;
+  const float* add;
+  const float* z;
+  int lda, ldadd, ldz;
+  const void* Wq;  // bf16x3 fragments of the [64, 128] matrix (gemm_pack_bf16x3)
+  float* c0;
+  float* c1;
+  int ldc0, ldc1;
+};
+int launch_chain_b2_resident(const ChainB2Args& g, hipStream_t stream);
 // element count of the fragment-ordered copy of a [K,N] matrix, and the host-side packer
 size_t gemm_packed_elems(int K, int N);
 void gemm_pack_b(const double* B, int K, int N, double* out);

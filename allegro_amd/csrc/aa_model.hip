@@ -2483,8 +2483,29 @@ struct Runner {
           ca.L[0].ld_a2add = 64;
           ca.L[0].a2_z = buf(w.lat_h[l][0]);
           ca.L[0].ld_a2z = 64;
+          if (sizeof(T) == 4 && S == 64 && u == 64 && !p->opt.chain_staged_weights) {
+            // the same layer with its 48 KB of weights resident in LDS (aa_chain_res.hip): one persistent workgroup per CU, no
+            // per-workgroup staging, no barriers in the row loop
+            ChainB2Args b2{};
+            b2.M = E;
+            b2.a = reinterpret_cast<const float*>(buf(w.g_fcat)) + S * (l + 1);
+            b2.lda = SL1;
+            b2.add = reinterpret_cast<const float*>(buf(w.g_aenv));
+            b2.ldadd = 64;
+            b2.z = reinterpret_cast<const float*>(buf(w.lat_h[l][0]));
+            b2.ldz = 64;
+            b2.Wq = wt(p->latent[l].wtq[0]);
+            b2.c0 = reinterpret_cast<float*>(buf(w.g_fcat));
+            b2.ldc0 = SL1;
+            b2.c1 = reinterpret_cast<float*>(buf(w.g_scal[l]));
+            b2.ldc1 = u;
+            if (int rc = launch_chain_b2_resident(b2, stream)) return rc;
+            if (int rc = mark("gc_64x128", gemm_row_elems(ca.L[0].g, true) + 2.0 * 64, 0, 2.0 * double(E) * 64 * 128)) return rc;
+            goto b2_done;
+          }
         }
         if (int rc = run_chain(ca, "B2")) return rc;
+      b2_done:;
       } else {
       SegList go;
       go.count = (l < L - 1 && !p->env_mom) ? 2 : 1;

@@ -313,6 +313,8 @@ typedef struct {
                              * (lock step), 1 = the one-wave-per-SIMD kernel of rounds 2-5 (A/B, tests).  Boxes of at most 4 atoms per CU take the
                              * round 2-5 kernel under 0 (every CU holds at most one workgroup anyway); 3 = the four-wave form there too (tests); 5 = 3 with the env
                              * projections as bf16x3 layers on the matrix cores (A/B: measured slower) */
+  int32_t chain_staged_weights; /* one-layer reverse chains: 1 = the per-workgroup weight staging of the general chain kernel also where the
+                                 * persistent form with LDS-resident weights applies (round 6; A/B, tests)                               */
 } aa_plan_options;
 
 int aa_model_plan_create(const aa_model_config* cfg, aa_model_plan** out);

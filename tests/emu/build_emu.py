@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "allegro_amd", "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "liballegro_amd_emu.so")
-SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_tp_dense.hip", "aa_train.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused8.hip", "aa_model.hip", "aa_nl.hip", "aa_hostfile.hip"]
+SOURCES = ["aa_gemm.hip", "aa_tp.hip", "aa_tp_spec.hip", "aa_tp_op.hip", "aa_tp_dense.hip", "aa_train.hip", "aa_edge.hip", "aa_fused.hip", "aa_fused8.hip", "aa_chain_res.hip", "aa_model.hip", "aa_nl.hip", "aa_hostfile.hip"]
 
 
 EXPERIMENTAL = os.environ.get("AA_BUILD_EXPERIMENTAL", "0")[:1] == "1"  # (see allegro_amd/build.py)

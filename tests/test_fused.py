@@ -521,3 +521,34 @@ def test_staged_pipeline_in_folded_and_unfolded_form_vs_fp64_oracle_emulated(nof
     m = _vs_oracle64(_cfg(), pos, cell, ei, shift, types, emu_lib(), torch.device("cpu"))
     _assert_launched(m, pos, cell, ei, shift, types, present=["gc_64x64_64x64_64x256" if nofold else "gc_64x64_64x256",
                                                                 "gc_128x64_64x64" if nofold else "gc_128x64"], absent=["fused_fwd"])
+
+
+def _resident_chain_case(lib, dev, monkeypatch, exact):
+    """The latent-0 reverse chain with LDS-resident weights (aa_chain_res.hip) is the general chain kernel's layer evaluated by a
+    persistent workgroup per CU: same arithmetic in the same order -- energies and forces bit-equal to AA_CHAIN_STAGED=1."""
+    fx = load_model_fixture("c2", torch.float32)
+    out = {}
+    for staged in ("0", "1"):
+        monkeypatch.setenv("AA_CHAIN_STAGED", staged)
+        m = model_from_fixture(fx, torch.float32, lib, device=dev)
+        data, sv = fixture_data(fx, torch.float32, dev)
+        g = m.prepare_graph(data["edge_index"], data["atom_types"], data["pos"].shape[0], sv)
+        e, f = m.energy_forces(data["pos"], g)
+        out[staged] = (e.cpu().clone(), f.cpu().clone())
+        assert (out[staged][1] - fx["out"]["forces"]).abs().max().item() <= 5e-5 * max(1.0, float(fx["out"]["forces"].abs().max()))
+    assert torch.equal(out["0"][0], out["1"][0])
+    if exact:
+        assert torch.equal(out["0"][1], out["1"][1])
+    else:  # (on the device the two kernels' operand transforms are contracted into FMAs differently by the compiler: last-bit differences)
+        assert (out["0"][1] - out["1"][1]).abs().max().item() <= 2e-6 * max(1.0, float(out["1"][1].abs().max()))
+
+
+def test_resident_weight_chain_is_bit_equal_to_the_staged_chain_emulated(monkeypatch):
+    _opt_in(monkeypatch)
+    _resident_chain_case(emu_lib(), torch.device("cpu"), monkeypatch, exact=True)
+
+
+@pytest.mark.gpu
+def test_resident_weight_chain_matches_the_staged_chain_on_gpu(monkeypatch):
+    _opt_in(monkeypatch)
+    _resident_chain_case(None, torch.device("cuda"), monkeypatch, exact=False)
