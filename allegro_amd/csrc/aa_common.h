@@ -1,6 +1,7 @@
 // Shared declarations of the gfx950 Allegro hot-path library (internal; the public C ABI is
 // include/allegro_amd.h).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -75,6 +76,13 @@ __device__ __forceinline__ void opaque_scalar(int& v) { asm volatile("" : "+s"(v
 // the same for a per-lane value: what is derived from it afterwards is recomputed where it is used, not hoisted out of a loop
 __device__ __forceinline__ void opaque_vector(unsigned& v) { asm volatile("" : "+v"(v)); }
 #endif
+// element of a WAVE-UNIFORM `base` at a 32-bit byte offset: a byte GEP with a zero-extended index is the saddr + voffset addressing
+// mode (one instruction); a per-lane 64-bit pointer costs a v_lshl_add_u64 per access
+template <class T>
+__device__ __forceinline__ T* lane_at(T* base, unsigned byte_off) {
+  using B = std::conditional_t<std::is_const_v<T>, const char, char>;
+  return reinterpret_cast<T*>(reinterpret_cast<B*>(base) + byte_off);
+}
 // DPP lane pattern applied to v (fused by the compiler into the consuming VALU op)
 constexpr int kDppRowRor8 = 0x128, kDppRowRor4 = 0x124, kDppHalfMirror = 0x141, kDppQuad1032 = 0xB1, kDppQuad2301 = 0x4E;
 template <int CTRL>

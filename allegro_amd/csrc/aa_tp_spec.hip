@@ -1251,8 +1251,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? AA_MOM_F
   constexpr int D = Sig0::D2, D1 = Sig0::D1, DOUT = Sig0::DOUT, R = Sig0::LMAX + 1;
   typedef typename Pk<T>::type T2;
   AA_MOM_PROLOGUE(D)
-  const T* gs0 = static_cast<const T*>(a.gscal0) + lane;
-  const T* gs1 = static_cast<const T*>(a.gscal1) + lane;
+  // (uniform row pointers + one 32-bit lane offset: every stream access of the pair loop is a saddr + voffset instruction)
+  const T* gs0 = static_cast<const T*>(a.gscal0);
+  const T* gs1 = static_cast<const T*>(a.gscal1);
+  const T* w0u = static_cast<const T*>(a.w0);
+  const unsigned lane_b0 = unsigned(lane) * unsigned(sizeof(T));
   T x2s0[D], x2s1[D], g2acc[D];
   {
     const int64_t base = atom * D * 64 + lane;
@@ -1292,17 +1295,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? AA_MOM_F
   }
   auto fetch = [&](int s, int ce, PairIn<T, R>& in) {
     const int sa = s < ce ? s : ce - 1, sb = s + 1 < ce ? s + 1 : ce - 1;
-    const T* wa = w0g + int64_t(sa) * a.ld_w0;
-    const T* wb = w0g + int64_t(sb) * a.ld_w0;
+    unsigned lane_b = lane_b0;
+    opaque_vector(lane_b);  // (keeps the zero-extension of the lane offset next to its loads: hoisted as a 64-bit pair it defeats the saddr pattern)
+    const T* wa = w0u + int64_t(sa) * a.ld_w0;
+    const T* wb = w0u + int64_t(sb) * a.ld_w0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) in.wa[r] = T2{ld_stream(wa + r * 64), ld_stream(wb + r * 64)};
+    for (int r = 0; r < R; ++r) in.wa[r] = T2{ld_stream(lane_at(wa + r * 64, lane_b)), ld_stream(lane_at(wb + r * 64, lane_b))};
     const bool vb2 = s + 1 < ce;
-    const T g0a = ld_stream(gs0 + int64_t(sa) * a.ld_gscal), g0b = ld_stream(gs0 + int64_t(sb) * a.ld_gscal);
-    const T g1a = ld_stream(gs1 + int64_t(sa) * a.ld_gscal), g1b = ld_stream(gs1 + int64_t(sb) * a.ld_gscal);
+    const T g0a = ld_stream(lane_at(gs0 + int64_t(sa) * a.ld_gscal, lane_b)), g0b = ld_stream(lane_at(gs0 + int64_t(sb) * a.ld_gscal, lane_b));
+    const T g1a = ld_stream(lane_at(gs1 + int64_t(sa) * a.ld_gscal, lane_b)), g1b = ld_stream(lane_at(gs1 + int64_t(sb) * a.ld_gscal, lane_b));
     in.g0 = T2{g0a, vb2 ? g0b : T(0)};
     in.g1 = T2{g1a, vb2 ? g1b : T(0)};
   };
-  T* gw0 = static_cast<T*>(a.g_w0) + lane;
+  T* gw0 = static_cast<T*>(a.g_w0);
   T* gsx = static_cast<T*>(a.gsh_x1);
 #ifndef AA_MOM_FIRST_AHEAD
 #define AA_MOM_FIRST_AHEAD 1  // pairs of HBM operands in flight ahead of the contraction (A/B: profiles/r05_v10_ab_*)
@@ -1325,11 +1330,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 && Sig0::LMAX <= 2) ? AA_MOM_F
       gya[i] = t[0];
       gyb[i] = t[1];
     }
+    unsigned lane_b = lane_b0;
+    opaque_vector(lane_b);
 #pragma unroll
-    for (int r = 0; r < R; ++r) st_stream(gw0 + int64_t(s) * a.ld_gw0 + r * 64, gw[r][0]);
+    for (int r = 0; r < R; ++r) st_stream(lane_at(gw0 + int64_t(s) * a.ld_gw0 + r * 64, lane_b), gw[r][0]);
     if (vb) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) st_stream(gw0 + int64_t(s + 1) * a.ld_gw0 + r * 64, gw[r][1]);
+      for (int r = 0; r < R; ++r) st_stream(lane_at(gw0 + int64_t(s + 1) * a.ld_gw0 + r * 64, lane_b), gw[r][1]);
     }
     wave_sum_store2<T, D1>(gya, gyb, gsx + int64_t(s) * a.ld_gsh, gsx + int64_t(s + (vb ? 1 : 0)) * a.ld_gsh, true, vb);
   });

@@ -36,17 +36,29 @@ __device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, boo
   T r;
   if constexpr (sizeof(T) == 4) {
     float y[8], z[4], q[2];
+    {
+      // lower half: {x_lo[k], x_hi[k]}, upper half: {x_lo[k+8], x_hi[k+8]}; swaps in blocks of four (one pair of hazard nops per block)
+      float a[8], b[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float a = x[k], b = x[k + 8];
-      permlane32_swap(a, b);  // lower half: {x_lo[k], x_hi[k]}, upper half: {x_lo[k+8], x_hi[k+8]}
-      y[k] = a + b;
+      for (int k = 0; k < 8; ++k) {
+        a[k] = x[k];
+        b[k] = x[k + 8];
+      }
+      permlane32_swap4(a, b);
+      permlane32_swap4(a + 4, b + 4);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) y[k] = a[k] + b[k];
     }
+    {
+      float a[4], b[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = y[k], b = y[k + 4];
-      permlane16_swap(a, b);
-      z[k] = a + b;
+      for (int k = 0; k < 4; ++k) {
+        a[k] = y[k];
+        b[k] = y[k + 4];
+      }
+      permlane16_swap4(a, b);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] = a[k] + b[k];
     }
     {
       const bool hi = lane & 8;
@@ -106,6 +118,26 @@ __device__ __forceinline__ void wave_sum_store(const T* v, T* dst, bool act, boo
   }
 }
 
+// N independent v_permlane32/16_swap of (a[i], b[i]) in blocks of four (permlane*_swap4: one pair of hazard nops per block)
+template <int W, int N>
+__device__ __forceinline__ void permlane_swap_n(float* a, float* b) {
+  constexpr int N4 = N & ~3;
+#pragma unroll
+  for (int i = 0; i < N4; i += 4) {
+    if constexpr (W == 32)
+      permlane32_swap4(a + i, b + i);
+    else
+      permlane16_swap4(a + i, b + i);
+  }
+#pragma unroll
+  for (int i = N4; i < N; ++i) {
+    if constexpr (W == 32)
+      permlane32_swap(a[i], b[i]);
+    else
+      permlane16_swap(a[i], b[i]);
+  }
+}
+
 // One level of a reduce-scatter over the lane bit BIT: of the N values a lane holds it keeps ceil(N / 2) (the lower ones if its
 // bit is clear, the upper ones -- padded with a zero when N is odd -- if it is set) and adds its partner's partial sums of the
 // same values.  N == 1: a plain sum over the bit.  Bits 5 / 4: v_permlane32/16_swap (the swap leaves each half holding exactly
@@ -126,15 +158,15 @@ __device__ __forceinline__ void scatter_level(const float* in, float* out, int l
       out[0] = in[0] + dpp_move<kDppQuad1032>(in[0]);
     }
   } else if constexpr (BIT >= 4) {
+    float sa[H], sb[H];
 #pragma unroll
     for (int i = 0; i < H; ++i) {
-      float a = in[i], b = i + H < N ? in[i + H] : 0.f;
-      if constexpr (BIT == 5)
-        permlane32_swap(a, b);
-      else
-        permlane16_swap(a, b);
-      out[i] = a + b;
+      sa[i] = in[i];
+      sb[i] = i + H < N ? in[i + H] : 0.f;
     }
+    permlane_swap_n<(BIT == 5 ? 32 : 16), H>(sa, sb);  // (blocks of four swaps: see wave_sum_store2)
+#pragma unroll
+    for (int i = 0; i < H; ++i) out[i] = sa[i] + sb[i];
   } else {
     const bool hi = lane & (1 << BIT);
 #pragma unroll
@@ -167,11 +199,18 @@ __device__ __forceinline__ void wave_sum_store2(const T* va, const T* vb, T* dst
     const int lane = threadIdx.x & 63;
     constexpr int N4 = D, N3 = (N4 + 1) / 2, N2 = (N3 + 1) / 2, N1 = (N2 + 1) / 2, N0 = (N1 + 1) / 2;
     float x4[N4], x3[N3], x2[N2], x1[N1], x0[N0], r[1];
+    {
+      // lower half: both halves' partial sums of edge a, upper half: of edge b.  The swaps go in blocks of four (one pair of hazard
+      // nops per block instead of per swap: 6 instead of 18 s_nop issue slots per edge pair at D = 9)
+      float sa[D], sb[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      float a = va[i], b = vb[i];
-      permlane32_swap(a, b);  // lower half: both halves' partial sums of edge a, upper half: of edge b
-      x4[i] = a + b;
+      for (int i = 0; i < D; ++i) {
+        sa[i] = va[i];
+        sb[i] = vb[i];
+      }
+      permlane_swap_n<32, D>(sa, sb);
+#pragma unroll
+      for (int i = 0; i < D; ++i) x4[i] = sa[i] + sb[i];
     }
     scatter_level<4, N4>(x4, x3, lane);
     scatter_level<3, N3>(x3, x2, lane);
