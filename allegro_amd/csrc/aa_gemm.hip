@@ -459,10 +459,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
   }
   const int sr = tid >> 4, sc = (tid & 15) * SPT;
   v2d rb[SPT / 2];
+  // Branch-free fetches: a weight column beyond N is read from a clamped (valid) address instead of being predicated -- the output
+  // columns it feeds are never stored (f64_tile_epilogue resolves only columns < N; N is a multiple of 16 here, so a thread's SPT
+  // columns are inside or outside together).  The predicated form, and a per-chunk search for the operand segment (see a_load below),
+  // compiled to four exec-masked branches around the staging loads and a dozen scalar branches per chunk.
   auto stage_load = [&](int c, int n0) {
-    const double* src = B + int64_t(16 * c + sr) * g.N + n0 + sc;
+    int col = n0 + sc;
+    col = col + SPT <= g.N ? col : g.N - SPT;
+    const double* src = B + int64_t(16 * c + sr) * g.N + col;
 #pragma unroll
-    for (int q = 0; q < SPT / 2; ++q) rb[q] = n0 + sc + 2 * q + 1 < g.N ? *reinterpret_cast<const v2d*>(src + 2 * q) : v2d{0.0, 0.0};
+    for (int q = 0; q < SPT / 2; ++q) rb[q] = *reinterpret_cast<const v2d*>(src + 2 * q);
   };
   auto stage_write = [&](int b) {
     double* d = smem + b * 16 * LDB + sr * LDB + sc;
@@ -470,21 +476,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
     for (int q = 0; q < SPT / 2; ++q) *reinterpret_cast<v2d*>(d + 2 * q) = rb[q];
   };
   // operand chunk c of the lane's two rows: A[row][16 c + 4 lg .. + 3]
-  auto a_load = [&](int c, v2d (*a)[2]) {
-    int kk = 16 * c;
-    const double* base = nullptr;
-    int ld = 0;
-#pragma unroll
-    for (int s2 = 0; s2 < 3; ++s2) {
-      if (s2 < g.a.count && base == nullptr) {
-        if (kk < g.a.s[s2].n) {
-          base = static_cast<const double*>(g.a.s[s2].p) + kk + a_sh;
-          ld = g.a.s[s2].ld;
-        } else {
-          kk -= g.a.s[s2].n;
-        }
+  // The chunks are fetched in order, so the operand segment of the NEXT chunk is a running state (pointer, row stride, chunks left
+  // in the segment) advanced once per fetch; a segment boundary is one rarely-taken uniform branch.
+  const double* nx_p = static_cast<const double*>(g.a.s[0].p) + a_sh;
+  int nx_ld = g.a.s[0].ld, nx_left = g.a.s[0].n >> 4, nx_seg = 0;
+  auto a_next_segment = [&]() {  // (also steps over empty segments)
+    while (nx_left <= 0 && nx_seg + 1 < g.a.count) {
+      ++nx_seg;
+      if (nx_seg == 1) {  // (compile-time member indices: a run-time index into the argument struct would move it to scratch memory)
+        nx_p = static_cast<const double*>(g.a.s[1].p) + a_sh;
+        nx_ld = g.a.s[1].ld;
+        nx_left = g.a.s[1].n >> 4;
+      } else {
+        nx_p = static_cast<const double*>(g.a.s[2].p) + a_sh;
+        nx_ld = g.a.s[2].ld;
+        nx_left = g.a.s[2].n >> 4;
       }
     }
+  };
+  a_next_segment();
+  auto a_load = [&](int c, v2d (*a)[2]) {
+    (void)c;
+    const double* base = nx_p;
+    const int ld = nx_ld;
+    nx_p += 16;
+    --nx_left;
+    a_next_segment();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const double* ap = base + arow[i] * ld + 4 * lg;
