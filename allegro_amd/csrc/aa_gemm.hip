@@ -257,6 +257,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_f64_kernel(GemmArgs g) {
 // tile j + 1 issued before the arithmetic and stores of tile j (two operand sets in flight) -- 3 % on the accumulator-
 // resident kernel's z layers, but 57-150 spilled registers in the staged and the operand-resident kernel, whose K loops
 // then run 25-50 % slower (profiles/archive/r03_n_stages_c5.log); not kept.
+// NT: non-temporal result stores -- the operand-resident kernel's wide layers (128 -> 640 at C5: 8.8 GB of results nobody re-reads from
+// a cache) gain 4 % (profiles/r06_v43_ab_c5_f64_epilogue_nt_stores.txt); the N <= 128 layers do not (+1 %) and keep plain stores.
+template <bool NT = false>
 __device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int64_t m_base, int li, int lg, const v4d& acc0, const v4d& acc1,
                                                   int64_t c_shift = 0) {
   if (t0 >= g.N) return;
@@ -311,7 +314,12 @@ __device__ __forceinline__ void f64_tile_epilogue(const GemmArgs& g, int t0, int
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e)
-    if (gm[e] < g.M) cp[gm[e] * ldc + col] = v[e];
+    if (gm[e] < g.M) {
+      if constexpr (NT)
+        __builtin_nontemporal_store(v[e], &cp[gm[e] * ldc + col]);
+      else
+        cp[gm[e] * ldc + col] = v[e];
+    }
 }
 
 // 128 x 64 block tile, 16-deep steps; the next step's global loads are in flight while this step's 32 MFMAs per
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_rows_kernel(GemmArgs g) {
   };
   auto epilogue = [&](int n0, v4d (*acc)[JT]) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j) f64_tile_epilogue(g, n0 + j * 16, m_base, li, lg, acc[0][j], acc[1][j], c_sh);
+    for (int j = 0; j < JT; ++j) f64_tile_epilogue<ASTAT>(g, n0 + j * 16, m_base, li, lg, acc[0][j], acc[1][j], c_sh);
   };
   v4d acc[2][JT];
   auto zero_acc = [&]() {
