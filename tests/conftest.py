@@ -37,6 +37,21 @@ def forward_mode(request, monkeypatch):
     return request.param
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`: ~280 tests, most of them kernels under the CPU emulation and multi-process gloo jobs) takes
+    ~9 minutes on 6 workers and ~40 serially: when it is invoked without `-n`, run it on pytest-xdist workers.  Never for `-m gpu`
+    (one device: the GPU tests run one at a time), never inside a worker, never when `-n` / `-p no:xdist` / AA_TEST_SERIAL=1 say otherwise."""
+    opt = config.option
+    if getattr(opt, "markexpr", "") != "not gpu" or os.environ.get("AA_TEST_SERIAL") == "1" or hasattr(config, "workerinput"):
+        return None
+    if not config.pluginmanager.hasplugin("xdist") or getattr(opt, "numprocesses", None) is not None or getattr(opt, "collectonly", False):
+        return None
+    opt.numprocesses = min(6, max(1, (os.cpu_count() or 1) - 2))
+    opt.dist = "load"
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference mounted (build container only)")
